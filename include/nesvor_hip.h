@@ -1,0 +1,105 @@
+/*
+ * nesvor_hip.h — C ABI of libnesvor_hip.so, the MI355X (gfx950) native backend
+ * for the NeSVoR INR-training hot path.
+ *
+ * Plain C: raw device pointers, sizes and an opaque hipStream_t (void*).  No
+ * torch types.  Every entry point enqueues work on `stream` and returns the
+ * hipError_t of the launch (0 == hipSuccess); nothing synchronises.
+ * All tensors are dense, contiguous, fp32 unless stated otherwise.
+ *
+ * Each group cites the reference interface it replaces (paths relative to the
+ * reference tree, daviddmc/NeSVoR v0.1.0).
+ */
+#ifndef NESVOR_HIP_H
+#define NESVOR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NESVOR_MAX_LEVELS 32
+#define NESVOR_MAX_MLP_LAYERS 4
+
+/* ABI version; bumped on any signature change. */
+int nesvor_hip_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Rigid-transform conversion.  Replaces the pybind module
+ * `nesvor.transform_convert_cuda`
+ * (nesvor/transform/transform_convert_cuda.cpp:64-69; kernels
+ * transform_convert_cuda_kernel.cu:14-440).
+ *   ax  : (n,6)   [rotation vector | translation]
+ *   mat : (n,3,4) [R | t]
+ * ---------------------------------------------------------------------- */
+int nesvor_axisangle2mat_forward(const float* ax, float* mat, int n, void* stream);
+int nesvor_axisangle2mat_backward(const float* grad_mat, const float* ax, float* grad_ax, int n, void* stream);
+int nesvor_mat2axisangle_forward(const float* mat, float* ax, int n, void* stream);
+int nesvor_mat2axisangle_backward(const float* mat, const float* grad_ax, float* grad_mat, int n, void* stream);
+/* double-precision variants (the reference dispatches float and double) */
+int nesvor_axisangle2mat_forward_f64(const double* ax, double* mat, int n, void* stream);
+int nesvor_axisangle2mat_backward_f64(const double* grad_mat, const double* ax, double* grad_ax, int n, void* stream);
+int nesvor_mat2axisangle_forward_f64(const double* mat, double* ax, int n, void* stream);
+int nesvor_mat2axisangle_backward_f64(const double* mat, const double* grad_ax, double* grad_mat, int n, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Slice acquisition forward operator A.  Replaces
+ * `nesvor.slice_acq_cuda.forward`
+ * (nesvor/slice_acquisition/slice_acq_cuda.cpp:156-161; kernel
+ * slice_acq_cuda_kernel.cu:17-171, host :954-991).
+ *   transforms (n,3,4) translation in voxel units; vol (D,H,W);
+ *   vol_mask (D,H,W) uint8/bool or NULL; slices_mask (n,h,w) uint8/bool or
+ *   NULL; psf (d_p,h_p,w_p); slices (n,h,w) out — must be zero-filled by the
+ *   caller; slices_weight (n,h,w) out (zero-filled) or NULL.
+ * ---------------------------------------------------------------------- */
+int nesvor_slice_acq_forward(const float* transforms, const float* vol, const uint8_t* vol_mask,
+                             const uint8_t* slices_mask, const float* psf, float* slices, float* slices_weight,
+                             int D, int H, int W, int d_p, int h_p, int w_p, int n, int h, int w,
+                             float res_slice, int interp_psf, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Multi-resolution hash-grid encoding.  Replaces `tinycudann.Encoding`
+ * (external module; call site nesvor/nesvor/models.py:22-25, config
+ * models.py:102-111).  See oracle/hashgrid.py for the algorithm statement.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int32_t n_levels;
+  int32_t n_features;                 /* features per level: 1, 2, 4 or 8 */
+  float scale[NESVOR_MAX_LEVELS];     /* fp32 grid scale per level */
+  uint32_t res[NESVOR_MAX_LEVELS];    /* vertices per axis */
+  uint32_t size[NESVOR_MAX_LEVELS];   /* entries in the level */
+  uint32_t offset[NESVOR_MAX_LEVELS]; /* entry offset into the flat table */
+  uint32_t hashed[NESVOR_MAX_LEVELS]; /* 1: spatial hash, 0: dense index */
+} nesvor_grid_t;
+
+/* layout of the encoded matrix pe / dpe */
+#define NESVOR_LAYOUT_ROW_MAJOR 0     /* (N, L*F): what tcnn returns to PyTorch */
+#define NESVOR_LAYOUT_FEATURE_MAJOR 1 /* (L*F, N): coalesced producer/consumer layout */
+
+/* u (N,3) in [0,1]; table flat fp32; pe out. */
+int nesvor_hashgrid_forward(const nesvor_grid_t* grid, const float* u, const float* table, float* pe,
+                            int64_t N, int layout, void* stream);
+/* grad_table is ACCUMULATED into (caller zero-fills when needed);
+ * grad_u (N,3) is OVERWRITTEN, or NULL to skip the input gradient. */
+int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* u, const float* table, const float* dpe,
+                             float* grad_table, float* grad_u, int64_t N, int layout, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused AdamW over a flat fp32 parameter buffer.  Replaces the
+ * torch.optim.AdamW step at nesvor/nesvor/train.py:144-152,195-197
+ * (betas (0.9,0.99), eps 1e-15, decoupled weight decay):
+ *   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ *   p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+ * grad is multiplied by grad_scale first (DDP mean) and, if zero_grad != 0,
+ * zero-filled afterwards (fuses optimizer.zero_grad()).
+ * ---------------------------------------------------------------------- */
+int nesvor_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay,
+                      float bias_correction1, float bias_correction2, float grad_scale, int zero_grad,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NESVOR_HIP_H */

@@ -1,0 +1,117 @@
+"""ctypes binding of libnesvor_hip.so (the C ABI declared in include/nesvor_hip.h).
+
+The library is the product's only compute backend for the native ops: there is
+no CPU or eager fallback.  ``load()`` raises if the shared object is missing and
+every op wrapper raises on non-device tensors.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnesvor_hip.so")
+MAX_LEVELS = 32
+ABI_VERSION = 1
+
+LAYOUT_ROW_MAJOR = 0
+LAYOUT_FEATURE_MAJOR = 1
+
+
+class GridT(Structure):
+    """Mirror of nesvor_grid_t."""
+
+    _fields_ = [
+        ("n_levels", c_int32),
+        ("n_features", c_int32),
+        ("scale", c_float * MAX_LEVELS),
+        ("res", c_uint32 * MAX_LEVELS),
+        ("size", c_uint32 * MAX_LEVELS),
+        ("offset", c_uint32 * MAX_LEVELS),
+        ("hashed", c_uint32 * MAX_LEVELS),
+    ]
+
+
+_lib = None
+
+_P = c_void_p
+_SIGNATURES = {
+    "nesvor_hip_abi_version": ([], c_int),
+    "nesvor_axisangle2mat_forward": ([_P, _P, c_int, _P], c_int),
+    "nesvor_axisangle2mat_backward": ([_P, _P, _P, c_int, _P], c_int),
+    "nesvor_mat2axisangle_forward": ([_P, _P, c_int, _P], c_int),
+    "nesvor_mat2axisangle_backward": ([_P, _P, _P, c_int, _P], c_int),
+    "nesvor_axisangle2mat_forward_f64": ([_P, _P, c_int, _P], c_int),
+    "nesvor_axisangle2mat_backward_f64": ([_P, _P, _P, c_int, _P], c_int),
+    "nesvor_mat2axisangle_forward_f64": ([_P, _P, c_int, _P], c_int),
+    "nesvor_mat2axisangle_backward_f64": ([_P, _P, _P, c_int, _P], c_int),
+    "nesvor_slice_acq_forward": (
+        [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 9 + [c_float, c_int, _P],
+        c_int,
+    ),
+    "nesvor_hashgrid_forward": ([POINTER(GridT), _P, _P, _P, c_int64, c_int, _P], c_int),
+    "nesvor_hashgrid_backward": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
+    "nesvor_adamw_step": (
+        [_P, _P, _P, _P, c_int64] + [c_float] * 8 + [c_int, _P],
+        c_int,
+    ),
+}
+
+
+def exported_symbols():
+    """Names declared in include/nesvor_hip.h (used by the CPU symbol test)."""
+    return list(_SIGNATURES)
+
+
+def load():
+    """Load the shared library once; fail loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP backend has not been built. "
+            "Run `python -m nesvor_amd.csrc.build` (or __graft_entry__.build()). "
+            "There is no CPU fallback for the native ops."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = restype
+    v = lib.nesvor_hip_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f"libnesvor_hip ABI {v} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def stream_ptr(device=None):
+    """hipStream_t of torch's current stream on `device` (so launches order with torch ops)."""
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return c_void_p(0)
+    return c_void_p(t.data_ptr())
+
+
+def check(err, what):
+    if err != 0:
+        raise RuntimeError(f"{what}: HIP error {err}")
+
+
+def require_device(*tensors, dtype=None, name="tensor"):
+    """Reference semantics (CHECK_CUDA / CHECK_CONTIGUOUS): raise on host or strided input."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a device (HIP) tensor — the native ops have no CPU path")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} must be contiguous")
+        if dtype is not None and t.dtype != dtype:
+            raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")

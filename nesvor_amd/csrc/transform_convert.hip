@@ -1,0 +1,225 @@
+// Rigid-transform conversion kernels for gfx950 (axis-angle <-> [R|t]).
+//
+// Behavioural spec: the reference's `transform_convert_cuda` extension
+// (nesvor/transform/transform_convert_cuda_kernel.cu:14-440).  Written from
+// the math, not from that file: R = c I + (1-c) k k^T + s [k]x with the
+// first-order branch R = I + [a]x when |a|^2 <= 1e-6; the inverse goes through
+// a 4-branch quaternion (branch masks r22 < 1e-6, r00 > r11, r00 < -r11) with
+// the w >= 0 sign fix.  One thread per transform; n is tiny (n_slices or the
+// batch size), so these kernels are latency- not bandwidth-bound: the point is
+// to keep them on the stream (no host sync) and fuse the surrounding algebra.
+#include <hip/hip_runtime.h>
+#include "common.h"
+
+namespace {
+
+constexpr double kEps = 1e-6;
+
+template <typename T> __device__ __forceinline__ T t_sqrt(T x);
+template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
+template <typename T> __device__ __forceinline__ void t_sincos(T x, T* s, T* c);
+template <> __device__ __forceinline__ void t_sincos<float>(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }
+template <> __device__ __forceinline__ void t_sincos<double>(double x, double* s, double* c) { *s = sin(x); *c = cos(x); }
+template <typename T> __device__ __forceinline__ T t_atan2(T y, T x);
+template <> __device__ __forceinline__ float t_atan2<float>(float y, float x) { return atan2f(y, x); }
+template <> __device__ __forceinline__ double t_atan2<double>(double y, double x) { return atan2(y, x); }
+
+template <typename T>
+__global__ void ax2mat_fwd(const T* __restrict__ ax, T* __restrict__ mat, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const T* a = ax + (size_t)i * 6;
+  T* m = mat + (size_t)i * 12;
+  T x = a[0], y = a[1], z = a[2];
+  T th2 = x * x + y * y + z * z;
+  T R[9];
+  if (th2 > (T)kEps) {
+    T th = t_sqrt(th2);
+    x /= th; y /= th; z /= th;
+    T s, c;
+    t_sincos(th, &s, &c);
+    T oc = 1 - c;
+    R[0] = c + x * x * oc;      R[1] = x * y * oc - z * s;  R[2] = y * s + x * z * oc;
+    R[3] = z * s + x * y * oc;  R[4] = c + y * y * oc;      R[5] = -x * s + y * z * oc;
+    R[6] = -y * s + x * z * oc; R[7] = x * s + y * z * oc;  R[8] = c + z * z * oc;
+  } else {
+    R[0] = 1;  R[1] = -z; R[2] = y;
+    R[3] = z;  R[4] = 1;  R[5] = -x;
+    R[6] = -y; R[7] = x;  R[8] = 1;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    m[r * 4 + 0] = R[r * 3 + 0];
+    m[r * 4 + 1] = R[r * 3 + 1];
+    m[r * 4 + 2] = R[r * 3 + 2];
+    m[r * 4 + 3] = a[3 + r];
+  }
+}
+
+template <typename T>
+__global__ void ax2mat_bwd(const T* __restrict__ gmat, const T* __restrict__ ax, T* __restrict__ gax, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const T* a = ax + (size_t)i * 6;
+  const T* g = gmat + (size_t)i * 12;
+  T* o = gax + (size_t)i * 6;
+  T G[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) G[r][c] = g[r * 4 + c];
+  // vee of the antisymmetric part
+  T sk[3] = {G[2][1] - G[1][2], G[0][2] - G[2][0], G[1][0] - G[0][1]};
+  T k[3] = {a[0], a[1], a[2]};
+  T th2 = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+  if (th2 > (T)kEps) {
+    T th = t_sqrt(th2);
+    k[0] /= th; k[1] /= th; k[2] /= th;
+    T s, c;
+    t_sincos(th, &s, &c);
+    T oc = 1 - c;
+    // dL/dc, dL/ds, dL/dk with k, c, s treated as independent
+    T dc = 0, dk[3] = {0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        dc += G[r][cc] * ((r == cc ? (T)1 : (T)0) - k[r] * k[cc]);
+        dk[r] += oc * (G[r][cc] + G[cc][r]) * k[cc];
+      }
+    T ds = sk[0] * k[0] + sk[1] * k[1] + sk[2] * k[2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) dk[d] += s * sk[d];
+    T dth = c * ds - s * dc;
+    T kd = dk[0] * k[0] + dk[1] * k[1] + dk[2] * k[2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) o[d] = dth * k[d] + (dk[d] - kd * k[d]) / th;
+  } else {
+    o[0] = sk[0]; o[1] = sk[1]; o[2] = sk[2];
+  }
+  o[3] = g[3]; o[4] = g[7]; o[5] = g[11];
+}
+
+// Quaternion (w,x,y,z) from R with the reference's branch selection; `s` is the
+// branch's 2*sqrt(trace-like) value and `br` the branch id.
+template <typename T>
+__device__ __forceinline__ void quat_from_R(const T* m, T q[4], T* s_out, int* br_out) {
+  T r00 = m[0], r01 = m[1], r02 = m[2];
+  T r10 = m[4], r11 = m[5], r12 = m[6];
+  T r20 = m[8], r21 = m[9], r22 = m[10];
+  bool d2 = r22 < (T)kEps, d01 = r00 > r11, d0n1 = r00 < -r11;
+  int br = (!d2 && !d0n1) ? 0 : (d2 && d01) ? 1 : (d2 && !d01) ? 2 : 3;
+  T s;
+  if (br == 0) {
+    s = 2 * t_sqrt(r00 + r11 + r22 + 1);
+    q[0] = (T)0.25 * s; q[1] = (r21 - r12) / s; q[2] = (r02 - r20) / s; q[3] = (r10 - r01) / s;
+  } else if (br == 1) {
+    s = 2 * t_sqrt(r00 - r11 - r22 + 1);
+    q[0] = (r21 - r12) / s; q[1] = (T)0.25 * s; q[2] = (r01 + r10) / s; q[3] = (r02 + r20) / s;
+  } else if (br == 2) {
+    s = 2 * t_sqrt(r11 - r00 - r22 + 1);
+    q[0] = (r02 - r20) / s; q[1] = (r01 + r10) / s; q[2] = (T)0.25 * s; q[3] = (r12 + r21) / s;
+  } else {
+    s = 2 * t_sqrt(r22 - r00 - r11 + 1);
+    q[0] = (r10 - r01) / s; q[1] = (r02 + r20) / s; q[2] = (r12 + r21) / s; q[3] = (T)0.25 * s;
+  }
+  *s_out = s;
+  *br_out = br;
+}
+
+template <typename T>
+__global__ void mat2ax_fwd(const T* __restrict__ mat, T* __restrict__ ax, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const T* m = mat + (size_t)i * 12;
+  T* o = ax + (size_t)i * 6;
+  T q[4], s;
+  int br;
+  quat_from_R(m, q, &s, &br);
+  if (q[0] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+  T n2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  T si = t_sqrt(n2);
+  T th = 2 * t_atan2(si, q[0]);
+  T fac = (n2 > (T)kEps) ? th / si : (T)2 / q[0];
+  o[0] = q[1] * fac; o[1] = q[2] * fac; o[2] = q[3] * fac;
+  o[3] = m[3]; o[4] = m[7]; o[5] = m[11];
+}
+
+template <typename T>
+__global__ void mat2ax_bwd(const T* __restrict__ mat, const T* __restrict__ gax, T* __restrict__ gmat, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const T* m = mat + (size_t)i * 12;
+  const T* ga = gax + (size_t)i * 6;
+  T* o = gmat + (size_t)i * 12;
+  T q[4], s;
+  int br;
+  quat_from_R(m, q, &s, &br);
+  T sgn = q[0] < 0 ? (T)-1 : (T)1;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) q[d] *= sgn;
+  T n2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  T si = t_sqrt(n2);
+  T th = 2 * t_atan2(si, q[0]);
+  bool big = n2 > (T)kEps;
+  // reference regularises the small-angle denominators with +eps
+  T sid = big ? si : si + (T)kEps;
+  T fac = big ? th / si : (T)2 / q[0];
+  T dot = q[1] * ga[0] + q[2] * ga[1] + q[3] * ga[2];
+  T inv = (T)2 / (q[0] * q[0] + si * si);
+  T t2 = (q[0] * inv - fac) / sid;
+  T dq[4];
+  dq[0] = -dot * inv;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) dq[d + 1] = dot * t2 * (q[d + 1] / sid) + fac * ga[d];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) { q[d] *= sgn; dq[d] *= sgn; }
+  // Wire quaternion-component grads back to matrix entries.
+  // antisymmetric numerators: A=(r21-r12) B=(r02-r20) C=(r10-r01)
+  // symmetric numerators:     P=(r01+r10) Q=(r02+r20) Rr=(r12+r21)
+  T gA = 0, gB = 0, gC = 0, gP = 0, gQ = 0, gR = 0, major, acc;
+  T ds0, ds1, ds2;  // signs of d s / d r_dd
+  if (br == 0) {
+    gA = dq[1]; gB = dq[2]; gC = dq[3]; major = dq[0];
+    acc = q[1] * dq[1] + q[2] * dq[2] + q[3] * dq[3];
+    ds0 = 1; ds1 = 1; ds2 = 1;
+  } else if (br == 1) {
+    gA = dq[0]; gP = dq[2]; gQ = dq[3]; major = dq[1];
+    acc = q[0] * dq[0] + q[2] * dq[2] + q[3] * dq[3];
+    ds0 = 1; ds1 = -1; ds2 = -1;
+  } else if (br == 2) {
+    gB = dq[0]; gP = dq[1]; gR = dq[3]; major = dq[2];
+    acc = q[0] * dq[0] + q[1] * dq[1] + q[3] * dq[3];
+    ds0 = -1; ds1 = 1; ds2 = -1;
+  } else {
+    gC = dq[0]; gQ = dq[1]; gR = dq[2]; major = dq[3];
+    acc = q[0] * dq[0] + q[1] * dq[1] + q[2] * dq[2];
+    ds0 = -1; ds1 = -1; ds2 = 1;
+  }
+  T dS = (-acc / s + (T)0.25 * major) * ((T)2 / s);
+  o[0] = ds0 * dS;          o[1] = (gP - gC) / s;     o[2] = (gQ + gB) / s;   o[3] = ga[3];
+  o[4] = (gP + gC) / s;     o[5] = ds1 * dS;          o[6] = (gR - gA) / s;   o[7] = ga[4];
+  o[8] = (gQ - gB) / s;     o[9] = (gR + gA) / s;     o[10] = ds2 * dS;       o[11] = ga[5];
+}
+
+template <typename K, typename... Args>
+int launch1d(K kernel, int n, void* stream, Args... args) {
+  if (n <= 0) return 0;
+  constexpr int B = 64;
+  hipLaunchKernelGGL(kernel, dim3((n + B - 1) / B), dim3(B), 0, (hipStream_t)stream, args..., n);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+int nesvor_axisangle2mat_forward(const float* ax, float* mat, int n, void* st) { return launch1d(ax2mat_fwd<float>, n, st, ax, mat); }
+int nesvor_axisangle2mat_backward(const float* g, const float* ax, float* gax, int n, void* st) { return launch1d(ax2mat_bwd<float>, n, st, g, ax, gax); }
+int nesvor_mat2axisangle_forward(const float* mat, float* ax, int n, void* st) { return launch1d(mat2ax_fwd<float>, n, st, mat, ax); }
+int nesvor_mat2axisangle_backward(const float* mat, const float* gax, float* gmat, int n, void* st) { return launch1d(mat2ax_bwd<float>, n, st, mat, gax, gmat); }
+int nesvor_axisangle2mat_forward_f64(const double* ax, double* mat, int n, void* st) { return launch1d(ax2mat_fwd<double>, n, st, ax, mat); }
+int nesvor_axisangle2mat_backward_f64(const double* g, const double* ax, double* gax, int n, void* st) { return launch1d(ax2mat_bwd<double>, n, st, g, ax, gax); }
+int nesvor_mat2axisangle_forward_f64(const double* mat, double* ax, int n, void* st) { return launch1d(mat2ax_fwd<double>, n, st, mat, ax); }
+int nesvor_mat2axisangle_backward_f64(const double* mat, const double* gax, double* gmat, int n, void* st) { return launch1d(mat2ax_bwd<double>, n, st, mat, gax, gmat); }
+}

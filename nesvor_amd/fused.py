@@ -1,0 +1,93 @@
+"""Fused training step for the NeSVoR INR (the loop body of train.py:179-198).
+
+All trainable tensors of the model are re-homed into ONE flat fp32 parameter
+buffer with matching flat gradient and Adam-moment buffers, so that
+* the optimiser + zero_grad is one HBM-streaming launch (nesvor_adamw_step),
+* data-parallel training needs exactly one RCCL collective per iteration over
+  one contiguous buffer (nesvor_amd.ddp),
+* the hash-grid backward scatters straight into the flat gradient.
+"""
+import math
+from argparse import Namespace
+from typing import Dict
+
+import torch
+
+from . import _lib
+from .models import NeSVoR
+from .train import loss_weights
+
+
+class FlatParams:
+    """Re-home every parameter of `module` into one flat buffer (params become views)."""
+
+    def __init__(self, module: torch.nn.Module):
+        named = [(n, p) for n, p in module.named_parameters() if p.numel() > 0]
+        # big table first, 16-byte aligned segments so float4 access never straddles a tensor
+        named.sort(key=lambda kv: -kv[1].numel())
+        self.names, self.offsets, total = [], {}, 0
+        for n, p in named:
+            self.offsets[n] = (total, p.numel())
+            self.names.append(n)
+            total += (p.numel() + 3) // 4 * 4
+        dev = named[0][1].device
+        self.param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        for n, p in named:
+            off, cnt = self.offsets[n]
+            self.param[off : off + cnt].copy_(p.data.reshape(-1))
+            p.data = self.param[off : off + cnt].view(p.shape)
+            p.grad = self.grad[off : off + cnt].view(p.shape)
+        self.numel = total
+
+    def grad_view(self, name):
+        off, cnt = self.offsets[name]
+        return self.grad[off : off + cnt]
+
+
+class FusedTrainer:
+    def __init__(self, model: NeSVoR, args: Namespace, world_size: int = 1):
+        if next(model.parameters()).device.type != "cuda":
+            raise RuntimeError("FusedTrainer needs the model on a HIP device (no CPU path)")
+        self.model, self.args = model, args
+        self.flat = FlatParams(model)
+        enc = model.inr.encoding
+        enc.grad_accum = self.flat.grad_view("inr.encoding.params")
+        self.weights = loss_weights(args)
+        self.lr = float(args.learning_rate)
+        self.betas, self.eps, self.weight_decay = (0.9, 0.99), 1e-15, 1e-2
+        self.t = 0
+        self.world_size = world_size
+        self.reduce_hook = None  # set by ddp: callable(flat_grad) performing the all-reduce(sum)
+
+    def decay_lr(self, gamma: float) -> None:
+        self.lr *= gamma
+
+    def step(self, xyz, v, slice_idx) -> Dict[str, torch.Tensor]:
+        losses = self.model(xyz, v, slice_idx)
+        loss = 0
+        for k, val in losses.items():
+            if k in self.weights and self.weights[k]:
+                loss = loss + self.weights[k] * val
+        loss.backward()
+        self.optimizer_step()
+        return losses
+
+    def optimizer_step(self) -> None:
+        if self.reduce_hook is not None:
+            self.reduce_hook(self.flat.grad)
+        self.t += 1
+        b1, b2 = self.betas
+        f = self.flat
+        with torch.cuda.device(f.param.device):
+            err = _lib.load().nesvor_adamw_step(
+                _lib.ptr(f.param), _lib.ptr(f.grad), _lib.ptr(f.exp_avg), _lib.ptr(f.exp_avg_sq), f.numel,
+                self.lr, b1, b2, self.eps, self.weight_decay, 1 - b1**self.t, 1 - b2**self.t,
+                1.0 / self.world_size, 1, _lib.stream_ptr(),
+            )
+        _lib.check(err, "adamw step")
+
+    def finish(self) -> None:
+        self.model.inr.encoding.grad_accum = None

@@ -1,0 +1,87 @@
+"""Drop-in for the slice of the external ``tinycudann`` module the reference uses
+(nesvor/nesvor/models.py:22-41): ``Encoding`` (HashGrid) and ``Network``.
+
+    import nesvor_amd.tinycudann as tcnn
+    enc = tcnn.Encoding(3, {"otype": "HashGrid", "n_levels": 16, ...}, dtype=torch.float32)
+
+Both are ``nn.Module``s with one flat fp32 ``params`` Parameter, as in
+tinycudann's PyTorch binding.  ``Encoding`` runs the gfx950 hash-grid kernels.
+``Network`` is the bias-free MLP tinycudann provides ("CutlassMLP" /
+"FullyFusedMLP"); here its GEMMs run through rocBLAS (torch.matmul) on views of
+the flat parameter tensor — a plain library GEMM.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .encoding import hashgrid_encode
+from .grid import HashGridSpec
+
+
+class Encoding(nn.Module):
+    def __init__(self, n_input_dims: int, encoding_config: dict, seed: int = 1337, dtype=torch.float32):
+        super().__init__()
+        if n_input_dims != 3:
+            raise ValueError("only 3-D hash grids are built")
+        if encoding_config.get("otype", "HashGrid") not in ("HashGrid", "Grid"):
+            raise ValueError(f"unsupported encoding otype {encoding_config.get('otype')}")
+        if encoding_config.get("interpolation", "Linear") != "Linear":
+            raise ValueError("only linear interpolation is built")
+        self.n_input_dims = n_input_dims
+        self.dtype = dtype
+        self.spec = HashGridSpec(
+            int(encoding_config["n_levels"]),
+            int(encoding_config.get("n_features_per_level", 2)),
+            int(encoding_config.get("log2_hashmap_size", 19)),
+            int(encoding_config.get("base_resolution", 16)),
+            float(encoding_config.get("per_level_scale", 2.0)),
+        )
+        self.n_output_dims = self.spec.n_output_dims
+        g = torch.Generator().manual_seed(seed)
+        # tinycudann initialises grid parameters U(-1e-4, 1e-4)
+        init = (torch.rand(self.spec.n_params, generator=g, dtype=torch.float32) * 2 - 1) * 1e-4
+        self.params = nn.Parameter(init)
+        self.grad_accum = None  # optional flat-buffer view the backward scatters into (see fused.py)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        out = hashgrid_encode(x.to(torch.float32), self.params, self.spec, grad_accum=self.grad_accum)
+        return out.to(self.dtype)
+
+
+class Network(nn.Module):
+    """Bias-free MLP with flat params; output width padded to a multiple of 16 as tinycudann does."""
+
+    def __init__(self, n_input_dims: int, n_output_dims: int, network_config: dict, seed: int = 1337):
+        super().__init__()
+        self.n_input_dims = n_input_dims
+        self.n_output_dims = n_output_dims
+        width = int(network_config["n_neurons"])
+        depth = int(network_config["n_hidden_layers"])
+        self.activation = network_config.get("activation", "ReLU")
+        self.output_activation = network_config.get("output_activation", "None")
+        pad_out = (n_output_dims + 15) // 16 * 16
+        dims = [n_input_dims] + [width] * depth + [pad_out]
+        self.shapes = [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]
+        g = torch.Generator().manual_seed(seed)
+        chunks = []
+        for o, i in self.shapes:  # xavier-uniform, tinycudann's default
+            bound = math.sqrt(6.0 / (i + o))
+            chunks.append(((torch.rand(o * i, generator=g) * 2 - 1) * bound))
+        self.params = nn.Parameter(torch.cat(chunks))
+
+    def _act(self, name, x):
+        if name == "None":
+            return x
+        return getattr(F, name.lower())(x)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        off = 0
+        h = x.to(self.params.dtype)
+        for li, (o, i) in enumerate(self.shapes):
+            w = self.params[off : off + o * i].view(o, i)
+            off += o * i
+            h = h @ w.t()
+            h = self._act(self.activation if li < len(self.shapes) - 1 else self.output_activation, h)
+        return h[..., : self.n_output_dims]

@@ -1,0 +1,131 @@
+"""CPU oracle: slice acquisition forward operator A (volume -> PSF-blurred slices).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Restates, vectorised over slice
+pixels with a Python loop over PSF taps,
+``slice_acquisition_forward_cuda_kernel``
+(nesvor/slice_acquisition/slice_acq_cuda_kernel.cu:17-171; host :954-991):
+
+* pixel centre in voxel units: R (p + T) + (dims-1)/2              (.cu:42-56)
+* tap loop bounds -d/2 .. (d+1)/2, zero taps skipped               (.cu:61-65)
+* tap position = centre + R (ix_p, iy_p, iz_p); dropped unless
+  0 <= pos < dim-1                                                 (.cu:66-69)
+* default: trilinear sampling of the volume with PSF weight        (.cu:110-160)
+* ``interp_psf``: nearest voxel + trilinear re-interpolation of
+  the PSF at the voxel's offset from the centre                    (.cu:71-109)
+* out = sum(w v) / sum(w) where sum(w) > 0                         (.cu:167-170)
+"""
+import torch
+
+
+def slice_acquisition_forward(
+    transforms: torch.Tensor,  # (n,3,4), translation in voxel units
+    vol: torch.Tensor,  # (1,1,D,H,W)
+    vol_mask,  # bool (1,1,D,H,W) or None
+    slices_mask,  # bool (n,1,h,w) or None
+    psf: torch.Tensor,  # (d_p,h_p,w_p)
+    slice_shape,
+    res_slice: float,
+    need_weight: bool = False,
+    interp_psf: bool = False,
+):
+    dt = vol.dtype
+    n = transforms.shape[0]
+    h, w = int(slice_shape[0]), int(slice_shape[1])
+    D, H, W = vol.shape[-3:]
+    d_p, h_p, w_p = psf.shape
+    volf = vol.reshape(-1)
+    vmask = None if vol_mask is None or vol_mask.numel() == 0 else vol_mask.reshape(-1)
+    R = transforms[:, :, :3]  # (n,3,3)
+    T = transforms[:, :, 3]  # (n,3)
+    # the reference evaluates (i - (w-1)/2.) * res_slice + t in double and rounds once (.cu:46-47)
+    rs = float(torch.tensor(res_slice, dtype=dt))
+    px = (torch.arange(w, dtype=torch.float64) - (w - 1) / 2.0) * rs  # (w,)
+    py = (torch.arange(h, dtype=torch.float64) - (h - 1) / 2.0) * rs  # (h,)
+    _x = (px[None, None, :] + T[:, 0, None, None].double()).to(dt)  # (n,1,w)
+    _y = (py[None, :, None] + T[:, 1, None, None].double()).to(dt)  # (n,h,1)
+    _z = T[:, 2, None, None]
+    _x, _y, _z = torch.broadcast_tensors(_x, _y, _z)
+    _x, _y, _z = _x.expand(n, h, w), _y.expand(n, h, w), _z.expand(n, h, w)
+
+    def rot(row, a, b, c):
+        return (
+            R[:, row, 0, None, None] * a
+            + R[:, row, 1, None, None] * b
+            + R[:, row, 2, None, None] * c
+        )
+
+    xc = rot(0, _x, _y, _z) + (W - 1) / 2.0
+    yc = rot(1, _x, _y, _z) + (H - 1) / 2.0
+    zc = rot(2, _x, _y, _z) + (D - 1) / 2.0
+    val = torch.zeros(n, h, w, dtype=dt)
+    wsum = torch.zeros(n, h, w, dtype=dt)
+    active = torch.ones(n, h, w, dtype=torch.bool)
+    if slices_mask is not None and slices_mask.numel() > 0:
+        active = slices_mask.reshape(n, h, w).clone()
+    Sy, Sz = W, H * W
+    psff = psf.reshape(-1)
+    i_p = -1
+    for iz_p in range(-(d_p // 2), (d_p + 1) // 2):
+        for iy_p in range(-(h_p // 2), (h_p + 1) // 2):
+            for ix_p in range(-(w_p // 2), (w_p + 1) // 2):
+                i_p += 1
+                pv = psff[i_p]
+                if float(pv) == 0.0:
+                    continue
+                x = xc + rot(0, ix_p, iy_p, iz_p)
+                y = yc + rot(1, ix_p, iy_p, iz_p)
+                z = zc + rot(2, ix_p, iy_p, iz_p)
+                ok = active & (x >= 0) & (y >= 0) & (z >= 0) & (x < W - 1) & (y < H - 1) & (z < D - 1)
+                if not bool(ok.any()):
+                    continue
+                xs = torch.where(ok, x, torch.zeros_like(x))
+                ys = torch.where(ok, y, torch.zeros_like(y))
+                zs = torch.where(ok, z, torch.zeros_like(z))
+                if interp_psf:
+                    xr = torch.floor(xs + 0.5)
+                    yr = torch.floor(ys + 0.5)
+                    zr = torch.floor(zs + 0.5)
+                    iv = (zr * Sz + yr * Sy + xr).long()
+                    if vmask is not None:
+                        ok = ok & vmask[iv]
+                    v_ = volf[iv]
+                    dx_, dy_, dz_ = xr - xc, yr - yc, zr - zc
+                    # R^T (voxel - centre) + PSF half extent
+                    xp = R[:, 0, 0, None, None] * dx_ + R[:, 1, 0, None, None] * dy_ + R[:, 2, 0, None, None] * dz_ + (w_p - 1) / 2.0
+                    yp = R[:, 0, 1, None, None] * dx_ + R[:, 1, 1, None, None] * dy_ + R[:, 2, 1, None, None] * dz_ + (h_p - 1) / 2.0
+                    zp = R[:, 0, 2, None, None] * dx_ + R[:, 1, 2, None, None] * dy_ + R[:, 2, 2, None, None] * dz_ + (d_p - 1) / 2.0
+                    ok = ok & (xp >= 0) & (yp >= 0) & (zp >= 0) & (xp < w_p - 1) & (yp < h_p - 1) & (zp < d_p - 1)
+                    xp = torch.where(ok, xp, torch.zeros_like(xp))
+                    yp = torch.where(ok, yp, torch.zeros_like(yp))
+                    zp = torch.where(ok, zp, torch.zeros_like(zp))
+                    xf, yf, zf = torch.floor(xp), torch.floor(yp), torch.floor(zp)
+                    wx, wy, wz = xp - xf, yp - yf, zp - zf
+                    ip = (zf * (w_p * h_p) + yf * w_p + xf).long()
+                    pw = torch.zeros_like(xp)
+                    for cz in (0, 1):
+                        for cy in (0, 1):
+                            for cx in (0, 1):
+                                wgt = (wx if cx else 1 - wx) * (wy if cy else 1 - wy) * (wz if cz else 1 - wz)
+                                pw = pw + wgt * psff[ip + cx + cy * w_p + cz * w_p * h_p]
+                    pw = torch.where(ok, pw, torch.zeros_like(pw))
+                    val = val + pw * v_
+                    wsum = wsum + pw
+                else:
+                    xf, yf, zf = torch.floor(xs), torch.floor(ys), torch.floor(zs)
+                    wx, wy, wz = xs - xf, ys - yf, zs - zf
+                    iv = (zf * Sz + yf * Sy + xf).long()
+                    for cz in (0, 1):
+                        for cy in (0, 1):
+                            for cx in (0, 1):
+                                wgt = (wx if cx else 1 - wx) * (wy if cy else 1 - wy) * (wz if cz else 1 - wz) * pv
+                                ic = iv + cx + cy * Sy + cz * Sz
+                                okc = ok if vmask is None else (ok & vmask[ic])
+                                wgt = torch.where(okc, wgt, torch.zeros_like(wgt))
+                                val = val + wgt * volf[ic]
+                                wsum = wsum + wgt
+    pos = wsum > 0
+    out = torch.where(pos, val / torch.where(pos, wsum, torch.ones_like(wsum)), torch.zeros_like(val))
+    out = out.view(n, 1, h, w)
+    if need_weight:
+        return out, torch.where(pos, wsum, torch.zeros_like(wsum)).view(n, 1, h, w)
+    return out

@@ -1,0 +1,173 @@
+"""CPU: pin the oracle against the reference's golden vectors / known answers."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import scipy_table, small_args
+from oracle import hashgrid as hg
+from oracle import nesvor_model as nm
+from oracle import slice_acq as osa
+from oracle import train_loop as otl
+from oracle import transform_convert as tc
+
+
+# ---- transforms: the reference's scipy table (tests/transform/test_transform_convert.py:13-21)
+def test_axisangle2mat_vs_scipy_table():
+    ax, mat = scipy_table()
+    torch.testing.assert_close(tc.axisangle2mat_forward(ax), mat)  # default fp32 tolerances, as the reference
+
+
+def test_mat2axisangle_vs_scipy_table():
+    ax, mat = scipy_table()
+    torch.testing.assert_close(tc.mat2axisangle_forward(mat), ax)
+
+
+def test_compose_inv_identity():
+    """tests/transform/test_transform.py:7-23 on the oracle algebra (all trans_first)."""
+    ax, mat = scipy_table()
+    for i in range(len(ax)):
+        a, b = mat[i : i + 1], mat[-i - 1 : len(ax) - i]
+        ab = nm.mat_compose(a, b)
+        binv_ainv = nm.mat_compose(nm.mat_inv(b), nm.mat_inv(a))
+        err = tc.mat2axisangle_forward(nm.mat_compose(ab, binv_ainv))
+        # rotation to the reference's 2e-5; translations here are O(300) all-trans_first, so fp32 roundoff ~3e-5
+        torch.testing.assert_close(err[:, :3], torch.zeros(1, 3), atol=2e-5, rtol=1e-3)
+        torch.testing.assert_close(err[:, 3:], torch.zeros(1, 3), atol=2e-4, rtol=1e-3)
+
+
+def test_transform_backward_gradcheck_fp64():
+    """No reference test covers the backward kernels -> pin the analytic formulas with gradcheck."""
+    torch.manual_seed(0)
+    ax = torch.randn(24, 6, dtype=torch.float64)
+    ax[:4, :3] *= 1e-4  # small-angle branch
+    ax[4:8, :3] *= 2.5  # large angles -> all quaternion branches
+    ax.requires_grad_(True)
+    assert torch.autograd.gradcheck(nm.axisangle2mat, (ax,), eps=1e-7, atol=1e-6)
+    ax2 = torch.randn(32, 6, dtype=torch.float64)
+    ax2[:, :3] *= torch.linspace(0.05, 3.0, 32, dtype=torch.float64)[:, None] / ax2[:, :3].norm(dim=-1, keepdim=True)
+    ax2.requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda a: nm.mat2axisangle(nm.axisangle2mat(a)), (ax2,), eps=1e-7, atol=1e-5)
+
+
+def test_quaternion_branches_all_hit():
+    ax, mat = scipy_table()
+    torch.manual_seed(3)
+    extra = torch.randn(200, 6) * 1.5
+    m = tc.axisangle2mat_forward(torch.cat([ax, extra]))
+    _, masks = tc._quat_branches(m)
+    assert all(bool(b.any()) for b in masks)
+    back = tc.axisangle2mat_forward(tc.mat2axisangle_forward(m))
+    torch.testing.assert_close(back, m, atol=2e-5, rtol=1e-4)
+
+
+# ---- hash grid (parity unpinned: self-consistency only)
+def test_hashgrid_level_table_matches_survey():
+    lv = hg.make_levels(16, 19, 9, 1.26)
+    assert [l.size for l in lv[:10]] == [736, 1728, 3376, 6864, 12168, 24392, 50656, 97336, 195112, 389024]
+    assert all(l.hashed and l.size == 2**19 for l in lv[10:])
+    assert hg.n_params(lv, 2) == 7854240
+
+
+def test_hashgrid_autograd_equals_published_backward():
+    lv = hg.make_levels(6, 10, 4, 1.5)
+    torch.manual_seed(1)
+    u = torch.rand(300, 3, dtype=torch.float64)
+    tab = torch.randn(hg.n_params(lv, 2), dtype=torch.float64)
+    dy = torch.randn(300, 12, dtype=torch.float64)
+    gt, gu = hg.encode_backward(u, tab, lv, 2, dy)
+    gt2, gu2 = hg.encode_backward_explicit(u, tab, lv, 2, dy)
+    torch.testing.assert_close(gt, gt2)
+    torch.testing.assert_close(gu, gu2)
+
+
+def test_hashgrid_known_answers():
+    # a dense level interpolates linearly: table = linear function of vertex coords -> exact recovery
+    lv = hg.make_levels(1, 19, 5, 2.0)
+    l0 = lv[0]
+    assert not l0.hashed
+    tab = torch.zeros(l0.size, 1, dtype=torch.float64)
+    g = torch.arange(l0.res)
+    zz, yy, xx = torch.meshgrid(g, g, g, indexing="ij")
+    tab[: l0.res**3, 0] = (1.0 * xx + 10.0 * yy + 100.0 * zz).reshape(-1).double()
+    u = torch.rand(50, 3, dtype=torch.float64) * 0.8  # keep cell+1 < res (beyond, tcnn wraps)
+    y = hg.encode(u, tab.view(-1), lv, 1)[:, 0]
+    pos = u * l0.scale + 0.5
+    torch.testing.assert_close(y, pos[:, 0] + 10 * pos[:, 1] + 100 * pos[:, 2])
+
+
+# ---- slice acquisition
+def test_slice_acq_identity_psf_delta():
+    """Known answer: delta PSF, identity pose, unit spacing -> the central slice of the volume."""
+    torch.manual_seed(0)
+    vol = torch.rand(1, 1, 9, 9, 9)
+    psf = torch.zeros(3, 3, 3)
+    psf[1, 1, 1] = 1.0
+    tf = torch.eye(3, 4)[None]
+    out = osa.slice_acquisition_forward(tf, vol, None, None, psf, (7, 7), 1.0, False, False)
+    torch.testing.assert_close(out[0, 0], vol[0, 0, 4, 1:8, 1:8])
+
+
+def test_slice_acq_linearity_and_constant():
+    from nesvor_amd.utils import get_PSF
+
+    psf = get_PSF(res_ratio=(1.5, 1.5, 3.0))
+    tf = tc.axisangle2mat_forward(torch.tensor([[0.3, -0.2, 0.5, 0.5, 0.5, 1.0], [0.0, 0.7, 0.1, -1.0, 0.5, -2.0]]))
+    v1, v2 = torch.rand(1, 1, 16, 16, 16), torch.rand(1, 1, 16, 16, 16)
+    f = lambda v: osa.slice_acquisition_forward(tf, v, None, None, psf, (12, 12), 1.5, True, False)
+    (a, wa), (b, _), (c, _) = f(v1), f(v2), f(2 * v1 + 3 * v2)
+    torch.testing.assert_close(c, 2 * a + 3 * b, atol=1e-5, rtol=1e-5)
+    ones, w1 = f(torch.ones_like(v1))
+    torch.testing.assert_close(ones[w1 > 0], torch.ones_like(ones[w1 > 0]))
+
+
+# ---- model / training loop vs fixtures captured from the reference's Python
+def _params_from_golden(golden, tag):
+    P = {}
+    for k in golden[f"fw{tag}_state_keys"]:
+        k = str(k)
+        P[k] = torch.tensor(golden[f"fw{tag}_sd::{k}"])
+    return P
+
+
+@pytest.mark.parametrize("tag,over", [("", {}), ("_bias", {"n_levels_bias": 2, "depth": 2})])
+def test_nesvor_forward_losses_and_grads_vs_reference(golden, tag, over):
+    args = small_args(**over)
+    P = _params_from_golden(golden, tag)
+    bb = P.pop("inr.bounding_box")
+    ax_init = P.pop("axisangle_init")
+    base, L = nm.grid_config(bb, args)
+    levels = hg.make_levels(L, args.log2_hashmap_size, base, args.level_scale)
+    for v in P.values():
+        v.requires_grad_(True)
+    losses = nm.nesvor_forward(
+        P, levels, args, bb, torch.tensor(golden[f"fw{tag}_psf_sigma"]), ax_init, float(golden[f"fw{tag}_delta"]),
+        torch.tensor(golden[f"fw{tag}_xyz"]), torch.tensor(golden[f"fw{tag}_v"]), torch.tensor(golden[f"fw{tag}_idx"]),
+        torch.tensor(golden[f"fw{tag}_noise"]),
+    )
+    keys = [str(k) for k in golden[f"fw{tag}_loss_keys"]]
+    assert list(losses.keys()) == keys
+    got = np.array([float(losses[k]) for k in keys])
+    np.testing.assert_allclose(got, golden[f"fw{tag}_loss_vals"], rtol=1e-5, atol=1e-7)
+    nm.total_loss(losses, args).backward()
+    for k, p in P.items():
+        ref = golden[f"fw{tag}_grad::{k}"]
+        scale = max(np.abs(ref).max(), 1e-12)
+        np.testing.assert_allclose(p.grad.numpy(), ref, rtol=1e-4, atol=1e-5 * scale, err_msg=k)
+
+
+def test_train_trajectory_and_sample_volume_vs_reference(golden):
+    """20 iterations of train() (AdamW, lr milestones at 10/15/18) with the reference's RNG order."""
+    args = small_args()
+    ds = otl.ArrayDataset(
+        torch.tensor(golden["ds_xyz"]), torch.tensor(golden["ds_v"]), torch.tensor(golden["ds_slice_idx"]),
+        torch.tensor(golden["ds_transformation"]), torch.tensor(golden["ds_resolution"]),
+    )
+    torch.testing.assert_close(ds.bounding_box, torch.tensor(golden["ds_bounding_box"]))
+    assert abs(ds.mean - float(golden["ds_mean"])) < 1e-6
+    torch.manual_seed(0)
+    P, levels, bb, info = otl.train(ds, args)
+    for k in ("inr.encoding.params", "inr.density_net.0.weight", "inr.density_net.2.bias"):
+        ref = golden["train_sd::" + k.replace("inr.", "", 1)]
+        np.testing.assert_allclose(P[k].numpy(), ref, rtol=2e-4, atol=2e-6, err_msg=k)
+    got_tf = tc.axisangle2mat_forward(P["axisangle"])
+    np.testing.assert_allclose(got_tf.numpy(), golden["train_out_tf"], rtol=1e-4, atol=1e-4)
