@@ -81,9 +81,17 @@ typedef struct {
 int nesvor_hashgrid_forward(const nesvor_grid_t* grid, const float* u, const float* table, float* pe,
                             int64_t N, int layout, void* stream);
 /* grad_table is ACCUMULATED into (caller zero-fills when needed);
- * grad_u (N,3) is OVERWRITTEN, or NULL to skip the input gradient. */
+ * grad_u (N,3) is OVERWRITTEN, or NULL to skip the input gradient.
+ * Owner-computes scatter (LDS aggregation per 256 samples -> per-chunk queues ->
+ * one owner workgroup per table chunk); `workspace` is scratch device memory of
+ * nesvor_hashgrid_backward_workspace_bytes(grid, N) bytes (-1: grid outside the
+ * plan's limits, use the _atomic variant). */
+int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t* grid, int64_t N);
 int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* u, const float* table, const float* dpe,
-                             float* grad_table, float* grad_u, int64_t N, int layout, void* stream);
+                             float* grad_table, float* grad_u, int64_t N, int layout, void* workspace, void* stream);
+/* Same contract, tcnn-style per-corner global atomics (slow on MI355X: memory-side atomics). */
+int nesvor_hashgrid_backward_atomic(const nesvor_grid_t* grid, const float* u, const float* table, const float* dpe,
+                                    float* grad_table, float* grad_u, int64_t N, int layout, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused AdamW over a flat fp32 parameter buffer.  Replaces the

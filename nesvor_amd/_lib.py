@@ -51,7 +51,9 @@ _SIGNATURES = {
         c_int,
     ),
     "nesvor_hashgrid_forward": ([POINTER(GridT), _P, _P, _P, c_int64, c_int, _P], c_int),
-    "nesvor_hashgrid_backward": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
+    "nesvor_hashgrid_backward_workspace_bytes": ([POINTER(GridT), c_int64], c_int64),
+    "nesvor_hashgrid_backward": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, _P], c_int),
+    "nesvor_hashgrid_backward_atomic": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
     "nesvor_adamw_step": (
         [_P, _P, _P, _P, c_int64] + [c_float] * 8 + [c_int, _P],
         c_int,

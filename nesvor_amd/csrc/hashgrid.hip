@@ -18,12 +18,23 @@
 //   path so that each lane writes/reads consecutive addresses (coalesced
 //   dwordx1/x2 streams); the row-major (N, L*F) layout tinycudann hands to
 //   PyTorch is supported for the drop-in module.
-// * backward: hardware fp32 atomics (global_atomic_add_f32, built with
-//   -munsafe-fp-atomics).  A PSF cloud hits the same cell with most lanes of a
-//   wave at the coarse levels, so lanes that share the wave leader's cell are
-//   first summed across the wave and committed by one lane
-//   (16 atomics instead of 16 x group size); lanes in sparsely shared cells
-//   fall through to plain per-lane atomics.
+// * backward: global fp32 atomics are executed memory-side on MI355X (they
+//   drop the line from the XCD L2; measured ~16 G atomics/s chip-wide), so a
+//   tcnn-style "one atomicAdd per corner" scatter costs 8-16 ms at N = 2^20.
+//   The backward is therefore an owner-computes scatter in two launches:
+//     (1) hashgrid_bwd_aggregate: one workgroup per 256 consecutive samples
+//         (= one PSF cloud); per level the 2048 corner contributions are
+//         summed by table entry in an LDS open-addressing hash table (lanes
+//         sharing the wave leader's cell are first summed across the wave),
+//         then the distinct (entry, grad) records are binned by table chunk
+//         and appended to that chunk's queue in HBM (one returning atomic per
+//         non-empty (workgroup, chunk) pair to reserve the span);
+//     (2) hashgrid_bwd_owner: one workgroup per table chunk accumulates its
+//         queue into LDS (ds_add_f32) and adds the chunk to grad_table with
+//         plain coalesced read-modify-writes - it is the only writer.
+//   Records that do not fit a queue fall back to global atomics, so the
+//   result is exact for any input distribution.  The legacy all-atomics
+//   kernel is kept as hashgrid_bwd (used for tiny N and as a cross-check).
 #include <hip/hip_runtime.h>
 #include "common.h"
 #include "../../include/nesvor_hip.h"
@@ -219,6 +230,259 @@ __global__ __launch_bounds__(256) void hashgrid_bwd(const nesvor_grid_t g, const
   }
 }
 
+// ------------------------------------------- backward, owner-computes version
+constexpr int kSlotsLog2 = 12;
+constexpr int kSlots = 1 << kSlotsLog2;       // LDS hash table: 256 samples x 8 corners <= 2048 distinct keys
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr int kMaxChunks = 256;               // table chunks (queues) per level
+constexpr int kOwnerLdsFloats = 16384;        // 64 KiB accumulator per owner workgroup
+
+struct BwdPlan {
+  uint32_t chunk_shift;                        // chunk = 2^chunk_shift entries = kOwnerLdsFloats / F
+  uint32_t n_buckets;
+  uint32_t n_chunks[NESVOR_MAX_LEVELS];
+  uint32_t bucket_base[NESVOR_MAX_LEVELS];     // first global bucket id of the level
+  uint32_t cap[NESVOR_MAX_LEVELS];             // queue capacity (records) of each bucket of the level
+  uint64_t rec_off[NESVOR_MAX_LEVELS];         // first record of the level's queues
+};
+
+template <int F>
+__device__ __forceinline__ void lds_insert(uint32_t* keys, float* vals, uint32_t key, const float (&v)[F]) {
+  uint32_t slot = (key * 2654435769u) >> (32 - kSlotsLog2);
+  while (true) {
+    const uint32_t prev = atomicCAS(&keys[slot], kEmpty, key);
+    if (prev == kEmpty || prev == key) break;
+    slot = (slot + 1) & (kSlots - 1);
+  }
+#pragma unroll
+  for (int f = 0; f < F; ++f) atomicAdd(&vals[slot * F + f], v[f]);
+}
+
+template <int F, int LAYOUT, bool INPUT_GRAD>
+__global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_t g, const BwdPlan plan,
+                                                              const float* __restrict__ u,
+                                                              const float* __restrict__ table,
+                                                              const float* __restrict__ dpe,
+                                                              float* __restrict__ grad_table,
+                                                              float* __restrict__ grad_u, uint32_t* __restrict__ tails,
+                                                              uint32_t* __restrict__ records, int64_t N) {
+  __shared__ uint32_t keys[kSlots];
+  __shared__ float vals[kSlots * F];
+  __shared__ uint32_t bcount[kMaxChunks];
+  __shared__ uint32_t bbase[kMaxChunks];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  const bool valid = i < N;
+  const int64_t ii = valid ? i : N - 1;
+  const float ux = u[3 * ii], uy = u[3 * ii + 1], uz = u[3 * ii + 2];
+  const int E = g.n_levels * F;
+  float gux = 0.f, guy = 0.f, guz = 0.f;
+  constexpr int kPerThread = kSlots / 256;
+
+  for (int level = 0; level < g.n_levels; ++level) {
+    const LevelParams p = load_level(g, level);
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+      keys[tid + j * 256] = kEmpty;
+#pragma unroll
+      for (int f = 0; f < F; ++f) vals[(tid + j * 256) * F + f] = 0.f;
+    }
+    if (tid < kMaxChunks) bcount[tid] = 0;
+    __syncthreads();
+
+    const CellPos c = locate(p, ux, uy, uz);
+    float dy[F];
+    if constexpr (LAYOUT == NESVOR_LAYOUT_ROW_MAJOR) {
+      const float* o = dpe + (size_t)ii * E + level * F;
+#pragma unroll
+      for (int f = 0; f < F; ++f) dy[f] = valid ? o[f] : 0.f;
+    } else {
+#pragma unroll
+      for (int f = 0; f < F; ++f) dy[f] = valid ? dpe[(size_t)(level * F + f) * N + ii] : 0.f;
+    }
+    uint32_t idx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) idx[k] = corner_index(p, c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + (k >> 2));
+
+    if constexpr (INPUT_GRAD) {
+      const float* tab = table + (size_t)p.offset * F;
+      float v[8][F];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) load_feat<F>(tab + (size_t)idx[k] * F, v[k]);
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float fd = 0.f;
+#pragma unroll
+        for (int f = 0; f < F; ++f) fd = fmaf(v[k][f], dy[f], fd);
+        const float wxk = (k & 1) ? c.wx : 1.f - c.wx, wyk = ((k >> 1) & 1) ? c.wy : 1.f - c.wy, wzk = (k >> 2) ? c.wz : 1.f - c.wz;
+        sx += ((k & 1) ? fd : -fd) * wyk * wzk;
+        sy += (((k >> 1) & 1) ? fd : -fd) * wxk * wzk;
+        sz += ((k >> 2) ? fd : -fd) * wxk * wyk;
+      }
+      gux = fmaf(p.scale, sx, gux); guy = fmaf(p.scale, sy, guy); guz = fmaf(p.scale, sz, guz);
+    }
+
+    float val[8][F];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float w = ((k & 1) ? c.wx : 1.f - c.wx) * (((k >> 1) & 1) ? c.wy : 1.f - c.wy) * ((k >> 2) ? c.wz : 1.f - c.wz);
+#pragma unroll
+      for (int f = 0; f < F; ++f) val[k][f] = w * dy[f];
+    }
+    // wave pre-merge: lanes sharing the leader's cell are summed across the wave, the leader inserts
+    bool pending = valid;
+    for (int round = 0; round < 4; ++round) {
+      const unsigned long long rem = __ballot(pending);
+      if (rem == 0) break;
+      const int leader = __ffsll((long long)rem) - 1;
+      const uint32_t lx = __shfl(c.gx, leader, 64), ly = __shfl(c.gy, leader, 64), lz = __shfl(c.gz, leader, 64);
+      const bool mine = pending && c.gx == lx && c.gy == ly && c.gz == lz;
+      if (__popcll(__ballot(mine)) < 8) break;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float sred[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) sred[f] = wave_sum(mine ? val[k][f] : 0.f);
+        if (lane == leader) lds_insert<F>(keys, vals, idx[k], sred);
+      }
+      pending = pending && !mine;
+    }
+    if (pending) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) lds_insert<F>(keys, vals, idx[k], val[k]);
+    }
+    __syncthreads();
+
+    // bin the distinct records by table chunk and append them to the chunk queues
+    uint32_t rank[kPerThread];
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+      const uint32_t key = keys[tid + j * 256];
+      rank[j] = (key != kEmpty) ? atomicAdd(&bcount[key >> plan.chunk_shift], 1u) : 0u;
+    }
+    __syncthreads();
+    const uint32_t nb = plan.n_chunks[level];
+    if (tid < nb) {
+      const uint32_t cnt = bcount[tid];
+      bbase[tid] = cnt ? atomicAdd(&tails[plan.bucket_base[level] + tid], cnt) : 0u;
+    }
+    __syncthreads();
+    const uint32_t cap = plan.cap[level];
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+      const int slot = tid + j * 256;
+      const uint32_t key = keys[slot];
+      if (key != kEmpty) {
+        const uint32_t b = key >> plan.chunk_shift;
+        const uint32_t pos = bbase[b] + rank[j];
+        if (pos < cap) {
+          uint32_t* r = records + (plan.rec_off[level] + (uint64_t)b * cap + pos) * (1 + F);
+          r[0] = key;
+#pragma unroll
+          for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(vals[slot * F + f]);
+        } else {  // queue full: exact fallback
+#pragma unroll
+          for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)p.offset + key) * F + f, vals[slot * F + f]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if constexpr (INPUT_GRAD) {
+    if (valid) { grad_u[3 * i] = gux; grad_u[3 * i + 1] = guy; grad_u[3 * i + 2] = guz; }
+  }
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void hashgrid_bwd_owner(const nesvor_grid_t g, const BwdPlan plan,
+                                                          uint32_t* __restrict__ tails,
+                                                          const uint32_t* __restrict__ records,
+                                                          float* __restrict__ grad_table) {
+  __shared__ float acc[kOwnerLdsFloats];
+  const int tid = threadIdx.x;
+  const uint32_t gb = blockIdx.x;
+  int level = 0;
+  while (level + 1 < g.n_levels && gb >= plan.bucket_base[level + 1]) ++level;
+  const uint32_t chunk = gb - plan.bucket_base[level];
+  uint32_t n = tails[gb];
+  if (n == 0) return;  // untouched chunk: nothing to add, tail already clean
+  if (n > plan.cap[level]) n = plan.cap[level];
+  for (int t = tid; t < kOwnerLdsFloats; t += 256) acc[t] = 0.f;
+  __syncthreads();
+  const uint32_t mask = (1u << plan.chunk_shift) - 1u;
+  const uint32_t* rec = records + (plan.rec_off[level] + (uint64_t)chunk * plan.cap[level]) * (1 + F);
+  for (uint32_t r = tid; r < n; r += 256) {
+    const uint32_t* q = rec + (size_t)r * (1 + F);
+    const uint32_t local = q[0] & mask;
+#pragma unroll
+    for (int f = 0; f < F; ++f) atomicAdd(&acc[local * F + f], __uint_as_float(q[1 + f]));
+  }
+  __syncthreads();
+  const uint32_t e0 = chunk << plan.chunk_shift;
+  const uint32_t ne = min((uint32_t)(1u << plan.chunk_shift), g.size[level] - e0);
+  float* out = grad_table + ((size_t)g.offset[level] + e0) * F;
+  for (uint32_t t = tid; t < ne * F; t += 256) {
+    const float a = acc[t];
+    if (a != 0.f) out[t] += a;  // this workgroup is the only writer of the chunk
+  }
+  if (tid == 0) tails[gb] = 0;  // leave the queue empty for the next call
+}
+
+// host: chunking / queue plan.  Returns false if the grid does not fit the plan's limits.
+inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t* n_records) {
+  const int F = g->n_features;
+  uint32_t shift = 0;
+  while ((1u << (shift + 1)) * (uint32_t)F <= (uint32_t)kOwnerLdsFloats) ++shift;
+  plan->chunk_shift = shift;
+  uint32_t nb = 0;
+  uint64_t off = 0;
+  for (int l = 0; l < g->n_levels; ++l) {
+    const uint32_t nc = (g->size[l] + (1u << shift) - 1) >> shift;
+    if (nc > (uint32_t)kMaxChunks) return false;
+    plan->n_chunks[l] = nc;
+    plan->bucket_base[l] = nb;
+    nb += nc;
+    const uint64_t per = (uint64_t)(8 * N) / nc;
+    uint64_t cap = per + per / 32 + 4096;
+    if (cap > 0x7FFFFFFFull) return false;
+    plan->cap[l] = (uint32_t)cap;
+    plan->rec_off[l] = off;
+    off += cap * nc;
+  }
+  for (int l = g->n_levels; l < NESVOR_MAX_LEVELS; ++l) {
+    plan->n_chunks[l] = 0; plan->bucket_base[l] = nb; plan->cap[l] = 0; plan->rec_off[l] = off;
+  }
+  plan->n_buckets = nb;
+  *n_records = off;
+  return true;
+}
+
+constexpr uint64_t kTailBytes = 16384;  // tails region at the start of the workspace
+
+template <int F, int LAYOUT>
+int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table, const float* dpe, float* gt,
+                     float* gu, int64_t N, void* workspace, hipStream_t st) {
+  BwdPlan plan;
+  uint64_t n_rec;
+  if (!make_plan(g, N, &plan, &n_rec)) return (int)hipErrorInvalidValue;
+  uint32_t* tails = reinterpret_cast<uint32_t*>(workspace);
+  uint32_t* records = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + kTailBytes);
+  hipError_t e = hipMemsetAsync(tails, 0, kTailBytes, st);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid((unsigned)((N + 255) / 256)), block(256);
+  if (gu != nullptr)
+    hipLaunchKernelGGL((hashgrid_bwd_aggregate<F, LAYOUT, true>), grid, block, 0, st, *g, plan, u, table, dpe, gt, gu,
+                       tails, records, N);
+  else
+    hipLaunchKernelGGL((hashgrid_bwd_aggregate<F, LAYOUT, false>), grid, block, 0, st, *g, plan, u, table, dpe, gt, gu,
+                       tails, records, N);
+  e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((hashgrid_bwd_owner<F>), dim3(plan.n_buckets), block, 0, st, *g, plan, tails, records, gt);
+  return (int)hipGetLastError();
+}
+
 template <int F, int LAYOUT>
 int launch_fwd(const nesvor_grid_t* g, const float* u, const float* table, float* pe, int64_t N, hipStream_t st) {
   dim3 grid((unsigned)((N + 255) / 256), g->n_levels), block(256);
@@ -266,10 +530,29 @@ extern "C" int nesvor_hashgrid_forward(const nesvor_grid_t* grid, const float* u
   DISPATCH_F_LAYOUT(launch_fwd, grid, u, table, pe, N, (hipStream_t)stream);
 }
 
-extern "C" int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* u, const float* table,
-                                        const float* dpe, float* grad_table, float* grad_u, int64_t N, int layout,
-                                        void* stream) {
+extern "C" int nesvor_hashgrid_backward_atomic(const nesvor_grid_t* grid, const float* u, const float* table,
+                                               const float* dpe, float* grad_table, float* grad_u, int64_t N,
+                                               int layout, void* stream) {
   if (N <= 0) return 0;
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
   DISPATCH_F_LAYOUT(launch_bwd, grid, u, table, dpe, grad_table, grad_u, N, (hipStream_t)stream);
+}
+
+extern "C" int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t* grid, int64_t N) {
+  if (N <= 0) return 0;
+  BwdPlan plan;
+  uint64_t n_rec;
+  if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return -1;
+  if (!make_plan(grid, N, &plan, &n_rec)) return -1;
+  if (plan.n_buckets * sizeof(uint32_t) > kTailBytes) return -1;
+  return (int64_t)(kTailBytes + n_rec * (1 + grid->n_features) * sizeof(uint32_t));
+}
+
+extern "C" int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* u, const float* table,
+                                        const float* dpe, float* grad_table, float* grad_u, int64_t N, int layout,
+                                        void* workspace, void* stream) {
+  if (N <= 0) return 0;
+  if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
+  if (workspace == nullptr) return (int)hipErrorInvalidValue;
+  DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, (hipStream_t)stream);
 }

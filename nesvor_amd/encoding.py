@@ -22,18 +22,46 @@ def hashgrid_forward(spec: HashGridSpec, u: torch.Tensor, table: torch.Tensor, l
     return pe
 
 
-def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True, layout=_lib.LAYOUT_ROW_MAJOR):
-    """Accumulates into grad_table (allocated zero-filled if None); returns (grad_table, grad_u|None)."""
+_WORKSPACES = {}
+
+
+def _workspace(spec, N, device):
+    """Scratch for the owner-computes backward (queues of (entry, grad) records), cached per (device, size)."""
+    nbytes = _lib.load().nesvor_hashgrid_backward_workspace_bytes(ctypes.byref(spec.c_struct), N)
+    if nbytes < 0:
+        return None
+    key = (device, nbytes)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        for k in [k for k in _WORKSPACES if k[0] == device]:
+            del _WORKSPACES[k]  # one live workspace per device
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True, layout=_lib.LAYOUT_ROW_MAJOR,
+                      method="owner"):
+    """Accumulates into grad_table (allocated zero-filled if None); returns (grad_table, grad_u|None).
+    method: "owner" (LDS aggregation + per-chunk owners, the MI355X path) or "atomic" (per-corner atomics)."""
     _lib.require_device(u, table, dpe, dtype=torch.float32, name="hashgrid backward input")
     N = u.shape[0]
     if grad_table is None:
         grad_table = torch.zeros_like(table)
     grad_u = torch.empty_like(u) if need_input_grad else None
+    lib = _lib.load()
+    ws = _workspace(spec, N, u.device) if method == "owner" else None
     with torch.cuda.device(u.device):
-        err = _lib.load().nesvor_hashgrid_backward(
-            ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(dpe), _lib.ptr(grad_table),
-            _lib.ptr(grad_u), N, layout, _lib.stream_ptr(),
-        )
+        if ws is not None:
+            err = lib.nesvor_hashgrid_backward(
+                ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(dpe), _lib.ptr(grad_table),
+                _lib.ptr(grad_u), N, layout, _lib.ptr(ws), _lib.stream_ptr(),
+            )
+        else:
+            err = lib.nesvor_hashgrid_backward_atomic(
+                ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(dpe), _lib.ptr(grad_table),
+                _lib.ptr(grad_u), N, layout, _lib.stream_ptr(),
+            )
     _lib.check(err, "hashgrid backward")
     return grad_table, grad_u
 

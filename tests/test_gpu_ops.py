@@ -1,0 +1,307 @@
+"""GPU (-m gpu): parity of every HIP op with the CPU oracle on the same seeded inputs,
+through the C ABI (ctypes).  Tolerances are stated per test; index/byte work is exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import scipy_table
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ transforms
+def test_axisangle2mat_mat2axisangle_scipy_table(device):
+    """The reference's own test (tests/transform/test_transform_convert.py:13-21), default fp32 tolerances."""
+    from nesvor_amd.transform import axisangle2mat, mat2axisangle
+
+    ax, mat = scipy_table()
+    for i in range(len(ax)):
+        torch.testing.assert_close(axisangle2mat(ax[i : i + 1].to(device)).cpu(), mat[i : i + 1])
+        torch.testing.assert_close(mat2axisangle(mat[i : i + 1].to(device)).cpu(), ax[i : i + 1])
+
+
+def test_compose_inv_reference_test_gpu(device):
+    """tests/transform/test_transform.py:7-23 with the reference's tolerance (atol 2e-5 rotation;
+    translations O(300) get 1e-4, one fp32 ulp there being 3e-5)."""
+    from nesvor_amd.transform import RigidTransform
+
+    ax, mat = scipy_table()
+    ax, mat = ax.to(device), mat.to(device)
+    n = len(ax)
+    for i in range(n):
+        a_ax, a_m, b_ax, b_m = ax[i : i + 1], mat[i : i + 1], ax[n - 1 - i : n - i], mat[n - 1 - i : n - i]
+        ab = RigidTransform(a_ax, trans_first=i % 2 == 0).compose(RigidTransform(b_m, trans_first=i % 2 == 1))
+        ba = RigidTransform(b_ax, trans_first=i % 2 == 1).inv().compose(RigidTransform(a_m, trans_first=i % 2 == 0).inv())
+        err = ab.compose(ba).axisangle().cpu()
+        torch.testing.assert_close(err[:, :3], torch.zeros(1, 3), atol=2e-5, rtol=1e-3)
+        torch.testing.assert_close(err[:, 3:], torch.zeros(1, 3), atol=1e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_transform_kernels_vs_oracle_fwd_bwd(device, dtype):
+    from nesvor_amd import transform_convert_cuda as K
+    from oracle import transform_convert as O
+
+    torch.manual_seed(0)
+    ax = torch.randn(4096, 6, dtype=dtype)
+    ax[:64, :3] *= 1e-4  # small-angle branch
+    ax[64:1024, :3] *= 2.5  # all quaternion branches
+    ax[1024] = 0
+    g = torch.randn(4096, 3, 4, dtype=dtype)
+    ga = torch.randn(4096, 6, dtype=dtype)
+    tol = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=1e-10, atol=1e-10)
+    m_ref = O.axisangle2mat_forward(ax)
+    m = K.axisangle2mat_forward(ax.to(device))[0]
+    torch.testing.assert_close(m.cpu(), m_ref, **tol)
+    torch.testing.assert_close(K.axisangle2mat_backward(g.to(device), ax.to(device))[0].cpu(),
+                               O.axisangle2mat_backward(g, ax), **tol)
+    _, masks = O._quat_branches(m_ref)
+    assert all(bool(b.any()) for b in masks)
+    # feed the ORACLE's matrices to both so branch selection sees identical inputs
+    torch.testing.assert_close(K.mat2axisangle_forward(m_ref.to(device))[0].cpu(), O.mat2axisangle_forward(m_ref),
+                               rtol=1e-4, atol=1e-4) if dtype == torch.float32 else None
+    a_k = K.mat2axisangle_forward(m_ref.to(device))[0].cpu()
+    a_o = O.mat2axisangle_forward(m_ref)
+    # near theta = pi the axis sign is ill-conditioned: compare through the rotation it represents
+    torch.testing.assert_close(O.axisangle2mat_forward(a_k), O.axisangle2mat_forward(a_o),
+                               rtol=1e-4, atol=1e-4 if dtype == torch.float32 else 1e-9)
+    gk = K.mat2axisangle_backward(m_ref.to(device), ga.to(device))[0].cpu()
+    go = O.mat2axisangle_backward(m_ref, ga)
+    # the backward divides by sin(theta/2): scale the tolerance by the conditioning of each row
+    scale = go.abs().amax((1, 2), keepdim=True).clamp(min=1.0)
+    assert float(((gk - go).abs() / scale).max()) < (5e-4 if dtype == torch.float32 else 1e-8)
+
+
+def test_transform_ops_reject_bad_input(device):
+    from nesvor_amd import transform_convert_cuda as K
+
+    with pytest.raises(RuntimeError):
+        K.axisangle2mat_forward(torch.zeros(3, 6))  # host tensor
+    with pytest.raises(RuntimeError):
+        K.axisangle2mat_forward(torch.zeros(6, 3, device=device).t())  # non-contiguous
+    assert K.axisangle2mat_forward(torch.zeros(0, 6, device=device))[0].shape == (0, 3, 4)  # empty input
+
+
+# ------------------------------------------------------------- slice acquisition
+def _acq(device, tf, vol, vm, sm, psf, shape, rs, need_w, interp):
+    from nesvor_amd import slice_acq_cuda as K
+
+    d = lambda t: None if t is None else t.to(device)
+    e = torch.empty(0, device=device)
+    out = K.forward(d(tf), d(vol), e if vm is None else d(vm), e if sm is None else d(sm), d(psf), shape, rs, need_w, interp)
+    return [o.cpu() for o in out]
+
+
+@pytest.mark.parametrize("interp_psf", [False, True])
+@pytest.mark.parametrize("masks", [False, True])
+def test_slice_acq_vs_oracle(device, interp_psf, masks):
+    from nesvor_amd.utils import get_PSF
+    from oracle import slice_acq as O
+    from oracle import transform_convert as tc
+
+    torch.manual_seed(0)
+    vol = torch.rand(1, 1, 20, 22, 24)
+    psf = get_PSF(res_ratio=(1.5, 1.5, 3.0))
+    ax = torch.randn(7, 6) * torch.tensor([0.6, 0.6, 0.6, 3.0, 3.0, 3.0])
+    ax[0] = 0
+    tf = tc.axisangle2mat_forward(ax)
+    vm = (torch.rand(1, 1, 20, 22, 24) > 0.2) if masks else None
+    sm = (torch.rand(7, 1, 18, 16) > 0.3) if masks else None
+    ref, wref = O.slice_acquisition_forward(tf, vol, vm, sm, psf, (18, 16), 1.5, True, interp_psf)
+    got, wgot = _acq(device, tf, vol, vm, sm, psf, (18, 16), 1.5, True, interp_psf)
+    # fp32: <=153 taps x 8 corners accumulated in the same order; floor() decisions can differ only
+    # where a coordinate lands within 1 ulp of a voxel boundary (continuous there for the linear mode)
+    tol = dict(rtol=1e-4, atol=1e-5) if not interp_psf else dict(rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(wgot, wref, **tol)
+    torch.testing.assert_close(got, ref, **tol)
+    if masks:
+        assert float(got[~sm].abs().max()) == 0.0  # masked-out pixels stay exactly zero
+
+
+def test_slice_acq_golden_stacks_and_properties(device, golden):
+    """The phantom stacks the reference's wrappers produced (tests/golden) + linearity / constant-volume."""
+    from nesvor_amd.utils import get_PSF
+
+    vs, res, res_s, s_thick, gap, n_slice, ss = golden["sim_geom"]
+    psf = get_PSF(res_ratio=(res_s / res, res_s / res, s_thick / res))
+    vol = torch.tensor(golden["sim_volume"])[None, None]
+    tf = torch.tensor(golden["sim_transforms"])
+    (got,) = _acq(device, tf, vol, None, None, psf, (int(ss), int(ss)), float(res_s / res), False, False)
+    np.testing.assert_allclose(got.numpy(), golden["sim_stacks"], rtol=1e-4, atol=1e-5)
+    v2 = torch.rand_like(vol)
+    f = lambda v: _acq(device, tf, v, None, None, psf, (int(ss), int(ss)), float(res_s / res), True, False)
+    (a, w), (b, _), (c, _) = f(vol), f(v2), f(2 * vol + 3 * v2)
+    torch.testing.assert_close(c, 2 * a + 3 * b, rtol=1e-4, atol=1e-5)
+    ones, w1 = f(torch.ones_like(vol))
+    torch.testing.assert_close(ones[w1 > 0], torch.ones_like(ones[w1 > 0]), rtol=1e-5, atol=1e-6)
+    # empty input
+    (e,) = _acq(device, tf[:0], vol, None, None, psf, (4, 4), 1.5, False, False)
+    assert e.shape == (0, 1, 4, 4)
+
+
+# --------------------------------------------------------------------- hash grid
+def _psf_cloud(n_pix, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    c = torch.rand(n_pix, 1, 3, generator=g) * 110 + 10
+    x = c + torch.randn(n_pix, S, 3, generator=g) * torch.tensor([0.77, 0.77, 1.27])
+    return (x.reshape(-1, 3) / 130.0).clamp(0, 1).contiguous()
+
+
+@pytest.mark.parametrize("method", ["owner", "atomic"])
+@pytest.mark.parametrize("F", [1, 2, 4, 8])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_hashgrid_fwd_bwd_vs_oracle(device, F, layout, method):
+    from nesvor_amd.encoding import hashgrid_backward, hashgrid_forward
+    from nesvor_amd.grid import HashGridSpec
+    from oracle import hashgrid as O
+
+    spec = HashGridSpec(8, F, 10, 5, 1.5)  # dense and hashed levels, tables small enough to collide a lot
+    lv = O.make_levels(8, 10, 5, 1.5)
+    assert any(l.hashed for l in lv) and not all(l.hashed for l in lv)
+    torch.manual_seed(F * 10 + layout)
+    N = 3000  # ragged: not a multiple of the 256-thread block
+    u = torch.cat([torch.rand(N - 512, 3), _psf_cloud(2, 256, 1)])
+    u[0] = 0.0
+    u[1] = 1.0  # the u == 1 face wraps the dense index (tcnn semantics)
+    table = torch.randn(spec.n_params)
+    dy = torch.randn(N, spec.n_output_dims)
+    ref = O.encode(u, table, lv, F)
+    gt_ref, gu_ref = O.encode_backward(u, table, lv, F, dy)
+    pe = hashgrid_forward(spec, u.to(device), table.to(device), layout).cpu()
+    pe = pe if layout == 0 else pe.t()
+    # fp32, 8-term interpolation: same pos (fma) and indices; only summation order differs
+    torch.testing.assert_close(pe, ref, rtol=1e-5, atol=1e-5)
+    dyk = (dy if layout == 0 else dy.t().contiguous()).to(device)
+    gt, gu = hashgrid_backward(spec, u.to(device), table.to(device), dyk, None, True, layout, method)
+    # atomics: order-nondeterministic fp32 sums of up to ~N/8 terms
+    torch.testing.assert_close(gt.cpu(), gt_ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gu.cpu(), gu_ref, rtol=1e-4, atol=2e-3)
+    # accumulate semantics + no input grad
+    gt2, none = hashgrid_backward(spec, u.to(device), table.to(device), dyk, gt.clone(), False, layout, method)
+    assert none is None
+    torch.testing.assert_close(gt2.cpu(), 2 * gt_ref, rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("method", ["owner", "atomic"])
+def test_hashgrid_headline_config_vs_oracle(device, method):
+    """L=16, F=2, T=2^19, base 9, scale 1.26 on both mandated distributions, oracle-sized N."""
+    from nesvor_amd.encoding import hashgrid_backward, hashgrid_forward
+    from nesvor_amd.grid import HashGridSpec
+    from oracle import hashgrid as O
+
+    spec = HashGridSpec(16, 2, 19, 9, 1.26)
+    lv = O.make_levels(16, 19, 9, 1.26)
+    g = torch.Generator().manual_seed(1337)
+    table = (torch.rand(spec.n_params, generator=g) * 2 - 1) * 1e-4
+    for name, u in (("U", torch.rand(8192, 3, generator=torch.Generator().manual_seed(0))), ("P", _psf_cloud(32, 256, 0))):
+        dy = torch.randn(u.shape[0], 32, generator=torch.Generator().manual_seed(1))
+        ref = O.encode(u, table, lv, 2)
+        pe = hashgrid_forward(spec, u.to(device), table.to(device), 0).cpu()
+        torch.testing.assert_close(pe, ref, rtol=1e-5, atol=1e-9, msg=name)
+        gt_ref, gu_ref = O.encode_backward(u, table, lv, 2, dy)
+        gt, gu = hashgrid_backward(spec, u.to(device), table.to(device), dy.to(device), None, True, 0, method)
+        torch.testing.assert_close(gt.cpu(), gt_ref, rtol=1e-4, atol=1e-4, msg=name)
+        torch.testing.assert_close(gu.cpu(), gu_ref, rtol=1e-3, atol=1e-5, msg=name)
+
+
+def test_hashgrid_full_size_properties(device):
+    """N = 2^20 (BASELINE size): size-independent invariants instead of the oracle.
+    * constant table -> every feature equals the constant (corner weights sum to 1), zero input grad
+    * dy = 1 -> grad_table sums to N per level-feature (checksum of the scatter), linear in dy."""
+    from nesvor_amd.encoding import hashgrid_backward, hashgrid_forward
+    from nesvor_amd.grid import HashGridSpec
+
+    spec = HashGridSpec(16, 2, 19, 9, 1.26)
+    N = 1 << 20
+    u = _psf_cloud(4096, 256, 3).to(device)
+    table = torch.full((spec.n_params,), 0.75, device=device)
+    pe = hashgrid_forward(spec, u, table, 1)
+    torch.testing.assert_close(pe, torch.full_like(pe, 0.75), rtol=1e-6, atol=1e-6)
+    dy = torch.ones(32, N, device=device)
+    gt, gu = hashgrid_backward(spec, u, table, dy, None, True, 1)
+    assert float(gu.abs().max()) < 1e-3
+    for li, lv in enumerate(spec.levels):
+        seg = gt[lv.offset * 2 : (lv.offset + lv.size) * 2].view(-1, 2).double().sum(0)
+        assert abs(float(seg[0]) - N) < N * 1e-4 and abs(float(seg[1]) - N) < N * 1e-4, li
+    table = torch.randn(spec.n_params, device=device) * 0.1
+    dy1, dy2 = torch.randn(32, N, device=device), torch.randn(32, N, device=device)
+    g1, _ = hashgrid_backward(spec, u, table, dy1, None, False, 1)
+    g2, _ = hashgrid_backward(spec, u, table, dy2, None, False, 1)
+    g3, _ = hashgrid_backward(spec, u, table, 2 * dy1 - dy2, None, False, 1)
+    err = (g3 - (2 * g1 - g2)).abs().max() / g3.abs().max()
+    assert float(err) < 1e-4
+    # <pe, dy> == <table, grad_table> (adjointness of the linear map table -> pe)
+    pe = hashgrid_forward(spec, u, table, 1)
+    lhs = (pe.double() * dy1.double()).sum()
+    rhs = (table.double() * g1.double()).sum()
+    assert abs(float(lhs - rhs)) < 1e-4 * abs(float(lhs)) + 1e-3
+
+
+def test_hashgrid_owner_equals_atomic_full_size_uniform(device):
+    """Uniform points defeat the per-cloud aggregation and fill the chunk queues to (and past) their
+    capacity: the queue-overflow fallback must keep the result exact."""
+    from nesvor_amd.encoding import hashgrid_backward
+    from nesvor_amd.grid import HashGridSpec
+
+    spec = HashGridSpec(16, 2, 19, 9, 1.26)
+    N = (1 << 20) - 77  # ragged
+    g = torch.Generator().manual_seed(0)
+    u = torch.rand(N, 3, generator=g).to(device)
+    table = (torch.randn(spec.n_params, generator=g) * 0.1).to(device)
+    dy = torch.randn(N, 32, generator=g).to(device)
+    g_own, gu_own = hashgrid_backward(spec, u, table, dy, None, True, 0, "owner")
+    g_atm, gu_atm = hashgrid_backward(spec, u, table, dy, None, True, 0, "atomic")
+    scale = float(g_atm.abs().max())
+    assert float((g_own - g_atm).abs().max()) < 2e-4 * scale
+    torch.testing.assert_close(gu_own, gu_atm, rtol=1e-3, atol=1e-3)
+
+
+def test_hashgrid_autograd_module(device):
+    import nesvor_amd.tinycudann as tcnn
+    from oracle import hashgrid as O
+
+    cfg = {"otype": "HashGrid", "n_levels": 6, "n_features_per_level": 2, "log2_hashmap_size": 9,
+           "base_resolution": 4, "per_level_scale": 1.6}
+    enc = tcnn.Encoding(3, cfg, dtype=torch.float32).to(device)
+    assert enc.params.dtype == torch.float32 and float(enc.params.abs().max()) <= 1e-4
+    with torch.no_grad():
+        enc.params.mul_(1e4)
+    x = torch.rand(500, 3, device=device, requires_grad=True)
+    y = enc(x)
+    assert y.shape == (500, 12)
+    w = torch.randn(500, 12, device=device)
+    (y * w).sum().backward()
+    lv = O.make_levels(6, 9, 4, 1.6)
+    gt, gu = O.encode_backward(x.detach().cpu(), enc.params.detach().cpu(), lv, 2, w.cpu())
+    torch.testing.assert_close(enc.params.grad.cpu(), gt, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(x.grad.cpu(), gu, rtol=1e-4, atol=1e-3)
+
+
+# ------------------------------------------------------------------------ AdamW
+def test_fused_adamw_vs_torch(device):
+    from nesvor_amd import _lib
+
+    torch.manual_seed(0)
+    n = 100003  # odd length exercises the scalar tail
+    p0 = torch.randn(n, device=device)
+    p_ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p_ref], lr=5e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay=1e-2)
+    p, m, v = p0.clone(), torch.zeros(n, device=device), torch.zeros(n, device=device)
+    lr = 5e-3
+    for t in range(1, 6):
+        g = torch.randn(n, device=device) * (10.0 ** torch.randint(-6, 2, (n,), device=device).float())
+        if t == 2:
+            g[::2] = 0  # untouched table entries: weight decay still applies (train.py:144-152)
+        p_ref.grad = g.clone()
+        opt.step()
+        gbuf = g.clone()
+        err = _lib.load().nesvor_adamw_step(_lib.ptr(p), _lib.ptr(gbuf), _lib.ptr(m), _lib.ptr(v), n, lr, 0.9, 0.99,
+                                            1e-15, 1e-2, 1 - 0.9**t, 1 - 0.99**t, 1.0, 1, _lib.stream_ptr())
+        assert err == 0
+        assert float(gbuf.abs().max()) == 0.0  # fused zero_grad
+        if t == 3:
+            lr *= 0.33
+            opt.param_groups[0]["lr"] = lr
+        torch.testing.assert_close(p, p_ref.data, rtol=1e-5, atol=1e-6)
