@@ -17,3 +17,31 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
   return v;
 }
+
+// Full-wave sum on the VALU only (DPP butterflies inside each 16-lane row, then 4 readlanes):
+// no LDS crossbar traffic, unlike __shfl_xor which lowers to ds_bpermute.  Result is wave-uniform.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  const int iv = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+// fp32 add into LDS through an integer compare-and-swap loop.  On gfx950 ds_add_f32 retires ~1 lane
+// per 3 cycles (192+ cycles per wave-instruction, measured, independent of conflicts) while
+// ds_cmpst_rtn_b32 runs at ~7 cycles per conflict-free wave-instruction, so the CAS loop wins
+// whenever few lanes of an instruction collide.
+__device__ __forceinline__ void lds_add_f32_cas(float* addr, float v) {
+  unsigned int* a = reinterpret_cast<unsigned int*>(addr);
+  unsigned int old = *reinterpret_cast<volatile unsigned int*>(a), assumed;
+  do {
+    assumed = old;
+    old = atomicCAS(a, assumed, __float_as_uint(__uint_as_float(assumed) + v));
+  } while (old != assumed);
+}

@@ -246,7 +246,7 @@ struct BwdPlan {
   uint64_t rec_off[NESVOR_MAX_LEVELS];         // first record of the level's queues
 };
 
-template <int F>
+template <int F, bool CAS_ADD = true>
 __device__ __forceinline__ void lds_insert(uint32_t* keys, float* vals, uint32_t key, const float (&v)[F]) {
   uint32_t slot = (key * 2654435769u) >> (32 - kSlotsLog2);
   while (true) {
@@ -255,10 +255,13 @@ __device__ __forceinline__ void lds_insert(uint32_t* keys, float* vals, uint32_t
     slot = (slot + 1) & (kSlots - 1);
   }
 #pragma unroll
-  for (int f = 0; f < F; ++f) atomicAdd(&vals[slot * F + f], v[f]);
+  for (int f = 0; f < F; ++f) {
+    if (CAS_ADD) lds_add_f32_cas(&vals[slot * F + f], v[f]);
+    else atomicAdd(&vals[slot * F + f], v[f]);
+  }
 }
 
-template <int F, int LAYOUT, bool INPUT_GRAD>
+template <int F, int LAYOUT, bool INPUT_GRAD, int VAR = 0>
 __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_t g, const BwdPlan plan,
                                                               const float* __restrict__ u,
                                                               const float* __restrict__ table,
@@ -330,29 +333,50 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
 #pragma unroll
       for (int f = 0; f < F; ++f) val[k][f] = w * dy[f];
     }
-    // wave pre-merge: lanes sharing the leader's cell are summed across the wave, the leader inserts
+    // wave pre-merge: lanes sharing the leader's cell are summed across the wave (DPP), the leader inserts.
+    // The size of the last leader group seen also picks the LDS add flavour for the remaining lanes:
+    // crowded cells -> ds_add_f32 (serial but conflict-insensitive), sparse cells -> CAS loop (fast when
+    // conflict-free).  Measured on gfx950: ds_add_f32 192-255 cycles / wave-instr at any conflict degree,
+    // ds_cmpst_rtn_b32 ~7 cycles conflict-free, ~60 at 8-way.
     bool pending = valid;
-    for (int round = 0; round < 4; ++round) {
+    int last_group = 0;
+    for (int round = 0; round < ((VAR & 1) ? 0 : 4); ++round) {
       const unsigned long long rem = __ballot(pending);
       if (rem == 0) break;
       const int leader = __ffsll((long long)rem) - 1;
       const uint32_t lx = __shfl(c.gx, leader, 64), ly = __shfl(c.gy, leader, 64), lz = __shfl(c.gz, leader, 64);
       const bool mine = pending && c.gx == lx && c.gy == ly && c.gz == lz;
-      if (__popcll(__ballot(mine)) < 8) break;
+      last_group = __popcll(__ballot(mine));
+      if (last_group < 8) break;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         float sred[F];
 #pragma unroll
-        for (int f = 0; f < F; ++f) sred[f] = wave_sum(mine ? val[k][f] : 0.f);
-        if (lane == leader) lds_insert<F>(keys, vals, idx[k], sred);
+        for (int f = 0; f < F; ++f) sred[f] = (VAR & 16) ? wave_sum(mine ? val[k][f] : 0.f) : wave_sum_dpp(mine ? val[k][f] : 0.f);
+        if (lane == leader) lds_insert<F, false>(keys, vals, idx[k], sred);
       }
       pending = pending && !mine;
     }
-    if (pending) {
+    if (!(VAR & 2)) {
+      const bool sparse = (VAR & 8) ? false : ((VAR & 32) ? true : last_group <= 2);
+      if (sparse) {
+        if (pending) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) lds_insert<F>(keys, vals, idx[k], val[k]);
+          for (int k = 0; k < 8; ++k) lds_insert<F, true>(keys, vals, idx[k], val[k]);
+        }
+      } else {
+        if (pending) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) lds_insert<F, false>(keys, vals, idx[k], val[k]);
+        }
+      }
+    }
+    if (VAR & 2) {  // ablation: keep the values live without touching LDS
+#pragma unroll
+      for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(val[k][0]), "v"(idx[k]));
     }
     __syncthreads();
+    if (VAR & 4) continue;  // ablation: no binning / record writes
 
     // bin the distinct records by table chunk and append them to the chunk queues
     uint32_t rank[kPerThread];
@@ -394,29 +418,46 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
   }
 }
 
-template <int F>
+constexpr uint32_t kOwnerSlice = 32768;  // records per owner workgroup
+
+// grid.x = sum over buckets of ceil(cap / kOwnerSlice) slices; a slice past the queue tail exits at once.
+template <int F, bool CAS_ADD = true>
 __global__ __launch_bounds__(256) void hashgrid_bwd_owner(const nesvor_grid_t g, const BwdPlan plan,
-                                                          uint32_t* __restrict__ tails,
+                                                          const uint32_t* __restrict__ tails,
                                                           const uint32_t* __restrict__ records,
                                                           float* __restrict__ grad_table) {
   __shared__ float acc[kOwnerLdsFloats];
   const int tid = threadIdx.x;
-  const uint32_t gb = blockIdx.x;
+  // decode (level, chunk, slice) from the flat workgroup id
+  uint32_t wg = blockIdx.x;
   int level = 0;
-  while (level + 1 < g.n_levels && gb >= plan.bucket_base[level + 1]) ++level;
-  const uint32_t chunk = gb - plan.bucket_base[level];
+  uint32_t spl = 0;
+  for (;; ++level) {
+    spl = (plan.cap[level] + kOwnerSlice - 1) / kOwnerSlice;
+    const uint32_t cnt = plan.n_chunks[level] * spl;
+    if (wg < cnt || level + 1 >= g.n_levels) break;
+    wg -= cnt;
+  }
+  const uint32_t chunk = wg / spl, slice = wg % spl;
+  const uint32_t gb = plan.bucket_base[level] + chunk;
   uint32_t n = tails[gb];
-  if (n == 0) return;  // untouched chunk: nothing to add, tail already clean
   if (n > plan.cap[level]) n = plan.cap[level];
+  const uint32_t r0 = slice * kOwnerSlice;
+  if (r0 >= n) return;
+  const uint32_t r1 = min(n, r0 + kOwnerSlice);
+  const bool sole_writer = n <= kOwnerSlice;
   for (int t = tid; t < kOwnerLdsFloats; t += 256) acc[t] = 0.f;
   __syncthreads();
   const uint32_t mask = (1u << plan.chunk_shift) - 1u;
   const uint32_t* rec = records + (plan.rec_off[level] + (uint64_t)chunk * plan.cap[level]) * (1 + F);
-  for (uint32_t r = tid; r < n; r += 256) {
+  for (uint32_t r = r0 + tid; r < r1; r += 256) {
     const uint32_t* q = rec + (size_t)r * (1 + F);
     const uint32_t local = q[0] & mask;
 #pragma unroll
-    for (int f = 0; f < F; ++f) atomicAdd(&acc[local * F + f], __uint_as_float(q[1 + f]));
+    for (int f = 0; f < F; ++f) {
+      if (CAS_ADD) lds_add_f32_cas(&acc[local * F + f], __uint_as_float(q[1 + f]));
+      else atomicAdd(&acc[local * F + f], __uint_as_float(q[1 + f]));
+    }
   }
   __syncthreads();
   const uint32_t e0 = chunk << plan.chunk_shift;
@@ -424,9 +465,17 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_owner(const nesvor_grid_t g,
   float* out = grad_table + ((size_t)g.offset[level] + e0) * F;
   for (uint32_t t = tid; t < ne * F; t += 256) {
     const float a = acc[t];
-    if (a != 0.f) out[t] += a;  // this workgroup is the only writer of the chunk
+    if (a != 0.f) {
+      if (sole_writer) out[t] += a;  // only writer of the chunk: plain read-modify-write
+      else atomicAdd(out + t, a);    // long queue shared by several slices (rare: coarse level, un-clustered input)
+    }
   }
-  if (tid == 0) tails[gb] = 0;  // leave the queue empty for the next call
+}
+
+inline uint32_t owner_grid(const nesvor_grid_t* g, const BwdPlan& plan) {
+  uint32_t n = 0;
+  for (int l = 0; l < g->n_levels; ++l) n += plan.n_chunks[l] * ((plan.cap[l] + kOwnerSlice - 1) / kOwnerSlice);
+  return n;
 }
 
 // host: chunking / queue plan.  Returns false if the grid does not fit the plan's limits.
@@ -479,7 +528,7 @@ int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table,
                        tails, records, N);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((hashgrid_bwd_owner<F>), dim3(plan.n_buckets), block, 0, st, *g, plan, tails, records, gt);
+  hipLaunchKernelGGL((hashgrid_bwd_owner<F>), dim3(owner_grid(g, plan)), block, 0, st, *g, plan, tails, records, gt);
   return (int)hipGetLastError();
 }
 
@@ -536,6 +585,34 @@ extern "C" int nesvor_hashgrid_backward_atomic(const nesvor_grid_t* grid, const 
   if (N <= 0) return 0;
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
   DISPATCH_F_LAYOUT(launch_bwd, grid, u, table, dpe, grad_table, grad_u, N, (hipStream_t)stream);
+}
+
+// Debug/ablation entry (not part of the public ABI): F=2, feature-major, no input grad.
+extern "C" int nesvor_hashgrid_backward_debug(const nesvor_grid_t* g, const float* u, const float* table,
+                                              const float* dpe, float* gt, int64_t N, void* workspace, int variant,
+                                              int run_owner, void* stream) {
+  BwdPlan plan;
+  uint64_t n_rec;
+  if (!make_plan(g, N, &plan, &n_rec)) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t* tails = reinterpret_cast<uint32_t*>(workspace);
+  uint32_t* records = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + kTailBytes);
+  (void)hipMemsetAsync(tails, 0, kTailBytes, st);
+  dim3 grid((unsigned)((N + 255) / 256)), block(256);
+#define LAUNCH_VAR(V)                                                                                          \
+  case V:                                                                                                      \
+    hipLaunchKernelGGL((hashgrid_bwd_aggregate<2, 1, false, V>), grid, block, 0, st, *g, plan, u, table, dpe, gt, \
+                       (float*)nullptr, tails, records, N);                                                    \
+    break;
+  switch (variant) {
+    LAUNCH_VAR(0) LAUNCH_VAR(1) LAUNCH_VAR(2) LAUNCH_VAR(3) LAUNCH_VAR(4) LAUNCH_VAR(6) LAUNCH_VAR(7)
+    LAUNCH_VAR(8) LAUNCH_VAR(16) LAUNCH_VAR(24) LAUNCH_VAR(9) LAUNCH_VAR(32)
+    default: return (int)hipErrorInvalidValue;
+  }
+#undef LAUNCH_VAR
+  if (run_owner == 1) hipLaunchKernelGGL((hashgrid_bwd_owner<2, true>), dim3(owner_grid(g, plan)), block, 0, st, *g, plan, tails, records, gt);
+  if (run_owner == 2) hipLaunchKernelGGL((hashgrid_bwd_owner<2, false>), dim3(owner_grid(g, plan)), block, 0, st, *g, plan, tails, records, gt);
+  return (int)hipGetLastError();
 }
 
 extern "C" int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t* grid, int64_t N) {

@@ -72,9 +72,10 @@ def slice_acquisition_forward(
                 pv = psff[i_p]
                 if float(pv) == 0.0:
                     continue
-                x = xc + rot(0, ix_p, iy_p, iz_p)
-                y = yc + rot(1, ix_p, iy_p, iz_p)
-                z = zc + rot(2, ix_p, iy_p, iz_p)
+                # left-to-right like the reference: ((centre + r1 ix) + r2 iy) + r3 iz   (.cu:66-68)
+                x = xc + R[:, 0, 0, None, None] * ix_p + R[:, 0, 1, None, None] * iy_p + R[:, 0, 2, None, None] * iz_p
+                y = yc + R[:, 1, 0, None, None] * ix_p + R[:, 1, 1, None, None] * iy_p + R[:, 1, 2, None, None] * iz_p
+                z = zc + R[:, 2, 0, None, None] * ix_p + R[:, 2, 1, None, None] * iy_p + R[:, 2, 2, None, None] * iz_p
                 ok = active & (x >= 0) & (y >= 0) & (z >= 0) & (x < W - 1) & (y < H - 1) & (z < D - 1)
                 if not bool(ok.any()):
                     continue
