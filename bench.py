@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""bench.py — NeSVoR INR training iterations/s on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training iteration of the hot path (train.py:179-198): batch fetch, PSF
+sampling + rigid transform, hash-grid encode, MLPs, imaging model + losses, backward, (grad
+all-reduce), AdamW — on a batch of 4096 slice pixels x 256 PSF samples = 2^20 sample points per
+GPU, L=16 (level_scale 1.26), T=2^19, F=2, 64-wide MLPs with 2 hidden layers, fp32, poses
+optimised.  Data: 3 stacks simulated from the 128^3 Shepp-Logan phantom with the slice-acquisition
+kernel (synthetic; no dataset on the box), resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     — the dominant native kernel timed with HIP events inside the timed region
+  cpu_baseline — the CPU oracle (a port of the same loop) on a bounded sample, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+
+def make_args(device, batch_size, n_samples, depth, n_iter):
+    from argparse import Namespace
+
+    a = Namespace(
+        n_features_per_level=2, log2_hashmap_size=19, level_scale=1.26, coarsest_resolution=16.0,
+        finest_resolution=0.5, n_levels_bias=0, depth=depth, width=64, n_features_z=15, n_features_slice=16,
+        no_transformation_optimization=False, no_slice_scale=False, no_pixel_variance=False,
+        no_slice_variance=False, single_precision=True, weight_transformation=0.1, weight_bias=100.0,
+        image_regularization="edge", weight_image=2.0, delta=0.2, learning_rate=5e-3, gamma=0.33,
+        milestones=[0.5, 0.75, 0.9], n_iter=n_iter, batch_size=batch_size, n_samples=n_samples,
+        output_resolution=0.8, output_intensity_mean=700.0, mask_threshold=1.0, no_output_psf=False,
+        debug=False, device=device, dtype=torch.float32,
+    )
+    a.inference_batch_size = 8 * a.batch_size
+    a.n_inference_samples = 2 * a.n_samples
+    return a
+
+
+def cpu_baseline(ds, args, seconds_budget=25.0):
+    """The CPU oracle (kind "port") on a bounded sample of the same workload: same model/config,
+    batch 256 pixels x 256 samples (2^16 points/iter), a few iterations on the host cores."""
+    from argparse import Namespace
+
+    from oracle import train_loop as otl
+
+    cargs = Namespace(**{**vars(args), "device": torch.device("cpu"), "batch_size": 256})
+    cds = otl.ArrayDataset(ds.xyz.cpu(), ds.v.cpu(), ds.slice_idx.cpu(), ds.transformation.matrix().cpu(), ds.resolution.cpu())
+    torch.manual_seed(0)
+    t0 = time.time()
+    iters = []
+
+    def log(i, _):
+        iters.append(time.time())
+
+    n_iter = 1
+    otl.train(cds, cargs, n_iter=1, log=log)  # warm-up / first-touch
+    per = max(time.time() - t0, 1e-3)
+    n_iter = int(max(2, min(20, seconds_budget / per)))
+    iters.clear()
+    cds = otl.ArrayDataset(ds.xyz.cpu(), ds.v.cpu(), ds.slice_idx.cpu(), ds.transformation.matrix().cpu(), ds.resolution.cpu())
+    t1 = time.time()
+    otl.train(cds, cargs, n_iter=n_iter, log=log)
+    dt = time.time() - t1
+    pts_per_s = n_iter * cargs.batch_size * cargs.n_samples / dt
+    return {
+        "value": pts_per_s / float(1 << 20),
+        "unit": "iters/s (2^20-sample iterations)",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{n_iter} iterations of the CPU oracle train loop at batch 256 px x 256 samples (2^16 points/iter), "
+                  f"same model/config, {dt:.1f} s wall; rate scaled to 2^20-point iterations",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-size", type=int, default=4096, help="slice pixels per GPU per iteration")
+    ap.add_argument("--n-samples", type=int, default=256)
+    ap.add_argument("--depth", type=int, default=2)
+    ap.add_argument("--stacks", type=int, default=3)
+    ap.add_argument("--phantom", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    opt = ap.parse_args()
+
+    import __graft_entry__ as ge
+
+    from nesvor_amd import _lib, ddp
+
+    rank, local_rank, world = ddp.init_distributed()
+    if world != opt.gpus:
+        raise SystemExit(f"--gpus {opt.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the native ops have no CPU path)")
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        torch.distributed.barrier()
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from nesvor_amd.fused import FusedTrainer
+    from nesvor_amd.models import NeSVoR
+    from nesvor_amd.phantom import phantom3d, simulate_stacks
+    from nesvor_amd.train import Dataset
+
+    # ---- synthetic data, resident in HBM -------------------------------------------------
+    torch.manual_seed(0)
+    vol = torch.tensor(phantom3d(n=opt.phantom), dtype=torch.float32, device=device)
+    slices, _ = simulate_stacks(vol, n_stacks=opt.stacks)
+    args = make_args(device, opt.batch_size, opt.n_samples, opt.depth, n_iter=6000)
+    ds = Dataset(slices, args)
+    model = NeSVoR(ds.transformation, ds.resolution, ds.mean, ds.bounding_box, args)
+    L = model.inr.n_levels
+    trainer = FusedTrainer(model, args, world_size=world)
+    if world > 1:
+        ddp.broadcast_params_(trainer.flat.param)
+        trainer.reduce_hook = ddp.make_reduce_hook()
+    torch.manual_seed(1234 + rank)  # per-rank PSF noise stream; the permutation below is rank-independent
+    perm_gen = torch.Generator(device=device).manual_seed(0)
+
+    global_b = opt.batch_size * world  # weak scaling: per-GPU work fixed
+    M = ds.v.shape[0]
+    state = {"count": M, "perm": None}
+
+    def next_batch():
+        if state["count"] + global_b > M:
+            state["perm"] = torch.randperm(M, device=device, generator=perm_gen)
+            state["count"] = 0
+        lo = state["count"] + rank * opt.batch_size
+        idx = state["perm"][lo : lo + opt.batch_size]
+        state["count"] += global_b
+        return ds.xyz[idx], ds.v[idx], ds.slice_idx[idx]
+
+    def step():
+        xyz, v, sidx = next_batch()
+        return trainer.step(xyz, v, sidx)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(opt.warmup):
+        step()
+    _lib.kernel_timer.reset(enabled=not opt.no_kernel_timing)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(opt.steps):
+        losses = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    ktimes = _lib.kernel_timer.summary() if not opt.no_kernel_timing else {}
+    _lib.kernel_timer.reset(enabled=False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = {k: float(val.detach()) for k, val in losses.items()}
+
+    if rank == 0:
+        n_points = opt.batch_size * opt.n_samples  # per GPU per step
+        iters_per_s = opt.steps * (n_points * world / float(1 << 20)) / elapsed
+        F = args.n_features_per_level
+        # algorithmic bytes per sample point: fwd 12+64L+8L ; bwd(params) 12+8L+64L ; bwd(input) 64L+12
+        bytes_pt = {
+            "hashgrid_fwd": 12 + 32 * F * L + 4 * F * L,
+            "hashgrid_bwd_aggregate": (12 + 4 * F * L + 32 * F * L) + (32 * F * L + 12),
+        }
+        roof = None
+        if ktimes:
+            dom = max((k for k in ktimes if k in bytes_pt), key=lambda k: ktimes[k][1])
+            ms = ktimes[dom][1]
+            achieved = bytes_pt[dom] * n_points / (ms * 1e-3) / 1e9
+            roof = {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                "frac": achieved / 8000.0, "traffic": None, "launch_ms": ms,
+                "algorithmic_bytes_per_launch": bytes_pt[dom] * n_points,
+                "other_kernels_ms": {k: round(v[1], 4) for k, v in ktimes.items() if k != dom},
+            }
+        out = {
+            "metric": "INR train iters/sec (2^20 samples, L=16 hash, 64-wide MLP)",
+            "value": iters_per_s,
+            "unit": "iters/s (2^20-sample iterations, whole job)",
+            "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
+            "ms_per_step": elapsed / opt.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"phantom3d({opt.phantom}) {opt.stacks}-stack, L={L} T=2^19 F=2 hash + {opt.depth}x64 MLPs, "
+                            f"{opt.batch_size} px x {opt.n_samples} samples = 2^{(n_points).bit_length() - 1} points/iter/GPU, "
+                            f"fp32, poses optimised, edge regulariser",
+                "global_batch_pixels": global_b, "n_levels": L, "parallelism": f"dp{world}",
+                "masked_pixels": int(M), "n_slices": len(slices),
+            },
+            "roofline": roof,
+            "final_losses": final_loss,
+        }
+        if world == 1 and not opt.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ds, args)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,10 +85,13 @@ int nesvor_hashgrid_forward(const nesvor_grid_t* grid, const float* u, const flo
  * Owner-computes scatter (LDS aggregation per 256 samples -> per-chunk queues ->
  * one owner workgroup per table chunk); `workspace` is scratch device memory of
  * nesvor_hashgrid_backward_workspace_bytes(grid, N) bytes (-1: grid outside the
- * plan's limits, use the _atomic variant). */
+ * plan's limits, use the _atomic variant).  `stages`: 3 = whole backward;
+ * 1 = aggregation launch only, 2 = owner launch only (so a caller can bracket
+ * each launch with its own events; 1 then 2 on one stream == 3). */
 int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t* grid, int64_t N);
 int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* u, const float* table, const float* dpe,
-                             float* grad_table, float* grad_u, int64_t N, int layout, void* workspace, void* stream);
+                             float* grad_table, float* grad_u, int64_t N, int layout, void* workspace, int stages,
+                             void* stream);
 /* Same contract, tcnn-style per-corner global atomics (slow on MI355X: memory-side atomics). */
 int nesvor_hashgrid_backward_atomic(const nesvor_grid_t* grid, const float* u, const float* table, const float* dpe,
                                     float* grad_table, float* grad_u, int64_t N, int layout, void* stream);

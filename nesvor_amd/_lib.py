@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -52,7 +52,7 @@ _SIGNATURES = {
     ),
     "nesvor_hashgrid_forward": ([POINTER(GridT), _P, _P, _P, c_int64, c_int, _P], c_int),
     "nesvor_hashgrid_backward_workspace_bytes": ([POINTER(GridT), c_int64], c_int64),
-    "nesvor_hashgrid_backward": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, _P], c_int),
+    "nesvor_hashgrid_backward": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P], c_int),
     "nesvor_hashgrid_backward_atomic": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
     "nesvor_adamw_step": (
         [_P, _P, _P, _P, c_int64] + [c_float] * 8 + [c_int, _P],
@@ -117,3 +117,43 @@ def require_device(*tensors, dtype=None, name="tensor"):
             raise RuntimeError(f"{name} must be contiguous")
         if dtype is not None and t.dtype != dtype:
             raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+class KernelTimer:
+    """Optional HIP-event timing of native launches on the launch stream (bench.py's roofline leg).
+    Disabled by default: zero overhead on the product path."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}
+
+    def reset(self, enabled):
+        self.enabled = enabled
+        self.records = {}
+
+    class _Span:
+        def __init__(self, timer, name):
+            self.timer, self.name = timer, name
+
+        def __enter__(self):
+            if self.timer.enabled:
+                self.s = torch.cuda.Event(enable_timing=True)
+                self.e = torch.cuda.Event(enable_timing=True)
+                self.s.record()  # torch's current stream == the stream the C ABI launches on
+            return self
+
+        def __exit__(self, *exc):
+            if self.timer.enabled:
+                self.e.record()
+                self.timer.records.setdefault(self.name, []).append((self.s, self.e))
+            return False
+
+    def span(self, name):
+        return KernelTimer._Span(self, name)
+
+    def summary(self):
+        """name -> (count, mean ms); call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(s.elapsed_time(e) for s, e in v) / len(v)) for k, v in self.records.items()}
+
+
+kernel_timer = KernelTimer()

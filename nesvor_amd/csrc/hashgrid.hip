@@ -511,15 +511,17 @@ constexpr uint64_t kTailBytes = 16384;  // tails region at the start of the work
 
 template <int F, int LAYOUT>
 int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table, const float* dpe, float* gt,
-                     float* gu, int64_t N, void* workspace, hipStream_t st) {
+                     float* gu, int64_t N, void* workspace, int stages, hipStream_t st) {
   BwdPlan plan;
   uint64_t n_rec;
   if (!make_plan(g, N, &plan, &n_rec)) return (int)hipErrorInvalidValue;
   uint32_t* tails = reinterpret_cast<uint32_t*>(workspace);
   uint32_t* records = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + kTailBytes);
-  hipError_t e = hipMemsetAsync(tails, 0, kTailBytes, st);
-  if (e != hipSuccess) return (int)e;
   dim3 grid((unsigned)((N + 255) / 256)), block(256);
+  hipError_t e;
+  if (!(stages & 1)) goto owner_stage;
+  e = hipMemsetAsync(tails, 0, kTailBytes, st);
+  if (e != hipSuccess) return (int)e;
   if (gu != nullptr)
     hipLaunchKernelGGL((hashgrid_bwd_aggregate<F, LAYOUT, true>), grid, block, 0, st, *g, plan, u, table, dpe, gt, gu,
                        tails, records, N);
@@ -528,7 +530,9 @@ int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table,
                        tails, records, N);
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((hashgrid_bwd_owner<F>), dim3(owner_grid(g, plan)), block, 0, st, *g, plan, tails, records, gt);
+owner_stage:
+  if (stages & 2)
+    hipLaunchKernelGGL((hashgrid_bwd_owner<F>), dim3(owner_grid(g, plan)), block, 0, st, *g, plan, tails, records, gt);
   return (int)hipGetLastError();
 }
 
@@ -627,9 +631,10 @@ extern "C" int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t*
 
 extern "C" int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* u, const float* table,
                                         const float* dpe, float* grad_table, float* grad_u, int64_t N, int layout,
-                                        void* workspace, void* stream) {
+                                        void* workspace, int stages, void* stream) {
   if (N <= 0) return 0;
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
-  if (workspace == nullptr) return (int)hipErrorInvalidValue;
-  DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, (hipStream_t)stream);
+  if (workspace == nullptr || (stages & 3) == 0) return (int)hipErrorInvalidValue;
+  DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages,
+                    (hipStream_t)stream);
 }

@@ -1,0 +1,86 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU,
+``torch.distributed`` (backend "nccl" == RCCL over xGMI; "gloo" for CPU tests).
+
+The reference is single-process; this is the build's addition
+(SURVEY.md §8e).  Every rank holds all parameters and the whole flat data set,
+draws the same permutation (same seed) and takes its own slice of each global
+batch; per-rank PSF noise differs (seed + rank).  The only exchange step per
+iteration is ONE all-reduce over the contiguous flat gradient buffer
+(hash table first, ~30 MB fp32, then the small MLP / per-slice gradients).
+
+xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU): a ring all-reduce
+of the 30 MB buffer moves 2(W-1)/W x 30 MB per GPU through single links
+(~0.34 ms at W=8), comparable to a fast iteration, so the buffer can be reduced
+in ``n_buckets`` chunks launched asynchronously on RCCL's stream while the
+optimiser processes finished chunks (see FusedTrainer.optimizer_step).
+"""
+import os
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None):
+    """Initialise from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+    Returns (rank, local_rank, world_size).  No-op single-process fallback when WORLD_SIZE is unset."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[str, torch.Tensor]:
+    """Rank r takes rows [r*B/W, (r+1)*B/W) of a global batch of B rows (B % W == 0)."""
+    if world == 1:
+        return batch
+    out = {}
+    for k, v in batch.items():
+        b = v.shape[0]
+        assert b % world == 0, f"global batch {b} not divisible by world size {world}"
+        per = b // world
+        out[k] = v[rank * per : (rank + 1) * per]
+    return out
+
+
+def allreduce_flat_(flat_grad: torch.Tensor, group=None, n_buckets: int = 1):
+    """Sum-all-reduce the flat gradient buffer in place.  Returns the list of async work handles
+    (one per bucket) so the caller may overlap; call .wait() on each (or use wait_all)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return []
+    n = flat_grad.numel()
+    n_buckets = max(1, min(n_buckets, n))
+    per = -(-n // n_buckets)
+    per = (per + 1023) // 1024 * 1024
+    works = []
+    for s in range(0, n, per):
+        works.append(dist.all_reduce(flat_grad[s : s + per], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    return works
+
+
+def wait_all(works) -> None:
+    for w in works:
+        w.wait()
+
+
+def make_reduce_hook(group=None, n_buckets: int = 1):
+    """Hook for FusedTrainer.reduce_hook: blocking sum-all-reduce of the flat gradient."""
+
+    def hook(flat_grad: torch.Tensor) -> None:
+        wait_all(allreduce_flat_(flat_grad, group, n_buckets))
+
+    return hook
+
+
+def broadcast_params_(flat_param: torch.Tensor, src: int = 0, group=None) -> None:
+    """Make every rank start from rank `src`'s parameters."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_param, src=src, group=group)

@@ -1,0 +1,89 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange step (batch sharding + one flat all-reduce)
+reproduces the single-process full-batch gradient.  Compute is the CPU oracle (the product has no
+CPU path); the code under test is nesvor_amd.ddp — the same functions the GPU trainer uses over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import small_args
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _flat_grads(golden, rows, noise):
+    from oracle import hashgrid as hg
+    from oracle import nesvor_model as nm
+
+    args = small_args()
+    P = {str(k): torch.tensor(golden[f"fw_sd::{k}"]) for k in golden["fw_state_keys"]}
+    bb, ax0 = P.pop("inr.bounding_box"), P.pop("axisangle_init")
+    base, L = nm.grid_config(bb, args)
+    levels = hg.make_levels(L, args.log2_hashmap_size, base, args.level_scale)
+    for v in P.values():
+        v.requires_grad_(True)
+    t = lambda k: torch.tensor(golden[f"fw_{k}"])[rows]
+    losses = nm.nesvor_forward(P, levels, args, bb, torch.tensor(golden["fw_psf_sigma"]), ax0, float(golden["fw_delta"]),
+                               t("xyz"), t("v"), t("idx"), noise[rows])
+    nm.total_loss(losses, args).backward()
+    names = sorted(P)
+    return torch.cat([P[n].grad.reshape(-1) for n in names]), names
+
+
+def _worker(rank, world, port, path, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from nesvor_amd import ddp
+
+    r, lr, w = ddp.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    golden = np.load(path)
+    noise = torch.tensor(golden["fw_noise"])
+    B = noise.shape[0]
+    batch = {"rows": torch.arange(B)}
+    rows = ddp.shard_batch(batch, rank, world)["rows"]
+    flat, _ = _flat_grads(golden, rows, noise)
+    ddp.make_reduce_hook(n_buckets=3)(flat)  # bucketed all-reduce(sum) in place
+    flat /= world
+    p = torch.full((5,), float(rank))
+    ddp.broadcast_params_(p, src=0)
+    assert float(p.sum()) == 0.0
+    if rank == 0:
+        torch.save(flat, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_allreduce_equals_full_batch(golden, tmp_path):
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_golden.npz")
+    out = str(tmp_path / "flat.pt")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, path, out), nprocs=2, join=True)
+    got = torch.load(out)
+    noise = torch.tensor(golden["fw_noise"])
+    full, names = _flat_grads(golden, torch.arange(noise.shape[0]), noise)
+    # every loss term is a mean over pixels (or a function of replicated params): the average of the two
+    # half-batch gradients equals the full-batch gradient up to fp32 summation order
+    scale = float(full.abs().max())
+    assert float((got - full).abs().max()) < 1e-5 * scale + 1e-9
+
+
+def test_shard_batch_rows():
+    from nesvor_amd.ddp import shard_batch
+
+    b = {"xyz": torch.arange(24.0).view(8, 3), "v": torch.arange(8.0)}
+    parts = [shard_batch(b, r, 4) for r in range(4)]
+    assert torch.equal(torch.cat([p["v"] for p in parts]), b["v"])
+    assert all(p["xyz"].shape == (2, 3) for p in parts)
+    assert shard_batch(b, 0, 1) is b
+    with pytest.raises(AssertionError):
+        shard_batch(b, 0, 3)
