@@ -97,6 +97,38 @@ int nesvor_hashgrid_backward_atomic(const nesvor_grid_t* grid, const float* u, c
                                     float* grad_table, float* grad_u, int64_t N, int layout, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Fused small MLP (fp32 matrix cores).  Replaces the nn.Linear/ReLU stacks that
+ * build_network creates in single-precision mode (nesvor/nesvor/models.py:42-67)
+ * for density_net (:113-121), sigma_net (:238-246) and b_net (:249-258), plus the
+ * expand/cat glue of NeSVoR.net_forward (:339-353).
+ *   input  = [ xa[n / samples_per_pixel][0..k_a) | xb[b_row0 .. b_row0+k_b)[n] ]
+ *            xa: (P, k_a) per-pixel features or NULL (k_a = 0); xb: (rows, N) feature-major
+ *   layers = Linear(k_a+k_b, 64) ReLU [Linear(64,64) ReLU]*(n_hidden-1) Linear(64, out_dim)
+ *            weight[l]: (out,in) row-major as in nn.Linear; bias[l]: (out)
+ *   y      : (out_dim, N) feature-major
+ * saved_hidden[l] (l < n_hidden): N_pad16*64 floats each, written by forward (pass
+ * NULL for inference), read by backward.  dpre_scratch[l]: same size, scratch.
+ * backward: dy (out_dim,N) -> dxa (N,k_a) per-sample (or NULL), dxb (k_b,N) (or NULL)
+ * and dw_partial (n_partial, sum_l(out*in+out)) partial parameter gradients in
+ * order W0,b0,W1,b1,.. that the caller sums over dim 0 (no atomics anywhere).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int32_t width;              /* hidden width; 64 */
+  int32_t n_hidden;           /* hidden layers, 1..NESVOR_MAX_MLP_LAYERS-1 */
+  int32_t out_dim;            /* 1..16 */
+  int32_t k_a, k_b, b_row0;
+  int32_t samples_per_pixel;
+  const float* weight[NESVOR_MAX_MLP_LAYERS];
+  const float* bias[NESVOR_MAX_MLP_LAYERS];
+} nesvor_mlp_t;
+
+int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, const float* xb, float* y,
+                       float* const* saved_hidden, int64_t N, void* stream);
+int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, const float* xb, const float* dy,
+                        float* const* saved_hidden, float* const* dpre_scratch, float* dxa, float* dxb,
+                        float* dw_partial, int n_partial, int64_t N, void* stream);
+
+/* ------------------------------------------------------------------------
  * Fused AdamW over a flat fp32 parameter buffer.  Replaces the
  * torch.optim.AdamW step at nesvor/nesvor/train.py:144-152,195-197
  * (betas (0.9,0.99), eps 1e-15, decoupled weight decay):

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -30,6 +30,16 @@ class GridT(Structure):
         ("size", c_uint32 * MAX_LEVELS),
         ("offset", c_uint32 * MAX_LEVELS),
         ("hashed", c_uint32 * MAX_LEVELS),
+    ]
+
+
+class MlpT(Structure):
+    """Mirror of nesvor_mlp_t."""
+
+    _fields_ = [
+        ("width", c_int32), ("n_hidden", c_int32), ("out_dim", c_int32),
+        ("k_a", c_int32), ("k_b", c_int32), ("b_row0", c_int32), ("samples_per_pixel", c_int32),
+        ("weight", c_void_p * 4), ("bias", c_void_p * 4),
     ]
 
 
@@ -54,6 +64,11 @@ _SIGNATURES = {
     "nesvor_hashgrid_backward_workspace_bytes": ([POINTER(GridT), c_int64], c_int64),
     "nesvor_hashgrid_backward": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P], c_int),
     "nesvor_hashgrid_backward_atomic": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
+    "nesvor_mlp_forward": ([POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), c_int64, _P], c_int),
+    "nesvor_mlp_backward": (
+        [POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), POINTER(c_void_p), _P, _P, _P, c_int, c_int64, _P],
+        c_int,
+    ),
     "nesvor_adamw_step": (
         [_P, _P, _P, _P, c_int64] + [c_float] * 8 + [c_int, _P],
         c_int,

@@ -1,0 +1,464 @@
+// Fused small-MLP forward / backward for gfx950 on the fp32 matrix cores.
+//
+// Replaces the nn.Linear/ReLU stacks that the reference's build_network creates in
+// single-precision mode (nesvor/nesvor/models.py:42-67; used for density_net :113-121,
+// sigma_net :238-246, b_net :249-258) and the concat/expand glue in NeSVoR.net_forward
+// (models.py:339-353).  rocBLAS runs these (N = 2^20) x 64 x 64 fp32 GEMMs at ~1-7 ms each
+// (measured: 41 ms of a 46 ms iteration); here one launch runs a whole network.
+//
+// Formulation (all fp32, exact: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain):
+//   H^T = W . X^T : MFMA rows i = output features, columns j = 16 samples, k = input features.
+//   Lane l = (j = l & 15, q = l >> 4).  The accumulator fragment of a 16-feature block holds, in
+//   lane (j,q), registers r = 0..3 -> feature 4q + r of sample j — which is exactly the B-operand
+//   shape of the next layer if K is walked as k = 16 kb + 4 q + r.  Activations therefore never
+//   leave registers between layers; only the weights are re-laid-out, once per workgroup, into LDS
+//   images img[ob][kb][lane][r] = W[16 ob + (lane & 15)][16 kb + 4 (lane >> 4) + r] that every lane
+//   reads with one conflict-free ds_read_b128 per four MFMAs.
+//   Backward dX uses the same scheme with transposed images; dW/db contract over samples
+//   (k = sample) and read their operands straight from the saved fragments.
+//
+// A network input is the concatenation [pixel features (P, k_a) broadcast over the S samples of a
+// pixel | rows b_row0 .. b_row0 + k_b of a feature-major matrix (rows, N)], which covers
+// density_net (pe), sigma_net (slice embedding | z[1:]) and b_net (slice embedding | pe[:n]) without
+// materialising any expand/cat tensor (130 MB each in the reference).
+//
+// Saved for backward: post-ReLU hidden activations, stored as raw accumulator fragments
+// ([group of 16 samples][feature block][lane][4]) so both the store and the reload are fully
+// coalesced 1 KiB wave transactions.
+#include <hip/hip_runtime.h>
+#include "common.h"
+#include "../../include/nesvor_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWidth = 64;      // hidden width (the reference's default and BASELINE's config)
+constexpr int kHB = kWidth / 16;  // feature blocks per hidden layer
+constexpr int kG = 4;           // 16-sample groups per wave per tile (64 samples / wave, 256 / workgroup)
+constexpr int kMaxLayers = NESVOR_MAX_MLP_LAYERS;  // linear layers incl. the output layer
+
+struct MlpArgs {
+  const float* W[kMaxLayers];   // nn.Linear weights, (out, in) row-major
+  const float* b[kMaxLayers];   // biases (out)
+  float* H[kMaxLayers];         // saved hidden fragments per hidden layer (fwd: out, bwd: in); may be null in fwd
+  float* dpre[kMaxLayers];      // bwd: grad w.r.t. pre-activation of each hidden layer, fragment layout
+  const float* xa;              // pixel features (P, k_a) or null
+  const float* xb;              // feature-major matrix (rows, N)
+  float* y;                     // fwd: output (out_dim, N) feature-major;  bwd: dY (out_dim, N) (read)
+  float* dxa;                   // bwd: (N, k_a) per-sample grad of the pixel features, or null
+  float* dxb;                   // bwd: (k_b, N) feature-major grad of the matrix rows, or null
+  float* dW_partial;            // dW kernel: (n_wg, total_params) partial sums
+  int64_t N;
+  int n_linear;                 // n_hidden + 1
+  int k_a, k_b, b_row0;         // input composition
+  int out_dim;                  // <= 16
+  int S;                        // samples per pixel (pixel = n / S)
+  int total_params;             // sum of W and b sizes (dW partial row length)
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------- LDS images
+// forward image of a layer with `ob_n` output blocks and `kb_n` input blocks
+__device__ void build_image(float* img, const float* __restrict__ W, int out_dim, int in_dim, int ob_n, int kb_n) {
+  const int total = ob_n * kb_n * 256;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int r = e & 3, lane = (e >> 2) & 63, blk = e >> 8;
+    const int kb = blk % kb_n, ob = blk / kb_n;
+    const int o = 16 * ob + (lane & 15), k = 16 * kb + 4 * (lane >> 4) + r;
+    img[e] = (o < out_dim && k < in_dim) ? W[(size_t)o * in_dim + k] : 0.f;
+  }
+}
+// transposed image: rows i = input features (ib blocks), k = output features (kb blocks)
+__device__ void build_image_T(float* img, const float* __restrict__ W, int out_dim, int in_dim, int ib_n, int kb_n) {
+  const int total = ib_n * kb_n * 256;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int r = e & 3, lane = (e >> 2) & 63, blk = e >> 8;
+    const int kb = blk % kb_n, ib = blk / kb_n;
+    const int in = 16 * ib + (lane & 15), o = 16 * kb + 4 * (lane >> 4) + r;
+    img[e] = (o < out_dim && in < in_dim) ? W[(size_t)o * in_dim + in] : 0.f;
+  }
+}
+
+// y[g][ob] (+)= img . x   for G groups at once; KB input blocks, OB output blocks
+template <int KB, int OB>
+__device__ __forceinline__ void apply_layer(const float* __restrict__ img, const f32x4 (&x)[kG][KB], f32x4 (&y)[kG][OB],
+                                            int lane) {
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(img + ((ob * KB + kb) * 64 + lane) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < kG; ++g) y[g][ob] = mfma4(a[r], x[g][kb][r], y[g][ob]);
+    }
+  }
+}
+
+__device__ __forceinline__ float fetch_input(const MlpArgs& a, int kk, int64_t n) {
+  if (kk < a.k_a) return a.xa[(size_t)(n / a.S) * a.k_a + kk];
+  const int kb_ = kk - a.k_a;
+  if (kb_ < a.k_b) return a.xb[(size_t)(a.b_row0 + kb_) * a.N + n];
+  return 0.f;
+}
+
+// ------------------------------------------------------------------- forward
+template <int KB1>
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int n_hidden = a.n_linear - 1;
+  const int k_in = a.k_a + a.k_b;
+  // LDS carve: [img1 | img hidden 2..n_hidden | img out | biases]
+  float* img1 = lds;
+  float* imgh = img1 + kHB * KB1 * 256;
+  float* imgo = imgh + (n_hidden - 1) * kHB * kHB * 256;
+  float* bias = imgo + 1 * kHB * 256;
+  build_image(img1, a.W[0], kWidth, k_in, kHB, KB1);
+  for (int l = 1; l < n_hidden; ++l) build_image(imgh + (l - 1) * kHB * kHB * 256, a.W[l], kWidth, kWidth, kHB, kHB);
+  build_image(imgo, a.W[n_hidden], a.out_dim, kWidth, 1, kHB);
+  for (int e = threadIdx.x; e < a.n_linear * kWidth; e += blockDim.x) {
+    const int l = e / kWidth, o = e % kWidth;
+    bias[e] = (l < n_hidden || o < a.out_dim) ? a.b[l][o] : 0.f;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int64_t n_groups = (a.N + 15) / 16;
+  const int64_t n_tiles = (n_groups + 4 * kG - 1) / (4 * kG);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t g0 = (tile * 4 + wave) * kG;
+    f32x4 x[kG][KB1];
+#pragma unroll
+    for (int g = 0; g < kG; ++g) {
+      const int64_t n = min((g0 + g) * 16 + j, a.N - 1);
+#pragma unroll
+      for (int kb = 0; kb < KB1; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[g][kb][r] = fetch_input(a, 16 * kb + 4 * q + r, n);
+    }
+    f32x4 h[kG][kHB];
+#pragma unroll
+    for (int ob = 0; ob < kHB; ++ob) {
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + 16 * ob + 4 * q);
+#pragma unroll
+      for (int g = 0; g < kG; ++g) h[g][ob] = bq;
+    }
+    apply_layer<KB1, kHB>(img1, x, h, lane);
+    for (int l = 0;; ++l) {
+      // ReLU + save fragments of hidden layer l
+#pragma unroll
+      for (int g = 0; g < kG; ++g)
+#pragma unroll
+        for (int ob = 0; ob < kHB; ++ob) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[g][ob][r] = fmaxf(h[g][ob][r], 0.f);
+          if (a.H[l] != nullptr && g0 + g < n_groups)
+            *reinterpret_cast<f32x4*>(a.H[l] + (((size_t)(g0 + g) * kHB + ob) * 64 + lane) * 4) = h[g][ob];
+        }
+      if (l + 1 >= n_hidden) break;
+      f32x4 h2[kG][kHB];
+#pragma unroll
+      for (int ob = 0; ob < kHB; ++ob) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + (l + 1) * kWidth + 16 * ob + 4 * q);
+#pragma unroll
+        for (int g = 0; g < kG; ++g) h2[g][ob] = bq;
+      }
+      apply_layer<kHB, kHB>(imgh + l * kHB * kHB * 256, h, h2, lane);
+#pragma unroll
+      for (int g = 0; g < kG; ++g)
+#pragma unroll
+        for (int ob = 0; ob < kHB; ++ob) h[g][ob] = h2[g][ob];
+    }
+    f32x4 o[kG][1];
+    {
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + n_hidden * kWidth + 4 * q);
+#pragma unroll
+      for (int g = 0; g < kG; ++g) o[g][0] = bq;
+    }
+    apply_layer<kHB, 1>(imgo, h, o, lane);
+#pragma unroll
+    for (int g = 0; g < kG; ++g) {
+      const int64_t n = (g0 + g) * 16 + j;
+      if (n < a.N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * q + r < a.out_dim) a.y[(size_t)(4 * q + r) * a.N + n] = o[g][0][r];
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------- backward: dX
+// dY (out_dim, N) -> dpre of every hidden layer (fragment layout, saved for the dW pass) and the
+// input gradients.  Needs the saved post-ReLU fragments H[l] for the masks.
+template <int KB1>
+__global__ __launch_bounds__(256) void mlp_bwd_dx_kernel(const MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int n_hidden = a.n_linear - 1;
+  const int k_in = a.k_a + a.k_b;
+  float* imgo = lds;                                    // W_out^T : ib = 4 (hidden), kb = 1 (out padded to 16)
+  float* imgh = imgo + kHB * 1 * 256;                   // W_l^T for l = 1..n_hidden-1 : 4 x 4
+  float* img1 = imgh + (n_hidden - 1) * kHB * kHB * 256;  // W_1^T : ib = KB1, kb = 4
+  build_image_T(imgo, a.W[n_hidden], a.out_dim, kWidth, kHB, 1);
+  for (int l = 1; l < n_hidden; ++l) build_image_T(imgh + (l - 1) * kHB * kHB * 256, a.W[l], kWidth, kWidth, kHB, kHB);
+  build_image_T(img1, a.W[0], kWidth, k_in, KB1, kHB);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int64_t n_groups = (a.N + 15) / 16;
+  const int64_t n_tiles = (n_groups + 4 * kG - 1) / (4 * kG);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t g0 = (tile * 4 + wave) * kG;
+    f32x4 go[kG][1];
+#pragma unroll
+    for (int g = 0; g < kG; ++g) {
+      const int64_t n = (g0 + g) * 16 + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        go[g][0][r] = (n < a.N && 4 * q + r < a.out_dim) ? a.y[(size_t)(4 * q + r) * a.N + n] : 0.f;
+    }
+    f32x4 d[kG][kHB];
+#pragma unroll
+    for (int g = 0; g < kG; ++g)
+#pragma unroll
+      for (int ib = 0; ib < kHB; ++ib) d[g][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+    apply_layer<1, kHB>(imgo, go, d, lane);
+    for (int l = n_hidden - 1;; --l) {
+      // d holds dL/dH_l (post-ReLU); mask -> dpre_l, save
+#pragma unroll
+      for (int g = 0; g < kG; ++g) {
+        const bool ok = g0 + g < n_groups;
+#pragma unroll
+        for (int ib = 0; ib < kHB; ++ib) {
+          const size_t off = (((size_t)(g0 + g) * kHB + ib) * 64 + lane) * 4;
+          f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (ok) hv = *reinterpret_cast<const f32x4*>(a.H[l] + off);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) d[g][ib][r] = hv[r] > 0.f ? d[g][ib][r] : 0.f;
+          if (ok) *reinterpret_cast<f32x4*>(a.dpre[l] + off) = d[g][ib];
+        }
+      }
+      if (l == 0) break;
+      f32x4 d2[kG][kHB];
+#pragma unroll
+      for (int g = 0; g < kG; ++g)
+#pragma unroll
+        for (int ib = 0; ib < kHB; ++ib) d2[g][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+      apply_layer<kHB, kHB>(imgh + (l - 1) * kHB * kHB * 256, d, d2, lane);
+#pragma unroll
+      for (int g = 0; g < kG; ++g)
+#pragma unroll
+        for (int ib = 0; ib < kHB; ++ib) d[g][ib] = d2[g][ib];
+    }
+    if (a.dxa != nullptr || a.dxb != nullptr) {
+      f32x4 dx[kG][KB1];
+#pragma unroll
+      for (int g = 0; g < kG; ++g)
+#pragma unroll
+        for (int ib = 0; ib < KB1; ++ib) dx[g][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+      apply_layer<kHB, KB1>(img1, d, dx, lane);
+#pragma unroll
+      for (int g = 0; g < kG; ++g) {
+        const int64_t n = (g0 + g) * 16 + j;
+        if (n >= a.N) continue;
+#pragma unroll
+        for (int ib = 0; ib < KB1; ++ib)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kk = 16 * ib + 4 * q + r;
+            if (kk < a.k_a) {
+              if (a.dxa != nullptr) a.dxa[(size_t)n * a.k_a + kk] = dx[g][ib][r];
+            } else if (kk - a.k_a < a.k_b) {
+              if (a.dxb != nullptr) a.dxb[(size_t)(kk - a.k_a) * a.N + n] = dx[g][ib][r];
+            }
+          }
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------- backward: dW, db
+// One workgroup accumulates, layer after layer, over its share of the sample groups:
+//   dW_l[out][in] = sum_n dY_l[out][n] X_l[in][n]   (MFMA rows = out, cols = in, k = samples)
+//   db_l[out]     = sum_n dY_l[out][n]
+// and writes its partial sums to dW_partial[wg][...] (PyTorch parameter order W0,b0,W1,b1,...);
+// the (n_wg x params) partials are summed by the caller.  No atomics anywhere.
+__device__ __forceinline__ float frag_elem(const float* __restrict__ F, int64_t gi, int f, int s) {
+  // element (feature f, sample s) of group gi in the saved fragment layout
+  return F[(((size_t)gi * kHB + (f >> 4)) * 64 + ((f & 15) >> 2) * 16 + s) * 4 + (f & 3)];
+}
+
+template <int KB1>
+__global__ __launch_bounds__(256) void mlp_bwd_dw_kernel(const MlpArgs a) {
+  __shared__ float red[4][kHB * 256];  // per-wave staging of one accumulator column (16 KB)
+  const int n_hidden = a.n_linear - 1;
+  const int k_in = a.k_a + a.k_b;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int64_t n_groups = (a.N + 15) / 16;
+  float* out = a.dW_partial + (size_t)blockIdx.x * a.total_params;
+  int poff = 0;
+  for (int l = 0; l < a.n_linear; ++l) {
+    const int in_dim = (l == 0) ? k_in : kWidth;
+    const int out_dim = (l == n_hidden) ? a.out_dim : kWidth;
+    const int IB = (l == 0) ? KB1 : kHB;   // runtime, <= 4
+    const int OB = (l == n_hidden) ? 1 : kHB;
+    f32x4 acc[kHB][4];  // [ob][ib], ib up to max(KB1, 4) <= 4
+    float db[kHB];
+#pragma unroll
+    for (int ob = 0; ob < kHB; ++ob) {
+      db[ob] = 0.f;
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib) acc[ob][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t gi = (int64_t)blockIdx.x * 4 + wave; gi < n_groups; gi += (int64_t)gridDim.x * 4) {
+      // operands: lane (i,q) holds feature 16 b + i of samples 4q .. 4q+3 of the group
+      float av[kHB][4], bv[4][4];
+#pragma unroll
+      for (int ob = 0; ob < kHB; ++ob) {
+        if (ob < OB) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int64_t n = gi * 16 + 4 * q + t;
+            float v;
+            if (l == n_hidden) v = (n < a.N && i < a.out_dim) ? a.y[(size_t)i * a.N + n] : 0.f;
+            else v = (n < a.N) ? frag_elem(a.dpre[l], gi, 16 * ob + i, 4 * q + t) : 0.f;
+            av[ob][t] = v;
+          }
+          db[ob] += (av[ob][0] + av[ob][1]) + (av[ob][2] + av[ob][3]);
+        }
+      }
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib) {
+        if (ib < IB) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int64_t n = min(gi * 16 + 4 * q + t, a.N - 1);
+            bv[ib][t] = (l == 0) ? fetch_input(a, 16 * ib + i, n) : frag_elem(a.H[l - 1], gi, 16 * ib + i, 4 * q + t);
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ob = 0; ob < kHB; ++ob)
+#pragma unroll
+          for (int ib = 0; ib < 4; ++ib)
+            if (ob < OB && ib < IB) acc[ob][ib] = mfma4(av[ob][t], bv[ib][t], acc[ob][ib]);
+    }
+    // reduce the four waves' partials through LDS, one output block at a time, and write W (out,in)
+#pragma unroll
+    for (int ob = 0; ob < kHB; ++ob) {  // static index into acc[]; OB is workgroup-uniform
+      if (ob >= OB) break;
+      __syncthreads();
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib)
+        *reinterpret_cast<f32x4*>(&red[wave][(ib * 64 + lane) * 4]) = acc[ob][ib];
+      __syncthreads();
+      for (int e = threadIdx.x; e < IB * 256; e += blockDim.x) {
+        const float s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        const int r = e & 3, ln = (e >> 2) & 63, ib = e >> 8;
+        const int o = 16 * ob + 4 * (ln >> 4) + r, in = 16 * ib + (ln & 15);
+        if (o < out_dim && in < in_dim) out[poff + o * in_dim + in] = s;
+      }
+    }
+    // bias grads: sum over q (lanes i, i+16, i+32, i+48) and over waves
+    __syncthreads();
+#pragma unroll
+    for (int ob = 0; ob < kHB; ++ob) red[wave][ob * 64 + lane] = db[ob];
+    __syncthreads();
+    for (int e = threadIdx.x; e < OB * 16; e += blockDim.x) {
+      const int ob = e >> 4, ii = e & 15;
+      float s = 0.f;
+      for (int w = 0; w < 4; ++w)
+        for (int qq = 0; qq < 4; ++qq) s += red[w][ob * 64 + qq * 16 + ii];
+      if (16 * ob + ii < out_dim) out[poff + out_dim * in_dim + 16 * ob + ii] = s;
+    }
+    poff += out_dim * in_dim + out_dim;
+  }
+}
+
+size_t fwd_lds_bytes(int n_linear, int kb1) {
+  const int n_hidden = n_linear - 1;
+  return sizeof(float) * ((size_t)kHB * kb1 * 256 + (size_t)(n_hidden - 1) * kHB * kHB * 256 + kHB * 256 + (size_t)n_linear * kWidth);
+}
+size_t bwd_lds_bytes(int n_linear, int kb1) {
+  const int n_hidden = n_linear - 1;
+  return sizeof(float) * ((size_t)kHB * 256 + (size_t)(n_hidden - 1) * kHB * kHB * 256 + (size_t)kb1 * kHB * 256);
+}
+
+template <typename K>
+int launch_kb(K k1, K k2, K k3, K k4, int kb1, dim3 grid, size_t lds, hipStream_t st, const MlpArgs& a) {
+  K k = kb1 == 1 ? k1 : kb1 == 2 ? k2 : kb1 == 3 ? k3 : k4;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+  return (int)hipGetLastError();
+}
+
+int fill_args(MlpArgs* a, const nesvor_mlp_t* d, int64_t N) {
+  if (d->width != kWidth || d->n_hidden < 1 || d->n_hidden + 1 > kMaxLayers || d->out_dim < 1 || d->out_dim > 16 ||
+      d->k_a < 0 || d->k_b < 0 || d->k_a + d->k_b < 1 || d->k_a + d->k_b > 64 || d->samples_per_pixel < 1)
+    return (int)hipErrorInvalidValue;
+  a->N = N;
+  a->n_linear = d->n_hidden + 1;
+  a->k_a = d->k_a; a->k_b = d->k_b; a->b_row0 = d->b_row0; a->out_dim = d->out_dim; a->S = d->samples_per_pixel;
+  int total = 0;
+  for (int l = 0; l < a->n_linear; ++l) {
+    a->W[l] = d->weight[l]; a->b[l] = d->bias[l];
+    const int in = l == 0 ? d->k_a + d->k_b : kWidth, out = l == d->n_hidden ? d->out_dim : kWidth;
+    total += in * out + out;
+  }
+  for (int l = a->n_linear; l < kMaxLayers; ++l) { a->W[l] = nullptr; a->b[l] = nullptr; }
+  a->total_params = total;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, const float* xb, float* y,
+                                  float* const* saved_hidden, int64_t N, void* stream) {
+  if (N <= 0) return 0;
+  MlpArgs a{};
+  int e = fill_args(&a, net, N);
+  if (e) return e;
+  a.xa = xa; a.xb = xb; a.y = y;
+  for (int l = 0; l < kMaxLayers; ++l) a.H[l] = (saved_hidden != nullptr && l < net->n_hidden) ? saved_hidden[l] : nullptr;
+  const int kb1 = (net->k_a + net->k_b + 15) / 16;
+  const int64_t n_tiles = ((N + 15) / 16 + 4 * kG - 1) / (4 * kG);
+  dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512));
+  return launch_kb(mlp_fwd_kernel<1>, mlp_fwd_kernel<2>, mlp_fwd_kernel<3>, mlp_fwd_kernel<4>, kb1, grid,
+                   fwd_lds_bytes(a.n_linear, kb1), (hipStream_t)stream, a);
+}
+
+extern "C" int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, const float* xb, const float* dy,
+                                   float* const* saved_hidden, float* const* dpre_scratch, float* dxa, float* dxb,
+                                   float* dw_partial, int n_partial, int64_t N, void* stream) {
+  if (N <= 0) return 0;
+  MlpArgs a{};
+  int e = fill_args(&a, net, N);
+  if (e) return e;
+  if (saved_hidden == nullptr || dpre_scratch == nullptr || dw_partial == nullptr || n_partial < 1) return (int)hipErrorInvalidValue;
+  a.xa = xa; a.xb = xb; a.y = const_cast<float*>(dy); a.dxa = dxa; a.dxb = dxb; a.dW_partial = dw_partial;
+  for (int l = 0; l < kMaxLayers; ++l) {
+    a.H[l] = l < net->n_hidden ? saved_hidden[l] : nullptr;
+    a.dpre[l] = l < net->n_hidden ? dpre_scratch[l] : nullptr;
+  }
+  const int kb1 = (net->k_a + net->k_b + 15) / 16;
+  const int64_t n_tiles = ((N + 15) / 16 + 4 * kG - 1) / (4 * kG);
+  dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512));
+  e = launch_kb(mlp_bwd_dx_kernel<1>, mlp_bwd_dx_kernel<2>, mlp_bwd_dx_kernel<3>, mlp_bwd_dx_kernel<4>, kb1, grid,
+                bwd_lds_bytes(a.n_linear, kb1), (hipStream_t)stream, a);
+  if (e) return e;
+  return launch_kb(mlp_bwd_dw_kernel<1>, mlp_bwd_dw_kernel<2>, mlp_bwd_dw_kernel<3>, mlp_bwd_dw_kernel<4>, kb1,
+                   dim3((unsigned)n_partial), 0, (hipStream_t)stream, a);
+}

@@ -1,0 +1,131 @@
+"""Fused small-MLP op (gfx950 fp32 matrix cores): autograd Function over nesvor_mlp_forward/backward.
+
+The network is an ``nn.Sequential`` of Linear/ReLU exactly as ``build_network`` creates it in
+single-precision mode (same parameters, same state_dict); this op only changes how it is
+evaluated.  Input = [pixel features xa (P,k_a) broadcast over each pixel's S samples |
+rows [b_row0, b_row0+k_b) of a feature-major matrix xb (rows,N)];  output (out_dim, N) feature-major.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _lib
+
+N_PARTIAL = 256  # workgroups (= partial sums) of the dW kernel
+
+
+def linear_layers(seq: nn.Sequential):
+    layers = [m for m in seq if isinstance(m, nn.Linear)]
+    others = [m for m in seq if not isinstance(m, (nn.Linear, nn.ReLU))]
+    if others:
+        raise ValueError(f"fused MLP supports Linear/ReLU stacks only, found {others}")
+    return layers
+
+
+def supported(seq) -> bool:
+    if not isinstance(seq, nn.Sequential):
+        return False
+    try:
+        layers = linear_layers(seq)
+    except ValueError:
+        return False
+    if not 2 <= len(layers) <= 4:
+        return False
+    if any(l.out_features != 64 for l in layers[:-1]) or any(l.in_features != 64 for l in layers[1:]):
+        return False
+    return layers[-1].out_features <= 16 and layers[0].in_features <= 64 and all(l.bias is not None for l in layers)
+
+
+def _desc(weights, biases, k_a, k_b, b_row0, S):
+    d = _lib.MlpT()
+    d.width, d.n_hidden, d.out_dim = 64, len(weights) - 1, weights[-1].shape[0]
+    d.k_a, d.k_b, d.b_row0, d.samples_per_pixel = k_a, k_b, b_row0, S
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        d.weight[i], d.bias[i] = w.data_ptr(), b.data_ptr()
+    return d
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * 4)()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class FusedMLPFunction(Function):
+    @staticmethod
+    def forward(ctx, xa, xb, b_row0, k_b, S, n_layers, *params):
+        weights, biases = params[:n_layers], params[n_layers:]
+        _lib.require_device(xb, *params, dtype=torch.float32, name="fused MLP input/params")
+        N = xb.shape[1]
+        k_a = 0 if xa is None else xa.shape[1]
+        if xa is not None:
+            _lib.require_device(xa, dtype=torch.float32, name="fused MLP pixel features")
+            if xa.shape[0] * S != N:
+                raise RuntimeError("pixel features: P * samples_per_pixel must equal N")
+        if weights[0].shape[1] != k_a + k_b:
+            raise RuntimeError("first layer width does not match k_a + k_b")
+        d = _desc(weights, biases, k_a, k_b, b_row0, S)
+        need_grad = any(ctx.needs_input_grad)
+        n_pad = (N + 15) // 16 * 16
+        saved = [torch.empty(n_pad * 64, dtype=torch.float32, device=xb.device) for _ in range(n_layers - 1)] if need_grad else []
+        y = torch.empty((d.out_dim, N), dtype=torch.float32, device=xb.device)
+        with torch.cuda.device(xb.device), _lib.kernel_timer.span("mlp_fwd"):
+            err = _lib.load().nesvor_mlp_forward(
+                ctypes.byref(d), _lib.ptr(xa), _lib.ptr(xb), _lib.ptr(y), _ptr_array(saved) if need_grad else None,
+                N, _lib.stream_ptr())
+        _lib.check(err, "mlp forward")
+        ctx.save_for_backward(xa, xb, *params, *saved)
+        ctx.cfg = (b_row0, k_b, S, n_layers)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        b_row0, k_b, S, n_layers = ctx.cfg
+        t = ctx.saved_tensors
+        xa, xb = t[0], t[1]
+        params = t[2 : 2 + 2 * n_layers]
+        saved = t[2 + 2 * n_layers :]
+        weights, biases = params[:n_layers], params[n_layers:]
+        N = xb.shape[1]
+        k_a = 0 if xa is None else xa.shape[1]
+        d = _desc(weights, biases, k_a, k_b, b_row0, S)
+        dev = xb.device
+        dy = dy.contiguous()
+        dpre = [torch.empty_like(s) for s in saved]
+        dxa = torch.empty((N, k_a), dtype=torch.float32, device=dev) if (xa is not None and ctx.needs_input_grad[0]) else None
+        dxb = torch.empty((k_b, N), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        total = sum(w.numel() + b.numel() for w, b in zip(weights, biases))
+        partial = torch.empty((N_PARTIAL, total), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev), _lib.kernel_timer.span("mlp_bwd"):
+            err = _lib.load().nesvor_mlp_backward(
+                ctypes.byref(d), _lib.ptr(xa), _lib.ptr(xb), _lib.ptr(dy), _ptr_array(saved), _ptr_array(dpre),
+                _lib.ptr(dxa), _lib.ptr(dxb), _lib.ptr(partial), N_PARTIAL, N, _lib.stream_ptr())
+        _lib.check(err, "mlp backward")
+        flat = partial.sum(0)
+        gw, gb, off = [], [], 0
+        for w, b in zip(weights, biases):
+            gw.append(flat[off : off + w.numel()].view_as(w))
+            off += w.numel()
+            gb.append(flat[off : off + b.numel()])
+            off += b.numel()
+        g_xa = None
+        if dxa is not None:
+            g_xa = dxa.view(xa.shape[0], S, k_a).sum(1)
+        g_xb = None
+        if dxb is not None:
+            if b_row0 == 0 and k_b == xb.shape[0]:
+                g_xb = dxb
+            else:
+                g_xb = torch.zeros_like(xb)
+                g_xb[b_row0 : b_row0 + k_b] = dxb
+        return (g_xa, g_xb, None, None, None, None, *gw, *gb)
+
+
+def fused_mlp(seq: nn.Sequential, xa, xb, b_row0: int, k_b: int, samples_per_pixel: int):
+    """Evaluate `seq` on [xa broadcast | xb rows] -> (out_dim, N) feature-major."""
+    layers = linear_layers(seq)
+    params = [l.weight for l in layers] + [l.bias for l in layers]
+    return FusedMLPFunction.apply(xa, xb.contiguous(), b_row0, k_b, samples_per_pixel, len(layers), *params)

@@ -21,7 +21,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
+from . import mlp as fused_mlp_mod
 from . import tinycudann as tcnn
+from .encoding import hashgrid_encode
 from .transform import RigidTransform, ax_transform_points, mat_transform_points
 from .utils import resolution2sigma
 
@@ -107,9 +110,20 @@ class INR(nn.Module):
             dtype=args.dtype,
         )
 
+    def use_fused_mlp(self) -> bool:
+        return (self.bounding_box.is_cuda and self.encoding.dtype == torch.float32
+                and getattr(self, "fused_mlp", True) and fused_mlp_mod.supported(self.density_net))
+
     def forward(self, x: torch.Tensor, return_all: bool = True):
         x = (x - self.bounding_box[0]) / (self.bounding_box[1] - self.bounding_box[0])
         prefix_shape = x.shape[:-1]
+        if self.use_fused_mlp():
+            # feature-major hash grid -> fused fp32-MFMA MLP; (N,E)/(N,16) views are returned for API parity
+            enc = self.encoding
+            pe_fm = hashgrid_encode(x.reshape(-1, 3), enc.params, enc.spec, _lib.LAYOUT_FEATURE_MAJOR, enc.grad_accum)
+            z_fm = fused_mlp_mod.fused_mlp(self.density_net, None, pe_fm, 0, pe_fm.shape[0], 1)
+            density = F.softplus(z_fm[0].view(prefix_shape))
+            return (density, pe_fm.t(), z_fm.t()) if return_all else density
         pe = self.encoding(x.reshape(-1, x.shape[-1]))
         z = self.density_net(pe)
         density = F.softplus(z[..., 0].view(prefix_shape))
@@ -203,8 +217,11 @@ class NeSVoR(nn.Module):
         sigma = self.psf_sigma[slice_idx][:, None]
         pose = self.axisangle[slice_idx][:, None]
         x = ax_transform_points(pose, xyz[:, None] + noise * sigma, self.trans_first)
-        se = self.slice_embedding(slice_idx)[:, None].expand(-1, S, -1) if a.n_features_slice else None
-        results = self.net_forward(x, se)
+        if self.use_fused_mlp():
+            results = self.net_forward_fused(x, slice_idx)
+        else:
+            se = self.slice_embedding(slice_idx)[:, None].expand(-1, S, -1) if a.n_features_slice else None
+            results = self.net_forward(x, se)
         density = results["density"]
         if "log_bias" in results:
             log_bias = results["log_bias"]
@@ -231,6 +248,38 @@ class NeSVoR(nn.Module):
             losses[B_REG] = log_bias.mean() ** 2
         losses[I_REG] = self.image_regularization(density, x, self.delta)
         return losses
+
+    def use_fused_mlp(self) -> bool:
+        """Fused fp32-MFMA evaluation of the three MLPs (default on a HIP device in single precision)."""
+        a = self.args
+        nets = [self.inr.density_net]
+        if not a.no_pixel_variance:
+            nets.append(self.sigma_net)
+        if a.n_levels_bias:
+            nets.append(self.b_net)
+        return (getattr(a, "fused_mlp", True) and a.dtype == torch.float32 and self.axisangle.is_cuda
+                and all(fused_mlp_mod.supported(n) for n in nets))
+
+    def net_forward_fused(self, x: torch.Tensor, slice_idx: torch.Tensor) -> Dict[str, Any]:
+        """net_forward (models.py:329-355) without materialising pe (N,E) row-major, the expanded slice
+        embedding or the concatenated MLP inputs: the hash grid writes feature-major (E,N) and the fused
+        MLPs read [slice embedding of the pixel | matrix rows] directly."""
+        a = self.args
+        inr = self.inr
+        B, S = x.shape[0], x.shape[1]
+        u = ((x - inr.bounding_box[0]) / (inr.bounding_box[1] - inr.bounding_box[0])).reshape(-1, 3)
+        enc = inr.encoding
+        pe = hashgrid_encode(u, enc.params, enc.spec, _lib.LAYOUT_FEATURE_MAJOR, enc.grad_accum)  # (E, N)
+        E = pe.shape[0]
+        z = fused_mlp_mod.fused_mlp(inr.density_net, None, pe, 0, E, S)  # (1 + n_features_z, N)
+        results = {"density": F.softplus(z[0]).view(B, S)}
+        se = self.slice_embedding(slice_idx) if a.n_features_slice else None  # (B, n_features_slice)
+        if a.n_levels_bias:
+            kb = a.n_levels_bias * a.n_features_per_level
+            results["log_bias"] = fused_mlp_mod.fused_mlp(self.b_net, se, pe, 0, kb, S)[0].view(B, S)
+        if not a.no_pixel_variance:
+            results["log_var"] = fused_mlp_mod.fused_mlp(self.sigma_net, se, z, 1, a.n_features_z, S)[0].view(B, S)
+        return results
 
     def net_forward(self, x: torch.Tensor, se: Optional[torch.Tensor] = None) -> Dict[str, Any]:
         a = self.args

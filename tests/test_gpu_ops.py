@@ -279,6 +279,70 @@ def test_hashgrid_autograd_module(device):
     torch.testing.assert_close(x.grad.cpu(), gu, rtol=1e-4, atol=1e-3)
 
 
+# -------------------------------------------------------------------- fused MLP
+@pytest.mark.parametrize("k_a,k_b,b_row0,rows,depth,out_dim,S,N", [
+    (0, 32, 0, 32, 2, 16, 8, 1000),     # density_net (ragged N, not a multiple of 16)
+    (16, 15, 1, 16, 2, 1, 8, 1000),     # sigma_net: [slice embedding | z[1:]]
+    (16, 4, 0, 32, 1, 1, 16, 2048),     # b_net: [slice embedding | pe[:4]]
+    (0, 16, 0, 16, 1, 16, 1, 300),      # default depth 1, E=16
+    (0, 24, 0, 24, 3, 16, 256, 512),    # L=12 (default level scale), depth 3
+    (16, 15, 1, 16, 1, 1, 256, 65536),  # full pixel clouds
+])
+def test_fused_mlp_vs_torch_fp32_reference(device, k_a, k_b, b_row0, rows, depth, out_dim, S, N):
+    """fp32 MFMA network vs the same nn.Sequential evaluated by PyTorch (fp32 reference of the same op).
+    Tolerance: fp32 with K <= 64 per layer and different summation order: rtol 2e-4 / atol 2e-5 fwd,
+    grads relative to their max."""
+    from nesvor_amd.mlp import fused_mlp
+    from nesvor_amd.models import build_network
+
+    torch.manual_seed(N + k_a)
+    net = build_network(n_input_dims=k_a + k_b, n_output_dims=out_dim, activation="ReLU", output_activation="None",
+                        n_neurons=64, n_hidden_layers=depth, dtype=torch.float32).to(device)
+    P = N // S
+    xa = torch.randn(P, k_a, device=device, requires_grad=True) if k_a else None
+    xb = torch.randn(rows, N, device=device, requires_grad=True)
+    w = torch.randn(out_dim, N, device=device)
+    y = fused_mlp(net, xa, xb, b_row0, k_b, S)
+    (y * w).sum().backward()
+    got = {"y": y.detach(), "xb": xb.grad.clone(), "xa": None if xa is None else xa.grad.clone()}
+    got.update({n: p.grad.clone() for n, p in net.named_parameters()})
+    for p in net.parameters():
+        p.grad = None
+    xb.grad = None
+    if xa is not None:
+        xa.grad = None
+    feats = [] if xa is None else [xa[:, None].expand(-1, S, -1).reshape(N, k_a)]
+    inp = torch.cat(feats + [xb[b_row0 : b_row0 + k_b].t()], -1)
+    y_ref = net(inp).t()
+    (y_ref * w).sum().backward()
+    torch.testing.assert_close(got["y"], y_ref.detach(), rtol=2e-4, atol=2e-5)
+
+    def close(a, b, name):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 3e-4 * scale, (name, float((a - b).abs().max()), scale)
+
+    close(got["xb"], xb.grad, "xb")
+    if xa is not None:
+        close(got["xa"], xa.grad, "xa")
+    for n, p in net.named_parameters():
+        close(got[n], p.grad, n)
+
+
+def test_fused_mlp_vs_oracle_cpu(device):
+    from nesvor_amd.mlp import fused_mlp
+    from nesvor_amd.models import build_network
+    from oracle import nesvor_model as nm
+
+    torch.manual_seed(0)
+    net = build_network(n_input_dims=32, n_output_dims=16, activation="ReLU", output_activation="None",
+                        n_neurons=64, n_hidden_layers=2, dtype=torch.float32)
+    P = {f"n.{k}": v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.randn(32, 4096)
+    ref = nm.mlp_forward(P, "n", x.t(), 3).t()
+    y = fused_mlp(net.to(device), None, x.to(device), 0, 32, 1).cpu()
+    torch.testing.assert_close(y, ref, rtol=2e-4, atol=2e-5)
+
+
 # ------------------------------------------------------------------------ AdamW
 def test_fused_adamw_vs_torch(device):
     from nesvor_amd import _lib
