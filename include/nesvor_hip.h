@@ -97,6 +97,23 @@ int nesvor_hashgrid_backward_atomic(const nesvor_grid_t* grid, const float* u, c
                                     float* grad_table, float* grad_u, int64_t N, int layout, void* stream);
 
 /* ------------------------------------------------------------------------
+ * PSF sampling + rigid transform of a batch of slice pixels.  Replaces the head of
+ * NeSVoR.forward (nesvor/nesvor/models.py:267-278), ax/mat_transform_points
+ * (nesvor/transform/transform.py:259-280, trans_first = True) and the bounding-box
+ * normalisation of INR.forward (models.py:143):
+ *   x[b,s] = R_k (xyz[b] + noise[b,s] * sigma_k + t_k),  k = slice_idx[b];  u = (x - bb0)/(bb1 - bb0)
+ * mat (n,3,4) per-slice [R|t]; slice_idx (B) int64; xyz (B,3); sigma (n,3); noise (B,S,3)
+ * standard normal; bb (2,3); x (B,S,3) out; u (B*S,3) out or NULL.
+ * backward: dx (B,S,3) and/or du (B*S,3) (either may be NULL) -> dmat (B,3,4) per PIXEL
+ * (gradient w.r.t. the pixel's slice matrix; the caller index-adds pixels into slices).
+ * ---------------------------------------------------------------------- */
+int nesvor_psf_transform_forward(const float* mat, const int64_t* slice_idx, const float* xyz, const float* sigma,
+                                 const float* noise, const float* bb, float* x, float* u, int B, int S, void* stream);
+int nesvor_psf_transform_backward(const float* mat, const int64_t* slice_idx, const float* xyz, const float* sigma,
+                                  const float* noise, const float* bb, const float* dx, const float* du, float* dmat,
+                                  int B, int S, void* stream);
+
+/* ------------------------------------------------------------------------
  * Fused small MLP (fp32 matrix cores).  Replaces the nn.Linear/ReLU stacks that
  * build_network creates in single-precision mode (nesvor/nesvor/models.py:42-67)
  * for density_net (:113-121), sigma_net (:238-246) and b_net (:249-258), plus the

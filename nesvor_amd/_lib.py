@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -64,6 +64,8 @@ _SIGNATURES = {
     "nesvor_hashgrid_backward_workspace_bytes": ([POINTER(GridT), c_int64], c_int64),
     "nesvor_hashgrid_backward": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P], c_int),
     "nesvor_hashgrid_backward_atomic": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
+    "nesvor_psf_transform_forward": ([_P] * 8 + [c_int, c_int, _P], c_int),
+    "nesvor_psf_transform_backward": ([_P] * 9 + [c_int, c_int, _P], c_int),
     "nesvor_mlp_forward": ([POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), c_int64, _P], c_int),
     "nesvor_mlp_backward": (
         [POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), POINTER(c_void_p), _P, _P, _P, c_int, c_int64, _P],

@@ -25,7 +25,8 @@ from . import _lib
 from . import mlp as fused_mlp_mod
 from . import tinycudann as tcnn
 from .encoding import hashgrid_encode
-from .transform import RigidTransform, ax_transform_points, mat_transform_points
+from .sampler import psf_transform
+from .transform import RigidTransform, ax_transform_points, axisangle2mat, mat_transform_points
 from .utils import resolution2sigma
 
 # loss / regulariser keys (models.py:14-19)
@@ -214,12 +215,15 @@ class NeSVoR(nn.Module):
     def forward_with_noise(self, xyz, v, slice_idx, noise) -> Dict[str, Any]:
         a = self.args
         S = noise.shape[1]
-        sigma = self.psf_sigma[slice_idx][:, None]
-        pose = self.axisangle[slice_idx][:, None]
-        x = ax_transform_points(pose, xyz[:, None] + noise * sigma, self.trans_first)
         if self.use_fused_mlp():
-            results = self.net_forward_fused(x, slice_idx)
+            # fused sampler: per-slice matrices (n is a few hundred) -> x and the normalised u in one launch
+            mat = axisangle2mat(self.axisangle)
+            x, u = psf_transform(mat, slice_idx, xyz, self.psf_sigma, noise, self.inr.bounding_box)
+            results = self.net_forward_fused(x, slice_idx, u)
         else:
+            sigma = self.psf_sigma[slice_idx][:, None]
+            pose = self.axisangle[slice_idx][:, None]
+            x = ax_transform_points(pose, xyz[:, None] + noise * sigma, self.trans_first)
             se = self.slice_embedding(slice_idx)[:, None].expand(-1, S, -1) if a.n_features_slice else None
             results = self.net_forward(x, se)
         density = results["density"]
@@ -260,14 +264,15 @@ class NeSVoR(nn.Module):
         return (getattr(a, "fused_mlp", True) and a.dtype == torch.float32 and self.axisangle.is_cuda
                 and all(fused_mlp_mod.supported(n) for n in nets))
 
-    def net_forward_fused(self, x: torch.Tensor, slice_idx: torch.Tensor) -> Dict[str, Any]:
+    def net_forward_fused(self, x: torch.Tensor, slice_idx: torch.Tensor, u: Optional[torch.Tensor] = None) -> Dict[str, Any]:
         """net_forward (models.py:329-355) without materialising pe (N,E) row-major, the expanded slice
         embedding or the concatenated MLP inputs: the hash grid writes feature-major (E,N) and the fused
         MLPs read [slice embedding of the pixel | matrix rows] directly."""
         a = self.args
         inr = self.inr
         B, S = x.shape[0], x.shape[1]
-        u = ((x - inr.bounding_box[0]) / (inr.bounding_box[1] - inr.bounding_box[0])).reshape(-1, 3)
+        if u is None:
+            u = ((x - inr.bounding_box[0]) / (inr.bounding_box[1] - inr.bounding_box[0])).reshape(-1, 3)
         enc = inr.encoding
         pe = hashgrid_encode(u, enc.params, enc.spec, _lib.LAYOUT_FEATURE_MAJOR, enc.grad_accum)  # (E, N)
         E = pe.shape[0]

@@ -279,6 +279,38 @@ def test_hashgrid_autograd_module(device):
     torch.testing.assert_close(x.grad.cpu(), gu, rtol=1e-4, atol=1e-3)
 
 
+# ---------------------------------------------------------------------- sampler
+@pytest.mark.parametrize("B,S", [(37, 8), (64, 256), (5, 100)])
+def test_psf_transform_vs_oracle(device, B, S):
+    """x = R(ax)(xyz + noise*sigma + t), u = (x-bb0)/(bb1-bb0), and d/d(mat) vs the oracle's
+    mat_transform_points (transform.py:259-271) under autograd.  fp32: forward to 1e-5 abs on O(100) mm
+    coordinates; the pose gradient sums S*|coord| terms -> relative 1e-4."""
+    from nesvor_amd.sampler import psf_transform
+    from oracle import nesvor_model as nm
+    from oracle import transform_convert as tc
+
+    torch.manual_seed(B)
+    n = 9
+    ax = torch.randn(n, 6) * torch.tensor([0.5, 0.5, 0.5, 20, 20, 20.0])
+    mat = tc.axisangle2mat_forward(ax).requires_grad_(True)
+    idx = torch.randint(0, n, (B,))
+    xyz = torch.randn(B, 3) * 30
+    sigma = torch.rand(n, 3) + 0.5
+    noise = torch.randn(B, S, 3)
+    bb = torch.tensor([[-150.0, -140, -130], [160, 170, 180]])
+    x_ref = nm.transform_points_trans_first(mat[idx][:, None], xyz[:, None] + noise * sigma[idx][:, None])
+    u_ref = ((x_ref - bb[0]) / (bb[1] - bb[0])).reshape(-1, 3)
+    wx, wu = torch.randn(B, S, 3), torch.randn(B * S, 3)
+    ((x_ref * wx).sum() + (u_ref * wu).sum()).backward()
+    mat_d = mat.detach().to(device).requires_grad_(True)
+    x, u = psf_transform(mat_d, idx.to(device), xyz.to(device), sigma.to(device), noise.to(device), bb.to(device))
+    ((x * wx.to(device)).sum() + (u * wu.to(device)).sum()).backward()
+    torch.testing.assert_close(x.detach().cpu(), x_ref.detach(), rtol=1e-5, atol=5e-5)
+    torch.testing.assert_close(u.detach().cpu(), u_ref.detach(), rtol=1e-5, atol=1e-6)
+    scale = float(mat.grad.abs().max())
+    assert float((mat_d.grad.cpu() - mat.grad).abs().max()) < 2e-4 * scale
+
+
 # -------------------------------------------------------------------- fused MLP
 @pytest.mark.parametrize("k_a,k_b,b_row0,rows,depth,out_dim,S,N", [
     (0, 32, 0, 32, 2, 16, 8, 1000),     # density_net (ragged N, not a multiple of 16)
