@@ -23,9 +23,10 @@
 //   tcnn-style "one atomicAdd per corner" scatter costs 8-16 ms at N = 2^20.
 //   The backward is therefore an owner-computes scatter in two launches:
 //     (1) hashgrid_bwd_aggregate: one workgroup per 256 consecutive samples
-//         (= one PSF cloud); per level the 2048 corner contributions are
-//         summed by table entry in an LDS open-addressing hash table (lanes
-//         sharing the wave leader's cell are first summed across the wave),
+//         (= one PSF cloud), sorted once by Morton code; per level a segmented
+//         wave scan sums runs of lanes in the same cell, the run tails add
+//         their 8 corner sums into an LDS open-addressing hash table with
+//         integer-CAS adds (ds_add_f32 retires ~1 lane / 3 cycles on gfx950),
 //         then the distinct (entry, grad) records are binned by table chunk
 //         and appended to that chunk's queue in HBM (one returning atomic per
 //         non-empty (workgroup, chunk) pair to reserve the span);
@@ -246,22 +247,42 @@ struct BwdPlan {
   uint64_t rec_off[NESVOR_MAX_LEVELS];         // first record of the level's queues
 };
 
-template <int F, bool CAS_ADD = true>
-__device__ __forceinline__ void lds_insert(uint32_t* keys, float* vals, uint32_t key, const float (&v)[F]) {
+// Insert (key, v[F]) into the LDS open-addressing table.  Integer CAS finds/claims the slot
+// (new slots are appended to the occupied list), the values are added with a CAS loop:
+// callers guarantee that lanes of one instruction carry distinct keys (see the segmented scan
+// below), so the loop almost never retries.
+template <int F>
+__device__ __forceinline__ void lds_insert(uint32_t* keys, float* vals, uint16_t* occ, uint32_t* n_occ, uint32_t key,
+                                           const float (&v)[F]) {
   uint32_t slot = (key * 2654435769u) >> (32 - kSlotsLog2);
   while (true) {
     const uint32_t prev = atomicCAS(&keys[slot], kEmpty, key);
-    if (prev == kEmpty || prev == key) break;
+    if (prev == kEmpty) { occ[atomicAdd(n_occ, 1u)] = (uint16_t)slot; break; }
+    if (prev == key) break;
     slot = (slot + 1) & (kSlots - 1);
   }
 #pragma unroll
-  for (int f = 0; f < F; ++f) {
-    if (CAS_ADD) lds_add_f32_cas(&vals[slot * F + f], v[f]);
-    else atomicAdd(&vals[slot * F + f], v[f]);
-  }
+  for (int f = 0; f < F; ++f) lds_add_f32_cas(&vals[slot * F + f], v[f]);
 }
 
-template <int F, int LAYOUT, bool INPUT_GRAD, int VAR = 0>
+__device__ __forceinline__ uint32_t spread3(uint32_t x) {  // 8 bits -> every third bit
+  x &= 0xffu;
+  x = (x ^ (x << 8)) & 0x0300f00fu;
+  x = (x ^ (x << 4)) & 0x030c30c3u;
+  x = (x ^ (x << 2)) & 0x09249249u;
+  return x;
+}
+
+// Phase 1 of the backward.  One workgroup = 256 consecutive samples (one PSF cloud).
+//  * once per workgroup: bitonic-sort the samples by the Morton code of their finest-level cell, so
+//    that at EVERY level lanes falling into the same cell sit (almost always) next to each other;
+//  * per level: each lane forms its 8 corner contributions, a segmented wave scan sums runs of equal
+//    cells, and only the last lane of a run inserts into the LDS table -> within one instruction all
+//    active lanes carry distinct keys, so integer-CAS adds do not collide (ds_add_f32 would cost
+//    ~3 cycles per lane on gfx950);
+//  * the occupied-slot list makes flush and re-initialisation proportional to the number of
+//    distinct entries (8 at the coarsest level, ~1500 at the finest), not to the table size.
+template <int F, int LAYOUT, bool INPUT_GRAD>
 __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_t g, const BwdPlan plan,
                                                               const float* __restrict__ u,
                                                               const float* __restrict__ table,
@@ -271,28 +292,62 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
                                                               uint32_t* __restrict__ records, int64_t N) {
   __shared__ uint32_t keys[kSlots];
   __shared__ float vals[kSlots * F];
+  __shared__ uint16_t occ[2048];
   __shared__ uint32_t bcount[kMaxChunks];
   __shared__ uint32_t bbase[kMaxChunks];
+  __shared__ uint32_t sortbuf[256];
+  __shared__ uint32_t n_occ;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  const int64_t base = (int64_t)blockIdx.x * 256;
+  const int E = g.n_levels * F;
+#pragma unroll
+  for (int j = 0; j < kSlots / 256; ++j) {
+    keys[tid + j * 256] = kEmpty;
+#pragma unroll
+    for (int f = 0; f < F; ++f) vals[(tid + j * 256) * F + f] = 0.f;
+  }
+  if (tid < kMaxChunks) bcount[tid] = 0;
+  if (tid == 0) n_occ = 0;
+
+  // ---- sort the workgroup's samples by Morton code of the finest-level cell
+  uint32_t sv;
+  {
+    const int64_t i0 = base + tid;
+    uint32_t code = 0x00ffffffu;
+    if (i0 < N) {
+      const LevelParams pf = load_level(g, g.n_levels - 1);
+      const CellPos c = locate(pf, u[3 * i0], u[3 * i0 + 1], u[3 * i0 + 2]);
+      code = spread3(c.gx) | (spread3(c.gy) << 1) | (spread3(c.gz) << 2);
+    }
+    sv = (code << 8) | (uint32_t)tid;
+#pragma unroll 1
+    for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll 1
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        uint32_t other;
+        if (j < 64) {
+          other = __shfl_xor(sv, j, 64);
+        } else {
+          __syncthreads();
+          sortbuf[tid] = sv;
+          __syncthreads();
+          other = sortbuf[tid ^ j];
+        }
+        const bool up = (tid & k) == 0, lower = (tid & j) == 0;
+        const uint32_t mn = min(sv, other), mx = max(sv, other);
+        sv = (lower == up) ? mn : mx;
+      }
+    }
+  }
+  const int64_t i = base + (sv & 255u);  // the sample this lane owns from now on
   const bool valid = i < N;
   const int64_t ii = valid ? i : N - 1;
   const float ux = u[3 * ii], uy = u[3 * ii + 1], uz = u[3 * ii + 2];
-  const int E = g.n_levels * F;
   float gux = 0.f, guy = 0.f, guz = 0.f;
-  constexpr int kPerThread = kSlots / 256;
+  __syncthreads();
 
   for (int level = 0; level < g.n_levels; ++level) {
     const LevelParams p = load_level(g, level);
-#pragma unroll
-    for (int j = 0; j < kPerThread; ++j) {
-      keys[tid + j * 256] = kEmpty;
-#pragma unroll
-      for (int f = 0; f < F; ++f) vals[(tid + j * 256) * F + f] = 0.f;
-    }
-    if (tid < kMaxChunks) bcount[tid] = 0;
-    __syncthreads();
-
     const CellPos c = locate(p, ux, uy, uz);
     float dy[F];
     if constexpr (LAYOUT == NESVOR_LAYOUT_ROW_MAJOR) {
@@ -333,71 +388,56 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
 #pragma unroll
       for (int f = 0; f < F; ++f) val[k][f] = w * dy[f];
     }
-    // wave pre-merge: lanes sharing the leader's cell are summed across the wave (DPP), the leader inserts.
-    // The size of the last leader group seen also picks the LDS add flavour for the remaining lanes:
-    // crowded cells -> ds_add_f32 (serial but conflict-insensitive), sparse cells -> CAS loop (fast when
-    // conflict-free).  Measured on gfx950: ds_add_f32 192-255 cycles / wave-instr at any conflict degree,
-    // ds_cmpst_rtn_b32 ~7 cycles conflict-free, ~60 at 8-way.
-    bool pending = valid;
-    int last_group = 0;
-    for (int round = 0; round < ((VAR & 1) ? 0 : 4); ++round) {
-      const unsigned long long rem = __ballot(pending);
-      if (rem == 0) break;
-      const int leader = __ffsll((long long)rem) - 1;
-      const uint32_t lx = __shfl(c.gx, leader, 64), ly = __shfl(c.gy, leader, 64), lz = __shfl(c.gz, leader, 64);
-      const bool mine = pending && c.gx == lx && c.gy == ly && c.gz == lz;
-      last_group = __popcll(__ballot(mine));
-      if (last_group < 8) break;
+    // segmented inclusive scan over the wave: a run = consecutive lanes in the same cell
+    const uint32_t px_ = __shfl_up(c.gx, 1, 64), py_ = __shfl_up(c.gy, 1, 64), pz_ = __shfl_up(c.gz, 1, 64);
+    const bool vprev = __shfl_up((int)valid, 1, 64) != 0;
+    bool head = lane == 0 || !valid || !vprev || c.gx != px_ || c.gy != py_ || c.gz != pz_;
+    const bool next_head = __shfl_down((int)head, 1, 64) != 0;
+    const bool tail = valid && (lane == 63 || next_head);
+    int flag = head ? 1 : 0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        float sred[F];
+    for (int d = 1; d < 64; d <<= 1) {
+      const int fprev = __shfl_up(flag, d, 64);
+      const bool take = lane >= d && flag == 0;
 #pragma unroll
-        for (int f = 0; f < F; ++f) sred[f] = (VAR & 16) ? wave_sum(mine ? val[k][f] : 0.f) : wave_sum_dpp(mine ? val[k][f] : 0.f);
-        if (lane == leader) lds_insert<F, false>(keys, vals, idx[k], sred);
-      }
-      pending = pending && !mine;
-    }
-    if (!(VAR & 2)) {
-      const bool sparse = (VAR & 8) ? false : ((VAR & 32) ? true : last_group <= 2);
-      if (sparse) {
-        if (pending) {
+      for (int k = 0; k < 8; ++k)
 #pragma unroll
-          for (int k = 0; k < 8; ++k) lds_insert<F, true>(keys, vals, idx[k], val[k]);
+        for (int f = 0; f < F; ++f) {
+          const float o = __shfl_up(val[k][f], d, 64);
+          val[k][f] += take ? o : 0.f;
         }
-      } else {
-        if (pending) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) lds_insert<F, false>(keys, vals, idx[k], val[k]);
-        }
-      }
+      flag |= (lane >= d) ? fprev : 1;
     }
-    if (VAR & 2) {  // ablation: keep the values live without touching LDS
+    if (tail) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(val[k][0]), "v"(idx[k]));
+      for (int k = 0; k < 8; ++k) lds_insert<F>(keys, vals, occ, &n_occ, idx[k], val[k]);
     }
     __syncthreads();
-    if (VAR & 4) continue;  // ablation: no binning / record writes
 
-    // bin the distinct records by table chunk and append them to the chunk queues
-    uint32_t rank[kPerThread];
+    // bin the distinct records by table chunk, reserve queue space, write, and reset the touched slots
+    const uint32_t n = n_occ;
+    constexpr int kPer = 2048 / 256;
+    uint32_t rank[kPer];
 #pragma unroll
-    for (int j = 0; j < kPerThread; ++j) {
-      const uint32_t key = keys[tid + j * 256];
-      rank[j] = (key != kEmpty) ? atomicAdd(&bcount[key >> plan.chunk_shift], 1u) : 0u;
+    for (int j = 0; j < kPer; ++j) {
+      const uint32_t t = tid + j * 256;
+      rank[j] = (t < n) ? atomicAdd(&bcount[keys[occ[t]] >> plan.chunk_shift], 1u) : 0u;
     }
     __syncthreads();
     const uint32_t nb = plan.n_chunks[level];
     if (tid < nb) {
       const uint32_t cnt = bcount[tid];
       bbase[tid] = cnt ? atomicAdd(&tails[plan.bucket_base[level] + tid], cnt) : 0u;
+      bcount[tid] = 0;
     }
     __syncthreads();
     const uint32_t cap = plan.cap[level];
 #pragma unroll
-    for (int j = 0; j < kPerThread; ++j) {
-      const int slot = tid + j * 256;
-      const uint32_t key = keys[slot];
-      if (key != kEmpty) {
+    for (int j = 0; j < kPer; ++j) {
+      const uint32_t t = tid + j * 256;
+      if (t < n) {
+        const uint32_t slot = occ[t];
+        const uint32_t key = keys[slot];
         const uint32_t b = key >> plan.chunk_shift;
         const uint32_t pos = bbase[b] + rank[j];
         if (pos < cap) {
@@ -409,8 +449,12 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
 #pragma unroll
           for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)p.offset + key) * F + f, vals[slot * F + f]);
         }
+        keys[slot] = kEmpty;
+#pragma unroll
+        for (int f = 0; f < F; ++f) vals[slot * F + f] = 0.f;
       }
     }
+    if (tid == 0) n_occ = 0;
     __syncthreads();
   }
   if constexpr (INPUT_GRAD) {
@@ -589,34 +633,6 @@ extern "C" int nesvor_hashgrid_backward_atomic(const nesvor_grid_t* grid, const 
   if (N <= 0) return 0;
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
   DISPATCH_F_LAYOUT(launch_bwd, grid, u, table, dpe, grad_table, grad_u, N, (hipStream_t)stream);
-}
-
-// Debug/ablation entry (not part of the public ABI): F=2, feature-major, no input grad.
-extern "C" int nesvor_hashgrid_backward_debug(const nesvor_grid_t* g, const float* u, const float* table,
-                                              const float* dpe, float* gt, int64_t N, void* workspace, int variant,
-                                              int run_owner, void* stream) {
-  BwdPlan plan;
-  uint64_t n_rec;
-  if (!make_plan(g, N, &plan, &n_rec)) return (int)hipErrorInvalidValue;
-  hipStream_t st = (hipStream_t)stream;
-  uint32_t* tails = reinterpret_cast<uint32_t*>(workspace);
-  uint32_t* records = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + kTailBytes);
-  (void)hipMemsetAsync(tails, 0, kTailBytes, st);
-  dim3 grid((unsigned)((N + 255) / 256)), block(256);
-#define LAUNCH_VAR(V)                                                                                          \
-  case V:                                                                                                      \
-    hipLaunchKernelGGL((hashgrid_bwd_aggregate<2, 1, false, V>), grid, block, 0, st, *g, plan, u, table, dpe, gt, \
-                       (float*)nullptr, tails, records, N);                                                    \
-    break;
-  switch (variant) {
-    LAUNCH_VAR(0) LAUNCH_VAR(1) LAUNCH_VAR(2) LAUNCH_VAR(3) LAUNCH_VAR(4) LAUNCH_VAR(6) LAUNCH_VAR(7)
-    LAUNCH_VAR(8) LAUNCH_VAR(16) LAUNCH_VAR(24) LAUNCH_VAR(9) LAUNCH_VAR(32)
-    default: return (int)hipErrorInvalidValue;
-  }
-#undef LAUNCH_VAR
-  if (run_owner == 1) hipLaunchKernelGGL((hashgrid_bwd_owner<2, true>), dim3(owner_grid(g, plan)), block, 0, st, *g, plan, tails, records, gt);
-  if (run_owner == 2) hipLaunchKernelGGL((hashgrid_bwd_owner<2, false>), dim3(owner_grid(g, plan)), block, 0, st, *g, plan, tails, records, gt);
-  return (int)hipGetLastError();
 }
 
 extern "C" int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t* grid, int64_t N) {

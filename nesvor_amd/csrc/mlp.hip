@@ -35,7 +35,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWidth = 64;      // hidden width (the reference's default and BASELINE's config)
 constexpr int kHB = kWidth / 16;  // feature blocks per hidden layer
-constexpr int kG = 4;           // 16-sample groups per wave per tile (64 samples / wave, 256 / workgroup)
+#ifndef NESVOR_MLP_G
+#define NESVOR_MLP_G 2
+#endif
+constexpr int kG = NESVOR_MLP_G;  // 16-sample groups per wave per tile; 2 keeps the kernels under 128 VGPRs (>= 4 waves/SIMD)
 constexpr int kMaxLayers = NESVOR_MAX_MLP_LAYERS;  // linear layers incl. the output layer
 
 struct MlpArgs {
@@ -435,7 +438,7 @@ extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, cons
   for (int l = 0; l < kMaxLayers; ++l) a.H[l] = (saved_hidden != nullptr && l < net->n_hidden) ? saved_hidden[l] : nullptr;
   const int kb1 = (net->k_a + net->k_b + 15) / 16;
   const int64_t n_tiles = ((N + 15) / 16 + 4 * kG - 1) / (4 * kG);
-  dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512));
+  dim3 grid((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
   return launch_kb(mlp_fwd_kernel<1>, mlp_fwd_kernel<2>, mlp_fwd_kernel<3>, mlp_fwd_kernel<4>, kb1, grid,
                    fwd_lds_bytes(a.n_linear, kb1), (hipStream_t)stream, a);
 }
@@ -455,7 +458,7 @@ extern "C" int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, con
   }
   const int kb1 = (net->k_a + net->k_b + 15) / 16;
   const int64_t n_tiles = ((N + 15) / 16 + 4 * kG - 1) / (4 * kG);
-  dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512));
+  dim3 grid((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
   e = launch_kb(mlp_bwd_dx_kernel<1>, mlp_bwd_dx_kernel<2>, mlp_bwd_dx_kernel<3>, mlp_bwd_dx_kernel<4>, kb1, grid,
                 bwd_lds_bytes(a.n_linear, kb1), (hipStream_t)stream, a);
   if (e) return e;

@@ -13,7 +13,7 @@ from torch.autograd import Function
 
 from . import _lib
 
-N_PARTIAL = 256  # workgroups (= partial sums) of the dW kernel
+N_PARTIAL = 1024  # workgroups (= partial sums) of the dW kernel: 4 per CU so loads overlap MFMAs
 
 
 def linear_layers(seq: nn.Sequential):
