@@ -43,6 +43,14 @@ int nesvor_axisangle2mat_backward_f64(const double* grad_mat, const double* ax, 
 int nesvor_mat2axisangle_forward_f64(const double* mat, double* ax, int n, void* stream);
 int nesvor_mat2axisangle_backward_f64(const double* mat, const double* grad_ax, double* grad_mat, int n, void* stream);
 
+/* Pose regulariser, forward + gradient in one launch.  Replaces NeSVoR.trans_loss
+ * (nesvor/nesvor/models.py:357-363: axisangle2mat x2, RigidTransform.inv/.compose
+ * transform.py:44-63, mat2axisangle, and their backwards):
+ *   err_k = axisangle(inv(T_init,k) o T_k);  loss = mean(err_R^2) + 1e-3 mean(err_T^2)
+ * loss_per_slice (n): each slice's share of the loss (sum == loss);
+ * grad_ax (n,6): d loss / d ax. */
+int nesvor_trans_loss(const float* ax, const float* ax_init, float* loss_per_slice, float* grad_ax, int n, void* stream);
+
 /* ------------------------------------------------------------------------
  * Slice acquisition forward operator A.  Replaces
  * `nesvor.slice_acq_cuda.forward`

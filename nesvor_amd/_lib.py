@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -56,6 +56,7 @@ _SIGNATURES = {
     "nesvor_axisangle2mat_backward_f64": ([_P, _P, _P, c_int, _P], c_int),
     "nesvor_mat2axisangle_forward_f64": ([_P, _P, c_int, _P], c_int),
     "nesvor_mat2axisangle_backward_f64": ([_P, _P, _P, c_int, _P], c_int),
+    "nesvor_trans_loss": ([_P, _P, _P, _P, c_int, _P], c_int),
     "nesvor_slice_acq_forward": (
         [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 9 + [c_float, c_int, _P],
         c_int,

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd(const nesvor_grid_t g, const
 constexpr int kSlotsLog2 = 12;
 constexpr int kSlots = 1 << kSlotsLog2;       // LDS hash table: 256 samples x 8 corners <= 2048 distinct keys
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-constexpr int kMaxChunks = 256;               // table chunks (queues) per level
+constexpr int kMaxChunks = 128;               // table chunks (queues) per level (LDS budget: 3 workgroups / CU)
 constexpr int kOwnerLdsFloats = 16384;        // 64 KiB accumulator per owner workgroup
 
 struct BwdPlan {
@@ -292,10 +292,11 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
                                                               uint32_t* __restrict__ records, int64_t N) {
   __shared__ uint32_t keys[kSlots];
   __shared__ float vals[kSlots * F];
-  __shared__ uint16_t occ[2048];
+  __shared__ uint32_t occ_words[1024];  // occupied-slot list (uint16 x 2048); doubles as the sort exchange buffer
+  uint16_t* occ = reinterpret_cast<uint16_t*>(occ_words);
   __shared__ uint32_t bcount[kMaxChunks];
   __shared__ uint32_t bbase[kMaxChunks];
-  __shared__ uint32_t sortbuf[256];
+  uint32_t* sortbuf = occ_words;
   __shared__ uint32_t n_occ;
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t base = (int64_t)blockIdx.x * 256;
@@ -346,10 +347,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
   float gux = 0.f, guy = 0.f, guz = 0.f;
   __syncthreads();
 
-  for (int level = 0; level < g.n_levels; ++level) {
-    const LevelParams p = load_level(g, level);
-    const CellPos c = locate(p, ux, uy, uz);
-    float dy[F];
+  auto load_dy = [&](int level, float (&dy)[F]) {
     if constexpr (LAYOUT == NESVOR_LAYOUT_ROW_MAJOR) {
       const float* o = dpe + (size_t)ii * E + level * F;
 #pragma unroll
@@ -358,10 +356,17 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
 #pragma unroll
       for (int f = 0; f < F; ++f) dy[f] = valid ? dpe[(size_t)(level * F + f) * N + ii] : 0.f;
     }
-    uint32_t idx[8];
+  };
+
+  // Everything of a level that needs no LDS table: corner indices, run-summed corner values, tail flag.
+  uint32_t idx[8];
+  float val[8][F];
+  bool tail;
+  auto prepare = [&](int level, const float (&dy)[F]) {
+    const LevelParams p = load_level(g, level);
+    const CellPos c = locate(p, ux, uy, uz);
 #pragma unroll
     for (int k = 0; k < 8; ++k) idx[k] = corner_index(p, c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + (k >> 2));
-
     if constexpr (INPUT_GRAD) {
       const float* tab = table + (size_t)p.offset * F;
       float v[8][F];
@@ -380,8 +385,6 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
       }
       gux = fmaf(p.scale, sx, gux); guy = fmaf(p.scale, sy, guy); guz = fmaf(p.scale, sz, guz);
     }
-
-    float val[8][F];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float w = ((k & 1) ? c.wx : 1.f - c.wx) * (((k >> 1) & 1) ? c.wy : 1.f - c.wy) * ((k >> 2) ? c.wz : 1.f - c.wz);
@@ -391,9 +394,9 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
     // segmented inclusive scan over the wave: a run = consecutive lanes in the same cell
     const uint32_t px_ = __shfl_up(c.gx, 1, 64), py_ = __shfl_up(c.gy, 1, 64), pz_ = __shfl_up(c.gz, 1, 64);
     const bool vprev = __shfl_up((int)valid, 1, 64) != 0;
-    bool head = lane == 0 || !valid || !vprev || c.gx != px_ || c.gy != py_ || c.gz != pz_;
+    const bool head = lane == 0 || !valid || !vprev || c.gx != px_ || c.gy != py_ || c.gz != pz_;
     const bool next_head = __shfl_down((int)head, 1, 64) != 0;
-    const bool tail = valid && (lane == 63 || next_head);
+    tail = valid && (lane == 63 || next_head);
     int flag = head ? 1 : 0;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -408,15 +411,21 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
         }
       flag |= (lane >= d) ? fprev : 1;
     }
+  };
+
+  float dy_cur[F], dy_next[F];
+  load_dy(0, dy_cur);
+  if (g.n_levels > 1) load_dy(1, dy_next);
+  prepare(0, dy_cur);
+  constexpr int kPer = 2048 / 256;
+  for (int level = 0; level < g.n_levels; ++level) {
     if (tail) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) lds_insert<F>(keys, vals, occ, &n_occ, idx[k], val[k]);
     }
     __syncthreads();
-
-    // bin the distinct records by table chunk, reserve queue space, write, and reset the touched slots
+    // bin the distinct records by table chunk
     const uint32_t n = n_occ;
-    constexpr int kPer = 2048 / 256;
     uint32_t rank[kPer];
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
@@ -424,12 +433,23 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
       rank[j] = (t < n) ? atomicAdd(&bcount[keys[occ[t]] >> plan.chunk_shift], 1u) : 0u;
     }
     __syncthreads();
+    // reserve queue space: one returning (memory-side, ~2 us) atomic per non-empty chunk ...
     const uint32_t nb = plan.n_chunks[level];
+    uint32_t my_base = 0;
     if (tid < nb) {
       const uint32_t cnt = bcount[tid];
-      bbase[tid] = cnt ? atomicAdd(&tails[plan.bucket_base[level] + tid], cnt) : 0u;
+      if (cnt) my_base = atomicAdd(&tails[plan.bucket_base[level] + tid], cnt);
       bcount[tid] = 0;
     }
+    // ... and hide its latency behind the next level's register-only work
+    const uint32_t offset_cur = g.offset[level];
+    if (level + 1 < g.n_levels) {
+#pragma unroll
+      for (int f = 0; f < F; ++f) dy_cur[f] = dy_next[f];
+      if (level + 2 < g.n_levels) load_dy(level + 2, dy_next);
+      prepare(level + 1, dy_cur);
+    }
+    if (tid < nb) bbase[tid] = my_base;
     __syncthreads();
     const uint32_t cap = plan.cap[level];
 #pragma unroll
@@ -447,7 +467,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
           for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(vals[slot * F + f]);
         } else {  // queue full: exact fallback
 #pragma unroll
-          for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)p.offset + key) * F + f, vals[slot * F + f]);
+          for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)offset_cur + key) * F + f, vals[slot * F + f]);
         }
         keys[slot] = kEmpty;
 #pragma unroll

@@ -26,11 +26,7 @@ template <> __device__ __forceinline__ float t_atan2<float>(float y, float x) { 
 template <> __device__ __forceinline__ double t_atan2<double>(double y, double x) { return atan2(y, x); }
 
 template <typename T>
-__global__ void ax2mat_fwd(const T* __restrict__ ax, T* __restrict__ mat, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const T* a = ax + (size_t)i * 6;
-  T* m = mat + (size_t)i * 12;
+__device__ __forceinline__ void ax2mat_fwd_one(const T* a, T* m) {
   T x = a[0], y = a[1], z = a[2];
   T th2 = x * x + y * y + z * z;
   T R[9];
@@ -58,12 +54,14 @@ __global__ void ax2mat_fwd(const T* __restrict__ ax, T* __restrict__ mat, int n)
 }
 
 template <typename T>
-__global__ void ax2mat_bwd(const T* __restrict__ gmat, const T* __restrict__ ax, T* __restrict__ gax, int n) {
+__global__ void ax2mat_fwd(const T* __restrict__ ax, T* __restrict__ mat, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const T* a = ax + (size_t)i * 6;
-  const T* g = gmat + (size_t)i * 12;
-  T* o = gax + (size_t)i * 6;
+  ax2mat_fwd_one(ax + (size_t)i * 6, mat + (size_t)i * 12);
+}
+
+template <typename T>
+__device__ __forceinline__ void ax2mat_bwd_one(const T* g, const T* a, T* o) {
   T G[3][3];
 #pragma unroll
   for (int r = 0; r < 3; ++r)
@@ -101,6 +99,13 @@ __global__ void ax2mat_bwd(const T* __restrict__ gmat, const T* __restrict__ ax,
   o[3] = g[3]; o[4] = g[7]; o[5] = g[11];
 }
 
+template <typename T>
+__global__ void ax2mat_bwd(const T* __restrict__ gmat, const T* __restrict__ ax, T* __restrict__ gax, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ax2mat_bwd_one(gmat + (size_t)i * 12, ax + (size_t)i * 6, gax + (size_t)i * 6);
+}
+
 // Quaternion (w,x,y,z) from R with the reference's branch selection; `s` is the
 // branch's 2*sqrt(trace-like) value and `br` the branch id.
 template <typename T>
@@ -129,11 +134,7 @@ __device__ __forceinline__ void quat_from_R(const T* m, T q[4], T* s_out, int* b
 }
 
 template <typename T>
-__global__ void mat2ax_fwd(const T* __restrict__ mat, T* __restrict__ ax, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const T* m = mat + (size_t)i * 12;
-  T* o = ax + (size_t)i * 6;
+__device__ __forceinline__ void mat2ax_fwd_one(const T* m, T* o) {
   T q[4], s;
   int br;
   quat_from_R(m, q, &s, &br);
@@ -147,12 +148,14 @@ __global__ void mat2ax_fwd(const T* __restrict__ mat, T* __restrict__ ax, int n)
 }
 
 template <typename T>
-__global__ void mat2ax_bwd(const T* __restrict__ mat, const T* __restrict__ gax, T* __restrict__ gmat, int n) {
+__global__ void mat2ax_fwd(const T* __restrict__ mat, T* __restrict__ ax, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const T* m = mat + (size_t)i * 12;
-  const T* ga = gax + (size_t)i * 6;
-  T* o = gmat + (size_t)i * 12;
+  mat2ax_fwd_one(mat + (size_t)i * 12, ax + (size_t)i * 6);
+}
+
+template <typename T>
+__device__ __forceinline__ void mat2ax_bwd_one(const T* m, const T* ga, T* o) {
   T q[4], s;
   int br;
   quat_from_R(m, q, &s, &br);
@@ -203,6 +206,56 @@ __global__ void mat2ax_bwd(const T* __restrict__ mat, const T* __restrict__ gax,
   o[8] = (gQ - gB) / s;     o[9] = (gR + gA) / s;     o[10] = ds2 * dS;       o[11] = ga[5];
 }
 
+template <typename T>
+__global__ void mat2ax_bwd(const T* __restrict__ mat, const T* __restrict__ gax, T* __restrict__ gmat, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  mat2ax_bwd_one(mat + (size_t)i * 12, gax + (size_t)i * 6, gmat + (size_t)i * 12);
+}
+
+// Pose regulariser of NeSVoR.trans_loss (nesvor/nesvor/models.py:357-363), forward AND gradient in one
+// launch (the reference runs axisangle2mat x2, inv, compose, mat2axisangle and their backwards: ~20
+// launches incl. batched 3x3 GEMMs, every iteration):
+//   err = axisangle( inv(T_init) o T_cur );  loss = mean(err_R^2) + 1e-3 mean(err_T^2)
+// per slice: loss_k (its share of the two means) and d loss / d axisangle_k.
+__global__ void trans_loss_kernel(const float* __restrict__ ax, const float* __restrict__ ax_init,
+                                  float* __restrict__ loss_k, float* __restrict__ grad_ax, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a[6], a0[6], X[12], Y[12], M[12], err[6];
+#pragma unroll
+  for (int d = 0; d < 6; ++d) { a[d] = ax[(size_t)i * 6 + d]; a0[d] = ax_init[(size_t)i * 6 + d]; }
+  ax2mat_fwd_one(a, X);
+  ax2mat_fwd_one(a0, Y);
+  // inv(Y) = [Ry^T | -Ry ty];  compose(inv(Y), X): R = Ry^T Rx,  t = tx + Rx^T (-Ry ty)
+  float w[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) w[r] = -(Y[r * 4 + 0] * Y[3] + Y[r * 4 + 1] * Y[7] + Y[r * 4 + 2] * Y[11]);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) M[r * 4 + c] = Y[0 * 4 + r] * X[0 * 4 + c] + Y[1 * 4 + r] * X[1 * 4 + c] + Y[2 * 4 + r] * X[2 * 4 + c];
+    M[r * 4 + 3] = X[r * 4 + 3] + (X[0 * 4 + r] * w[0] + X[1 * 4 + r] * w[1] + X[2 * 4 + r] * w[2]);
+  }
+  mat2ax_fwd_one(M, err);
+  const float cr = 1.f / (3.f * n), ct = 1e-3f / (3.f * n);
+  loss_k[i] = cr * (err[0] * err[0] + err[1] * err[1] + err[2] * err[2]) + ct * (err[3] * err[3] + err[4] * err[4] + err[5] * err[5]);
+  float gerr[6] = {2 * cr * err[0], 2 * cr * err[1], 2 * cr * err[2], 2 * ct * err[3], 2 * ct * err[4], 2 * ct * err[5]};
+  float gM[12], gX[12], g[6];
+  mat2ax_bwd_one(M, gerr, gM);
+  // dRx = Ry gR  -  w gt^T (from t = tx + Rx^T w: dRx[i][k] += w_i gt_k),  dtx = gt
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      gX[r * 4 + c] = Y[r * 4 + 0] * gM[0 * 4 + c] + Y[r * 4 + 1] * gM[1 * 4 + c] + Y[r * 4 + 2] * gM[2 * 4 + c] + w[r] * gM[c * 4 + 3];
+    gX[r * 4 + 3] = gM[r * 4 + 3];
+  }
+  ax2mat_bwd_one(gX, a, g);
+#pragma unroll
+  for (int d = 0; d < 6; ++d) grad_ax[(size_t)i * 6 + d] = g[d];
+}
+
 template <typename K, typename... Args>
 int launch1d(K kernel, int n, void* stream, Args... args) {
   if (n <= 0) return 0;
@@ -212,6 +265,11 @@ int launch1d(K kernel, int n, void* stream, Args... args) {
 }
 
 }  // namespace
+
+extern "C" int nesvor_trans_loss(const float* ax, const float* ax_init, float* loss_per_slice, float* grad_ax, int n,
+                                 void* stream) {
+  return launch1d(trans_loss_kernel, n, stream, ax, ax_init, loss_per_slice, grad_ax);
+}
 
 extern "C" {
 int nesvor_axisangle2mat_forward(const float* ax, float* mat, int n, void* st) { return launch1d(ax2mat_fwd<float>, n, st, ax, mat); }

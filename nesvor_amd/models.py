@@ -26,7 +26,7 @@ from . import mlp as fused_mlp_mod
 from . import tinycudann as tcnn
 from .encoding import hashgrid_encode
 from .sampler import psf_transform
-from .transform import RigidTransform, ax_transform_points, axisangle2mat, mat_transform_points
+from .transform import RigidTransform, ax_transform_points, axisangle2mat, mat_transform_points, trans_loss_fused
 from .utils import resolution2sigma
 
 # loss / regulariser keys (models.py:14-19)
@@ -301,6 +301,8 @@ class NeSVoR(nn.Module):
         return results
 
     def trans_loss(self, trans_first: bool = True) -> torch.Tensor:
+        if trans_first and self.axisangle.is_cuda and self.axisangle.dtype == torch.float32 and getattr(self.args, "fused_mlp", True):
+            return trans_loss_fused(self.axisangle, self.axisangle_init)
         cur = RigidTransform(self.axisangle, trans_first=trans_first)
         init = RigidTransform(self.axisangle_init, trans_first=trans_first)
         err = init.inv().compose(cur).axisangle(trans_first=trans_first)

@@ -74,6 +74,27 @@ def test_transform_kernels_vs_oracle_fwd_bwd(device, dtype):
     assert float(((gk - go).abs() / scale).max()) < (5e-4 if dtype == torch.float32 else 1e-8)
 
 
+def test_trans_loss_fused_vs_oracle(device):
+    """Fused pose regulariser (forward + gradient) vs the oracle's composition of the four conversions."""
+    from nesvor_amd.transform import trans_loss_fused
+    from oracle import nesvor_model as nm
+
+    torch.manual_seed(0)
+    ax0 = torch.randn(231, 6) * torch.tensor([1.0, 1.0, 1.0, 40, 40, 40])
+    ax = (ax0 + torch.randn(231, 6) * torch.tensor([0.05, 0.05, 0.05, 1.0, 1.0, 1.0])).requires_grad_(True)
+    ref = nm.trans_loss(ax, ax0)
+    ref.backward()
+    axd = ax.detach().to(device).requires_grad_(True)
+    got = trans_loss_fused(axd, ax0.to(device))
+    (3.0 * got).backward()
+    assert abs(float(got) - float(ref)) <= 2e-4 * abs(float(ref)) + 1e-9
+    scale = float(ax.grad.abs().max())
+    assert float((axd.grad.cpu() / 3.0 - ax.grad).abs().max()) < 2e-3 * scale
+    # identical poses: err == 0 (small-angle branch), zero gradient
+    z = trans_loss_fused(ax0.to(device).requires_grad_(True), ax0.to(device))
+    assert float(z) < 1e-9
+
+
 def test_transform_ops_reject_bad_input(device):
     from nesvor_amd import transform_convert_cuda as K
 
