@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd(const nesvor_grid_t g, const
 constexpr int kSlotsLog2 = 12;
 constexpr int kSlots = 1 << kSlotsLog2;       // LDS hash table: 256 samples x 8 corners <= 2048 distinct keys
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-constexpr int kMaxChunks = 128;               // table chunks (queues) per level (LDS budget: 3 workgroups / CU)
+constexpr int kMaxChunks = 64;                // table chunks (queues) per level (LDS budget: 3 workgroups / CU)
 constexpr int kOwnerLdsFloats = 16384;        // 64 KiB accumulator per owner workgroup
 
 struct BwdPlan {
@@ -247,22 +247,59 @@ struct BwdPlan {
   uint64_t rec_off[NESVOR_MAX_LEVELS];         // first record of the level's queues
 };
 
-// Insert (key, v[F]) into the LDS open-addressing table.  Integer CAS finds/claims the slot
-// (new slots are appended to the occupied list), the values are added with a CAS loop:
-// callers guarantee that lanes of one instruction carry distinct keys (see the segmented scan
-// below), so the loop almost never retries.
+// Insert 8 (key, v[F]) pairs per active lane into the LDS open-addressing table.  All LDS atomics are
+// issued in batches (8 slot claims, then 8F reads, then 8F compare-and-swaps) so that a wave pays a
+// handful of LDS round trips per level instead of one per atomic.  Integer CAS finds/claims the slot
+// (new slots are appended to the occupied list); the values are added with CAS loops: callers
+// guarantee that lanes of one instruction carry distinct keys (segmented scan below), so retries only
+// come from other waves and are rare.
 template <int F>
-__device__ __forceinline__ void lds_insert(uint32_t* keys, float* vals, uint16_t* occ, uint32_t* n_occ, uint32_t key,
-                                           const float (&v)[F]) {
-  uint32_t slot = (key * 2654435769u) >> (32 - kSlotsLog2);
-  while (true) {
-    const uint32_t prev = atomicCAS(&keys[slot], kEmpty, key);
-    if (prev == kEmpty) { occ[atomicAdd(n_occ, 1u)] = (uint16_t)slot; break; }
-    if (prev == key) break;
-    slot = (slot + 1) & (kSlots - 1);
-  }
+__device__ __forceinline__ void lds_insert8(uint32_t* keys, float* vals, uint16_t* occ, uint32_t* n_occ, bool active,
+                                            const uint32_t (&key)[8], const float (&v)[8][F]) {
+  uint32_t slot[8], prev[8];
 #pragma unroll
-  for (int f = 0; f < F; ++f) lds_add_f32_cas(&vals[slot * F + f], v[f]);
+  for (int k = 0; k < 8; ++k) slot[k] = (key[k] * 2654435769u) >> (32 - kSlotsLog2);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) prev[k] = active ? atomicCAS(&keys[slot[k]], kEmpty, key[k]) : key[k];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    bool fresh = active && prev[k] == kEmpty;
+    if (active && prev[k] != kEmpty && prev[k] != key[k]) {  // collision: linear probing (rare at load <= 0.5)
+      while (true) {
+        slot[k] = (slot[k] + 1) & (kSlots - 1);
+        const uint32_t p2 = atomicCAS(&keys[slot[k]], kEmpty, key[k]);
+        if (p2 == kEmpty) { fresh = true; break; }
+        if (p2 == key[k]) break;
+      }
+    }
+    if (fresh) occ[atomicAdd(n_occ, 1u)] = (uint16_t)slot[k];
+  }
+  if (!active) return;
+  uint32_t old[8][F], got[8][F];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+      old[k][f] = *reinterpret_cast<volatile uint32_t*>(&vals[slot[k] * F + f]);
+  unsigned long long pending = (8 * F >= 64) ? ~0ull : ((1ull << (8 * F)) - 1ull);
+  do {
+    // issue every compare-and-swap of the batch before looking at any result
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const bool p = (pending >> (k * F + f)) & 1ull;
+        const uint32_t want = p ? __float_as_uint(__uint_as_float(old[k][f]) + v[k][f]) : old[k][f];
+        got[k][f] = atomicCAS(reinterpret_cast<uint32_t*>(&vals[slot[k] * F + f]), old[k][f], want);
+      }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        if (got[k][f] == old[k][f]) pending &= ~(1ull << (k * F + f));
+        old[k][f] = got[k][f];
+      }
+  } while (pending);
 }
 
 __device__ __forceinline__ uint32_t spread3(uint32_t x) {  // 8 bits -> every third bit
@@ -391,25 +428,44 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
 #pragma unroll
       for (int f = 0; f < F; ++f) val[k][f] = w * dy[f];
     }
-    // segmented inclusive scan over the wave: a run = consecutive lanes in the same cell
+    // Segmented inclusive scan over the wave (a run = consecutive lanes in the same cell), on the VALU:
+    // Hillis-Steele inside each 16-lane row with DPP row_shr (out-of-row sources read 0), then the
+    // row-end totals are carried into the following rows through v_readlane.  `flag` = a run head lies
+    // between the row start and this lane.
     const uint32_t px_ = __shfl_up(c.gx, 1, 64), py_ = __shfl_up(c.gy, 1, 64), pz_ = __shfl_up(c.gz, 1, 64);
     const bool vprev = __shfl_up((int)valid, 1, 64) != 0;
     const bool head = lane == 0 || !valid || !vprev || c.gx != px_ || c.gy != py_ || c.gz != pz_;
     const bool next_head = __shfl_down((int)head, 1, 64) != 0;
     tail = valid && (lane == 63 || next_head);
     int flag = head ? 1 : 0;
+#define NESVOR_SCAN_STEP(CTRL)                                                                             \
+    {                                                                                                      \
+      const float m = flag ? 0.f : 1.f;                                                                    \
+      _Pragma("unroll") for (int k = 0; k < 8; ++k) _Pragma("unroll") for (int f = 0; f < F; ++f) {        \
+        const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, val[k][f]), CTRL, 0xf, 0xf, true)); \
+        val[k][f] = fmaf(m, o, val[k][f]);                                                                 \
+      }                                                                                                    \
+      flag |= __builtin_amdgcn_update_dpp(0, flag, CTRL, 0xf, 0xf, true);                                  \
+    }
+    NESVOR_SCAN_STEP(0x111)  // row_shr:1
+    NESVOR_SCAN_STEP(0x112)  // row_shr:2
+    NESVOR_SCAN_STEP(0x114)  // row_shr:4
+    NESVOR_SCAN_STEP(0x118)  // row_shr:8
+#undef NESVOR_SCAN_STEP
+    {
+      const int row = lane >> 4;
+      const float open = flag ? 0.f : 1.f;  // this lane's run started before its row
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int fprev = __shfl_up(flag, d, 64);
-      const bool take = lane >= d && flag == 0;
+      for (int r = 1; r < 4; ++r) {
+        const float m = (row == r) ? open : 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < 8; ++k)
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
-          const float o = __shfl_up(val[k][f], d, 64);
-          val[k][f] += take ? o : 0.f;
-        }
-      flag |= (lane >= d) ? fprev : 1;
+          for (int f = 0; f < F; ++f) {
+            const float carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val[k][f]), 16 * r - 1));
+            val[k][f] = fmaf(m, carry, val[k][f]);
+          }
+      }
     }
   };
 
@@ -419,10 +475,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
   prepare(0, dy_cur);
   constexpr int kPer = 2048 / 256;
   for (int level = 0; level < g.n_levels; ++level) {
-    if (tail) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) lds_insert<F>(keys, vals, occ, &n_occ, idx[k], val[k]);
-    }
+    lds_insert8<F>(keys, vals, occ, &n_occ, tail, idx, val);
     __syncthreads();
     // bin the distinct records by table chunk
     const uint32_t n = n_occ;

@@ -1,4 +1,4 @@
-"""One pass of hash-grid fwd + owner-backward at N=2^20 on the PSF-cloud distribution (for rocprofv3)."""
+"""A few passes of the hash-grid owner-backward at N=2^20 (for rocprofv3 --pmc / --kernel-trace)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,7 +18,7 @@ u = u.contiguous().to(dev)
 table = ((torch.rand(spec.n_params, generator=torch.Generator().manual_seed(1337)) * 2 - 1) * 1e-4).to(dev)
 dy = torch.randn(32, N, device=dev)
 gt = torch.zeros_like(table)
-for _ in range(10):
+for _ in range(3):
     hashgrid_forward(spec, u, table, 1)
     hashgrid_backward(spec, u, table, dy, gt, True, 1, "owner")
 torch.cuda.synchronize()
