@@ -24,14 +24,13 @@
 //   The backward is therefore an owner-computes scatter in two launches:
 //     (1) hashgrid_bwd_aggregate: one workgroup per 256 consecutive samples
 //         (= one PSF cloud), sorted once by Morton code; per level a segmented
-//         wave scan sums runs of lanes in the same cell, the run tails add
-//         their 8 corner sums into an LDS open-addressing hash table with
-//         integer-CAS adds (ds_add_f32 retires ~1 lane / 3 cycles on gfx950),
-//         then the distinct (entry, grad) records are binned by table chunk
-//         and appended to that chunk's queue in HBM (one returning atomic per
-//         non-empty (workgroup, chunk) pair to reserve the span);
+//         wave scan on the VALU sums runs of lanes in the same cell, and the
+//         run tails' (entry, grad) records are binned by table chunk and
+//         appended to that chunk's queue in HBM (one LDS counter op per record,
+//         one returning atomic per non-empty (workgroup, chunk) pair);
 //     (2) hashgrid_bwd_owner: one workgroup per table chunk accumulates its
-//         queue into LDS (ds_add_f32) and adds the chunk to grad_table with
+//         queue into LDS (integer-CAS adds: ds_add_f32 retires only ~1 lane
+//         per 3 cycles on gfx950) and adds the chunk to grad_table with
 //         plain coalesced read-modify-writes - it is the only writer.
 //   Records that do not fit a queue fall back to global atomics, so the
 //   result is exact for any input distribution.  The legacy all-atomics
@@ -232,10 +231,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd(const nesvor_grid_t g, const
 }
 
 // ------------------------------------------- backward, owner-computes version
-constexpr int kSlotsLog2 = 12;
-constexpr int kSlots = 1 << kSlotsLog2;       // LDS hash table: 256 samples x 8 corners <= 2048 distinct keys
-constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-constexpr int kMaxChunks = 64;                // table chunks (queues) per level (LDS budget: 3 workgroups / CU)
+constexpr int kMaxChunks = 256;               // table chunks (queues) per level
 constexpr int kOwnerLdsFloats = 16384;        // 64 KiB accumulator per owner workgroup
 
 struct BwdPlan {
@@ -247,61 +243,6 @@ struct BwdPlan {
   uint64_t rec_off[NESVOR_MAX_LEVELS];         // first record of the level's queues
 };
 
-// Insert 8 (key, v[F]) pairs per active lane into the LDS open-addressing table.  All LDS atomics are
-// issued in batches (8 slot claims, then 8F reads, then 8F compare-and-swaps) so that a wave pays a
-// handful of LDS round trips per level instead of one per atomic.  Integer CAS finds/claims the slot
-// (new slots are appended to the occupied list); the values are added with CAS loops: callers
-// guarantee that lanes of one instruction carry distinct keys (segmented scan below), so retries only
-// come from other waves and are rare.
-template <int F>
-__device__ __forceinline__ void lds_insert8(uint32_t* keys, float* vals, uint16_t* occ, uint32_t* n_occ, bool active,
-                                            const uint32_t (&key)[8], const float (&v)[8][F]) {
-  uint32_t slot[8], prev[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) slot[k] = (key[k] * 2654435769u) >> (32 - kSlotsLog2);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) prev[k] = active ? atomicCAS(&keys[slot[k]], kEmpty, key[k]) : key[k];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    bool fresh = active && prev[k] == kEmpty;
-    if (active && prev[k] != kEmpty && prev[k] != key[k]) {  // collision: linear probing (rare at load <= 0.5)
-      while (true) {
-        slot[k] = (slot[k] + 1) & (kSlots - 1);
-        const uint32_t p2 = atomicCAS(&keys[slot[k]], kEmpty, key[k]);
-        if (p2 == kEmpty) { fresh = true; break; }
-        if (p2 == key[k]) break;
-      }
-    }
-    if (fresh) occ[atomicAdd(n_occ, 1u)] = (uint16_t)slot[k];
-  }
-  if (!active) return;
-  uint32_t old[8][F], got[8][F];
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-#pragma unroll
-    for (int f = 0; f < F; ++f)
-      old[k][f] = *reinterpret_cast<volatile uint32_t*>(&vals[slot[k] * F + f]);
-  unsigned long long pending = (8 * F >= 64) ? ~0ull : ((1ull << (8 * F)) - 1ull);
-  do {
-    // issue every compare-and-swap of the batch before looking at any result
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-      for (int f = 0; f < F; ++f) {
-        const bool p = (pending >> (k * F + f)) & 1ull;
-        const uint32_t want = p ? __float_as_uint(__uint_as_float(old[k][f]) + v[k][f]) : old[k][f];
-        got[k][f] = atomicCAS(reinterpret_cast<uint32_t*>(&vals[slot[k] * F + f]), old[k][f], want);
-      }
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-      for (int f = 0; f < F; ++f) {
-        if (got[k][f] == old[k][f]) pending &= ~(1ull << (k * F + f));
-        old[k][f] = got[k][f];
-      }
-  } while (pending);
-}
-
 __device__ __forceinline__ uint32_t spread3(uint32_t x) {  // 8 bits -> every third bit
   x &= 0xffu;
   x = (x ^ (x << 8)) & 0x0300f00fu;
@@ -312,13 +253,17 @@ __device__ __forceinline__ uint32_t spread3(uint32_t x) {  // 8 bits -> every th
 
 // Phase 1 of the backward.  One workgroup = 256 consecutive samples (one PSF cloud).
 //  * once per workgroup: bitonic-sort the samples by the Morton code of their finest-level cell, so
-//    that at EVERY level lanes falling into the same cell sit (almost always) next to each other;
-//  * per level: each lane forms its 8 corner contributions, a segmented wave scan sums runs of equal
-//    cells, and only the last lane of a run inserts into the LDS table -> within one instruction all
-//    active lanes carry distinct keys, so integer-CAS adds do not collide (ds_add_f32 would cost
-//    ~3 cycles per lane on gfx950);
-//  * the occupied-slot list makes flush and re-initialisation proportional to the number of
-//    distinct entries (8 at the coarsest level, ~1500 at the finest), not to the table size.
+//    that at every level lanes falling into the same cell sit (mostly) next to each other;
+//  * per level: each lane forms its 8 corner contributions and a segmented wave scan on the VALU
+//    (DPP row_shr inside 16-lane rows, v_readlane carries across rows) sums runs of equal cells;
+//    only the last lane of a run keeps records.  That removes the bulk of the duplication of a PSF
+//    cloud (all of it at the coarse levels) without any LDS traffic;
+//  * the surviving (entry, grad) records are binned by table chunk: one LDS counter increment per
+//    record, one returning global atomic per non-empty (workgroup, chunk) to reserve queue space
+//    (its ~2 us latency is hidden behind the next level's register-only work), then the records go
+//    straight from registers to the chunk queues.  Residual duplicates (same vertex reached from
+//    neighbouring cells / other waves) are summed by the chunk's owner in phase 2.
+// LDS: 2 x 64 counters, so occupancy is set by registers only.
 template <int F, int LAYOUT, bool INPUT_GRAD>
 __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_t g, const BwdPlan plan,
                                                               const float* __restrict__ u,
@@ -327,25 +272,13 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
                                                               float* __restrict__ grad_table,
                                                               float* __restrict__ grad_u, uint32_t* __restrict__ tails,
                                                               uint32_t* __restrict__ records, int64_t N) {
-  __shared__ uint32_t keys[kSlots];
-  __shared__ float vals[kSlots * F];
-  __shared__ uint32_t occ_words[1024];  // occupied-slot list (uint16 x 2048); doubles as the sort exchange buffer
-  uint16_t* occ = reinterpret_cast<uint16_t*>(occ_words);
   __shared__ uint32_t bcount[kMaxChunks];
   __shared__ uint32_t bbase[kMaxChunks];
-  uint32_t* sortbuf = occ_words;
-  __shared__ uint32_t n_occ;
+  __shared__ uint32_t sortbuf[256];
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t base = (int64_t)blockIdx.x * 256;
   const int E = g.n_levels * F;
-#pragma unroll
-  for (int j = 0; j < kSlots / 256; ++j) {
-    keys[tid + j * 256] = kEmpty;
-#pragma unroll
-    for (int f = 0; f < F; ++f) vals[(tid + j * 256) * F + f] = 0.f;
-  }
   if (tid < kMaxChunks) bcount[tid] = 0;
-  if (tid == 0) n_occ = 0;
 
   // ---- sort the workgroup's samples by Morton code of the finest-level cell
   uint32_t sv;
@@ -395,11 +328,8 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
     }
   };
 
-  // Everything of a level that needs no LDS table: corner indices, run-summed corner values, tail flag.
-  uint32_t idx[8];
-  float val[8][F];
-  bool tail;
-  auto prepare = [&](int level, const float (&dy)[F]) {
+  // Everything of a level that needs no shared state: corner indices, run-summed corner values, tail flag.
+  auto prepare = [&](int level, const float (&dy)[F], uint32_t (&idx)[8], float (&val)[8][F], bool& tail) {
     const LevelParams p = load_level(g, level);
     const CellPos c = locate(p, ux, uy, uz);
 #pragma unroll
@@ -469,22 +399,18 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
     }
   };
 
-  float dy_cur[F], dy_next[F];
-  load_dy(0, dy_cur);
-  if (g.n_levels > 1) load_dy(1, dy_next);
-  prepare(0, dy_cur);
-  constexpr int kPer = 2048 / 256;
+  float dy_a[F], dy_b[F];
+  uint32_t idx[8], idx_n[8];
+  float val[8][F], val_n[8][F];
+  bool tail, tail_n = false;
+  load_dy(0, dy_a);
+  if (g.n_levels > 1) load_dy(1, dy_b);
+  prepare(0, dy_a, idx, val, tail);
   for (int level = 0; level < g.n_levels; ++level) {
-    lds_insert8<F>(keys, vals, occ, &n_occ, tail, idx, val);
-    __syncthreads();
-    // bin the distinct records by table chunk
-    const uint32_t n = n_occ;
-    uint32_t rank[kPer];
+    // rank of every record inside its chunk's span (LDS integer atomics: ~6 cycles / wave-instruction)
+    uint32_t rank[8];
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-      const uint32_t t = tid + j * 256;
-      rank[j] = (t < n) ? atomicAdd(&bcount[keys[occ[t]] >> plan.chunk_shift], 1u) : 0u;
-    }
+    for (int k = 0; k < 8; ++k) rank[k] = tail ? atomicAdd(&bcount[idx[k] >> plan.chunk_shift], 1u) : 0u;
     __syncthreads();
     // reserve queue space: one returning (memory-side, ~2 us) atomic per non-empty chunk ...
     const uint32_t nb = plan.n_chunks[level];
@@ -495,40 +421,39 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
       bcount[tid] = 0;
     }
     // ... and hide its latency behind the next level's register-only work
-    const uint32_t offset_cur = g.offset[level];
     if (level + 1 < g.n_levels) {
 #pragma unroll
-      for (int f = 0; f < F; ++f) dy_cur[f] = dy_next[f];
-      if (level + 2 < g.n_levels) load_dy(level + 2, dy_next);
-      prepare(level + 1, dy_cur);
+      for (int f = 0; f < F; ++f) dy_a[f] = dy_b[f];
+      if (level + 2 < g.n_levels) load_dy(level + 2, dy_b);
+      prepare(level + 1, dy_a, idx_n, val_n, tail_n);
     }
     if (tid < nb) bbase[tid] = my_base;
     __syncthreads();
-    const uint32_t cap = plan.cap[level];
+    if (tail) {
+      const uint32_t cap = plan.cap[level];
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-      const uint32_t t = tid + j * 256;
-      if (t < n) {
-        const uint32_t slot = occ[t];
-        const uint32_t key = keys[slot];
-        const uint32_t b = key >> plan.chunk_shift;
-        const uint32_t pos = bbase[b] + rank[j];
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t b = idx[k] >> plan.chunk_shift;
+        const uint32_t pos = bbase[b] + rank[k];
         if (pos < cap) {
           uint32_t* r = records + (plan.rec_off[level] + (uint64_t)b * cap + pos) * (1 + F);
-          r[0] = key;
+          r[0] = idx[k];
 #pragma unroll
-          for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(vals[slot * F + f]);
+          for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(val[k][f]);
         } else {  // queue full: exact fallback
 #pragma unroll
-          for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)offset_cur + key) * F + f, vals[slot * F + f]);
+          for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + idx[k]) * F + f, val[k][f]);
         }
-        keys[slot] = kEmpty;
-#pragma unroll
-        for (int f = 0; f < F; ++f) vals[slot * F + f] = 0.f;
       }
     }
-    if (tid == 0) n_occ = 0;
-    __syncthreads();
+    __syncthreads();  // bbase is rewritten by the next level
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      idx[k] = idx_n[k];
+#pragma unroll
+      for (int f = 0; f < F; ++f) val[k][f] = val_n[k][f];
+    }
+    tail = tail_n;
   }
   if constexpr (INPUT_GRAD) {
     if (valid) { grad_u[3 * i] = gux; grad_u[3 * i + 1] = guy; grad_u[3 * i + 2] = guz; }
@@ -538,12 +463,12 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
 constexpr uint32_t kOwnerSlice = 32768;  // records per owner workgroup
 
 // grid.x = sum over buckets of ceil(cap / kOwnerSlice) slices; a slice past the queue tail exits at once.
-template <int F, bool CAS_ADD = true>
+template <int F>
 __global__ __launch_bounds__(256) void hashgrid_bwd_owner(const nesvor_grid_t g, const BwdPlan plan,
                                                           const uint32_t* __restrict__ tails,
                                                           const uint32_t* __restrict__ records,
                                                           float* __restrict__ grad_table) {
-  __shared__ float acc[kOwnerLdsFloats];
+  __shared__ __attribute__((aligned(16))) float acc[kOwnerLdsFloats];
   const int tid = threadIdx.x;
   // decode (level, chunk, slice) from the flat workgroup id
   uint32_t wg = blockIdx.x;
@@ -570,10 +495,18 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_owner(const nesvor_grid_t g,
   for (uint32_t r = r0 + tid; r < r1; r += 256) {
     const uint32_t* q = rec + (size_t)r * (1 + F);
     const uint32_t local = q[0] & mask;
+    if constexpr (F == 2) {  // one 64-bit compare-and-swap adds both features
+      unsigned long long* a = reinterpret_cast<unsigned long long*>(&acc[local * 2]);
+      const float v0 = __uint_as_float(q[1]), v1 = __uint_as_float(q[2]);
+      unsigned long long old = *reinterpret_cast<volatile unsigned long long*>(a), assumed;
+      do {
+        assumed = old;
+        const float n0 = __uint_as_float((uint32_t)assumed) + v0, n1 = __uint_as_float((uint32_t)(assumed >> 32)) + v1;
+        old = atomicCAS(a, assumed, ((unsigned long long)__float_as_uint(n1) << 32) | __float_as_uint(n0));
+      } while (old != assumed);
+    } else {
 #pragma unroll
-    for (int f = 0; f < F; ++f) {
-      if (CAS_ADD) lds_add_f32_cas(&acc[local * F + f], __uint_as_float(q[1 + f]));
-      else atomicAdd(&acc[local * F + f], __uint_as_float(q[1 + f]));
+      for (int f = 0; f < F; ++f) lds_add_f32_cas(&acc[local * F + f], __uint_as_float(q[1 + f]));
     }
   }
   __syncthreads();
