@@ -240,6 +240,7 @@ struct BwdPlan {
   uint32_t n_chunks[NESVOR_MAX_LEVELS];
   uint32_t bucket_base[NESVOR_MAX_LEVELS];     // first global bucket id of the level
   uint32_t cap[NESVOR_MAX_LEVELS];             // queue capacity (records) of each bucket of the level
+  uint32_t slice[NESVOR_MAX_LEVELS];           // records per owner workgroup of the level
   uint64_t rec_off[NESVOR_MAX_LEVELS];         // first record of the level's queues
 };
 
@@ -460,11 +461,13 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
   }
 }
 
-constexpr uint32_t kOwnerSlice = 32768;  // records per owner workgroup
+constexpr uint32_t kOwnerSlice = 1u << 18;  // records per owner workgroup: a PSF-cloud batch keeps every queue in ONE slice (sole writer, no atomics)
 
 // grid.x = sum over buckets of ceil(cap / kOwnerSlice) slices; a slice past the queue tail exits at once.
+constexpr int kOwnerThreads = 1024;  // 16 waves: the owner is latency-bound per thread (global load -> LDS CAS)
+
 template <int F>
-__global__ __launch_bounds__(256) void hashgrid_bwd_owner(const nesvor_grid_t g, const BwdPlan plan,
+__global__ __launch_bounds__(1024) void hashgrid_bwd_owner(const nesvor_grid_t g, const BwdPlan plan,
                                                           const uint32_t* __restrict__ tails,
                                                           const uint32_t* __restrict__ records,
                                                           float* __restrict__ grad_table) {
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_owner(const nesvor_grid_t g,
   int level = 0;
   uint32_t spl = 0;
   for (;; ++level) {
-    spl = (plan.cap[level] + kOwnerSlice - 1) / kOwnerSlice;
+    spl = (plan.cap[level] + plan.slice[level] - 1) / plan.slice[level];
     const uint32_t cnt = plan.n_chunks[level] * spl;
     if (wg < cnt || level + 1 >= g.n_levels) break;
     wg -= cnt;
@@ -484,36 +487,63 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_owner(const nesvor_grid_t g,
   const uint32_t gb = plan.bucket_base[level] + chunk;
   uint32_t n = tails[gb];
   if (n > plan.cap[level]) n = plan.cap[level];
-  const uint32_t r0 = slice * kOwnerSlice;
+  const uint32_t r0 = slice * plan.slice[level];
   if (r0 >= n) return;
-  const uint32_t r1 = min(n, r0 + kOwnerSlice);
-  const bool sole_writer = n <= kOwnerSlice;
-  for (int t = tid; t < kOwnerLdsFloats; t += 256) acc[t] = 0.f;
+  const uint32_t r1 = min(n, r0 + plan.slice[level]);
+  const bool sole_writer = n <= plan.slice[level];
+  for (int t = tid; t < kOwnerLdsFloats; t += kOwnerThreads) acc[t] = 0.f;
   __syncthreads();
   const uint32_t mask = (1u << plan.chunk_shift) - 1u;
   const uint32_t* rec = records + (plan.rec_off[level] + (uint64_t)chunk * plan.cap[level]) * (1 + F);
-  for (uint32_t r = r0 + tid; r < r1; r += 256) {
-    const uint32_t* q = rec + (size_t)r * (1 + F);
-    const uint32_t local = q[0] & mask;
+  auto add_record = [&](uint32_t key, const float (&v)[F]) {
+    const uint32_t local = key & mask;
     if constexpr (F == 2) {  // one 64-bit compare-and-swap adds both features
       unsigned long long* a = reinterpret_cast<unsigned long long*>(&acc[local * 2]);
-      const float v0 = __uint_as_float(q[1]), v1 = __uint_as_float(q[2]);
       unsigned long long old = *reinterpret_cast<volatile unsigned long long*>(a), assumed;
       do {
         assumed = old;
-        const float n0 = __uint_as_float((uint32_t)assumed) + v0, n1 = __uint_as_float((uint32_t)(assumed >> 32)) + v1;
+        const float n0 = __uint_as_float((uint32_t)assumed) + v[0], n1 = __uint_as_float((uint32_t)(assumed >> 32)) + v[1];
         old = atomicCAS(a, assumed, ((unsigned long long)__float_as_uint(n1) << 32) | __float_as_uint(n0));
       } while (old != assumed);
     } else {
 #pragma unroll
-      for (int f = 0; f < F; ++f) lds_add_f32_cas(&acc[local * F + f], __uint_as_float(q[1 + f]));
+      for (int f = 0; f < F; ++f) lds_add_f32_cas(&acc[local * F + f], v[f]);
     }
+  };
+  // Records of one pixel sit next to each other in the queue and repeat the same few table entries
+  // (shared cell corners), so neighbouring lanes must NOT take neighbouring records (measured: the
+  // coalesced walk is 2x slower from compare-and-swap retries): each thread walks its own contiguous
+  // sub-range, which spreads the lanes over the whole slice.
+  // (sub-ranges are multiples of 32 records = 3 x 128 B so that a cache line is fetched by one thread only)
+  const uint32_t per = (((r1 - r0 + kOwnerThreads - 1) / kOwnerThreads) + 31u) & ~31u;
+  uint32_t r = r0 + tid * per;
+  const uint32_t rend = min(r1, r + per);
+  constexpr int kUnroll = 8;  // records in flight per thread: 96 contiguous bytes, i.e. most of a 128-B line per fetch
+  for (; r + kUnroll <= rend; r += kUnroll) {
+    uint32_t key[kUnroll];
+    float v[kUnroll][F];
+#pragma unroll
+    for (int j = 0; j < kUnroll; ++j) {
+      const uint32_t* q = rec + (size_t)(r + j) * (1 + F);
+      key[j] = q[0];
+#pragma unroll
+      for (int f = 0; f < F; ++f) v[j][f] = __uint_as_float(q[1 + f]);
+    }
+#pragma unroll
+    for (int j = 0; j < kUnroll; ++j) add_record(key[j], v[j]);
+  }
+  for (; r < rend; ++r) {
+    const uint32_t* q = rec + (size_t)r * (1 + F);
+    float v[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) v[f] = __uint_as_float(q[1 + f]);
+    add_record(q[0], v);
   }
   __syncthreads();
   const uint32_t e0 = chunk << plan.chunk_shift;
   const uint32_t ne = min((uint32_t)(1u << plan.chunk_shift), g.size[level] - e0);
   float* out = grad_table + ((size_t)g.offset[level] + e0) * F;
-  for (uint32_t t = tid; t < ne * F; t += 256) {
+  for (uint32_t t = tid; t < ne * F; t += kOwnerThreads) {
     const float a = acc[t];
     if (a != 0.f) {
       if (sole_writer) out[t] += a;  // only writer of the chunk: plain read-modify-write
@@ -524,7 +554,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_owner(const nesvor_grid_t g,
 
 inline uint32_t owner_grid(const nesvor_grid_t* g, const BwdPlan& plan) {
   uint32_t n = 0;
-  for (int l = 0; l < g->n_levels; ++l) n += plan.n_chunks[l] * ((plan.cap[l] + kOwnerSlice - 1) / kOwnerSlice);
+  for (int l = 0; l < g->n_levels; ++l) n += plan.n_chunks[l] * ((plan.cap[l] + plan.slice[l] - 1) / plan.slice[l]);
   return n;
 }
 
@@ -546,11 +576,18 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
     uint64_t cap = per + per / 32 + 4096;
     if (cap > 0x7FFFFFFFull) return false;
     plan->cap[l] = (uint32_t)cap;
+    // small (coarse, dense) levels collect very many records on few entries: split their queue over many
+    // workgroups (the closing atomics are then only entries x slices); big chunks keep one sole writer
+    const uint32_t ents = g->size[l] < (1u << shift) ? g->size[l] : (1u << shift);
+    uint64_t sl = (uint64_t)ents * 16;
+    if (sl < 8192) sl = 8192;
+    if (sl > kOwnerSlice) sl = kOwnerSlice;
+    plan->slice[l] = (uint32_t)sl;
     plan->rec_off[l] = off;
     off += cap * nc;
   }
   for (int l = g->n_levels; l < NESVOR_MAX_LEVELS; ++l) {
-    plan->n_chunks[l] = 0; plan->bucket_base[l] = nb; plan->cap[l] = 0; plan->rec_off[l] = off;
+    plan->n_chunks[l] = 0; plan->bucket_base[l] = nb; plan->cap[l] = 0; plan->slice[l] = kOwnerSlice; plan->rec_off[l] = off;
   }
   plan->n_buckets = nb;
   *n_records = off;
@@ -582,7 +619,7 @@ int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table,
   if (e != hipSuccess) return (int)e;
 owner_stage:
   if (stages & 2)
-    hipLaunchKernelGGL((hashgrid_bwd_owner<F>), dim3(owner_grid(g, plan)), block, 0, st, *g, plan, tails, records, gt);
+    hipLaunchKernelGGL((hashgrid_bwd_owner<F>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt);
   return (int)hipGetLastError();
 }
 
