@@ -14,6 +14,8 @@ from torch.autograd import Function
 from . import _lib
 
 N_PARTIAL = 1024  # workgroups (= partial sums) of the dW kernel: 4 per CU so loads overlap MFMAs
+N_PARTIAL_FUSED = 512  # fused backward: persistent workgroups, 2 per CU (LDS-limited)
+FUSED_BACKWARD = True  # False: separate dX and dW kernels (kept as cross-check and for depth 3)
 
 
 def linear_layers(seq: nn.Sequential):
@@ -94,15 +96,18 @@ class FusedMLPFunction(Function):
         d = _desc(weights, biases, k_a, k_b, b_row0, S)
         dev = xb.device
         dy = dy.contiguous()
-        dpre = [torch.empty_like(s) for s in saved]
+        fused = (n_layers - 1) <= 2 and FUSED_BACKWARD
+        # fused dX+dW+db kernel needs no dpre scratch (signalled by NULL entries); the two-kernel path does
+        dpre = [] if fused else [torch.empty_like(s) for s in saved]
         dxa = torch.empty((N, k_a), dtype=torch.float32, device=dev) if (xa is not None and ctx.needs_input_grad[0]) else None
         dxb = torch.empty((k_b, N), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         total = sum(w.numel() + b.numel() for w, b in zip(weights, biases))
-        partial = torch.empty((N_PARTIAL, total), dtype=torch.float32, device=dev)
+        n_partial = N_PARTIAL_FUSED if fused else N_PARTIAL
+        partial = torch.empty((n_partial, total), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev), _lib.kernel_timer.span("mlp_bwd"):
             err = _lib.load().nesvor_mlp_backward(
                 ctypes.byref(d), _lib.ptr(xa), _lib.ptr(xb), _lib.ptr(dy), _ptr_array(saved), _ptr_array(dpre),
-                _lib.ptr(dxa), _lib.ptr(dxb), _lib.ptr(partial), N_PARTIAL, N, _lib.stream_ptr())
+                _lib.ptr(dxa), _lib.ptr(dxb), _lib.ptr(partial), n_partial, N, _lib.stream_ptr())
         _lib.check(err, "mlp backward")
         flat = partial.sum(0)
         gw, gb, off = [], [], 0

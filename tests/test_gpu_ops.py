@@ -341,13 +341,16 @@ def test_psf_transform_vs_oracle(device, B, S):
     (0, 24, 0, 24, 3, 16, 256, 512),    # L=12 (default level scale), depth 3
     (16, 15, 1, 16, 1, 1, 256, 65536),  # full pixel clouds
 ])
-def test_fused_mlp_vs_torch_fp32_reference(device, k_a, k_b, b_row0, rows, depth, out_dim, S, N):
+@pytest.mark.parametrize("fused_bwd", [True, False])
+def test_fused_mlp_vs_torch_fp32_reference(device, k_a, k_b, b_row0, rows, depth, out_dim, S, N, fused_bwd, monkeypatch):
     """fp32 MFMA network vs the same nn.Sequential evaluated by PyTorch (fp32 reference of the same op).
     Tolerance: fp32 with K <= 64 per layer and different summation order: rtol 2e-4 / atol 2e-5 fwd,
     grads relative to their max."""
+    import nesvor_amd.mlp as M
     from nesvor_amd.mlp import fused_mlp
     from nesvor_amd.models import build_network
 
+    monkeypatch.setattr(M, "FUSED_BACKWARD", fused_bwd)  # fused dX+dW+db kernel vs the two-kernel path
     torch.manual_seed(N + k_a)
     net = build_network(n_input_dims=k_a + k_b, n_output_dims=out_dim, activation="ReLU", output_activation="None",
                         n_neurons=64, n_hidden_layers=depth, dtype=torch.float32).to(device)
