@@ -154,6 +154,30 @@ int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, const float* x
                         float* dw_partial, int n_partial, int64_t N, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Imaging model + losses, value and gradient in one launch.  Replaces the tail of
+ * NeSVoR.forward (nesvor/nesvor/models.py:286-325), edge_reg/tv_reg/l2_reg
+ * (models.py:366-384) and their autograd backward.  See csrc/loss.hip for the math.
+ * Inputs (device): z0, log_var, log_bias (B*S) [log_var / log_bias may be NULL],
+ * x (B,S,3), v (B), slice_idx (B) int64, c (n) slice scale or NULL, log_var_slice (n) or
+ * NULL, log_bias_mean (1) (only read when log_bias != NULL).
+ * Forward launch (gw == NULL) writes loss_pix (B,3) = per-pixel [MSE term, logVar term,
+ * sum_s regulariser term].  Backward launch (gw = device pointer to the 4 upstream
+ * gradients d total / d {MSE, logVar, imageReg, biasReg}) writes dz0, dlog_var, dlog_bias
+ * (B*S), dx (B,S,3) or NULL, dc_pix (B) or NULL, dlvs_pix (B) or NULL.
+ * reg_type: 0 edge, 1 TV, 2 L2.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  const float* z0; const float* log_var; const float* log_bias; const float* x; const float* v;
+  const int64_t* slice_idx; const float* c; const float* log_var_slice; const float* log_bias_mean;
+  const float* gw;
+  float* loss_pix; float* dz0; float* dlog_var; float* dlog_bias; float* dx; float* dc_pix; float* dlvs_pix;
+  int32_t B, S, reg_type;
+  float delta;
+} nesvor_loss_t;
+
+int nesvor_imaging_loss(const nesvor_loss_t* args, void* stream);
+
+/* ------------------------------------------------------------------------
  * Fused AdamW over a flat fp32 parameter buffer.  Replaces the
  * torch.optim.AdamW step at nesvor/nesvor/train.py:144-152,195-197
  * (betas (0.9,0.99), eps 1e-15, decoupled weight decay):

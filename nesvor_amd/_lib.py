@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -41,6 +41,15 @@ class MlpT(Structure):
         ("k_a", c_int32), ("k_b", c_int32), ("b_row0", c_int32), ("samples_per_pixel", c_int32),
         ("weight", c_void_p * 4), ("bias", c_void_p * 4),
     ]
+
+
+class LossT(Structure):
+    """Mirror of nesvor_loss_t."""
+
+    _fields_ = [(n, c_void_p) for n in (
+        "z0", "log_var", "log_bias", "x", "v", "slice_idx", "c", "log_var_slice", "log_bias_mean", "gw",
+        "loss_pix", "dz0", "dlog_var", "dlog_bias", "dx", "dc_pix", "dlvs_pix")] + [
+        ("B", c_int32), ("S", c_int32), ("reg_type", c_int32), ("delta", c_float)]
 
 
 _lib = None
@@ -72,6 +81,7 @@ _SIGNATURES = {
         [POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), POINTER(c_void_p), _P, _P, _P, c_int, c_int64, _P],
         c_int,
     ),
+    "nesvor_imaging_loss": ([POINTER(LossT), _P], c_int),
     "nesvor_adamw_step": (
         [_P, _P, _P, _P, c_int64] + [c_float] * 8 + [c_int, _P],
         c_int,

@@ -71,4 +71,4 @@ extern "C" int nesvor_adamw_step(float* param, float* grad, float* exp_avg, floa
   return (int)hipGetLastError();
 }
 
-extern "C" int nesvor_hip_abi_version(void) { return 5; }
+extern "C" int nesvor_hip_abi_version(void) { return 6; }

@@ -1,0 +1,132 @@
+// Imaging model + losses of NeSVoR.forward, value AND gradient in one launch (gfx950).
+//
+// Replaces the tail of NeSVoR.forward (nesvor/nesvor/models.py:286-325) and edge_reg / tv_reg /
+// l2_reg (models.py:366-384) together with their autograd backward — ~60 elementwise / reduction
+// launches over (B,S) tensors per iteration in the reference.  Per pixel b with slice k = idx[b]:
+//   density = softplus(z0);  bias = exp(log_bias) | 1;  varp = exp(log_var) | 1
+//   v_out = c_k mean_s(bias density);   var = (c_k mean_s(bias varp))^2 [pixel variance] + exp(lvs_k) [slice variance]
+//   MSE   = mean_b (v_out - v)^2 / (2 var);   logVar = mean_b 0.5 log var
+//   imageReg(edge) = delta (mean_{b,s} sqrt(1 + dd^2 / (dx2 delta^2)) - 1),
+//       dd = density_s - density_{S-1-s},  dx2 = |x_s - x_{S-1-s}|^2 + 1e-6          (TV / L2 analogous)
+//   biasReg = (mean_{b,s} log_bias)^2   (the global mean is passed in: it needs a prior reduction)
+// bias and c enter `var` detached, exactly as the reference writes it.
+// Forward launch (gw == NULL): per pixel, the three loss partial sums.  Backward launch (gw = the four
+// upstream gradients d total / d {MSE, logVar, imageReg, biasReg}, on the device): per pixel
+// d(total)/d(c_k), d(total)/d(lvs_k) and per sample d(total)/d(z0, log_var, log_bias, x).
+// One wave per pixel; two streaming passes over the pixel's S samples (pass 1: the two means and the
+// regulariser sums, pass 2: gradients); partner samples S-1-s are re-read from L1/L2.
+#include <hip/hip_runtime.h>
+#include "common.h"
+#include "../../include/nesvor_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); }
+
+// REG: 0 edge, 1 TV, 2 L2
+template <int REG>
+__global__ __launch_bounds__(256) void imaging_loss_kernel(const nesvor_loss_t a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  const int S = a.S;
+  const int64_t k = a.slice_idx[b];
+  const size_t base = (size_t)b * S;
+  const float c = a.c != nullptr ? a.c[k] : 1.f;
+  const bool has_lv = a.log_var != nullptr, has_lb = a.log_bias != nullptr;
+  const float inv_d2 = 1.f / (a.delta * a.delta);
+
+  float s1 = 0.f, s2 = 0.f, sreg = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float dens = softplus_f(a.z0[base + s]);
+    const float bias = has_lb ? expf(a.log_bias[base + s]) : 1.f;
+    s1 += bias * dens;
+    if (has_lv) s2 += bias * expf(a.log_var[base + s]);
+    const int m = S - 1 - s;
+    const float dd = dens - softplus_f(a.z0[base + m]);
+    const float* xs = a.x + (base + s) * 3;
+    const float* xm = a.x + (base + m) * 3;
+    const float ex = xs[0] - xm[0], ey = xs[1] - xm[1], ez = xs[2] - xm[2];
+    const float dx2 = (ex * ex + ey * ey + ez * ez) + 1e-6f;
+    if (REG == 0) sreg += sqrtf(1.f + dd * dd / dx2 * inv_d2);
+    if (REG == 1) sreg += fabsf(dd / sqrtf(dx2));
+    if (REG == 2) sreg += dd * dd / dx2;
+  }
+  s1 = wave_sum_dpp(s1); s2 = wave_sum_dpp(s2); sreg = wave_sum_dpp(sreg);
+  const float m1 = s1 / S, m2 = s2 / S;
+  const float v_out = c * m1;
+  float var = 1.f, pv = 0.f;
+  if (has_lv) { pv = c * m2; var = pv * pv; }
+  const float slice_var = a.log_var_slice != nullptr ? expf(a.log_var_slice[k]) : 0.f;
+  var += slice_var;  // the reference starts from var = 1 when there is no pixel variance (models.py:300-314)
+  const bool has_var = has_lv || a.log_var_slice != nullptr;
+  const float e = v_out - a.v[b];
+  const float invB = 1.f / a.B;
+  if (a.gw == nullptr) {  // forward launch
+    if (lane == 0) {
+      a.loss_pix[3 * b + 0] = e * e / (2.f * var);
+      a.loss_pix[3 * b + 1] = has_var ? 0.5f * logf(var) : 0.f;
+      a.loss_pix[3 * b + 2] = sreg;  // sum over the pixel's samples of the regulariser term
+    }
+    return;
+  }
+  // backward launch: gradients of  gw0 MSE + gw1 logVar + gw2 imageReg + gw3 biasReg
+  const float gw_mse = a.gw[0], gw_lv = a.gw[1], gw_img = a.gw[2], gw_bias = a.gw[3];
+  const float g_vout = gw_mse * e / var * invB;
+  const float g_var = has_var ? (gw_mse * (-e * e / (2.f * var * var)) + gw_lv * 0.5f / var) * invB : 0.f;
+  const float g_m2 = has_lv ? g_var * 2.f * pv * c : 0.f;  // c detached inside var
+  if (lane == 0) {
+    if (a.dc_pix != nullptr) a.dc_pix[b] = g_vout * m1;
+    if (a.dlvs_pix != nullptr) a.dlvs_pix[b] = g_var * slice_var;
+  }
+  const float reg_scale = (REG == 0 ? a.delta : 1.f) * gw_img / ((float)a.B * S);
+  const float g_lb_reg = has_lb ? gw_bias * 2.f * a.log_bias_mean[0] / ((float)a.B * S) : 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float z = a.z0[base + s];
+    const float dens = softplus_f(z);
+    const float bias = has_lb ? expf(a.log_bias[base + s]) : 1.f;
+    float g_dens = g_vout * c * bias / S;
+    // regulariser: the pair (s, S-1-s) appears twice in the mean (as s and as its mirror)
+    const int m = S - 1 - s;
+    const float dd = dens - softplus_f(a.z0[base + m]);
+    const float* xs = a.x + (base + s) * 3;
+    const float* xm = a.x + (base + m) * 3;
+    const float ex = xs[0] - xm[0], ey = xs[1] - xm[1], ez = xs[2] - xm[2];
+    const float dx2 = (ex * ex + ey * ey + ez * ez) + 1e-6f;
+    float g_dd, g_dx2;  // d term / d dd, d term / d dx2
+    if (REG == 0) {
+      const float term = sqrtf(1.f + dd * dd / dx2 * inv_d2);
+      g_dd = dd / dx2 * inv_d2 / term;
+      g_dx2 = -0.5f * dd * dd / (dx2 * dx2) * inv_d2 / term;
+    } else if (REG == 1) {
+      const float r = sqrtf(dx2);
+      g_dd = (dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f)) / r;
+      g_dx2 = -0.5f * fabsf(dd) / (dx2 * r);
+    } else {
+      g_dd = 2.f * dd / dx2;
+      g_dx2 = -dd * dd / (dx2 * dx2);
+    }
+    g_dens += 2.f * reg_scale * g_dd;
+    a.dz0[base + s] = g_dens * sigmoid_f(z);
+    if (a.dx != nullptr) {
+      const float gx = 2.f * reg_scale * g_dx2 * 2.f;
+      float* o = a.dx + (base + s) * 3;
+      o[0] = gx * ex; o[1] = gx * ey; o[2] = gx * ez;
+    }
+    if (has_lv) a.dlog_var[base + s] = g_m2 * bias * expf(a.log_var[base + s]) / S;  // bias detached
+    if (has_lb) a.dlog_bias[base + s] = g_vout * c * dens * bias / S + g_lb_reg;
+  }
+}
+
+}  // namespace
+
+extern "C" int nesvor_imaging_loss(const nesvor_loss_t* args, void* stream) {
+  if (args->B <= 0 || args->S <= 0) return 0;
+  dim3 grid((args->B + 3) / 4), block(256);
+  if (args->reg_type == 0) hipLaunchKernelGGL(imaging_loss_kernel<0>, grid, block, 0, (hipStream_t)stream, *args);
+  else if (args->reg_type == 1) hipLaunchKernelGGL(imaging_loss_kernel<1>, grid, block, 0, (hipStream_t)stream, *args);
+  else if (args->reg_type == 2) hipLaunchKernelGGL(imaging_loss_kernel<2>, grid, block, 0, (hipStream_t)stream, *args);
+  else return (int)hipErrorInvalidValue;
+  return (int)hipGetLastError();
+}

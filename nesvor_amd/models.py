@@ -25,6 +25,7 @@ from . import _lib
 from . import mlp as fused_mlp_mod
 from . import tinycudann as tcnn
 from .encoding import hashgrid_encode
+from .loss import imaging_loss
 from .sampler import psf_transform
 from .transform import RigidTransform, ax_transform_points, axisangle2mat, mat_transform_points, trans_loss_fused
 from .utils import resolution2sigma
@@ -219,6 +220,8 @@ class NeSVoR(nn.Module):
             # fused sampler: per-slice matrices (n is a few hundred) -> x and the normalised u in one launch
             mat = axisangle2mat(self.axisangle)
             x, u = psf_transform(mat, slice_idx, xyz, self.psf_sigma, noise, self.inr.bounding_box)
+            if getattr(a, "fused_loss", True):
+                return self.fused_losses(x, u, v, slice_idx)
             results = self.net_forward_fused(x, slice_idx, u)
         else:
             sigma = self.psf_sigma[slice_idx][:, None]
@@ -253,6 +256,25 @@ class NeSVoR(nn.Module):
         losses[I_REG] = self.image_regularization(density, x, self.delta)
         return losses
 
+    def fused_losses(self, x, u, v, slice_idx) -> Dict[str, Any]:
+        """Imaging model + losses (models.py:286-325) through the fused loss kernel; same dict, same order."""
+        a = self.args
+        z, log_var, log_bias = self.fused_outputs(u, slice_idx, x.shape[1])
+        c = F.softmax(self.logit_coef, 0) * self.n_slices if not a.no_slice_scale else None
+        lvs = self.log_var_slice if not a.no_slice_variance else None
+        mse, logvar, ireg, breg = imaging_loss(z[0], log_var, log_bias, x, v, slice_idx, c, lvs,
+                                               a.image_regularization, self.delta)
+        losses = {D_LOSS: mse}
+        if not (a.no_pixel_variance and a.no_slice_variance):
+            losses[S_LOSS] = logvar
+            losses[DS_LOSS] = mse + logvar
+        if not a.no_transformation_optimization:
+            losses[T_REG] = self.trans_loss(trans_first=self.trans_first)
+        if a.n_levels_bias:
+            losses[B_REG] = breg
+        losses[I_REG] = ireg
+        return losses
+
     def use_fused_mlp(self) -> bool:
         """Fused fp32-MFMA evaluation of the three MLPs (default on a HIP device in single precision)."""
         a = self.args
@@ -264,26 +286,36 @@ class NeSVoR(nn.Module):
         return (getattr(a, "fused_mlp", True) and a.dtype == torch.float32 and self.axisangle.is_cuda
                 and all(fused_mlp_mod.supported(n) for n in nets))
 
-    def net_forward_fused(self, x: torch.Tensor, slice_idx: torch.Tensor, u: Optional[torch.Tensor] = None) -> Dict[str, Any]:
-        """net_forward (models.py:329-355) without materialising pe (N,E) row-major, the expanded slice
-        embedding or the concatenated MLP inputs: the hash grid writes feature-major (E,N) and the fused
-        MLPs read [slice embedding of the pixel | matrix rows] directly."""
+    def fused_outputs(self, u: torch.Tensor, slice_idx: torch.Tensor, S: int):
+        """Hash grid (feature-major) + the three fused MLPs -> raw network outputs:
+        z (1 + n_features_z, N), log_var (N) | None, log_bias (N) | None.  No (N,E) row-major pe, no expanded
+        slice embedding, no concatenated MLP inputs are materialised (models.py:329-355 builds all three)."""
         a = self.args
+        inr = self.inr
+        enc = inr.encoding
+        pe = hashgrid_encode(u, enc.params, enc.spec, _lib.LAYOUT_FEATURE_MAJOR, enc.grad_accum)  # (E, N)
+        z = fused_mlp_mod.fused_mlp(inr.density_net, None, pe, 0, pe.shape[0], S)
+        se = self.slice_embedding(slice_idx) if a.n_features_slice else None  # (B, n_features_slice)
+        log_bias = log_var = None
+        if a.n_levels_bias:
+            kb = a.n_levels_bias * a.n_features_per_level
+            log_bias = fused_mlp_mod.fused_mlp(self.b_net, se, pe, 0, kb, S)[0]
+        if not a.no_pixel_variance:
+            log_var = fused_mlp_mod.fused_mlp(self.sigma_net, se, z, 1, a.n_features_z, S)[0]
+        return z, log_var, log_bias
+
+    def net_forward_fused(self, x: torch.Tensor, slice_idx: torch.Tensor, u: Optional[torch.Tensor] = None) -> Dict[str, Any]:
+        """net_forward (models.py:329-355) on the fused kernels; same result dict."""
         inr = self.inr
         B, S = x.shape[0], x.shape[1]
         if u is None:
             u = ((x - inr.bounding_box[0]) / (inr.bounding_box[1] - inr.bounding_box[0])).reshape(-1, 3)
-        enc = inr.encoding
-        pe = hashgrid_encode(u, enc.params, enc.spec, _lib.LAYOUT_FEATURE_MAJOR, enc.grad_accum)  # (E, N)
-        E = pe.shape[0]
-        z = fused_mlp_mod.fused_mlp(inr.density_net, None, pe, 0, E, S)  # (1 + n_features_z, N)
+        z, log_var, log_bias = self.fused_outputs(u, slice_idx, S)
         results = {"density": F.softplus(z[0]).view(B, S)}
-        se = self.slice_embedding(slice_idx) if a.n_features_slice else None  # (B, n_features_slice)
-        if a.n_levels_bias:
-            kb = a.n_levels_bias * a.n_features_per_level
-            results["log_bias"] = fused_mlp_mod.fused_mlp(self.b_net, se, pe, 0, kb, S)[0].view(B, S)
-        if not a.no_pixel_variance:
-            results["log_var"] = fused_mlp_mod.fused_mlp(self.sigma_net, se, z, 1, a.n_features_z, S)[0].view(B, S)
+        if log_bias is not None:
+            results["log_bias"] = log_bias.view(B, S)
+        if log_var is not None:
+            results["log_var"] = log_var.view(B, S)
         return results
 
     def net_forward(self, x: torch.Tensor, se: Optional[torch.Tensor] = None) -> Dict[str, Any]:

@@ -332,6 +332,64 @@ def test_psf_transform_vs_oracle(device, B, S):
     assert float((mat_d.grad.cpu() - mat.grad).abs().max()) < 2e-4 * scale
 
 
+# ------------------------------------------------------------------ imaging loss
+@pytest.mark.parametrize("reg", ["edge", "TV", "L2"])
+@pytest.mark.parametrize("pix_var,slice_var,bias,scale", [(True, True, False, True), (True, True, True, True),
+                                                          (False, True, False, False), (True, False, True, True),
+                                                          (False, False, False, True)])
+def test_imaging_loss_vs_reference_math(device, reg, pix_var, slice_var, bias, scale):
+    """Fused loss kernel (values + every gradient) vs the reference's formulas (models.py:286-325,366-384)
+    evaluated with PyTorch autograd in fp64 on the CPU.  fp32 kernel: rtol 2e-4 on values, 5e-4 x max|grad|."""
+    from nesvor_amd.loss import imaging_loss
+    from oracle import nesvor_model as nm
+
+    torch.manual_seed(7)
+    B, S, n = 37, 24, 5
+    idx = torch.randint(0, n, (B,))
+    f64 = lambda *sh: torch.randn(*sh, dtype=torch.float64)
+    z0 = (f64(B, S) * 2).requires_grad_(True)
+    lv = (f64(B, S) * 0.3).requires_grad_(True) if pix_var else None
+    lb = (f64(B, S) * 0.1).requires_grad_(True) if bias else None
+    x = (f64(B, 1, 3) * 20 + f64(B, S, 3)).requires_grad_(True)
+    v = torch.rand(B, dtype=torch.float64)
+    c = (torch.rand(n, dtype=torch.float64) + 0.5).requires_grad_(True) if scale else None
+    lvs = (f64(n) * 0.2).requires_grad_(True) if slice_var else None
+    delta = 0.13
+    w = [1.0, 1.0, 2.0, 100.0]
+    # reference formulas
+    density = torch.nn.functional.softplus(z0)
+    bias_t = lb.exp() if bias else 1
+    bias_d = bias_t.detach() if bias else 1
+    cc = c[idx] if scale else 1
+    v_out = cc * (bias_t * density).mean(-1)
+    var = lv.exp() if pix_var else 1
+    if pix_var:
+        var = ((cc.detach() if scale else 1) * (bias_d * var).mean(-1)) ** 2
+    if slice_var:
+        var = var + lvs.exp()[idx]
+    mse = ((v_out - v) ** 2 / (2 * var)).mean()
+    has_var = pix_var or slice_var
+    logvar = 0.5 * var.log().mean() if has_var else torch.zeros((), dtype=torch.float64)
+    ireg = nm.IMAGE_REG[reg](density, x, delta)
+    breg = lb.mean() ** 2 if bias else torch.zeros((), dtype=torch.float64)
+    (w[0] * mse + w[1] * logvar + w[2] * ireg + w[3] * breg).backward()
+
+    d = lambda t: None if t is None else t.detach().float().to(device).requires_grad_(t.requires_grad)
+    Z0, LV, LB, X, C, LVS = d(z0), d(lv), d(lb), d(x), d(c), d(lvs)
+    got = imaging_loss(Z0.view(-1), None if LV is None else LV.view(-1), None if LB is None else LB.view(-1), X,
+                       v.float().to(device), idx.to(device), C, LVS, reg, delta)
+    (w[0] * got[0] + w[1] * got[1] + w[2] * got[2] + w[3] * got[3]).backward()
+    for name, a_, b_ in (("mse", got[0], mse), ("logvar", got[1], logvar), ("ireg", got[2], ireg), ("breg", got[3], breg)):
+        assert abs(float(a_) - float(b_)) <= 2e-4 * abs(float(b_)) + 1e-6, name
+    for name, a_, b_ in (("z0", Z0, z0), ("lv", LV, lv), ("lb", LB, lb), ("x", X, x), ("c", C, c), ("lvs", LVS, lvs)):
+        if b_ is None:
+            continue
+        ref = b_.grad if b_.grad is not None else torch.zeros_like(b_)
+        gotg = a_.grad.cpu().double() if a_.grad is not None else torch.zeros_like(ref)
+        scale_ = float(ref.abs().max()) + 1e-9
+        assert float((gotg - ref).abs().max()) <= 5e-4 * scale_, (name, float((gotg - ref).abs().max()), scale_)
+
+
 # -------------------------------------------------------------------- fused MLP
 @pytest.mark.parametrize("k_a,k_b,b_row0,rows,depth,out_dim,S,N", [
     (0, 32, 0, 32, 2, 16, 8, 1000),     # density_net (ragged N, not a multiple of 16)
