@@ -186,9 +186,17 @@ def main():
             dom = max((k for k in ktimes if k in bytes_pt), key=lambda k: ktimes[k][1])
             ms = ktimes[dom][1]
             achieved = bytes_pt[dom] * n_points / (ms * 1e-3) / 1e9
+            traffic = None
+            try:  # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                    traffic = json.load(fh).get(dom, {}).get("traffic_bytes")
+                if traffic is not None and n_points != (1 << 20):
+                    traffic = None  # the counters were collected at 2^20 points per launch
+            except OSError:
+                pass
             roof = {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": None, "launch_ms": ms,
+                "frac": achieved / 8000.0, "traffic": traffic, "launch_ms": ms,
                 "algorithmic_bytes_per_launch": bytes_pt[dom] * n_points,
                 "other_kernels_ms": {k: round(v[1], 4) for k, v in ktimes.items() if k != dom},
             }
