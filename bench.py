@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--phantom", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="EXPERIMENTAL: replay the step from a captured hipGraph (round 1: faults on replay, off by default)")
     opt = ap.parse_args()
 
     import __graft_entry__ as ge
@@ -155,17 +157,29 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(opt.warmup):
+    # per-kernel HIP-event timing needs eager launches: it runs over its own K steps BEFORE the graph is
+    # captured (same process, same data, same kernels); the timed region then replays the hipGraph.
+    use_graph = opt.graph
+    ktimes = {}
+    if not opt.no_kernel_timing:
+        for _ in range(2):
+            step()
+        _lib.kernel_timer.reset(enabled=True)
+        for _ in range(opt.steps):
+            step()
+        torch.cuda.synchronize(device)
+        ktimes = _lib.kernel_timer.summary()
+        _lib.kernel_timer.reset(enabled=False)
+    if use_graph:
+        trainer.enable_graph(opt.batch_size)
+    for _ in range(opt.warmup + (4 if use_graph else 0)):  # 3 eager warm-up steps + the capture step
         step()
-    _lib.kernel_timer.reset(enabled=not opt.no_kernel_timing)
     sync()
     t0 = time.perf_counter()
     for _ in range(opt.steps):
         losses = step()
     sync()
     elapsed = time.perf_counter() - t0
-    ktimes = _lib.kernel_timer.summary() if not opt.no_kernel_timing else {}
-    _lib.kernel_timer.reset(enabled=False)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -197,6 +211,8 @@ def main():
             roof = {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": achieved / 8000.0, "traffic": traffic, "launch_ms": ms,
+                "timing": f"HIP events on the launch stream over {opt.steps} eagerly launched steps of this run"
+                          + (" (the timed region replays the same kernels from a hipGraph)" if use_graph else ""),
                 "algorithmic_bytes_per_launch": bytes_pt[dom] * n_points,
                 "other_kernels_ms": {k: round(v[1], 4) for k, v in ktimes.items() if k != dom},
             }
@@ -212,7 +228,7 @@ def main():
                 "workload": f"phantom3d({opt.phantom}) {opt.stacks}-stack, L={L} T=2^19 F=2 hash + {opt.depth}x64 MLPs, "
                             f"{opt.batch_size} px x {opt.n_samples} samples = 2^{(n_points).bit_length() - 1} points/iter/GPU, "
                             f"fp32, poses optimised, edge regulariser",
-                "global_batch_pixels": global_b, "n_levels": L, "parallelism": f"dp{world}",
+                "global_batch_pixels": global_b, "n_levels": L, "parallelism": f"dp{world}", "hip_graph": use_graph,
                 "masked_pixels": int(M), "n_slices": len(slices),
             },
             "roofline": roof,

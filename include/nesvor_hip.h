@@ -190,6 +190,11 @@ int nesvor_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_
                       float lr, float beta1, float beta2, float eps, float weight_decay,
                       float bias_correction1, float bias_correction2, float grad_scale, int zero_grad,
                       void* stream);
+/* Same step with the eight scalars {lr, beta1, beta2, eps, weight_decay, bias_correction1,
+ * bias_correction2, grad_scale} read from device memory, so that a captured hipGraph of the
+ * training step can be replayed while the step count and the learning rate change. */
+int nesvor_adamw_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                          const float* hyper, int zero_grad, void* stream);
 
 #ifdef __cplusplus
 }
