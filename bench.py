@@ -111,7 +111,7 @@ def main():
         ge.build()
     if world > 1:
         torch.distributed.barrier()
-    device = torch.device("cuda", local_rank)
+    device = ddp.local_device(local_rank)
     torch.cuda.set_device(device)
 
     from nesvor_amd.fused import FusedTrainer

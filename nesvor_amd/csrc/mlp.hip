@@ -516,37 +516,47 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const MlpArgs a) {
     }
   }
 
-  for (int64_t gi = (int64_t)blockIdx.x * 4 + wave; gi < n_groups; gi += (int64_t)gridDim.x * 4) {
+  // All global inputs of a group (dY, the saved activations of every hidden layer, the network input)
+  // are fetched one group AHEAD: this kernel runs one wave per SIMD (the dW accumulators fill the register
+  // file), so nothing else hides the HBM latency.
+  auto load_group = [&](int64_t gi, f32x4 (&go)[1], f32x4 (&hs)[NH][kHB], f32x4 (&x)[KB1]) {
     const int64_t n = gi * 16 + j;
     const bool nv = n < a.N;
-    f32x4 go[1];
+    const int64_t nc = nv ? n : a.N - 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) go[0][r] = (nv && 4 * q + r < a.out_dim) ? a.y[(size_t)(4 * q + r) * a.N + n] : 0.f;
-    f32x4 h[kHB];
 #pragma unroll
-    for (int ib = 0; ib < kHB; ++ib) h[ib] = *reinterpret_cast<const f32x4*>(a.H[NH - 1] + (((size_t)gi * kHB + ib) * 64 + lane) * 4);
-    accumulate_dw<1, kHB>(scratch, go, h, acc_o, db_o, lane);
+    for (int l = 0; l < NH; ++l)
+#pragma unroll
+      for (int ib = 0; ib < kHB; ++ib)
+        hs[l][ib] = *reinterpret_cast<const f32x4*>(a.H[l] + (((size_t)gi * kHB + ib) * 64 + lane) * 4);
+#pragma unroll
+    for (int kb = 0; kb < KB1; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[kb][r] = nv ? fetch_input(a, 16 * kb + 4 * q + r, nc) : 0.f;
+  };
+  const int64_t gstride = (int64_t)gridDim.x * 4;
+  f32x4 go[1], go_n[1], hs[NH][kHB], hs_n[NH][kHB], x[KB1], x_n[KB1];
+  int64_t gi = (int64_t)blockIdx.x * 4 + wave;
+  if (gi < n_groups) load_group(gi, go, hs, x);
+  for (; gi < n_groups; gi += gstride) {
+    const int64_t n = gi * 16 + j;
+    const bool nv = n < a.N;
+    if (gi + gstride < n_groups) load_group(gi + gstride, go_n, hs_n, x_n);
+    accumulate_dw<1, kHB>(scratch, go, hs[NH - 1], acc_o, db_o, lane);
     f32x4 d[kHB];
-    {
-      f32x4 gg[1][1] = {{go[0]}}, dd[1][kHB];
 #pragma unroll
-      for (int ib = 0; ib < kHB; ++ib) dd[0][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-      apply_layer_g1<1, kHB>(imgo, gg[0], dd[0], lane);
-#pragma unroll
-      for (int ib = 0; ib < kHB; ++ib) d[ib] = dd[0][ib];
-    }
+    for (int ib = 0; ib < kHB; ++ib) d[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+    apply_layer_g1<1, kHB>(imgo, go, d, lane);
 #pragma unroll
     for (int l = NH - 1; l >= 0; --l) {
-      // d = dL/dH_l; mask with the saved post-ReLU activations (already in h) -> dpre_l
+      // d = dL/dH_l; mask with the saved post-ReLU activations -> dpre_l
 #pragma unroll
       for (int ib = 0; ib < kHB; ++ib)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d[ib][r] = h[ib][r] > 0.f ? d[ib][r] : 0.f;
+        for (int r = 0; r < 4; ++r) d[ib][r] = hs[l][ib][r] > 0.f ? d[ib][r] : 0.f;
       if (l > 0) {
-        // layer input = H_{l-1}: load once, use for dW_l now and as the mask of the next step
-#pragma unroll
-        for (int ib = 0; ib < kHB; ++ib) h[ib] = *reinterpret_cast<const f32x4*>(a.H[l - 1] + (((size_t)gi * kHB + ib) * 64 + lane) * 4);
-        accumulate_dw<kHB, kHB>(scratch, d, h, acc_h[l - 1], db_h[l - 1], lane);
+        accumulate_dw<kHB, kHB>(scratch, d, hs[l - 1], acc_h[l - 1], db_h[l - 1], lane);
         f32x4 d2[kHB];
 #pragma unroll
         for (int ib = 0; ib < kHB; ++ib) d2[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -554,12 +564,6 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const MlpArgs a) {
 #pragma unroll
         for (int ib = 0; ib < kHB; ++ib) d[ib] = d2[ib];
       } else {
-        f32x4 x[KB1];
-        const int64_t nc = nv ? n : a.N - 1;
-#pragma unroll
-        for (int kb = 0; kb < KB1; ++kb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) x[kb][r] = nv ? fetch_input(a, 16 * kb + 4 * q + r, nc) : 0.f;
         accumulate_dw<kHB, KB1>(scratch, d, x, acc_1, db_1, lane);
         if (a.dxa != nullptr || a.dxb != nullptr) {
           f32x4 dx[KB1];
@@ -582,6 +586,14 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const MlpArgs a) {
         }
       }
     }
+    // rotate the prefetched group in
+    go[0] = go_n[0];
+#pragma unroll
+    for (int l = 0; l < NH; ++l)
+#pragma unroll
+      for (int ib = 0; ib < kHB; ++ib) hs[l][ib] = hs_n[l][ib];
+#pragma unroll
+    for (int kb = 0; kb < KB1; ++kb) x[kb] = x_n[kb];
   }
   // epilogue: per-workgroup partial sums in nn.Linear parameter order W0,b0,W1,b1,...
   float* out = a.dW_partial + (size_t)blockIdx.x * a.total_params;

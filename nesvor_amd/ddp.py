@@ -31,11 +31,20 @@ def init_distributed(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # NESVOR_DIST_BACKEND=gloo lets the multi-process path be exercised on a 1-GPU box (every rank
+            # then shares device 0, see local_device()); production is nccl (= RCCL over xGMI)
+            backend = os.environ.get("NESVOR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def local_device(local_rank: int) -> torch.device:
+    """cuda:<local_rank>, or cuda:0 for every rank when NESVOR_SINGLE_DEVICE=1 (1-GPU test boxes)."""
+    if os.environ.get("NESVOR_SINGLE_DEVICE") == "1":
+        return torch.device("cuda", 0)
+    return torch.device("cuda", local_rank)
 
 
 def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[str, torch.Tensor]:
