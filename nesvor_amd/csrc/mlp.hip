@@ -26,6 +26,8 @@
 // ([group of 16 samples][feature block][lane][4]) so both the store and the reload are fully
 // coalesced 1 KiB wave transactions.
 #include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
 #include "common.h"
 #include "../../include/nesvor_hip.h"
 
@@ -629,8 +631,18 @@ template <typename K>
 int launch_kb(K k1, K k2, K k3, K k4, int kb1, dim3 grid, size_t lds, hipStream_t st, const MlpArgs& a) {
   K k = kb1 == 1 ? k1 : kb1 == 2 ? k2 : kb1 == 3 ? k3 : k4;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    // raise the dynamic-LDS limit once per kernel and size (not per launch: the call is a host-side
+    // attribute change and must not happen inside a stream capture)
+    static std::mutex mu;
+    static std::map<const void*, size_t> raised;
+    std::lock_guard<std::mutex> lock(mu);
+    const void* fn = reinterpret_cast<const void*>(k);
+    auto it = raised.find(fn);
+    if (it == raised.end() || it->second < lds) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      raised[fn] = lds;
+    }
   }
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
   return (int)hipGetLastError();

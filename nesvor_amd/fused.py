@@ -107,7 +107,8 @@ class FusedTrainer:
         st["xyz"].copy_(xyz)
         st["v"].copy_(v)
         st["slice_idx"].copy_(slice_idx)
-        full = self.reduce_hook is None  # with DDP the all-reduce and the optimiser stay outside the graph
+        import os
+        full = self.reduce_hook is None and os.environ.get("NESVOR_GRAPH_FWD_BWD_ONLY") != "1"  # with DDP the all-reduce and the optimiser stay outside the graph
         if self._graph is None:
             if self._graph_warm < 3:
                 self._graph_warm += 1

@@ -100,7 +100,16 @@ class FusedMLPFunction(Function):
         # fused dX+dW+db kernel needs no dpre scratch (signalled by NULL entries); the two-kernel path does
         dpre = [] if fused else [torch.empty_like(s) for s in saved]
         dxa = torch.empty((N, k_a), dtype=torch.float32, device=dev) if (xa is not None and ctx.needs_input_grad[0]) else None
-        dxb = torch.empty((k_b, N), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        # the kernel writes rows [b_row0, b_row0+k_b) of the full-size gradient directly; only the other rows
+        # (row 0 of z for sigma_net) need a zero-fill
+        g_xb = dxb = None
+        if ctx.needs_input_grad[1]:
+            g_xb = torch.empty_like(xb)
+            if b_row0 > 0:
+                g_xb[:b_row0].zero_()
+            if b_row0 + k_b < xb.shape[0]:
+                g_xb[b_row0 + k_b :].zero_()
+            dxb = g_xb[b_row0 : b_row0 + k_b]
         total = sum(w.numel() + b.numel() for w, b in zip(weights, biases))
         n_partial = N_PARTIAL_FUSED if fused else N_PARTIAL
         partial = torch.empty((n_partial, total), dtype=torch.float32, device=dev)
@@ -119,13 +128,6 @@ class FusedMLPFunction(Function):
         g_xa = None
         if dxa is not None:
             g_xa = dxa.view(xa.shape[0], S, k_a).sum(1)
-        g_xb = None
-        if dxb is not None:
-            if b_row0 == 0 and k_b == xb.shape[0]:
-                g_xb = dxb
-            else:
-                g_xb = torch.zeros_like(xb)
-                g_xb[b_row0 : b_row0 + k_b] = dxb
         return (g_xa, g_xb, None, None, None, None, *gw, *gb)
 
 
