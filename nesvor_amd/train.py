@@ -61,11 +61,11 @@ class Dataset(object):
         q1, q2 = torch.quantile(sample, q)
         return self.v[torch.logical_and(self.v > q1, self.v < q2)].mean().item()
 
-    def get_batch(self, batch_size: int, device) -> Dict[str, torch.Tensor]:
+    def get_batch(self, batch_size: int, device, generator=None) -> Dict[str, torch.Tensor]:
         if self.count + batch_size > self.xyz.shape[0]:  # epoch boundary: reshuffle, drop the partial batch
             self.count = 0
             self.epoch += 1
-            perm = torch.randperm(self.xyz.shape[0], device=device)
+            perm = torch.randperm(self.xyz.shape[0], device=device, generator=generator)
             self.xyz, self.v, self.slice_idx = self.xyz[perm], self.v[perm], self.slice_idx[perm]
         sl = slice(self.count, self.count + batch_size)
         self.count += batch_size
@@ -116,10 +116,30 @@ def train(slices: List[Slice], args: Namespace) -> Tuple[INR, List[Slice], Volum
     dataset = Dataset(slices, args)
     model = NeSVoR(dataset.transformation, dataset.resolution, dataset.mean, dataset.bounding_box, args)
     use_fused = getattr(args, "fused", True) and args.dtype == torch.float32
+    # data parallel (one process per GPU): args.batch_size is the GLOBAL batch, every rank draws the same
+    # permutation (seed the global RNG identically before calling train) and takes its slice of each batch
+    import torch.distributed as dist
+
+    from . import ddp
+
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    if world > 1 and not use_fused:
+        raise RuntimeError("data-parallel training needs the fused trainer (flat gradient buffer)")
     if use_fused:
         from .fused import FusedTrainer
 
-        trainer = FusedTrainer(model, args)
+        trainer = FusedTrainer(model, args, world_size=world)
+        if world > 1:
+            ddp.broadcast_params_(trainer.flat.param)
+            trainer.reduce_hook = ddp.make_reduce_hook()
+    perm_gen = None
+    if world > 1:
+        # identical batch permutations on every rank from a dedicated generator; the global stream (PSF
+        # noise) becomes rank-specific
+        perm_gen = torch.Generator(device=args.device)
+        perm_gen.manual_seed(torch.initial_seed())
+        torch.manual_seed(torch.initial_seed() + 7919 * (rank + 1))
     else:
         optimizer, scheduler = build_optimizer(model, args)
     decay_milestones = [int(m * args.n_iter) for m in args.milestones]
@@ -129,7 +149,7 @@ def train(slices: List[Slice], args: Namespace) -> Tuple[INR, List[Slice], Volum
     logging.info("NeSVoR training starts.")
     t0 = time.time()
     for i in range(1, args.n_iter + 1):
-        batch = dataset.get_batch(args.batch_size, args.device)
+        batch = ddp.shard_batch(dataset.get_batch(args.batch_size, args.device, perm_gen), rank, world)
         if use_fused:
             losses = trainer.step(**batch)
         else:

@@ -131,3 +131,49 @@ def test_sample_volume_runs_and_matches_inr(device, golden):
     with torch.no_grad():
         ref = model.inr(xyz[:, None], False).mean(-1)
     torch.testing.assert_close(v, ref)
+
+
+def _ddp_train_worker(rank, world, port, out_dir):
+    import os
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), NESVOR_DIST_BACKEND="gloo", NESVOR_SINGLE_DEVICE="1")
+    import torch.distributed as dist
+
+    from nesvor_amd import ddp
+    from nesvor_amd.phantom import phantom3d, simulate_stacks
+    from nesvor_amd.train import train
+
+    ddp.init_distributed()
+    device = ddp.local_device(rank)
+    torch.cuda.set_device(device)
+    vol = torch.tensor(phantom3d(n=24), dtype=torch.float32, device=device)
+    slices, _ = simulate_stacks(vol, n_stacks=3)
+    args = small_args(device=device, n_iter=12, batch_size=256, n_samples=16)
+    torch.manual_seed(0)
+    inr, out_slices, mask = train(slices, args)
+    sd = {k: v.detach().cpu() for k, v in inr.state_dict().items()}
+    torch.save(sd, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_data_parallel_two_ranks_stay_in_sync(device, tmp_path):
+    """train() under torch.distributed (2 processes, gloo backend, both on the one GPU of the test box):
+    every rank shards the global batch, the flat gradient is all-reduced, and the replicas end with the
+    same parameters (bit-identical: same reduced gradient, same AdamW)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_ddp_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(tmp_path / "rank0.pt")
+    b = torch.load(tmp_path / "rank1.pt")
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert all(torch.isfinite(v).all() for v in a.values())
