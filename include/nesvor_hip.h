@@ -66,6 +66,24 @@ int nesvor_slice_acq_forward(const float* transforms, const float* vol, const ui
                              int D, int H, int W, int d_p, int h_p, int w_p, int n, int h, int w,
                              float res_slice, int interp_psf, void* stream);
 
+/* Adjoint operator A^T (+ optional equalisation) and backward of A, linear-interpolation mode.
+ * Replace `nesvor.slice_acq_cuda.adjoint_forward` / `.backward`
+ * (slice_acq_cuda.cpp:156-161; kernels slice_acq_cuda_kernel.cu:472-693 and :173-470).
+ * Evaluated as a gather over voxels (no atomics, see csrc/slice_acq.hip).
+ *   adjoint_forward: slices (n,h,w) -> vol (D,H,W) overwritten; vol_weight (D,H,W) out or NULL;
+ *                    equalize != 0 divides vol by the accumulated weight where it is > 0.
+ *   backward       : grad_slices (n,h,w) -> grad_vol (D,H,W) overwritten (or NULL) and
+ *                    grad_transforms (n,3,4) overwritten (or NULL).
+ *   scratch        : 2*n*h*w floats (adjoint) / n*h*w floats (backward) of device memory. */
+int nesvor_slice_acq_adjoint_forward(const float* transforms, const float* psf, const float* slices,
+                                     const uint8_t* slices_mask, const uint8_t* vol_mask, float* vol, float* vol_weight,
+                                     float* scratch, int D, int H, int W, int d_p, int h_p, int w_p, int n, int h, int w,
+                                     float res_slice, int equalize, void* stream);
+int nesvor_slice_acq_backward(const float* transforms, const float* vol, const uint8_t* vol_mask, const float* psf,
+                              const float* grad_slices, const uint8_t* slices_mask, float* grad_vol,
+                              float* grad_transforms, float* scratch, int D, int H, int W, int d_p, int h_p, int w_p,
+                              int n, int h, int w, float res_slice, void* stream);
+
 /* ------------------------------------------------------------------------
  * Multi-resolution hash-grid encoding.  Replaces `tinycudann.Encoding`
  * (external module; call site nesvor/nesvor/models.py:22-25, config

@@ -111,6 +111,190 @@ __global__ __launch_bounds__(256) void slice_acq_fwd(
   }
 }
 
+// ------------------------------------------------------------------ adjoint A^T and backward of A
+// The reference scatters every (pixel, PSF tap) into 8 voxels with atomicAdd
+// (slice_acq_cuda_kernel.cu:173-470 backward, :472-670 adjoint).  On MI355X global atomics execute
+// memory-side (~16 G/s): one adjoint of 3 stacks of 77 x 151^2 pixels would be 13 G atomics.  Both
+// operators are therefore evaluated as a GATHER OVER VOXELS: a voxel collects, slice by slice, the
+// samples p = R (q_pixel + tap) + c0 that have it as one of their 8 trilinear corners
+// (-1 <= p - v < 1 per axis).  In the slice frame that is the small box |q + tap - R^T (v - c0)| < sqrt 3,
+// so per slice only ~6 x 6 pixels x <= 4^3 taps are visited.  No atomics, each voxel written once.
+//   pass 1 (per pixel): PSF weight = sum of the taps inside the volume; coef = value / weight under the
+//                       operator's activity rule (adjoint: weight >= 0.5; backward: grad != 0, weight != 0)
+//   pass 2 (per voxel): vol[v] = sum coef * psf[tap] * trilinear(p - v)   [+ the same sum with 1/weight]
+//   backward only     : grad_transforms by one workgroup per slice (block reduction, no atomics)
+constexpr float kSqrt3 = 1.7320509f;
+
+struct PixelGeom { float qx, qy, qz, xc, yc, zc; };
+
+__device__ __forceinline__ PixelGeom pixel_geom(const float* t, int ix, int iy, int h, int w, float res_slice, int D, int H, int W) {
+  PixelGeom g;
+  g.qx = (float)((ix - (w - 1) / 2.) * (double)res_slice + (double)t[3]);
+  g.qy = (float)((iy - (h - 1) / 2.) * (double)res_slice + (double)t[7]);
+  g.qz = t[11];
+  g.xc = t[0] * g.qx + t[1] * g.qy + t[2] * g.qz + (W - 1) / 2.f;
+  g.yc = t[4] * g.qx + t[5] * g.qy + t[6] * g.qz + (H - 1) / 2.f;
+  g.zc = t[8] * g.qx + t[9] * g.qy + t[10] * g.qz + (D - 1) / 2.f;
+  return g;
+}
+
+// mode 0: adjoint (value = slices, active iff weight >= 0.5); mode 1: backward (value = grad_slices,
+// active iff value != 0 and weight != 0).  coef[idx] = value / weight, cw[idx] = 1 / weight (0 if inactive).
+__global__ __launch_bounds__(256) void slice_acq_pixel_coef(const float* __restrict__ transforms, const float* __restrict__ psf,
+                                                            const float* __restrict__ value, const uint8_t* __restrict__ slices_mask,
+                                                            float* __restrict__ coef, float* __restrict__ cw, int D, int H, int W,
+                                                            int d_p, int h_p, int w_p, int n, int h, int w, float res_slice, int mode) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n * h * w) return;
+  float c = 0.f, iw = 0.f;
+  const float val = value[idx];
+  const bool on = (slices_mask == nullptr || slices_mask[idx]) && (mode == 0 || val != 0.f);
+  if (on) {
+    const int ix = idx % w, iy = (idx / w) % h, in = idx / ((int64_t)h * w);
+    const float* t = transforms + (size_t)in * 12;
+    const PixelGeom g = pixel_geom(t, ix, iy, h, w, res_slice, D, H, W);
+    float weight = 0.f;
+    int ip = 0;
+    for (int iz = -d_p / 2; iz < (d_p + 1) / 2; ++iz)
+      for (int iyp = -h_p / 2; iyp < (h_p + 1) / 2; ++iyp)
+        for (int ixp = -w_p / 2; ixp < (w_p + 1) / 2; ++ixp, ++ip) {
+          const float pv = psf[ip];
+          if (pv == 0.f) continue;
+          const float x = g.xc + t[0] * ixp + t[1] * iyp + t[2] * iz;
+          const float y = g.yc + t[4] * ixp + t[5] * iyp + t[6] * iz;
+          const float z = g.zc + t[8] * ixp + t[9] * iyp + t[10] * iz;
+          if (x < 0 || y < 0 || z < 0 || x >= W - 1 || y >= H - 1 || z >= D - 1) continue;
+          weight += pv;
+        }
+    const bool active = mode == 0 ? weight >= 0.5f : weight != 0.f;
+    if (active) { c = val / weight; iw = 1.f / weight; }
+  }
+  coef[idx] = c;
+  if (cw != nullptr) cw[idx] = iw;
+}
+
+__global__ __launch_bounds__(256) void slice_acq_adjoint_gather(const float* __restrict__ transforms, const float* __restrict__ psf,
+                                                                const float* __restrict__ coef, const float* __restrict__ cw,
+                                                                const uint8_t* __restrict__ vol_mask, float* __restrict__ vol,
+                                                                float* __restrict__ vol_weight, int D, int H, int W, int d_p,
+                                                                int h_p, int w_p, int n, int h, int w, float res_slice,
+                                                                int equalize, int accumulate) {
+  const int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (iv >= (int64_t)D * H * W) return;
+  const int vx = iv % W, vy = (iv / W) % H, vz = iv / ((int64_t)H * W);
+  float acc = 0.f, accw = 0.f;
+  if (vol_mask == nullptr || vol_mask[iv]) {
+    const float d0 = vx - (W - 1) / 2.f, d1 = vy - (H - 1) / 2.f, d2 = vz - (D - 1) / 2.f;
+    const int tz0 = -d_p / 2, tz1 = (d_p + 1) / 2 - 1, ty0 = -h_p / 2, ty1 = (h_p + 1) / 2 - 1, tx0 = -w_p / 2, tx1 = (w_p + 1) / 2 - 1;
+    for (int k = 0; k < n; ++k) {
+      const float* t = transforms + (size_t)k * 12;
+      // voxel in the slice frame: r = R^T (v - c0)
+      const float rz = t[2] * d0 + t[6] * d1 + t[10] * d2;
+      const float ez = rz - t[11];
+      const int izlo = max(tz0, (int)ceilf(ez - kSqrt3)), izhi = min(tz1, (int)floorf(ez + kSqrt3));
+      if (izlo > izhi) continue;
+      const float rx = t[0] * d0 + t[4] * d1 + t[8] * d2, ry = t[1] * d0 + t[5] * d1 + t[9] * d2;
+      const int ixlo = max(0, (int)ceilf((rx - t[3] - kSqrt3 - tx1) / res_slice + (w - 1) / 2.f));
+      const int ixhi = min(w - 1, (int)floorf((rx - t[3] + kSqrt3 - tx0) / res_slice + (w - 1) / 2.f));
+      const int iylo = max(0, (int)ceilf((ry - t[7] - kSqrt3 - ty1) / res_slice + (h - 1) / 2.f));
+      const int iyhi = min(h - 1, (int)floorf((ry - t[7] + kSqrt3 - ty0) / res_slice + (h - 1) / 2.f));
+      for (int iy = iylo; iy <= iyhi; ++iy)
+        for (int ix = ixlo; ix <= ixhi; ++ix) {
+          const size_t pidx = ((size_t)k * h + iy) * w + ix;
+          const float cf = coef[pidx];
+          const float cwv = cw != nullptr ? cw[pidx] : 0.f;
+          if (cf == 0.f && cwv == 0.f) continue;
+          const PixelGeom g = pixel_geom(t, ix, iy, h, w, res_slice, D, H, W);
+          const int jxlo = max(tx0, (int)ceilf(rx - g.qx - kSqrt3)), jxhi = min(tx1, (int)floorf(rx - g.qx + kSqrt3));
+          const int jylo = max(ty0, (int)ceilf(ry - g.qy - kSqrt3)), jyhi = min(ty1, (int)floorf(ry - g.qy + kSqrt3));
+          for (int iz = izlo; iz <= izhi; ++iz)
+            for (int jy = jylo; jy <= jyhi; ++jy)
+              for (int jx = jxlo; jx <= jxhi; ++jx) {
+                const float pv = psf[((iz - tz0) * h_p + (jy - ty0)) * w_p + (jx - tx0)];
+                if (pv == 0.f) continue;
+                const float x = g.xc + t[0] * jx + t[1] * jy + t[2] * iz;
+                const float y = g.yc + t[4] * jx + t[5] * jy + t[6] * iz;
+                const float z = g.zc + t[8] * jx + t[9] * jy + t[10] * iz;
+                if (x < 0 || y < 0 || z < 0 || x >= W - 1 || y >= H - 1 || z >= D - 1) continue;
+                const float ex = x - vx, ey = y - vy, ezz = z - vz;
+                if (ex < -1.f || ex >= 1.f || ey < -1.f || ey >= 1.f || ezz < -1.f || ezz >= 1.f) continue;
+                // the voxel must be floor(p) or floor(p) + 1 on every axis, with the scatter's weights
+                const float wx = ex >= 0.f ? 1.f - ex : 1.f + ex, wy = ey >= 0.f ? 1.f - ey : 1.f + ey, wz = ezz >= 0.f ? 1.f - ezz : 1.f + ezz;
+                const float wgt = wx * wy * wz * pv;
+                acc += wgt * cf;
+                accw += wgt * cwv;
+              }
+        }
+    }
+  }
+  if (equalize && accw > 0.f) acc /= accw;
+  if (accumulate) vol[iv] += acc; else vol[iv] = acc;
+  if (vol_weight != nullptr) vol_weight[iv] = accw;
+}
+
+// d L / d transforms of the forward operator: one workgroup per slice, block reduction of 12 sums.
+__global__ __launch_bounds__(256) void slice_acq_bwd_transforms(const float* __restrict__ transforms, const float* __restrict__ vol,
+                                                                const uint8_t* __restrict__ vol_mask, const float* __restrict__ psf,
+                                                                const float* __restrict__ coef, float* __restrict__ grad_transforms,
+                                                                int D, int H, int W, int d_p, int h_p, int w_p, int h, int w,
+                                                                float res_slice) {
+  __shared__ float red[4][12];
+  const int k = blockIdx.x;
+  const float* t = transforms + (size_t)k * 12;
+  const int Sy = W, Sz = H * W;
+  float g[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) g[i] = 0.f;
+  for (int pix = threadIdx.x; pix < h * w; pix += blockDim.x) {
+    const float gs = coef[(size_t)k * h * w + pix];
+    if (gs == 0.f) continue;
+    const int ix = pix % w, iy = pix / w;
+    const PixelGeom pg = pixel_geom(t, ix, iy, h, w, res_slice, D, H, W);
+    int ip = 0;
+    for (int iz = -d_p / 2; iz < (d_p + 1) / 2; ++iz)
+      for (int iyp = -h_p / 2; iyp < (h_p + 1) / 2; ++iyp)
+        for (int ixp = -w_p / 2; ixp < (w_p + 1) / 2; ++ixp, ++ip) {
+          const float pv = psf[ip];
+          if (pv == 0.f) continue;
+          const float x = pg.xc + t[0] * ixp + t[1] * iyp + t[2] * iz;
+          const float y = pg.yc + t[4] * ixp + t[5] * iyp + t[6] * iz;
+          const float z = pg.zc + t[8] * ixp + t[9] * iyp + t[10] * iz;
+          if (x < 0 || y < 0 || z < 0 || x >= W - 1 || y >= H - 1 || z >= D - 1) continue;
+          const int xf = (int)floorf(x), yf = (int)floorf(y), zf = (int)floorf(z);
+          const float wx = x - xf, wy = y - yf, wz = z - zf;
+          const int i0 = zf * Sz + yf * Sy + xf;
+          const float pgs = pv * gs;
+          float dx = 0.f, dy = 0.f, dz = 0.f;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const int cx = c & 1, cy = (c >> 1) & 1, cz = c >> 2;
+            const int ic = i0 + cx + cy * Sy + cz * Sz;
+            if (vol_mask != nullptr && !vol_mask[ic]) continue;
+            const float val = pgs * vol[ic];
+            const float ax = cx ? wx : 1.f - wx, ay = cy ? wy : 1.f - wy, az = cz ? wz : 1.f - wz;
+            dx += (cx ? val : -val) * ay * az;
+            dy += (cy ? val : -val) * ax * az;
+            dz += (cz ? val : -val) * ax * ay;
+          }
+          const float ox = pg.qx + ixp, oy = pg.qy + iyp, oz = pg.qz + iz;
+          g[0] += dx * ox; g[1] += dx * oy; g[2] += dx * oz;
+          g[4] += dy * ox; g[5] += dy * oy; g[6] += dy * oz;
+          g[8] += dz * ox; g[9] += dz * oy; g[10] += dz * oz;
+          g[3] += dx * t[0] + dy * t[4] + dz * t[8];
+          g[7] += dx * t[1] + dy * t[5] + dz * t[9];
+          g[11] += dx * t[2] + dy * t[6] + dz * t[10];
+        }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const float s = wave_sum_dpp(g[i]);
+    if (lane == 0) red[wave][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) grad_transforms[(size_t)k * 12 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 }  // namespace
 
 extern "C" int nesvor_slice_acq_forward(const float* transforms, const float* vol, const uint8_t* vol_mask,
@@ -127,5 +311,44 @@ extern "C" int nesvor_slice_acq_forward(const float* transforms, const float* vo
   else
     hipLaunchKernelGGL(slice_acq_fwd<false>, grid, block, 0, (hipStream_t)stream, transforms, vol, vol_mask, slices_mask,
                        psf, slices, slices_weight, D, H, W, d_p, h_p, w_p, n, h, w, res_slice);
+  return (int)hipGetLastError();
+}
+
+extern "C" int nesvor_slice_acq_adjoint_forward(const float* transforms, const float* psf, const float* slices,
+                                                const uint8_t* slices_mask, const uint8_t* vol_mask, float* vol,
+                                                float* vol_weight, float* scratch, int D, int H, int W, int d_p, int h_p,
+                                                int w_p, int n, int h, int w, float res_slice, int equalize, void* stream) {
+  const int64_t np = (int64_t)n * h * w, nv = (int64_t)D * H * W;
+  if (nv <= 0) return 0;
+  if ((int64_t)d_p * h_p * w_p > kMaxTaps) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  float* coef = scratch;
+  float* cw = scratch + np;
+  if (np > 0)
+    hipLaunchKernelGGL(slice_acq_pixel_coef, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, transforms, psf, slices,
+                       slices_mask, coef, cw, D, H, W, d_p, h_p, w_p, n, h, w, res_slice, 0);
+  hipLaunchKernelGGL(slice_acq_adjoint_gather, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, transforms, psf, coef,
+                     (equalize || vol_weight != nullptr) ? cw : (const float*)nullptr, vol_mask, vol, vol_weight, D, H, W, d_p, h_p,
+                     w_p, n, h, w, res_slice, equalize, 0);
+  return (int)hipGetLastError();
+}
+
+extern "C" int nesvor_slice_acq_backward(const float* transforms, const float* vol, const uint8_t* vol_mask,
+                                         const float* psf, const float* grad_slices, const uint8_t* slices_mask,
+                                         float* grad_vol, float* grad_transforms, float* scratch, int D, int H, int W,
+                                         int d_p, int h_p, int w_p, int n, int h, int w, float res_slice, void* stream) {
+  const int64_t np = (int64_t)n * h * w, nv = (int64_t)D * H * W;
+  if (np <= 0 || nv <= 0) return 0;
+  if ((int64_t)d_p * h_p * w_p > kMaxTaps) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  float* coef = scratch;
+  hipLaunchKernelGGL(slice_acq_pixel_coef, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, transforms, psf, grad_slices,
+                     slices_mask, coef, (float*)nullptr, D, H, W, d_p, h_p, w_p, n, h, w, res_slice, 1);
+  if (grad_vol != nullptr)
+    hipLaunchKernelGGL(slice_acq_adjoint_gather, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, transforms, psf, coef,
+                       (const float*)nullptr, vol_mask, grad_vol, (float*)nullptr, D, H, W, d_p, h_p, w_p, n, h, w, res_slice, 0, 0);
+  if (grad_transforms != nullptr)
+    hipLaunchKernelGGL(slice_acq_bwd_transforms, dim3((unsigned)n), dim3(256), 0, st, transforms, vol, vol_mask, psf, coef,
+                       grad_transforms, D, H, W, d_p, h_p, w_p, h, w, res_slice);
   return (int)hipGetLastError();
 }

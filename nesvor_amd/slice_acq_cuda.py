@@ -1,9 +1,10 @@
 """Drop-in for the reference's pybind module ``nesvor.slice_acq_cuda``
 (nesvor/slice_acquisition/slice_acq_cuda.cpp:156-161).
 
-``forward`` is implemented (gfx950 HIP kernel).  ``backward``,
-``adjoint_forward`` and ``adjoint_backward`` are SURVEY.md §8(f) rank-1 "next"
-rows: they raise until built, they never fall back.
+``forward``, ``backward`` and ``adjoint_forward`` run gfx950 HIP kernels (the latter two in the
+default linear-interpolation mode; ``interp_psf=True`` is never used by the reference's own callers
+and raises).  ``adjoint_backward`` (only reached from SVoRT training) is still a §8(f) "next" row:
+it raises, nothing ever falls back.
 """
 import torch
 
@@ -35,13 +36,56 @@ def forward(transforms, vol, vol_mask, slices_mask, psf, slice_shape, res_slice,
     return [slices, weight] if need_weight else [slices]
 
 
-def backward(*args, **kwargs):
-    raise NotImplementedError("slice_acq backward: SURVEY.md §8(f) rank 1, not built yet (no fallback)")
+def _mask(m):
+    m = m if (m is not None and m.numel() > 0) else None
+    if m is not None:
+        _lib.require_device(m, dtype=torch.bool, name="mask")
+    return m
 
 
-def adjoint_forward(*args, **kwargs):
-    raise NotImplementedError("slice_acq adjoint_forward: SURVEY.md §8(f) rank 1, not built yet (no fallback)")
+def backward(transforms, vol, vol_mask, psf, grad_slices, slices_mask, res_slice, interp_psf, need_vol_grad,
+             need_transforms_grad):
+    """-> [grad_vol | None, grad_transforms | None] (slice_acq_cuda_kernel.cu:173-470, host :993-1027)."""
+    if interp_psf:
+        raise NotImplementedError("slice_acq backward: interp_psf=True is not built (no fallback)")
+    _lib.require_device(transforms, vol, psf, grad_slices, dtype=torch.float32, name="slice_acq backward input")
+    vm, sm = _mask(vol_mask), _mask(slices_mask)
+    n, h, w = grad_slices.shape[0], grad_slices.shape[-2], grad_slices.shape[-1]
+    D, H, W = (int(s) for s in vol.shape[-3:])
+    d_p, h_p, w_p = (int(s) for s in psf.shape)
+    grad_vol = torch.empty_like(vol) if need_vol_grad else None
+    grad_tf = torch.empty_like(transforms) if need_transforms_grad else None
+    scratch = torch.empty(n * h * w, dtype=torch.float32, device=vol.device)
+    with torch.cuda.device(vol.device):
+        err = _lib.load().nesvor_slice_acq_backward(
+            _lib.ptr(transforms), _lib.ptr(vol), _lib.ptr(vm), _lib.ptr(psf), _lib.ptr(grad_slices), _lib.ptr(sm),
+            _lib.ptr(grad_vol), _lib.ptr(grad_tf), _lib.ptr(scratch), D, H, W, d_p, h_p, w_p, n, h, w, float(res_slice),
+            _lib.stream_ptr())
+    _lib.check(err, "slice_acq backward")
+    return [grad_vol, grad_tf]
+
+
+def adjoint_forward(transforms, psf, slices, slices_mask, vol_mask, vol_shape, res_slice, interp_psf, equalize):
+    """A^T -> [vol (1,1,D,H,W), vol_weight (same shape, or an empty tensor when not equalising)]
+    (slice_acq_cuda_kernel.cu:472-693, host :1029-1077)."""
+    if interp_psf:
+        raise NotImplementedError("slice_acq adjoint_forward: interp_psf=True is not built (no fallback)")
+    _lib.require_device(transforms, psf, slices, dtype=torch.float32, name="slice_acq adjoint input")
+    vm, sm = _mask(vol_mask), _mask(slices_mask)
+    n, h, w = slices.shape[0], slices.shape[-2], slices.shape[-1]
+    D, H, W = (int(s) for s in vol_shape)
+    d_p, h_p, w_p = (int(s) for s in psf.shape)
+    vol = torch.empty((1, 1, D, H, W), dtype=slices.dtype, device=slices.device)
+    vol_weight = torch.empty_like(vol) if equalize else None
+    scratch = torch.empty(2 * n * h * w, dtype=torch.float32, device=slices.device)
+    with torch.cuda.device(slices.device):
+        err = _lib.load().nesvor_slice_acq_adjoint_forward(
+            _lib.ptr(transforms), _lib.ptr(psf), _lib.ptr(slices), _lib.ptr(sm), _lib.ptr(vm), _lib.ptr(vol),
+            _lib.ptr(vol_weight), _lib.ptr(scratch), D, H, W, d_p, h_p, w_p, n, h, w, float(res_slice), int(bool(equalize)),
+            _lib.stream_ptr())
+    _lib.check(err, "slice_acq adjoint_forward")
+    return [vol, vol_weight if equalize else torch.empty(0, device=slices.device)]
 
 
 def adjoint_backward(*args, **kwargs):
-    raise NotImplementedError("slice_acq adjoint_backward: SURVEY.md §8(f) rank 1, not built yet (no fallback)")
+    raise NotImplementedError("slice_acq adjoint_backward: SURVEY.md §8(f), not built yet (no fallback)")

@@ -1,6 +1,6 @@
 """Autograd wrappers over the slice-acquisition native module.  Mirrors
 ``nesvor.slice_acquisition`` (slice_acquisition/slice_acq.py:22-211).
-Forward operator A is built; its backward and the adjoint are §8(f) "next".
+A (forward + backward) and A^T (forward) are built; the backward of A^T is §8(f) "next".
 """
 import torch
 from torch.autograd import Function
@@ -40,7 +40,28 @@ def slice_acquisition(transforms, vol, vol_mask, slices_mask, psf, slice_shape, 
     )
 
 
+class SliceAcqAdjointFunction(Function):
+    """slice_acq.py:86-163"""
+
+    @staticmethod
+    def forward(ctx, transforms, psf, slices, slices_mask, vol_mask, vol_shape, res_slice, interp_psf, equalize):
+        if vol_mask is None:
+            vol_mask = torch.empty(0, device=slices.device)
+        if slices_mask is None:
+            slices_mask = torch.empty(0, device=slices.device)
+        vol, vol_weight = _backend.adjoint_forward(
+            transforms.contiguous(), psf.contiguous(), slices.contiguous(), slices_mask, vol_mask, vol_shape, res_slice,
+            interp_psf, equalize)
+        ctx.set_materialize_grads(False)
+        return vol
+
+    @staticmethod
+    def backward(ctx, grad_vol):
+        if grad_vol is None:
+            return (None,) * 9
+        _backend.adjoint_backward()  # raises: SURVEY.md §8(f)
+
+
 def slice_acquisition_adjoint(transforms, psf, slices, slices_mask, vol_mask, vol_shape, res_slice, interp_psf, equalize):
-    return _backend.adjoint_forward(
-        transforms, psf, slices, slices_mask, vol_mask, vol_shape, res_slice, interp_psf, equalize
-    )
+    return SliceAcqAdjointFunction.apply(
+        transforms, psf, slices, slices_mask, vol_mask, vol_shape, res_slice, interp_psf, equalize)

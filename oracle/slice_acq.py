@@ -130,3 +130,161 @@ def slice_acquisition_forward(
     if need_weight:
         return out, torch.where(pos, wsum, torch.zeros_like(wsum)).view(n, 1, h, w)
     return out
+
+
+# --------------------------------------------------------------------------- adjoint and backward
+# SURVEY.md §8(f) rank 1.  Linear (default) interpolation mode only — `interp_psf=True` is never used by
+# the reference's own callers (svort/srr.py, svort/models.py, svort/inference.py all pass False).
+def _geometry(transforms, shape_dhw, slice_shape, res_slice, dt):
+    """Pixel centres in voxel units (n,h,w) x 3 and q = pixel + t in the slice frame."""
+    n = transforms.shape[0]
+    h, w = int(slice_shape[0]), int(slice_shape[1])
+    D, H, W = shape_dhw
+    R = transforms[:, :, :3]
+    T = transforms[:, :, 3]
+    rs = float(torch.tensor(res_slice, dtype=dt))
+    px = (torch.arange(w, dtype=torch.float64) - (w - 1) / 2.0) * rs
+    py = (torch.arange(h, dtype=torch.float64) - (h - 1) / 2.0) * rs
+    qx = (px[None, None, :] + T[:, 0, None, None].double()).to(dt).expand(n, h, w)
+    qy = (py[None, :, None] + T[:, 1, None, None].double()).to(dt).expand(n, h, w)
+    qz = T[:, 2, None, None].expand(n, h, w)
+
+    def rot(row, a, b, c):
+        return R[:, row, 0, None, None] * a + R[:, row, 1, None, None] * b + R[:, row, 2, None, None] * c
+
+    xc = rot(0, qx, qy, qz) + (W - 1) / 2.0
+    yc = rot(1, qx, qy, qz) + (H - 1) / 2.0
+    zc = rot(2, qx, qy, qz) + (D - 1) / 2.0
+    return R, (qx, qy, qz), (xc, yc, zc)
+
+
+def _taps(psf):
+    d_p, h_p, w_p = psf.shape
+    psff = psf.reshape(-1)
+    i_p = -1
+    for iz in range(-(d_p // 2), (d_p + 1) // 2):
+        for iy in range(-(h_p // 2), (h_p + 1) // 2):
+            for ix in range(-(w_p // 2), (w_p + 1) // 2):
+                i_p += 1
+                if float(psff[i_p]) != 0.0:
+                    yield ix, iy, iz, psff[i_p]
+
+
+def _tap_pos(R, centre, ix, iy, iz):
+    xc, yc, zc = centre
+    x = xc + R[:, 0, 0, None, None] * ix + R[:, 0, 1, None, None] * iy + R[:, 0, 2, None, None] * iz
+    y = yc + R[:, 1, 0, None, None] * ix + R[:, 1, 1, None, None] * iy + R[:, 1, 2, None, None] * iz
+    z = zc + R[:, 2, 0, None, None] * ix + R[:, 2, 1, None, None] * iy + R[:, 2, 2, None, None] * iz
+    return x, y, z
+
+
+def _psf_weight(R, centre, psf, dims):
+    """sum of the PSF taps that fall inside the volume (pass 1 of the backward / adjoint kernels,
+    .cu:220-261, :510-558): note it ignores vol_mask and the trilinear split."""
+    D, H, W = dims
+    wsum = torch.zeros_like(centre[0])
+    for ix, iy, iz, pv in _taps(psf):
+        x, y, z = _tap_pos(R, centre, ix, iy, iz)
+        ok = (x >= 0) & (y >= 0) & (z >= 0) & (x < W - 1) & (y < H - 1) & (z < D - 1)
+        wsum = wsum + torch.where(ok, pv.expand_as(x), torch.zeros_like(x))
+    return wsum
+
+
+def slice_acquisition_adjoint_forward(transforms, psf, slices, slices_mask, vol_mask, vol_shape, res_slice,
+                                      interp_psf=False, equalize=False):
+    """A^T: slices (n,1,h,w) -> (vol (1,1,D,H,W), vol_weight | None).
+    Restates slice_acquisition_adjoint_forward_cuda_kernel (.cu:472-670) + equalize (.cu:672-693):
+    every pixel with PSF weight >= 0.5 scatters s * psf/weight * trilinear into the volume."""
+    assert not interp_psf, "oracle restates the linear mode only"
+    dt = slices.dtype
+    D, H, W = (int(s) for s in vol_shape)
+    n, _, h, w = slices.shape
+    R, _, centre = _geometry(transforms, (D, H, W), (h, w), res_slice, dt)
+    weight = _psf_weight(R, centre, psf, (D, H, W))
+    active = weight >= 0.5
+    if slices_mask is not None and slices_mask.numel() > 0:
+        active = active & slices_mask.reshape(n, h, w)
+    s = slices.reshape(n, h, w)
+    vol = torch.zeros(D * H * W, dtype=dt)
+    vw = torch.zeros(D * H * W, dtype=dt)
+    vm = None if vol_mask is None or vol_mask.numel() == 0 else vol_mask.reshape(-1)
+    wsafe = torch.where(active, weight, torch.ones_like(weight))
+    for ix, iy, iz, pv in _taps(psf):
+        x, y, z = _tap_pos(R, centre, ix, iy, iz)
+        ok = active & (x >= 0) & (y >= 0) & (z >= 0) & (x < W - 1) & (y < H - 1) & (z < D - 1)
+        xs, ys, zs = (torch.where(ok, t, torch.zeros_like(t)) for t in (x, y, z))
+        xf, yf, zf = torch.floor(xs), torch.floor(ys), torch.floor(zs)
+        wx, wy, wz = xs - xf, ys - yf, zs - zf
+        iv = (zf * (H * W) + yf * W + xf).long()
+        pn = pv / wsafe
+        for cz in (0, 1):
+            for cy in (0, 1):
+                for cx in (0, 1):
+                    wgt = (wx if cx else 1 - wx) * (wy if cy else 1 - wy) * (wz if cz else 1 - wz) * pn
+                    ic = iv + cx + cy * W + cz * H * W
+                    okc = ok if vm is None else (ok & vm[ic])
+                    wgt = torch.where(okc, wgt, torch.zeros_like(wgt))
+                    vol.index_add_(0, ic.reshape(-1), (wgt * s).reshape(-1))
+                    vw.index_add_(0, ic.reshape(-1), wgt.reshape(-1))
+    if equalize:
+        pos = vw > 0
+        vol = torch.where(pos, vol / torch.where(pos, vw, torch.ones_like(vw)), vol)
+    return vol.view(1, 1, D, H, W), (vw.view(1, 1, D, H, W) if equalize else None)
+
+
+def slice_acquisition_backward(transforms, vol, vol_mask, psf, grad_slices, slices_mask, res_slice,
+                               interp_psf=False, need_vol_grad=True, need_transforms_grad=True):
+    """Backward of A as the reference computes it (.cu:173-470): gs = grad / sum(psf in bounds) is
+    distributed with psf * trilinear weights; the normalising weight is treated as constant."""
+    assert not interp_psf, "oracle restates the linear mode only"
+    dt = vol.dtype
+    D, H, W = vol.shape[-3:]
+    n, _, h, w = grad_slices.shape
+    R, q, centre = _geometry(transforms, (D, H, W), (h, w), res_slice, dt)
+    weight = _psf_weight(R, centre, psf, (D, H, W))
+    g = grad_slices.reshape(n, h, w)
+    active = (weight != 0) & (g != 0)
+    if slices_mask is not None and slices_mask.numel() > 0:
+        active = active & slices_mask.reshape(n, h, w)
+    gs = torch.where(active, g / torch.where(active, weight, torch.ones_like(weight)), torch.zeros_like(g))
+    volf = vol.reshape(-1)
+    vm = None if vol_mask is None or vol_mask.numel() == 0 else vol_mask.reshape(-1)
+    gvol = torch.zeros(D * H * W, dtype=dt)
+    gR = torch.zeros(n, 3, 3, dtype=dt)
+    gT = torch.zeros(n, 3, dtype=dt)
+    qx, qy, qz = q
+    for ix, iy, iz, pv in _taps(psf):
+        x, y, z = _tap_pos(R, centre, ix, iy, iz)
+        ok = active & (x >= 0) & (y >= 0) & (z >= 0) & (x < W - 1) & (y < H - 1) & (z < D - 1)
+        xs, ys, zs = (torch.where(ok, t, torch.zeros_like(t)) for t in (x, y, z))
+        xf, yf, zf = torch.floor(xs), torch.floor(ys), torch.floor(zs)
+        wx, wy, wz = xs - xf, ys - yf, zs - zf
+        iv = (zf * (H * W) + yf * W + xf).long()
+        pg = pv * gs
+        dx = torch.zeros_like(x)
+        dy = torch.zeros_like(x)
+        dz = torch.zeros_like(x)
+        for cz in (0, 1):
+            for cy in (0, 1):
+                for cx in (0, 1):
+                    ax_, ay_, az_ = (wx if cx else 1 - wx), (wy if cy else 1 - wy), (wz if cz else 1 - wz)
+                    ic = iv + cx + cy * W + cz * H * W
+                    okc = ok if vm is None else (ok & vm[ic])
+                    if need_vol_grad:
+                        gvol.index_add_(0, ic.reshape(-1), torch.where(okc, ax_ * ay_ * az_ * pg, torch.zeros_like(pg)).reshape(-1))
+                    if need_transforms_grad:
+                        val = torch.where(okc, pg * volf[ic], torch.zeros_like(pg))
+                        dx = dx + (1.0 if cx else -1.0) * ay_ * az_ * val
+                        dy = dy + (1.0 if cy else -1.0) * ax_ * az_ * val
+                        dz = dz + (1.0 if cz else -1.0) * ax_ * ay_ * val
+        if need_transforms_grad:
+            ox, oy, oz = qx + ix, qy + iy, qz + iz
+            for row, dd in enumerate((dx, dy, dz)):
+                gR[:, row, 0] += (dd * ox).sum((1, 2))
+                gR[:, row, 1] += (dd * oy).sum((1, 2))
+                gR[:, row, 2] += (dd * oz).sum((1, 2))
+            for c in range(3):
+                gT[:, c] += (dx * R[:, 0, c, None, None] + dy * R[:, 1, c, None, None] + dz * R[:, 2, c, None, None]).sum((1, 2))
+    grad_vol = gvol.view(vol.shape) if need_vol_grad else None
+    grad_tf = torch.cat([gR, gT[:, :, None]], -1) if need_transforms_grad else None
+    return grad_vol, grad_tf

@@ -43,7 +43,10 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError, match="device"):
         hashgrid_forward(spec, torch.rand(4, 3), torch.zeros(spec.n_params))
     with pytest.raises(NotImplementedError):
-        slice_acq_cuda.adjoint_forward()
+        slice_acq_cuda.adjoint_backward()
+    with pytest.raises(RuntimeError, match="device"):
+        slice_acq_cuda.adjoint_forward(torch.zeros(1, 3, 4), torch.ones(1, 1, 1), torch.zeros(1, 1, 2, 2), torch.empty(0),
+                                       torch.empty(0), (4, 4, 4), 1.0, False, False)
 
 
 def test_product_does_not_import_oracle():

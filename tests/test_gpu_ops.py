@@ -162,6 +162,117 @@ def test_slice_acq_golden_stacks_and_properties(device, golden):
     assert e.shape == (0, 1, 4, 4)
 
 
+def _sa_setup(masks, seed=0):
+    from nesvor_amd.utils import get_PSF
+    from oracle import transform_convert as tc
+
+    torch.manual_seed(seed)
+    vol = torch.rand(1, 1, 18, 20, 22)
+    psf = get_PSF(res_ratio=(1.5, 1.5, 3.0))
+    ax = torch.randn(6, 6) * torch.tensor([0.6, 0.6, 0.6, 3.0, 3.0, 3.0])
+    ax[0] = 0
+    tf = tc.axisangle2mat_forward(ax)
+    vm = (torch.rand(1, 1, 18, 20, 22) > 0.2) if masks else None
+    sm = (torch.rand(6, 1, 14, 12) > 0.3) if masks else None
+    return vol, psf, tf, vm, sm
+
+
+@pytest.mark.parametrize("masks", [False, True])
+@pytest.mark.parametrize("equalize", [False, True])
+def test_slice_acq_adjoint_vs_oracle(device, masks, equalize):
+    """A^T as a gather over voxels vs the oracle's scatter restatement (same pixel activity rule weight >= 0.5)."""
+    from nesvor_amd import slice_acq_cuda as K
+    from oracle import slice_acq as O
+
+    vol, psf, tf, vm, sm = _sa_setup(masks)
+    y = torch.rand(6, 1, 14, 12)
+    ref, wref = O.slice_acquisition_adjoint_forward(tf, psf, y, sm, vm, (18, 20, 22), 1.5, False, equalize)
+    e = torch.empty(0, device=device)
+    got, wgot = K.adjoint_forward(tf.to(device), psf.to(device), y.to(device), e if sm is None else sm.to(device),
+                                  e if vm is None else vm.to(device), (18, 20, 22), 1.5, False, equalize)
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-4, atol=1e-5)
+    if equalize:
+        torch.testing.assert_close(wgot.cpu(), wref, rtol=1e-4, atol=1e-5)
+    else:
+        assert wgot.numel() == 0
+
+
+def test_slice_acq_adjointness_gpu(device):
+    """<A x, y> == <x, A^T y> over the pixels the adjoint keeps (PSF weight >= 0.5), forward and adjoint both HIP."""
+    from nesvor_amd import slice_acq_cuda as K
+    from oracle import slice_acq as O
+
+    vol, psf, tf, _, _ = _sa_setup(False, seed=3)
+    y = torch.rand(6, 1, 14, 12)
+    R, q, c = O._geometry(tf, (18, 20, 22), (14, 12), 1.5, torch.float32)
+    keep = (O._psf_weight(R, c, psf, (18, 20, 22)) >= 0.5).view(6, 1, 14, 12)
+    e = torch.empty(0, device=device)
+    Ax = K.forward(tf.to(device), vol.to(device), e, e, psf.to(device), (14, 12), 1.5, False, False)[0].cpu()
+    Aty = K.adjoint_forward(tf.to(device), psf.to(device), (y * keep).to(device), e, e, (18, 20, 22), 1.5, False, False)[0].cpu()
+    lhs, rhs = float((Ax * y * keep).double().sum()), float((vol * Aty).double().sum())
+    assert abs(lhs - rhs) <= 1e-4 * abs(lhs)
+
+
+@pytest.mark.parametrize("masks", [False, True])
+def test_slice_acq_backward_vs_oracle(device, masks):
+    from nesvor_amd import slice_acq_cuda as K
+    from oracle import slice_acq as O
+
+    vol, psf, tf, vm, sm = _sa_setup(masks, seed=5)
+    g = torch.randn(6, 1, 14, 12)
+    g[0, 0, :3] = 0  # exact zeros are skipped by the reference
+    gv_ref, gt_ref = O.slice_acquisition_backward(tf, vol, vm, psf, g, sm, 1.5)
+    e = torch.empty(0, device=device)
+    gv, gt = K.backward(tf.to(device), vol.to(device), e if vm is None else vm.to(device), psf.to(device), g.to(device),
+                        e if sm is None else sm.to(device), 1.5, False, True, True)
+    torch.testing.assert_close(gv.cpu(), gv_ref, rtol=1e-4, atol=1e-5)
+    scale = float(gt_ref.abs().max())
+    assert float((gt.cpu() - gt_ref).abs().max()) <= 2e-4 * scale
+    only_t = K.backward(tf.to(device), vol.to(device), e, psf.to(device), g.to(device), e, 1.5, False, False, True)
+    assert only_t[0] is None and only_t[1] is not None
+    # autograd through the public wrapper
+    from nesvor_amd.slice_acquisition import slice_acquisition
+
+    v = vol.to(device).requires_grad_(True)
+    t = tf.to(device).requires_grad_(True)
+    out = slice_acquisition(t, v, None, None, psf.to(device), (14, 12), 1.5, False, False)
+    (out * g.to(device)).sum().backward()
+    gv2, gt2 = O.slice_acquisition_backward(tf, vol, None, psf, g, None, 1.5)
+    torch.testing.assert_close(v.grad.cpu(), gv2, rtol=1e-4, atol=1e-5)
+    assert float((t.grad.cpu() - gt2).abs().max()) <= 2e-4 * float(gt2.abs().max())
+
+
+def test_cg_recon_reference_test(device):
+    """tests/slice_acquisition/test_slice_acq.py:13-81: 16 stacks x 22 slices x 40x40 simulated from the 32^3
+    phantom; SRR(n_iter=20, use_CG=True, tol=1e-8) started from the true volume must return it (atol 3e-5)."""
+    from nesvor_amd.phantom import STACK_ANGLES, phantom3d, stack_geometry, stack_transforms
+    from nesvor_amd.slice_acquisition import slice_acquisition
+    from nesvor_amd.srr import SRR
+    from nesvor_amd.transform import RigidTransform, mat_update_resolution
+    from nesvor_amd.utils import get_PSF
+
+    vs, gap, res, res_s = 32, 3, 1, 1.5
+    n_slice, ss = stack_geometry(vs, res, res_s, gap)
+    assert (n_slice, ss) == (22, 40)
+    volume = torch.tensor(phantom3d(n=vs), dtype=torch.float32, device=device)[None, None]
+    psf = get_PSF(res_ratio=(res_s / res, res_s / res, gap / res), device=device)
+    stacks, tfs = [], []
+    for ang in STACK_ANGLES:
+        tf = stack_transforms(ang, n_slice, gap, device)
+        mat = mat_update_resolution(tf.matrix(), 1, res)
+        stacks.append(slice_acquisition(mat, volume, None, None, psf, (ss, ss), res_s / res, False, False))
+        tfs.append(tf)
+    slices, transforms = torch.cat(stacks, 0), RigidTransform.cat(tfs)
+    params = {"psf": psf, "slice_shape": (ss, ss), "res_s": res_s, "res_r": res, "interp_psf": False, "volume_shape": (vs, vs, vs)}
+    theta = mat_update_resolution(transforms.matrix(), 1, res)
+    out = SRR(n_iter=20, use_CG=True, tol=1e-8)(theta, slices, volume, params)
+    torch.testing.assert_close(out, volume, atol=3e-5, rtol=1e-5)
+    # and from a perturbed start CG must move back towards the phantom
+    start = (volume + 0.05 * torch.randn_like(volume)).clamp(min=0)
+    out2 = SRR(n_iter=10, use_CG=True, tol=0.0)(theta, slices, start.clone(), params)
+    assert float((out2 - volume).abs().mean()) < float((start - volume).abs().mean())
+
+
 # --------------------------------------------------------------------- hash grid
 def _psf_cloud(n_pix, S, seed):
     g = torch.Generator().manual_seed(seed)

@@ -179,3 +179,22 @@ def test_moving_average_semantics():
         ema("k", x)
     v = ((1.0 * 0.001) * 0.999 + 2.0 * 0.001) * 0.999 + 4.0 * 0.001
     assert abs(ema["k"] - v / (1 - 0.999**3)) < 1e-12 and ema["missing"] == 0
+
+
+def test_cg_vs_scipy_reference_test():
+    """tests/svort/test_cg.py:9-20 — CG on a 5x5 Hankel system against scipy.sparse.linalg.cg (pure host logic)."""
+    import scipy.linalg
+    import scipy.sparse.linalg
+
+    from nesvor_amd.srr import CG
+
+    n = 5
+    A = scipy.linalg.hankel(np.arange(1, n + 1, dtype=np.float64)) + np.eye(n) * 20  # SPD, as the reference builds it
+    b = np.arange(n, dtype=np.float64)
+    x_ref, _ = scipy.sparse.linalg.cg(A, b, np.zeros_like(b), maxiter=n, atol=1e-12)
+    At = torch.tensor(A)
+    x = CG(lambda v: At @ v, torch.tensor(b), torch.zeros(n, dtype=torch.float64), n, 0.0)
+    np.testing.assert_allclose(x.numpy(), x_ref, rtol=1e-8, atol=1e-10)
+    # started at the exact solution the residual is exactly zero: no NaN (deterministic operators)
+    x2 = CG(lambda v: At @ v, At @ torch.tensor(x_ref), torch.tensor(x_ref), 3, 0.0)
+    assert torch.isfinite(x2).all()
