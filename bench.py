@@ -136,16 +136,12 @@ def main():
 
     global_b = opt.batch_size * world  # weak scaling: per-GPU work fixed
     M = ds.v.shape[0]
-    state = {"count": M, "perm": None}
 
     def next_batch():
-        if state["count"] + global_b > M:
-            state["perm"] = torch.randperm(M, device=device, generator=perm_gen)
-            state["count"] = 0
-        lo = state["count"] + rank * opt.batch_size
-        idx = state["perm"][lo : lo + opt.batch_size]
-        state["count"] += global_b
-        return ds.xyz[idx], ds.v[idx], ds.slice_idx[idx]
+        # the reference's Dataset.get_batch (train.py:60-75): arrays reshuffled once per epoch, batches are
+        # contiguous windows; every rank draws the same permutation and takes its slice of the global batch
+        b = ddp.shard_batch(ds.get_batch(global_b, device, perm_gen), rank, world)
+        return b["xyz"], b["v"], b["slice_idx"]
 
     def step():
         xyz, v, sidx = next_batch()

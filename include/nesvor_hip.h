@@ -181,7 +181,8 @@ int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, const float* x
  * Forward launch (gw == NULL) writes loss_pix (B,3) = per-pixel [MSE term, logVar term,
  * sum_s regulariser term].  Backward launch (gw = device pointer to the 4 upstream
  * gradients d total / d {MSE, logVar, imageReg, biasReg}) writes dz0, dlog_var, dlog_bias
- * (B*S), dx (B,S,3) or NULL, dc_pix (B) or NULL, dlvs_pix (B) or NULL.
+ * (B*S), dx (B,S,3) or NULL, dc_pix (B) or NULL, dlvs_pix (B) or NULL; if loss_pix is
+ * non-NULL as well, the same launch also writes the loss values.
  * reg_type: 0 edge, 1 TV, 2 L2.
  * ---------------------------------------------------------------------- */
 typedef struct {
@@ -194,6 +195,16 @@ typedef struct {
 } nesvor_loss_t;
 
 int nesvor_imaging_loss(const nesvor_loss_t* args, void* stream);
+
+/* Per-pixel -> per-slice gradient accumulation of one training iteration (the index_add /
+ * embedding-backward / sum-over-samples steps autograd runs for models.py:267-325):
+ *   dc[k] += dc_pix[b]; dlvs[k] += dlvs_pix[b]; dmat[k,:] += dpix[b,:] (12 floats);
+ *   dse[k,:] += sum_s dxa[b,s,:]   with k = slice_idx[b].
+ * dxa (B*S, ks) per-sample gradient w.r.t. the slice embedding fed to an MLP.  Any of the four
+ * source pointers may be NULL (skipped).  Outputs are ACCUMULATED into (caller zero-fills). */
+int nesvor_slice_grads(const int64_t* slice_idx, const float* dc_pix, const float* dlvs_pix, const float* dxa,
+                       const float* dpix, float* dc, float* dlvs, float* dse, float* dmat, int B, int S, int ks,
+                       void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused AdamW over a flat fp32 parameter buffer.  Replaces the

@@ -10,9 +10,10 @@
 //       dd = density_s - density_{S-1-s},  dx2 = |x_s - x_{S-1-s}|^2 + 1e-6          (TV / L2 analogous)
 //   biasReg = (mean_{b,s} log_bias)^2   (the global mean is passed in: it needs a prior reduction)
 // bias and c enter `var` detached, exactly as the reference writes it.
-// Forward launch (gw == NULL): per pixel, the three loss partial sums.  Backward launch (gw = the four
+// Forward launch (gw == NULL): per pixel, the three loss partial sums (loss_pix).  Backward launch (gw = the four
 // upstream gradients d total / d {MSE, logVar, imageReg, biasReg}, on the device): per pixel
-// d(total)/d(c_k), d(total)/d(lvs_k) and per sample d(total)/d(z0, log_var, log_bias, x).
+// d(total)/d(c_k), d(total)/d(lvs_k) and per sample d(total)/d(z0, log_var, log_bias, x); with loss_pix != NULL
+// too the launch produces values and gradients together (the autograd-free training step).
 // One wave per pixel; two streaming passes over the pixel's S samples (pass 1: the two means and the
 // regulariser sums, pass 2: gradients); partner samples S-1-s are re-read from L1/L2.
 #include <hip/hip_runtime.h>
@@ -63,14 +64,12 @@ __global__ __launch_bounds__(256) void imaging_loss_kernel(const nesvor_loss_t a
   const bool has_var = has_lv || a.log_var_slice != nullptr;
   const float e = v_out - a.v[b];
   const float invB = 1.f / a.B;
-  if (a.gw == nullptr) {  // forward launch
-    if (lane == 0) {
-      a.loss_pix[3 * b + 0] = e * e / (2.f * var);
-      a.loss_pix[3 * b + 1] = has_var ? 0.5f * logf(var) : 0.f;
-      a.loss_pix[3 * b + 2] = sreg;  // sum over the pixel's samples of the regulariser term
-    }
-    return;
+  if (a.loss_pix != nullptr && lane == 0) {  // loss values (forward launch, or a combined value+gradient launch)
+    a.loss_pix[3 * b + 0] = e * e / (2.f * var);
+    a.loss_pix[3 * b + 1] = has_var ? 0.5f * logf(var) : 0.f;
+    a.loss_pix[3 * b + 2] = sreg;  // sum over the pixel's samples of the regulariser term
   }
+  if (a.gw == nullptr) return;  // forward launch
   // backward launch: gradients of  gw0 MSE + gw1 logVar + gw2 imageReg + gw3 biasReg
   const float gw_mse = a.gw[0], gw_lv = a.gw[1], gw_img = a.gw[2], gw_bias = a.gw[3];
   const float g_vout = gw_mse * e / var * invB;
@@ -128,5 +127,78 @@ extern "C" int nesvor_imaging_loss(const nesvor_loss_t* args, void* stream) {
   else if (args->reg_type == 1) hipLaunchKernelGGL(imaging_loss_kernel<1>, grid, block, 0, (hipStream_t)stream, *args);
   else if (args->reg_type == 2) hipLaunchKernelGGL(imaging_loss_kernel<2>, grid, block, 0, (hipStream_t)stream, *args);
   else return (int)hipErrorInvalidValue;
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-pixel -> per-slice gradient accumulation of the training step (one launch instead of four
+// index_add + one (N,k)->(B,k) reduction): for pixel b of slice k = slice_idx[b]
+//   dc[k] += dc_pix[b];  dlvs[k] += dlvs_pix[b];  dmat[k] += dpix[b] (12 floats);
+//   dse[k] += sum_s dxa[b,s,:]   (dxa: the per-SAMPLE gradient of the slice-embedding input of an MLP)
+// One wave per pixel; global fp32 atomics (n is a few hundred slices: ~B/n adds per address).
+namespace {
+
+__global__ __launch_bounds__(256) void slice_grads_kernel(const int64_t* __restrict__ slice_idx, const float* __restrict__ dc_pix,
+                                                          const float* __restrict__ dlvs_pix, const float* __restrict__ dxa,
+                                                          const float* __restrict__ dpix, float* dc, float* dlvs, float* dse,
+                                                          float* dmat, int B, int S, int ks) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int64_t k = slice_idx[b];
+  if (dc_pix != nullptr && lane == 0) atomicAdd(dc + k, dc_pix[b]);
+  if (dlvs_pix != nullptr && lane == 1) atomicAdd(dlvs + k, dlvs_pix[b]);
+  if (dpix != nullptr && lane >= 16 && lane < 28) atomicAdd(dmat + k * 12 + (lane - 16), dpix[(size_t)b * 12 + (lane - 16)]);
+  if (dxa == nullptr || ks <= 0) return;
+  const float* src = dxa + (size_t)b * S * ks;
+  const int k4 = ks >> 2;
+  if ((ks & 3) == 0 && (64 % k4) == 0 && ((S * k4) & 255) == 0) {
+    // float4 rows: lane <-> features 4 (lane % k4) .. +3; 1 KB per wave-load, four independent loads in flight
+    const float4* src4 = reinterpret_cast<const float4*>(src);
+    float4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int total4 = S * k4;
+    for (int e = lane; e < total4; e += 256) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 v = src4[e + 64 * t];
+        acc[t].x += v.x; acc[t].y += v.y; acc[t].z += v.z; acc[t].w += v.w;
+      }
+    }
+    float r[4] = {(acc[0].x + acc[1].x) + (acc[2].x + acc[3].x), (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y),
+                  (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z), (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w)};
+    for (int off = 32; off >= k4; off >>= 1) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) r[t] += __shfl_xor(r[t], off, 64);
+    }
+    if (lane < k4) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) atomicAdd(dse + k * ks + 4 * lane + t, r[t]);
+    }
+  } else if ((64 % ks) == 0) {  // lane <-> feature lane % ks, coalesced 256-byte rows
+    float acc = 0.f;
+    const int total = S * ks;
+    for (int e = lane; e < total; e += 64) acc += src[e];
+    for (int off = 32; off >= ks; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane < ks) atomicAdd(dse + k * ks + lane, acc);
+  } else {
+    for (int f = 0; f < ks; ++f) {
+      float acc = 0.f;
+      for (int s = lane; s < S; s += 64) acc += src[(size_t)s * ks + f];
+      acc = wave_sum(acc);
+      if (lane == 0) atomicAdd(dse + k * ks + f, acc);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int nesvor_slice_grads(const int64_t* slice_idx, const float* dc_pix, const float* dlvs_pix, const float* dxa,
+                                  const float* dpix, float* dc, float* dlvs, float* dse, float* dmat, int B, int S, int ks,
+                                  void* stream) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(slice_grads_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, slice_idx, dc_pix, dlvs_pix, dxa,
+                     dpix, dc, dlvs, dse, dmat, B, S, ks);
   return (int)hipGetLastError();
 }

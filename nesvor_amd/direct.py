@@ -1,0 +1,200 @@
+"""Autograd-free evaluation of one NeSVoR training iteration (the loop body of train.py:179-194 around
+``NeSVoR.forward`` models.py:260-327 and ``loss.backward()``).
+
+The autograd path (models.NeSVoR.fused_losses) already runs every heavy stage on the HIP kernels, but the
+engine around them costs ~70 small launches per iteration (gradient accumulation adds, index_put sorts,
+zero-fills, the loss weighting) and the host falls behind the GPU.  Here the same kernels are called
+back-to-back in a fixed order and every parameter gradient is written straight into the flat gradient
+buffer.  Results equal the autograd path up to summation order (tests/test_gpu_model.py).
+
+Supported configuration = the fused one without a bias field (n_levels_bias == 0); anything else keeps the
+autograd path (FusedTrainer decides through ``supported``).
+"""
+import ctypes
+from typing import Dict
+
+import torch
+
+from . import _lib, loss as loss_mod, mlp as mlp_mod, sampler
+from . import transform_convert_cuda as tcc
+from .encoding import hashgrid_backward, hashgrid_forward
+from .models import D_LOSS, DS_LOSS, I_REG, S_LOSS, T_REG, NeSVoR
+from .transform import trans_loss_raw
+
+
+def supported(model: NeSVoR) -> bool:
+    a = model.args
+    if not (model.use_fused_mlp() and getattr(a, "fused_loss", True) and getattr(a, "direct_step", True)):
+        return False
+    if a.n_levels_bias:
+        return False
+    nets = [model.inr.density_net] + ([] if a.no_pixel_variance else [model.sigma_net])
+    return all(len(mlp_mod.linear_layers(n)) - 1 <= 2 for n in nets) and mlp_mod.FUSED_BACKWARD
+
+
+class DirectStep:
+    def __init__(self, model: NeSVoR, flat, weights: Dict[str, float]):
+        self.model, self.flat = model, flat
+        a = model.args
+        dev = flat.param.device
+        self.opt_T = not a.no_transformation_optimization
+        self.has_lv = not a.no_pixel_variance
+        self.has_c = not a.no_slice_scale
+        self.has_lvs = not a.no_slice_variance
+        self.ks = a.n_features_slice if self.has_lv else 0  # the slice embedding only feeds sigma_net here
+        self.has_var = self.has_lv or self.has_lvs
+        w = weights
+        # upstream gradients of the loss kernel's four terms; DS_LOSS is reported but not weighted (train.py:183-186)
+        self.gw = torch.tensor([w.get(D_LOSS, 0), w.get(S_LOSS, 0) if self.has_var else 0, w.get(I_REG, 0), 0.0],
+                               dtype=torch.float32, device=dev)
+        self.w_T = float(w.get(T_REG, 0))
+        self.reg_type = loss_mod.REG_TYPES[a.image_regularization]
+        self.delta = float(model.delta)
+        self.d_layers = mlp_mod.linear_layers(model.inr.density_net)
+        self.s_layers = mlp_mod.linear_layers(model.sigma_net) if self.has_lv else None
+        self.d_seg = self._segment("inr.density_net", self.d_layers)
+        self.s_seg = self._segment("sigma_net", self.s_layers) if self.has_lv else None
+        self._loss_map = None
+        self.side = torch.cuda.Stream(device=dev) if self.opt_T else None
+
+    def _segment(self, prefix, layers):
+        """Flat-gradient segment holding a net's parameters in the kernel's partial-sum order W0,b0,W1,b1,...
+        (None when the flat layout does not keep them contiguous in that order)."""
+        names = []
+        for i, _ in enumerate(layers):
+            names += ["%s.%d.weight" % (prefix, 2 * i), "%s.%d.bias" % (prefix, 2 * i)]
+        offs = self.flat.offsets
+        if any(n not in offs for n in names):
+            return None
+        start = offs[names[0]][0]
+        pos = start
+        for n in names:
+            if offs[n][0] != pos:
+                return None
+            pos += offs[n][1]
+        return self.flat.grad[start:pos]
+
+    def _store_net_grads(self, partial, layers, seg, prefix):
+        if seg is not None:
+            torch.sum(partial, 0, out=seg)
+            return
+        flat = partial.sum(0)
+        off = 0
+        for i, l in enumerate(layers):
+            for p in (l.weight, l.bias):
+                p.grad.copy_(flat[off : off + p.numel()].view_as(p))
+                off += p.numel()
+
+    @torch.no_grad()
+    def run(self, xyz, v, slice_idx, noise=None) -> Dict[str, torch.Tensor]:
+        m, a = self.model, self.model.args
+        lib = _lib.load()
+        dev = xyz.device
+        B, S = xyz.shape[0], a.n_samples
+        N = B * S
+        n = m.n_slices
+        inr = m.inr
+        enc = inr.encoding
+        bb = inr.bounding_box
+        xyz, v, slice_idx = xyz.contiguous(), v.contiguous(), slice_idx.contiguous()
+
+        # pose regulariser (a long serial chain per slice, independent of the batch): on a side stream, joined
+        # where its gradient is added
+        if self.opt_T:
+            main = torch.cuda.current_stream(dev)
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                per, g_t = trans_loss_raw(m.axisangle, m.axisangle_init)
+                t_reg = per.sum()
+            for t in (per, g_t, t_reg):
+                t.record_stream(main)
+
+        # ---- forward ----------------------------------------------------------------------------------
+        if noise is None:
+            noise = torch.randn(B, S, 3, dtype=xyz.dtype, device=dev)
+        mat = tcc.axisangle2mat_forward(m.axisangle)[0]
+        x, u = sampler.forward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb)
+        pe = hashgrid_forward(enc.spec, u, enc.params, _lib.LAYOUT_FEATURE_MAJOR)  # (E, N)
+        dW = [l.weight for l in self.d_layers]
+        dB = [l.bias for l in self.d_layers]
+        z, saved_d = mlp_mod.forward_raw(dW, dB, None, pe, 0, pe.shape[0], S, True)  # (1 + n_features_z, N)
+        log_var = se = None
+        if self.has_lv:
+            sW = [l.weight for l in self.s_layers]
+            sB = [l.bias for l in self.s_layers]
+            se = m.slice_embedding.weight[slice_idx] if self.ks else None
+            log_var, saved_s = mlp_mod.forward_raw(sW, sB, se, z, 1, a.n_features_z, S, True)  # (1, N)
+        c = torch.softmax(m.logit_coef, 0) * n if self.has_c else None
+        lvs = m.log_var_slice if self.has_lvs else None
+
+        # ---- losses: values and gradients in one launch -------------------------------------------------
+        dz = torch.empty_like(z)  # row 0 <- loss kernel, rows [1, 1+n_features_z) <- sigma_net backward
+        written = 1 + (a.n_features_z if self.has_lv else 0)
+        if written < z.shape[0]:
+            dz[written:].zero_()
+        dlv = torch.empty(N, dtype=torch.float32, device=dev) if self.has_lv else None
+        dxl = torch.empty_like(x) if self.opt_T else None
+        loss_pix = torch.empty((B, 3), dtype=torch.float32, device=dev)
+        # per-slice accumulators: [dc (n) | dmat (n,12)] in one zero-filled buffer
+        acc = torch.zeros(n * 13, dtype=torch.float32, device=dev)
+        dc, dmat = acc[:n], acc[n:].view(n, 3, 4)
+        pix = torch.empty((2, B), dtype=torch.float32, device=dev)
+        la = loss_mod._fill(z[0], log_var, None, x, v, slice_idx, c, lvs, None, self.reg_type, self.delta)
+        la.gw, la.loss_pix, la.dz0 = self.gw.data_ptr(), loss_pix.data_ptr(), dz[0].data_ptr()
+        la.dlog_var = None if dlv is None else dlv.data_ptr()
+        la.dx = None if dxl is None else dxl.data_ptr()
+        la.dc_pix = pix[0].data_ptr() if self.has_c else None
+        la.dlvs_pix = pix[1].data_ptr() if self.has_lvs else None
+        with torch.cuda.device(dev), _lib.kernel_timer.span("imaging_loss_bwd"):
+            err = lib.nesvor_imaging_loss(ctypes.byref(la), _lib.stream_ptr())
+        _lib.check(err, "imaging loss (value + gradient)")
+
+        # ---- backward through the networks ----------------------------------------------------------------
+        dxa = None
+        if self.has_lv:
+            dxa, partial_s = mlp_mod.backward_raw(sW, sB, se, z, dlv.view(1, N), saved_s, 1, a.n_features_z, S,
+                                                  dz[1 : 1 + a.n_features_z], se is not None)
+            self._store_net_grads(partial_s, self.s_layers, self.s_seg, "sigma_net")
+        dpe = torch.empty_like(pe)
+        _, partial_d = mlp_mod.backward_raw(dW, dB, None, pe, dz, saved_d, 0, pe.shape[0], S, dpe, False)
+        self._store_net_grads(partial_d, self.d_layers, self.d_seg, "inr.density_net")
+        _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, enc.params.grad.view(-1), self.opt_T,
+                                  _lib.LAYOUT_FEATURE_MAJOR)
+        dpix = sampler.backward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb, dxl, du) if self.opt_T else None
+
+        # ---- per-slice parameters ---------------------------------------------------------------------------
+        g_se = m.slice_embedding.weight.grad if self.ks else None
+        with torch.cuda.device(dev):
+            err = lib.nesvor_slice_grads(
+                _lib.ptr(slice_idx), la.dc_pix, la.dlvs_pix, _lib.ptr(dxa), _lib.ptr(dpix), _lib.ptr(dc),
+                m.log_var_slice.grad.data_ptr() if self.has_lvs else None, _lib.ptr(g_se), _lib.ptr(dmat), B, S,
+                self.ks, _lib.stream_ptr())
+        _lib.check(err, "slice_grads")
+        if self.has_c:  # c = n softmax(l):  dl = c (dc - <dc, c>/n)
+            torch.mul(c, dc - torch.dot(dc, c) / n, out=m.logit_coef.grad)
+        losses = self._loss_dict(loss_pix, B, S)
+        if self.opt_T:
+            dax = tcc.axisangle2mat_backward(dmat, m.axisangle)[0]
+            main.wait_stream(self.side)
+            torch.add(dax, g_t, alpha=self.w_T, out=m.axisangle.grad)
+            losses[T_REG] = t_reg
+            # keep the reference's key order (models.py:316-326): ..., transReg, imageReg
+            losses[I_REG] = losses.pop(I_REG)
+        return losses
+
+    def _loss_dict(self, loss_pix, B, S):
+        """{MSE, logVar, MSE+logVar, imageReg} from the per-pixel partial sums: one reduction + one tiny matmul."""
+        if self._loss_map is None or self._loss_map[2] != (B, S):
+            d = self.delta
+            img = d / (B * S) if self.reg_type == 0 else 1.0 / (B * S)
+            M = torch.tensor([[1.0 / B, 0, 0], [0, 1.0 / B, 0], [1.0 / B, 1.0 / B, 0], [0, 0, img]], dtype=torch.float32)
+            off = torch.tensor([0, 0, 0, -d if self.reg_type == 0 else 0.0], dtype=torch.float32)
+            self._loss_map = (M.to(loss_pix.device), off.to(loss_pix.device), (B, S))
+        M, off, _ = self._loss_map
+        vals = torch.addmv(off, M, loss_pix.sum(0))
+        out = {D_LOSS: vals[0]}
+        if self.has_var:
+            out[S_LOSS] = vals[1]
+            out[DS_LOSS] = vals[2]
+        out[I_REG] = vals[3]
+        return out

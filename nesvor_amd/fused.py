@@ -23,8 +23,11 @@ class FlatParams:
 
     def __init__(self, module: torch.nn.Module):
         named = [(n, p) for n, p in module.named_parameters() if p.numel() > 0]
-        # big table first, 16-byte aligned segments so float4 access never straddles a tensor
-        named.sort(key=lambda kv: -kv[1].numel())
+        # the big table first, everything else in definition order (so each MLP's W0,b0,W1,b1,... stay
+        # adjacent: nesvor_amd.direct sums the kernels' partial gradients straight into that segment);
+        # 16-byte aligned segments so float4 access never straddles a tensor
+        biggest = max(p.numel() for _, p in named)
+        named.sort(key=lambda kv: 0 if kv[1].numel() == biggest else 1)
         self.names, self.offsets, total = [], {}, 0
         for n, p in named:
             self.offsets[n] = (total, p.numel())
@@ -68,11 +71,17 @@ class FusedTrainer:
         dev = self.flat.param.device
         self._hyper = torch.zeros(8, dtype=torch.float32, device=dev)
         self._hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory()
+        # autograd-free evaluation of the iteration when the configuration allows it (nesvor_amd.direct)
+        from . import direct
+
+        self.direct = direct.DirectStep(model, self.flat, self.weights) if direct.supported(model) else None
 
     def decay_lr(self, gamma: float) -> None:
         self.lr *= gamma
 
     def _forward_backward(self, xyz, v, slice_idx) -> Dict[str, torch.Tensor]:
+        if self.direct is not None:
+            return self.direct.run(xyz, v, slice_idx)
         losses = self.model(xyz, v, slice_idx)
         loss = 0
         for k, val in losses.items():

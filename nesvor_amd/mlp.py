@@ -56,29 +56,57 @@ def _ptr_array(tensors):
     return arr
 
 
+def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved):
+    """One forward launch, no autograd: -> (y (out_dim, N), saved hidden activations [] when not need_saved)."""
+    _lib.require_device(xb, *weights, *biases, dtype=torch.float32, name="fused MLP input/params")
+    N = xb.shape[1]
+    k_a = 0 if xa is None else xa.shape[1]
+    if xa is not None:
+        _lib.require_device(xa, dtype=torch.float32, name="fused MLP pixel features")
+        if xa.shape[0] * S != N:
+            raise RuntimeError("pixel features: P * samples_per_pixel must equal N")
+    if weights[0].shape[1] != k_a + k_b:
+        raise RuntimeError("first layer width does not match k_a + k_b")
+    d = _desc(weights, biases, k_a, k_b, b_row0, S)
+    n_pad = (N + 15) // 16 * 16
+    saved = [torch.empty(n_pad * 64, dtype=torch.float32, device=xb.device) for _ in range(len(weights) - 1)] if need_saved else []
+    y = torch.empty((d.out_dim, N), dtype=torch.float32, device=xb.device)
+    with torch.cuda.device(xb.device), _lib.kernel_timer.span("mlp_fwd"):
+        err = _lib.load().nesvor_mlp_forward(
+            ctypes.byref(d), _lib.ptr(xa), _lib.ptr(xb), _lib.ptr(y), _ptr_array(saved) if need_saved else None,
+            N, _lib.stream_ptr())
+    _lib.check(err, "mlp forward")
+    return y, saved
+
+
+def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_dxa):
+    """One backward pass, no autograd.  dxb: (k_b, N) contiguous tensor the input gradient is written to (or
+    None); -> (dxa (N, k_a) per-sample | None, partial (n_partial, n_params) to be summed over dim 0)."""
+    n_layers = len(weights)
+    N = xb.shape[1]
+    k_a = 0 if xa is None else xa.shape[1]
+    d = _desc(weights, biases, k_a, k_b, b_row0, S)
+    dev = xb.device
+    fused = (n_layers - 1) <= 2 and FUSED_BACKWARD
+    # fused dX+dW+db kernel needs no dpre scratch (signalled by NULL entries); the two-kernel path does
+    dpre = [] if fused else [torch.empty_like(s) for s in saved]
+    dxa = torch.empty((N, k_a), dtype=torch.float32, device=dev) if (xa is not None and need_dxa) else None
+    total = sum(w.numel() + b.numel() for w, b in zip(weights, biases))
+    n_partial = N_PARTIAL_FUSED if fused else N_PARTIAL
+    partial = torch.empty((n_partial, total), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _lib.kernel_timer.span("mlp_bwd"):
+        err = _lib.load().nesvor_mlp_backward(
+            ctypes.byref(d), _lib.ptr(xa), _lib.ptr(xb), _lib.ptr(dy), _ptr_array(saved), _ptr_array(dpre),
+            _lib.ptr(dxa), _lib.ptr(dxb), _lib.ptr(partial), n_partial, N, _lib.stream_ptr())
+    _lib.check(err, "mlp backward")
+    return dxa, partial
+
+
 class FusedMLPFunction(Function):
     @staticmethod
     def forward(ctx, xa, xb, b_row0, k_b, S, n_layers, *params):
         weights, biases = params[:n_layers], params[n_layers:]
-        _lib.require_device(xb, *params, dtype=torch.float32, name="fused MLP input/params")
-        N = xb.shape[1]
-        k_a = 0 if xa is None else xa.shape[1]
-        if xa is not None:
-            _lib.require_device(xa, dtype=torch.float32, name="fused MLP pixel features")
-            if xa.shape[0] * S != N:
-                raise RuntimeError("pixel features: P * samples_per_pixel must equal N")
-        if weights[0].shape[1] != k_a + k_b:
-            raise RuntimeError("first layer width does not match k_a + k_b")
-        d = _desc(weights, biases, k_a, k_b, b_row0, S)
-        need_grad = any(ctx.needs_input_grad)
-        n_pad = (N + 15) // 16 * 16
-        saved = [torch.empty(n_pad * 64, dtype=torch.float32, device=xb.device) for _ in range(n_layers - 1)] if need_grad else []
-        y = torch.empty((d.out_dim, N), dtype=torch.float32, device=xb.device)
-        with torch.cuda.device(xb.device), _lib.kernel_timer.span("mlp_fwd"):
-            err = _lib.load().nesvor_mlp_forward(
-                ctypes.byref(d), _lib.ptr(xa), _lib.ptr(xb), _lib.ptr(y), _ptr_array(saved) if need_grad else None,
-                N, _lib.stream_ptr())
-        _lib.check(err, "mlp forward")
+        y, saved = forward_raw(weights, biases, xa, xb, b_row0, k_b, S, any(ctx.needs_input_grad))
         ctx.save_for_backward(xa, xb, *params, *saved)
         ctx.cfg = (b_row0, k_b, S, n_layers)
         return y
@@ -89,17 +117,8 @@ class FusedMLPFunction(Function):
         t = ctx.saved_tensors
         xa, xb = t[0], t[1]
         params = t[2 : 2 + 2 * n_layers]
-        saved = t[2 + 2 * n_layers :]
+        saved = list(t[2 + 2 * n_layers :])
         weights, biases = params[:n_layers], params[n_layers:]
-        N = xb.shape[1]
-        k_a = 0 if xa is None else xa.shape[1]
-        d = _desc(weights, biases, k_a, k_b, b_row0, S)
-        dev = xb.device
-        dy = dy.contiguous()
-        fused = (n_layers - 1) <= 2 and FUSED_BACKWARD
-        # fused dX+dW+db kernel needs no dpre scratch (signalled by NULL entries); the two-kernel path does
-        dpre = [] if fused else [torch.empty_like(s) for s in saved]
-        dxa = torch.empty((N, k_a), dtype=torch.float32, device=dev) if (xa is not None and ctx.needs_input_grad[0]) else None
         # the kernel writes rows [b_row0, b_row0+k_b) of the full-size gradient directly; only the other rows
         # (row 0 of z for sigma_net) need a zero-fill
         g_xb = dxb = None
@@ -110,14 +129,8 @@ class FusedMLPFunction(Function):
             if b_row0 + k_b < xb.shape[0]:
                 g_xb[b_row0 + k_b :].zero_()
             dxb = g_xb[b_row0 : b_row0 + k_b]
-        total = sum(w.numel() + b.numel() for w, b in zip(weights, biases))
-        n_partial = N_PARTIAL_FUSED if fused else N_PARTIAL
-        partial = torch.empty((n_partial, total), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), _lib.kernel_timer.span("mlp_bwd"):
-            err = _lib.load().nesvor_mlp_backward(
-                ctypes.byref(d), _lib.ptr(xa), _lib.ptr(xb), _lib.ptr(dy), _ptr_array(saved), _ptr_array(dpre),
-                _lib.ptr(dxa), _lib.ptr(dxb), _lib.ptr(partial), n_partial, N, _lib.stream_ptr())
-        _lib.check(err, "mlp backward")
+        dxa, partial = backward_raw(weights, biases, xa, xb, dy.contiguous(), saved, b_row0, k_b, S, dxb,
+                                    ctx.needs_input_grad[0])
         flat = partial.sum(0)
         gw, gb, off = [], [], 0
         for w, b in zip(weights, biases):
@@ -127,7 +140,7 @@ class FusedMLPFunction(Function):
             off += b.numel()
         g_xa = None
         if dxa is not None:
-            g_xa = dxa.view(xa.shape[0], S, k_a).sum(1)
+            g_xa = dxa.view(xa.shape[0], S, dxa.shape[1]).sum(1)
         return (g_xa, g_xb, None, None, None, None, *gw, *gb)
 
 

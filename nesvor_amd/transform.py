@@ -57,22 +57,28 @@ def mat2axisangle(mat: torch.Tensor) -> torch.Tensor:
     return _Mat2Axisangle.apply(mat.contiguous())
 
 
+def trans_loss_raw(axisangle, axisangle_init):
+    """One launch, no autograd: -> (per-slice loss terms (n), d loss / d axisangle (n,6))."""
+    from . import _lib
+
+    ax, ax0 = axisangle.contiguous(), axisangle_init.contiguous()
+    _lib.require_device(ax, ax0, dtype=torch.float32, name="trans_loss input")
+    n = ax.shape[0]
+    per = torch.empty(n, dtype=torch.float32, device=ax.device)
+    grad = torch.empty((n, 6), dtype=torch.float32, device=ax.device)
+    with torch.cuda.device(ax.device):
+        err = _lib.load().nesvor_trans_loss(_lib.ptr(ax), _lib.ptr(ax0), _lib.ptr(per), _lib.ptr(grad), n, _lib.stream_ptr())
+    _lib.check(err, "trans_loss")
+    return per, grad
+
+
 class _TransLoss(Function):
     """mean(err_R^2) + 1e-3 mean(err_T^2), err = axisangle(inv(init) o cur): one fused launch
     (models.py:357-363)."""
 
     @staticmethod
     def forward(ctx, axisangle, axisangle_init):
-        from . import _lib
-
-        ax, ax0 = axisangle.contiguous(), axisangle_init.contiguous()
-        _lib.require_device(ax, ax0, dtype=torch.float32, name="trans_loss input")
-        n = ax.shape[0]
-        per = torch.empty(n, dtype=torch.float32, device=ax.device)
-        grad = torch.empty((n, 6), dtype=torch.float32, device=ax.device)
-        with torch.cuda.device(ax.device):
-            err = _lib.load().nesvor_trans_loss(_lib.ptr(ax), _lib.ptr(ax0), _lib.ptr(per), _lib.ptr(grad), n, _lib.stream_ptr())
-        _lib.check(err, "trans_loss")
+        per, grad = trans_loss_raw(axisangle, axisangle_init)
         ctx.save_for_backward(grad)
         return per.sum()
 

@@ -75,6 +75,57 @@ def test_fused_trainer_step_equals_autograd_plus_adamw(device, golden):
         torch.testing.assert_close(p2.detach(), p1.detach(), rtol=5e-3, atol=2e-5, msg=n1)
 
 
+@pytest.mark.parametrize("over", [
+    {}, {"depth": 2}, {"no_transformation_optimization": True}, {"no_pixel_variance": True},
+    {"no_slice_scale": True, "no_slice_variance": True}, {"image_regularization": "TV"},
+])
+def test_direct_step_equals_autograd_step(device, golden, over):
+    """The autograd-free iteration (nesvor_amd.direct) against autograd over the same kernels: same losses,
+    same flat gradient (up to fp32 summation order), same parameters after three AdamW steps."""
+    from nesvor_amd.fused import FusedTrainer
+    from nesvor_amd.train import loss_weights
+
+    from nesvor_amd.models import NeSVoR
+    from nesvor_amd.transform import RigidTransform
+
+    args = small_args(device=device, **over)
+    tf = RigidTransform(torch.tensor(golden["fw_sd::axisangle_init"]).to(device), trans_first=True)
+    res = torch.tensor(golden["ds_resolution"]).to(device)
+    bbox = torch.tensor(golden["fw_sd::inr.bounding_box"]).to(device)
+    torch.manual_seed(3)
+    m1 = NeSVoR(tf, res, float(golden["ds_mean"]), bbox, args)
+    with torch.no_grad():  # per-slice parameters start at 0 / identity: move them so every gradient path is live
+        for name, p in m1.named_parameters():
+            if name in ("logit_coef", "log_var_slice"):
+                p.add_(0.3 * torch.randn_like(p))
+            if name == "axisangle":
+                p.add_(0.02 * torch.randn_like(p))
+    m2 = NeSVoR(tf, res, float(golden["ds_mean"]), bbox, args)
+    m2.load_state_dict(m1.state_dict())
+    d = lambda k: torch.tensor(golden[f"fw_{k}"]).to(device)
+    args.direct_step = False
+    t1 = FusedTrainer(m1, args)
+    args.direct_step = True
+    t2 = FusedTrainer(m2, args)
+    assert t1.direct is None and t2.direct is not None
+    w = loss_weights(args)
+    for it in range(3):
+        noise = torch.randn(48, args.n_samples, 3, generator=torch.Generator().manual_seed(it)).to(device)
+        l1 = m1.forward_with_noise(d("xyz"), d("v"), d("idx"), noise)
+        sum(w[k] * l1[k] for k in l1 if k in w and w[k]).backward()
+        l2 = t2.direct.run(d("xyz"), d("v"), d("idx"), noise)
+        assert list(l1.keys()) == list(l2.keys())
+        for k in l1:
+            assert abs(float(l1[k]) - float(l2[k])) <= 1e-5 * abs(float(l1[k])) + 1e-7, (it, k)
+        for name in t1.flat.names:
+            g1, g2 = t1.flat.grad_view(name), t2.flat.grad_view(name)
+            scale = max(float(g1.abs().max()), 1e-12)
+            assert float((g1 - g2).abs().max()) <= 1e-4 * scale, (it, name)
+        t1.optimizer_step()
+        t2.optimizer_step()
+    torch.testing.assert_close(t2.flat.param, t1.flat.param, rtol=1e-3, atol=1e-5)
+
+
 def _psnr(a, b, peak):
     return 10 * math.log10(peak**2 / float(((a - b) ** 2).mean()))
 
