@@ -12,6 +12,12 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ int wave_sum_u32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));

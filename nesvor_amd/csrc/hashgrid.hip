@@ -265,7 +265,18 @@ __device__ __forceinline__ uint32_t spread3(uint32_t x) {  // 8 bits -> every th
 //    straight from registers to the chunk queues.  Residual duplicates (same vertex reached from
 //    neighbouring cells / other waves) are summed by the chunk's owner in phase 2.
 // LDS: 2 x 64 counters, so occupancy is set by registers only.
-template <int F, int LAYOUT, bool INPUT_GRAD>
+// float (|x| < 2^62, an integer after scaling by a power of two) <-> two's-complement 64-bit fixed point without the
+// compiler's generic f32<->i64 expansions: hi = floor(x / 2^32), lo = x - hi 2^32 (exact in fp32).
+__device__ __forceinline__ unsigned long long to_fixed(float x) {
+  const float t = floorf(x * 0x1p-32f);
+  const float r = fmaf(-t, 0x1p32f, x);  // in [0, 2^32), exact
+  return ((unsigned long long)(uint32_t)(int32_t)t << 32) | (unsigned long long)(uint32_t)r;
+}
+__device__ __forceinline__ float from_fixed(unsigned long long q) {
+  return fmaf((float)(int32_t)(q >> 32), 0x1p32f, (float)(uint32_t)q);
+}
+
+template <int F, int LAYOUT, bool INPUT_GRAD, bool MERGE>
 __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_t g, const BwdPlan plan,
                                                               const float* __restrict__ u,
                                                               const float* __restrict__ table,
@@ -276,10 +287,28 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
   __shared__ uint32_t bcount[kMaxChunks];
   __shared__ uint32_t bbase[kMaxChunks];
   __shared__ uint32_t sortbuf[256];
+  // workgroup-wide merge table (open addressing, keyed by the level-local entry index)
+  constexpr int kSlots = F <= 2 ? 1024 : (F == 4 ? 512 : 256);
+  constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+  __shared__ __attribute__((aligned(16))) uint32_t tkeys[kSlots];
+  // slot values are 64-bit fixed point: integer LDS atomics are returnless and resolve same-address lanes in
+  // hardware (ds_add_f32 retires ~3 cycles per lane on gfx950, a compare-and-swap loop pays a round trip per
+  // retry), and the sum no longer depends on the order of the adds
+  __shared__ __attribute__((aligned(16))) unsigned long long tvals[kSlots * F];
+  __shared__ float wmax[2][4];        // per wave max |dy| of the level (double-buffered: written one level ahead)
+  __shared__ uint32_t merge_stat[2];  // records inserted / drained at the current level
+  __shared__ uint32_t slots_log2;     // slots of the table used at the current level: 256 .. kSlots, ~4x the
+                                      // previous level's distinct vertices (they grow ~1.3-1.5x per level), so that
+                                      // the drain only walks what can be occupied
+  __shared__ uint32_t merge_off;      // set once merging stops paying: finer levels skip the table
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t base = (int64_t)blockIdx.x * 256;
   const int E = g.n_levels * F;
   if (tid < kMaxChunks) bcount[tid] = 0;
+  for (int t = tid; t < kSlots; t += 256) tkeys[t] = kEmpty;
+  for (int t = tid; t < kSlots * F; t += 256) tvals[t] = 0ull;
+  if (tid < 2) merge_stat[tid] = 0;
+  if (tid == 0) { merge_off = MERGE ? 0u : 1u; slots_log2 = __builtin_ctz(kSlots); }
 
   // ---- sort the workgroup's samples by Morton code of the finest-level cell
   uint32_t sv;
@@ -332,6 +361,13 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
   // Everything of a level that needs no shared state: corner indices, run-summed corner values, tail flag.
   auto prepare = [&](int level, const float (&dy)[F], uint32_t (&idx)[8], float (&val)[8][F], bool& tail) {
     const LevelParams p = load_level(g, level);
+    if constexpr (MERGE) {
+      float m = 0.f;
+#pragma unroll
+      for (int f = 0; f < F; ++f) m = fmaxf(m, fabsf(dy[f]));
+      m = wave_max(m);
+      if (lane == 0) wmax[level & 1][tid >> 6] = m;
+    }
     const CellPos c = locate(p, ux, uy, uz);
 #pragma unroll
     for (int k = 0; k < 8; ++k) idx[k] = corner_index(p, c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + (k >> 2));
@@ -407,11 +443,99 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
   load_dy(0, dy_a);
   if (g.n_levels > 1) load_dy(1, dy_b);
   prepare(0, dy_a, idx, val, tail);
+  if constexpr (MERGE) __syncthreads();  // wmax of level 0 must be visible to the other waves
   for (int level = 0; level < g.n_levels; ++level) {
-    // rank of every record inside its chunk's span (LDS integer atomics: ~6 cycles / wave-instruction)
-    uint32_t rank[8];
+    // records this thread will write at this level: either its own 8 run-tail corners, or (merge mode) the
+    // table slots it drains
+    uint32_t rkey[8], rank[8];
+    float rval[8][F];
+    bool rhas[8];
+    const bool merge = MERGE && merge_off == 0u;  // workgroup-uniform (written before the previous barrier)
+    if (merge) {
+      // (a) run tails go through the workgroup's table: duplicates of a vertex reached from neighbouring
+      //     cells, from other runs and from other waves collapse into one record
+      // fixed-point scale of the level: the adds of one slot sum to at most 256 max|dy| (corner weights of a
+      // sample sum to 1), which is mapped below 2^61
+      const float mx = 256.f * fmaxf(fmaxf(wmax[level & 1][0], wmax[level & 1][1]), fmaxf(wmax[level & 1][2], wmax[level & 1][3]));
+      int sexp = 60 - ((int)((__float_as_uint(mx) >> 23) & 0xFFu) - 127);
+      sexp = sexp > 100 ? 100 : sexp;
+      const float fscale = __uint_as_float((uint32_t)(sexp + 127) << 23), finv = __uint_as_float((uint32_t)(127 - sexp) << 23);
+      const uint32_t slog = slots_log2, smask = (1u << slog) - 1u;
+      if (tail) {
+        uint32_t h[8];
+        uint32_t pending = 0;
+        // claim / find the 8 slots: first probes issued together, collisions walked one by one
 #pragma unroll
-    for (int k = 0; k < 8; ++k) rank[k] = tail ? atomicAdd(&bcount[idx[k] >> plan.chunk_shift], 1u) : 0u;
+        for (int k = 0; k < 8; ++k) h[k] = (idx[k] * 2654435761u) >> (32 - slog);
+        uint32_t prev[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) prev[k] = atomicCAS(&tkeys[h[k]], kEmpty, idx[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (prev[k] != kEmpty && prev[k] != idx[k]) pending |= 1u << k;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (pending & (1u << k)) {
+            bool done = false;
+#pragma unroll 1
+            for (int probe = 0; probe < 64 && !done; ++probe) {
+              h[k] = (h[k] + 1) & smask;
+              const uint32_t pv = atomicCAS(&tkeys[h[k]], kEmpty, idx[k]);
+              done = pv == kEmpty || pv == idx[k];
+            }
+            if (done) pending &= ~(1u << k);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (pending & (1u << k)) {  // table crowded: exact fallback
+#pragma unroll
+            for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + idx[k]) * F + f, val[k][f]);
+          } else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) atomicAdd(&tvals[h[k] * F + f], to_fixed(val[k][f] * fscale));
+          }
+        }
+      }
+      const uint32_t n_tail = __builtin_popcountll(__ballot(tail));
+      if (lane == 0 && n_tail) atomicAdd(&merge_stat[0], 8u * n_tail);
+      __syncthreads();
+      // (b) drain: slot -> register record, slot cleared for the next level
+      uint32_t mine = 0;
+      const int spt = 1 << (slog - 8);  // slots per thread at this level (1, 2 or 4)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        rhas[j] = false; rkey[j] = 0; rank[j] = 0;
+#pragma unroll
+        for (int f = 0; f < F; ++f) rval[j][f] = 0.f;
+        if (j < kSlots / 256 && j < spt) {
+          const int slot = tid * spt + j;
+          const uint32_t key = tkeys[slot];
+          if (key != kEmpty) {
+            rhas[j] = true; rkey[j] = key;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+              rval[j][f] = from_fixed(tvals[slot * F + f]) * finv;
+              tvals[slot * F + f] = 0ull;
+            }
+            tkeys[slot] = kEmpty;
+            rank[j] = atomicAdd(&bcount[key >> plan.chunk_shift], 1u);
+            ++mine;
+          }
+        }
+      }
+      const uint32_t wave_mine = (uint32_t)wave_sum_u32(mine);
+      if (lane == 0 && wave_mine) atomicAdd(&merge_stat[1], wave_mine);
+    } else {
+      // rank of every record inside its chunk's span (LDS integer atomics: ~6 cycles / wave-instruction)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        rhas[k] = tail; rkey[k] = idx[k];
+#pragma unroll
+        for (int f = 0; f < F; ++f) rval[k][f] = val[k][f];
+        rank[k] = tail ? atomicAdd(&bcount[idx[k] >> plan.chunk_shift], 1u) : 0u;
+      }
+    }
     __syncthreads();
     // reserve queue space: one returning (memory-side, ~2 us) atomic per non-empty chunk ...
     const uint32_t nb = plan.n_chunks[level];
@@ -420,6 +544,16 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
       const uint32_t cnt = bcount[tid];
       if (cnt) my_base = atomicAdd(&tails[plan.bucket_base[level] + tid], cnt);
       bcount[tid] = 0;
+    }
+    if (merge && tid == 255) {
+      // merging stops paying once fewer than a quarter of the records collapse, and must stop before the
+      // table gets crowded
+      const uint32_t drained = merge_stat[1];
+      if (drained * 4u > merge_stat[0] * 3u || drained * 10u > (uint32_t)kSlots * 7u) merge_off = 1u;
+      uint32_t lg = 8;
+      while ((1u << lg) < 4u * drained && (1u << lg) < (uint32_t)kSlots) ++lg;
+      slots_log2 = lg;
+      merge_stat[0] = 0; merge_stat[1] = 0;
     }
     // ... and hide its latency behind the next level's register-only work
     if (level + 1 < g.n_levels) {
@@ -430,20 +564,21 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
     }
     if (tid < nb) bbase[tid] = my_base;
     __syncthreads();
-    if (tail) {
+    {
       const uint32_t cap = plan.cap[level];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const uint32_t b = idx[k] >> plan.chunk_shift;
+        if (!rhas[k]) continue;
+        const uint32_t b = rkey[k] >> plan.chunk_shift;
         const uint32_t pos = bbase[b] + rank[k];
         if (pos < cap) {
           uint32_t* r = records + (plan.rec_off[level] + (uint64_t)b * cap + pos) * (1 + F);
-          r[0] = idx[k];
+          r[0] = rkey[k];
 #pragma unroll
-          for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(val[k][f]);
+          for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(rval[k][f]);
         } else {  // queue full: exact fallback
 #pragma unroll
-          for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + idx[k]) * F + f, val[k][f]);
+          for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + rkey[k]) * F + f, rval[k][f]);
         }
       }
     }
@@ -609,12 +744,15 @@ int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table,
   if (!(stages & 1)) goto owner_stage;
   e = hipMemsetAsync(tails, 0, kTailBytes, st);
   if (e != hipSuccess) return (int)e;
-  if (gu != nullptr)
-    hipLaunchKernelGGL((hashgrid_bwd_aggregate<F, LAYOUT, true>), grid, block, 0, st, *g, plan, u, table, dpe, gt, gu,
-                       tails, records, N);
-  else
-    hipLaunchKernelGGL((hashgrid_bwd_aggregate<F, LAYOUT, false>), grid, block, 0, st, *g, plan, u, table, dpe, gt, gu,
-                       tails, records, N);
+  {
+    static const bool merge = []() { const char* e = getenv("NESVOR_HASHGRID_MERGE"); return e == nullptr || atoi(e) != 0; }();
+#define NESVOR_LAUNCH_AGG(IG, MG)                                                                                     \
+    hipLaunchKernelGGL((hashgrid_bwd_aggregate<F, LAYOUT, IG, MG>), grid, block, 0, st, *g, plan, u, table, dpe, gt, gu, \
+                       tails, records, N)
+    if (gu != nullptr) { if (merge) NESVOR_LAUNCH_AGG(true, true); else NESVOR_LAUNCH_AGG(true, false); }
+    else { if (merge) NESVOR_LAUNCH_AGG(false, true); else NESVOR_LAUNCH_AGG(false, false); }
+#undef NESVOR_LAUNCH_AGG
+  }
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
 owner_stage:
