@@ -395,15 +395,18 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
 #pragma unroll
       for (int f = 0; f < F; ++f) val[k][f] = w * dy[f];
     }
-    // Segmented inclusive scan over the wave (a run = consecutive lanes in the same cell), on the VALU:
-    // Hillis-Steele inside each 16-lane row with DPP row_shr (out-of-row sources read 0), then the
-    // row-end totals are carried into the following rows through v_readlane.  `flag` = a run head lies
-    // between the row start and this lane.
-    const uint32_t px_ = __shfl_up(c.gx, 1, 64), py_ = __shfl_up(c.gy, 1, 64), pz_ = __shfl_up(c.gz, 1, 64);
-    const bool vprev = __shfl_up((int)valid, 1, 64) != 0;
-    const bool head = lane == 0 || !valid || !vprev || c.gx != px_ || c.gy != py_ || c.gz != pz_;
-    const bool next_head = __shfl_down((int)head, 1, 64) != 0;
-    tail = valid && (lane == 63 || next_head);
+    // Segmented inclusive scan (a run = consecutive lanes of a 16-lane row in the same cell), on the VALU:
+    // Hillis-Steele with DPP row_shr (out-of-row sources read 0).  `flag` = a run head lies between the row
+    // start and this lane.  Runs are cut at the row boundaries: what a longer run would have merged is merged
+    // by the workgroup's table, and the neighbour compares stay on the VALU as row_shr:1 / row_shl:1 DPP moves.
+    const int rl = lane & 15;
+    const uint32_t px_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c.gx, 0x111, 0xf, 0xf, true);
+    const uint32_t py_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c.gy, 0x111, 0xf, 0xf, true);
+    const uint32_t pz_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c.gz, 0x111, 0xf, 0xf, true);
+    const bool vprev = __builtin_amdgcn_update_dpp(0, (int)valid, 0x111, 0xf, 0xf, true) != 0;
+    const bool head = rl == 0 || !valid || !vprev || c.gx != px_ || c.gy != py_ || c.gz != pz_;
+    const bool next_head = __builtin_amdgcn_update_dpp(1, (int)head, 0x101, 0xf, 0xf, false) != 0;  // row_shl:1
+    tail = valid && (rl == 15 || next_head);
     int flag = head ? 1 : 0;
 #define NESVOR_SCAN_STEP(CTRL)                                                                             \
     {                                                                                                      \
@@ -419,21 +422,6 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
     NESVOR_SCAN_STEP(0x114)  // row_shr:4
     NESVOR_SCAN_STEP(0x118)  // row_shr:8
 #undef NESVOR_SCAN_STEP
-    {
-      const int row = lane >> 4;
-      const float open = flag ? 0.f : 1.f;  // this lane's run started before its row
-#pragma unroll
-      for (int r = 1; r < 4; ++r) {
-        const float m = (row == r) ? open : 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-#pragma unroll
-          for (int f = 0; f < F; ++f) {
-            const float carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val[k][f]), 16 * r - 1));
-            val[k][f] = fmaf(m, carry, val[k][f]);
-          }
-      }
-    }
   };
 
   float dy_a[F], dy_b[F];

@@ -31,5 +31,7 @@ for name, u in (("P", uP), ("U", uU)):
     nb = 0
     tails = ws[:16384].view(torch.int32).cpu()
     tot = int(tails.sum())
+    tn = timeit(lambda: run(u, 1, False))
+    print(f"{name}: aggregate without input grad {tn:.3f} ms")
     ta = timeit(lambda: run(u, 1)); to = timeit(lambda: run(u, 2)); t3 = timeit(lambda: run(u, 3))
     print(f"{name}: records {tot/1e6:.2f} M  aggregate {ta:.3f} ms  owner {to:.3f} ms  both {t3:.3f} ms", flush=True)
