@@ -589,7 +589,7 @@ constexpr uint32_t kOwnerSlice = 1u << 18;  // records per owner workgroup: a PS
 // grid.x = sum over buckets of ceil(cap / kOwnerSlice) slices; a slice past the queue tail exits at once.
 constexpr int kOwnerThreads = 1024;  // 16 waves: the owner is latency-bound per thread (global load -> LDS CAS)
 
-template <int F>
+template <int F, bool COALESCED>
 __global__ __launch_bounds__(1024) void hashgrid_bwd_owner(const nesvor_grid_t g, const BwdPlan plan,
                                                           const uint32_t* __restrict__ tails,
                                                           const uint32_t* __restrict__ records,
@@ -638,10 +638,35 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_owner(const nesvor_grid_t g
   // coalesced walk is 2x slower from compare-and-swap retries): each thread walks its own contiguous
   // sub-range, which spreads the lanes over the whole slice.
   // (sub-ranges are multiples of 32 records = 3 x 128 B so that a cache line is fetched by one thread only)
+  constexpr int kUnroll = 8;  // records in flight per thread
+  if constexpr (COALESCED) {
+    // merged queues: a workgroup of the aggregation pass emits every vertex once per level, so neighbouring
+    // records no longer repeat a table entry and neighbouring lanes can take neighbouring records
+    uint32_t r = r0 + tid;
+    for (; r + (kUnroll - 1) * kOwnerThreads < r1; r += kUnroll * kOwnerThreads) {
+      uint32_t key[kUnroll];
+      float v[kUnroll][F];
+#pragma unroll
+      for (int j = 0; j < kUnroll; ++j) {
+        const uint32_t* q = rec + (size_t)(r + j * kOwnerThreads) * (1 + F);
+        key[j] = q[0];
+#pragma unroll
+        for (int f = 0; f < F; ++f) v[j][f] = __uint_as_float(q[1 + f]);
+      }
+#pragma unroll
+      for (int j = 0; j < kUnroll; ++j) add_record(key[j], v[j]);
+    }
+    for (; r < r1; r += kOwnerThreads) {
+      const uint32_t* q = rec + (size_t)r * (1 + F);
+      float v[F];
+#pragma unroll
+      for (int f = 0; f < F; ++f) v[f] = __uint_as_float(q[1 + f]);
+      add_record(q[0], v);
+    }
+  } else {
   const uint32_t per = (((r1 - r0 + kOwnerThreads - 1) / kOwnerThreads) + 31u) & ~31u;
   uint32_t r = r0 + tid * per;
   const uint32_t rend = min(r1, r + per);
-  constexpr int kUnroll = 8;  // records in flight per thread: 96 contiguous bytes, i.e. most of a 128-B line per fetch
   for (; r + kUnroll <= rend; r += kUnroll) {
     uint32_t key[kUnroll];
     float v[kUnroll][F];
@@ -661,6 +686,7 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_owner(const nesvor_grid_t g
 #pragma unroll
     for (int f = 0; f < F; ++f) v[f] = __uint_as_float(q[1 + f]);
     add_record(q[0], v);
+  }
   }
   __syncthreads();
   const uint32_t e0 = chunk << plan.chunk_shift;
@@ -744,8 +770,13 @@ int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table,
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
 owner_stage:
-  if (stages & 2)
-    hipLaunchKernelGGL((hashgrid_bwd_owner<F>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt);
+  if (stages & 2) {
+    static const int coalesced = []() { const char* e = getenv("NESVOR_OWNER_COALESCED"); return e == nullptr ? 1 : atoi(e); }();
+    if (coalesced)
+      hipLaunchKernelGGL((hashgrid_bwd_owner<F, true>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt);
+    else
+      hipLaunchKernelGGL((hashgrid_bwd_owner<F, false>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt);
+  }
   return (int)hipGetLastError();
 }
 
