@@ -189,12 +189,16 @@ def main():
         # algorithmic bytes per sample point: fwd 12+64L+8L ; bwd(params) 12+8L+64L ; bwd(input) 64L+12
         bytes_pt = {
             "hashgrid_fwd": 12 + 32 * F * L + 4 * F * L,
-            "hashgrid_bwd_aggregate": (12 + 4 * F * L + 32 * F * L) + (32 * F * L + 12),
+            "hashgrid_bwd": (12 + 4 * F * L + 32 * F * L) + (32 * F * L + 12),
         }
         roof = None
         if ktimes:
-            dom = max((k for k in ktimes if k in bytes_pt), key=lambda k: ktimes[k][1])
-            ms = ktimes[dom][1]
+            # the hash-grid backward is two launches (aggregation pass + owner pass): one operation, one roofline entry
+            kt = {k: v[1] for k, v in ktimes.items()}
+            if "hashgrid_bwd_aggregate" in kt:
+                kt["hashgrid_bwd"] = kt["hashgrid_bwd_aggregate"] + kt.get("hashgrid_bwd_owner", 0.0)
+            dom = max((k for k in kt if k in bytes_pt), key=lambda k: kt[k])
+            ms = kt[dom]
             achieved = bytes_pt[dom] * n_points / (ms * 1e-3) / 1e9
             traffic = None
             try:  # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
@@ -205,13 +209,24 @@ def main():
             except OSError:
                 pass
             roof = {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                "bound": "hbm", "kernel": dom + (" (hashgrid_bwd_aggregate + hashgrid_bwd_owner launches)" if dom == "hashgrid_bwd" else ""),
+                "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": achieved / 8000.0, "traffic": traffic, "launch_ms": ms,
                 "timing": f"HIP events on the launch stream over {opt.steps} eagerly launched steps of this run"
                           + (" (the timed region replays the same kernels from a hipGraph)" if use_graph else ""),
                 "algorithmic_bytes_per_launch": bytes_pt[dom] * n_points,
                 "other_kernels_ms": {k: round(v[1], 4) for k, v in ktimes.items() if k != dom},
             }
+        roof_mlp = None
+        if ktimes and "mlp_bwd" in ktimes and not args.n_levels_bias and not args.no_pixel_variance:
+            # second-largest consumer: the two fused MLP backward launches (dX + dW + db), fp32 matrix cores
+            nz, ns, W = args.n_features_z, args.n_features_slice, args.width
+            hid = (opt.depth - 1) * W * W
+            fl = 2 * n_points * ((L * F * W + hid + W * (1 + nz)) + ((ns + nz) * W + hid + W))  # one forward of both nets
+            ms2 = 2 * ktimes["mlp_bwd"][1]
+            roof_mlp = {"bound": "mfma", "kernel": "mlp_bwd_fused (density_net + sigma_net launches)", "achieved": 2 * fl / (ms2 * 1e-3) / 1e12,
+                        "peak": 157.3, "unit": "TFLOP/s", "frac": 2 * fl / (ms2 * 1e-3) / 1e12 / 157.3, "traffic": None,
+                        "launch_ms": ms2, "note": "fp32 MFMA (v_mfma_f32_16x16x4_f32) dense peak; flops = 2x forward (dX and dW), padding excluded"}
         out = {
             "metric": "INR train iters/sec (2^20 samples, L=16 hash, 64-wide MLP)",
             "value": iters_per_s,
@@ -228,6 +243,7 @@ def main():
                 "masked_pixels": int(M), "n_slices": len(slices),
             },
             "roofline": roof,
+            "roofline_mlp": roof_mlp,
             "final_losses": final_loss,
         }
         if world == 1 and not opt.no_cpu_baseline:
