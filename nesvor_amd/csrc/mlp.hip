@@ -60,6 +60,8 @@ struct MlpArgs {
   int out_dim;                  // <= 16
   int S;                        // samples per pixel (pixel = n / S)
   int total_params;             // sum of W and b sizes (dW partial row length)
+  int fast;                     // N % 16 == 0, S % 16 == 0, k_a % 16 == 0: group = one pixel, input blocks homogeneous
+  int spg_shift;                // log2(S / 16) when that is a power of two, else -1
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -130,6 +132,55 @@ __device__ __forceinline__ float fetch_input(const MlpArgs& a, int kk, int64_t n
   return 0.f;
 }
 
+// Fast input path (a.fast): the 16 samples of group `gi` belong to one pixel and every 16-feature input block is
+// either all pixel features (one 16-byte load per lane, no per-element index arithmetic) or all rows of xb.
+template <int KB1>
+__device__ __forceinline__ void load_x_fast(const MlpArgs& a, int64_t gi, int j, int q, f32x4 (&x)[KB1]) {
+  const int ka_blocks = a.k_a >> 4;
+  const int64_t n = gi * 16 + j;
+#pragma unroll
+  for (int kb = 0; kb < KB1; ++kb) {
+    if (kb < ka_blocks) {
+      const int64_t pixel = a.spg_shift >= 0 ? (gi >> a.spg_shift) : gi / (a.S >> 4);
+      x[kb] = *reinterpret_cast<const f32x4*>(a.xa + (size_t)pixel * a.k_a + 16 * kb + 4 * q);
+    } else {
+      const int row0 = 16 * (kb - ka_blocks) + 4 * q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + r;
+        const float v = a.xb[(size_t)(a.b_row0 + min(row, a.k_b - 1)) * a.N + n];
+        x[kb][r] = row < a.k_b ? v : 0.f;
+      }
+    }
+  }
+}
+template <int KB1>
+__device__ __forceinline__ void store_dx_fast(const MlpArgs& a, int64_t gi, int j, int q, const f32x4 (&dx)[KB1]) {
+  const int ka_blocks = a.k_a >> 4;
+  const int64_t n = gi * 16 + j;
+#pragma unroll
+  for (int kb = 0; kb < KB1; ++kb) {
+    if (kb < ka_blocks) {
+      if (a.dxa != nullptr) *reinterpret_cast<f32x4*>(a.dxa + (size_t)n * a.k_a + 16 * kb + 4 * q) = dx[kb];
+    } else if (a.dxb != nullptr) {
+      const int row0 = 16 * (kb - ka_blocks) + 4 * q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (row0 + r < a.k_b) a.dxb[(size_t)(row0 + r) * a.N + n] = dx[kb][r];
+    }
+  }
+}
+__device__ __forceinline__ f32x4 load_dy_fast(const MlpArgs& a, int64_t gi, int j, int q) {
+  const int64_t n = gi * 16 + j;
+  f32x4 g;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v = a.y[(size_t)min(4 * q + r, a.out_dim - 1) * a.N + n];
+    g[r] = 4 * q + r < a.out_dim ? v : 0.f;
+  }
+  return g;
+}
+
 // ------------------------------------------------------------------- forward
 template <int KB1>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
@@ -150,7 +201,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
   const int64_t n_groups = (a.N + 15) / 16;
   const int64_t n_tiles = (n_groups + 4 * kG - 1) / (4 * kG);
@@ -159,11 +210,15 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
     f32x4 x[kG][KB1];
 #pragma unroll
     for (int g = 0; g < kG; ++g) {
-      const int64_t n = min((g0 + g) * 16 + j, a.N - 1);
+      if (a.fast) {
+        load_x_fast<KB1>(a, min(g0 + g, n_groups - 1), j, q, x[g]);
+      } else {
+        const int64_t n = min((g0 + g) * 16 + j, a.N - 1);
 #pragma unroll
-      for (int kb = 0; kb < KB1; ++kb)
+        for (int kb = 0; kb < KB1; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[g][kb][r] = fetch_input(a, 16 * kb + 4 * q + r, n);
+          for (int r = 0; r < 4; ++r) x[g][kb][r] = fetch_input(a, 16 * kb + 4 * q + r, n);
+      }
     }
     f32x4 h[kG][kHB];
 #pragma unroll
@@ -443,6 +498,9 @@ __device__ __forceinline__ void accumulate_dw(float* scratch, const f32x4 (&dy)[
   }
 #pragma unroll
   for (int ib = 0; ib < IB; ++ib) read_operand(scratch + (4 + ib) * kTileFloats, j, q, bv[ib]);
+  // keep the operand reads together and ahead of the MFMAs: left alone the scheduler sinks each ds_read next to
+  // its MFMA (register pressure), and with one wave per SIMD every read's latency is then paid in full
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -495,7 +553,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const MlpArgs a) {
   build_image_T(img1, a.W[0], kWidth, k_in, KB1, kHB);
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
   float* scratch = scratch_all + wave * kTilesPerWave * kTileFloats;
   const int64_t n_groups = (a.N + 15) / 16;
@@ -525,17 +583,25 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const MlpArgs a) {
     const int64_t n = gi * 16 + j;
     const bool nv = n < a.N;
     const int64_t nc = nv ? n : a.N - 1;
+    if (a.fast) {
+      go[0] = load_dy_fast(a, gi, j, q);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) go[0][r] = (nv && 4 * q + r < a.out_dim) ? a.y[(size_t)(4 * q + r) * a.N + n] : 0.f;
+      for (int r = 0; r < 4; ++r) go[0][r] = (nv && 4 * q + r < a.out_dim) ? a.y[(size_t)(4 * q + r) * a.N + n] : 0.f;
+    }
 #pragma unroll
     for (int l = 0; l < NH; ++l)
 #pragma unroll
       for (int ib = 0; ib < kHB; ++ib)
         hs[l][ib] = *reinterpret_cast<const f32x4*>(a.H[l] + (((size_t)gi * kHB + ib) * 64 + lane) * 4);
+    if (a.fast) {
+      load_x_fast<KB1>(a, gi, j, q, x);
+    } else {
 #pragma unroll
-    for (int kb = 0; kb < KB1; ++kb)
+      for (int kb = 0; kb < KB1; ++kb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) x[kb][r] = nv ? fetch_input(a, 16 * kb + 4 * q + r, nc) : 0.f;
+        for (int r = 0; r < 4; ++r) x[kb][r] = nv ? fetch_input(a, 16 * kb + 4 * q + r, nc) : 0.f;
+    }
   };
   const int64_t gstride = (int64_t)gridDim.x * 4;
   f32x4 go[1], go_n[1], hs[NH][kHB], hs_n[NH][kHB], x[KB1], x_n[KB1];
@@ -572,7 +638,14 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const MlpArgs a) {
 #pragma unroll
           for (int ib = 0; ib < KB1; ++ib) dx[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
           apply_layer_g1<kHB, KB1>(img1, d, dx, lane);
-          if (nv) {
+          // gfx9 counts loads and stores in one vmcnt and the compiler waits for vmcnt(0) once both kinds are
+          // pending: drain the prefetch loads (issued a whole group of MFMAs ago) HERE, before the stores below,
+          // so that the next iteration does not stall on the latency of these stores when it first touches the
+          // prefetched registers
+          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+          if (a.fast) {
+            store_dx_fast<KB1>(a, gi, j, q, dx);
+          } else if (nv) {
 #pragma unroll
             for (int ib = 0; ib < KB1; ++ib)
 #pragma unroll
@@ -611,6 +684,231 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const MlpArgs a) {
   flush_dw<1, kHB>(red, acc_o, db_o, out + poff, a.out_dim, kWidth);
 }
 
+// ------------------------------------------------- backward, wave-specialised (dX chain | dW)
+// The fused kernel above runs ONE wave per SIMD (its dW accumulators fill the register file), so every LDS
+// round trip, every layer-boundary dependency and every bit of index arithmetic is paid with an idle matrix
+// pipe (measured: ~15 k cycles per 16-sample group for 7.2 k cycles of MFMA).  Here a workgroup is 8 waves:
+//   waves 0-3 ("chain"): dY -> dpre of every layer -> dX, exactly the dX chain above; every dY / dpre fragment
+//                        is also written as a transposed tile into LDS (double-buffered per wave pair);
+//   waves 4-7 ("dW")   : own the dW / db accumulators; one group behind, they read the tiles as A operands,
+//                        fetch the layer inputs (saved activations, network input) straight from global memory
+//                        in B-operand layout, and run the dW MFMAs.
+// Wave w and wave w+4 sit on the same SIMD, each issues half of the MFMAs, and whatever one of them waits for
+// is covered by the other.  One workgroup barrier per group; both roles stay under 256 registers.
+// Requires the fast input path (a.fast).
+template <int OB, int IB>
+__device__ void flush_dw_ws(float* red /* 4 x kHB*256 floats */, const f32x4 (&acc)[OB][IB], const float (&db)[OB],
+                            float* out, int out_dim, int in_dim, int slot /* 0..3: accumulator wave, -1: none */) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob) {
+    __syncthreads();
+    if (slot >= 0) {
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) *reinterpret_cast<f32x4*>(&red[slot * kHB * 256 + (ib * 64 + lane) * 4]) = acc[ob][ib];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < IB * 256; e += blockDim.x) {
+      const float s = (red[e] + red[kHB * 256 + e]) + (red[2 * kHB * 256 + e] + red[3 * kHB * 256 + e]);
+      const int r = e & 3, ln = (e >> 2) & 63, ib = e >> 8;
+      const int o = 16 * ob + 4 * (ln >> 4) + r, in = 16 * ib + (ln & 15);
+      if (o < out_dim && in < in_dim) out[o * in_dim + in] = s;
+    }
+  }
+  __syncthreads();
+  if (slot >= 0) {
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) red[slot * kHB * 256 + ob * 64 + lane] = db[ob];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < OB * 16; e += blockDim.x) {
+    const int ob = e >> 4, ii = e & 15;
+    float s = 0.f;
+    for (int w = 0; w < 4; ++w)
+      for (int qq = 0; qq < 4; ++qq) s += red[w * kHB * 256 + ob * 64 + qq * 16 + ii];
+    if (16 * ob + ii < out_dim) out[out_dim * in_dim + 16 * ob + ii] = s;
+  }
+}
+
+// dW accumulation from a staged A tile set and B operands already in registers
+template <int OB, int IB>
+__device__ __forceinline__ void accumulate_dw_regs(const float* tiles, const f32x4 (&bv)[IB], f32x4 (&acc)[OB][IB],
+                                                   float (&db)[OB], int i, int q) {
+  float av[OB][4];
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob) {
+    read_operand(tiles + ob * kTileFloats, i, q, av[ob]);
+    db[ob] += (av[ob][0] + av[ob][1]) + (av[ob][2] + av[ob][3]);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma4(av[ob][t], bv[ib][t], acc[ob][ib]);
+}
+
+template <int KB1, int NH>
+__global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int k_in = a.k_a + a.k_b;
+  constexpr int kT = 1 + NH * kHB;                      // tiles per group: dY, then dpre of layers NH-1 .. 0
+  float* imgo = lds;                                    // W_out^T : ib = 4, kb = 1
+  float* imgh = imgo + kHB * 1 * 256;                   // W_l^T, l = 1..NH-1
+  float* img1 = imgh + (NH - 1) * kHB * kHB * 256;      // W_1^T : ib = KB1, kb = 4
+  float* tiles = img1 + KB1 * kHB * 256;                // [pair][buffer][kT] tiles; reused as the flush buffer
+  build_image_T(imgo, a.W[NH], a.out_dim, kWidth, kHB, 1);
+  for (int l = 1; l < NH; ++l) build_image_T(imgh + (l - 1) * kHB * kHB * 256, a.W[l], kWidth, kWidth, kHB, kHB);
+  build_image_T(img1, a.W[0], kWidth, k_in, KB1, kHB);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, q = lane >> 4;               // chain: sample j, feature quad q;  dW: feature j, sample quad q
+  const int role = wave >> 2, pair = wave & 3;
+  float* my_tiles = tiles + pair * 2 * kT * kTileFloats;
+  const int64_t n_groups = a.N >> 4;
+  const int64_t gstride = (int64_t)gridDim.x * 4;
+  const int64_t wg_first = (int64_t)blockIdx.x * 4;
+  const int n_it = wg_first < n_groups ? (int)((n_groups - wg_first + gstride - 1) / gstride) : 0;  // same for all 8 waves
+  const int64_t g_first = wg_first + pair;
+
+  f32x4 acc_o[1][kHB];
+  f32x4 acc_h[NH > 1 ? NH - 1 : 1][kHB][kHB];
+  f32x4 acc_1[kHB][KB1];
+  float db_o[1] = {0.f}, db_h[NH > 1 ? NH - 1 : 1][kHB], db_1[kHB];
+
+  if (role == 0) {
+    // ------------------------------------------------------------------ chain waves
+    auto load_group = [&](int64_t gi, f32x4& go, f32x4 (&hs)[NH][kHB]) {
+      go = load_dy_fast(a, gi, j, q);
+#pragma unroll
+      for (int l = 0; l < NH; ++l)
+#pragma unroll
+        for (int ib = 0; ib < kHB; ++ib)
+          hs[l][ib] = *reinterpret_cast<const f32x4*>(a.H[l] + (((size_t)gi * kHB + ib) * 64 + lane) * 4);
+    };
+    f32x4 go, go_n, hs[NH][kHB], hs_n[NH][kHB];
+    if (g_first < n_groups) load_group(g_first, go, hs);
+    for (int it = 0; it <= n_it; ++it) {
+      const int64_t gi = g_first + (int64_t)it * gstride;
+      if (it < n_it && gi < n_groups) {
+        if (gi + gstride < n_groups) load_group(gi + gstride, go_n, hs_n);
+        float* buf = my_tiles + (it & 1) * kT * kTileFloats;
+        stage_tile(buf, go, j, q);
+        f32x4 gov[1] = {go};
+        f32x4 d[kHB];
+#pragma unroll
+        for (int ib = 0; ib < kHB; ++ib) d[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+        apply_layer_g1<1, kHB>(imgo, gov, d, lane);
+#pragma unroll
+        for (int l = NH - 1; l >= 0; --l) {
+#pragma unroll
+          for (int ib = 0; ib < kHB; ++ib) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[ib][r] = hs[l][ib][r] > 0.f ? d[ib][r] : 0.f;
+            stage_tile(buf + (1 + (NH - 1 - l) * kHB + ib) * kTileFloats, d[ib], j, q);
+          }
+          if (l > 0) {
+            f32x4 d2[kHB];
+#pragma unroll
+            for (int ib = 0; ib < kHB; ++ib) d2[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+            apply_layer_g1<kHB, kHB>(imgh + (l - 1) * kHB * kHB * 256, d, d2, lane);
+#pragma unroll
+            for (int ib = 0; ib < kHB; ++ib) d[ib] = d2[ib];
+          } else if (a.dxa != nullptr || a.dxb != nullptr) {
+            f32x4 dx[KB1];
+#pragma unroll
+            for (int ib = 0; ib < KB1; ++ib) dx[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+            apply_layer_g1<kHB, KB1>(img1, d, dx, lane);
+            store_dx_fast<KB1>(a, gi, j, q, dx);
+          }
+        }
+        go = go_n;
+#pragma unroll
+        for (int l = 0; l < NH; ++l)
+#pragma unroll
+          for (int ib = 0; ib < kHB; ++ib) hs[l][ib] = hs_n[l][ib];
+      }
+      __syncthreads();
+    }
+  } else {
+    // ------------------------------------------------------------------ dW waves
+#pragma unroll
+    for (int x = 0; x < kHB; ++x) {
+      acc_o[0][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+      db_1[x] = 0.f;
+#pragma unroll
+      for (int y = 0; y < KB1; ++y) acc_1[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int l = 0; l < (NH > 1 ? NH - 1 : 1); ++l) {
+        db_h[l][x] = 0.f;
+#pragma unroll
+        for (int y = 0; y < kHB; ++y) acc_h[l][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    // B operands (layer inputs) of one group: lane (feature j, sample quad q) holds feature j of samples 4q..4q+3
+    auto load_b = [&](int64_t gi, f32x4 (&hb)[NH][kHB], f32x4 (&xb_)[KB1]) {
+#pragma unroll
+      for (int l = 0; l < NH; ++l)
+#pragma unroll
+        for (int ib = 0; ib < kHB; ++ib) {
+          const float* p = a.H[l] + (((size_t)gi * kHB + ib) * 64 + (j >> 2) * 16 + 4 * q) * 4 + (j & 3);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) hb[l][ib][t] = p[4 * t];
+        }
+      const int ka_blocks = a.k_a >> 4;
+#pragma unroll
+      for (int kb = 0; kb < KB1; ++kb) {
+        if (kb < ka_blocks) {
+          const int64_t pixel = a.spg_shift >= 0 ? (gi >> a.spg_shift) : gi / (a.S >> 4);
+          const float v = a.xa[(size_t)pixel * a.k_a + 16 * kb + j];
+          xb_[kb] = f32x4{v, v, v, v};
+        } else {
+          const int row = 16 * (kb - ka_blocks) + j;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(a.xb + (size_t)(a.b_row0 + min(row, a.k_b - 1)) * a.N + gi * 16 + 4 * q);
+          xb_[kb] = row < a.k_b ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    };
+    f32x4 hb[NH][kHB], xb_[KB1];
+    for (int it = 0; it <= n_it; ++it) {
+      const int64_t gi = g_first + (int64_t)(it - 1) * gstride;
+      if (it > 0 && gi < n_groups) {
+        load_b(gi, hb, xb_);
+        const float* buf = my_tiles + ((it - 1) & 1) * kT * kTileFloats;
+        accumulate_dw_regs<1, kHB>(buf, hb[NH - 1], acc_o, db_o, j, q);
+#pragma unroll
+        for (int l = NH - 1; l >= 0; --l) {
+          const float* dt = buf + (1 + (NH - 1 - l) * kHB) * kTileFloats;
+          if (l > 0) accumulate_dw_regs<kHB, kHB>(dt, hb[l - 1], acc_h[l - 1], db_h[l - 1], j, q);
+          else accumulate_dw_regs<kHB, KB1>(dt, xb_, acc_1, db_1, j, q);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // epilogue: per-workgroup partial sums in nn.Linear parameter order W0,b0,W1,b1,... (accumulators live in waves 4-7)
+  const int slot = role == 1 ? pair : -1;
+  float* out = a.dW_partial + (size_t)blockIdx.x * a.total_params;
+  float* red = tiles;
+  int poff = 0;
+  flush_dw_ws<kHB, KB1>(red, acc_1, db_1, out + poff, kWidth, k_in, slot);
+  poff += kWidth * k_in + kWidth;
+#pragma unroll
+  for (int l = 1; l < NH; ++l) {
+    flush_dw_ws<kHB, kHB>(red, acc_h[l - 1], db_h[l - 1], out + poff, kWidth, kWidth, slot);
+    poff += kWidth * kWidth + kWidth;
+  }
+  flush_dw_ws<1, kHB>(red, acc_o, db_o, out + poff, a.out_dim, kWidth, slot);
+}
+
+size_t ws_bwd_lds_bytes(int n_hidden, int kb1) {
+  size_t img = (size_t)kHB * 256 + (size_t)(n_hidden - 1) * kHB * kHB * 256 + (size_t)kb1 * kHB * 256;
+  size_t tiles = 4 * 2 * (size_t)(1 + n_hidden * kHB) * kTileFloats;
+  if (tiles < 4 * (size_t)kHB * 256) tiles = 4 * (size_t)kHB * 256;
+  return sizeof(float) * (img + tiles);
+}
+
 size_t fused_bwd_lds_bytes(int n_hidden, int kb1) {
   size_t img = (size_t)kHB * 256 + (size_t)(n_hidden - 1) * kHB * kHB * 256 + (size_t)kb1 * kHB * 256;
   size_t scratch = 4 * (size_t)kTilesPerWave * kTileFloats;
@@ -628,7 +926,7 @@ size_t bwd_lds_bytes(int n_linear, int kb1) {
 }
 
 template <typename K>
-int launch_kb(K k1, K k2, K k3, K k4, int kb1, dim3 grid, size_t lds, hipStream_t st, const MlpArgs& a) {
+int launch_kb(K k1, K k2, K k3, K k4, int kb1, dim3 grid, size_t lds, hipStream_t st, const MlpArgs& a, int threads = 256) {
   K k = kb1 == 1 ? k1 : kb1 == 2 ? k2 : kb1 == 3 ? k3 : k4;
   if (lds > 48 * 1024) {
     // raise the dynamic-LDS limit once per kernel and size (not per launch: the call is a host-side
@@ -644,7 +942,7 @@ int launch_kb(K k1, K k2, K k3, K k4, int kb1, dim3 grid, size_t lds, hipStream_
       raised[fn] = lds;
     }
   }
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k, grid, dim3(threads), lds, st, a);
   return (int)hipGetLastError();
 }
 
@@ -663,6 +961,13 @@ int fill_args(MlpArgs* a, const nesvor_mlp_t* d, int64_t N) {
   }
   for (int l = a->n_linear; l < kMaxLayers; ++l) { a->W[l] = nullptr; a->b[l] = nullptr; }
   a->total_params = total;
+  const int S = d->samples_per_pixel;
+  a->fast = (N % 16 == 0 && S % 16 == 0 && d->k_a % 16 == 0) ? 1 : 0;
+  a->spg_shift = -1;
+  if (a->fast) {
+    const int spg = S / 16;
+    if ((spg & (spg - 1)) == 0) a->spg_shift = __builtin_ctz(spg);
+  }
   return 0;
 }
 
@@ -699,6 +1004,15 @@ extern "C" int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, con
   const int kb1 = (net->k_a + net->k_b + 15) / 16;
   if (net->n_hidden <= 2 && dpre_scratch[0] == nullptr) {
     // fused dX + dW + db (the caller signals it by passing no dpre scratch); grid = n_partial workgroups
+    static const bool use_ws = []() { const char* e = getenv("NESVOR_MLP_BWD_WS"); return e == nullptr || atoi(e) != 0; }();
+    if (use_ws && a.fast) {  // wave-specialised: 8 waves per workgroup
+      const size_t lds_ws = ws_bwd_lds_bytes(net->n_hidden, kb1);
+      if (net->n_hidden == 1)
+        return launch_kb(mlp_bwd_ws_kernel<1, 1>, mlp_bwd_ws_kernel<2, 1>, mlp_bwd_ws_kernel<3, 1>, mlp_bwd_ws_kernel<4, 1>,
+                         kb1, dim3((unsigned)n_partial), lds_ws, (hipStream_t)stream, a, 512);
+      return launch_kb(mlp_bwd_ws_kernel<1, 2>, mlp_bwd_ws_kernel<2, 2>, mlp_bwd_ws_kernel<3, 2>, mlp_bwd_ws_kernel<4, 2>,
+                       kb1, dim3((unsigned)n_partial), lds_ws, (hipStream_t)stream, a, 512);
+    }
     const size_t lds = fused_bwd_lds_bytes(net->n_hidden, kb1);
     if (net->n_hidden == 1)
       return launch_kb(mlp_bwd_fused_kernel<1, 1>, mlp_bwd_fused_kernel<2, 1>, mlp_bwd_fused_kernel<3, 1>,

@@ -14,7 +14,7 @@ from torch.autograd import Function
 from . import _lib
 
 N_PARTIAL = 1024  # workgroups (= partial sums) of the dW kernel: 4 per CU so loads overlap MFMAs
-N_PARTIAL_FUSED = 512  # fused backward: persistent workgroups, 2 per CU (LDS-limited)
+N_PARTIAL_FUSED = 256  # fused backward: one persistent 8-wave workgroup per CU (wave-specialised kernel)
 FUSED_BACKWARD = True  # False: separate dX and dW kernels (kept as cross-check and for depth 3)
 
 
