@@ -748,6 +748,24 @@ __device__ __forceinline__ void accumulate_dw_regs(const float* tiles, const f32
       for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma4(av[ob][t], bv[ib][t], acc[ob][ib]);
 }
 
+// Loads whose issue point the compiler cannot move: written as source-level "prefetch into registers" the loads of
+// the next group get sunk to their first use (register pressure) and their latency is paid in full each group.
+// The compiler does not know these registers are pending, so every consumer must sit behind await_loads().
+__device__ __forceinline__ void issue_load_b128(f32x4& dst, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void issue_load_b32(float& dst, const float* p) {
+  asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void await_loads() {
+  __builtin_amdgcn_sched_barrier(0);  // nothing (in particular no MFMA) may be scheduled across the wait
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// an empty volatile asm that "modifies" x: volatile asms keep their order, so a consumer of x cannot be scheduled
+// above the await_loads() that precedes this call
+__device__ __forceinline__ void pin(f32x4& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
+
 template <int KB1, int NH>
 __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -779,20 +797,45 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 
   if (role == 0) {
     // ------------------------------------------------------------------ chain waves
-    auto load_group = [&](int64_t gi, f32x4& go, f32x4 (&hs)[NH][kHB]) {
-      go = load_dy_fast(a, gi, j, q);
+    auto issue_group = [&](int64_t gi, float (&gy)[4], f32x4 (&hs)[NH][kHB]) {
+      const int64_t n = gi * 16 + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) issue_load_b32(gy[r], a.y + (size_t)min(4 * q + r, a.out_dim - 1) * a.N + n);
 #pragma unroll
       for (int l = 0; l < NH; ++l)
 #pragma unroll
-        for (int ib = 0; ib < kHB; ++ib)
-          hs[l][ib] = *reinterpret_cast<const f32x4*>(a.H[l] + (((size_t)gi * kHB + ib) * 64 + lane) * 4);
+        for (int ib = 0; ib < kHB; ++ib) issue_load_b128(hs[l][ib], a.H[l] + (((size_t)gi * kHB + ib) * 64 + lane) * 4);
     };
-    f32x4 go, go_n, hs[NH][kHB], hs_n[NH][kHB];
-    if (g_first < n_groups) load_group(g_first, go, hs);
+    auto settle_group = [&](float (&gy)[4], f32x4 (&hs)[NH][kHB]) {
+      await_loads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pin(gy[r]);
+#pragma unroll
+      for (int l = 0; l < NH; ++l)
+#pragma unroll
+        for (int ib = 0; ib < kHB; ++ib) pin(hs[l][ib]);
+    };
+    float gy_n[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 hs[NH][kHB], hs_n[NH][kHB];
+#pragma unroll
+    for (int l = 0; l < NH; ++l)
+#pragma unroll
+      for (int ib = 0; ib < kHB; ++ib) hs_n[l][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g_first < n_groups) { issue_group(g_first, gy_n, hs_n); settle_group(gy_n, hs_n); }
     for (int it = 0; it <= n_it; ++it) {
       const int64_t gi = g_first + (int64_t)it * gstride;
       if (it < n_it && gi < n_groups) {
-        if (gi + gstride < n_groups) load_group(gi + gstride, go_n, hs_n);
+        f32x4 go;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) go[r] = 4 * q + r < a.out_dim ? gy_n[r] : 0.f;
+#pragma unroll
+        for (int l = 0; l < NH; ++l)
+#pragma unroll
+          for (int ib = 0; ib < kHB; ++ib) hs[l][ib] = hs_n[l][ib];
+        // next group's inputs, one whole group of MFMAs ahead of their settle_group().  No control flow may merge
+        // between an issue and its settle (a register copy at the merge would read the in-flight registers), so the
+        // last iteration simply re-requests its own group
+        issue_group(min(gi + gstride, n_groups - 1), gy_n, hs_n);
         float* buf = my_tiles + (it & 1) * kT * kTileFloats;
         stage_tile(buf, go, j, q);
         f32x4 gov[1] = {go};
@@ -820,14 +863,14 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
             for (int ib = 0; ib < KB1; ++ib) dx[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
             apply_layer_g1<kHB, KB1>(img1, d, dx, lane);
+            // drain the prefetch BEFORE the stores below: loads and stores share vmcnt, and the wait would otherwise
+            // also cover the latency of these stores
+            settle_group(gy_n, hs_n);
             store_dx_fast<KB1>(a, gi, j, q, dx);
+          } else {
+            settle_group(gy_n, hs_n);
           }
         }
-        go = go_n;
-#pragma unroll
-        for (int l = 0; l < NH; ++l)
-#pragma unroll
-          for (int ib = 0; ib < kHB; ++ib) hs[l][ib] = hs_n[l][ib];
       }
       __syncthreads();
     }
@@ -847,34 +890,71 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
       }
     }
     // B operands (layer inputs) of one group: lane (feature j, sample quad q) holds feature j of samples 4q..4q+3
-    auto load_b = [&](int64_t gi, f32x4 (&hb)[NH][kHB], f32x4 (&xb_)[KB1]) {
+    const int ka_blocks = a.k_a >> 4;
+    auto issue_b = [&](int64_t gi, float (&hraw)[NH][kHB][4], f32x4 (&xraw)[KB1], float (&xsraw)[KB1]) {
 #pragma unroll
       for (int l = 0; l < NH; ++l)
 #pragma unroll
         for (int ib = 0; ib < kHB; ++ib) {
           const float* p = a.H[l] + (((size_t)gi * kHB + ib) * 64 + (j >> 2) * 16 + 4 * q) * 4 + (j & 3);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) hb[l][ib][t] = p[4 * t];
+          for (int t = 0; t < 4; ++t) issue_load_b32(hraw[l][ib][t], p + 4 * t);
         }
-      const int ka_blocks = a.k_a >> 4;
+      // both candidate sources of every input block are requested (no branch between issue and settle); the block
+      // type picks one after the loads have landed
+      const int64_t pixel = a.spg_shift >= 0 ? (gi >> a.spg_shift) : gi / (a.S >> 4);
 #pragma unroll
       for (int kb = 0; kb < KB1; ++kb) {
-        if (kb < ka_blocks) {
-          const int64_t pixel = a.spg_shift >= 0 ? (gi >> a.spg_shift) : gi / (a.S >> 4);
-          const float v = a.xa[(size_t)pixel * a.k_a + 16 * kb + j];
-          xb_[kb] = f32x4{v, v, v, v};
-        } else {
-          const int row = 16 * (kb - ka_blocks) + j;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(a.xb + (size_t)(a.b_row0 + min(row, a.k_b - 1)) * a.N + gi * 16 + 4 * q);
-          xb_[kb] = row < a.k_b ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        const bool is_a = kb < ka_blocks;
+        const int row = is_a ? 0 : min(16 * (kb - ka_blocks) + j, a.k_b - 1);
+        const float* pa = is_a ? a.xa + (size_t)pixel * a.k_a + 16 * kb + j : a.xb + (size_t)a.b_row0 * a.N;
+        issue_load_b32(xsraw[kb], pa);
+        issue_load_b128(xraw[kb], a.xb + (size_t)(a.b_row0 + row) * a.N + gi * 16 + 4 * q);
       }
     };
-    f32x4 hb[NH][kHB], xb_[KB1];
+    auto settle_b = [&](float (&hraw)[NH][kHB][4], f32x4 (&xraw)[KB1], float (&xsraw)[KB1]) {
+      await_loads();
+#pragma unroll
+      for (int l = 0; l < NH; ++l)
+#pragma unroll
+        for (int ib = 0; ib < kHB; ++ib)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) pin(hraw[l][ib][t]);
+#pragma unroll
+      for (int kb = 0; kb < KB1; ++kb) { pin(xraw[kb]); pin(xsraw[kb]); }
+    };
+    float hraw[NH][kHB][4];
+    f32x4 xraw[KB1];
+    float xsraw[KB1];
+#pragma unroll
+    for (int l = 0; l < NH; ++l)
+#pragma unroll
+      for (int ib = 0; ib < kHB; ++ib)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) hraw[l][ib][t] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KB1; ++kb) { xraw[kb] = f32x4{0.f, 0.f, 0.f, 0.f}; xsraw[kb] = 0.f; }
+    if (g_first < n_groups) { issue_b(g_first, hraw, xraw, xsraw); settle_b(hraw, xraw, xsraw); }
     for (int it = 0; it <= n_it; ++it) {
       const int64_t gi = g_first + (int64_t)(it - 1) * gstride;
       if (it > 0 && gi < n_groups) {
-        load_b(gi, hb, xb_);
+        f32x4 hb[NH][kHB], xb_[KB1];
+#pragma unroll
+        for (int l = 0; l < NH; ++l)
+#pragma unroll
+          for (int ib = 0; ib < kHB; ++ib)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) hb[l][ib][t] = hraw[l][ib][t];
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb) {
+          if (kb < ka_blocks) {
+            const float v = xsraw[kb];
+            xb_[kb] = f32x4{v, v, v, v};
+          } else {
+            xb_[kb] = (16 * (kb - ka_blocks) + j) < a.k_b ? xraw[kb] : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+        issue_b(min(gi + gstride, n_groups - 1), hraw, xraw, xsraw);  // one group ahead (see the chain waves)
         const float* buf = my_tiles + ((it - 1) & 1) * kT * kTileFloats;
         accumulate_dw_regs<1, kHB>(buf, hb[NH - 1], acc_o, db_o, j, q);
 #pragma unroll
@@ -883,6 +963,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           if (l > 0) accumulate_dw_regs<kHB, kHB>(dt, hb[l - 1], acc_h[l - 1], db_h[l - 1], j, q);
           else accumulate_dw_regs<kHB, KB1>(dt, xb_, acc_1, db_1, j, q);
         }
+        settle_b(hraw, xraw, xsraw);
       }
       __syncthreads();
     }
@@ -1005,7 +1086,7 @@ extern "C" int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, con
   if (net->n_hidden <= 2 && dpre_scratch[0] == nullptr) {
     // fused dX + dW + db (the caller signals it by passing no dpre scratch); grid = n_partial workgroups
     static const bool use_ws = []() { const char* e = getenv("NESVOR_MLP_BWD_WS"); return e == nullptr || atoi(e) != 0; }();
-    if (use_ws && a.fast) {  // wave-specialised: 8 waves per workgroup
+    if (use_ws && a.fast && (kb1 <= 2 || net->n_hidden == 1)) {  // wave-specialised: 8 waves per workgroup (wider inputs would spill)
       const size_t lds_ws = ws_bwd_lds_bytes(net->n_hidden, kb1);
       if (net->n_hidden == 1)
         return launch_kb(mlp_bwd_ws_kernel<1, 1>, mlp_bwd_ws_kernel<2, 1>, mlp_bwd_ws_kernel<3, 1>, mlp_bwd_ws_kernel<4, 1>,
