@@ -79,6 +79,16 @@ int nesvor_slice_acq_adjoint_forward(const float* transforms, const float* psf, 
                                      const uint8_t* slices_mask, const uint8_t* vol_mask, float* vol, float* vol_weight,
                                      float* scratch, int D, int H, int W, int d_p, int h_p, int w_p, int n, int h, int w,
                                      float res_slice, int equalize, void* stream);
+/* Backward of A^T: replaces `nesvor.slice_acq_cuda.adjoint_backward` (slice_acq_cuda.cpp:156-161; kernels
+ * slice_acq_cuda_kernel.cu:672-950, host :1079-1131), linear mode.  grad_vol (D,H,W) is divided IN PLACE by
+ * max(vol_weight, 1e-3) where vol_weight > 0 when equalize != 0, exactly like the reference; vol is the
+ * equalised adjoint output (read only when equalize).  grad_slices (n,h,w) must be zero-filled by the caller
+ * (pixels with no PSF weight are left untouched), grad_transforms (n,3,4) is overwritten; either may be NULL. */
+int nesvor_slice_acq_adjoint_backward(const float* transforms, float* grad_vol, const float* vol_weight,
+                                      const uint8_t* vol_mask, const float* psf, const float* slices,
+                                      const uint8_t* slices_mask, const float* vol, float* grad_slices,
+                                      float* grad_transforms, int D, int H, int W, int d_p, int h_p, int w_p, int n, int h,
+                                      int w, float res_slice, int equalize, void* stream);
 int nesvor_slice_acq_backward(const float* transforms, const float* vol, const uint8_t* vol_mask, const float* psf,
                               const float* grad_slices, const uint8_t* slices_mask, float* grad_vol,
                               float* grad_transforms, float* scratch, int D, int H, int W, int d_p, int h_p, int w_p,

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -72,6 +72,7 @@ _SIGNATURES = {
     ),
     "nesvor_slice_acq_adjoint_forward": ([_P] * 8 + [c_int] * 9 + [c_float, c_int, _P], c_int),
     "nesvor_slice_acq_backward": ([_P] * 9 + [c_int] * 9 + [c_float, _P], c_int),
+    "nesvor_slice_acq_adjoint_backward": ([_P] * 10 + [c_int] * 9 + [c_float, c_int, _P], c_int),
     "nesvor_hashgrid_forward": ([POINTER(GridT), _P, _P, _P, c_int64, c_int, _P], c_int),
     "nesvor_hashgrid_backward_workspace_bytes": ([POINTER(GridT), c_int64], c_int64),
     "nesvor_hashgrid_backward": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P], c_int),

@@ -295,7 +295,117 @@ __global__ __launch_bounds__(256) void slice_acq_bwd_transforms(const float* __r
   if (threadIdx.x < 12) grad_transforms[(size_t)k * 12 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// in-place "equalise a gradient" step of adjoint_backward (slice_acq_cuda_kernel.cu:672-693 with is_grad = true)
+__global__ void slice_acq_equalize_grad(float* __restrict__ grad_vol, const float* __restrict__ vol_weight, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float wgt = vol_weight[i];
+  if (wgt > 0.f) grad_vol[i] /= (wgt < 1e-3f ? 1e-3f : wgt);
+}
+
+// Backward of A^T (slice_acq_cuda_kernel.cu:695-950, linear mode): a gather per slice pixel,
+//   grad_slices[p] = sum_taps psf * trilinear(grad_vol) / sum_taps psf            (taps inside the volume)
+//   grad_transforms[k] += d/dT of the same expression with the corner values weighted by
+//                         (slices[p] - vol[corner]) (equalised adjoint) or slices[p].
+// One workgroup per slice; the 12 pose sums are block-reduced (the reference adds them with atomics).
+__global__ __launch_bounds__(256) void slice_acq_adjoint_bwd(const float* __restrict__ transforms, const float* __restrict__ grad_vol,
+                                                             const float* __restrict__ psf, const float* __restrict__ slices,
+                                                             const uint8_t* __restrict__ slices_mask, const float* __restrict__ vol,
+                                                             const uint8_t* __restrict__ vol_mask, float* __restrict__ grad_slices,
+                                                             float* __restrict__ grad_transforms, int D, int H, int W, int d_p,
+                                                             int h_p, int w_p, int h, int w, float res_slice) {
+  __shared__ float red[4][12];
+  const int k = blockIdx.x;
+  const float* t = transforms + (size_t)k * 12;
+  const int Sy = W, Sz = H * W;
+  float g[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) g[i] = 0.f;
+  for (int pix = threadIdx.x; pix < h * w; pix += blockDim.x) {
+    const size_t idx = (size_t)k * h * w + pix;
+    if (slices_mask != nullptr && !slices_mask[idx]) continue;
+    const int ix = pix % w, iy = pix / w;
+    const PixelGeom pg = pixel_geom(t, ix, iy, h, w, res_slice, D, H, W);
+    const float sv = slices[idx];
+    float val = 0.f, weight = 0.f;
+    float gp[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) gp[i] = 0.f;
+    int ip = 0;
+    for (int iz = -d_p / 2; iz < (d_p + 1) / 2; ++iz)
+      for (int iyp = -h_p / 2; iyp < (h_p + 1) / 2; ++iyp)
+        for (int ixp = -w_p / 2; ixp < (w_p + 1) / 2; ++ixp, ++ip) {
+          const float pv = psf[ip];
+          if (pv == 0.f) continue;
+          const float x = pg.xc + t[0] * ixp + t[1] * iyp + t[2] * iz;
+          const float y = pg.yc + t[4] * ixp + t[5] * iyp + t[6] * iz;
+          const float z = pg.zc + t[8] * ixp + t[9] * iyp + t[10] * iz;
+          if (x < 0 || y < 0 || z < 0 || x >= W - 1 || y >= H - 1 || z >= D - 1) continue;
+          const int xf = (int)floorf(x), yf = (int)floorf(y), zf = (int)floorf(z);
+          const float wx = x - xf, wy = y - yf, wz = z - zf;
+          const int i0 = zf * Sz + yf * Sy + xf;
+          float v_ = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const int cx = c & 1, cy = (c >> 1) & 1, cz = c >> 2;
+            const int ic = i0 + cx + cy * Sy + cz * Sz;
+            if (vol_mask != nullptr && !vol_mask[ic]) continue;
+            const float gv = grad_vol[ic];
+            const float ax = cx ? wx : 1.f - wx, ay = cy ? wy : 1.f - wy, az = cz ? wz : 1.f - wz;
+            v_ += ax * ay * az * gv;
+            const float s = (vol == nullptr ? sv : sv - vol[ic]) * gv;
+            dx += (cx ? s : -s) * ay * az;
+            dy += (cy ? s : -s) * ax * az;
+            dz += (cz ? s : -s) * ax * ay;
+          }
+          val += pv * v_;
+          weight += pv;
+          dx *= pv; dy *= pv; dz *= pv;
+          const float ox = pg.qx + ixp, oy = pg.qy + iyp, oz = pg.qz + iz;
+          gp[0] += dx * ox; gp[1] += dx * oy; gp[2] += dx * oz;
+          gp[4] += dy * ox; gp[5] += dy * oy; gp[6] += dy * oz;
+          gp[8] += dz * ox; gp[9] += dz * oy; gp[10] += dz * oz;
+          gp[3] += dx * t[0] + dy * t[4] + dz * t[8];
+          gp[7] += dx * t[1] + dy * t[5] + dz * t[9];
+          gp[11] += dx * t[2] + dy * t[6] + dz * t[10];
+        }
+    if (weight > 0.f) {
+      if (grad_slices != nullptr) grad_slices[idx] = val / weight;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) g[i] += gp[i] / weight;
+    }
+  }
+  if (grad_transforms == nullptr) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const float s = wave_sum_dpp(g[i]);
+    if (lane == 0) red[wave][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) grad_transforms[(size_t)k * 12 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 }  // namespace
+
+extern "C" int nesvor_slice_acq_adjoint_backward(const float* transforms, float* grad_vol, const float* vol_weight,
+                                                 const uint8_t* vol_mask, const float* psf, const float* slices,
+                                                 const uint8_t* slices_mask, const float* vol, float* grad_slices,
+                                                 float* grad_transforms, int D, int H, int W, int d_p, int h_p, int w_p,
+                                                 int n, int h, int w, float res_slice, int equalize, void* stream) {
+  if ((int64_t)n * h * w <= 0) return 0;
+  if ((int64_t)d_p * h_p * w_p > kMaxTaps) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  if (equalize) {
+    if (vol_weight == nullptr || vol == nullptr) return (int)hipErrorInvalidValue;
+    const int64_t nv = (int64_t)D * H * W;
+    hipLaunchKernelGGL(slice_acq_equalize_grad, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, grad_vol, vol_weight, nv);
+  }
+  hipLaunchKernelGGL(slice_acq_adjoint_bwd, dim3((unsigned)n), dim3(256), 0, st, transforms, (const float*)grad_vol, psf, slices,
+                     slices_mask, equalize ? vol : (const float*)nullptr, vol_mask, grad_slices, grad_transforms, D, H, W, d_p, h_p,
+                     w_p, h, w, res_slice);
+  return (int)hipGetLastError();
+}
 
 extern "C" int nesvor_slice_acq_forward(const float* transforms, const float* vol, const uint8_t* vol_mask,
                                         const uint8_t* slices_mask, const float* psf, float* slices,

@@ -2,9 +2,9 @@
 (nesvor/slice_acquisition/slice_acq_cuda.cpp:156-161).
 
 ``forward``, ``backward`` and ``adjoint_forward`` run gfx950 HIP kernels (the latter two in the
-default linear-interpolation mode; ``interp_psf=True`` is never used by the reference's own callers
-and raises).  ``adjoint_backward`` (only reached from SVoRT training) is still a §8(f) "next" row:
-it raises, nothing ever falls back.
+default linear-interpolation mode) and so does ``adjoint_backward`` (only reached from SVoRT training in
+the reference).  ``interp_psf=True`` is never used by the reference's own callers: it raises, nothing
+ever falls back.
 """
 import torch
 
@@ -87,5 +87,25 @@ def adjoint_forward(transforms, psf, slices, slices_mask, vol_mask, vol_shape, r
     return [vol, vol_weight if equalize else torch.empty(0, device=slices.device)]
 
 
-def adjoint_backward(*args, **kwargs):
-    raise NotImplementedError("slice_acq adjoint_backward: SURVEY.md §8(f), not built yet (no fallback)")
+def adjoint_backward(transforms, grad_vol, vol_weight, vol_mask, psf, slices, slices_mask, vol, res_slice, interp_psf,
+                     equalize, need_slices_grad, need_transforms_grad):
+    """-> [grad_slices | None, grad_transforms | None] (slice_acq_cuda_kernel.cu:695-950, host :1079-1131).
+    Like the reference, ``grad_vol`` is equalised IN PLACE when ``equalize`` is set."""
+    if interp_psf:
+        raise NotImplementedError("slice_acq adjoint_backward: interp_psf=True is not built (no fallback)")
+    _lib.require_device(transforms, grad_vol, psf, slices, dtype=torch.float32, name="slice_acq adjoint_backward input")
+    if equalize:
+        _lib.require_device(vol_weight, vol, dtype=torch.float32, name="slice_acq adjoint_backward vol/vol_weight")
+    vm, sm = _mask(vol_mask), _mask(slices_mask)
+    n, h, w = slices.shape[0], slices.shape[-2], slices.shape[-1]
+    D, H, W = (int(s) for s in grad_vol.shape[-3:])
+    d_p, h_p, w_p = (int(s) for s in psf.shape)
+    grad_slices = torch.zeros_like(slices) if need_slices_grad else None
+    grad_tf = torch.empty_like(transforms) if need_transforms_grad else None
+    with torch.cuda.device(slices.device):
+        err = _lib.load().nesvor_slice_acq_adjoint_backward(
+            _lib.ptr(transforms), _lib.ptr(grad_vol), _lib.ptr(vol_weight if equalize else None), _lib.ptr(vm), _lib.ptr(psf),
+            _lib.ptr(slices), _lib.ptr(sm), _lib.ptr(vol if equalize else None), _lib.ptr(grad_slices), _lib.ptr(grad_tf),
+            D, H, W, d_p, h_p, w_p, n, h, w, float(res_slice), int(bool(equalize)), _lib.stream_ptr())
+    _lib.check(err, "slice_acq adjoint_backward")
+    return [grad_slices, grad_tf]

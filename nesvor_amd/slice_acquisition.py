@@ -1,6 +1,6 @@
 """Autograd wrappers over the slice-acquisition native module.  Mirrors
 ``nesvor.slice_acquisition`` (slice_acquisition/slice_acq.py:22-211).
-A (forward + backward) and A^T (forward) are built; the backward of A^T is §8(f) "next".
+A and A^T, forward and backward, in the default linear-interpolation mode.
 """
 import torch
 from torch.autograd import Function
@@ -49,17 +49,29 @@ class SliceAcqAdjointFunction(Function):
             vol_mask = torch.empty(0, device=slices.device)
         if slices_mask is None:
             slices_mask = torch.empty(0, device=slices.device)
+        transforms, psf, slices = transforms.contiguous(), psf.contiguous(), slices.contiguous()
         vol, vol_weight = _backend.adjoint_forward(
-            transforms.contiguous(), psf.contiguous(), slices.contiguous(), slices_mask, vol_mask, vol_shape, res_slice,
-            interp_psf, equalize)
-        ctx.set_materialize_grads(False)
+            transforms, psf, slices, slices_mask, vol_mask, vol_shape, res_slice, interp_psf, equalize)
+        if equalize:
+            ctx.save_for_backward(transforms, psf, slices, slices_mask, vol_mask, vol, vol_weight)
+        else:
+            ctx.save_for_backward(transforms, psf, slices, slices_mask, vol_mask)
+        ctx.res_slice, ctx.interp_psf, ctx.equalize = res_slice, interp_psf, equalize
         return vol
 
     @staticmethod
     def backward(ctx, grad_vol):
-        if grad_vol is None:
-            return (None,) * 9
-        _backend.adjoint_backward()  # raises: SURVEY.md §8(f)
+        if ctx.equalize:
+            transforms, psf, slices, slices_mask, vol_mask, vol, vol_weight = ctx.saved_tensors
+        else:
+            transforms, psf, slices, slices_mask, vol_mask = ctx.saved_tensors
+            vol = vol_weight = None
+        # the native op equalises grad_vol in place (as the reference does): work on a private contiguous copy
+        grad_vol = grad_vol.contiguous().clone() if ctx.equalize else grad_vol.contiguous()
+        grad_slices, grad_transforms = _backend.adjoint_backward(
+            transforms, grad_vol, vol_weight, vol_mask, psf, slices, slices_mask, vol, ctx.res_slice, ctx.interp_psf,
+            ctx.equalize, ctx.needs_input_grad[2], ctx.needs_input_grad[0])
+        return grad_transforms, None, grad_slices, None, None, None, None, None, None
 
 
 def slice_acquisition_adjoint(transforms, psf, slices, slices_mask, vol_mask, vol_shape, res_slice, interp_psf, equalize):

@@ -288,3 +288,66 @@ def slice_acquisition_backward(transforms, vol, vol_mask, psf, grad_slices, slic
     grad_vol = gvol.view(vol.shape) if need_vol_grad else None
     grad_tf = torch.cat([gR, gT[:, :, None]], -1) if need_transforms_grad else None
     return grad_vol, grad_tf
+
+
+def slice_acquisition_adjoint_backward(transforms, grad_vol, vol_weight, vol_mask, psf, slices, slices_mask, vol, res_slice,
+                                       interp_psf=False, equalize=False):
+    """Backward of A^T as the reference computes it (.cu:695-950 + equalize_cuda_kernel with is_grad, .cu:672-693):
+    -> (grad_slices (n,1,h,w), grad_transforms (n,3,4)).  grad_vol is NOT modified here (the native op does it in place).
+      g = grad_vol / max(vol_weight, 1e-3) where vol_weight > 0            [equalize only]
+      grad_slices[p] = sum_taps psf * trilinear(g) / sum_taps psf          (taps inside the volume, masked corners dropped)
+      grad_T: the same expression differentiated w.r.t. the tap position, corner values weighted by
+              (slices[p] - vol[corner]) when equalising, by slices[p] otherwise."""
+    assert not interp_psf, "oracle restates the linear mode only"
+    dt = slices.dtype
+    D, H, W = grad_vol.shape[-3:]
+    n, h, w = slices.shape[0], slices.shape[-2], slices.shape[-1]
+    g = grad_vol.reshape(-1).clone()
+    if equalize:
+        wv = vol_weight.reshape(-1)
+        pos = wv > 0
+        g[pos] = g[pos] / wv[pos].clamp(min=1e-3)
+    volf = vol.reshape(-1) if equalize else None
+    vm = vol_mask.reshape(-1) if vol_mask is not None else None
+    R, q, centre = _geometry(transforms, (D, H, W), (h, w), res_slice, dt)
+    sv = slices.reshape(n, h, w)
+    val = torch.zeros((n, h, w), dtype=dt)
+    weight = torch.zeros((n, h, w), dtype=dt)
+    gT = torch.zeros((n, h, w, 12), dtype=dt)
+    Sy, Sz = W, H * W
+    for ix, iy, iz, pv in _taps(psf):
+        x, y, z = _tap_pos(R, centre, ix, iy, iz)
+        inb = (x >= 0) & (y >= 0) & (z >= 0) & (x < W - 1) & (y < H - 1) & (z < D - 1)
+        xf, yf, zf = x.floor().clamp(0, W - 2), y.floor().clamp(0, H - 2), z.floor().clamp(0, D - 2)
+        wx, wy, wz = x - xf, y - yf, z - zf
+        i0 = (zf * Sz + yf * Sy + xf).long()
+        v_ = torch.zeros_like(x)
+        dx, dy, dz = torch.zeros_like(x), torch.zeros_like(x), torch.zeros_like(x)
+        for c in range(8):
+            cx, cy, cz = c & 1, (c >> 1) & 1, c >> 2
+            ic = i0 + cx + cy * Sy + cz * Sz
+            ok = inb if vm is None else inb & vm[ic]
+            gv = torch.where(ok, g[ic], torch.zeros_like(x))
+            ax, ay, az = (wx if cx else 1 - wx), (wy if cy else 1 - wy), (wz if cz else 1 - wz)
+            v_ = v_ + ax * ay * az * gv
+            s = (sv - volf[ic] if equalize else sv) * gv
+            dx = dx + (s if cx else -s) * ay * az
+            dy = dy + (s if cy else -s) * ax * az
+            dz = dz + (s if cz else -s) * ax * ay
+        inbf = inb.to(dt)
+        val = val + pv * v_ * inbf
+        weight = weight + pv * inbf
+        dx, dy, dz = dx * pv * inbf, dy * pv * inbf, dz * pv * inbf
+        ox, oy, oz = q[0] + ix, q[1] + iy, q[2] + iz
+        r = lambda a, b: R[:, a, b].view(n, 1, 1)
+        terms = [dx * ox, dx * oy, dx * oz, dx * r(0, 0) + dy * r(1, 0) + dz * r(2, 0),
+                 dy * ox, dy * oy, dy * oz, dx * r(0, 1) + dy * r(1, 1) + dz * r(2, 1),
+                 dz * ox, dz * oy, dz * oz, dx * r(0, 2) + dy * r(1, 2) + dz * r(2, 2)]
+        gT = gT + torch.stack(terms, -1)
+    live = weight > 0
+    if slices_mask is not None:
+        live = live & slices_mask.reshape(n, h, w)
+    safe = torch.where(live, weight, torch.ones_like(weight))
+    grad_slices = torch.where(live, val / safe, torch.zeros_like(val)).view(n, 1, h, w)
+    grad_transforms = (torch.where(live[..., None], gT / safe[..., None], torch.zeros_like(gT))).sum((1, 2)).view(n, 3, 4)
+    return grad_slices, grad_transforms

@@ -42,8 +42,8 @@ def test_no_cpu_fallback():
     spec = HashGridSpec(2, 2, 8, 4, 1.5)
     with pytest.raises(RuntimeError, match="device"):
         hashgrid_forward(spec, torch.rand(4, 3), torch.zeros(spec.n_params))
-    with pytest.raises(NotImplementedError):
-        slice_acq_cuda.adjoint_backward()
+    with pytest.raises(NotImplementedError):  # the PSF-interpolation mode is not built: it raises, it never falls back
+        slice_acq_cuda.adjoint_backward(None, None, None, None, None, None, None, None, 1.0, True, False, True, True)
     with pytest.raises(RuntimeError, match="device"):
         slice_acq_cuda.adjoint_forward(torch.zeros(1, 3, 4), torch.ones(1, 1, 1), torch.zeros(1, 1, 2, 2), torch.empty(0),
                                        torch.empty(0), (4, 4, 4), 1.0, False, False)

@@ -242,6 +242,42 @@ def test_slice_acq_backward_vs_oracle(device, masks):
     assert float((t.grad.cpu() - gt2).abs().max()) <= 2e-4 * float(gt2.abs().max())
 
 
+@pytest.mark.parametrize("masks", [False, True])
+@pytest.mark.parametrize("equalize", [False, True])
+def test_slice_acq_adjoint_backward_vs_oracle(device, masks, equalize):
+    """Backward of A^T (gather per pixel, per-slice reduction instead of the reference's atomics) vs the oracle,
+    including the in-place equalisation of grad_vol; then through the autograd wrapper."""
+    from nesvor_amd import slice_acq_cuda as K
+    from nesvor_amd.slice_acquisition import slice_acquisition_adjoint
+    from oracle import slice_acq as O
+
+    vol, psf, tf, vm, sm = _sa_setup(masks, seed=7)
+    dims = (18, 20, 22)
+    y = torch.rand(6, 1, 14, 12)
+    G = torch.randn(1, 1, *dims)
+    v_ref, w_ref = O.slice_acquisition_adjoint_forward(tf, psf, y, sm, vm, dims, 1.5, False, equalize)
+    gs_ref, gt_ref = O.slice_acquisition_adjoint_backward(tf, G, w_ref if equalize else None, vm, psf, y, sm,
+                                                          v_ref if equalize else None, 1.5, False, equalize)
+    e = torch.empty(0, device=device)
+    d = lambda t: e if t is None else t.to(device)
+    G_dev = G.to(device).clone()
+    gs, gt = K.adjoint_backward(tf.to(device), G_dev, d(w_ref) if equalize else None, d(vm), psf.to(device), y.to(device), d(sm),
+                                d(v_ref) if equalize else None, 1.5, False, equalize, True, True)
+    torch.testing.assert_close(gs.cpu(), gs_ref, rtol=2e-4, atol=2e-5 * float(gs_ref.abs().max()))
+    assert float((gt.cpu() - gt_ref).abs().max()) <= 3e-4 * float(gt_ref.abs().max())
+    if equalize:  # grad_vol was equalised in place, like the reference
+        pos = w_ref > 0
+        torch.testing.assert_close(G_dev.cpu()[pos], (G / w_ref.clamp(min=1e-3))[pos], rtol=1e-5, atol=1e-6)
+    # autograd wrapper: d/d(slices), d/d(transforms) of <A^T y, G>
+    t = tf.to(device).requires_grad_(True)
+    yy = y.to(device).requires_grad_(True)
+    out = slice_acquisition_adjoint(t, psf.to(device), yy, None if sm is None else sm.to(device),
+                                    None if vm is None else vm.to(device), dims, 1.5, False, equalize)
+    (out * G.to(device)).sum().backward()
+    torch.testing.assert_close(yy.grad.cpu(), gs_ref, rtol=2e-4, atol=2e-5 * float(gs_ref.abs().max()))
+    assert float((t.grad.cpu() - gt_ref).abs().max()) <= 3e-4 * float(gt_ref.abs().max())
+
+
 def test_cg_recon_reference_test(device):
     """tests/slice_acquisition/test_slice_acq.py:13-81: 16 stacks x 22 slices x 40x40 simulated from the 32^3
     phantom; SRR(n_iter=20, use_CG=True, tol=1e-8) started from the true volume must return it (atol 3e-5)."""

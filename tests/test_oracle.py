@@ -178,6 +178,30 @@ def test_slice_acq_adjoint_equalize():
     assert float(eq[~pos].abs().max()) == 0.0 if (~pos).any() else True
 
 
+@pytest.mark.parametrize("equalize", [False, True])
+def test_slice_acq_adjoint_backward_equals_autograd_fp64(equalize):
+    """Backward of A^T (slice_acq_cuda_kernel.cu:695-950, no reference test): against autograd through the adjoint
+    restatement in fp64.  Pixels are restricted to those A^T keeps (weight >= 0.5; the reference's backward uses
+    weight > 0) and, when equalising, voxels in the clamped range 0 < weight < 1e-3 carry no upstream gradient
+    (there the reference's backward deliberately differs from the exact derivative)."""
+    tf, _, psf, _, _ = _sa_case(torch.float64, False)
+    dims = (12, 13, 14)
+    y = torch.rand(4, 1, 10, 9, dtype=torch.float64)
+    G = torch.randn(1, 1, *dims, dtype=torch.float64)
+    R, q, c = osa._geometry(tf, dims, (10, 9), 1.5, torch.float64)
+    sm = (osa._psf_weight(R, c, psf, dims) >= 0.5).view(4, 1, 10, 9)
+    if equalize:
+        _, wv0 = osa.slice_acquisition_adjoint_forward(tf, psf, y, sm, None, dims, 1.5, False, True)
+        G = torch.where((wv0 > 0) & (wv0 < 1e-3), torch.zeros_like(G), G)
+    tf_a, y_a = tf.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    v, wv = osa.slice_acquisition_adjoint_forward(tf_a, psf, y_a, sm, None, dims, 1.5, False, equalize)
+    (v * G).sum().backward()
+    gs, gt = osa.slice_acquisition_adjoint_backward(
+        tf, G, wv.detach() if equalize else None, None, psf, y, sm, v.detach() if equalize else None, 1.5, False, equalize)
+    torch.testing.assert_close(gs, y_a.grad, rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(gt, tf_a.grad, rtol=1e-9, atol=1e-10)
+
+
 # ---- model / training loop vs fixtures captured from the reference's Python
 def _params_from_golden(golden, tag):
     P = {}
