@@ -232,7 +232,8 @@ __global__ __launch_bounds__(256) void hashgrid_bwd(const nesvor_grid_t g, const
 
 // ------------------------------------------- backward, owner-computes version
 constexpr int kMaxChunks = 256;               // table chunks (queues) per level
-constexpr int kOwnerLdsFloats = 16384;        // 64 KiB accumulator per owner workgroup
+constexpr int kOwnerLdsFloats = 8192;         // 32 KiB accumulator per owner workgroup: 4096-entry chunks (measured: 16 / 64 / 128 KiB are slower -
+                                              // fewer, hotter queue counters on one side, more reservations per workgroup on the other)
 
 struct BwdPlan {
   uint32_t chunk_shift;                        // chunk = 2^chunk_shift entries = kOwnerLdsFloats / F
