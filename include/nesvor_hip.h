@@ -212,6 +212,19 @@ int nesvor_imaging_loss(const nesvor_loss_t* args, void* stream);
  *   dse[k,:] += sum_s dxa[b,s,:]   with k = slice_idx[b].
  * dxa (B*S, ks) per-sample gradient w.r.t. the slice embedding fed to an MLP.  Any of the four
  * source pointers may be NULL (skipped).  Outputs are ACCUMULATED into (caller zero-fills). */
+/* Small-tensor bookkeeping of one training iteration (nesvor_amd/direct.py), one launch each:
+ *   prologue: c (n) = n softmax(logit_coef) (models.py:296; logit_coef may be NULL), mat (n,3,4) =
+ *             axisangle2mat(axisangle) (axisangle may be NULL), zero_buf[0..n_zero) = 0;
+ *   epilogue: dlogit (n) = c (dc - <dc,c>/n) (dc may be NULL); daxisangle (n,6) = axisangle2mat_backward(dmat,
+ *             axisangle) + w_trans * dtrans and losses[3] = sum(trans_terms) (dmat may be NULL);
+ *             losses[0,1,2,4] = {MSE, logVar, MSE+logVar, imageReg} from loss_pix (B,3) (nesvor_imaging_loss):
+ *             imageReg = img_scale * sum(loss_pix[:,2]) + img_offset. */
+int nesvor_step_prologue(const float* logit_coef, float* c, const float* axisangle, float* mat, float* zero_buf,
+                         int n_zero, int n, void* stream);
+int nesvor_step_epilogue(const float* dc, const float* c, float* dlogit, const float* dmat, const float* axisangle,
+                         const float* dtrans, float w_trans, float* daxisangle, const float* loss_pix,
+                         const float* trans_terms, float* losses, int n, int B, float img_scale, float img_offset,
+                         void* stream);
 int nesvor_slice_grads(const int64_t* slice_idx, const float* dc_pix, const float* dlvs_pix, const float* dxa,
                        const float* dpix, float* dc, float* dlvs, float* dse, float* dmat, int B, int S, int ks,
                        void* stream);

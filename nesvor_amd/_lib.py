@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -86,6 +86,8 @@ _SIGNATURES = {
     ),
     "nesvor_imaging_loss": ([POINTER(LossT), _P], c_int),
     "nesvor_slice_grads": ([_P] * 9 + [c_int, c_int, c_int, _P], c_int),
+    "nesvor_step_prologue": ([_P] * 5 + [c_int, c_int, _P], c_int),
+    "nesvor_step_epilogue": ([_P] * 6 + [c_float, _P, _P, _P, _P, c_int, c_int, c_float, c_float, _P], c_int),
     "nesvor_adamw_step": (
         [_P, _P, _P, _P, c_int64] + [c_float] * 8 + [c_int, _P],
         c_int,

@@ -102,4 +102,4 @@ extern "C" int nesvor_adamw_step_dev(float* param, float* grad, float* exp_avg, 
   return (int)hipGetLastError();
 }
 
-extern "C" int nesvor_hip_abi_version(void) { return 10; }
+extern "C" int nesvor_hip_abi_version(void) { return 11; }

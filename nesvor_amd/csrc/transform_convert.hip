@@ -256,6 +256,83 @@ __global__ void trans_loss_kernel(const float* __restrict__ ax, const float* __r
   for (int d = 0; d < 6; ++d) grad_ax[(size_t)i * 6 + d] = g[d];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small-tensor bookkeeping of one training iteration, two launches instead of ~15 (per-slice tensors of a few
+// hundred elements: every separate launch costs more than the work).
+//   prologue: c = n softmax(logit_coef) (models.py:296), mat = axisangle2mat(axisangle), zero-fill of the
+//             per-slice accumulators;
+//   epilogue: d logit_coef from d c (softmax backward), d axisangle = axisangle2mat_backward(dmat) + w_T dtrans,
+//             and the loss values {MSE, logVar, MSE+logVar, transReg, imageReg} from the per-pixel partial sums.
+// One workgroup each (n and B are small); block-wide sums through LDS.
+__device__ __forceinline__ float block_sum_1024(float v, float* red /* 16 floats */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+  return s;
+}
+
+__global__ __launch_bounds__(1024) void step_prologue_kernel(const float* __restrict__ logit_coef, float* __restrict__ c,
+                                                            const float* __restrict__ axisangle, float* __restrict__ mat,
+                                                            float* __restrict__ zero_buf, int n_zero, int n) {
+  __shared__ float red[16];
+  if (logit_coef != nullptr) {
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, logit_coef[i]);
+    mx = wave_max(mx);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) mx = fmaxf(mx, red[w]);
+    float se = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) se += expf(logit_coef[i] - mx);
+    se = block_sum_1024(se, red);
+    const float scale = (float)n / se;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) c[i] = expf(logit_coef[i] - mx) * scale;
+  }
+  if (axisangle != nullptr)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) ax2mat_fwd_one(axisangle + (size_t)i * 6, mat + (size_t)i * 12);
+  for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_buf[i] = 0.f;
+}
+
+__global__ __launch_bounds__(1024) void step_epilogue_kernel(const float* __restrict__ dc, const float* __restrict__ c,
+                                                            float* __restrict__ dlogit, const float* __restrict__ dmat,
+                                                            const float* __restrict__ axisangle, const float* __restrict__ dtrans,
+                                                            float w_trans, float* __restrict__ daxisangle,
+                                                            const float* __restrict__ loss_pix, const float* __restrict__ trans_terms,
+                                                            float* __restrict__ losses, int n, int B, float inv_B, float img_scale,
+                                                            float img_offset) {
+  __shared__ float red[16];
+  if (dc != nullptr) {  // c = n softmax(l):  dl = c (dc - <dc, c> / n)
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dot += dc[i] * c[i];
+    dot = block_sum_1024(dot, red) / (float)n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dlogit[i] = c[i] * (dc[i] - dot);
+  }
+  float tr = 0.f;
+  if (dmat != nullptr) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      float g[6];
+      ax2mat_bwd_one(dmat + (size_t)i * 12, axisangle + (size_t)i * 6, g);
+#pragma unroll
+      for (int d = 0; d < 6; ++d) daxisangle[(size_t)i * 6 + d] = g[d] + w_trans * dtrans[(size_t)i * 6 + d];
+      tr += trans_terms[i];
+    }
+    tr = block_sum_1024(tr, red);
+  }
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) { s0 += loss_pix[3 * i]; s1 += loss_pix[3 * i + 1]; s2 += loss_pix[3 * i + 2]; }
+  s0 = block_sum_1024(s0, red); s1 = block_sum_1024(s1, red); s2 = block_sum_1024(s2, red);
+  if (threadIdx.x == 0) {
+    losses[0] = s0 * inv_B; losses[1] = s1 * inv_B; losses[2] = (s0 + s1) * inv_B;
+    losses[3] = tr; losses[4] = s2 * img_scale + img_offset;
+  }
+}
+
 template <typename K, typename... Args>
 int launch1d(K kernel, int n, void* stream, Args... args) {
   if (n <= 0) return 0;
@@ -265,6 +342,24 @@ int launch1d(K kernel, int n, void* stream, Args... args) {
 }
 
 }  // namespace
+
+extern "C" int nesvor_step_prologue(const float* logit_coef, float* c, const float* axisangle, float* mat, float* zero_buf,
+                                    int n_zero, int n, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(step_prologue_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logit_coef, c, axisangle, mat, zero_buf,
+                     n_zero, n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int nesvor_step_epilogue(const float* dc, const float* c, float* dlogit, const float* dmat, const float* axisangle,
+                                    const float* dtrans, float w_trans, float* daxisangle, const float* loss_pix,
+                                    const float* trans_terms, float* losses, int n, int B, float img_scale, float img_offset,
+                                    void* stream) {
+  if (n <= 0 || B <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(step_epilogue_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dc, c, dlogit, dmat, axisangle, dtrans,
+                     w_trans, daxisangle, loss_pix, trans_terms, losses, n, B, 1.f / (float)B, img_scale, img_offset);
+  return (int)hipGetLastError();
+}
 
 extern "C" int nesvor_trans_loss(const float* ax, const float* ax_init, float* loss_per_slice, float* grad_ax, int n,
                                  void* stream) {

@@ -16,7 +16,6 @@ from typing import Dict
 import torch
 
 from . import _lib, loss as loss_mod, mlp as mlp_mod, sampler
-from . import transform_convert_cuda as tcc
 from .encoding import hashgrid_backward, hashgrid_forward
 from .models import D_LOSS, DS_LOSS, I_REG, S_LOSS, T_REG, NeSVoR
 from .transform import trans_loss_raw
@@ -54,7 +53,6 @@ class DirectStep:
         self.s_layers = mlp_mod.linear_layers(model.sigma_net) if self.has_lv else None
         self.d_seg = self._segment("inr.density_net", self.d_layers)
         self.s_seg = self._segment("sigma_net", self.s_layers) if self.has_lv else None
-        self._loss_map = None
         self.side = torch.cuda.Stream(device=dev) if self.opt_T else None
 
     def _segment(self, prefix, layers):
@@ -105,14 +103,21 @@ class DirectStep:
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
                 per, g_t = trans_loss_raw(m.axisangle, m.axisangle_init)
-                t_reg = per.sum()
-            for t in (per, g_t, t_reg):
+            for t in (per, g_t):
                 t.record_stream(main)
 
         # ---- forward ----------------------------------------------------------------------------------
         if noise is None:
             noise = torch.randn(B, S, 3, dtype=xyz.dtype, device=dev)
-        mat = tcc.axisangle2mat_forward(m.axisangle)[0]
+        # per-slice small tensors in one launch: c = n softmax(logit_coef), pose matrices, zeroed accumulators
+        small = torch.empty(n * (1 + 12 + 13), dtype=torch.float32, device=dev)
+        c = small[:n] if self.has_c else None
+        mat = small[n : 13 * n].view(n, 3, 4)
+        acc = small[13 * n :]  # [dc (n) | dmat (n,12)]
+        with torch.cuda.device(dev):
+            err = lib.nesvor_step_prologue(_lib.ptr(m.logit_coef if self.has_c else None), _lib.ptr(c), _lib.ptr(m.axisangle),
+                                           _lib.ptr(mat), _lib.ptr(acc), 13 * n, n, _lib.stream_ptr())
+        _lib.check(err, "step prologue")
         x, u = sampler.forward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb)
         pe = hashgrid_forward(enc.spec, u, enc.params, _lib.LAYOUT_FEATURE_MAJOR)  # (E, N)
         dW = [l.weight for l in self.d_layers]
@@ -124,7 +129,6 @@ class DirectStep:
             sB = [l.bias for l in self.s_layers]
             se = m.slice_embedding.weight[slice_idx] if self.ks else None
             log_var, saved_s = mlp_mod.forward_raw(sW, sB, se, z, 1, a.n_features_z, S, True)  # (1, N)
-        c = torch.softmax(m.logit_coef, 0) * n if self.has_c else None
         lvs = m.log_var_slice if self.has_lvs else None
 
         # ---- losses: values and gradients in one launch -------------------------------------------------
@@ -135,9 +139,7 @@ class DirectStep:
         dlv = torch.empty(N, dtype=torch.float32, device=dev) if self.has_lv else None
         dxl = torch.empty_like(x) if self.opt_T else None
         loss_pix = torch.empty((B, 3), dtype=torch.float32, device=dev)
-        # per-slice accumulators: [dc (n) | dmat (n,12)] in one zero-filled buffer
-        acc = torch.zeros(n * 13, dtype=torch.float32, device=dev)
-        dc, dmat = acc[:n], acc[n:].view(n, 3, 4)
+        dc, dmat = acc[:n], acc[n:].view(n, 3, 4)  # zero-filled by the prologue
         pix = torch.empty((2, B), dtype=torch.float32, device=dev)
         la = loss_mod._fill(z[0], log_var, None, x, v, slice_idx, c, lvs, None, self.reg_type, self.delta)
         la.gw, la.loss_pix, la.dz0 = self.gw.data_ptr(), loss_pix.data_ptr(), dz[0].data_ptr()
@@ -170,31 +172,24 @@ class DirectStep:
                 m.log_var_slice.grad.data_ptr() if self.has_lvs else None, _lib.ptr(g_se), _lib.ptr(dmat), B, S,
                 self.ks, _lib.stream_ptr())
         _lib.check(err, "slice_grads")
-        if self.has_c:  # c = n softmax(l):  dl = c (dc - <dc, c>/n)
-            torch.mul(c, dc - torch.dot(dc, c) / n, out=m.logit_coef.grad)
-        losses = self._loss_dict(loss_pix, B, S)
+        # d logit_coef, d axisangle (+ pose regulariser) and the loss values: one launch
+        vals = torch.empty(5, dtype=torch.float32, device=dev)
+        img_scale = (self.delta if self.reg_type == 0 else 1.0) / (B * S)
+        img_off = -self.delta if self.reg_type == 0 else 0.0
         if self.opt_T:
-            dax = tcc.axisangle2mat_backward(dmat, m.axisangle)[0]
             main.wait_stream(self.side)
-            torch.add(dax, g_t, alpha=self.w_T, out=m.axisangle.grad)
-            losses[T_REG] = t_reg
-            # keep the reference's key order (models.py:316-326): ..., transReg, imageReg
-            losses[I_REG] = losses.pop(I_REG)
-        return losses
-
-    def _loss_dict(self, loss_pix, B, S):
-        """{MSE, logVar, MSE+logVar, imageReg} from the per-pixel partial sums: one reduction + one tiny matmul."""
-        if self._loss_map is None or self._loss_map[2] != (B, S):
-            d = self.delta
-            img = d / (B * S) if self.reg_type == 0 else 1.0 / (B * S)
-            M = torch.tensor([[1.0 / B, 0, 0], [0, 1.0 / B, 0], [1.0 / B, 1.0 / B, 0], [0, 0, img]], dtype=torch.float32)
-            off = torch.tensor([0, 0, 0, -d if self.reg_type == 0 else 0.0], dtype=torch.float32)
-            self._loss_map = (M.to(loss_pix.device), off.to(loss_pix.device), (B, S))
-        M, off, _ = self._loss_map
-        vals = torch.addmv(off, M, loss_pix.sum(0))
-        out = {D_LOSS: vals[0]}
+        with torch.cuda.device(dev):
+            err = lib.nesvor_step_epilogue(
+                _lib.ptr(dc if self.has_c else None), _lib.ptr(c), _lib.ptr(m.logit_coef.grad if self.has_c else None),
+                _lib.ptr(dmat if self.opt_T else None), _lib.ptr(m.axisangle), _lib.ptr(g_t if self.opt_T else None), self.w_T,
+                _lib.ptr(m.axisangle.grad if self.opt_T else None), _lib.ptr(loss_pix), _lib.ptr(per if self.opt_T else None),
+                _lib.ptr(vals), n, B, img_scale, img_off, _lib.stream_ptr())
+        _lib.check(err, "step epilogue")
+        losses = {D_LOSS: vals[0]}
         if self.has_var:
-            out[S_LOSS] = vals[1]
-            out[DS_LOSS] = vals[2]
-        out[I_REG] = vals[3]
-        return out
+            losses[S_LOSS] = vals[1]
+            losses[DS_LOSS] = vals[2]
+        if self.opt_T:
+            losses[T_REG] = vals[3]
+        losses[I_REG] = vals[4]
+        return losses
