@@ -248,6 +248,10 @@ int nesvor_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_
 int nesvor_adamw_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                           const float* hyper, int zero_grad, void* stream);
 
+/* out[c] = sum_r in[r][c] for a row-major (rows, cols) matrix: reduces the dw_partial of nesvor_mlp_backward
+ * (the `partial.sum(0)` of the host side) straight into a gradient segment. */
+int nesvor_sum_rows(const float* in, float* out, int rows, int cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

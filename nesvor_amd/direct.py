@@ -73,8 +73,10 @@ class DirectStep:
         return self.flat.grad[start:pos]
 
     def _store_net_grads(self, partial, layers, seg, prefix):
-        if seg is not None:
-            torch.sum(partial, 0, out=seg)
+        if seg is not None and seg.numel() == partial.shape[1]:
+            with torch.cuda.device(partial.device):
+                err = _lib.load().nesvor_sum_rows(_lib.ptr(partial), _lib.ptr(seg), partial.shape[0], partial.shape[1], _lib.stream_ptr())
+            _lib.check(err, "sum_rows")
             return
         flat = partial.sum(0)
         off = 0
