@@ -171,6 +171,8 @@ typedef struct {
   int32_t out_dim;            /* 1..16 */
   int32_t k_a, k_b, b_row0;
   int32_t samples_per_pixel;
+  int32_t dxa_group_sums;     /* backward only: dxa is (N/16, k_a), one row per 16-sample group = the sum over its samples
+                                 (needs N, samples_per_pixel and k_a multiples of 16 and the fused backward) */
   const float* weight[NESVOR_MAX_MLP_LAYERS];
   const float* bias[NESVOR_MAX_MLP_LAYERS];
 } nesvor_mlp_t;

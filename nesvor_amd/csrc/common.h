@@ -39,6 +39,15 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// Sum over the 16 lanes of a DPP row (VALU only); every lane of the row gets the row total.
+__device__ __forceinline__ float row_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+  return v;
+}
+
 // fp32 add into LDS through an integer compare-and-swap loop.  On gfx950 ds_add_f32 retires ~1 lane
 // per 3 cycles (192+ cycles per wave-instruction, measured, independent of conflicts) while
 // ds_cmpst_rtn_b32 runs at ~7 cycles per conflict-free wave-instruction, so the CAS loop wins

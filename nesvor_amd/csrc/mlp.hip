@@ -62,6 +62,7 @@ struct MlpArgs {
   int total_params;             // sum of W and b sizes (dW partial row length)
   int fast;                     // N % 16 == 0, S % 16 == 0, k_a % 16 == 0: group = one pixel, input blocks homogeneous
   int spg_shift;                // log2(S / 16) when that is a power of two, else -1
+  int dxa_group;                // dxa holds one row per 16-sample GROUP (sum over its samples) instead of one per sample
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -161,7 +162,16 @@ __device__ __forceinline__ void store_dx_fast(const MlpArgs& a, int64_t gi, int 
 #pragma unroll
   for (int kb = 0; kb < KB1; ++kb) {
     if (kb < ka_blocks) {
-      if (a.dxa != nullptr) *reinterpret_cast<f32x4*>(a.dxa + (size_t)n * a.k_a + 16 * kb + 4 * q) = dx[kb];
+      if (a.dxa != nullptr) {
+        if (a.dxa_group) {  // the group lies inside one pixel: reduce its 16 samples here, 16x less to write and re-read
+          f32x4 sgrp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sgrp[r] = row_sum_dpp(dx[kb][r]);
+          if (j == 0) *reinterpret_cast<f32x4*>(a.dxa + (size_t)gi * a.k_a + 16 * kb + 4 * q) = sgrp;
+        } else {
+          *reinterpret_cast<f32x4*>(a.dxa + (size_t)n * a.k_a + 16 * kb + 4 * q) = dx[kb];
+        }
+      }
     } else if (a.dxb != nullptr) {
       const int row0 = 16 * (kb - ka_blocks) + 4 * q;
 #pragma unroll
@@ -1044,6 +1054,7 @@ int fill_args(MlpArgs* a, const nesvor_mlp_t* d, int64_t N) {
   a->total_params = total;
   const int S = d->samples_per_pixel;
   a->fast = (N % 16 == 0 && S % 16 == 0 && d->k_a % 16 == 0) ? 1 : 0;
+  a->dxa_group = d->dxa_group_sums ? 1 : 0;
   a->spg_shift = -1;
   if (a->fast) {
     const int spg = S / 16;
@@ -1083,6 +1094,7 @@ extern "C" int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, con
     a.dpre[l] = l < net->n_hidden ? dpre_scratch[l] : nullptr;
   }
   const int kb1 = (net->k_a + net->k_b + 15) / 16;
+  if (a.dxa_group && !(a.fast && net->n_hidden <= 2 && dpre_scratch[0] == nullptr)) return (int)hipErrorInvalidValue;
   if (net->n_hidden <= 2 && dpre_scratch[0] == nullptr) {
     // fused dX + dW + db (the caller signals it by passing no dpre scratch); grid = n_partial workgroups
     static const bool use_ws = []() { const char* e = getenv("NESVOR_MLP_BWD_WS"); return e == nullptr || atoi(e) != 0; }();

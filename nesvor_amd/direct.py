@@ -171,8 +171,8 @@ class DirectStep:
         with torch.cuda.device(dev):
             err = lib.nesvor_slice_grads(
                 _lib.ptr(slice_idx), la.dc_pix, la.dlvs_pix, _lib.ptr(dxa), _lib.ptr(dpix), _lib.ptr(dc),
-                m.log_var_slice.grad.data_ptr() if self.has_lvs else None, _lib.ptr(g_se), _lib.ptr(dmat), B, S,
-                self.ks, _lib.stream_ptr())
+                m.log_var_slice.grad.data_ptr() if self.has_lvs else None, _lib.ptr(g_se), _lib.ptr(dmat), B,
+                (dxa.shape[0] // B) if dxa is not None else S, self.ks, _lib.stream_ptr())
         _lib.check(err, "slice_grads")
         # d logit_coef, d axisangle (+ pose regulariser) and the loss values: one launch
         vals = torch.empty(5, dtype=torch.float32, device=dev)

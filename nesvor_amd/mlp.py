@@ -81,7 +81,8 @@ def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved):
 
 def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_dxa):
     """One backward pass, no autograd.  dxb: (k_b, N) contiguous tensor the input gradient is written to (or
-    None); -> (dxa (N, k_a) per-sample | None, partial (n_partial, n_params) to be summed over dim 0)."""
+    None); -> (dxa (N, k_a) per-sample or (N/16, k_a) per 16-sample group | None - sum it over each pixel's rows -,
+    partial (n_partial, n_params) to be summed over dim 0)."""
     n_layers = len(weights)
     N = xb.shape[1]
     k_a = 0 if xa is None else xa.shape[1]
@@ -90,7 +91,11 @@ def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_d
     fused = (n_layers - 1) <= 2 and FUSED_BACKWARD
     # fused dX+dW+db kernel needs no dpre scratch (signalled by NULL entries); the two-kernel path does
     dpre = [] if fused else [torch.empty_like(s) for s in saved]
-    dxa = torch.empty((N, k_a), dtype=torch.float32, device=dev) if (xa is not None and need_dxa) else None
+    # pixel-feature gradient: one row per 16-sample group (summed in the kernel) when a group lies inside a pixel
+    group_sums = fused and N % 16 == 0 and S % 16 == 0 and k_a % 16 == 0
+    d.dxa_group_sums = 1 if group_sums else 0
+    rows = N // 16 if group_sums else N
+    dxa = torch.empty((rows, k_a), dtype=torch.float32, device=dev) if (xa is not None and need_dxa) else None
     total = sum(w.numel() + b.numel() for w, b in zip(weights, biases))
     n_partial = N_PARTIAL_FUSED if fused else N_PARTIAL
     partial = torch.empty((n_partial, total), dtype=torch.float32, device=dev)
@@ -140,7 +145,7 @@ class FusedMLPFunction(Function):
             off += b.numel()
         g_xa = None
         if dxa is not None:
-            g_xa = dxa.view(xa.shape[0], S, dxa.shape[1]).sum(1)
+            g_xa = dxa.view(xa.shape[0], -1, dxa.shape[1]).sum(1)
         return (g_xa, g_xb, None, None, None, None, *gw, *gb)
 
 
