@@ -1,6 +1,6 @@
 """Image containers on the hot path: ``Slice`` (input), ``Volume`` (mask / output),
 ``Stack``.  Mirrors the container part of ``nesvor.image`` (image/image.py:17-250).
-NIfTI I/O is out of scope for this tier and absent.
+File I/O (NIfTI, checkpoints) lives in ``nesvor_amd.image_io``; ``Image.save`` forwards to it.
 """
 from __future__ import annotations
 
@@ -35,6 +35,12 @@ class Image(object):
 
     def clone(self, zero: bool = False):
         raise NotImplementedError
+
+    def save(self, path: str, masked: bool = True) -> None:
+        """image.py:64-78"""
+        from .image_io import save_image
+
+        save_image(self, path, masked)
 
     def _clone_image(self, zero: bool = False) -> Dict:
         return {
