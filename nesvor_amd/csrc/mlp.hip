@@ -1075,7 +1075,8 @@ extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, cons
   for (int l = 0; l < kMaxLayers; ++l) a.H[l] = (saved_hidden != nullptr && l < net->n_hidden) ? saved_hidden[l] : nullptr;
   const int kb1 = (net->k_a + net->k_b + 15) / 16;
   const int64_t n_tiles = ((N + 15) / 16 + 4 * kG - 1) / (4 * kG);
-  dim3 grid((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
+  // 2 persistent workgroups per CU = the occupancy (measured: 256 / 768 / 1024 / 2048 workgroups are slower)
+  dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512));
   return launch_kb(mlp_fwd_kernel<1>, mlp_fwd_kernel<2>, mlp_fwd_kernel<3>, mlp_fwd_kernel<4>, kb1, grid,
                    fwd_lds_bytes(a.n_linear, kb1), (hipStream_t)stream, a);
 }
