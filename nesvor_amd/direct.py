@@ -7,8 +7,8 @@ zero-fills, the loss weighting) and the host falls behind the GPU.  Here the sam
 back-to-back in a fixed order and every parameter gradient is written straight into the flat gradient
 buffer.  Results equal the autograd path up to summation order (tests/test_gpu_model.py).
 
-Supported configuration = the fused one without a bias field (n_levels_bias == 0); anything else keeps the
-autograd path (FusedTrainer decides through ``supported``).
+Supported configuration = the fused one (MLPs of at most two hidden layers); anything else keeps the autograd path
+(FusedTrainer decides through ``supported``).
 """
 import ctypes
 from typing import Dict
@@ -17,7 +17,7 @@ import torch
 
 from . import _lib, loss as loss_mod, mlp as mlp_mod, sampler
 from .encoding import hashgrid_backward, hashgrid_forward
-from .models import D_LOSS, DS_LOSS, I_REG, S_LOSS, T_REG, NeSVoR
+from .models import B_REG, D_LOSS, DS_LOSS, I_REG, S_LOSS, T_REG, NeSVoR
 from .transform import trans_loss_raw
 
 
@@ -25,9 +25,7 @@ def supported(model: NeSVoR) -> bool:
     a = model.args
     if not (model.use_fused_mlp() and getattr(a, "fused_loss", True) and getattr(a, "direct_step", True)):
         return False
-    if a.n_levels_bias:
-        return False
-    nets = [model.inr.density_net] + ([] if a.no_pixel_variance else [model.sigma_net])
+    nets = [model.inr.density_net] + ([] if a.no_pixel_variance else [model.sigma_net]) + ([model.b_net] if a.n_levels_bias else [])
     return all(len(mlp_mod.linear_layers(n)) - 1 <= 2 for n in nets) and mlp_mod.FUSED_BACKWARD
 
 
@@ -40,12 +38,14 @@ class DirectStep:
         self.has_lv = not a.no_pixel_variance
         self.has_c = not a.no_slice_scale
         self.has_lvs = not a.no_slice_variance
-        self.ks = a.n_features_slice if self.has_lv else 0  # the slice embedding only feeds sigma_net here
+        self.has_b = bool(a.n_levels_bias)
+        self.kb_bias = a.n_levels_bias * a.n_features_per_level  # rows of pe the bias field sees
+        self.ks = a.n_features_slice if (self.has_lv or self.has_b) else 0  # slice embedding feeds sigma_net / b_net
         self.has_var = self.has_lv or self.has_lvs
         w = weights
         # upstream gradients of the loss kernel's four terms; DS_LOSS is reported but not weighted (train.py:183-186)
-        self.gw = torch.tensor([w.get(D_LOSS, 0), w.get(S_LOSS, 0) if self.has_var else 0, w.get(I_REG, 0), 0.0],
-                               dtype=torch.float32, device=dev)
+        self.gw = torch.tensor([w.get(D_LOSS, 0), w.get(S_LOSS, 0) if self.has_var else 0, w.get(I_REG, 0),
+                                w.get(B_REG, 0) if self.has_b else 0.0], dtype=torch.float32, device=dev)
         self.w_T = float(w.get(T_REG, 0))
         self.reg_type = loss_mod.REG_TYPES[a.image_regularization]
         self.delta = float(model.delta)
@@ -53,6 +53,8 @@ class DirectStep:
         self.s_layers = mlp_mod.linear_layers(model.sigma_net) if self.has_lv else None
         self.d_seg = self._segment("inr.density_net", self.d_layers)
         self.s_seg = self._segment("sigma_net", self.s_layers) if self.has_lv else None
+        self.b_layers = mlp_mod.linear_layers(model.b_net) if self.has_b else None
+        self.b_seg = self._segment("b_net", self.b_layers) if self.has_b else None
         self.side = torch.cuda.Stream(device=dev) if self.opt_T else None
 
     def _segment(self, prefix, layers):
@@ -125,11 +127,16 @@ class DirectStep:
         dW = [l.weight for l in self.d_layers]
         dB = [l.bias for l in self.d_layers]
         z, saved_d = mlp_mod.forward_raw(dW, dB, None, pe, 0, pe.shape[0], S, True)  # (1 + n_features_z, N)
-        log_var = se = None
+        log_var = log_bias = lb_mean = None
+        se = m.slice_embedding.weight[slice_idx] if self.ks else None
+        if self.has_b:  # bias field: [slice embedding | the coarsest levels of pe] -> log bias (models.py:341-346)
+            bW = [l.weight for l in self.b_layers]
+            bB = [l.bias for l in self.b_layers]
+            log_bias, saved_b = mlp_mod.forward_raw(bW, bB, se, pe, 0, self.kb_bias, S, True)  # (1, N)
+            lb_mean = log_bias.mean().reshape(1)
         if self.has_lv:
             sW = [l.weight for l in self.s_layers]
             sB = [l.bias for l in self.s_layers]
-            se = m.slice_embedding.weight[slice_idx] if self.ks else None
             log_var, saved_s = mlp_mod.forward_raw(sW, sB, se, z, 1, a.n_features_z, S, True)  # (1, N)
         lvs = m.log_var_slice if self.has_lvs else None
 
@@ -143,7 +150,9 @@ class DirectStep:
         loss_pix = torch.empty((B, 3), dtype=torch.float32, device=dev)
         dc, dmat = acc[:n], acc[n:].view(n, 3, 4)  # zero-filled by the prologue
         pix = torch.empty((2, B), dtype=torch.float32, device=dev)
-        la = loss_mod._fill(z[0], log_var, None, x, v, slice_idx, c, lvs, None, self.reg_type, self.delta)
+        dlb = torch.empty(N, dtype=torch.float32, device=dev) if self.has_b else None
+        la = loss_mod._fill(z[0], log_var, log_bias, x, v, slice_idx, c, lvs, lb_mean, self.reg_type, self.delta)
+        la.dlog_bias = None if dlb is None else dlb.data_ptr()
         la.gw, la.loss_pix, la.dz0 = self.gw.data_ptr(), loss_pix.data_ptr(), dz[0].data_ptr()
         la.dlog_var = None if dlv is None else dlv.data_ptr()
         la.dx = None if dxl is None else dxl.data_ptr()
@@ -162,6 +171,15 @@ class DirectStep:
         dpe = torch.empty_like(pe)
         _, partial_d = mlp_mod.backward_raw(dW, dB, None, pe, dz, saved_d, 0, pe.shape[0], S, dpe, False)
         self._store_net_grads(partial_d, self.d_layers, self.d_seg, "inr.density_net")
+        dxa_b = None
+        if self.has_b:
+            dpe_b = torch.empty((self.kb_bias, N), dtype=torch.float32, device=dev)
+            dxa_b, partial_b = mlp_mod.backward_raw(bW, bB, se, pe, dlb.view(1, N), saved_b, 0, self.kb_bias, S, dpe_b,
+                                                    se is not None)
+            self._store_net_grads(partial_b, self.b_layers, self.b_seg, "b_net")
+            dpe[: self.kb_bias] += dpe_b
+            if dxa is None:
+                dxa, dxa_b = dxa_b, None
         _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, enc.params.grad.view(-1), self.opt_T,
                                   _lib.LAYOUT_FEATURE_MAJOR)
         dpix = sampler.backward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb, dxl, du) if self.opt_T else None
@@ -174,6 +192,11 @@ class DirectStep:
                 m.log_var_slice.grad.data_ptr() if self.has_lvs else None, _lib.ptr(g_se), _lib.ptr(dmat), B,
                 (dxa.shape[0] // B) if dxa is not None else S, self.ks, _lib.stream_ptr())
         _lib.check(err, "slice_grads")
+        if dxa_b is not None:  # second consumer of the slice embedding (sigma_net's share went in with the call above)
+            with torch.cuda.device(dev):
+                err = lib.nesvor_slice_grads(_lib.ptr(slice_idx), None, None, _lib.ptr(dxa_b), None, None, None, _lib.ptr(g_se),
+                                             None, B, dxa_b.shape[0] // B, self.ks, _lib.stream_ptr())
+            _lib.check(err, "slice_grads (bias field)")
         # d logit_coef, d axisangle (+ pose regulariser) and the loss values: one launch
         vals = torch.empty(5, dtype=torch.float32, device=dev)
         img_scale = (self.delta if self.reg_type == 0 else 1.0) / (B * S)
@@ -193,5 +216,7 @@ class DirectStep:
             losses[DS_LOSS] = vals[2]
         if self.opt_T:
             losses[T_REG] = vals[3]
+        if self.has_b:
+            losses[B_REG] = lb_mean[0] ** 2
         losses[I_REG] = vals[4]
         return losses

@@ -78,6 +78,7 @@ def test_fused_trainer_step_equals_autograd_plus_adamw(device, golden):
 @pytest.mark.parametrize("over", [
     {}, {"depth": 2}, {"no_transformation_optimization": True}, {"no_pixel_variance": True},
     {"no_slice_scale": True, "no_slice_variance": True}, {"image_regularization": "TV"},
+    {"n_levels_bias": 2}, {"n_levels_bias": 2, "no_pixel_variance": True, "depth": 2},
 ])
 def test_direct_step_equals_autograd_step(device, golden, over):
     """The autograd-free iteration (nesvor_amd.direct) against autograd over the same kernels: same losses,
