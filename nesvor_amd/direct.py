@@ -56,6 +56,9 @@ class DirectStep:
         self.b_layers = mlp_mod.linear_layers(model.b_net) if self.has_b else None
         self.b_seg = self._segment("b_net", self.b_layers) if self.has_b else None
         self.side = torch.cuda.Stream(device=dev) if self.opt_T else None
+        import torch.distributed as dist
+
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
     def _segment(self, prefix, layers):
         """Flat-gradient segment holding a net's parameters in the kernel's partial-sum order W0,b0,W1,b1,...
@@ -134,6 +137,10 @@ class DirectStep:
             bB = [l.bias for l in self.b_layers]
             log_bias, saved_b = mlp_mod.forward_raw(bW, bB, se, pe, 0, self.kb_bias, S, True)  # (1, N)
             lb_mean = log_bias.mean().reshape(1)
+            if self.world > 1:  # biasReg = (mean log_bias)^2 is not a mean of per-sample terms: use the GLOBAL mean, so that
+                # the averaged gradients and the loss value are exactly those of the undivided batch (SURVEY.md 8e caveat 1)
+                torch.distributed.all_reduce(lb_mean)
+                lb_mean /= self.world
         if self.has_lv:
             sW = [l.weight for l in self.s_layers]
             sB = [l.bias for l in self.s_layers]
