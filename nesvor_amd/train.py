@@ -161,8 +161,7 @@ def train(slices: List[Slice], args: Namespace) -> Tuple[INR, List[Slice], Volum
             loss.backward()
             optimizer.step()
             optimizer.zero_grad()
-        for k in losses:
-            average(k, losses[k].detach())  # stays on the device: no per-iteration sync
+        average.update_all(losses)  # stays on the device: no per-iteration sync, two small launches
         if (decay_milestones and i >= decay_milestones[0]) or i == args.n_iter:
             logging.info(
                 "time %.1fs epoch %d iter %d %s", time.time() - t0, dataset.epoch, i,

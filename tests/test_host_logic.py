@@ -181,6 +181,21 @@ def test_moving_average_semantics():
     assert abs(ema["k"] - v / (1 - 0.999**3)) < 1e-12 and ema["missing"] == 0
 
 
+def test_moving_average_update_all_matches_per_key_calls():
+    from nesvor_amd.utils import MovingAverage
+
+    a, b = MovingAverage(0.999), MovingAverage(0.999)
+    g = torch.Generator().manual_seed(0)
+    for _ in range(5):
+        vals = {"x": torch.rand((), generator=g, dtype=torch.float64), "y": torch.rand((), generator=g, dtype=torch.float64)}
+        for k, v in vals.items():
+            a(k, v)
+        b.update_all(vals)
+    for k in ("x", "y"):
+        assert abs(float(a[k]) - float(b[k])) < 1e-12
+    assert a.value[0] == b.value[0] == 5
+
+
 def test_cg_vs_scipy_reference_test():
     """tests/svort/test_cg.py:9-20 — CG on a 5x5 Hankel system against scipy.sparse.linalg.cg (pure host logic)."""
     import scipy.linalg
