@@ -545,6 +545,12 @@ def test_imaging_loss_vs_reference_math(device, reg, pix_var, slice_var, bias, s
     (0, 16, 0, 16, 1, 16, 1, 300),      # default depth 1, E=16
     (0, 24, 0, 24, 3, 16, 256, 512),    # L=12 (default level scale), depth 3
     (16, 15, 1, 16, 1, 1, 256, 65536),  # full pixel clouds
+    (0, 32, 0, 32, 2, 16, 256, 4096),   # bench shapes: wave-specialised backward, two hidden layers, density_net
+    (16, 15, 1, 16, 2, 1, 256, 4096),   # ... sigma_net
+    (0, 16, 0, 16, 2, 16, 16, 512),     # one input block, two hidden layers
+    (0, 48, 0, 48, 1, 16, 16, 512),     # three input blocks, one hidden layer
+    (16, 40, 0, 48, 2, 1, 16, 512),     # four input blocks, two hidden layers (single-role fused backward, fast I/O path)
+    (32, 20, 2, 24, 2, 3, 32, 1024),    # two pixel-feature blocks + a ragged row block
 ])
 @pytest.mark.parametrize("fused_bwd", [True, False])
 def test_fused_mlp_vs_torch_fp32_reference(device, k_a, k_b, b_row0, rows, depth, out_dim, S, N, fused_bwd, monkeypatch):
