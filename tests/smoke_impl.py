@@ -36,10 +36,20 @@ def run_smoke(device):
     for k in ref:
         a, b = float(losses[k].detach()), float(ref[k])
         assert abs(a - b) <= 2e-5 * abs(b) + 1e-7, (k, a, b)
+    # the autograd-free evaluation of the same iteration (what train() runs): same losses, same gradients
+    assert trainer.direct is not None
+    l2 = trainer.direct.run(d("xyz"), d("v"), d("idx"), d("noise"))
+    for k in ref:
+        a, b = float(l2[k]), float(ref[k])
+        assert abs(a - b) <= 2e-5 * abs(b) + 1e-7, ("direct", k, a, b)
+    g_direct = trainer.flat.grad.clone()
+    trainer.flat.grad.zero_()
     from nesvor_amd.train import loss_weights
 
     w = loss_weights(args)
     sum(w[k] * losses[k] for k in losses if k in w and w[k]).backward()
+    scale = float(trainer.flat.grad.abs().max())
+    assert float((trainer.flat.grad - g_direct).abs().max()) <= 1e-4 * scale
     trainer.optimizer_step()
     torch.cuda.synchronize()
     assert all(torch.isfinite(p).all() for p in model.parameters())
