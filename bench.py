@@ -94,8 +94,6 @@ def main():
     ap.add_argument("--phantom", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="EXPERIMENTAL: replay the step from a captured hipGraph (round 1: faults on replay, off by default)")
     opt = ap.parse_args()
 
     import __graft_entry__ as ge
@@ -153,9 +151,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
-    # per-kernel HIP-event timing needs eager launches: it runs over its own K steps BEFORE the graph is
-    # captured (same process, same data, same kernels); the timed region then replays the hipGraph.
-    use_graph = opt.graph
+    # per-kernel HIP-event timing runs over its own K steps before the timed region (same process, data, kernels)
     ktimes = {}
     if not opt.no_kernel_timing:
         for _ in range(2):
@@ -166,9 +162,7 @@ def main():
         torch.cuda.synchronize(device)
         ktimes = _lib.kernel_timer.summary()
         _lib.kernel_timer.reset(enabled=False)
-    if use_graph:
-        trainer.enable_graph(opt.batch_size)
-    for _ in range(opt.warmup + (4 if use_graph else 0)):  # 3 eager warm-up steps + the capture step
+    for _ in range(opt.warmup):
         step()
     sync()
     t0 = time.perf_counter()
@@ -212,8 +206,7 @@ def main():
                 "bound": "hbm", "kernel": dom + (" (hashgrid_bwd_aggregate + hashgrid_bwd_owner launches)" if dom == "hashgrid_bwd" else ""),
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": achieved / 8000.0, "traffic": traffic, "launch_ms": ms,
-                "timing": f"HIP events on the launch stream over {opt.steps} eagerly launched steps of this run"
-                          + (" (the timed region replays the same kernels from a hipGraph)" if use_graph else ""),
+                "timing": f"HIP events on the launch stream over {opt.steps} steps of this run, before the timed region",
                 "algorithmic_bytes_per_launch": bytes_pt[dom] * n_points,
                 "other_kernels_ms": {k: round(v[1], 4) for k, v in ktimes.items() if k != dom},
             }
@@ -239,7 +232,7 @@ def main():
                 "workload": f"phantom3d({opt.phantom}) {opt.stacks}-stack, L={L} T=2^19 F=2 hash + {opt.depth}x64 MLPs, "
                             f"{opt.batch_size} px x {opt.n_samples} samples = 2^{(n_points).bit_length() - 1} points/iter/GPU, "
                             f"fp32, poses optimised, edge regulariser",
-                "global_batch_pixels": global_b, "n_levels": L, "parallelism": f"dp{world}", "hip_graph": use_graph,
+                "global_batch_pixels": global_b, "n_levels": L, "parallelism": f"dp{world}",
                 "masked_pixels": int(M), "n_slices": len(slices),
             },
             "roofline": roof,

@@ -244,11 +244,6 @@ int nesvor_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_
                       float lr, float beta1, float beta2, float eps, float weight_decay,
                       float bias_correction1, float bias_correction2, float grad_scale, int zero_grad,
                       void* stream);
-/* Same step with the eight scalars {lr, beta1, beta2, eps, weight_decay, bias_correction1,
- * bias_correction2, grad_scale} read from device memory, so that a captured hipGraph of the
- * training step can be replayed while the step count and the learning rate change. */
-int nesvor_adamw_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                          const float* hyper, int zero_grad, void* stream);
 
 /* out[c] = sum_r in[r][c] for a row-major (rows, cols) matrix: reduces the dw_partial of nesvor_mlp_backward
  * (the `partial.sum(0)` of the host side) straight into a gradient segment. */

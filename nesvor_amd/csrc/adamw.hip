@@ -24,24 +24,9 @@ __device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, co
   p -= a.step_size * (m / denom);
 }
 
-__device__ __forceinline__ AdamArgs make_args(float lr, float beta1, float beta2, float eps, float weight_decay,
-                                              float bc1, float bc2, float grad_scale) {
-  AdamArgs a;
-  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
-  a.decay_mul = 1.f - lr * weight_decay;
-  a.step_size = lr / bc1;
-  a.inv_sqrt_bc2 = 1.f / sqrtf(bc2);
-  a.grad_scale = grad_scale;
-  return a;
-}
-
-// HYPER_DEV: the eight step scalars are read from device memory (so that a captured hipGraph can be
-// replayed with a changing step count / learning rate), otherwise they arrive by value.
-template <bool ZERO, bool HYPER_DEV>
+template <bool ZERO>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, int64_t n, AdamArgs a,
-                                                    const float* __restrict__ hyper) {
-  if (HYPER_DEV) a = make_args(hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7]);
+                                                    float* __restrict__ v, int64_t n, const AdamArgs a) {
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -78,27 +63,11 @@ extern "C" int nesvor_adamw_step(float* param, float* grad, float* exp_avg, floa
   if (blocks < 1) blocks = 1;
   if (blocks > 256 * 8) blocks = 256 * 8;
   if (zero_grad)
-    hipLaunchKernelGGL((adamw_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param,
-                       grad, exp_avg, exp_avg_sq, n, a, (const float*)nullptr);
+    hipLaunchKernelGGL((adamw_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, n, a);
   else
-    hipLaunchKernelGGL((adamw_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param,
-                       grad, exp_avg, exp_avg_sq, n, a, (const float*)nullptr);
-  return (int)hipGetLastError();
-}
-
-extern "C" int nesvor_adamw_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                                     const float* hyper, int zero_grad, void* stream) {
-  if (n <= 0) return 0;
-  AdamArgs a{};
-  int64_t blocks = ((n >> 2) + 255) / 256;
-  if (blocks < 1) blocks = 1;
-  if (blocks > 256 * 8) blocks = 256 * 8;
-  if (zero_grad)
-    hipLaunchKernelGGL((adamw_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param,
-                       grad, exp_avg, exp_avg_sq, n, a, hyper);
-  else
-    hipLaunchKernelGGL((adamw_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param,
-                       grad, exp_avg, exp_avg_sq, n, a, hyper);
+    hipLaunchKernelGGL((adamw_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, n, a);
   return (int)hipGetLastError();
 }
 
@@ -129,4 +98,4 @@ extern "C" int nesvor_sum_rows(const float* in, float* out, int rows, int cols, 
   return (int)hipGetLastError();
 }
 
-extern "C" int nesvor_hip_abi_version(void) { return 13; }
+extern "C" int nesvor_hip_abi_version(void) { return 14; }

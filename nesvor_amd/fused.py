@@ -64,13 +64,6 @@ class FusedTrainer:
         self.t = 0
         self.world_size = world_size
         self.reduce_hook = None  # set by ddp: callable(flat_grad) performing the all-reduce(sum)
-        # hipGraph replay of the step (see enable_graph)
-        self._graph = None
-        self._graph_warm = 0
-        self._static = None
-        dev = self.flat.param.device
-        self._hyper = torch.zeros(8, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory()
         # autograd-free evaluation of the iteration when the configuration allows it (nesvor_amd.direct)
         from . import direct
 
@@ -91,72 +84,9 @@ class FusedTrainer:
         return losses
 
     def step(self, xyz, v, slice_idx) -> Dict[str, torch.Tensor]:
-        if self._static is not None:
-            return self._graph_step(xyz, v, slice_idx)
         losses = self._forward_backward(xyz, v, slice_idx)
         self.optimizer_step()
         return losses
-
-    # ---- hipGraph capture -------------------------------------------------------------------
-    def enable_graph(self, batch_size: int) -> None:
-        """EXPERIMENTAL (round 1: the replay hits a GPU memory fault, so nothing enables this by default).
-        Replay the training step (forward, backward and - single process - the optimiser) from a captured
-        hipGraph: the ~60 remaining small launches of an iteration stop costing CPU launch time.  The first
-        three steps still run eagerly (allocator / workspace warm-up), the fourth is captured."""
-        dev = self.flat.param.device
-        self._static = {
-            "xyz": torch.zeros((batch_size, 3), dtype=torch.float32, device=dev),
-            "v": torch.zeros(batch_size, dtype=torch.float32, device=dev),
-            "slice_idx": torch.zeros(batch_size, dtype=torch.int64, device=dev),
-            "losses": None,
-        }
-
-    def _graph_step(self, xyz, v, slice_idx):
-        st = self._static
-        st["xyz"].copy_(xyz)
-        st["v"].copy_(v)
-        st["slice_idx"].copy_(slice_idx)
-        import os
-        full = self.reduce_hook is None and os.environ.get("NESVOR_GRAPH_FWD_BWD_ONLY") != "1"  # with DDP the all-reduce and the optimiser stay outside the graph
-        if self._graph is None:
-            if self._graph_warm < 3:
-                self._graph_warm += 1
-                losses = self._forward_backward(st["xyz"], st["v"], st["slice_idx"])
-                self.optimizer_step()
-                return losses
-            torch.cuda.synchronize()
-            self._graph = torch.cuda.CUDAGraph()
-            if full:
-                self._upload_hyper(advance=True)
-            with torch.cuda.graph(self._graph):
-                st["losses"] = self._forward_backward(st["xyz"], st["v"], st["slice_idx"])
-                if full:
-                    self._adamw_dev()
-            self._graph.replay()  # capture only records: run the step that was just captured
-        else:
-            if full:
-                self._upload_hyper(advance=True)
-            self._graph.replay()
-        if not full:
-            self.optimizer_step()
-        return st["losses"]
-
-    def _upload_hyper(self, advance: bool) -> None:
-        if advance:
-            self.t += 1
-        b1, b2 = self.betas
-        h = self._hyper_host
-        h[0], h[1], h[2], h[3], h[4] = self.lr, b1, b2, self.eps, self.weight_decay
-        h[5], h[6], h[7] = 1 - b1**self.t, 1 - b2**self.t, 1.0 / self.world_size
-        self._hyper.copy_(h, non_blocking=True)
-
-    def _adamw_dev(self) -> None:
-        f = self.flat
-        with torch.cuda.device(f.param.device):
-            err = _lib.load().nesvor_adamw_step_dev(
-                _lib.ptr(f.param), _lib.ptr(f.grad), _lib.ptr(f.exp_avg), _lib.ptr(f.exp_avg_sq), f.numel,
-                _lib.ptr(self._hyper), 1, _lib.stream_ptr())
-        _lib.check(err, "adamw step (device hyper-parameters)")
 
     def optimizer_step(self) -> None:
         if self.reduce_hook is not None:
