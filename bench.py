@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--stacks", type=int, default=3)
     ap.add_argument("--phantom", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mlp-bf16", action="store_true",
+                    help="opt-in mixed precision (bf16 MLP matrix operands, fp32 accumulation): NOT the headline configuration")
     ap.add_argument("--no-kernel-timing", action="store_true")
     opt = ap.parse_args()
 
@@ -122,6 +124,7 @@ def main():
     vol = torch.tensor(phantom3d(n=opt.phantom), dtype=torch.float32, device=device)
     slices, _ = simulate_stacks(vol, n_stacks=opt.stacks)
     args = make_args(device, opt.batch_size, opt.n_samples, opt.depth, n_iter=6000)
+    args.mlp_bf16 = opt.mlp_bf16
     ds = Dataset(slices, args)
     model = NeSVoR(ds.transformation, ds.resolution, ds.mean, ds.bounding_box, args)
     L = model.inr.n_levels
@@ -227,7 +230,7 @@ def main():
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
             "ms_per_step": elapsed / opt.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if not opt.mlp_bf16 else "f32 (MLP matrix operands rounded to bf16, fp32 accumulation)", "data": "synthetic",
             "config": {
                 "workload": f"phantom3d({opt.phantom}) {opt.stacks}-stack, L={L} T=2^19 F=2 hash + {opt.depth}x64 MLPs, "
                             f"{opt.batch_size} px x {opt.n_samples} samples = 2^{(n_points).bit_length() - 1} points/iter/GPU, "

@@ -173,6 +173,10 @@ typedef struct {
   int32_t samples_per_pixel;
   int32_t dxa_group_sums;     /* backward only: dxa is (N/16, k_a), one row per 16-sample group = the sum over its samples
                                  (needs N, samples_per_pixel and k_a multiples of 16 and the fused backward) */
+  int32_t bf16_operands;      /* != 0: matrix operands (weights, activations, upstream gradients) rounded to bf16,
+                                 fp32 accumulation, everything else fp32 - an opt-in mixed-precision mode, not the
+                                 reference's fp32 semantics.  Backward: wave-specialised kernel only (N, S, k_a
+                                 multiples of 16, at most two hidden layers, k_a + k_b <= 32 for two hidden layers) */
   const float* weight[NESVOR_MAX_MLP_LAYERS];
   const float* bias[NESVOR_MAX_MLP_LAYERS];
 } nesvor_mlp_t;

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -39,7 +39,7 @@ class MlpT(Structure):
     _fields_ = [
         ("width", c_int32), ("n_hidden", c_int32), ("out_dim", c_int32),
         ("k_a", c_int32), ("k_b", c_int32), ("b_row0", c_int32), ("samples_per_pixel", c_int32),
-        ("dxa_group_sums", c_int32),
+        ("dxa_group_sums", c_int32), ("bf16_operands", c_int32),
         ("weight", c_void_p * 4), ("bias", c_void_p * 4),
     ]
 

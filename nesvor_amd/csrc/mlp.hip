@@ -63,38 +63,76 @@ struct MlpArgs {
   int fast;                     // N % 16 == 0, S % 16 == 0, k_a % 16 == 0: group = one pixel, input blocks homogeneous
   int spg_shift;                // log2(S / 16) when that is a power of two, else -1
   int dxa_group;                // dxa holds one row per 16-sample GROUP (sum over its samples) instead of one per sample
+  int bf16;                     // matrix operands rounded to bf16 (fp32 accumulation)
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Optional mixed-precision mode (nesvor_mlp_t.bf16_operands): the matrix operands - weights, activations, upstream
+// gradients - are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) and multiplied by
+// v_mfma_f32_16x16x16_bf16 with fp32 accumulation; everything else (master weights, biases, ReLU, saved activations,
+// outputs) stays fp32.  One bf16 MFMA contracts the same 16 k-values as four fp32 16x16x4 MFMAs with the same lane
+// maps (k = 4 (lane >> 4) + r), at 1/16 of their matrix-pipe time.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 pack_bf16(const f32x4& v) {
+  return __builtin_bit_cast(s16x4, __builtin_convertvector(v, bf16x4));
+}
+__device__ __forceinline__ f32x4 mfma16_bf16(s16x4 a, s16x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
 // ---------------------------------------------------------------- LDS images
 // forward image of a layer with `ob_n` output blocks and `kb_n` input blocks
+// (BF16: the image holds bf16 elements at the same element indices, i.e. it uses the first half of the fp32 carve)
+template <bool BF16 = false>
 __device__ void build_image(float* img, const float* __restrict__ W, int out_dim, int in_dim, int ob_n, int kb_n) {
   const int total = ob_n * kb_n * 256;
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
     const int r = e & 3, lane = (e >> 2) & 63, blk = e >> 8;
     const int kb = blk % kb_n, ob = blk / kb_n;
     const int o = 16 * ob + (lane & 15), k = 16 * kb + 4 * (lane >> 4) + r;
-    img[e] = (o < out_dim && k < in_dim) ? W[(size_t)o * in_dim + k] : 0.f;
+    const float w = (o < out_dim && k < in_dim) ? W[(size_t)o * in_dim + k] : 0.f;
+    if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w;
+    else img[e] = w;
   }
 }
 // transposed image: rows i = input features (ib blocks), k = output features (kb blocks)
+template <bool BF16 = false>
 __device__ void build_image_T(float* img, const float* __restrict__ W, int out_dim, int in_dim, int ib_n, int kb_n) {
   const int total = ib_n * kb_n * 256;
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
     const int r = e & 3, lane = (e >> 2) & 63, blk = e >> 8;
     const int kb = blk % kb_n, ib = blk / kb_n;
     const int in = 16 * ib + (lane & 15), o = 16 * kb + 4 * (lane >> 4) + r;
-    img[e] = (o < out_dim && in < in_dim) ? W[(size_t)o * in_dim + in] : 0.f;
+    const float w = (o < out_dim && in < in_dim) ? W[(size_t)o * in_dim + in] : 0.f;
+    if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w;
+    else img[e] = w;
   }
 }
 
 // y[g][ob] (+)= img . x   for G groups at once; KB input blocks, OB output blocks
-template <int KB, int OB>
+template <int KB, int OB, bool BF16 = false>
 __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const f32x4 (&x)[kG][KB], f32x4 (&y)[kG][OB],
                                             int lane) {
+  if constexpr (BF16) {
+    const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      s16x4 pb[kG];
+#pragma unroll
+      for (int g = 0; g < kG; ++g) pb[g] = pack_bf16(x[g][kb]);
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) {
+        const s16x4 a = *reinterpret_cast<const s16x4*>(img16 + ((ob * KB + kb) * 64 + lane) * 4);
+#pragma unroll
+        for (int g = 0; g < kG; ++g) y[g][ob] = mfma16_bf16(a, pb[g], y[g][ob]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
@@ -109,8 +147,19 @@ __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const
 }
 
 // single 16-sample group variant (used by the fused backward, where registers hold the dW accumulators)
-template <int KB, int OB>
+template <int KB, int OB, bool BF16 = false>
 __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, const f32x4 (&x)[KB], f32x4 (&y)[OB], int lane) {
+  if constexpr (BF16) {
+    const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const s16x4 pb = pack_bf16(x[kb]);
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+        y[ob] = mfma16_bf16(*reinterpret_cast<const s16x4*>(img16 + ((ob * KB + kb) * 64 + lane) * 4), pb, y[ob]);
+    }
+    return;
+  }
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
@@ -192,7 +241,7 @@ __device__ __forceinline__ f32x4 load_dy_fast(const MlpArgs& a, int64_t gi, int 
 }
 
 // ------------------------------------------------------------------- forward
-template <int KB1>
+template <int KB1, bool BF16 = false>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n_hidden = a.n_linear - 1;
@@ -202,9 +251,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
   float* imgh = img1 + kHB * KB1 * 256;
   float* imgo = imgh + (n_hidden - 1) * kHB * kHB * 256;
   float* bias = imgo + 1 * kHB * 256;
-  build_image(img1, a.W[0], kWidth, k_in, kHB, KB1);
-  for (int l = 1; l < n_hidden; ++l) build_image(imgh + (l - 1) * kHB * kHB * 256, a.W[l], kWidth, kWidth, kHB, kHB);
-  build_image(imgo, a.W[n_hidden], a.out_dim, kWidth, 1, kHB);
+  build_image<BF16>(img1, a.W[0], kWidth, k_in, kHB, KB1);
+  for (int l = 1; l < n_hidden; ++l) build_image<BF16>(imgh + (l - 1) * kHB * kHB * 256, a.W[l], kWidth, kWidth, kHB, kHB);
+  build_image<BF16>(imgo, a.W[n_hidden], a.out_dim, kWidth, 1, kHB);
   for (int e = threadIdx.x; e < a.n_linear * kWidth; e += blockDim.x) {
     const int l = e / kWidth, o = e % kWidth;
     bias[e] = (l < n_hidden || o < a.out_dim) ? a.b[l][o] : 0.f;
@@ -237,7 +286,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
 #pragma unroll
       for (int g = 0; g < kG; ++g) h[g][ob] = bq;
     }
-    apply_layer<KB1, kHB>(img1, x, h, lane);
+    apply_layer<KB1, kHB, BF16>(img1, x, h, lane);
     for (int l = 0;; ++l) {
       // ReLU + save fragments of hidden layer l
 #pragma unroll
@@ -257,7 +306,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
 #pragma unroll
         for (int g = 0; g < kG; ++g) h2[g][ob] = bq;
       }
-      apply_layer<kHB, kHB>(imgh + l * kHB * kHB * 256, h, h2, lane);
+      apply_layer<kHB, kHB, BF16>(imgh + l * kHB * kHB * 256, h, h2, lane);
 #pragma unroll
       for (int g = 0; g < kG; ++g)
 #pragma unroll
@@ -269,7 +318,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
 #pragma unroll
       for (int g = 0; g < kG; ++g) o[g][0] = bq;
     }
-    apply_layer<kHB, 1>(imgo, h, o, lane);
+    apply_layer<kHB, 1, BF16>(imgo, h, o, lane);
 #pragma unroll
     for (int g = 0; g < kG; ++g) {
       const int64_t n = (g0 + g) * 16 + j;
@@ -741,7 +790,7 @@ __device__ void flush_dw_ws(float* red /* 4 x kHB*256 floats */, const f32x4 (&a
 }
 
 // dW accumulation from a staged A tile set and B operands already in registers
-template <int OB, int IB>
+template <int OB, int IB, bool BF16 = false>
 __device__ __forceinline__ void accumulate_dw_regs(const float* tiles, const f32x4 (&bv)[IB], f32x4 (&acc)[OB][IB],
                                                    float (&db)[OB], int i, int q) {
   float av[OB][4];
@@ -749,6 +798,18 @@ __device__ __forceinline__ void accumulate_dw_regs(const float* tiles, const f32
   for (int ob = 0; ob < OB; ++ob) {
     read_operand(tiles + ob * kTileFloats, i, q, av[ob]);
     db[ob] += (av[ob][0] + av[ob][1]) + (av[ob][2] + av[ob][3]);
+  }
+  if constexpr (BF16) {
+    s16x4 pb[IB];
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) pb[ib] = pack_bf16(bv[ib]);
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) {
+      const s16x4 pa = pack_bf16(f32x4{av[ob][0], av[ob][1], av[ob][2], av[ob][3]});
+#pragma unroll
+      for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma16_bf16(pa, pb[ib], acc[ob][ib]);
+    }
+    return;
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -776,7 +837,7 @@ __device__ __forceinline__ void await_loads() {
 __device__ __forceinline__ void pin(f32x4& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 
-template <int KB1, int NH>
+template <int KB1, int NH, bool BF16 = false>
 __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int k_in = a.k_a + a.k_b;
@@ -785,9 +846,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   float* imgh = imgo + kHB * 1 * 256;                   // W_l^T, l = 1..NH-1
   float* img1 = imgh + (NH - 1) * kHB * kHB * 256;      // W_1^T : ib = KB1, kb = 4
   float* tiles = img1 + KB1 * kHB * 256;                // [pair][buffer][kT] tiles; reused as the flush buffer
-  build_image_T(imgo, a.W[NH], a.out_dim, kWidth, kHB, 1);
-  for (int l = 1; l < NH; ++l) build_image_T(imgh + (l - 1) * kHB * kHB * 256, a.W[l], kWidth, kWidth, kHB, kHB);
-  build_image_T(img1, a.W[0], kWidth, k_in, KB1, kHB);
+  build_image_T<BF16>(imgo, a.W[NH], a.out_dim, kWidth, kHB, 1);
+  for (int l = 1; l < NH; ++l) build_image_T<BF16>(imgh + (l - 1) * kHB * kHB * 256, a.W[l], kWidth, kWidth, kHB, kHB);
+  build_image_T<BF16>(img1, a.W[0], kWidth, k_in, KB1, kHB);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -852,7 +913,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         f32x4 d[kHB];
 #pragma unroll
         for (int ib = 0; ib < kHB; ++ib) d[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-        apply_layer_g1<1, kHB>(imgo, gov, d, lane);
+        apply_layer_g1<1, kHB, BF16>(imgo, gov, d, lane);
 #pragma unroll
         for (int l = NH - 1; l >= 0; --l) {
 #pragma unroll
@@ -865,14 +926,14 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             f32x4 d2[kHB];
 #pragma unroll
             for (int ib = 0; ib < kHB; ++ib) d2[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-            apply_layer_g1<kHB, kHB>(imgh + (l - 1) * kHB * kHB * 256, d, d2, lane);
+            apply_layer_g1<kHB, kHB, BF16>(imgh + (l - 1) * kHB * kHB * 256, d, d2, lane);
 #pragma unroll
             for (int ib = 0; ib < kHB; ++ib) d[ib] = d2[ib];
           } else if (a.dxa != nullptr || a.dxb != nullptr) {
             f32x4 dx[KB1];
 #pragma unroll
             for (int ib = 0; ib < KB1; ++ib) dx[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-            apply_layer_g1<kHB, KB1>(img1, d, dx, lane);
+            apply_layer_g1<kHB, KB1, BF16>(img1, d, dx, lane);
             // drain the prefetch BEFORE the stores below: loads and stores share vmcnt, and the wait would otherwise
             // also cover the latency of these stores
             settle_group(gy_n, hs_n);
@@ -966,12 +1027,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         }
         issue_b(min(gi + gstride, n_groups - 1), hraw, xraw, xsraw);  // one group ahead (see the chain waves)
         const float* buf = my_tiles + ((it - 1) & 1) * kT * kTileFloats;
-        accumulate_dw_regs<1, kHB>(buf, hb[NH - 1], acc_o, db_o, j, q);
+        accumulate_dw_regs<1, kHB, BF16>(buf, hb[NH - 1], acc_o, db_o, j, q);
 #pragma unroll
         for (int l = NH - 1; l >= 0; --l) {
           const float* dt = buf + (1 + (NH - 1 - l) * kHB) * kTileFloats;
-          if (l > 0) accumulate_dw_regs<kHB, kHB>(dt, hb[l - 1], acc_h[l - 1], db_h[l - 1], j, q);
-          else accumulate_dw_regs<kHB, KB1>(dt, xb_, acc_1, db_1, j, q);
+          if (l > 0) accumulate_dw_regs<kHB, kHB, BF16>(dt, hb[l - 1], acc_h[l - 1], db_h[l - 1], j, q);
+          else accumulate_dw_regs<kHB, KB1, BF16>(dt, xb_, acc_1, db_1, j, q);
         }
         settle_b(hraw, xraw, xsraw);
       }
@@ -1055,6 +1116,7 @@ int fill_args(MlpArgs* a, const nesvor_mlp_t* d, int64_t N) {
   const int S = d->samples_per_pixel;
   a->fast = (N % 16 == 0 && S % 16 == 0 && d->k_a % 16 == 0) ? 1 : 0;
   a->dxa_group = d->dxa_group_sums ? 1 : 0;
+  a->bf16 = d->bf16_operands ? 1 : 0;
   a->spg_shift = -1;
   if (a->fast) {
     const int spg = S / 16;
@@ -1077,6 +1139,9 @@ extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, cons
   const int64_t n_tiles = ((N + 15) / 16 + 4 * kG - 1) / (4 * kG);
   // 2 persistent workgroups per CU = the occupancy (measured: 256 / 768 / 1024 / 2048 workgroups are slower)
   dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512));
+  if (a.bf16)
+    return launch_kb(mlp_fwd_kernel<1, true>, mlp_fwd_kernel<2, true>, mlp_fwd_kernel<3, true>, mlp_fwd_kernel<4, true>, kb1,
+                     grid, fwd_lds_bytes(a.n_linear, kb1), (hipStream_t)stream, a);
   return launch_kb(mlp_fwd_kernel<1>, mlp_fwd_kernel<2>, mlp_fwd_kernel<3>, mlp_fwd_kernel<4>, kb1, grid,
                    fwd_lds_bytes(a.n_linear, kb1), (hipStream_t)stream, a);
 }
@@ -1101,12 +1166,20 @@ extern "C" int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, con
     static const bool use_ws = []() { const char* e = getenv("NESVOR_MLP_BWD_WS"); return e == nullptr || atoi(e) != 0; }();
     if (use_ws && a.fast && (kb1 <= 2 || net->n_hidden == 1)) {  // wave-specialised: 8 waves per workgroup (wider inputs would spill)
       const size_t lds_ws = ws_bwd_lds_bytes(net->n_hidden, kb1);
+      if (a.bf16) {
+        if (net->n_hidden == 1)
+          return launch_kb(mlp_bwd_ws_kernel<1, 1, true>, mlp_bwd_ws_kernel<2, 1, true>, mlp_bwd_ws_kernel<3, 1, true>,
+                           mlp_bwd_ws_kernel<4, 1, true>, kb1, dim3((unsigned)n_partial), lds_ws, (hipStream_t)stream, a, 512);
+        return launch_kb(mlp_bwd_ws_kernel<1, 2, true>, mlp_bwd_ws_kernel<2, 2, true>, mlp_bwd_ws_kernel<3, 2, true>,
+                         mlp_bwd_ws_kernel<4, 2, true>, kb1, dim3((unsigned)n_partial), lds_ws, (hipStream_t)stream, a, 512);
+      }
       if (net->n_hidden == 1)
         return launch_kb(mlp_bwd_ws_kernel<1, 1>, mlp_bwd_ws_kernel<2, 1>, mlp_bwd_ws_kernel<3, 1>, mlp_bwd_ws_kernel<4, 1>,
                          kb1, dim3((unsigned)n_partial), lds_ws, (hipStream_t)stream, a, 512);
       return launch_kb(mlp_bwd_ws_kernel<1, 2>, mlp_bwd_ws_kernel<2, 2>, mlp_bwd_ws_kernel<3, 2>, mlp_bwd_ws_kernel<4, 2>,
                        kb1, dim3((unsigned)n_partial), lds_ws, (hipStream_t)stream, a, 512);
     }
+    if (a.bf16) return (int)hipErrorInvalidValue;  // the bf16 mode exists in the wave-specialised backward only
     const size_t lds = fused_bwd_lds_bytes(net->n_hidden, kb1);
     if (net->n_hidden == 1)
       return launch_kb(mlp_bwd_fused_kernel<1, 1>, mlp_bwd_fused_kernel<2, 1>, mlp_bwd_fused_kernel<3, 1>,
@@ -1114,6 +1187,7 @@ extern "C" int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, con
     return launch_kb(mlp_bwd_fused_kernel<1, 2>, mlp_bwd_fused_kernel<2, 2>, mlp_bwd_fused_kernel<3, 2>,
                      mlp_bwd_fused_kernel<4, 2>, kb1, dim3((unsigned)n_partial), lds, (hipStream_t)stream, a);
   }
+  if (a.bf16) return (int)hipErrorInvalidValue;
   const int64_t n_tiles = ((N + 15) / 16 + 4 * kG - 1) / (4 * kG);
   dim3 grid((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
   e = launch_kb(mlp_bwd_dx_kernel<1>, mlp_bwd_dx_kernel<2>, mlp_bwd_dx_kernel<3>, mlp_bwd_dx_kernel<4>, kb1, grid,

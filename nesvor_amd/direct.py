@@ -56,6 +56,8 @@ class DirectStep:
         self.b_layers = mlp_mod.linear_layers(model.b_net) if self.has_b else None
         self.b_seg = self._segment("b_net", self.b_layers) if self.has_b else None
         self.side = torch.cuda.Stream(device=dev) if self.opt_T else None
+        # opt-in mixed precision of the MLPs: bf16 matrix operands, fp32 accumulation / master weights (args.mlp_bf16)
+        self.bf16 = bool(getattr(a, "mlp_bf16", False))
         import torch.distributed as dist
 
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -129,13 +131,13 @@ class DirectStep:
         pe = hashgrid_forward(enc.spec, u, enc.params, _lib.LAYOUT_FEATURE_MAJOR)  # (E, N)
         dW = [l.weight for l in self.d_layers]
         dB = [l.bias for l in self.d_layers]
-        z, saved_d = mlp_mod.forward_raw(dW, dB, None, pe, 0, pe.shape[0], S, True)  # (1 + n_features_z, N)
+        z, saved_d = mlp_mod.forward_raw(dW, dB, None, pe, 0, pe.shape[0], S, True, self.bf16)  # (1 + n_features_z, N)
         log_var = log_bias = lb_mean = None
         se = m.slice_embedding.weight[slice_idx] if self.ks else None
         if self.has_b:  # bias field: [slice embedding | the coarsest levels of pe] -> log bias (models.py:341-346)
             bW = [l.weight for l in self.b_layers]
             bB = [l.bias for l in self.b_layers]
-            log_bias, saved_b = mlp_mod.forward_raw(bW, bB, se, pe, 0, self.kb_bias, S, True)  # (1, N)
+            log_bias, saved_b = mlp_mod.forward_raw(bW, bB, se, pe, 0, self.kb_bias, S, True, self.bf16)  # (1, N)
             lb_mean = log_bias.mean().reshape(1)
             if self.world > 1:  # biasReg = (mean log_bias)^2 is not a mean of per-sample terms: use the GLOBAL mean, so that
                 # the averaged gradients and the loss value are exactly those of the undivided batch (SURVEY.md 8e caveat 1)
@@ -144,7 +146,7 @@ class DirectStep:
         if self.has_lv:
             sW = [l.weight for l in self.s_layers]
             sB = [l.bias for l in self.s_layers]
-            log_var, saved_s = mlp_mod.forward_raw(sW, sB, se, z, 1, a.n_features_z, S, True)  # (1, N)
+            log_var, saved_s = mlp_mod.forward_raw(sW, sB, se, z, 1, a.n_features_z, S, True, self.bf16)  # (1, N)
         lvs = m.log_var_slice if self.has_lvs else None
 
         # ---- losses: values and gradients in one launch -------------------------------------------------
@@ -173,16 +175,16 @@ class DirectStep:
         dxa = None
         if self.has_lv:
             dxa, partial_s = mlp_mod.backward_raw(sW, sB, se, z, dlv.view(1, N), saved_s, 1, a.n_features_z, S,
-                                                  dz[1 : 1 + a.n_features_z], se is not None)
+                                                  dz[1 : 1 + a.n_features_z], se is not None, self.bf16)
             self._store_net_grads(partial_s, self.s_layers, self.s_seg, "sigma_net")
         dpe = torch.empty_like(pe)
-        _, partial_d = mlp_mod.backward_raw(dW, dB, None, pe, dz, saved_d, 0, pe.shape[0], S, dpe, False)
+        _, partial_d = mlp_mod.backward_raw(dW, dB, None, pe, dz, saved_d, 0, pe.shape[0], S, dpe, False, self.bf16)
         self._store_net_grads(partial_d, self.d_layers, self.d_seg, "inr.density_net")
         dxa_b = None
         if self.has_b:
             dpe_b = torch.empty((self.kb_bias, N), dtype=torch.float32, device=dev)
             dxa_b, partial_b = mlp_mod.backward_raw(bW, bB, se, pe, dlb.view(1, N), saved_b, 0, self.kb_bias, S, dpe_b,
-                                                    se is not None)
+                                                    se is not None, self.bf16)
             self._store_net_grads(partial_b, self.b_layers, self.b_seg, "b_net")
             dpe[: self.kb_bias] += dpe_b
             if dxa is None:

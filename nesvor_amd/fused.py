@@ -68,6 +68,8 @@ class FusedTrainer:
         from . import direct
 
         self.direct = direct.DirectStep(model, self.flat, self.weights) if direct.supported(model) else None
+        if getattr(args, "mlp_bf16", False) and self.direct is None:
+            raise RuntimeError("args.mlp_bf16 needs the autograd-free step (fused fp32 model, MLPs of at most two hidden layers)")
 
     def decay_lr(self, gamma: float) -> None:
         self.lr *= gamma

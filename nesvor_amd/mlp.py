@@ -40,8 +40,9 @@ def supported(seq) -> bool:
     return layers[-1].out_features <= 16 and layers[0].in_features <= 64 and all(l.bias is not None for l in layers)
 
 
-def _desc(weights, biases, k_a, k_b, b_row0, S):
+def _desc(weights, biases, k_a, k_b, b_row0, S, bf16=False):
     d = _lib.MlpT()
+    d.bf16_operands = 1 if bf16 else 0
     d.width, d.n_hidden, d.out_dim = 64, len(weights) - 1, weights[-1].shape[0]
     d.k_a, d.k_b, d.b_row0, d.samples_per_pixel = k_a, k_b, b_row0, S
     for i, (w, b) in enumerate(zip(weights, biases)):
@@ -56,8 +57,9 @@ def _ptr_array(tensors):
     return arr
 
 
-def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved):
-    """One forward launch, no autograd: -> (y (out_dim, N), saved hidden activations [] when not need_saved)."""
+def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False):
+    """One forward launch, no autograd: -> (y (out_dim, N), saved hidden activations [] when not need_saved).
+    bf16: matrix operands rounded to bf16, fp32 accumulation (opt-in mixed precision, see include/nesvor_hip.h)."""
     _lib.require_device(xb, *weights, *biases, dtype=torch.float32, name="fused MLP input/params")
     N = xb.shape[1]
     k_a = 0 if xa is None else xa.shape[1]
@@ -67,7 +69,7 @@ def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved):
             raise RuntimeError("pixel features: P * samples_per_pixel must equal N")
     if weights[0].shape[1] != k_a + k_b:
         raise RuntimeError("first layer width does not match k_a + k_b")
-    d = _desc(weights, biases, k_a, k_b, b_row0, S)
+    d = _desc(weights, biases, k_a, k_b, b_row0, S, bf16)
     n_pad = (N + 15) // 16 * 16
     saved = [torch.empty(n_pad * 64, dtype=torch.float32, device=xb.device) for _ in range(len(weights) - 1)] if need_saved else []
     y = torch.empty((d.out_dim, N), dtype=torch.float32, device=xb.device)
@@ -79,14 +81,14 @@ def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved):
     return y, saved
 
 
-def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_dxa):
+def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_dxa, bf16=False):
     """One backward pass, no autograd.  dxb: (k_b, N) contiguous tensor the input gradient is written to (or
     None); -> (dxa (N, k_a) per-sample or (N/16, k_a) per 16-sample group | None - sum it over each pixel's rows -,
     partial (n_partial, n_params) to be summed over dim 0)."""
     n_layers = len(weights)
     N = xb.shape[1]
     k_a = 0 if xa is None else xa.shape[1]
-    d = _desc(weights, biases, k_a, k_b, b_row0, S)
+    d = _desc(weights, biases, k_a, k_b, b_row0, S, bf16)
     dev = xb.device
     fused = (n_layers - 1) <= 2 and FUSED_BACKWARD
     # fused dX+dW+db kernel needs no dpre scratch (signalled by NULL entries); the two-kernel path does

@@ -537,6 +537,63 @@ def test_imaging_loss_vs_reference_math(device, reg, pix_var, slice_var, bias, s
         assert float((gotg - ref).abs().max()) <= 5e-4 * scale_, (name, float((gotg - ref).abs().max()), scale_)
 
 
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("k_a,k_b,b_row0,rows,out_dim", [(0, 32, 0, 32, 16), (16, 15, 1, 16, 1)])
+def test_fused_mlp_bf16_operand_mode(device, k_a, k_b, b_row0, rows, out_dim):
+    """Opt-in mixed precision (nesvor_mlp_t.bf16_operands): every matrix product takes bf16-rounded operands and
+    accumulates in fp32.  Reference = the same arithmetic spelled out in torch (fp64 accumulation of the rounded
+    operands): forward, input gradients and parameter gradients.  Tolerance 2e-3 of the largest element (fp32
+    accumulation order)."""
+    from nesvor_amd import mlp
+    from nesvor_amd.models import build_network
+
+    torch.manual_seed(0)
+    N, S = 4096, 256
+    net = build_network(n_input_dims=k_a + k_b, n_output_dims=out_dim, activation="ReLU", output_activation="None",
+                        n_neurons=64, n_hidden_layers=2, dtype=torch.float32).to(device)
+    L = mlp.linear_layers(net)
+    W, Bs = [l.weight.detach() for l in L], [l.bias.detach() for l in L]
+    xa = torch.randn(N // S, k_a, device=device) if k_a else None
+    xb = torch.randn(rows, N, device=device)
+    dy = torch.randn(out_dim, N, device=device)
+    y, saved = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, True, bf16=True)
+    dxb = torch.empty(k_b, N, device=device)
+    dxa, partial = mlp.backward_raw(W, Bs, xa, xb, dy, saved, b_row0, k_b, S, dxb, xa is not None, bf16=True)
+    flat = partial.sum(0).cpu().double()
+    # reference (N, features) row-major, fp64 accumulation of bf16-rounded operands
+    X = xb[b_row0 : b_row0 + k_b].t()
+    if xa is not None:
+        X = torch.cat([xa.repeat_interleave(S, 0), X], 1)
+    X, Wd, Bd = X.cpu(), [w.cpu() for w in W], [b.cpu().double() for b in Bs]
+    mm = lambda a, b: _bf(a).double() @ _bf(b).double()
+    h1 = torch.relu(mm(X, Wd[0].t()) + Bd[0]).float()
+    h2 = torch.relu(mm(h1, Wd[1].t()) + Bd[1]).float()
+    yr = mm(h2, Wd[2].t()) + Bd[2]
+    close = lambda a, b, name: (float((a.double() - b.double()).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-6) or pytest.fail(name)
+    close(y.t().cpu(), yr, "y")
+    G = dy.t().cpu()
+    d2 = (mm(G, Wd[2]) * (h2 > 0)).float()
+    d1 = (mm(d2, Wd[1]) * (h1 > 0)).float()
+    dX = mm(d1, Wd[0])
+    gW = [mm(d1.t(), X), mm(d2.t(), h1), mm(G.t(), h2)]
+    gB = [d1.double().sum(0), d2.double().sum(0), G.double().sum(0)]
+    close(dxb.t().cpu(), dX[:, k_a:], "dxb")
+    if xa is not None:
+        close(dxa.view(N // S, -1, k_a).sum(1).cpu(), dX[:, :k_a].view(N // S, S, k_a).sum(1), "dxa")
+    off = 0
+    for w, gw, gb in zip(Wd, gW, gB):
+        close(flat[off : off + w.numel()].view_as(w), gw, "dW")
+        off += w.numel()
+        close(flat[off : off + gb.numel()], gb, "db")
+        off += gb.numel()
+    # and the mode really is coarser than fp32: it must NOT match the fp32 kernel to fp32 accuracy
+    y32, _ = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, False)
+    assert float((y32 - y).abs().max()) > 1e-4 * float(y32.abs().max())
+
+
 # -------------------------------------------------------------------- fused MLP
 @pytest.mark.parametrize("k_a,k_b,b_row0,rows,depth,out_dim,S,N", [
     (0, 32, 0, 32, 2, 16, 8, 1000),     # density_net (ragged N, not a multiple of 16)

@@ -28,5 +28,9 @@ for name, k_a, k_b, rows, row0, out in (("density", 0, 32, 32, 0, 16), ("sigma",
     tf0 = timeit(lambda: mlp.forward_raw(W, Bs, xa, xb, row0, k_b, S, False))
     print(f"{name}: fwd without saving activations {tf0:.3f} ms")
     tb = timeit(lambda: mlp.backward_raw(W, Bs, xa, xb, dy, saved, row0, k_b, S, dxb, k_a > 0))
+    tfb = timeit(lambda: mlp.forward_raw(W, Bs, xa, xb, row0, k_b, S, True, bf16=True))
+    yb, savedb = mlp.forward_raw(W, Bs, xa, xb, row0, k_b, S, True, bf16=True)
+    tbb = timeit(lambda: mlp.backward_raw(W, Bs, xa, xb, dy, savedb, row0, k_b, S, dxb, k_a > 0, bf16=True))
+    print(f"{name}: bf16-operand mode fwd {tfb:.3f} ms  bwd {tbb:.3f} ms")
     fl = 2 * N * (64 * (k_a + k_b) + 64 * 64 + 64 * out)
     print(f"{name}: fwd {tf:.3f} ms ({fl/tf/1e9:.1f} TF)  bwd {tb:.3f} ms ({2*fl/tb/1e9:.1f} TF)", flush=True)
