@@ -40,6 +40,8 @@ def _training_flags(p: argparse.ArgumentParser) -> None:
     g.add_argument("--no-pixel-variance", action="store_true")
     g.add_argument("--no-slice-variance", action="store_true")
     g.add_argument("--single-precision", action="store_true")
+    g.add_argument("--mlp-bf16", action="store_true",
+                   help="(not in the reference) with --single-precision: bf16 MLP matrix operands, fp32 accumulation / weights")
     g = p.add_argument_group("loss function")
     g.add_argument("--weight-transformation", default=0.1, type=float)
     g.add_argument("--weight-bias", default=100.0, type=float)
@@ -186,6 +188,8 @@ def reconstruct(args: Namespace) -> None:
     if not args.n_inference_samples:
         args.n_inference_samples = 2 * args.n_samples
     args.dtype = torch.float32 if args.single_precision else torch.float16
+    if args.mlp_bf16 and not args.single_precision:
+        raise SystemExit("--mlp-bf16 is a variant of the fp32 model: pass --single-precision too")
     if not args.single_precision:
         logging.info("fp16 module path selected; pass --single-precision for the fused fp32 HIP path")
     t0 = time.time()

@@ -27,6 +27,7 @@
 // coalesced 1 KiB wave transactions.
 #include <hip/hip_runtime.h>
 #include <map>
+#include <type_traits>
 #include <mutex>
 #include "common.h"
 #include "../../include/nesvor_hip.h"
@@ -72,11 +73,13 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 
 // Optional mixed-precision mode (nesvor_mlp_t.bf16_operands): the matrix operands - weights, activations, upstream
 // gradients - are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) and multiplied by
-// v_mfma_f32_16x16x16_bf16 with fp32 accumulation; everything else (master weights, biases, ReLU, saved activations,
-// outputs) stays fp32.  One bf16 MFMA contracts the same 16 k-values as four fp32 16x16x4 MFMAs with the same lane
+// v_mfma_f32_16x16x16_bf16 with fp32 accumulation; master weights, biases, ReLU and outputs stay fp32.  The saved
+// hidden activations are stored as bf16 (same fragment layout, 8 bytes per lane): they are only ever used as bf16
+// operands or as ReLU masks, so nothing is lost and the largest HBM stream of the MLPs halves.  One bf16 MFMA contracts the same 16 k-values as four fp32 16x16x4 MFMAs with the same lane
 // maps (k = 4 (lane >> 4) + r), at 1/16 of their matrix-pipe time.
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x4 pack_bf16(const f32x4& v) {
   return __builtin_bit_cast(s16x4, __builtin_convertvector(v, bf16x4));
 }
@@ -295,8 +298,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
         for (int ob = 0; ob < kHB; ++ob) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[g][ob][r] = fmaxf(h[g][ob][r], 0.f);
-          if (a.H[l] != nullptr && g0 + g < n_groups)
-            *reinterpret_cast<f32x4*>(a.H[l] + (((size_t)(g0 + g) * kHB + ob) * 64 + lane) * 4) = h[g][ob];
+          if (a.H[l] != nullptr && g0 + g < n_groups) {
+            const size_t e = (((size_t)(g0 + g) * kHB + ob) * 64 + lane) * 4;
+            if constexpr (BF16) *reinterpret_cast<s16x4*>(reinterpret_cast<__bf16*>(a.H[l]) + e) = pack_bf16(h[g][ob]);
+            else *reinterpret_cast<f32x4*>(a.H[l] + e) = h[g][ob];
+          }
         }
       if (l + 1 >= n_hidden) break;
       f32x4 h2[kG][kHB];
@@ -828,6 +834,19 @@ __device__ __forceinline__ void issue_load_b128(f32x4& dst, const float* p) {
 __device__ __forceinline__ void issue_load_b32(float& dst, const float* p) {
   asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
+__device__ __forceinline__ void issue_load_b64(f32x2& dst, const void* p) {
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void issue_load_u16(float& dst, const void* p) {  // zero-extended 16 bits in a 32-bit register
+  asm volatile("global_load_ushort %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void pin(f32x2& x) { asm volatile("" : "+v"(x)); }
+// four bf16 packed in two dwords -> fp32 (exact)
+__device__ __forceinline__ f32x4 unpack_bf16(const f32x2& v) {
+  const uint32_t u0 = __float_as_uint(v[0]), u1 = __float_as_uint(v[1]);
+  return f32x4{__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xFFFF0000u), __uint_as_float(u1 << 16),
+               __uint_as_float(u1 & 0xFFFF0000u)};
+}
 __device__ __forceinline__ void await_loads() {
   __builtin_amdgcn_sched_barrier(0);  // nothing (in particular no MFMA) may be scheduled across the wait
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -868,16 +887,22 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 
   if (role == 0) {
     // ------------------------------------------------------------------ chain waves
-    auto issue_group = [&](int64_t gi, float (&gy)[4], f32x4 (&hs)[NH][kHB]) {
+    // saved activations: fp32 fragments (16 B per lane) or, in the bf16 mode, bf16 fragments (8 B per lane)
+    using RawH = typename std::conditional<BF16, f32x2, f32x4>::type;
+    auto issue_group = [&](int64_t gi, float (&gy)[4], RawH (&hs)[NH][kHB]) {
       const int64_t n = gi * 16 + j;
 #pragma unroll
       for (int r = 0; r < 4; ++r) issue_load_b32(gy[r], a.y + (size_t)min(4 * q + r, a.out_dim - 1) * a.N + n);
 #pragma unroll
       for (int l = 0; l < NH; ++l)
 #pragma unroll
-        for (int ib = 0; ib < kHB; ++ib) issue_load_b128(hs[l][ib], a.H[l] + (((size_t)gi * kHB + ib) * 64 + lane) * 4);
+        for (int ib = 0; ib < kHB; ++ib) {
+          const size_t e = (((size_t)gi * kHB + ib) * 64 + lane) * 4;
+          if constexpr (BF16) issue_load_b64(hs[l][ib], reinterpret_cast<const __bf16*>(a.H[l]) + e);
+          else issue_load_b128(hs[l][ib], a.H[l] + e);
+        }
     };
-    auto settle_group = [&](float (&gy)[4], f32x4 (&hs)[NH][kHB]) {
+    auto settle_group = [&](float (&gy)[4], RawH (&hs)[NH][kHB]) {
       await_loads();
 #pragma unroll
       for (int r = 0; r < 4; ++r) pin(gy[r]);
@@ -887,11 +912,15 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         for (int ib = 0; ib < kHB; ++ib) pin(hs[l][ib]);
     };
     float gy_n[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 hs[NH][kHB], hs_n[NH][kHB];
+    f32x4 hs[NH][kHB];
+    RawH hs_n[NH][kHB];
 #pragma unroll
     for (int l = 0; l < NH; ++l)
 #pragma unroll
-      for (int ib = 0; ib < kHB; ++ib) hs_n[l][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ib = 0; ib < kHB; ++ib) {
+        if constexpr (BF16) hs_n[l][ib] = f32x2{0.f, 0.f};
+        else hs_n[l][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     if (g_first < n_groups) { issue_group(g_first, gy_n, hs_n); settle_group(gy_n, hs_n); }
     for (int it = 0; it <= n_it; ++it) {
       const int64_t gi = g_first + (int64_t)it * gstride;
@@ -902,7 +931,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
         for (int l = 0; l < NH; ++l)
 #pragma unroll
-          for (int ib = 0; ib < kHB; ++ib) hs[l][ib] = hs_n[l][ib];
+          for (int ib = 0; ib < kHB; ++ib) {
+            if constexpr (BF16) hs[l][ib] = unpack_bf16(hs_n[l][ib]);
+            else hs[l][ib] = hs_n[l][ib];
+          }
         // next group's inputs, one whole group of MFMAs ahead of their settle_group().  No control flow may merge
         // between an issue and its settle (a register copy at the merge would read the in-flight registers), so the
         // last iteration simply re-requests its own group
@@ -967,9 +999,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
       for (int l = 0; l < NH; ++l)
 #pragma unroll
         for (int ib = 0; ib < kHB; ++ib) {
-          const float* p = a.H[l] + (((size_t)gi * kHB + ib) * 64 + (j >> 2) * 16 + 4 * q) * 4 + (j & 3);
+          const size_t e = (((size_t)gi * kHB + ib) * 64 + (j >> 2) * 16 + 4 * q) * 4 + (j & 3);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) issue_load_b32(hraw[l][ib][t], p + 4 * t);
+          for (int t = 0; t < 4; ++t) {
+            if constexpr (BF16) issue_load_u16(hraw[l][ib][t], reinterpret_cast<const __bf16*>(a.H[l]) + e + 4 * t);
+            else issue_load_b32(hraw[l][ib][t], a.H[l] + e + 4 * t);
+          }
         }
       // both candidate sources of every input block are requested (no branch between issue and settle); the block
       // type picks one after the loads have landed
@@ -1015,7 +1050,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
           for (int ib = 0; ib < kHB; ++ib)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) hb[l][ib][t] = hraw[l][ib][t];
+            for (int t = 0; t < 4; ++t)
+              hb[l][ib][t] = BF16 ? __uint_as_float(__float_as_uint(hraw[l][ib][t]) << 16) : hraw[l][ib][t];
 #pragma unroll
         for (int kb = 0; kb < KB1; ++kb) {
           if (kb < ka_blocks) {

@@ -71,7 +71,9 @@ def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False)
         raise RuntimeError("first layer width does not match k_a + k_b")
     d = _desc(weights, biases, k_a, k_b, b_row0, S, bf16)
     n_pad = (N + 15) // 16 * 16
-    saved = [torch.empty(n_pad * 64, dtype=torch.float32, device=xb.device) for _ in range(len(weights) - 1)] if need_saved else []
+    # saved hidden activations, MFMA fragment layout; bf16 mode stores them as bf16 (they are only used as bf16 operands)
+    sdt = torch.bfloat16 if bf16 else torch.float32
+    saved = [torch.empty(n_pad * 64, dtype=sdt, device=xb.device) for _ in range(len(weights) - 1)] if need_saved else []
     y = torch.empty((d.out_dim, N), dtype=torch.float32, device=xb.device)
     with torch.cuda.device(xb.device), _lib.kernel_timer.span("mlp_fwd"):
         err = _lib.load().nesvor_mlp_forward(

@@ -16,6 +16,7 @@ vol = torch.tensor(phantom3d(n=n), dtype=torch.float32, device=dev)
 torch.manual_seed(0)
 slices, true_tf = simulate_stacks(vol, n_stacks=3, motion_deg=motion[0], motion_mm=motion[1])
 args = make_args(dev, 4096, 256, 2, n_iter)
+args.mlp_bf16 = os.environ.get("NESVOR_MLP_BF16") == "1"  # opt-in mixed precision of the MLPs
 t0 = time.time()
 inr, out_slices, mask = train(slices, args)
 torch.cuda.synchronize()
