@@ -668,6 +668,57 @@ def test_fused_mlp_vs_oracle_cpu(device):
 
 
 # ------------------------------------------------------------------------ AdamW
+def test_step_bookkeeping_kernels(device):
+    """nesvor_slice_grads / nesvor_step_prologue / nesvor_step_epilogue / nesvor_sum_rows against the torch ops they
+    replace in the training iteration (index_add, softmax forward/backward, axisangle2mat and its backward, sums)."""
+    from nesvor_amd import _lib
+    from oracle import transform_convert as tc
+
+    lib = _lib.load()
+    st = _lib.stream_ptr()
+    torch.manual_seed(0)
+    n, B, S, ks = 37, 200, 32, 16
+    idx = torch.randint(0, n, (B,), device=device)
+    dc_pix, dlvs_pix = torch.randn(B, device=device), torch.randn(B, device=device)
+    dxa = torch.randn(B * S // 16, ks, device=device)  # one row per 16-sample group
+    dpix = torch.randn(B, 3, 4, device=device)
+    dc, dlvs = torch.zeros(n, device=device), torch.zeros(n, device=device)
+    dse, dmat = torch.zeros(n, ks, device=device), torch.zeros(n, 3, 4, device=device)
+    assert lib.nesvor_slice_grads(_lib.ptr(idx), _lib.ptr(dc_pix), _lib.ptr(dlvs_pix), _lib.ptr(dxa), _lib.ptr(dpix), _lib.ptr(dc),
+                                  _lib.ptr(dlvs), _lib.ptr(dse), _lib.ptr(dmat), B, S // 16, ks, st) == 0
+    torch.testing.assert_close(dc, torch.zeros(n, device=device).index_add_(0, idx, dc_pix), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dlvs, torch.zeros(n, device=device).index_add_(0, idx, dlvs_pix), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dmat, torch.zeros(n, 3, 4, device=device).index_add_(0, idx, dpix), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dse, torch.zeros(n, ks, device=device).index_add_(0, idx, dxa.view(B, -1, ks).sum(1)), rtol=1e-4, atol=1e-4)
+
+    logit = torch.randn(n, device=device)
+    ax = torch.randn(n, 6, device=device) * torch.tensor([0.5, 0.5, 0.5, 3, 3, 3], device=device)
+    c, mat, zb = torch.empty(n, device=device), torch.empty(n, 3, 4, device=device), torch.ones(50, device=device)
+    assert lib.nesvor_step_prologue(_lib.ptr(logit), _lib.ptr(c), _lib.ptr(ax), _lib.ptr(mat), _lib.ptr(zb), 50, n, st) == 0
+    torch.testing.assert_close(c, torch.softmax(logit, 0) * n, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(mat.cpu(), tc.axisangle2mat_forward(ax.cpu()), rtol=1e-5, atol=1e-5)
+    assert float(zb.abs().max()) == 0.0
+
+    dcv, dm, dtr, terms = torch.randn(n, device=device), torch.randn(n, 3, 4, device=device), torch.randn(n, 6, device=device), torch.rand(n, device=device)
+    loss_pix = torch.rand(B, 3, device=device)
+    dlogit, dax, vals = torch.empty(n, device=device), torch.empty(n, 6, device=device), torch.empty(5, device=device)
+    assert lib.nesvor_step_epilogue(_lib.ptr(dcv), _lib.ptr(c), _lib.ptr(dlogit), _lib.ptr(dm), _lib.ptr(ax), _lib.ptr(dtr), 0.1,
+                                    _lib.ptr(dax), _lib.ptr(loss_pix), _lib.ptr(terms), _lib.ptr(vals), n, B, 0.25, -0.5, st) == 0
+    lg = logit.clone().requires_grad_(True)
+    (torch.softmax(lg, 0) * n * dcv).sum().backward()
+    torch.testing.assert_close(dlogit, lg.grad, rtol=1e-4, atol=1e-5)
+    ref_dax = tc.axisangle2mat_backward(dm.cpu(), ax.cpu()) + 0.1 * dtr.cpu()
+    torch.testing.assert_close(dax.cpu(), ref_dax, rtol=1e-4, atol=1e-4)
+    sums = loss_pix.sum(0)
+    ref_vals = torch.stack([sums[0] / B, sums[1] / B, (sums[0] + sums[1]) / B, terms.sum(), sums[2] * 0.25 - 0.5])
+    torch.testing.assert_close(vals, ref_vals, rtol=1e-5, atol=1e-5)
+
+    part = torch.randn(256, 6288, device=device)
+    out = torch.empty(6288, device=device)
+    assert lib.nesvor_sum_rows(_lib.ptr(part), _lib.ptr(out), 256, 6288, st) == 0
+    torch.testing.assert_close(out, part.sum(0), rtol=1e-4, atol=1e-4)
+
+
 def test_fused_adamw_vs_torch(device):
     from nesvor_amd import _lib
 
