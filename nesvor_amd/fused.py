@@ -7,7 +7,6 @@ buffer with matching flat gradient and Adam-moment buffers, so that
   one contiguous buffer (nesvor_amd.ddp),
 * the hash-grid backward scatters straight into the flat gradient.
 """
-import math
 from argparse import Namespace
 from typing import Dict
 

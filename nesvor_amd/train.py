@@ -16,7 +16,7 @@ from typing import Dict, List, Tuple
 import torch
 
 from .image import Slice, Volume
-from .models import B_REG, D_LOSS, DS_LOSS, I_REG, INR, S_LOSS, T_REG, NeSVoR
+from .models import B_REG, D_LOSS, I_REG, INR, S_LOSS, T_REG, NeSVoR
 from .transform import RigidTransform, transform_points
 from .utils import MovingAverage, gaussian_blur
 

@@ -4,7 +4,7 @@ pure PyTorch, device-agnostic, no native code involved.
 """
 import collections
 import math
-from typing import Any, Collection, Dict, List, Optional, Tuple, Union
+from typing import Any, Collection, Dict, List, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
