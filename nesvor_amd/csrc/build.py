@@ -50,14 +50,14 @@ def build(force=False, verbose=True):
             continue
         cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, "-I", os.path.join(ROOT, "include"), "-c", src, "-o", obj]
         if verbose:
-            print(" ".join(cmd), flush=True)
+            print(" ".join(cmd), file=sys.stderr, flush=True)  # stdout stays clean for bench.py's JSON line
         procs.append((src, subprocess.Popen(cmd)))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:
-        print(" ".join(cmd), flush=True)
+        print(" ".join(cmd), file=sys.stderr, flush=True)
     subprocess.check_call(cmd)
     return LIB
 
