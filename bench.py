@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mlp-bf16", action="store_true",
                     help="opt-in mixed precision (bf16 MLP matrix operands, fp32 accumulation): NOT the headline configuration")
+    ap.add_argument("--half-precision-model", action="store_true",
+                    help="the reference's default model structure (args.dtype float16: bias-free networks), evaluated with bf16 "
+                         "matrix operands and fp32 accumulation: NOT the headline configuration")
     ap.add_argument("--no-kernel-timing", action="store_true")
     opt = ap.parse_args()
 
@@ -125,6 +128,8 @@ def main():
     slices, _ = simulate_stacks(vol, n_stacks=opt.stacks)
     args = make_args(device, opt.batch_size, opt.n_samples, opt.depth, n_iter=6000)
     args.mlp_bf16 = opt.mlp_bf16
+    if opt.half_precision_model:
+        args.dtype, args.single_precision = torch.float16, False
     ds = Dataset(slices, args)
     model = NeSVoR(ds.transformation, ds.resolution, ds.mean, ds.bounding_box, args)
     L = model.inr.n_levels
@@ -220,9 +225,13 @@ def main():
             hid = (opt.depth - 1) * W * W
             fl = 2 * n_points * ((L * F * W + hid + W * (1 + nz)) + ((ns + nz) * W + hid + W))  # one forward of both nets
             ms2 = 2 * ktimes["mlp_bwd"][1]
+            bf16_ops = opt.mlp_bf16 or opt.half_precision_model
+            peak = 2500.0 if bf16_ops else 157.3
+            note = ("bf16 MFMA (v_mfma_f32_16x16x16_bf16) dense peak; the kernel is bound by its LDS/VALU work around the MFMAs "
+                    "in this mode, not by the matrix pipe" if bf16_ops else "fp32 MFMA (v_mfma_f32_16x16x4_f32) dense peak")
             roof_mlp = {"bound": "mfma", "kernel": "mlp_bwd_fused (density_net + sigma_net launches)", "achieved": 2 * fl / (ms2 * 1e-3) / 1e12,
-                        "peak": 157.3, "unit": "TFLOP/s", "frac": 2 * fl / (ms2 * 1e-3) / 1e12 / 157.3, "traffic": None,
-                        "launch_ms": ms2, "note": "fp32 MFMA (v_mfma_f32_16x16x4_f32) dense peak; flops = 2x forward (dX and dW), padding excluded"}
+                        "peak": peak, "unit": "TFLOP/s", "frac": 2 * fl / (ms2 * 1e-3) / 1e12 / peak, "traffic": None,
+                        "launch_ms": ms2, "note": note + "; flops = 2x forward (dX and dW), padding excluded"}
         out = {
             "metric": "INR train iters/sec (2^20 samples, L=16 hash, 64-wide MLP)",
             "value": iters_per_s,
@@ -230,7 +239,9 @@ def main():
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
             "ms_per_step": elapsed / opt.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not opt.mlp_bf16 else "f32 (MLP matrix operands rounded to bf16, fp32 accumulation)", "data": "synthetic",
+            "dtype": ("f32" if not (opt.mlp_bf16 or opt.half_precision_model) else
+                      "f32 (MLP matrix operands rounded to bf16, fp32 accumulation)" + (", bias-free half-precision model structure" if opt.half_precision_model else "")),
+            "data": "synthetic",
             "config": {
                 "workload": f"phantom3d({opt.phantom}) {opt.stacks}-stack, L={L} T=2^19 F=2 hash + {opt.depth}x64 MLPs, "
                             f"{opt.batch_size} px x {opt.n_samples} samples = 2^{(n_points).bit_length() - 1} points/iter/GPU, "

@@ -249,9 +249,10 @@ int nesvor_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_
                       float bias_correction1, float bias_correction2, float grad_scale, int zero_grad,
                       void* stream);
 
-/* out[c] = sum_r in[r][c] for a row-major (rows, cols) matrix: reduces the dw_partial of nesvor_mlp_backward
- * (the `partial.sum(0)` of the host side) straight into a gradient segment. */
-int nesvor_sum_rows(const float* in, float* out, int rows, int cols, void* stream);
+/* out[c] = sum_r in[r * ld + c], c < cols, for a row-major matrix of row pitch ld >= cols floats: reduces the
+ * dw_partial of nesvor_mlp_backward (the `partial.sum(0)` of the host side) straight into a gradient segment; with
+ * ld > cols, a column range of it (one layer's weights when the model keeps no biases, tinycudann.Network). */
+int nesvor_sum_rows(const float* in, float* out, int rows, int cols, int ld, void* stream);
 
 #ifdef __cplusplus
 }

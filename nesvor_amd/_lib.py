@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -93,7 +93,7 @@ _SIGNATURES = {
         [_P, _P, _P, _P, c_int64] + [c_float] * 8 + [c_int, _P],
         c_int,
     ),
-    "nesvor_sum_rows": ([_P, _P, c_int, c_int, _P], c_int),
+    "nesvor_sum_rows": ([_P, _P, c_int, c_int, c_int, _P], c_int),
 }
 
 

@@ -10,7 +10,8 @@ nesvor/cli/commands.py:64-146) for the commands that sit on the built path (SURV
 Differences from the reference, all because SVoRT / stack registration is out of scope here:
 ``--registration`` accepts the reference's choices but only ``none`` is implemented (and is the default; the
 reference defaults to ``svort``); there is no ``register`` command.  Precision follows the reference's switch
-(``--single-precision`` = fp32, which is the mode the fused HIP path accelerates; the default is the fp16 module path).
+(``--single-precision`` = the fp32 model with biased Linear layers; the default is the reference's half-precision
+structure - bias-free networks - which the HIP path evaluates with bf16 matrix operands and fp32 accumulation).
 """
 import argparse
 import logging
@@ -191,7 +192,7 @@ def reconstruct(args: Namespace) -> None:
     if args.mlp_bf16 and not args.single_precision:
         raise SystemExit("--mlp-bf16 is a variant of the fp32 model: pass --single-precision too")
     if not args.single_precision:
-        logging.info("fp16 module path selected; pass --single-precision for the fused fp32 HIP path")
+        logging.info("half-precision model structure (bias-free networks): bf16 matrix operands, fp32 accumulation")
     t0 = time.time()
     if args.input_slices is not None:
         slices = load_slices(args.input_slices, args.device)

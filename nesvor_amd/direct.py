@@ -7,8 +7,9 @@ zero-fills, the loss weighting) and the host falls behind the GPU.  Here the sam
 back-to-back in a fixed order and every parameter gradient is written straight into the flat gradient
 buffer.  Results equal the autograd path up to summation order (tests/test_gpu_model.py).
 
-Supported configuration = the fused one (MLPs of at most two hidden layers); anything else keeps the autograd path
-(FusedTrainer decides through ``supported``).
+Supported configurations: the fused single-precision model and the half-precision model structure (bias-free
+tinycudann networks, evaluated with bf16 matrix operands), MLPs of at most two hidden layers; anything else keeps the
+autograd path (FusedTrainer decides through ``supported``).
 """
 import ctypes
 from typing import Dict
@@ -21,12 +22,36 @@ from .models import B_REG, D_LOSS, DS_LOSS, I_REG, S_LOSS, T_REG, NeSVoR
 from .transform import trans_loss_raw
 
 
+def _nets(model: NeSVoR):
+    a = model.args
+    return [model.inr.density_net] + ([] if a.no_pixel_variance else [model.sigma_net]) + ([model.b_net] if a.n_levels_bias else [])
+
+
+def half_precision_model(model: NeSVoR) -> bool:
+    """The reference's default structure (args.dtype == float16, models.py:28-41): bias-free tinycudann networks.  Here
+    it trains on the same kernels with bf16 matrix operands and fp32 accumulation / master weights - at least the
+    precision of tinycudann's fp16 path, and no loss scaling is needed."""
+    from .tinycudann import Network
+
+    return model.args.dtype == torch.float16 and all(isinstance(n, Network) for n in _nets(model))
+
+
 def supported(model: NeSVoR) -> bool:
     a = model.args
-    if not (model.use_fused_mlp() and getattr(a, "fused_loss", True) and getattr(a, "direct_step", True)):
+    if not (getattr(a, "fused_loss", True) and getattr(a, "direct_step", True) and getattr(a, "fused_mlp", True)):
         return False
-    nets = [model.inr.density_net] + ([] if a.no_pixel_variance else [model.sigma_net]) + ([model.b_net] if a.n_levels_bias else [])
-    return all(len(mlp_mod.linear_layers(n)) - 1 <= 2 for n in nets) and mlp_mod.FUSED_BACKWARD
+    if not (model.axisangle.is_cuda and mlp_mod.FUSED_BACKWARD):
+        return False
+    if half_precision_model(model):
+        # the bf16-operand kernels exist for the wave-specialised layout only: a 16-sample group inside one pixel,
+        # pixel features in whole 16-blocks, first layer of at most 32 inputs unless there is a single hidden layer
+        ks = a.n_features_slice if (not a.no_pixel_variance or a.n_levels_bias) else 0
+        if not (a.n_samples % 16 == 0 and ks % 16 == 0 and all(
+                mlp_mod.supported(n) and (n.shapes[0][1] <= 32 or len(n.shapes) == 2) for n in _nets(model))):
+            return False
+    elif not model.use_fused_mlp():
+        return False
+    return all(mlp_mod.n_hidden_layers(n) <= 2 for n in _nets(model))
 
 
 class DirectStep:
@@ -49,48 +74,17 @@ class DirectStep:
         self.w_T = float(w.get(T_REG, 0))
         self.reg_type = loss_mod.REG_TYPES[a.image_regularization]
         self.delta = float(model.delta)
-        self.d_layers = mlp_mod.linear_layers(model.inr.density_net)
-        self.s_layers = mlp_mod.linear_layers(model.sigma_net) if self.has_lv else None
-        self.d_seg = self._segment("inr.density_net", self.d_layers)
-        self.s_seg = self._segment("sigma_net", self.s_layers) if self.has_lv else None
-        self.b_layers = mlp_mod.linear_layers(model.b_net) if self.has_b else None
-        self.b_seg = self._segment("b_net", self.b_layers) if self.has_b else None
+        # the parameters were re-homed into `flat` before this point: the views taken here stay valid
+        self.d_net = mlp_mod.NetParams(model.inr.density_net)
+        self.s_net = mlp_mod.NetParams(model.sigma_net) if self.has_lv else None
+        self.b_net = mlp_mod.NetParams(model.b_net) if self.has_b else None
         self.side = torch.cuda.Stream(device=dev) if self.opt_T else None
-        # opt-in mixed precision of the MLPs: bf16 matrix operands, fp32 accumulation / master weights (args.mlp_bf16)
-        self.bf16 = bool(getattr(a, "mlp_bf16", False))
+        # mixed precision of the MLPs: bf16 matrix operands, fp32 accumulation / master weights - opt-in for the fp32
+        # model (args.mlp_bf16), always for the half-precision model structure
+        self.bf16 = bool(getattr(a, "mlp_bf16", False)) or half_precision_model(model)
         import torch.distributed as dist
 
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-
-    def _segment(self, prefix, layers):
-        """Flat-gradient segment holding a net's parameters in the kernel's partial-sum order W0,b0,W1,b1,...
-        (None when the flat layout does not keep them contiguous in that order)."""
-        names = []
-        for i, _ in enumerate(layers):
-            names += ["%s.%d.weight" % (prefix, 2 * i), "%s.%d.bias" % (prefix, 2 * i)]
-        offs = self.flat.offsets
-        if any(n not in offs for n in names):
-            return None
-        start = offs[names[0]][0]
-        pos = start
-        for n in names:
-            if offs[n][0] != pos:
-                return None
-            pos += offs[n][1]
-        return self.flat.grad[start:pos]
-
-    def _store_net_grads(self, partial, layers, seg, prefix):
-        if seg is not None and seg.numel() == partial.shape[1]:
-            with torch.cuda.device(partial.device):
-                err = _lib.load().nesvor_sum_rows(_lib.ptr(partial), _lib.ptr(seg), partial.shape[0], partial.shape[1], _lib.stream_ptr())
-            _lib.check(err, "sum_rows")
-            return
-        flat = partial.sum(0)
-        off = 0
-        for i, l in enumerate(layers):
-            for p in (l.weight, l.bias):
-                p.grad.copy_(flat[off : off + p.numel()].view_as(p))
-                off += p.numel()
 
     @torch.no_grad()
     def run(self, xyz, v, slice_idx, noise=None) -> Dict[str, torch.Tensor]:
@@ -129,14 +123,12 @@ class DirectStep:
         _lib.check(err, "step prologue")
         x, u = sampler.forward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb)
         pe = hashgrid_forward(enc.spec, u, enc.params, _lib.LAYOUT_FEATURE_MAJOR)  # (E, N)
-        dW = [l.weight for l in self.d_layers]
-        dB = [l.bias for l in self.d_layers]
+        dW, dB = self.d_net.weights, self.d_net.biases
         z, saved_d = mlp_mod.forward_raw(dW, dB, None, pe, 0, pe.shape[0], S, True, self.bf16)  # (1 + n_features_z, N)
         log_var = log_bias = lb_mean = None
         se = m.slice_embedding.weight[slice_idx] if self.ks else None
         if self.has_b:  # bias field: [slice embedding | the coarsest levels of pe] -> log bias (models.py:341-346)
-            bW = [l.weight for l in self.b_layers]
-            bB = [l.bias for l in self.b_layers]
+            bW, bB = self.b_net.weights, self.b_net.biases
             log_bias, saved_b = mlp_mod.forward_raw(bW, bB, se, pe, 0, self.kb_bias, S, True, self.bf16)  # (1, N)
             lb_mean = log_bias.mean().reshape(1)
             if self.world > 1:  # biasReg = (mean log_bias)^2 is not a mean of per-sample terms: use the GLOBAL mean, so that
@@ -144,8 +136,7 @@ class DirectStep:
                 torch.distributed.all_reduce(lb_mean)
                 lb_mean /= self.world
         if self.has_lv:
-            sW = [l.weight for l in self.s_layers]
-            sB = [l.bias for l in self.s_layers]
+            sW, sB = self.s_net.weights, self.s_net.biases
             log_var, saved_s = mlp_mod.forward_raw(sW, sB, se, z, 1, a.n_features_z, S, True, self.bf16)  # (1, N)
         lvs = m.log_var_slice if self.has_lvs else None
 
@@ -176,16 +167,16 @@ class DirectStep:
         if self.has_lv:
             dxa, partial_s = mlp_mod.backward_raw(sW, sB, se, z, dlv.view(1, N), saved_s, 1, a.n_features_z, S,
                                                   dz[1 : 1 + a.n_features_z], se is not None, self.bf16)
-            self._store_net_grads(partial_s, self.s_layers, self.s_seg, "sigma_net")
+            self.s_net.store_grads(partial_s)
         dpe = torch.empty_like(pe)
         _, partial_d = mlp_mod.backward_raw(dW, dB, None, pe, dz, saved_d, 0, pe.shape[0], S, dpe, False, self.bf16)
-        self._store_net_grads(partial_d, self.d_layers, self.d_seg, "inr.density_net")
+        self.d_net.store_grads(partial_d)
         dxa_b = None
         if self.has_b:
             dpe_b = torch.empty((self.kb_bias, N), dtype=torch.float32, device=dev)
             dxa_b, partial_b = mlp_mod.backward_raw(bW, bB, se, pe, dlb.view(1, N), saved_b, 0, self.kb_bias, S, dpe_b,
                                                     se is not None, self.bf16)
-            self._store_net_grads(partial_b, self.b_layers, self.b_seg, "b_net")
+            self.b_net.store_grads(partial_b)
             dpe[: self.kb_bias] += dpe_b
             if dxa is None:
                 dxa, dxa_b = dxa_b, None

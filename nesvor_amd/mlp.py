@@ -27,6 +27,12 @@ def linear_layers(seq: nn.Sequential):
 
 
 def supported(seq) -> bool:
+    from .tinycudann import Network
+
+    if isinstance(seq, Network):  # the half-precision model structure: bias-free, output rows padded to 16
+        sh = seq.shapes
+        return (seq.activation == "ReLU" and seq.output_activation == "None" and 2 <= len(sh) <= 4 and sh[0][1] <= 64
+                and all(o == 64 for o, _ in sh[:-1]) and seq.n_output_dims <= 16)
     if not isinstance(seq, nn.Sequential):
         return False
     try:
@@ -38,6 +44,81 @@ def supported(seq) -> bool:
     if any(l.out_features != 64 for l in layers[:-1]) or any(l.in_features != 64 for l in layers[1:]):
         return False
     return layers[-1].out_features <= 16 and layers[0].in_features <= 64 and all(l.bias is not None for l in layers)
+
+
+def n_hidden_layers(net) -> int:
+    from .tinycudann import Network
+
+    return (len(net.shapes) if isinstance(net, Network) else len(linear_layers(net))) - 1
+
+
+class NetParams:
+    """One network in the kernels' terms (per-layer weight / bias tensors) for both structures ``build_network``
+    creates (nesvor/nesvor/models.py:28-69):
+
+    * single precision: ``nn.Sequential`` of Linear/ReLU - the layers' own Parameters;
+    * half precision: bias-free ``tinycudann.Network`` with one flat parameter vector - per-layer views of it (of the
+      padded last layer only the first ``n_output_dims`` rows are evaluated; the padding rows never reach an output and
+      keep a zero gradient, as in tinycudann) and one shared all-zero bias vector.
+
+    ``store_grads`` reduces the backward kernel's per-workgroup partial sums (columns W0,b0,W1,b1,...) into the
+    parameters' ``.grad`` - which the fused trainer has re-homed into its flat gradient buffer.
+    """
+
+    def __init__(self, net):
+        from .tinycudann import Network
+
+        self.net = net
+        self.flat_params = isinstance(net, Network)
+        if self.flat_params:
+            p = net.params.data
+            self.weights, self.w_off, off = [], [], 0
+            for li, (o, i) in enumerate(net.shapes):
+                rows = net.n_output_dims if li == len(net.shapes) - 1 else o
+                self.weights.append(p[off : off + rows * i].view(rows, i))
+                self.w_off.append(off)
+                off += o * i
+            zero = torch.zeros(64, dtype=torch.float32, device=p.device)
+            self.biases = [zero[: w.shape[0]] for w in self.weights]
+            self.segment = None
+        else:
+            layers = linear_layers(net)
+            self.weights = [l.weight for l in layers]
+            self.biases = [l.bias for l in layers]
+            # one contiguous gradient segment in the partial sums' column order? (the flat layout of fused.FlatParams)
+            ps = [t for l in layers for t in (l.weight, l.bias)]
+            g0 = ps[0].grad
+            contiguous = g0 is not None and all(
+                q.grad is not None and q.grad.data_ptr() == p_.grad.data_ptr() + 4 * p_.numel() for p_, q in zip(ps, ps[1:]))
+            n = sum(t.numel() for t in ps)
+            self.segment = torch.as_strided(g0, (n,), (1,), g0.storage_offset()) if contiguous else None
+
+    def n_hidden(self):
+        return len(self.weights) - 1
+
+    def _sum_rows(self, src_ptr, dst, rows, cols, ld):
+        with torch.cuda.device(dst.device):
+            err = _lib.load().nesvor_sum_rows(src_ptr, _lib.ptr(dst), rows, cols, ld, _lib.stream_ptr())
+        _lib.check(err, "sum_rows")
+
+    def store_grads(self, partial):
+        rows, ld = partial.shape
+        if self.flat_params:
+            g = self.net.params.grad
+            col = 0
+            for w, off in zip(self.weights, self.w_off):
+                self._sum_rows(partial.data_ptr() + 4 * col, g[off : off + w.numel()], rows, w.numel(), ld)
+                col += w.numel() + w.shape[0]
+            return
+        if self.segment is not None and self.segment.numel() == ld:
+            self._sum_rows(partial.data_ptr(), self.segment, rows, ld, ld)
+            return
+        flat = partial.sum(0)
+        off = 0
+        for w, b in zip(self.weights, self.biases):
+            for p in (w, b):
+                p.grad.copy_(flat[off : off + p.numel()].view_as(p))
+                off += p.numel()
 
 
 def _desc(weights, biases, k_a, k_b, b_row0, S, bf16=False):

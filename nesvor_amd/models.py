@@ -126,6 +126,18 @@ class INR(nn.Module):
             z_fm = fused_mlp_mod.fused_mlp(self.density_net, None, pe_fm, 0, pe_fm.shape[0], 1)
             density = F.softplus(z_fm[0].view(prefix_shape))
             return (density, pe_fm.t(), z_fm.t()) if return_all else density
+        if (not torch.is_grad_enabled() and self.bounding_box.is_cuda and self.encoding.dtype == torch.float16
+                and getattr(self, "fused_mlp", True) and fused_mlp_mod.supported(self.density_net)):
+            # half-precision model structure at inference (sample_volume / sample_slices): the same two kernels with
+            # bf16 matrix operands; outputs stay fp32
+            from .encoding import hashgrid_forward
+
+            enc = self.encoding
+            pe_fm = hashgrid_forward(enc.spec, x.reshape(-1, 3).float().contiguous(), enc.params, _lib.LAYOUT_FEATURE_MAJOR)
+            net = fused_mlp_mod.NetParams(self.density_net)
+            z_fm, _ = fused_mlp_mod.forward_raw(net.weights, net.biases, None, pe_fm, 0, pe_fm.shape[0], 1, False, bf16=True)
+            density = F.softplus(z_fm[0].view(prefix_shape))
+            return (density, pe_fm.t(), z_fm.t()) if return_all else density
         pe = self.encoding(x.reshape(-1, x.shape[-1]))
         z = self.density_net(pe)
         density = F.softplus(z[..., 0].view(prefix_shape))

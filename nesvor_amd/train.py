@@ -115,7 +115,11 @@ def build_optimizer(model: NeSVoR, args: Namespace):
 def train(slices: List[Slice], args: Namespace) -> Tuple[INR, List[Slice], Volume]:
     dataset = Dataset(slices, args)
     model = NeSVoR(dataset.transformation, dataset.resolution, dataset.mean, dataset.bounding_box, args)
-    use_fused = getattr(args, "fused", True) and args.dtype == torch.float32
+    from . import direct
+
+    # fused trainer: the single-precision model, and the half-precision model structure when the autograd-free step
+    # covers it (bf16 matrix operands, fp32 accumulation: no GradScaler); otherwise the module path below
+    use_fused = getattr(args, "fused", True) and (args.dtype == torch.float32 or direct.supported(model))
     # data parallel (one process per GPU): args.batch_size is the GLOBAL batch, every rank draws the same
     # permutation (seed the global RNG identically before calling train) and takes its slice of each batch
     import torch.distributed as dist

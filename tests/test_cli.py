@@ -39,7 +39,8 @@ def test_merge_args_new_overrides_old():
 
 
 @pytest.mark.gpu
-def test_cli_reconstruct_sample_roundtrip(tmp_path, device):
+@pytest.mark.parametrize("precision", [["--single-precision"], []])  # [] = the reference's default half-precision structure
+def test_cli_reconstruct_sample_roundtrip(tmp_path, device, precision):
     from nesvor_amd import cli
     from nesvor_amd.image import Volume
     from nesvor_amd.image_io import load_slices, load_volume
@@ -60,7 +61,7 @@ def test_cli_reconstruct_sample_roundtrip(tmp_path, device):
         Volume(img, img > 0, RigidTransform(ax), res_s, res_s, gap).save(p, masked=False)
         paths.append(p)
     out_vol, out_model = str(tmp_path / "recon.nii.gz"), str(tmp_path / "model.pt")
-    small = ["--single-precision", "--n-iter", "80", "--batch-size", "512", "--n-samples", "32", "--log2-hashmap-size", "12",
+    small = [*precision, "--n-iter", "80", "--batch-size", "512", "--n-samples", "32", "--log2-hashmap-size", "12",
              "--finest-resolution", "2.0", "--output-resolution", "2.0", "--seed", "0", "--verbose", "0"]
     cli.main(["reconstruct", "--input-stacks", *paths, "--thicknesses", "3", "3", "3", "--output-volume", out_vol,
               "--output-model", out_model, "--output-slices", str(tmp_path / "out_slices"),

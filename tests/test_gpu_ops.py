@@ -715,8 +715,11 @@ def test_step_bookkeeping_kernels(device):
 
     part = torch.randn(256, 6288, device=device)
     out = torch.empty(6288, device=device)
-    assert lib.nesvor_sum_rows(_lib.ptr(part), _lib.ptr(out), 256, 6288, st) == 0
+    assert lib.nesvor_sum_rows(_lib.ptr(part), _lib.ptr(out), 256, 6288, 6288, st) == 0
     torch.testing.assert_close(out, part.sum(0), rtol=1e-4, atol=1e-4)
+    out2 = torch.empty(1000, device=device)  # a column range of the wider matrix
+    assert lib.nesvor_sum_rows(part[:, 300:].data_ptr(), _lib.ptr(out2), 256, 1000, 6288, st) == 0
+    torch.testing.assert_close(out2, part[:, 300:1300].sum(0), rtol=1e-4, atol=1e-4)
 
 
 def test_fused_adamw_vs_torch(device):
