@@ -243,6 +243,7 @@ struct BwdPlan {
   uint32_t cap[NESVOR_MAX_LEVELS];             // queue capacity (records) of each bucket of the level
   uint32_t slice[NESVOR_MAX_LEVELS];           // records per owner workgroup of the level
   uint64_t rec_off[NESVOR_MAX_LEVELS];         // first record of the level's queues
+  uint32_t box_slots;                          // 0: the merge table is always hashed (A/B switch NESVOR_HASHGRID_BOX=0)
 };
 
 __device__ __forceinline__ uint32_t spread3(uint32_t x) {  // 8 bits -> every third bit
@@ -278,7 +279,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) {
 }
 
 template <int F, int LAYOUT, bool INPUT_GRAD, bool MERGE>
-__global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_t g, const BwdPlan plan,
+__global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_bwd_aggregate(const nesvor_grid_t g, const BwdPlan plan,
                                                               const float* __restrict__ u,
                                                               const float* __restrict__ table,
                                                               const float* __restrict__ dpe,
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
                                       // previous level's distinct vertices (they grow ~1.3-1.5x per level), so that
                                       // the drain only walks what can be occupied
   __shared__ uint32_t merge_off;      // set once merging stops paying: finer levels skip the table
+  __shared__ float ubox[4][6];        // per wave min / max of the samples' coordinates
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t base = (int64_t)blockIdx.x * 256;
   const int E = g.n_levels * F;
@@ -346,7 +348,31 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
   const int64_t ii = valid ? i : N - 1;
   const float ux = u[3 * ii], uy = u[3 * ii + 1], uz = u[3 * ii + 2];
   float gux = 0.f, guy = 0.f, guz = 0.f;
+  if constexpr (MERGE) {
+    // bounding box of the workgroup's samples: locate() is monotone in u, so the lattice box of every level follows
+    // from these six numbers
+    float lo[3] = {ux, uy, uz}, hi[3] = {ux, uy, uz};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = -wave_max(-lo[d]);
+      hi[d] = wave_max(hi[d]);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { ubox[tid >> 6][d] = lo[d]; ubox[tid >> 6][3 + d] = hi[d]; }
+    }
+  }
   __syncthreads();
+  float ulo[3] = {0.f, 0.f, 0.f}, uhi[3] = {0.f, 0.f, 0.f};
+  if constexpr (MERGE) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      ulo[d] = fminf(fminf(ubox[0][d], ubox[1][d]), fminf(ubox[2][d], ubox[3][d]));
+      uhi[d] = fmaxf(fmaxf(ubox[0][3 + d], ubox[1][3 + d]), fmaxf(ubox[2][3 + d], ubox[3][3 + d]));
+      ulo[d] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ulo[d])));
+      uhi[d] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, uhi[d])));
+    }
+  }
 
   auto load_dy = [&](int level, float (&dy)[F]) {
     if constexpr (LAYOUT == NESVOR_LAYOUT_ROW_MAJOR) {
@@ -433,14 +459,79 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
   if (g.n_levels > 1) load_dy(1, dy_b);
   prepare(0, dy_a, idx, val, tail);
   if constexpr (MERGE) __syncthreads();  // wmax of level 0 must be visible to the other waves
-  for (int level = 0; level < g.n_levels; ++level) {
-    // records this thread will write at this level: either its own 8 run-tail corners, or (merge mode) the
-    // table slots it drains
-    uint32_t rkey[8], rank[8];
-    float rval[8][F];
-    bool rhas[8];
-    const bool merge = MERGE && merge_off == 0u;  // workgroup-uniform (written before the previous barrier)
-    if (merge) {
+  // Merging is on for a prefix of the levels (merge_off is set once, workgroup-uniformly, before a barrier): two
+  // loops in sequence rather than a branch inside one loop, so that the compiler cannot hoist the common second
+  // half of the two paths above the branch (which made everything of the next level live during the insertion).
+  int level = 0;
+  bool merge = MERGE;
+  bool box = false;
+  uint32_t bvol = 0, bx0 = 0, by0 = 0, bz0 = 0, bnx = 1, bnxy = 1;
+  {
+    // Second half of a level, specialised on the number NR of records a thread can hold (table slots per thread in
+    // merge mode, the 8 corners otherwise) so that the merge path does not carry 8 record registers sets through the
+    // next level's prepare(): reserve queue space, prepare the next level, write the records.
+    auto finish_level = [&](auto& rkey, auto& rank, auto& rval, uint32_t rmask) {
+      constexpr int NR = sizeof(rkey) / sizeof(rkey[0]);
+      __syncthreads();
+      // reserve queue space: one returning (memory-side, ~2 us) atomic per non-empty chunk ...
+      const uint32_t nb = plan.n_chunks[level];
+      uint32_t my_base = 0;
+      if (tid < nb) {
+        const uint32_t cnt = bcount[tid];
+        if (cnt) my_base = atomicAdd(&tails[plan.bucket_base[level] + tid], cnt);
+        bcount[tid] = 0;
+      }
+      if (merge && tid == 255) {
+        // merging stops paying once fewer than a quarter of the records collapse, and (hashed table) must stop
+        // before the table gets crowded
+        const uint32_t drained = merge_stat[1];
+        if (drained * 4u > merge_stat[0] * 3u || (!box && drained * 10u > (uint32_t)kSlots * 7u)) merge_off = 1u;
+        uint32_t lg = 8;
+        while ((1u << lg) < 4u * drained && (1u << lg) < (uint32_t)kSlots) ++lg;
+        slots_log2 = lg;
+        merge_stat[0] = 0; merge_stat[1] = 0;
+      }
+      // ... and hide its latency behind the next level's register-only work
+      if (level + 1 < g.n_levels) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) dy_a[f] = dy_b[f];
+        if (level + 2 < g.n_levels) load_dy(level + 2, dy_b);
+        prepare(level + 1, dy_a, idx_n, val_n, tail_n);
+      }
+      if (tid < nb) bbase[tid] = my_base;
+      __syncthreads();
+      const uint32_t cap = plan.cap[level];
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        if (!(rmask & (1u << k))) continue;
+        const uint32_t b = rkey[k] >> plan.chunk_shift;
+        const uint32_t pos = bbase[b] + rank[k];
+        if (pos < cap) {
+          uint32_t* r = records + (plan.rec_off[level] + (uint64_t)b * cap + pos) * (1 + F);
+          r[0] = rkey[k];
+#pragma unroll
+          for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(rval[k][f]);
+        } else {  // queue full: exact fallback
+#pragma unroll
+          for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + rkey[k]) * F + f, rval[k][f]);
+        }
+      }
+      __syncthreads();  // bbase is rewritten by the next level
+    };
+    auto advance = [&]() {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        idx[k] = idx_n[k];
+#pragma unroll
+        for (int f = 0; f < F; ++f) val[k][f] = val_n[k][f];
+      }
+      tail = tail_n;
+    };
+    if constexpr (MERGE) {
+     for (; level < g.n_levels && merge_off == 0u; ++level) {
+      constexpr int NR = kSlots / 256;
+      uint32_t rkey[NR], rank[NR], rmask = 0;
+      float rval[NR][F];
       // (a) run tails go through the workgroup's table: duplicates of a vertex reached from neighbouring
       //     cells, from other runs and from other waves collapse into one record
       // fixed-point scale of the level: the adds of one slot sum to at most 256 max|dy| (corner weights of a
@@ -450,7 +541,30 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
       sexp = sexp > 100 ? 100 : sexp;
       const float fscale = __uint_as_float((uint32_t)(sexp + 127) << 23), finv = __uint_as_float((uint32_t)(127 - sexp) << 23);
       const uint32_t slog = slots_log2, smask = (1u << slog) - 1u;
-      if (tail) {
+      // Box mode: when the lattice box of the workgroup's vertices at this level has at most kSlots points, a slot is
+      // the vertex's position inside the box - no keys, no compare-and-swap claims, no probing (a third of the LDS
+      // atomics of the hashed table); the drain recomputes the entry index from the slot number.
+      const LevelParams pl = load_level(g, level);
+      const CellPos blo = locate(pl, ulo[0], ulo[1], ulo[2]), bhi = locate(pl, uhi[0], uhi[1], uhi[2]);
+      auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };  // wave-uniform values
+      bx0 = sgpr(blo.gx); by0 = sgpr(blo.gy); bz0 = sgpr(blo.gz);
+      const uint32_t ex = sgpr(bhi.gx) - bx0, ey = sgpr(bhi.gy) - by0, ez = sgpr(bhi.gz) - bz0;  // cells spanned - 1 (wraps if out of range)
+      const uint32_t bdx = ex + 2u, bdy = ey + 2u, bdz = ez + 2u;
+      box = plan.box_slots != 0u && ex < (uint32_t)kSlots && ey < (uint32_t)kSlots && ez < (uint32_t)kSlots &&
+            (uint64_t)bdx * bdy * bdz <= (uint64_t)kSlots;
+      bvol = box ? bdx * bdy * bdz : 0u;
+      bnx = bdx; bnxy = bdx * bdy;
+      if (tail && box) {
+        const CellPos c = locate(pl, ux, uy, uz);
+        const uint32_t s0 = ((c.gz - bz0) * bdy + (c.gy - by0)) * bdx + (c.gx - bx0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          // (the clamp only matters for NaN coordinates, which fall outside every box: keeps the adds inside the table)
+          const uint32_t slot = min(s0 + (k & 1) + ((k >> 1) & 1) * bnx + (k >> 2) * bnxy, (uint32_t)kSlots - 1u);
+#pragma unroll
+          for (int f = 0; f < F; ++f) atomicAdd(&tvals[slot * F + f], to_fixed(val[k][f] * fscale));
+        }
+      } else if (tail) {
         uint32_t h[8];
         uint32_t pending = 0;
         // claim / find the 8 slots: first probes issued together, collisions walked one by one
@@ -491,94 +605,58 @@ __global__ __launch_bounds__(256) void hashgrid_bwd_aggregate(const nesvor_grid_
       __syncthreads();
       // (b) drain: slot -> register record, slot cleared for the next level
       uint32_t mine = 0;
-      const int spt = 1 << (slog - 8);  // slots per thread at this level (1, 2 or 4)
+      const uint32_t n_slots = box ? bvol : (1u << slog);  // slots in use at this level: thread t drains t, t + 256, ...
+      const float inv_nxy = 1.f / (float)bnxy, inv_nx = 1.f / (float)bnx;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        rhas[j] = false; rkey[j] = 0; rank[j] = 0;
+      for (int j = 0; j < NR; ++j) {
+        rkey[j] = 0; rank[j] = 0;
 #pragma unroll
         for (int f = 0; f < F; ++f) rval[j][f] = 0.f;
-        if (j < kSlots / 256 && j < spt) {
-          const int slot = tid * spt + j;
-          const uint32_t key = tkeys[slot];
-          if (key != kEmpty) {
-            rhas[j] = true; rkey[j] = key;
+        const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
+        if (slot >= n_slots) continue;
+        uint32_t key;
+        bool occupied;
+        if (box) {
+          // slot -> lattice point (slot < 1024: the float quotients are exact after truncation); a vertex whose
+          // contributions sum to exactly zero needs no record
+          const uint32_t z = (uint32_t)(((float)slot + 0.5f) * inv_nxy);
+          const uint32_t r = slot - z * bnxy;
+          const uint32_t y = (uint32_t)(((float)r + 0.5f) * inv_nx);
+          key = corner_index(pl, bx0 + (r - y * bnx), by0 + y, bz0 + z);
+          occupied = false;
 #pragma unroll
-            for (int f = 0; f < F; ++f) {
-              rval[j][f] = from_fixed(tvals[slot * F + f]) * finv;
-              tvals[slot * F + f] = 0ull;
-            }
-            tkeys[slot] = kEmpty;
-            rank[j] = atomicAdd(&bcount[key >> plan.chunk_shift], 1u);
-            ++mine;
+          for (int f = 0; f < F; ++f) occupied = occupied || tvals[slot * F + f] != 0ull;
+        } else {
+          key = tkeys[slot];
+          occupied = key != kEmpty;
+          if (occupied) tkeys[slot] = kEmpty;
+        }
+        if (occupied) {
+          rmask |= 1u << j; rkey[j] = key;
+#pragma unroll
+          for (int f = 0; f < F; ++f) {
+            rval[j][f] = from_fixed(tvals[slot * F + f]) * finv;
+            tvals[slot * F + f] = 0ull;
           }
+          rank[j] = atomicAdd(&bcount[key >> plan.chunk_shift], 1u);
+          ++mine;
         }
       }
       const uint32_t wave_mine = (uint32_t)wave_sum_u32(mine);
       if (lane == 0 && wave_mine) atomicAdd(&merge_stat[1], wave_mine);
-    } else {
+      finish_level(rkey, rank, rval, rmask);
+      advance();
+     }
+    }
+    merge = false;
+    for (; level < g.n_levels; ++level) {
       // rank of every record inside its chunk's span (LDS integer atomics: ~6 cycles / wave-instruction)
+      uint32_t rank[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        rhas[k] = tail; rkey[k] = idx[k];
-#pragma unroll
-        for (int f = 0; f < F; ++f) rval[k][f] = val[k][f];
-        rank[k] = tail ? atomicAdd(&bcount[idx[k] >> plan.chunk_shift], 1u) : 0u;
-      }
+      for (int k = 0; k < 8; ++k) rank[k] = tail ? atomicAdd(&bcount[idx[k] >> plan.chunk_shift], 1u) : 0u;
+      finish_level(idx, rank, val, tail ? 0xFFu : 0u);
+      advance();
     }
-    __syncthreads();
-    // reserve queue space: one returning (memory-side, ~2 us) atomic per non-empty chunk ...
-    const uint32_t nb = plan.n_chunks[level];
-    uint32_t my_base = 0;
-    if (tid < nb) {
-      const uint32_t cnt = bcount[tid];
-      if (cnt) my_base = atomicAdd(&tails[plan.bucket_base[level] + tid], cnt);
-      bcount[tid] = 0;
-    }
-    if (merge && tid == 255) {
-      // merging stops paying once fewer than a quarter of the records collapse, and must stop before the
-      // table gets crowded
-      const uint32_t drained = merge_stat[1];
-      if (drained * 4u > merge_stat[0] * 3u || drained * 10u > (uint32_t)kSlots * 7u) merge_off = 1u;
-      uint32_t lg = 8;
-      while ((1u << lg) < 4u * drained && (1u << lg) < (uint32_t)kSlots) ++lg;
-      slots_log2 = lg;
-      merge_stat[0] = 0; merge_stat[1] = 0;
-    }
-    // ... and hide its latency behind the next level's register-only work
-    if (level + 1 < g.n_levels) {
-#pragma unroll
-      for (int f = 0; f < F; ++f) dy_a[f] = dy_b[f];
-      if (level + 2 < g.n_levels) load_dy(level + 2, dy_b);
-      prepare(level + 1, dy_a, idx_n, val_n, tail_n);
-    }
-    if (tid < nb) bbase[tid] = my_base;
-    __syncthreads();
-    {
-      const uint32_t cap = plan.cap[level];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (!rhas[k]) continue;
-        const uint32_t b = rkey[k] >> plan.chunk_shift;
-        const uint32_t pos = bbase[b] + rank[k];
-        if (pos < cap) {
-          uint32_t* r = records + (plan.rec_off[level] + (uint64_t)b * cap + pos) * (1 + F);
-          r[0] = rkey[k];
-#pragma unroll
-          for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(rval[k][f]);
-        } else {  // queue full: exact fallback
-#pragma unroll
-          for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + rkey[k]) * F + f, rval[k][f]);
-        }
-      }
-    }
-    __syncthreads();  // bbase is rewritten by the next level
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      idx[k] = idx_n[k];
-#pragma unroll
-      for (int f = 0; f < F; ++f) val[k][f] = val_n[k][f];
-    }
-    tail = tail_n;
   }
   if constexpr (INPUT_GRAD) {
     if (valid) { grad_u[3 * i] = gux; grad_u[3 * i + 1] = guy; grad_u[3 * i + 2] = guz; }
@@ -740,6 +818,8 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
     plan->n_chunks[l] = 0; plan->bucket_base[l] = nb; plan->cap[l] = 0; plan->slice[l] = kOwnerSlice; plan->rec_off[l] = off;
   }
   plan->n_buckets = nb;
+  static const uint32_t box = []() { const char* e = getenv("NESVOR_HASHGRID_BOX"); return (e == nullptr || atoi(e) != 0) ? 1u : 0u; }();
+  plan->box_slots = box;
   *n_records = off;
   return true;
 }
