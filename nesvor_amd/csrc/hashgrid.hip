@@ -232,6 +232,8 @@ __global__ __launch_bounds__(256) void hashgrid_bwd(const nesvor_grid_t g, const
 
 // ------------------------------------------- backward, owner-computes version
 constexpr int kMaxChunks = 256;               // table chunks (queues) per level
+constexpr int kSubQueues = 8;                 // every queue is split by the XCC the producing workgroup runs on (see below); plan.n_sub <= 8 are used
+constexpr uint32_t kTailStride = 4096;        // counters per sub-queue set (>= kMaxChunks * NESVOR_MAX_LEVELS)
 constexpr int kOwnerLdsFloats = 8192;         // 32 KiB accumulator per owner workgroup: 4096-entry chunks (measured: 16 / 64 / 128 KiB are slower -
                                               // fewer, hotter queue counters on one side, more reservations per workgroup on the other)
 
@@ -240,9 +242,10 @@ struct BwdPlan {
   uint32_t n_buckets;
   uint32_t n_chunks[NESVOR_MAX_LEVELS];
   uint32_t bucket_base[NESVOR_MAX_LEVELS];     // first global bucket id of the level
-  uint32_t cap[NESVOR_MAX_LEVELS];             // queue capacity (records) of each bucket of the level
+  uint32_t cap[NESVOR_MAX_LEVELS];             // capacity (records) of each of the kSubQueues sub-queues of a bucket of the level
   uint32_t slice[NESVOR_MAX_LEVELS];           // records per owner workgroup of the level
   uint64_t rec_off[NESVOR_MAX_LEVELS];         // first record of the level's queues
+  uint32_t n_sub;                              // sub-queues per bucket = XCCs of the device partition (1, 2, 4 or 8)
   uint32_t box_slots;                          // 0: the merge table is always hashed (A/B switch NESVOR_HASHGRID_BOX=0)
 };
 
@@ -307,6 +310,11 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t base = (int64_t)blockIdx.x * 256;
   const int E = g.n_levels * F;
+  // Queue tails are hot counters (every workgroup reserves space in ~100 of them per level).  The L2s of the eight
+  // XCCs are kept coherent by hardware, so a counter shared by all workgroups migrates between L2s on every
+  // reservation; a counter set per XCC stays in its own L2 (measured, tools/atomic_scope_probe.hip: 2.1x the
+  // throughput).  HW_REG_XCC_ID names the XCC this workgroup really runs on - no assumption about the dispatch order.
+  const uint32_t sub = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & (plan.n_sub - 1u);
   if (tid < kMaxChunks) bcount[tid] = 0;
   for (int t = tid; t < kSlots; t += 256) tkeys[t] = kEmpty;
   for (int t = tid; t < kSlots * F; t += 256) tvals[t] = 0ull;
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       uint32_t my_base = 0;
       if (tid < nb) {
         const uint32_t cnt = bcount[tid];
-        if (cnt) my_base = atomicAdd(&tails[plan.bucket_base[level] + tid], cnt);
+        if (cnt) my_base = atomicAdd(&tails[sub * kTailStride + plan.bucket_base[level] + tid], cnt);
         bcount[tid] = 0;
       }
       if (merge && tid == 255) {
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         const uint32_t b = rkey[k] >> plan.chunk_shift;
         const uint32_t pos = bbase[b] + rank[k];
         if (pos < cap) {
-          uint32_t* r = records + (plan.rec_off[level] + (uint64_t)b * cap + pos) * (1 + F);
+          uint32_t* r = records + (plan.rec_off[level] + ((uint64_t)b * plan.n_sub + sub) * cap + pos) * (1 + F);
           r[0] = rkey[k];
 #pragma unroll
           for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(rval[k][f]);
@@ -680,15 +688,30 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_owner(const nesvor_grid_t g
   int level = 0;
   uint32_t spl = 0;
   for (;; ++level) {
-    spl = (plan.cap[level] + plan.slice[level] - 1) / plan.slice[level];
+    spl = (plan.cap[level] * plan.n_sub + plan.slice[level] - 1) / plan.slice[level];
     const uint32_t cnt = plan.n_chunks[level] * spl;
     if (wg < cnt || level + 1 >= g.n_levels) break;
     wg -= cnt;
   }
   const uint32_t chunk = wg / spl, slice = wg % spl;
   const uint32_t gb = plan.bucket_base[level] + chunk;
-  uint32_t n = tails[gb];
-  if (n > plan.cap[level]) n = plan.cap[level];
+  // the bucket's records = the concatenation of its sub-queues; record r of that virtual queue sits at
+  // r + sum over the sub-queues that end at or before r of their unused tail
+  uint32_t n = 0;
+  uint32_t pre[kSubQueues], gap[kSubQueues];  // pre[x]: first virtual index of sub-queue x; gap[x]: hole before it
+#pragma unroll
+  for (int x = 0; x < kSubQueues; ++x) {
+    const uint32_t nx = (uint32_t)x < plan.n_sub ? min(tails[x * kTailStride + gb], plan.cap[level]) : 0u;
+    pre[x] = n;
+    gap[x] = x ? plan.cap[level] - (n - pre[x - 1]) : 0u;
+    n += nx;
+  }
+  auto slot_of = [&](uint32_t r) {
+    uint32_t o = r;
+#pragma unroll
+    for (int x = 1; x < kSubQueues; ++x) o += r >= pre[x] ? gap[x] : 0u;
+    return o;
+  };
   const uint32_t r0 = slice * plan.slice[level];
   if (r0 >= n) return;
   const uint32_t r1 = min(n, r0 + plan.slice[level]);
@@ -696,7 +719,7 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_owner(const nesvor_grid_t g
   for (int t = tid; t < kOwnerLdsFloats; t += kOwnerThreads) acc[t] = 0.f;
   __syncthreads();
   const uint32_t mask = (1u << plan.chunk_shift) - 1u;
-  const uint32_t* rec = records + (plan.rec_off[level] + (uint64_t)chunk * plan.cap[level]) * (1 + F);
+  const uint32_t* rec = records + (plan.rec_off[level] + (uint64_t)chunk * plan.n_sub * plan.cap[level]) * (1 + F);
   auto add_record = [&](uint32_t key, const float (&v)[F]) {
     const uint32_t local = key & mask;
     if constexpr (F == 2) {  // one 64-bit compare-and-swap adds both features
@@ -727,7 +750,7 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_owner(const nesvor_grid_t g
       float v[kUnroll][F];
 #pragma unroll
       for (int j = 0; j < kUnroll; ++j) {
-        const uint32_t* q = rec + (size_t)(r + j * kOwnerThreads) * (1 + F);
+        const uint32_t* q = rec + (size_t)slot_of(r + j * kOwnerThreads) * (1 + F);
         key[j] = q[0];
 #pragma unroll
         for (int f = 0; f < F; ++f) v[j][f] = __uint_as_float(q[1 + f]);
@@ -736,7 +759,7 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_owner(const nesvor_grid_t g
       for (int j = 0; j < kUnroll; ++j) add_record(key[j], v[j]);
     }
     for (; r < r1; r += kOwnerThreads) {
-      const uint32_t* q = rec + (size_t)r * (1 + F);
+      const uint32_t* q = rec + (size_t)slot_of(r) * (1 + F);
       float v[F];
 #pragma unroll
       for (int f = 0; f < F; ++f) v[f] = __uint_as_float(q[1 + f]);
@@ -751,7 +774,7 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_owner(const nesvor_grid_t g
     float v[kUnroll][F];
 #pragma unroll
     for (int j = 0; j < kUnroll; ++j) {
-      const uint32_t* q = rec + (size_t)(r + j) * (1 + F);
+      const uint32_t* q = rec + (size_t)slot_of(r + j) * (1 + F);
       key[j] = q[0];
 #pragma unroll
       for (int f = 0; f < F; ++f) v[j][f] = __uint_as_float(q[1 + f]);
@@ -760,7 +783,7 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_owner(const nesvor_grid_t g
     for (int j = 0; j < kUnroll; ++j) add_record(key[j], v[j]);
   }
   for (; r < rend; ++r) {
-    const uint32_t* q = rec + (size_t)r * (1 + F);
+    const uint32_t* q = rec + (size_t)slot_of(r) * (1 + F);
     float v[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) v[f] = __uint_as_float(q[1 + f]);
@@ -782,7 +805,7 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_owner(const nesvor_grid_t g
 
 inline uint32_t owner_grid(const nesvor_grid_t* g, const BwdPlan& plan) {
   uint32_t n = 0;
-  for (int l = 0; l < g->n_levels; ++l) n += plan.n_chunks[l] * ((plan.cap[l] + plan.slice[l] - 1) / plan.slice[l]);
+  for (int l = 0; l < g->n_levels; ++l) n += plan.n_chunks[l] * ((plan.cap[l] * plan.n_sub + plan.slice[l] - 1) / plan.slice[l]);
   return n;
 }
 
@@ -792,6 +815,16 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
   uint32_t shift = 0;
   while ((1u << (shift + 1)) * (uint32_t)F <= (uint32_t)kOwnerLdsFloats) ++shift;
   plan->chunk_shift = shift;
+  // XCCs of the current device (partition): 32 CUs each on gfx950
+  static const uint32_t n_xcc = []() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 8u;
+    uint32_t n = 1;
+    while (n < (uint32_t)kSubQueues && n * 2u * 32u <= (uint32_t)cus) n *= 2u;
+    return n;
+  }();
+  const uint32_t n_sub = n_xcc;
+  plan->n_sub = n_sub;
   uint32_t nb = 0;
   uint64_t off = 0;
   for (int l = 0; l < g->n_levels; ++l) {
@@ -800,9 +833,12 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
     plan->n_chunks[l] = nc;
     plan->bucket_base[l] = nb;
     nb += nc;
-    const uint64_t per = (uint64_t)(8 * N) / nc;
-    uint64_t cap = per + per / 32 + 4096;
-    if (cap > 0x7FFFFFFFull) return false;
+    // worst case 8N records per level; a chunk's share is split over kSubQueues producer groups (the XCCs, which
+    // the dispatcher feeds round-robin): 1/n_sub each plus slack for the imbalance.  Overflow is handled exactly
+    // (atomic fallback in the aggregation pass), so the capacity only has to make it rare.
+    const uint64_t per = (uint64_t)(8 * N) / nc / n_sub;
+    uint64_t cap = per + per / 8 + 1024;
+    if (cap * n_sub > 0x7FFFFFFFull) return false;
     plan->cap[l] = (uint32_t)cap;
     // small (coarse, dense) levels collect very many records on few entries: split their queue over many
     // workgroups (the closing atomics are then only entries x slices); big chunks keep one sole writer
@@ -812,7 +848,7 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
     if (sl > kOwnerSlice) sl = kOwnerSlice;
     plan->slice[l] = (uint32_t)sl;
     plan->rec_off[l] = off;
-    off += cap * nc;
+    off += cap * n_sub * nc;
   }
   for (int l = g->n_levels; l < NESVOR_MAX_LEVELS; ++l) {
     plan->n_chunks[l] = 0; plan->bucket_base[l] = nb; plan->cap[l] = 0; plan->slice[l] = kOwnerSlice; plan->rec_off[l] = off;
@@ -824,7 +860,7 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
   return true;
 }
 
-constexpr uint64_t kTailBytes = 16384;  // tails region at the start of the workspace
+constexpr uint64_t kTailBytes = (uint64_t)kSubQueues * kTailStride * sizeof(uint32_t);  // tails region at the start of the workspace
 
 template <int F, int LAYOUT>
 int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table, const float* dpe, float* gt,
@@ -922,7 +958,7 @@ extern "C" int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t*
   uint64_t n_rec;
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return -1;
   if (!make_plan(grid, N, &plan, &n_rec)) return -1;
-  if (plan.n_buckets * sizeof(uint32_t) > kTailBytes) return -1;
+  if (plan.n_buckets > kTailStride) return -1;
   return (int64_t)(kTailBytes + n_rec * (1 + grid->n_features) * sizeof(uint32_t));
 }
 

@@ -29,7 +29,7 @@ def timeit(fn, n=20):
 for name, u in (("P", uP), ("U", uU)):
     run(u, 1); torch.cuda.synchronize()
     nb = 0
-    tails = ws[:16384].view(torch.int32).cpu()
+    tails = ws[:8 * 4096 * 4].view(torch.int32).cpu()  # kSubQueues x kTailStride counters
     tot = int(tails.sum())
     tn = timeit(lambda: run(u, 1, False))
     print(f"{name}: aggregate without input grad {tn:.3f} ms")

@@ -16,7 +16,7 @@ ws = _workspace(spec, N, dev)
 lib = _lib.load()
 err = lib.nesvor_hashgrid_backward(ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(dy), _lib.ptr(gt), None, N, 1, _lib.ptr(ws), 1, _lib.stream_ptr())
 torch.cuda.synchronize()
-tails = ws[:16384].view(torch.int32).cpu()
+tails = ws[:8 * 4096 * 4].view(torch.int32).cpu()
 b = 0
 tot = 0
 for li, lv in enumerate(spec.levels):
