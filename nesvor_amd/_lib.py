@@ -11,7 +11,8 @@ from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_int64, c_uint3
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnesvor_hip.so")
+# NESVOR_HIP_LIB: load another build of the same ABI (tools/ablate_hashgrid.py times variants of one kernel this way)
+LIB_PATH = os.environ.get("NESVOR_HIP_LIB") or os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
 ABI_VERSION = 16
 

@@ -39,6 +39,13 @@
 #include "common.h"
 #include "../../include/nesvor_hip.h"
 
+// Timing ablations (tools/ablate_hashgrid.py): -DNESVOR_ABLATE=<bits> compiles pieces of the aggregation pass out.
+// Results are wrong with any bit set; the default build has none.
+#ifndef NESVOR_ABLATE
+#define NESVOR_ABLATE 0
+#endif
+#define NESVOR_ABL(bit) ((NESVOR_ABLATE & (bit)) != 0)
+
 namespace {
 
 constexpr uint32_t kPrimeY = 2654435761u;
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
                                                               float* __restrict__ grad_u, uint32_t* __restrict__ tails,
                                                               uint32_t* __restrict__ records, int64_t N) {
   __shared__ uint32_t bcount[kMaxChunks];
-  __shared__ uint32_t bbase[kMaxChunks];
+  __shared__ uint32_t bbase[2][kMaxChunks];  // double-buffered by level parity: no barrier between a level's record writes and the next level
   __shared__ uint32_t sortbuf[256];
   // workgroup-wide merge table (open addressing, keyed by the level-local entry index)
   constexpr int kSlots = F <= 2 ? 1024 : (F == 4 ? 512 : 256);
@@ -332,6 +339,8 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       code = spread3(c.gx) | (spread3(c.gy) << 1) | (spread3(c.gz) << 2);
     }
     sv = (code << 8) | (uint32_t)tid;
+#pragma unroll 1
+    for (int rep = 0; rep < (NESVOR_ABL(1) ? 2 : 1); ++rep)
 #pragma unroll 1
     for (int k = 2; k <= 256; k <<= 1) {
 #pragma unroll 1
@@ -452,10 +461,12 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       }                                                                                                    \
       flag |= __builtin_amdgcn_update_dpp(0, flag, CTRL, 0xf, 0xf, true);                                  \
     }
+    if constexpr (!NESVOR_ABL(2)) {
     NESVOR_SCAN_STEP(0x111)  // row_shr:1
     NESVOR_SCAN_STEP(0x112)  // row_shr:2
     NESVOR_SCAN_STEP(0x114)  // row_shr:4
     NESVOR_SCAN_STEP(0x118)  // row_shr:8
+    }
 #undef NESVOR_SCAN_STEP
   };
 
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       uint32_t my_base = 0;
       if (tid < nb) {
         const uint32_t cnt = bcount[tid];
-        if (cnt) my_base = atomicAdd(&tails[sub * kTailStride + plan.bucket_base[level] + tid], cnt);
+        if (cnt && !NESVOR_ABL(16)) my_base = atomicAdd(&tails[sub * kTailStride + plan.bucket_base[level] + tid], cnt);
         bcount[tid] = 0;
       }
       if (merge && tid == 255) {
@@ -506,14 +517,14 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         if (level + 2 < g.n_levels) load_dy(level + 2, dy_b);
         prepare(level + 1, dy_a, idx_n, val_n, tail_n);
       }
-      if (tid < nb) bbase[tid] = my_base;
+      if (tid < nb) bbase[level & 1][tid] = my_base;
       __syncthreads();
       const uint32_t cap = plan.cap[level];
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
-        if (!(rmask & (1u << k))) continue;
+        if (NESVOR_ABL(8) || !(rmask & (1u << k))) continue;
         const uint32_t b = rkey[k] >> plan.chunk_shift;
-        const uint32_t pos = bbase[b] + rank[k];
+        const uint32_t pos = bbase[level & 1][b] + rank[k];
         if (pos < cap) {
           uint32_t* r = records + (plan.rec_off[level] + ((uint64_t)b * plan.n_sub + sub) * cap + pos) * (1 + F);
           r[0] = rkey[k];
@@ -524,7 +535,6 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
           for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + rkey[k]) * F + f, rval[k][f]);
         }
       }
-      __syncthreads();  // bbase is rewritten by the next level
     };
     auto advance = [&]() {
 #pragma unroll
@@ -562,7 +572,8 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
             (uint64_t)bdx * bdy * bdz <= (uint64_t)kSlots;
       bvol = box ? bdx * bdy * bdz : 0u;
       bnx = bdx; bnxy = bdx * bdy;
-      if (tail && box) {
+      if (NESVOR_ABL(4)) {
+      } else if (tail && box) {
         const CellPos c = locate(pl, ux, uy, uz);
         const uint32_t s0 = ((c.gz - bz0) * bdy + (c.gy - by0)) * bdx + (c.gx - bx0);
 #pragma unroll
