@@ -300,8 +300,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
           for (int r = 0; r < 4; ++r) h[g][ob][r] = fmaxf(h[g][ob][r], 0.f);
           if (a.H[l] != nullptr && g0 + g < n_groups) {
             const size_t e = (((size_t)(g0 + g) * kHB + ob) * 64 + lane) * 4;
-            if constexpr (BF16) *reinterpret_cast<s16x4*>(reinterpret_cast<__bf16*>(a.H[l]) + e) = pack_bf16(h[g][ob]);
-            else *reinterpret_cast<f32x4*>(a.H[l] + e) = h[g][ob];
+            // written once, read by the backward many kernels later: streaming stores (no L2 allocation)
+            if constexpr (BF16) __builtin_nontemporal_store(pack_bf16(h[g][ob]), reinterpret_cast<s16x4*>(reinterpret_cast<__bf16*>(a.H[l]) + e));
+            else __builtin_nontemporal_store(h[g][ob], reinterpret_cast<f32x4*>(a.H[l] + e));
           }
         }
       if (l + 1 >= n_hidden) break;
