@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
     }
   }
 
-  auto load_dy = [&](int level, float (&dy)[F]) {
+  auto load_dy = [&](int level, float (&dy)[F]) __attribute__((always_inline)) {
     if constexpr (LAYOUT == NESVOR_LAYOUT_ROW_MAJOR) {
       const float* o = dpe + (size_t)ii * E + level * F;
 #pragma unroll
@@ -403,7 +403,9 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
   };
 
   // Everything of a level that needs no shared state: corner indices, run-summed corner values, tail flag.
-  auto prepare = [&](int level, const float (&dy)[F], uint32_t (&idx)[8], float (&val)[8][F], bool& tail) {
+  // (always_inline: with the inline-asm scan the inliner otherwise leaves this a real function - closure, kernel
+  // arguments and the value arrays then live in scratch memory: 6x slower)
+  auto prepare = [&](int level, const float (&dy)[F], uint32_t (&idx)[8], float (&val)[8][F], bool& tail) __attribute__((always_inline)) {
     const LevelParams p = load_level(g, level);
     if constexpr (MERGE) {
       float m = 0.f;
@@ -452,20 +454,29 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
     const bool next_head = __builtin_amdgcn_update_dpp(1, (int)head, 0x101, 0xf, 0xf, false) != 0;  // row_shl:1
     tail = valid && (rl == 15 || next_head);
     int flag = head ? 1 : 0;
-#define NESVOR_SCAN_STEP(CTRL)                                                                             \
+    // one instruction per value and step: v_fmac_f32 with a DPP source (val += shifted(val) * m); the compiler emits
+    // v_mov_dpp + v_fma for the same expression.  s_nop: a DPP read needs two wait states after the VALU write of its
+    // source, which the hazard recogniser does not see through inline asm.
+#define NESVOR_SCAN_STEP(SHR, CTRL)                                                                        \
     {                                                                                                      \
       const float m = flag ? 0.f : 1.f;                                                                    \
-      _Pragma("unroll") for (int k = 0; k < 8; ++k) _Pragma("unroll") for (int f = 0; f < F; ++f) {        \
-        const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, val[k][f]), CTRL, 0xf, 0xf, true)); \
-        val[k][f] = fmaf(m, o, val[k][f]);                                                                 \
-      }                                                                                                    \
+      _Pragma("unroll") for (int k = 0; k < 8; ++k) _Pragma("unroll") for (int f = 0; f < F; ++f)          \
+        asm volatile("v_fmac_f32_dpp %0, %0, %1 row_shr:" #SHR " row_mask:0xf bank_mask:0xf bound_ctrl:1"  \
+                     : "+v"(val[k][f]) : "v"(m));                                                          \
       flag |= __builtin_amdgcn_update_dpp(0, flag, CTRL, 0xf, 0xf, true);                                  \
     }
     if constexpr (!NESVOR_ABL(2)) {
-    NESVOR_SCAN_STEP(0x111)  // row_shr:1
-    NESVOR_SCAN_STEP(0x112)  // row_shr:2
-    NESVOR_SCAN_STEP(0x114)  // row_shr:4
-    NESVOR_SCAN_STEP(0x118)  // row_shr:8
+      // all values are written before this point and two wait states pass before the first DPP read
+#define NESVOR_FENCE8(f) asm volatile("s_nop 1" : "+v"(val[0][f]), "+v"(val[1][f]), "+v"(val[2][f]), "+v"(val[3][f]), "+v"(val[4][f]), "+v"(val[5][f]), "+v"(val[6][f]), "+v"(val[7][f]))
+      NESVOR_FENCE8(0);
+      if constexpr (F >= 2) NESVOR_FENCE8(1);
+      if constexpr (F >= 4) { NESVOR_FENCE8(2); NESVOR_FENCE8(3); }
+      if constexpr (F >= 8) { NESVOR_FENCE8(4); NESVOR_FENCE8(5); NESVOR_FENCE8(6); NESVOR_FENCE8(7); }
+#undef NESVOR_FENCE8
+      NESVOR_SCAN_STEP(1, 0x111)
+      NESVOR_SCAN_STEP(2, 0x112)
+      NESVOR_SCAN_STEP(4, 0x114)
+      NESVOR_SCAN_STEP(8, 0x118)
     }
 #undef NESVOR_SCAN_STEP
   };
@@ -489,7 +500,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
     // Second half of a level, specialised on the number NR of records a thread can hold (table slots per thread in
     // merge mode, the 8 corners otherwise) so that the merge path does not carry 8 record registers sets through the
     // next level's prepare(): reserve queue space, prepare the next level, write the records.
-    auto finish_level = [&](auto& rkey, auto& rank, auto& rval, uint32_t rmask) {
+    auto finish_level = [&](auto& rkey, auto& rank, auto& rval, uint32_t rmask) __attribute__((always_inline)) {
       constexpr int NR = sizeof(rkey) / sizeof(rkey[0]);
       __syncthreads();
       // reserve queue space: one returning (memory-side, ~2 us) atomic per non-empty chunk ...
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         }
       }
     };
-    auto advance = [&]() {
+    auto advance = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         idx[k] = idx_n[k];
@@ -717,7 +728,7 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_owner(const nesvor_grid_t g
     gap[x] = x ? plan.cap[level] - (n - pre[x - 1]) : 0u;
     n += nx;
   }
-  auto slot_of = [&](uint32_t r) {
+  auto slot_of = [&](uint32_t r) __attribute__((always_inline)) {
     uint32_t o = r;
 #pragma unroll
     for (int x = 1; x < kSubQueues; ++x) o += r >= pre[x] ? gap[x] : 0u;
@@ -731,7 +742,7 @@ __global__ __launch_bounds__(1024) void hashgrid_bwd_owner(const nesvor_grid_t g
   __syncthreads();
   const uint32_t mask = (1u << plan.chunk_shift) - 1u;
   const uint32_t* rec = records + (plan.rec_off[level] + (uint64_t)chunk * plan.n_sub * plan.cap[level]) * (1 + F);
-  auto add_record = [&](uint32_t key, const float (&v)[F]) {
+  auto add_record = [&](uint32_t key, const float (&v)[F]) __attribute__((always_inline)) {
     const uint32_t local = key & mask;
     if constexpr (F == 2) {  // one 64-bit compare-and-swap adds both features
       unsigned long long* a = reinterpret_cast<unsigned long long*>(&acc[local * 2]);
