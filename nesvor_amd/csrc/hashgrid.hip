@@ -847,6 +847,10 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
   }();
   const uint32_t n_sub = n_xcc;
   plan->n_sub = n_sub;
+  // NESVOR_HASHGRID_CAP_SCALE (tests only; read on every call): shrinks the queue capacities so that the exact
+  // overflow fallback is exercised
+  const char* cs = getenv("NESVOR_HASHGRID_CAP_SCALE");
+  const double cap_scale = cs ? atof(cs) : 0.0;
   uint32_t nb = 0;
   uint64_t off = 0;
   for (int l = 0; l < g->n_levels; ++l) {
@@ -860,6 +864,7 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
     // (atomic fallback in the aggregation pass), so the capacity only has to make it rare.
     const uint64_t per = (uint64_t)(8 * N) / nc / n_sub;
     uint64_t cap = per + per / 8 + 1024;
+    if (cap_scale > 0.0) cap = (uint64_t)((double)cap * cap_scale) + 1;  // test knob: force the overflow path
     if (cap * n_sub > 0x7FFFFFFFull) return false;
     plan->cap[l] = (uint32_t)cap;
     // small (coarse, dense) levels collect very many records on few entries: split their queue over many

@@ -426,6 +426,28 @@ def test_hashgrid_owner_equals_atomic_full_size_uniform(device):
     torch.testing.assert_close(gu_own, gu_atm, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("dist", ["P", "U"])
+def test_hashgrid_queue_overflow_fallback_is_exact(device, dist, monkeypatch):
+    """Queue capacities shrunk to 2 % (test knob NESVOR_HASHGRID_CAP_SCALE): most records of the fine levels no longer
+    fit their per-XCC sub-queue and take the atomic fallback of the aggregation pass; the gradient must not change."""
+    from nesvor_amd.encoding import hashgrid_backward
+    from nesvor_amd.grid import HashGridSpec
+
+    spec = HashGridSpec(16, 2, 19, 9, 1.26)
+    g = torch.Generator().manual_seed(5)
+    u = (_psf_cloud(512, 256, 1) if dist == "P" else torch.rand(512 * 256, 3, generator=g)).to(device)
+    N = u.shape[0]
+    table = (torch.randn(spec.n_params, generator=g) * 0.1).to(device)
+    dy = torch.randn(N, 32, generator=g).to(device)
+    g_ref, gu_ref = hashgrid_backward(spec, u, table, dy, None, True, 0, "owner")
+    monkeypatch.setenv("NESVOR_HASHGRID_CAP_SCALE", "0.02")
+    g_small, gu_small = hashgrid_backward(spec, u, table, dy, None, True, 0, "owner")
+    monkeypatch.delenv("NESVOR_HASHGRID_CAP_SCALE")
+    scale = float(g_ref.abs().max())
+    assert float((g_small - g_ref).abs().max()) < 2e-4 * scale
+    torch.testing.assert_close(gu_small, gu_ref, rtol=1e-4, atol=1e-5)
+
+
 def test_hashgrid_autograd_module(device):
     import nesvor_amd.tinycudann as tcnn
     from oracle import hashgrid as O
