@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mlp-bf16", action="store_true",
                     help="opt-in mixed precision (bf16 MLP matrix operands, fp32 accumulation): NOT the headline configuration")
+    ap.add_argument("--mlp-fp32-mfma", action="store_true",
+                    help="evaluate the MLP products with fp32 MFMAs (v_mfma_f32_16x16x4_f32) instead of the default split-bf16 "
+                         "evaluation of the same fp32 products; the default run reports this variant too (strict_fp32_mfma)")
     ap.add_argument("--half-precision-model", action="store_true",
                     help="the reference's default model structure (args.dtype float16: bias-free networks), evaluated with bf16 "
                          "matrix operands and fp32 accumulation: NOT the headline configuration")
@@ -128,6 +131,7 @@ def main():
     slices, _ = simulate_stacks(vol, n_stacks=opt.stacks)
     args = make_args(device, opt.batch_size, opt.n_samples, opt.depth, n_iter=6000)
     args.mlp_bf16 = opt.mlp_bf16
+    args.mlp_fp32_mfma = opt.mlp_fp32_mfma
     if opt.half_precision_model:
         args.dtype, args.single_precision = torch.float16, False
     ds = Dataset(slices, args)
@@ -184,6 +188,30 @@ def main():
         elapsed = float(t.item())
     final_loss = {k: float(val.detach()) for k, val in losses.items()}
 
+    # the same K steps with the MLP products evaluated by fp32 MFMAs (the default evaluates the same fp32 products as
+    # six bf16 MFMAs on split operands, with the same error against fp64): reported next to the headline value
+    strict = None
+    if trainer.direct is not None and trainer.direct.bf16 is False:
+        from nesvor_amd import mlp as _mlp
+
+        trainer.direct.bf16 = _mlp.MFMA_FP32
+        for _ in range(opt.warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(opt.steps):
+            step()
+        sync()
+        e2 = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([e2], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            e2 = float(t.item())
+        strict = {"value": opt.steps * (opt.batch_size * opt.n_samples * world / float(1 << 20)) / e2,
+                  "ms_per_step": e2 / opt.steps * 1e3,
+                  "note": "same run, MLP products as v_mfma_f32_16x16x4_f32 (python bench.py --mlp-fp32-mfma)"}
+        trainer.direct.bf16 = False
+
     if rank == 0:
         n_points = opt.batch_size * opt.n_samples  # per GPU per step
         iters_per_s = opt.steps * (n_points * world / float(1 << 20)) / elapsed
@@ -228,7 +256,10 @@ def main():
             bf16_ops = opt.mlp_bf16 or opt.half_precision_model
             peak = 2500.0 if bf16_ops else 157.3
             note = ("bf16 MFMA (v_mfma_f32_16x16x16_bf16) dense peak; the kernel is bound by its LDS/VALU work around the MFMAs "
-                    "in this mode, not by the matrix pipe" if bf16_ops else "fp32 MFMA (v_mfma_f32_16x16x4_f32) dense peak")
+                    "in this mode, not by the matrix pipe" if bf16_ops else
+                    "fp32 MFMA (v_mfma_f32_16x16x4_f32) dense peak" if opt.mlp_fp32_mfma else
+                    "fp32-equivalent flops against the fp32 MFMA (v_mfma_f32_16x16x4_f32) dense peak; the dW products run on that "
+                    "pipe, the dX chain as split-bf16 MFMAs (6 x v_mfma_f32_16x16x32_bf16 per 2 k-blocks)")
             roof_mlp = {"bound": "mfma", "kernel": "mlp_bwd_fused (density_net + sigma_net launches)", "achieved": 2 * fl / (ms2 * 1e-3) / 1e12,
                         "peak": peak, "unit": "TFLOP/s", "frac": 2 * fl / (ms2 * 1e-3) / 1e12 / peak, "traffic": None,
                         "launch_ms": ms2, "note": note + "; flops = 2x forward (dX and dW), padding excluded"}
@@ -249,6 +280,12 @@ def main():
                 "global_batch_pixels": global_b, "n_levels": L, "parallelism": f"dp{world}",
                 "masked_pixels": int(M), "n_slices": len(slices),
             },
+            "mlp_products": ("fp32 MFMA (v_mfma_f32_16x16x4_f32)" if opt.mlp_fp32_mfma else
+                             "bf16-rounded operands" if (opt.mlp_bf16 or opt.half_precision_model) else
+                             "fp32 operands split into three bf16 terms, six bf16 MFMAs per product, fp32 accumulation: error "
+                             "against fp64 equal to the fp32 MFMA chain's (tests/test_gpu_ops.py::"
+                             "test_fused_mlp_split_operands_keep_fp32_accuracy); dW products are fp32 MFMAs"),
+            "strict_fp32_mfma": strict,
             "roofline": roof,
             "roofline_mlp": roof_mlp,
             "final_losses": final_loss,

@@ -173,10 +173,17 @@ typedef struct {
   int32_t samples_per_pixel;
   int32_t dxa_group_sums;     /* backward only: dxa is (N/16, k_a), one row per 16-sample group = the sum over its samples
                                  (needs N, samples_per_pixel and k_a multiples of 16 and the fused backward) */
-  int32_t bf16_operands;      /* != 0: matrix operands (weights, activations, upstream gradients) rounded to bf16,
-                                 fp32 accumulation, everything else fp32 - an opt-in mixed-precision mode, not the
-                                 reference's fp32 semantics.  Backward: wave-specialised kernel only (N, S, k_a
-                                 multiples of 16, at most two hidden layers, k_a + k_b <= 32 for two hidden layers) */
+  int32_t bf16_operands;      /* how the matrix products are evaluated (storage, accumulation, outputs are fp32 in all modes):
+                                 0: fp32 MFMA (v_mfma_f32_16x16x4_f32, an fp32 FMA chain);
+                                 1: operands (weights, activations, upstream gradients) rounded to bf16 - an opt-in
+                                    mixed-precision mode, not the reference's fp32 semantics; the saved activations
+                                    are bf16.  Backward: wave-specialised kernel only (N, S, k_a multiples of 16, at
+                                    most two hidden layers, k_a + k_b <= 32 for two hidden layers);
+                                 2: every fp32 operand split into the exact sum of three bf16 numbers, six bf16 MFMAs
+                                    per product: fp32-equivalent accuracy (error against fp64 as the fp32 FMA chain's)
+                                    on the 16x faster bf16 matrix pipe.  Forward: all layers; backward: the dX chain of
+                                    the wave-specialised kernel (the dW products and every other backward kernel use
+                                    mode 0, which is always a valid evaluation of mode 2) */
   const float* weight[NESVOR_MAX_MLP_LAYERS];
   const float* bias[NESVOR_MAX_MLP_LAYERS];
 } nesvor_mlp_t;

@@ -64,7 +64,7 @@ struct MlpArgs {
   int fast;                     // N % 16 == 0, S % 16 == 0, k_a % 16 == 0: group = one pixel, input blocks homogeneous
   int spg_shift;                // log2(S / 16) when that is a power of two, else -1
   int dxa_group;                // dxa holds one row per 16-sample GROUP (sum over its samples) instead of one per sample
-  int bf16;                     // matrix operands rounded to bf16 (fp32 accumulation)
+  int bf16;                     // 1: matrix operands rounded to bf16 (fp32 accumulation); 2: operands split into three bf16 (fp32-equivalent)
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -87,10 +87,61 @@ __device__ __forceinline__ f32x4 mfma16_bf16(s16x4 a, s16x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
 
+// Split mode (nesvor_mlp_t.bf16_operands == 2): every fp32 operand is written as the exact sum of three bf16 numbers
+// (8 + 8 + 8 mantissa bits: hi = rn(x), mid = rn(x - hi), lo = rn(x - hi - mid)) and a product a.b is evaluated as
+// the six bf16 MFMAs  a_hi b_hi + a_hi b_mid + a_mid b_hi + a_mid b_mid + a_hi b_lo + a_lo b_hi  with fp32
+// accumulation.  The three dropped terms are below 2^-23 |a||b|: the result carries the accuracy of an fp32 FMA chain,
+// while six bf16 16x16x16 MFMAs (8 cycles each) replace four fp32 16x16x4 MFMAs (36 cycles each).
+struct Split3 { s16x4 hi, mid, lo; };
+__device__ __forceinline__ f32x4 widen_bf16(const s16x4& v) {  // four bf16 -> fp32 (exact)
+  const uint2 u = __builtin_bit_cast(uint2, v);
+  return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+               __uint_as_float(u.y & 0xFFFF0000u)};
+}
+__device__ __forceinline__ Split3 split3(const f32x4& v) {
+  Split3 s;
+  s.hi = pack_bf16(v);
+  const f32x4 r1 = v - widen_bf16(s.hi);
+  s.mid = pack_bf16(r1);
+  s.lo = pack_bf16(r1 - widen_bf16(s.mid));
+  return s;
+}
+// gfx950's full-rate bf16 shape contracts 32 k-values per instruction: lane (j, q) supplies k-slots (q, 0..7).  The
+// k index may be numbered freely as long as A and B agree, so slots 0..3 take the lane's four values of one 16-feature
+// block and slots 4..7 those of the next block: two of the kernels' fragments side by side, no data movement.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 join8(const s16x4& a, const s16x4& b) {
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ f32x4 mfma32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// two k-blocks at once (a0/b0: block kb, a1/b1: block kb + 1)
+__device__ __forceinline__ f32x4 mfma_split2(const Split3& a0, const Split3& a1, const Split3& b0, const Split3& b1, f32x4 c) {
+  const bf16x8 ah = join8(a0.hi, a1.hi), am = join8(a0.mid, a1.mid), al = join8(a0.lo, a1.lo);
+  const bf16x8 bh = join8(b0.hi, b1.hi), bm = join8(b0.mid, b1.mid), bl = join8(b0.lo, b1.lo);
+  c = mfma32_bf16(al, bh, c);
+  c = mfma32_bf16(ah, bl, c);
+  c = mfma32_bf16(am, bm, c);
+  c = mfma32_bf16(am, bh, c);
+  c = mfma32_bf16(ah, bm, c);
+  return mfma32_bf16(ah, bh, c);
+}
+__device__ __forceinline__ f32x4 mfma_split(const Split3& a, const Split3& b, f32x4 c) {
+  c = mfma16_bf16(a.lo, b.hi, c);
+  c = mfma16_bf16(a.hi, b.lo, c);
+  c = mfma16_bf16(a.mid, b.mid, c);
+  c = mfma16_bf16(a.mid, b.hi, c);
+  c = mfma16_bf16(a.hi, b.mid, c);
+  return mfma16_bf16(a.hi, b.hi, c);
+}
+
 // ---------------------------------------------------------------- LDS images
 // forward image of a layer with `ob_n` output blocks and `kb_n` input blocks
 // (BF16: the image holds bf16 elements at the same element indices, i.e. it uses the first half of the fp32 carve)
-template <bool BF16 = false>
+// (X6: three bf16 planes hi | mid | lo of `total` elements each, i.e. 1.5x the fp32 carve)
+template <bool BF16 = false, bool X6 = false>
 __device__ void build_image(float* img, const float* __restrict__ W, int out_dim, int in_dim, int ob_n, int kb_n) {
   const int total = ob_n * kb_n * 256;
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
@@ -98,12 +149,18 @@ __device__ void build_image(float* img, const float* __restrict__ W, int out_dim
     const int kb = blk % kb_n, ob = blk / kb_n;
     const int o = 16 * ob + (lane & 15), k = 16 * kb + 4 * (lane >> 4) + r;
     const float w = (o < out_dim && k < in_dim) ? W[(size_t)o * in_dim + k] : 0.f;
-    if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w;
+    if constexpr (X6) {
+      __bf16* p = reinterpret_cast<__bf16*>(img);
+      const __bf16 hi = (__bf16)w;
+      const float r1 = w - (float)hi;
+      const __bf16 mid = (__bf16)r1;
+      p[e] = hi; p[total + e] = mid; p[2 * total + e] = (__bf16)(r1 - (float)mid);
+    } else if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w;
     else img[e] = w;
   }
 }
 // transposed image: rows i = input features (ib blocks), k = output features (kb blocks)
-template <bool BF16 = false>
+template <bool BF16 = false, bool X6 = false>
 __device__ void build_image_T(float* img, const float* __restrict__ W, int out_dim, int in_dim, int ib_n, int kb_n) {
   const int total = ib_n * kb_n * 256;
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
@@ -111,15 +168,58 @@ __device__ void build_image_T(float* img, const float* __restrict__ W, int out_d
     const int kb = blk % kb_n, ib = blk / kb_n;
     const int in = 16 * ib + (lane & 15), o = 16 * kb + 4 * (lane >> 4) + r;
     const float w = (o < out_dim && in < in_dim) ? W[(size_t)o * in_dim + in] : 0.f;
-    if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w;
+    if constexpr (X6) {
+      __bf16* p = reinterpret_cast<__bf16*>(img);
+      const __bf16 hi = (__bf16)w;
+      const float r1 = w - (float)hi;
+      const __bf16 mid = (__bf16)r1;
+      p[e] = hi; p[total + e] = mid; p[2 * total + e] = (__bf16)(r1 - (float)mid);
+    } else if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w;
     else img[e] = w;
   }
 }
 
 // y[g][ob] (+)= img . x   for G groups at once; KB input blocks, OB output blocks
-template <int KB, int OB, bool BF16 = false>
+template <int KB, int OB, bool BF16 = false, bool X6 = false>
 __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const f32x4 (&x)[kG][KB], f32x4 (&y)[kG][OB],
                                             int lane) {
+  if constexpr (X6) {
+    const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
+    constexpr int plane = OB * KB * 256;
+    auto load_a = [&](int ob, int kb) __attribute__((always_inline)) {
+      const __bf16* pa = img16 + ((ob * KB + kb) * 64 + lane) * 4;
+      Split3 a;
+      a.hi = *reinterpret_cast<const s16x4*>(pa);
+      a.mid = *reinterpret_cast<const s16x4*>(pa + plane);
+      a.lo = *reinterpret_cast<const s16x4*>(pa + 2 * plane);
+      return a;
+    };
+#pragma unroll
+    for (int kb = 0; kb + 1 < KB; kb += 2) {
+      Split3 pb0[kG], pb1[kG];
+#pragma unroll
+      for (int g = 0; g < kG; ++g) { pb0[g] = split3(x[g][kb]); pb1[g] = split3(x[g][kb + 1]); }
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) {
+        const Split3 a0 = load_a(ob, kb), a1 = load_a(ob, kb + 1);
+#pragma unroll
+        for (int g = 0; g < kG; ++g) y[g][ob] = mfma_split2(a0, a1, pb0[g], pb1[g], y[g][ob]);
+      }
+    }
+    if constexpr (KB % 2 == 1) {
+      constexpr int kb = KB - 1;
+      Split3 pb[kG];
+#pragma unroll
+      for (int g = 0; g < kG; ++g) pb[g] = split3(x[g][kb]);
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) {
+        const Split3 a = load_a(ob, kb);
+#pragma unroll
+        for (int g = 0; g < kG; ++g) y[g][ob] = mfma_split(a, pb[g], y[g][ob]);
+      }
+    }
+    return;
+  }
   if constexpr (BF16) {
     const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
 #pragma unroll
@@ -150,8 +250,32 @@ __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const
 }
 
 // single 16-sample group variant (used by the fused backward, where registers hold the dW accumulators)
-template <int KB, int OB, bool BF16 = false>
+template <int KB, int OB, bool BF16 = false, bool X6 = false>
 __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, const f32x4 (&x)[KB], f32x4 (&y)[OB], int lane) {
+  if constexpr (X6) {
+    const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
+    constexpr int plane = OB * KB * 256;
+    auto load_a = [&](int ob, int kb) __attribute__((always_inline)) {
+      const __bf16* pa = img16 + ((ob * KB + kb) * 64 + lane) * 4;
+      Split3 a;
+      a.hi = *reinterpret_cast<const s16x4*>(pa);
+      a.mid = *reinterpret_cast<const s16x4*>(pa + plane);
+      a.lo = *reinterpret_cast<const s16x4*>(pa + 2 * plane);
+      return a;
+    };
+#pragma unroll
+    for (int kb = 0; kb + 1 < KB; kb += 2) {
+      const Split3 pb0 = split3(x[kb]), pb1 = split3(x[kb + 1]);
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) y[ob] = mfma_split2(load_a(ob, kb), load_a(ob, kb + 1), pb0, pb1, y[ob]);
+    }
+    if constexpr (KB % 2 == 1) {
+      const Split3 pb = split3(x[KB - 1]);
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) y[ob] = mfma_split(load_a(ob, KB - 1), pb, y[ob]);
+    }
+    return;
+  }
   if constexpr (BF16) {
     const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
 #pragma unroll
@@ -244,19 +368,20 @@ __device__ __forceinline__ f32x4 load_dy_fast(const MlpArgs& a, int64_t gi, int 
 }
 
 // ------------------------------------------------------------------- forward
-template <int KB1, bool BF16 = false>
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
+template <int KB1, bool BF16 = false, bool X6 = false>
+__global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_kernel(const MlpArgs a) {  // split mode: keep two workgroups per CU (the grid is sized for that)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n_hidden = a.n_linear - 1;
   const int k_in = a.k_a + a.k_b;
-  // LDS carve: [img1 | img hidden 2..n_hidden | img out | biases]
+  // LDS carve: [img1 | img hidden 2..n_hidden | img out | biases]   (an image block = 256 floats; 384 in split mode)
+  constexpr int kBlk = X6 ? 384 : 256;
   float* img1 = lds;
-  float* imgh = img1 + kHB * KB1 * 256;
-  float* imgo = imgh + (n_hidden - 1) * kHB * kHB * 256;
-  float* bias = imgo + 1 * kHB * 256;
-  build_image<BF16>(img1, a.W[0], kWidth, k_in, kHB, KB1);
-  for (int l = 1; l < n_hidden; ++l) build_image<BF16>(imgh + (l - 1) * kHB * kHB * 256, a.W[l], kWidth, kWidth, kHB, kHB);
-  build_image<BF16>(imgo, a.W[n_hidden], a.out_dim, kWidth, 1, kHB);
+  float* imgh = img1 + kHB * KB1 * kBlk;
+  float* imgo = imgh + (n_hidden - 1) * kHB * kHB * kBlk;
+  float* bias = imgo + 1 * kHB * kBlk;
+  build_image<BF16, X6>(img1, a.W[0], kWidth, k_in, kHB, KB1);
+  for (int l = 1; l < n_hidden; ++l) build_image<BF16, X6>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, kHB, kHB);
+  build_image<BF16, X6>(imgo, a.W[n_hidden], a.out_dim, kWidth, 1, kHB);
   for (int e = threadIdx.x; e < a.n_linear * kWidth; e += blockDim.x) {
     const int l = e / kWidth, o = e % kWidth;
     bias[e] = (l < n_hidden || o < a.out_dim) ? a.b[l][o] : 0.f;
@@ -289,7 +414,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
 #pragma unroll
       for (int g = 0; g < kG; ++g) h[g][ob] = bq;
     }
-    apply_layer<KB1, kHB, BF16>(img1, x, h, lane);
+    apply_layer<KB1, kHB, BF16, X6>(img1, x, h, lane);
     for (int l = 0;; ++l) {
       // ReLU + save fragments of hidden layer l
 #pragma unroll
@@ -313,7 +438,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
 #pragma unroll
         for (int g = 0; g < kG; ++g) h2[g][ob] = bq;
       }
-      apply_layer<kHB, kHB, BF16>(imgh + l * kHB * kHB * 256, h, h2, lane);
+      apply_layer<kHB, kHB, BF16, X6>(imgh + l * kHB * kHB * kBlk, h, h2, lane);
 #pragma unroll
       for (int g = 0; g < kG; ++g)
 #pragma unroll
@@ -325,7 +450,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
 #pragma unroll
       for (int g = 0; g < kG; ++g) o[g][0] = bq;
     }
-    apply_layer<kHB, 1, BF16>(imgo, h, o, lane);
+    apply_layer<kHB, 1, BF16, X6>(imgo, h, o, lane);
 #pragma unroll
     for (int g = 0; g < kG; ++g) {
       const int64_t n = (g0 + g) * 16 + j;
@@ -857,18 +982,21 @@ __device__ __forceinline__ void await_loads() {
 __device__ __forceinline__ void pin(f32x4& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 
-template <int KB1, int NH, bool BF16 = false>
+// X6: the dX chain (contraction over features, 32 at a time) runs on split-bf16 operands - see split3(); the dW waves
+// contract over the 16 samples of a group, where the split would not pay, and keep the fp32 MFMAs.
+template <int KB1, int NH, bool BF16 = false, bool X6 = false>
 __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int k_in = a.k_a + a.k_b;
   constexpr int kT = 1 + NH * kHB;                      // tiles per group: dY, then dpre of layers NH-1 .. 0
+  constexpr int kBlk = X6 ? 384 : 256;                  // floats per image block (three bf16 planes in split mode)
   float* imgo = lds;                                    // W_out^T : ib = 4, kb = 1
-  float* imgh = imgo + kHB * 1 * 256;                   // W_l^T, l = 1..NH-1
-  float* img1 = imgh + (NH - 1) * kHB * kHB * 256;      // W_1^T : ib = KB1, kb = 4
-  float* tiles = img1 + KB1 * kHB * 256;                // [pair][buffer][kT] tiles; reused as the flush buffer
-  build_image_T<BF16>(imgo, a.W[NH], a.out_dim, kWidth, kHB, 1);
-  for (int l = 1; l < NH; ++l) build_image_T<BF16>(imgh + (l - 1) * kHB * kHB * 256, a.W[l], kWidth, kWidth, kHB, kHB);
-  build_image_T<BF16>(img1, a.W[0], kWidth, k_in, KB1, kHB);
+  float* imgh = imgo + kHB * 1 * kBlk;                  // W_l^T, l = 1..NH-1
+  float* img1 = imgh + (NH - 1) * kHB * kHB * kBlk;     // W_1^T : ib = KB1, kb = 4
+  float* tiles = img1 + KB1 * kHB * kBlk;               // [pair][buffer][kT] tiles; reused as the flush buffer
+  build_image_T<BF16, X6>(imgo, a.W[NH], a.out_dim, kWidth, kHB, 1);
+  for (int l = 1; l < NH; ++l) build_image_T<BF16, X6>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, kHB, kHB);
+  build_image_T<BF16, X6>(img1, a.W[0], kWidth, k_in, KB1, kHB);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -946,7 +1074,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         f32x4 d[kHB];
 #pragma unroll
         for (int ib = 0; ib < kHB; ++ib) d[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-        apply_layer_g1<1, kHB, BF16>(imgo, gov, d, lane);
+        apply_layer_g1<1, kHB, BF16, X6>(imgo, gov, d, lane);
 #pragma unroll
         for (int l = NH - 1; l >= 0; --l) {
 #pragma unroll
@@ -959,14 +1087,14 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             f32x4 d2[kHB];
 #pragma unroll
             for (int ib = 0; ib < kHB; ++ib) d2[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-            apply_layer_g1<kHB, kHB, BF16>(imgh + (l - 1) * kHB * kHB * 256, d, d2, lane);
+            apply_layer_g1<kHB, kHB, BF16, X6>(imgh + (l - 1) * kHB * kHB * kBlk, d, d2, lane);
 #pragma unroll
             for (int ib = 0; ib < kHB; ++ib) d[ib] = d2[ib];
           } else if (a.dxa != nullptr || a.dxb != nullptr) {
             f32x4 dx[KB1];
 #pragma unroll
             for (int ib = 0; ib < KB1; ++ib) dx[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-            apply_layer_g1<kHB, KB1, BF16>(img1, d, dx, lane);
+            apply_layer_g1<kHB, KB1, BF16, X6>(img1, d, dx, lane);
             // drain the prefetch BEFORE the stores below: loads and stores share vmcnt, and the wait would otherwise
             // also cover the latency of these stores
             settle_group(gy_n, hs_n);
@@ -1091,8 +1219,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   flush_dw_ws<1, kHB>(red, acc_o, db_o, out + poff, a.out_dim, kWidth, slot);
 }
 
-size_t ws_bwd_lds_bytes(int n_hidden, int kb1) {
-  size_t img = (size_t)kHB * 256 + (size_t)(n_hidden - 1) * kHB * kHB * 256 + (size_t)kb1 * kHB * 256;
+size_t ws_bwd_lds_bytes(int n_hidden, int kb1, int blk = 256) {
+  size_t img = (size_t)kHB * blk + (size_t)(n_hidden - 1) * kHB * kHB * blk + (size_t)kb1 * kHB * blk;
   size_t tiles = 4 * 2 * (size_t)(1 + n_hidden * kHB) * kTileFloats;
   if (tiles < 4 * (size_t)kHB * 256) tiles = 4 * (size_t)kHB * 256;
   return sizeof(float) * (img + tiles);
@@ -1105,9 +1233,9 @@ size_t fused_bwd_lds_bytes(int n_hidden, int kb1) {
   return sizeof(float) * (img + scratch);
 }
 
-size_t fwd_lds_bytes(int n_linear, int kb1) {
+size_t fwd_lds_bytes(int n_linear, int kb1, int blk = 256) {
   const int n_hidden = n_linear - 1;
-  return sizeof(float) * ((size_t)kHB * kb1 * 256 + (size_t)(n_hidden - 1) * kHB * kHB * 256 + kHB * 256 + (size_t)n_linear * kWidth);
+  return sizeof(float) * ((size_t)kHB * kb1 * blk + (size_t)(n_hidden - 1) * kHB * kHB * blk + kHB * blk + (size_t)n_linear * kWidth);
 }
 size_t bwd_lds_bytes(int n_linear, int kb1) {
   const int n_hidden = n_linear - 1;
@@ -1153,7 +1281,8 @@ int fill_args(MlpArgs* a, const nesvor_mlp_t* d, int64_t N) {
   const int S = d->samples_per_pixel;
   a->fast = (N % 16 == 0 && S % 16 == 0 && d->k_a % 16 == 0) ? 1 : 0;
   a->dxa_group = d->dxa_group_sums ? 1 : 0;
-  a->bf16 = d->bf16_operands ? 1 : 0;
+  a->bf16 = d->bf16_operands;  // 0: fp32 MFMA, 1: bf16-rounded operands, 2: split (fp32-equivalent) operands
+  if (a->bf16 < 0 || a->bf16 > 2) return (int)hipErrorInvalidValue;
   a->spg_shift = -1;
   if (a->fast) {
     const int spg = S / 16;
@@ -1176,6 +1305,9 @@ extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, cons
   const int64_t n_tiles = ((N + 15) / 16 + 4 * kG - 1) / (4 * kG);
   // 2 persistent workgroups per CU = the occupancy (measured: 256 / 768 / 1024 / 2048 workgroups are slower)
   dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512));
+  if (a.bf16 == 2)
+    return launch_kb(mlp_fwd_kernel<1, false, true>, mlp_fwd_kernel<2, false, true>, mlp_fwd_kernel<3, false, true>,
+                     mlp_fwd_kernel<4, false, true>, kb1, grid, fwd_lds_bytes(a.n_linear, kb1, 384), (hipStream_t)stream, a);
   if (a.bf16)
     return launch_kb(mlp_fwd_kernel<1, true>, mlp_fwd_kernel<2, true>, mlp_fwd_kernel<3, true>, mlp_fwd_kernel<4, true>, kb1,
                      grid, fwd_lds_bytes(a.n_linear, kb1), (hipStream_t)stream, a);
@@ -1191,6 +1323,8 @@ extern "C" int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, con
   int e = fill_args(&a, net, N);
   if (e) return e;
   if (saved_hidden == nullptr || dpre_scratch == nullptr || dw_partial == nullptr || n_partial < 1) return (int)hipErrorInvalidValue;
+  const bool split = a.bf16 == 2;  // fp32 data everywhere; only the MFMA sites differ
+  if (split) a.bf16 = 0;
   a.xa = xa; a.xb = xb; a.y = const_cast<float*>(dy); a.dxa = dxa; a.dxb = dxb; a.dW_partial = dw_partial;
   for (int l = 0; l < kMaxLayers; ++l) {
     a.H[l] = l < net->n_hidden ? saved_hidden[l] : nullptr;
@@ -1209,6 +1343,14 @@ extern "C" int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, con
                            mlp_bwd_ws_kernel<4, 1, true>, kb1, dim3((unsigned)n_partial), lds_ws, (hipStream_t)stream, a, 512);
         return launch_kb(mlp_bwd_ws_kernel<1, 2, true>, mlp_bwd_ws_kernel<2, 2, true>, mlp_bwd_ws_kernel<3, 2, true>,
                          mlp_bwd_ws_kernel<4, 2, true>, kb1, dim3((unsigned)n_partial), lds_ws, (hipStream_t)stream, a, 512);
+      }
+      if (split) {
+        const size_t lds_x6 = ws_bwd_lds_bytes(net->n_hidden, kb1, 384);
+        if (net->n_hidden == 1)
+          return launch_kb(mlp_bwd_ws_kernel<1, 1, false, true>, mlp_bwd_ws_kernel<2, 1, false, true>, mlp_bwd_ws_kernel<3, 1, false, true>,
+                           mlp_bwd_ws_kernel<4, 1, false, true>, kb1, dim3((unsigned)n_partial), lds_x6, (hipStream_t)stream, a, 512);
+        return launch_kb(mlp_bwd_ws_kernel<1, 2, false, true>, mlp_bwd_ws_kernel<2, 2, false, true>, mlp_bwd_ws_kernel<3, 2, false, true>,
+                         mlp_bwd_ws_kernel<4, 2, false, true>, kb1, dim3((unsigned)n_partial), lds_x6, (hipStream_t)stream, a, 512);
       }
       if (net->n_hidden == 1)
         return launch_kb(mlp_bwd_ws_kernel<1, 1>, mlp_bwd_ws_kernel<2, 1>, mlp_bwd_ws_kernel<3, 1>, mlp_bwd_ws_kernel<4, 1>,

@@ -79,9 +79,13 @@ class DirectStep:
         self.s_net = mlp_mod.NetParams(model.sigma_net) if self.has_lv else None
         self.b_net = mlp_mod.NetParams(model.b_net) if self.has_b else None
         self.side = torch.cuda.Stream(device=dev) if self.opt_T else None
-        # mixed precision of the MLPs: bf16 matrix operands, fp32 accumulation / master weights - opt-in for the fp32
-        # model (args.mlp_bf16), always for the half-precision model structure
-        self.bf16 = bool(getattr(a, "mlp_bf16", False)) or half_precision_model(model)
+        # evaluation of the MLP matrix products (mlp.operand_mode): bf16-rounded operands for the half-precision model
+        # structure and, opt-in, for the fp32 model (args.mlp_bf16); otherwise fp32 - the split-bf16 default, or the
+        # plain fp32 MFMAs with args.mlp_fp32_mfma
+        if bool(getattr(a, "mlp_bf16", False)) or half_precision_model(model):
+            self.bf16 = True
+        else:
+            self.bf16 = mlp_mod.MFMA_FP32 if getattr(a, "mlp_fp32_mfma", False) else False
         import torch.distributed as dist
 
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1

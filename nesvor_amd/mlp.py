@@ -6,6 +6,7 @@ evaluated.  Input = [pixel features xa (P,k_a) broadcast over each pixel's S sam
 rows [b_row0, b_row0+k_b) of a feature-major matrix xb (rows,N)];  output (out_dim, N) feature-major.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -16,6 +17,26 @@ from . import _lib
 N_PARTIAL = 1024  # workgroups (= partial sums) of the dW kernel: 4 per CU so loads overlap MFMAs
 N_PARTIAL_FUSED = 256  # fused backward: one persistent 8-wave workgroup per CU (wave-specialised kernel)
 FUSED_BACKWARD = True  # False: separate dX and dW kernels (kept as cross-check and for depth 3)
+
+# How an fp32 matrix product is evaluated (nesvor_mlp_t.bf16_operands):
+#   MFMA_FP32 (0): v_mfma_f32_16x16x4_f32 - an fp32 FMA chain;
+#   BF16 (1): operands rounded to bf16 - mixed precision, opt-in (args.mlp_bf16) / the half-precision model structure;
+#   SPLIT (2): every fp32 operand written as the exact sum of three bf16 numbers, six bf16 MFMAs per product, fp32
+#     accumulation: the accuracy of the fp32 FMA chain (tools/bench_mlp_split.py: max error against fp64 2.4e-7 vs
+#     3.3e-7) at 1.25-1.6x the speed, because the fp32 matrix pipe of gfx950 is 16x slower than the bf16 one.
+# SPLIT is what "fp32" means by default; NESVOR_MLP_FP32=mfma (or FP32_OPERANDS = MFMA_FP32) selects the plain path.
+MFMA_FP32, BF16, SPLIT = 0, 1, 2
+FP32_OPERANDS = MFMA_FP32 if os.environ.get("NESVOR_MLP_FP32", "split").lower() == "mfma" else SPLIT
+
+
+def operand_mode(bf16) -> int:
+    """bf16: False -> the fp32 default (FP32_OPERANDS); True -> bf16-rounded operands; or an explicit mode constant
+    passed as an int (MFMA_FP32 is spelled 0, which `False` must not be confused with: pass it via `operands=`)."""
+    if bf16 is True or (bf16 is not False and int(bf16) == BF16):
+        return BF16
+    if bf16 is False:
+        return FP32_OPERANDS
+    return int(bf16)
 
 
 def linear_layers(seq: nn.Sequential):
@@ -123,7 +144,7 @@ class NetParams:
 
 def _desc(weights, biases, k_a, k_b, b_row0, S, bf16=False):
     d = _lib.MlpT()
-    d.bf16_operands = 1 if bf16 else 0
+    d.bf16_operands = operand_mode(bf16)
     d.width, d.n_hidden, d.out_dim = 64, len(weights) - 1, weights[-1].shape[0]
     d.k_a, d.k_b, d.b_row0, d.samples_per_pixel = k_a, k_b, b_row0, S
     for i, (w, b) in enumerate(zip(weights, biases)):
@@ -140,7 +161,8 @@ def _ptr_array(tensors):
 
 def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False):
     """One forward launch, no autograd: -> (y (out_dim, N), saved hidden activations [] when not need_saved).
-    bf16: matrix operands rounded to bf16, fp32 accumulation (opt-in mixed precision, see include/nesvor_hip.h)."""
+    bf16: False = fp32 (FP32_OPERANDS picks split-bf16 or fp32-MFMA evaluation of the products), True = matrix operands
+    rounded to bf16 with fp32 accumulation (opt-in mixed precision); an int selects a mode constant directly."""
     _lib.require_device(xb, *weights, *biases, dtype=torch.float32, name="fused MLP input/params")
     N = xb.shape[1]
     k_a = 0 if xa is None else xa.shape[1]
@@ -153,7 +175,7 @@ def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False)
     d = _desc(weights, biases, k_a, k_b, b_row0, S, bf16)
     n_pad = (N + 15) // 16 * 16
     # saved hidden activations, MFMA fragment layout; bf16 mode stores them as bf16 (they are only used as bf16 operands)
-    sdt = torch.bfloat16 if bf16 else torch.float32
+    sdt = torch.bfloat16 if operand_mode(bf16) == BF16 else torch.float32
     saved = [torch.empty(n_pad * 64, dtype=sdt, device=xb.device) for _ in range(len(weights) - 1)] if need_saved else []
     y = torch.empty((d.out_dim, N), dtype=torch.float32, device=xb.device)
     with torch.cuda.device(xb.device), _lib.kernel_timer.span("mlp_fwd"):

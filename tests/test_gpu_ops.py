@@ -614,6 +614,53 @@ def test_fused_mlp_bf16_operand_mode(device, k_a, k_b, b_row0, rows, out_dim):
     # and the mode really is coarser than fp32: it must NOT match the fp32 kernel to fp32 accuracy
     y32, _ = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, False)
     assert float((y32 - y).abs().max()) > 1e-4 * float(y32.abs().max())
+    # while the split evaluation of the fp32 products agrees with the fp32-MFMA one to fp32 rounding
+    y_mfma, _ = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, False, mlp.MFMA_FP32)
+    y_split, _ = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, False, mlp.SPLIT)
+    assert float((y_mfma - y_split).abs().max()) < 2e-6 * float(y_mfma.abs().max())
+
+
+@pytest.mark.parametrize("k_a,k_b,b_row0,rows,out_dim", [(0, 32, 0, 32, 16), (16, 15, 1, 16, 1)])
+def test_fused_mlp_split_operands_keep_fp32_accuracy(device, k_a, k_b, b_row0, rows, out_dim):
+    """The default evaluation of the fp32 products (three-way bf16 split, six MFMAs, nesvor_mlp_t.bf16_operands == 2)
+    against an fp64 evaluation of the same network: its error must not exceed that of the fp32-MFMA evaluation
+    (an fp32 FMA chain) by more than a factor 1.5 - forward output, input gradient and parameter gradients."""
+    from nesvor_amd import mlp
+    from nesvor_amd.models import build_network
+
+    torch.manual_seed(1)
+    N, S = 8192, 256
+    net = build_network(n_input_dims=k_a + k_b, n_output_dims=out_dim, activation="ReLU", output_activation="None",
+                        n_neurons=64, n_hidden_layers=2, dtype=torch.float32).to(device)
+    L = mlp.linear_layers(net)
+    W, Bs = [l.weight.detach() for l in L], [l.bias.detach() for l in L]
+    xa = torch.randn(N // S, k_a, device=device) if k_a else None
+    xb = torch.randn(rows, N, device=device)
+    dy = torch.randn(out_dim, N, device=device)
+    X = xb[b_row0 : b_row0 + k_b].t().double()
+    if xa is not None:
+        X = torch.cat([xa.double().repeat_interleave(S, 0), X], 1)
+    Wd, Bd = [w.double() for w in W], [b.double() for b in Bs]
+    p1 = X @ Wd[0].t() + Bd[0]
+    h1 = p1.relu()
+    p2 = h1 @ Wd[1].t() + Bd[1]
+    h2 = p2.relu()
+    y_ref = (h2 @ Wd[2].t() + Bd[2]).t()
+    G = dy.t().double()
+    d2 = (G @ Wd[2]) * (p2 > 0)
+    d1 = (d2 @ Wd[1]) * (p1 > 0)
+    dxb_ref = (d1 @ Wd[0])[:, k_a:].t()
+    dW_ref = torch.cat([(d1.t() @ X).reshape(-1), d1.sum(0), (d2.t() @ h1).reshape(-1), d2.sum(0), (G.t() @ h2).reshape(-1), G.sum(0)])
+    err = {}
+    for mode in (mlp.MFMA_FP32, mlp.SPLIT):
+        y, saved = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, True, mode)
+        dxb = torch.empty(k_b, N, device=device)
+        _, partial = mlp.backward_raw(W, Bs, xa, xb, dy, saved, b_row0, k_b, S, dxb, xa is not None, mode)
+        rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+        err[mode] = (rel(y, y_ref), rel(dxb, dxb_ref), rel(partial.double().sum(0), dW_ref))
+    print("max error / max|ref|  (y, dx, dW):  fp32 MFMA %s   split %s" % (err[mlp.MFMA_FP32], err[mlp.SPLIT]))
+    for e_split, e_mfma in zip(err[mlp.SPLIT], err[mlp.MFMA_FP32]):
+        assert e_split <= 1.5 * e_mfma + 1e-7
 
 
 # -------------------------------------------------------------------- fused MLP
@@ -632,15 +679,17 @@ def test_fused_mlp_bf16_operand_mode(device, k_a, k_b, b_row0, rows, out_dim):
     (32, 20, 2, 24, 2, 3, 32, 1024),    # two pixel-feature blocks + a ragged row block
 ])
 @pytest.mark.parametrize("fused_bwd", [True, False])
-def test_fused_mlp_vs_torch_fp32_reference(device, k_a, k_b, b_row0, rows, depth, out_dim, S, N, fused_bwd, monkeypatch):
-    """fp32 MFMA network vs the same nn.Sequential evaluated by PyTorch (fp32 reference of the same op).
-    Tolerance: fp32 with K <= 64 per layer and different summation order: rtol 2e-4 / atol 2e-5 fwd,
-    grads relative to their max."""
+@pytest.mark.parametrize("operands", ["split", "mfma"])
+def test_fused_mlp_vs_torch_fp32_reference(device, k_a, k_b, b_row0, rows, depth, out_dim, S, N, fused_bwd, operands, monkeypatch):
+    """fp32 network (products as split-bf16 MFMAs - the default - or as fp32 MFMAs) vs the same nn.Sequential evaluated
+    by PyTorch (fp32 reference of the same op).  Tolerance: fp32 with K <= 64 per layer and different summation order:
+    rtol 2e-4 / atol 2e-5 fwd, grads relative to their max."""
     import nesvor_amd.mlp as M
     from nesvor_amd.mlp import fused_mlp
     from nesvor_amd.models import build_network
 
     monkeypatch.setattr(M, "FUSED_BACKWARD", fused_bwd)  # fused dX+dW+db kernel vs the two-kernel path
+    monkeypatch.setattr(M, "FP32_OPERANDS", M.SPLIT if operands == "split" else M.MFMA_FP32)
     torch.manual_seed(N + k_a)
     net = build_network(n_input_dims=k_a + k_b, n_output_dims=out_dim, activation="ReLU", output_activation="None",
                         n_neurons=64, n_hidden_layers=depth, dtype=torch.float32).to(device)
