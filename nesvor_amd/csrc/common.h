@@ -48,6 +48,26 @@ __device__ __forceinline__ float row_sum_dpp(float v) {
   return v;
 }
 
+// Full-wave min / max of unsigned values on the VALU only (same DPP pattern as wave_sum_dpp).  Result is wave-uniform.
+__device__ __forceinline__ uint32_t wave_min_u32_dpp(uint32_t v) {
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));
+  const uint32_t r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+  return min(min(r0, r1), min(r2, r3));
+}
+__device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));
+  const uint32_t r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+  return max(max(r0, r1), max(r2, r3));
+}
+
 // fp32 add into LDS through an integer compare-and-swap loop.  On gfx950 ds_add_f32 retires ~1 lane
 // per 3 cycles (192+ cycles per wave-instruction, measured, independent of conflicts) while
 // ds_cmpst_rtn_b32 runs at ~7 cycles per conflict-free wave-instruction, so the CAS loop wins

@@ -107,23 +107,80 @@ __device__ __forceinline__ void load_feat(const float* __restrict__ p, float (&v
 }
 
 // ------------------------------------------------------------------ forward
+// A workgroup = 256 consecutive samples = (for S = 256) one PSF cloud.  Where the lattice box spanned by its cells at
+// this level has at most kFwdSlots vertices (the coarse and middle levels), the box is copied into LDS once - every
+// vertex fetched once per workgroup instead of once per touching sample - and the 8 corner reads are LDS reads; the
+// fine levels gather from global memory as before.  Cells are biased by +1 so that the unsigned min / max also order
+// the cell -1 of points just outside the unit cube.
 template <int F, int LAYOUT>
 __global__ __launch_bounds__(256) void hashgrid_fwd(const nesvor_grid_t g, const float* __restrict__ u,
                                                     const float* __restrict__ table, float* __restrict__ pe,
-                                                    int64_t N) {
-  const int level = blockIdx.y;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
+                                                    int64_t N, int box_cache) {
+  constexpr int kFwdSlots = F <= 2 ? 1024 : (F == 4 ? 512 : 256);
+  __shared__ uint32_t wbox[4][6];
+  __shared__ __attribute__((aligned(16))) float cache[kFwdSlots * F];
+  const int level = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  const bool valid = i < N;
+  const int64_t ii = valid ? i : N - 1;
   const LevelParams p = load_level(g, level);
-  const float ux = u[3 * i], uy = u[3 * i + 1], uz = u[3 * i + 2];
+  const float ux = u[3 * ii], uy = u[3 * ii + 1], uz = u[3 * ii + 2];
   const CellPos c = locate(p, ux, uy, uz);
   const float* tab = table + (size_t)p.offset * F;
   float v[8][F];
+  bool cached = false;
+  if (box_cache) {  // kernel argument: uniform
+    const uint32_t bx = c.gx + 1u, by = c.gy + 1u, bz = c.gz + 1u;
+    const uint32_t lo0 = wave_min_u32_dpp(bx), lo1 = wave_min_u32_dpp(by), lo2 = wave_min_u32_dpp(bz);
+    const uint32_t hi0 = wave_max_u32_dpp(bx), hi1 = wave_max_u32_dpp(by), hi2 = wave_max_u32_dpp(bz);
+    if (lane == 0) {
+      uint32_t* w = wbox[tid >> 6];
+      w[0] = lo0; w[1] = lo1; w[2] = lo2; w[3] = hi0; w[4] = hi1; w[5] = hi2;
+    }
+    __syncthreads();
+    uint32_t lo[3], hi[3];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const uint32_t idx = corner_index(p, c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + (k >> 2));
-    load_feat<F>(tab + (size_t)idx * F, v[k]);
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = min(min(wbox[0][d], wbox[1][d]), min(wbox[2][d], wbox[3][d]));
+      hi[d] = max(max(wbox[0][3 + d], wbox[1][3 + d]), max(wbox[2][3 + d], wbox[3][3 + d]));
+      lo[d] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo[d]);
+      hi[d] = (uint32_t)__builtin_amdgcn_readfirstlane((int)hi[d]);
+    }
+    const uint32_t ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    const uint32_t nx = ex + 2u, ny = ey + 2u, nz = ez + 2u, nxy = nx * ny;
+    cached = ex < (uint32_t)kFwdSlots && ey < (uint32_t)kFwdSlots && ez < (uint32_t)kFwdSlots &&
+             (uint64_t)nxy * nz <= (uint64_t)kFwdSlots;
+    if (cached) {  // workgroup-uniform
+      const uint32_t vol = nxy * nz;
+      const float inv_nxy = 1.f / (float)nxy, inv_nx = 1.f / (float)nx;
+      for (uint32_t s = tid; s < vol; s += 256) {
+        const uint32_t z = (uint32_t)(((float)s + 0.5f) * inv_nxy);
+        const uint32_t r = s - z * nxy;
+        const uint32_t y = (uint32_t)(((float)r + 0.5f) * inv_nx);
+        const uint32_t idx = corner_index(p, lo[0] - 1u + (r - y * nx), lo[1] - 1u + y, lo[2] - 1u + z);
+        float t[F];
+        load_feat<F>(tab + (size_t)idx * F, t);
+#pragma unroll
+        for (int f = 0; f < F; ++f) cache[s * F + f] = t[f];
+      }
+      __syncthreads();
+      const uint32_t s0 = ((bz - lo[2]) * ny + (by - lo[1])) * nx + (bx - lo[0]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t s = s0 + (k & 1) + ((k >> 1) & 1) * nx + (k >> 2) * nxy;
+#pragma unroll
+        for (int f = 0; f < F; ++f) v[k][f] = cache[s * F + f];
+      }
+    }
   }
+  if (!cached) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t idx = corner_index(p, c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + (k >> 2));
+      load_feat<F>(tab + (size_t)idx * F, v[k]);
+    }
+  }
+  if (!valid) return;
   float acc[F];
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.f;
@@ -927,7 +984,8 @@ owner_stage:
 template <int F, int LAYOUT>
 int launch_fwd(const nesvor_grid_t* g, const float* u, const float* table, float* pe, int64_t N, hipStream_t st) {
   dim3 grid((unsigned)((N + 255) / 256), g->n_levels), block(256);
-  hipLaunchKernelGGL((hashgrid_fwd<F, LAYOUT>), grid, block, 0, st, *g, u, table, pe, N);
+  static const int box_cache = []() { const char* e = getenv("NESVOR_HASHGRID_FWD_CACHE"); return (e == nullptr || atoi(e) != 0) ? 1 : 0; }();
+  hipLaunchKernelGGL((hashgrid_fwd<F, LAYOUT>), grid, block, 0, st, *g, u, table, pe, N, box_cache);
   return (int)hipGetLastError();
 }
 
