@@ -222,8 +222,22 @@ __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const
   }
   if constexpr (BF16) {
     const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
+    // two 16-feature blocks per full-rate 16x16x32 MFMA (see join8), a 16x16x16 one for an odd last block
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
+    for (int kb = 0; kb + 1 < KB; kb += 2) {
+      bf16x8 pb[kG];
+#pragma unroll
+      for (int g = 0; g < kG; ++g) pb[g] = join8(pack_bf16(x[g][kb]), pack_bf16(x[g][kb + 1]));
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) {
+        const bf16x8 a = join8(*reinterpret_cast<const s16x4*>(img16 + ((ob * KB + kb) * 64 + lane) * 4),
+                               *reinterpret_cast<const s16x4*>(img16 + ((ob * KB + kb + 1) * 64 + lane) * 4));
+#pragma unroll
+        for (int g = 0; g < kG; ++g) y[g][ob] = mfma32_bf16(a, pb[g], y[g][ob]);
+      }
+    }
+    if constexpr (KB % 2 == 1) {
+      constexpr int kb = KB - 1;
       s16x4 pb[kG];
 #pragma unroll
       for (int g = 0; g < kG; ++g) pb[g] = pack_bf16(x[g][kb]);
@@ -279,11 +293,18 @@ __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, co
   if constexpr (BF16) {
     const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const s16x4 pb = pack_bf16(x[kb]);
+    for (int kb = 0; kb + 1 < KB; kb += 2) {
+      const bf16x8 pb = join8(pack_bf16(x[kb]), pack_bf16(x[kb + 1]));
 #pragma unroll
       for (int ob = 0; ob < OB; ++ob)
-        y[ob] = mfma16_bf16(*reinterpret_cast<const s16x4*>(img16 + ((ob * KB + kb) * 64 + lane) * 4), pb, y[ob]);
+        y[ob] = mfma32_bf16(join8(*reinterpret_cast<const s16x4*>(img16 + ((ob * KB + kb) * 64 + lane) * 4),
+                                  *reinterpret_cast<const s16x4*>(img16 + ((ob * KB + kb + 1) * 64 + lane) * 4)), pb, y[ob]);
+    }
+    if constexpr (KB % 2 == 1) {
+      const s16x4 pb = pack_bf16(x[KB - 1]);
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob)
+        y[ob] = mfma16_bf16(*reinterpret_cast<const s16x4*>(img16 + ((ob * KB + KB - 1) * 64 + lane) * 4), pb, y[ob]);
     }
     return;
   }
