@@ -448,6 +448,34 @@ def test_hashgrid_queue_overflow_fallback_is_exact(device, dist, monkeypatch):
     torch.testing.assert_close(gu_small, gu_ref, rtol=1e-4, atol=1e-5)
 
 
+def test_hashgrid_points_outside_unit_cube(device):
+    """PSF samples of boundary pixels fall slightly outside the bounding box (u < 0 or u > 1, cells -1 / res): the
+    forward's LDS box cache, the backward's box-addressed merge table and the per-corner atomic kernel must index the
+    same entries.  Checks: owner backward == atomic backward, and <pe, dy> == <table, grad_table> (the forward and the
+    backward are adjoint maps only if they agree on every index)."""
+    from nesvor_amd.encoding import hashgrid_backward, hashgrid_forward
+    from nesvor_amd.grid import HashGridSpec
+
+    spec = HashGridSpec(16, 2, 19, 9, 1.26)
+    g = torch.Generator().manual_seed(11)
+    centres = torch.rand(256, 1, 3, generator=g)
+    centres[:128] = centres[:128].round()  # half of the clouds sit on faces / edges / corners of the cube
+    u = (centres + torch.randn(256, 256, 3, generator=g) * torch.tensor([0.006, 0.006, 0.01])).reshape(-1, 3).contiguous().to(device)
+    assert float(u.min()) < -0.01 and float(u.max()) > 1.01
+    N = u.shape[0]
+    table = (torch.randn(spec.n_params, generator=g) * 0.1).to(device)
+    dy = torch.randn(32, N, generator=g).to(device)
+    pe = hashgrid_forward(spec, u, table, 1)
+    g_own, gu_own = hashgrid_backward(spec, u, table, dy, None, True, 1, "owner")
+    g_atm, gu_atm = hashgrid_backward(spec, u, table, dy, None, True, 1, "atomic")
+    scale = float(g_atm.abs().max())
+    assert float((g_own - g_atm).abs().max()) < 2e-4 * scale
+    torch.testing.assert_close(gu_own, gu_atm, rtol=1e-3, atol=1e-3)
+    lhs = (pe.double() * dy.double()).sum()
+    rhs = (table.double() * g_own.double()).sum()
+    assert abs(float(lhs - rhs)) < 1e-4 * abs(float(lhs)) + 1e-3
+
+
 def test_hashgrid_autograd_module(device):
     import nesvor_amd.tinycudann as tcnn
     from oracle import hashgrid as O
