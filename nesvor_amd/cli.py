@@ -7,9 +7,10 @@ nesvor/cli/commands.py:64-146) for the commands that sit on the built path (SURV
     python -m nesvor_amd.cli sample-volume --input-model m.pt --output-volume v.nii.gz [--output-resolution 0.8] ...
     python -m nesvor_amd.cli sample-slices --input-model m.pt --input-slices DIR --simulated-slices DIR
 
-Differences from the reference, all because SVoRT / stack registration is out of scope here:
-``--registration`` accepts the reference's choices but only ``none`` is implemented (and is the default; the
-reference defaults to ``svort``); there is no ``register`` command.  Precision follows the reference's switch
+Differences from the reference, all because the SVoRT transformer (pretrained weights, torchvision) is out of scope
+here: ``--registration`` accepts the reference's choices, of which ``none`` (the default; the reference defaults to
+``svort``) and ``stack`` (stack-to-stack rigid registration, nesvor_amd/registration.py) are implemented; there is
+no ``register`` command.  Precision follows the reference's switch
 (``--single-precision`` = the fp32 model with biased Linear layers; the default is the reference's half-precision
 structure - bias-free networks - which the HIP path evaluates with bf16 matrix operands and fp32 accumulation).
 """
@@ -200,16 +201,22 @@ def reconstruct(args: Namespace) -> None:
     if args.input_slices is not None:
         slices = load_slices(args.input_slices, args.device)
     else:
-        if args.registration != "none":
-            raise NotImplementedError(f"--registration {args.registration}: SVoRT / stack registration is out of scope of this "
+        if args.registration not in ("none", "stack"):
+            raise NotImplementedError(f"--registration {args.registration}: the SVoRT transformer is out of scope of this "
                                       "build; register with the reference and pass the result through --input-slices, or use "
-                                      "--registration none")
+                                      "--registration stack / none")
         stacks = []
         for i, f in enumerate(args.input_stacks):
             st = load_stack(f, args.stack_masks[i] if args.stack_masks is not None else None, device=args.device)
             if args.thicknesses is not None:
                 st.thickness = args.thicknesses[i]
             stacks.append(st)
+        if args.registration == "stack":
+            from .registration import register_stacks
+
+            t1 = time.time()
+            stacks = register_stacks(stacks)
+            logging.info("Stack registration finished in %.1f s", time.time() - t1)
         slices = stacks_to_slices(stacks)
     logging.info("Data loading finished in %.1f s (%d slices)", time.time() - t0, len(slices))
     t0 = time.time()

@@ -112,6 +112,38 @@ def gaussian_blur(x: torch.Tensor, sigma, truncated: float) -> torch.Tensor:
     return x
 
 
+def ncc_loss(I: torch.Tensor, J: torch.Tensor, mask: Optional[torch.Tensor] = None, win: Optional[int] = 9, level: int = 0,
+             eps: float = 1e-6, reduction: str = "none") -> torch.Tensor:
+    """Negative squared normalised cross-correlation of (N,C,*spatial) images (nesvor/utils/loss.py:6-70):
+    ``win=None``: one value per (N,C) over the whole (optionally masked) image; otherwise local statistics in a
+    box window of ``2 * int(win / 2^level / 2) + 1`` voxels (zero padding), one value per voxel."""
+    nd = I.ndim - 2
+    if mask is not None:
+        I, J = I * mask, J * mask
+    c = I.shape[1]
+    if win is None:
+        I, J = torch.flatten(I, 1), torch.flatten(J, 1)
+        if mask is not None:
+            n = torch.flatten(mask, 1).sum(-1) + eps
+            avg = lambda t: t.sum(-1) / n
+        else:
+            avg = lambda t: t.mean(-1)
+    else:
+        I, J = I.reshape(-1, 1, *I.shape[2:]), J.reshape(-1, 1, *J.shape[2:])
+        w = 2 * int(win / 2**level / 2) + 1
+        box = torch.ones([1, 1] + [w] * nd, device=I.device, dtype=I.dtype) / w**nd
+        conv = [F.conv1d, F.conv2d, F.conv3d][nd - 1]
+        avg = lambda t: conv(t, box, stride=1, padding=w // 2)
+    mi, mj = avg(I), avg(J)
+    cross = avg(I * J) - mi * mj
+    cc = cross * cross / ((avg(I * I) - mi * mi) * (avg(J * J) - mj * mj) + eps)
+    if reduction == "mean":
+        return -cc.mean()
+    if reduction == "sum":
+        return -cc.sum()
+    return -cc.view(-1, c) if win is None else -cc.view(-1, c, *I.shape[2:])
+
+
 class MovingAverage:
     """Bias-corrected EMA (alpha>0) or running mean (alpha==0) per key (misc.py:91-145)."""
 

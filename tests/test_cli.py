@@ -82,3 +82,18 @@ def test_cli_reconstruct_sample_roundtrip(tmp_path, device, precision):
     assert len(os.listdir(str(tmp_path / "sim2"))) == n_out
     with pytest.raises(NotImplementedError):
         cli.main(["reconstruct", "--input-stacks", *paths, "--registration", "svort", "--output-volume", out_vol, *small])
+    if precision:  # --registration stack on stacks that are already aligned: the reconstruction must stay as good
+        out3 = str(tmp_path / "recon_stackreg.nii.gz")
+        def fit(out_dir, sim_dir):  # correlation between the acquired slices and the slices simulated from the model
+            a = torch.cat([s.image[s.mask] for s in load_slices(out_dir, device)])
+            b = torch.cat([s.image[m.mask] for s, m in zip(load_slices(sim_dir, device), load_slices(out_dir, device))])
+            return float(torch.corrcoef(torch.stack([a, b]))[0, 1])
+
+        cli.main(["reconstruct", "--input-stacks", *paths, "--thicknesses", "3", "3", "3", "--registration", "stack",
+                  "--output-volume", out3, "--output-slices", str(tmp_path / "out_slices3"),
+                  "--simulated-slices", str(tmp_path / "sim_slices3"), *small])
+        v3 = load_volume(out3, device=device)
+        assert torch.isfinite(v3.image).all() and abs(float(v3.image[v3.mask].mean()) - 700.0) < 1.0
+        c_none, c_stack = fit(str(tmp_path / "out_slices"), str(tmp_path / "sim_slices")), fit(str(tmp_path / "out_slices3"), str(tmp_path / "sim_slices3"))
+        print(f"slice fit (correlation): --registration none {c_none:.4f}, stack {c_stack:.4f}")
+        assert c_stack > c_none - 0.03  # a mis-registered stack could not be fitted by one volume
