@@ -261,6 +261,23 @@ int nesvor_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_
  * ld > cols, a column range of it (one layer's weights when the model keeps no biases, tinycudann.Network). */
 int nesvor_sum_rows(const float* in, float* out, int rows, int cols, int ld, void* stream);
 
+/* ----------------------------------------------------------------------
+ * Similarity sums of the stack registration.  Replaces, per optimisation step of `VVR`
+ * (nesvor/svort/registration.py:143-247), the K = 1 + 2 x 6 successive evaluations of
+ *   warped = F.grid_sample(source, (R_k (points + t_k)) * to_unit, align_corners=True)   (:233-247)
+ *   loss(warped, target) reduced over the points                                          (:166-170)
+ * by one pass over the points: for every pose k
+ *   sums[k] = { sum I, sum I^2, sum I J },  I = source sampled under pose k, J = target;
+ *   target_sums = { sum J, sum J^2 } (optional)
+ * from which NCC and MSE follow.  source (D,H,W) fp32, points (M,3) physical coordinates, target (M),
+ * mats (K,3,4) row-major [R | t] with the translation applied first, to_unit_xyz: HOST pointer to the three factors
+ * that map a moved point to grid_sample's normalised coordinates (x, y, z).  sums (K,3) / target_sums (2): fp64,
+ * zero-filled by the call.
+ * ---------------------------------------------------------------------- */
+int nesvor_vvr_similarity(const float* source, int D, int H, int W, const float* points, const float* target,
+                          const float* mats, const float* to_unit_xyz, int64_t M, int K, double* sums,
+                          double* target_sums, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

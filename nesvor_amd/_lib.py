@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NESVOR_HIP_LIB: load another build of the same ABI (tools/ablate_hashgrid.py times variants of one kernel this way)
 LIB_PATH = os.environ.get("NESVOR_HIP_LIB") or os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -95,6 +95,7 @@ _SIGNATURES = {
         c_int,
     ),
     "nesvor_sum_rows": ([_P, _P, c_int, c_int, c_int, _P], c_int),
+    "nesvor_vvr_similarity": ([_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P], c_int),
 }
 
 

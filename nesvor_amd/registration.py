@@ -15,9 +15,15 @@ Volume-to-volume registration by normalised gradient descent on a similarity los
   serves both parts.
 
 Written for this code base (explicit pyramid level object, one objective function); behaviour follows the reference,
-whose own test (``tests/svort/test_vvr.py``) is re-stated in ``tests/test_registration.py``.  Everything here is
-device-agnostic PyTorch, as in the reference: it is one-off preprocessing, not part of the training iteration.
+whose own test (``tests/svort/test_vvr.py``) is re-stated in ``tests/test_registration.py``.
+
+Two evaluation paths.  Generic (any loss callable, autograd gradients, any device the transform ops support):
+PyTorch ``grid_sample`` + the loss, as the reference does - one objective evaluation is ~25 small launches and a
+finite-difference gradient needs 13 of them.  Fused (HIP, ``nesvor_vvr_similarity``): when the loss is given by name
+(global NCC or MSE) and the gradient is by finite differences, ONE launch samples the source under all 13 poses and
+returns the moment sums the loss is a function of (fp64); ``stack_registration`` uses it.
 """
+import ctypes
 import logging
 import math
 import time
@@ -26,6 +32,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple, Union
 import torch
 import torch.nn.functional as F
 
+from . import _lib
 from .transform import RigidTransform, mat_transform_points
 from .utils import gaussian_blur, meshgrid, ncc_loss
 
@@ -57,8 +64,10 @@ class _Level:
         self.points = meshgrid(shape_xyz, (voxel, voxel, voxel), device=target.device).reshape(-1, 3)[keep]
         self.values = target.reshape(-1)[keep]
         # physical (mm, centred) -> grid_sample's normalised coordinates of the source
-        self.to_unit = torch.tensor([2.0 / (source.shape[-1] - 1), 2.0 / (source.shape[-2] - 1), 2.0 / (source.shape[-3] - 1)],
-                                    dtype=source.dtype, device=source.device) / voxel
+        unit = [2.0 / (source.shape[-1] - 1) / voxel, 2.0 / (source.shape[-2] - 1) / voxel, 2.0 / (source.shape[-3] - 1) / voxel]
+        self.to_unit = torch.tensor(unit, dtype=source.dtype, device=source.device)
+        self.to_unit_host = (ctypes.c_float * 3)(*unit)
+        self.target_sums = None  # (sum J, sum J^2) of the fused path, filled by its first call
 
 
 class VVR:
@@ -79,13 +88,17 @@ class VVR:
         if optimizer.get("name") != "gd":
             raise Exception("unknown optimizer")
         self.momentum = float(optimizer.get("momentum", 0))
+        self._fused_kind, self._eps = None, 1e-6
         if isinstance(loss, dict):
             kw = dict(loss)
             name = kw.pop("name")
             if name == "mse":
                 self._loss = lambda x, y: F.mse_loss(x, y, reduction="none", **kw)
+                self._fused_kind = "mse" if not kw else None
             elif name == "ncc":
                 self._loss = lambda x, y: ncc_loss(x, y, reduction="none", level=self.current_level, **kw)
+                if kw.get("win", 9) is None and set(kw) <= {"win", "eps"}:  # global NCC: a function of five moment sums
+                    self._fused_kind, self._eps = "ncc", float(kw.get("eps", 1e-6))
             else:
                 raise Exception("unknown loss")
         elif callable(loss):
@@ -126,7 +139,43 @@ class VVR:
         loss = self._loss(warped[:, None], lv.values.view(1, 1, -1).expand(warped.shape[0], -1, -1))
         return loss.reshape(loss.shape[0], -1).mean(1)
 
+    def _fused(self, theta: torch.Tensor, lv: _Level) -> bool:
+        return (self._fused_kind is not None and not self.auto_grad and theta.shape[0] == 1 and lv.source.is_cuda
+                and lv.source.dtype == torch.float32 and lv.source.shape[0] == 1)
+
+    def _objective_fused(self, thetas_deg: torch.Tensor, lv: _Level) -> torch.Tensor:
+        """Losses of K poses of ONE registration problem in one launch -> (K,)."""
+        K = thetas_deg.shape[0]
+        pose = RigidTransform(thetas_deg * self._unit(thetas_deg), trans_first=self.trans_first)
+        mats = pose.inv().compose(self.theta_t).matrix().contiguous()
+        dev = lv.source.device
+        sums = torch.empty((K, 3), dtype=torch.float64, device=dev)
+        first = lv.target_sums is None
+        if first:
+            lv.target_sums = torch.empty(2, dtype=torch.float64, device=dev)
+        src = lv.source.contiguous()
+        D, H, W = src.shape[-3:]
+        M = lv.values.numel()
+        with torch.cuda.device(dev):
+            err = _lib.load().nesvor_vvr_similarity(_lib.ptr(src), D, H, W, _lib.ptr(lv.points), _lib.ptr(lv.values), _lib.ptr(mats),
+                                                    lv.to_unit_host, M, K, _lib.ptr(sums),
+                                                    _lib.ptr(lv.target_sums) if first else None, _lib.stream_ptr())
+        _lib.check(err, "vvr similarity")
+        sI, sII, sIJ = sums[:, 0] / M, sums[:, 1] / M, sums[:, 2] / M
+        sJ, sJJ = lv.target_sums[0] / M, lv.target_sums[1] / M
+        if self._fused_kind == "mse":
+            return (sII - 2 * sIJ + sJJ).float()
+        cross = sIJ - sI * sJ
+        return (-(cross * cross) / ((sII - sI * sI) * (sJJ - sJ * sJ) + self._eps)).float()
+
     def _gradient(self, theta: torch.Tensor, lv: _Level, h: float) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._fused(theta, lv):  # the pose and its 12 perturbations in one launch
+            e = torch.zeros((13, 6), dtype=theta.dtype, device=theta.device)
+            idx = torch.arange(6, device=theta.device)
+            e[1 + 2 * idx, idx] = h
+            e[2 + 2 * idx, idx] = -h
+            l = self._objective_fused(theta + e, lv)
+            return l[:1], (l[1::2] - l[2::2]).view(1, 6)
         if self.auto_grad:
             with torch.enable_grad():
                 t = theta.detach().requires_grad_(True)
@@ -160,7 +209,7 @@ class VVR:
             else:
                 direction = grad
             move = direction / (torch.linalg.norm(direction, dim=-1, keepdim=True) + 1e-6) * (-step)
-            better = self._objective(cur + move, lv) < loss
+            better = (self._objective_fused(cur + move, lv) if self._fused(cur, lv) else self._objective(cur + move, lv)) < loss
             active[idx] = better
             if not bool(better.any()):
                 break
@@ -205,8 +254,9 @@ def stack_registration(transforms_list: List[List[RigidTransform]], transform_ta
     device = transform_target.device
     t_target = _mean_pose(transform_target)
     candidates = [[_mean_pose(t) for t in ts] for ts in transforms_list]
+    # global NCC given by name: on a HIP device VVR then evaluates a gradient's 13 poses in one launch
     vvr = VVR(num_levels=3, num_steps=4, step_size=2, max_iter=20, optimizer={"name": "gd", "momentum": 0.1},
-              loss=lambda s, x, y: ncc_loss(x[None], y[None], win=None, reduction="none"), auto_grad=False)
+              loss={"name": "ncc", "win": None}, auto_grad=False)
     trans_first = False
     registered = [t_target]
     target = stacks[0].squeeze(1)[None, None]

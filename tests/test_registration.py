@@ -69,6 +69,41 @@ def test_vvr_reference_test(device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["ncc", "mse"])
+def test_vvr_fused_similarity_equals_grid_sample_path(device, kind):
+    """nesvor_vvr_similarity (one launch, 13 poses, fp64 moment sums) against F.grid_sample + the loss for the same poses;
+    and the reference's VVR test through the fused path (loss given by name) reaches the same pose."""
+    from nesvor_amd.phantom import phantom3d
+    from nesvor_amd.registration import VVR, _Level
+    from nesvor_amd.transform import RigidTransform
+
+    volume = torch.tensor(phantom3d(n=64), dtype=torch.float32, device=device)[None, None]
+    loss = {"name": "ncc", "win": None} if kind == "ncc" else {"name": "mse"}
+    vvr = VVR(num_levels=3, num_steps=8, step_size=2, max_iter=20, optimizer={"name": "gd", "momentum": 0.1}, loss=loss, auto_grad=False)
+    vvr.theta_t = RigidTransform(torch.tensor([[0.2, -0.1, 0.3, 4.0, -3.0, 2.0]], device=device), trans_first=False)
+    vvr.trans_first = False
+    vvr.res, vvr.relative_res = 1.0, [1.5, 1.0, 1.0]
+    lv = vvr._level(1, volume, volume)
+    assert isinstance(lv, _Level) and lv.values.numel() > 1000
+    g = torch.Generator().manual_seed(0)
+    thetas = torch.tensor([[11.0, -6.0, 17.0, 4.5, -2.0, 2.5]]) + torch.randn(13, 6, generator=g) * torch.tensor([2.0, 2.0, 2.0, 1.5, 1.5, 1.5])
+    thetas = thetas.to(device)
+    fused = vvr._objective_fused(thetas, lv)
+    if kind == "ncc":
+        from nesvor_amd.utils import ncc_loss
+        ref = torch.cat([ncc_loss(vvr._warp(t[None], lv)[None], lv.values.view(1, 1, -1), win=None).view(-1) for t in thetas])
+    else:
+        ref = torch.cat([((vvr._warp(t[None], lv) - lv.values[None]) ** 2).mean(1) for t in thetas])
+    torch.testing.assert_close(fused, ref, rtol=2e-4, atol=1e-6)
+    if kind == "ncc":
+        ax = torch.tensor([[0.4, 0.1, -0.6, 20, -50, 100]], dtype=torch.float32, device=device)
+        t_target = RigidTransform(torch.tensor([[0.45, 0.05, -0.5, 23, -52, 101.5]], dtype=torch.float32, device=device), trans_first=False)
+        big = torch.tensor(phantom3d(n=128), dtype=torch.float32, device=device)[None, None]
+        out, l = vvr(ax, big, big, {"res_s": 1, "s_thick": 1.5}, t_target, False)
+        torch.testing.assert_close(out, t_target.axisangle(trans_first=False), atol=1e-5, rtol=1e-3)
+
+
+@pytest.mark.gpu
 def test_vvr_autograd_gradient_variant(device):
     """auto_grad=True (gradient through grid_sample) from a smaller offset, MSE loss given as a dict."""
     from nesvor_amd.phantom import phantom3d
