@@ -4,13 +4,14 @@ nesvor/cli/commands.py:64-146) for the commands that sit on the built path (SURV
     python -m nesvor_amd.cli reconstruct   --input-stacks a.nii.gz b.nii.gz [--stack-masks ...] [--thicknesses ...]
                                            | --input-slices DIR   --output-volume v.nii.gz [--output-model m.pt]
                                            [--output-slices DIR] [--simulated-slices DIR]  [training flags]
+    python -m nesvor_amd.cli register      --input-stacks a.nii.gz b.nii.gz --output-slices DIR [--registration stack|none]
     python -m nesvor_amd.cli sample-volume --input-model m.pt --output-volume v.nii.gz [--output-resolution 0.8] ...
     python -m nesvor_amd.cli sample-slices --input-model m.pt --input-slices DIR --simulated-slices DIR
 
 Differences from the reference, all because the SVoRT transformer (pretrained weights, torchvision) is out of scope
 here: ``--registration`` accepts the reference's choices, of which ``none`` (the default; the reference defaults to
 ``svort``) and ``stack`` (stack-to-stack rigid registration, nesvor_amd/registration.py) are implemented; there is
-no ``register`` command.  Precision follows the reference's switch
+the ``register`` command offers the same two.  Precision follows the reference's switch
 (``--single-precision`` = the fp32 model with biased Linear layers; the default is the reference's half-precision
 structure - bias-free networks - which the HIP path evaluates with bf16 matrix operands and fp32 accumulation).
 """
@@ -102,6 +103,18 @@ def build_parser() -> argparse.ArgumentParser:
     _training_flags(p)
     _common_flags(p)
 
+    p = sub.add_parser("register")
+    g = p.add_argument_group("input")
+    g.add_argument("--input-stacks", nargs="+", type=str, required=True)
+    g.add_argument("--thicknesses", nargs="+", type=float)
+    g.add_argument("--stack-masks", nargs="+", type=str)
+    g = p.add_argument_group("output")
+    g.add_argument("--output-slices", type=str, required=True)
+    g = p.add_argument_group("registration")
+    g.add_argument("--registration", default="stack", type=str, choices=["svort", "svort-stack", "stack", "none"])
+    g.add_argument("--svort-version", default="v1", type=str, choices=["v1", "v2"])
+    _common_flags(p)
+
     p = sub.add_parser("sample-volume")
     p.add_argument("--input-model", type=str, required=True)
     g = p.add_argument_group("output")
@@ -173,6 +186,41 @@ def _outputs(data: Dict, args: Namespace) -> None:
             save_slices(getattr(args, key), data[key])
 
 
+def _load_stacks(args: Namespace) -> List:
+    from .image_io import load_stack
+
+    for name in ("stack_masks", "thicknesses"):
+        if getattr(args, name, None) is not None and len(getattr(args, name)) != len(args.input_stacks):
+            raise SystemExit(f"The numbers of {name.replace('_', ' ')} and input stacks are different!")
+    stacks = []
+    for i, f in enumerate(args.input_stacks):
+        st = load_stack(f, args.stack_masks[i] if args.stack_masks is not None else None, device=args.device)
+        if args.thicknesses is not None:
+            st.thickness = args.thicknesses[i]
+        stacks.append(st)
+    return stacks
+
+
+def register(args: Namespace, stacks: List) -> List:
+    """Stacks -> motion-corrected slices (cli/commands.py:171-176): ``none`` keeps the nominal poses, ``stack``
+    registers every stack to the first one; the SVoRT-based choices need the pretrained transformer (out of scope)."""
+    if args.registration not in ("none", "stack"):
+        raise NotImplementedError(f"--registration {args.registration}: the SVoRT transformer is out of scope of this "
+                                  "build; register with the reference and pass the result through --input-slices, or use "
+                                  "--registration stack / none")
+    if args.registration == "stack":
+        from .registration import register_stacks
+
+        t1 = time.time()
+        stacks = register_stacks(stacks)
+        logging.info("Stack registration finished in %.1f s", time.time() - t1)
+    return stacks_to_slices(stacks)
+
+
+def register_cmd(args: Namespace) -> None:
+    _outputs({"output_slices": register(args, _load_stacks(args))}, args)
+
+
 def reconstruct(args: Namespace) -> None:
     from .image_io import load_slices, load_stack
     from .sample import sample_slices, sample_volume
@@ -201,23 +249,7 @@ def reconstruct(args: Namespace) -> None:
     if args.input_slices is not None:
         slices = load_slices(args.input_slices, args.device)
     else:
-        if args.registration not in ("none", "stack"):
-            raise NotImplementedError(f"--registration {args.registration}: the SVoRT transformer is out of scope of this "
-                                      "build; register with the reference and pass the result through --input-slices, or use "
-                                      "--registration stack / none")
-        stacks = []
-        for i, f in enumerate(args.input_stacks):
-            st = load_stack(f, args.stack_masks[i] if args.stack_masks is not None else None, device=args.device)
-            if args.thicknesses is not None:
-                st.thickness = args.thicknesses[i]
-            stacks.append(st)
-        if args.registration == "stack":
-            from .registration import register_stacks
-
-            t1 = time.time()
-            stacks = register_stacks(stacks)
-            logging.info("Stack registration finished in %.1f s", time.time() - t1)
-        slices = stacks_to_slices(stacks)
+        slices = register(args, _load_stacks(args))
     logging.info("Data loading finished in %.1f s (%d slices)", time.time() - t0, len(slices))
     t0 = time.time()
     model, output_slices, mask = train(slices, args)
@@ -256,7 +288,8 @@ def main(argv=None) -> None:
     args = build_parser().parse_args(argv)
     _setup(args)
     t0 = time.time()
-    {"reconstruct": reconstruct, "sample-volume": sample_volume_cmd, "sample-slices": sample_slices_cmd}[args.command](args)
+    {"reconstruct": reconstruct, "register": register_cmd, "sample-volume": sample_volume_cmd,
+     "sample-slices": sample_slices_cmd}[args.command](args)
     logging.info("Command 'nesvor %s' finished, overall time: %.1f s", args.command, time.time() - t0)
 
 

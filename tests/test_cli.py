@@ -96,4 +96,8 @@ def test_cli_reconstruct_sample_roundtrip(tmp_path, device, precision):
         assert torch.isfinite(v3.image).all() and abs(float(v3.image[v3.mask].mean()) - 700.0) < 1.0
         c_none, c_stack = fit(str(tmp_path / "out_slices"), str(tmp_path / "sim_slices")), fit(str(tmp_path / "out_slices3"), str(tmp_path / "sim_slices3"))
         print(f"slice fit (correlation): --registration none {c_none:.4f}, stack {c_stack:.4f}")
+        # the `register` command alone: stacks -> registered slices on disk, usable as --input-slices
+        cli.main(["register", "--input-stacks", *paths, "--thicknesses", "3", "3", "3", "--output-slices", str(tmp_path / "reg_slices"),
+                  "--verbose", "0"])
+        assert len(load_slices(str(tmp_path / "reg_slices"), device)) == n_out
         assert c_stack > c_none - 0.03  # a mis-registered stack could not be fitted by one volume
