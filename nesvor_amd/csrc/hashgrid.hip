@@ -311,6 +311,8 @@ struct BwdPlan {
   uint64_t rec_off[NESVOR_MAX_LEVELS];         // first record of the level's queues
   uint32_t n_sub;                              // sub-queues per bucket = XCCs of the device partition (1, 2, 4 or 8)
   uint32_t box_slots;                          // 0: the merge table is always hashed (A/B switch NESVOR_HASHGRID_BOX=0)
+  int32_t level_begin, level_end;              // this launch handles levels [level_begin, level_end) (all by default)
+  int32_t accumulate_u;                        // input gradient: add to grad_u instead of overwriting (later launches of a split backward)
 };
 
 __device__ __forceinline__ uint32_t spread3(uint32_t x) {  // 8 bits -> every third bit
@@ -542,14 +544,15 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
   uint32_t idx[8], idx_n[8];
   float val[8][F], val_n[8][F];
   bool tail, tail_n = false;
-  load_dy(0, dy_a);
-  if (g.n_levels > 1) load_dy(1, dy_b);
-  prepare(0, dy_a, idx, val, tail);
-  if constexpr (MERGE) __syncthreads();  // wmax of level 0 must be visible to the other waves
+  const int level_end = plan.level_end;
+  load_dy(plan.level_begin, dy_a);
+  if (plan.level_begin + 1 < level_end) load_dy(plan.level_begin + 1, dy_b);
+  prepare(plan.level_begin, dy_a, idx, val, tail);
+  if constexpr (MERGE) __syncthreads();  // wmax of the first level must be visible to the other waves
   // Merging is on for a prefix of the levels (merge_off is set once, workgroup-uniformly, before a barrier): two
   // loops in sequence rather than a branch inside one loop, so that the compiler cannot hoist the common second
   // half of the two paths above the branch (which made everything of the next level live during the insertion).
-  int level = 0;
+  int level = plan.level_begin;
   bool merge = MERGE;
   bool box = false;
   uint32_t bvol = 0, bx0 = 0, by0 = 0, bz0 = 0, bnx = 1, bnxy = 1;
@@ -579,10 +582,10 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         merge_stat[0] = 0; merge_stat[1] = 0;
       }
       // ... and hide its latency behind the next level's register-only work
-      if (level + 1 < g.n_levels) {
+      if (level + 1 < level_end) {
 #pragma unroll
         for (int f = 0; f < F; ++f) dy_a[f] = dy_b[f];
-        if (level + 2 < g.n_levels) load_dy(level + 2, dy_b);
+        if (level + 2 < level_end) load_dy(level + 2, dy_b);
         prepare(level + 1, dy_a, idx_n, val_n, tail_n);
       }
       if (tid < nb) bbase[level & 1][tid] = my_base;
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       tail = tail_n;
     };
     if constexpr (MERGE) {
-     for (; level < g.n_levels && merge_off == 0u; ++level) {
+     for (; level < level_end && merge_off == 0u; ++level) {
       constexpr int NR = kSlots / 256;
       uint32_t rkey[NR], rank[NR], rmask = 0;
       float rval[NR][F];
@@ -736,7 +739,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
      }
     }
     merge = false;
-    for (; level < g.n_levels; ++level) {
+    for (; level < level_end; ++level) {
       // rank of every record inside its chunk's span (LDS integer atomics: ~6 cycles / wave-instruction)
       uint32_t rank[8];
 #pragma unroll
@@ -746,7 +749,10 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
     }
   }
   if constexpr (INPUT_GRAD) {
-    if (valid) { grad_u[3 * i] = gux; grad_u[3 * i + 1] = guy; grad_u[3 * i + 2] = guz; }
+    if (valid) {
+      if (plan.accumulate_u) { gux += grad_u[3 * i]; guy += grad_u[3 * i + 1]; guz += grad_u[3 * i + 2]; }
+      grad_u[3 * i] = gux; grad_u[3 * i + 1] = guy; grad_u[3 * i + 2] = guz;
+    }
   }
 }
 
@@ -772,6 +778,7 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
     if (wg < cnt || level + 1 >= g.n_levels) break;
     wg -= cnt;
   }
+  if (level < plan.level_begin || level >= plan.level_end) return;  // split backward: another launch owns this level
   const uint32_t chunk = wg / spl, slice = wg % spl;
   const uint32_t gb = plan.bucket_base[level] + chunk;
   // the bucket's records = the concatenation of its sub-queues; record r of that virtual queue sits at
@@ -940,6 +947,7 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
   plan->n_buckets = nb;
   static const uint32_t box = []() { const char* e = getenv("NESVOR_HASHGRID_BOX"); return (e == nullptr || atoi(e) != 0) ? 1u : 0u; }();
   plan->box_slots = box;
+  plan->level_begin = 0; plan->level_end = g->n_levels; plan->accumulate_u = 0;
   *n_records = off;
   return true;
 }
@@ -948,17 +956,21 @@ constexpr uint64_t kTailBytes = (uint64_t)kSubQueues * kTailStride * sizeof(uint
 
 template <int F, int LAYOUT>
 int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table, const float* dpe, float* gt,
-                     float* gu, int64_t N, void* workspace, int stages, hipStream_t st) {
+                     float* gu, int64_t N, void* workspace, int stages, int level_begin, int level_end, hipStream_t st) {
   BwdPlan plan;
   uint64_t n_rec;
   if (!make_plan(g, N, &plan, &n_rec)) return (int)hipErrorInvalidValue;
+  plan.level_begin = level_begin; plan.level_end = level_end;
+  plan.accumulate_u = (stages & 8) ? 1 : 0;
   uint32_t* tails = reinterpret_cast<uint32_t*>(workspace);
   uint32_t* records = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + kTailBytes);
   dim3 grid((unsigned)((N + 255) / 256)), block(256);
   hipError_t e;
   if (!(stages & 1)) goto owner_stage;
-  e = hipMemsetAsync(tails, 0, kTailBytes, st);
-  if (e != hipSuccess) return (int)e;
+  if (!(stages & 4)) {  // bit 4: a later launch of a split backward - the queue tails of its levels are still zero
+    e = hipMemsetAsync(tails, 0, kTailBytes, st);
+    if (e != hipSuccess) return (int)e;
+  }
   {
     static const bool merge = []() { const char* e = getenv("NESVOR_HASHGRID_MERGE"); return e == nullptr || atoi(e) != 0; }();
 #define NESVOR_LAUNCH_AGG(IG, MG)                                                                                     \
@@ -1053,6 +1065,17 @@ extern "C" int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* 
   if (N <= 0) return 0;
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
   if (workspace == nullptr || (stages & 3) == 0) return (int)hipErrorInvalidValue;
-  DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages,
+  DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages & 3, 0, grid->n_levels,
+                    (hipStream_t)stream);
+}
+
+extern "C" int nesvor_hashgrid_backward_levels(const nesvor_grid_t* grid, const float* u, const float* table,
+                                               const float* dpe, float* grad_table, float* grad_u, int64_t N, int layout,
+                                               void* workspace, int stages, int level_begin, int level_end, void* stream) {
+  if (N <= 0) return 0;
+  if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
+  if (workspace == nullptr || (stages & 3) == 0) return (int)hipErrorInvalidValue;
+  if (level_begin < 0 || level_end > grid->n_levels || level_begin >= level_end) return (int)hipErrorInvalidValue;
+  DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages, level_begin, level_end,
                     (hipStream_t)stream);
 }

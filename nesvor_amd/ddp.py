@@ -5,14 +5,17 @@ The reference is single-process; this is the build's addition
 (SURVEY.md §8e).  Every rank holds all parameters and the whole flat data set,
 draws the same permutation (same seed) and takes its own slice of each global
 batch; per-rank PSF noise differs (seed + rank).  The only exchange step per
-iteration is ONE all-reduce over the contiguous flat gradient buffer
-(hash table first, ~30 MB fp32, then the small MLP / per-slice gradients).
+iteration is the sum-all-reduce of the flat gradient buffer (small MLP / per-slice
+gradients first, then the hash table, ~30 MB fp32, coarse levels before fine ones).
 
 xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU): a ring all-reduce
 of the 30 MB buffer moves 2(W-1)/W x 30 MB per GPU through single links
-(~0.34 ms at W=8), comparable to a fast iteration, so the buffer can be reduced
-in ``n_buckets`` chunks launched asynchronously on RCCL's stream while the
-optimiser processes finished chunks (see FusedTrainer.optimizer_step).
+(~0.34 ms at W=8), comparable to a fast iteration.  The autograd-free step
+(nesvor_amd.direct) therefore runs the hash-grid backward in two launches: the fine
+levels - half of the table's bytes, the end of the flat buffer - first; their
+all-reduce starts at once on RCCL's stream and overlaps the coarse levels' launch;
+the rest of the buffer (one contiguous range) follows when the step's gradients are
+complete (FusedTrainer.optimizer_step).  NESVOR_DDP_OVERLAP=0 = one all-reduce.
 """
 import os
 from typing import Dict, Optional

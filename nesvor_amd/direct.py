@@ -86,9 +86,29 @@ class DirectStep:
             self.bf16 = True
         else:
             self.bf16 = mlp_mod.MFMA_FP32 if getattr(a, "mlp_fp32_mfma", False) else False
+        import os
+
         import torch.distributed as dist
 
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # Data parallel: the hash-grid backward runs in two launches - the fine levels (about half of the table's bytes,
+        # the END of the flat buffer) first; their all-reduce is started at once and overlaps the coarse levels' launch
+        # (NESVOR_DDP_OVERLAP=0: one launch, one all-reduce after the step)
+        self._early = None
+        self.split_level = 0
+        if self.world > 1 and os.environ.get("NESVOR_DDP_OVERLAP", "1") != "0":
+            spec = model.inr.encoding.spec
+            F = spec.n_features
+            total = spec.n_params // F
+            if spec.n_levels > 1:
+                self.split_level = min(range(1, spec.n_levels), key=lambda l: abs(spec.levels[l].offset - total / 2))
+                off, cnt = flat.offsets["inr.encoding.params"]
+                self._early_range = (off + spec.levels[self.split_level].offset * F, off + cnt)
+
+    def take_early_reduce(self):
+        """(work handles, start, end) of the flat-gradient range whose all-reduce this step has already started, or None."""
+        early, self._early = self._early, None
+        return early
 
     @torch.no_grad()
     def run(self, xyz, v, slice_idx, noise=None) -> Dict[str, torch.Tensor]:
@@ -184,8 +204,19 @@ class DirectStep:
             dpe[: self.kb_bias] += dpe_b
             if dxa is None:
                 dxa, dxa_b = dxa_b, None
-        _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, enc.params.grad.view(-1), self.opt_T,
-                                  _lib.LAYOUT_FEATURE_MAJOR)
+        gt = enc.params.grad.view(-1)
+        if self.split_level:
+            from . import ddp
+
+            L = enc.spec.n_levels
+            _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR,
+                                      levels=(self.split_level, L))
+            a, b = self._early_range
+            self._early = (ddp.allreduce_flat_(self.flat.grad[a:b]), a, b)  # async: RCCL's stream, behind the launch above
+            _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR,
+                                      levels=(0, self.split_level), grad_u=du, first=False)
+        else:
+            _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR)
         dpix = sampler.backward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb, dxl, du) if self.opt_T else None
 
         # ---- per-slice parameters ---------------------------------------------------------------------------

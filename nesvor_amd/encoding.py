@@ -41,28 +41,39 @@ def _workspace(spec, N, device):
 
 
 def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True, layout=_lib.LAYOUT_ROW_MAJOR,
-                      method="owner"):
+                      method="owner", levels=None, grad_u=None, first=True):
     """Accumulates into grad_table (allocated zero-filled if None); returns (grad_table, grad_u|None).
-    method: "owner" (LDS aggregation + per-chunk owners, the MI355X path) or "atomic" (per-corner atomics)."""
+    method: "owner" (LDS aggregation + per-chunk owners, the MI355X path) or "atomic" (per-corner atomics).
+    levels = (begin, end): only these levels ("owner" method) - a data-parallel step splits the backward in two so
+    that the all-reduce of the first part overlaps the second; later parts pass the first part's ``grad_u`` and
+    ``first=False`` (queue tails are not reset, the input gradient is added)."""
     _lib.require_device(u, table, dpe, dtype=torch.float32, name="hashgrid backward input")
     N = u.shape[0]
     if grad_table is None:
         grad_table = torch.zeros_like(table)
-    grad_u = torch.empty_like(u) if need_input_grad else None
+    if grad_u is None:
+        if not first and need_input_grad:
+            raise RuntimeError("a later part of a split backward needs the first part's grad_u")
+        grad_u = torch.empty_like(u) if need_input_grad else None
     lib = _lib.load()
     ws = _workspace(spec, N, u.device) if method == "owner" else None
+    if levels is not None and ws is None:
+        raise RuntimeError("level ranges exist for the owner method only")
     with torch.cuda.device(u.device):
         if ws is not None:
             args = (ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(dpe), _lib.ptr(grad_table),
                     _lib.ptr(grad_u), N, layout, _lib.ptr(ws))
+            l0, l1 = (0, spec.n_levels) if levels is None else levels
+            extra = 0 if first else (4 | 8)  # keep the queue tails, add to grad_u
+            call = lambda stage: lib.nesvor_hashgrid_backward_levels(*args, stage | extra, l0, l1, _lib.stream_ptr())
             if _lib.kernel_timer.enabled:  # bracket each of the two launches with its own events
                 with _lib.kernel_timer.span("hashgrid_bwd_aggregate"):
-                    err = lib.nesvor_hashgrid_backward(*args, 1, _lib.stream_ptr())
+                    err = call(1)
                 if err == 0:
                     with _lib.kernel_timer.span("hashgrid_bwd_owner"):
-                        err = lib.nesvor_hashgrid_backward(*args, 2, _lib.stream_ptr())
+                        err = call(2)
             else:
-                err = lib.nesvor_hashgrid_backward(*args, 3, _lib.stream_ptr())
+                err = call(3)
         else:
             err = lib.nesvor_hashgrid_backward_atomic(
                 ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(dpe), _lib.ptr(grad_table),

@@ -22,11 +22,12 @@ class FlatParams:
 
     def __init__(self, module: torch.nn.Module):
         named = [(n, p) for n, p in module.named_parameters() if p.numel() > 0]
-        # the big table first, everything else in definition order (so each MLP's W0,b0,W1,b1,... stay
-        # adjacent: nesvor_amd.direct sums the kernels' partial gradients straight into that segment);
+        # everything in definition order (so each MLP's W0,b0,W1,b1,... stay adjacent: nesvor_amd.direct sums the
+        # kernels' partial gradients straight into that segment), the big table LAST: its fine levels - the end of the
+        # buffer - are the part a data-parallel step all-reduces early, and what remains is one contiguous range;
         # 16-byte aligned segments so float4 access never straddles a tensor
         biggest = max(p.numel() for _, p in named)
-        named.sort(key=lambda kv: 0 if kv[1].numel() == biggest else 1)
+        named.sort(key=lambda kv: 1 if kv[1].numel() == biggest else 0)
         self.names, self.offsets, total = [], {}, 0
         for n, p in named:
             self.offsets[n] = (total, p.numel())
@@ -91,7 +92,17 @@ class FusedTrainer:
 
     def optimizer_step(self) -> None:
         if self.reduce_hook is not None:
-            self.reduce_hook(self.flat.grad)
+            early = self.direct.take_early_reduce() if self.direct is not None else None
+            if early is not None:  # [start, end) of the flat gradient is already being all-reduced (nesvor_amd.direct)
+                works, start, end = early
+                if start > 0:
+                    self.reduce_hook(self.flat.grad[:start])
+                if end < self.flat.numel:
+                    self.reduce_hook(self.flat.grad[end:])
+                for w in works:
+                    w.wait()
+            else:
+                self.reduce_hook(self.flat.grad)
         self.t += 1
         b1, b2 = self.betas
         f = self.flat

@@ -294,11 +294,11 @@ def test_sample_volume_runs_and_matches_inr(device, golden):
     torch.testing.assert_close(v, ref)
 
 
-def _ddp_train_worker(rank, world, port, out_dir):
+def _ddp_train_worker(rank, world, port, out_dir, overlap="1"):
     import os
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), NESVOR_DIST_BACKEND="gloo", NESVOR_SINGLE_DEVICE="1")
+                      LOCAL_RANK=str(rank), NESVOR_DIST_BACKEND="gloo", NESVOR_SINGLE_DEVICE="1", NESVOR_DDP_OVERLAP=overlap)
     import torch.distributed as dist
 
     from nesvor_amd import ddp
@@ -314,7 +314,7 @@ def _ddp_train_worker(rank, world, port, out_dir):
     torch.manual_seed(0)
     inr, out_slices, mask = train(slices, args)
     sd = {k: v.detach().cpu() for k, v in inr.state_dict().items()}
-    torch.save(sd, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.save(sd, os.path.join(out_dir, f"rank{rank}_overlap{overlap}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -332,9 +332,19 @@ def test_train_data_parallel_two_ranks_stay_in_sync(device, tmp_path):
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_ddp_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    a = torch.load(tmp_path / "rank0.pt")
-    b = torch.load(tmp_path / "rank1.pt")
+    a = torch.load(tmp_path / "rank0_overlap1.pt")
+    b = torch.load(tmp_path / "rank1_overlap1.pt")
     assert a.keys() == b.keys()
     for k in a:
         assert torch.equal(a[k], b[k]), k
     assert all(torch.isfinite(v).all() for v in a.values())
+    # the default splits the hash-grid backward by levels and starts the all-reduce of the fine levels early; one launch +
+    # one all-reduce (NESVOR_DDP_OVERLAP=0) must train the same model (the input gradient is summed in another order)
+    s2 = socket.socket()
+    s2.bind(("127.0.0.1", 0))
+    port2 = s2.getsockname()[1]
+    s2.close()
+    mp.spawn(_ddp_train_worker, args=(2, port2, str(tmp_path), "0"), nprocs=2, join=True)
+    c = torch.load(tmp_path / "rank0_overlap0.pt")
+    for k in a:
+        torch.testing.assert_close(a[k], c[k], rtol=2e-3, atol=2e-5, msg=k)
