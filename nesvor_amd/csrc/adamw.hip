@@ -71,31 +71,38 @@ extern "C" int nesvor_adamw_step(float* param, float* grad, float* exp_avg, floa
   return (int)hipGetLastError();
 }
 
-// out[c] = sum_r in[r * ld + c], c < cols (ld = row pitch of `in` in floats, so a column range of a wider matrix can be summed): the per-workgroup partial parameter gradients of the MLP backward -> gradient segment.
-// 64 columns x 4 row groups per workgroup, rows read as 256-byte segments, four-way LDS reduction.
+// out[c] = sum_r in[r * ld + c], c < cols (ld = row pitch of `in` in floats, so a column range of a wider matrix can be summed):
+// the per-workgroup partial parameter gradients of the MLP backward -> gradient segment.
+// 64 columns x 16 row groups per workgroup (1024 threads: the matrix has only ~100 column blocks, so the rows carry the
+// parallelism), rows read as 256-byte segments, LDS reduction over the row groups.
 namespace {
-__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int ld) {
-  __shared__ float red[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+constexpr int kSumRowGroups = 16;
+__global__ __launch_bounds__(64 * kSumRowGroups) void sum_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int ld) {
+  __shared__ float red[kSumRowGroups][64];
+  const int lane = threadIdx.x & 63, col = blockIdx.x * 64 + lane, rg = threadIdx.x >> 6;
+  float a0 = 0.f, a1 = 0.f;
   if (col < cols) {
     int r = rg;
-    for (; r + 12 < rows; r += 16) {
-      a0 += in[(size_t)r * ld + col]; a1 += in[(size_t)(r + 4) * ld + col];
-      a2 += in[(size_t)(r + 8) * ld + col]; a3 += in[(size_t)(r + 12) * ld + col];
+    for (; r + kSumRowGroups < rows; r += 2 * kSumRowGroups) {
+      a0 += in[(size_t)r * ld + col]; a1 += in[(size_t)(r + kSumRowGroups) * ld + col];
     }
-    for (; r < rows; r += 4) a0 += in[(size_t)r * ld + col];
+    for (; r < rows; r += kSumRowGroups) a0 += in[(size_t)r * ld + col];
   }
-  red[rg][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+  red[rg][lane] = a0 + a1;
   __syncthreads();
-  if (rg == 0 && col < cols) out[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (rg == 0 && col < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < kSumRowGroups; ++g) s += red[g][lane];
+    out[col] = s;
+  }
 }
 }  // namespace
 
 extern "C" int nesvor_sum_rows(const float* in, float* out, int rows, int cols, int ld, void* stream) {
   if (rows <= 0 || cols <= 0) return 0;
   if (ld < cols) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols, ld);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(64 * kSumRowGroups), 0, (hipStream_t)stream, in, out, rows, cols, ld);
   return (int)hipGetLastError();
 }
 
