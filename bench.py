@@ -226,7 +226,11 @@ def main():
             # the hash-grid backward is two launches (aggregation pass + owner pass): one operation, one roofline entry
             kt = {k: v[1] for k, v in ktimes.items()}
             if "hashgrid_bwd_aggregate" in kt:
-                kt["hashgrid_bwd"] = kt["hashgrid_bwd_aggregate"] + kt.get("hashgrid_bwd_owner", 0.0)
+                # per step: under torch.distributed the backward is split by levels into two aggregation + two owner
+                # launches (the all-reduce of the first part overlaps the second), so sum the launches of one step
+                per_step = lambda k: ktimes[k][0] * ktimes[k][1] / opt.steps if k in ktimes else 0.0
+                kt["hashgrid_bwd_aggregate"], kt["hashgrid_bwd_owner"] = per_step("hashgrid_bwd_aggregate"), per_step("hashgrid_bwd_owner")
+                kt["hashgrid_bwd"] = kt["hashgrid_bwd_aggregate"] + kt["hashgrid_bwd_owner"]
             dom = max((k for k in kt if k in bytes_pt), key=lambda k: kt[k])
             ms = kt[dom]
             achieved = bytes_pt[dom] * n_points / (ms * 1e-3) / 1e9
