@@ -95,15 +95,21 @@ class DirectStep:
         # the END of the flat buffer) first; their all-reduce is started at once and overlaps the coarse levels' launch
         # (NESVOR_DDP_OVERLAP=0: one launch, one all-reduce after the step)
         self._early = None
-        self.split_level = 0
+        self.split_level = 0  # 0 = one launch; set by set_overlap() once a gradient all-reduce is installed
+        self._split_candidate = 0
         if self.world > 1 and os.environ.get("NESVOR_DDP_OVERLAP", "1") != "0":
             spec = model.inr.encoding.spec
             F = spec.n_features
             total = spec.n_params // F
             if spec.n_levels > 1:
-                self.split_level = min(range(1, spec.n_levels), key=lambda l: abs(spec.levels[l].offset - total / 2))
+                self._split_candidate = min(range(1, spec.n_levels), key=lambda l: abs(spec.levels[l].offset - total / 2))
                 off, cnt = flat.offsets["inr.encoding.params"]
-                self._early_range = (off + spec.levels[self.split_level].offset * F, off + cnt)
+                self._early_range = (off + spec.levels[self._split_candidate].offset * F, off + cnt)
+
+    def set_overlap(self, on: bool) -> None:
+        """Split the hash-grid backward and start the fine levels' all-reduce early (FusedTrainer turns this on when a
+        reduce hook is installed: the hook's owner then finishes the reduction in optimizer_step)."""
+        self.split_level = self._split_candidate if on else 0
 
     def take_early_reduce(self):
         """(work handles, start, end) of the flat-gradient range whose all-reduce this step has already started, or None."""

@@ -63,13 +63,23 @@ class FusedTrainer:
         self.betas, self.eps, self.weight_decay = (0.9, 0.99), 1e-15, 1e-2
         self.t = 0
         self.world_size = world_size
-        self.reduce_hook = None  # set by ddp: callable(flat_grad) performing the all-reduce(sum)
+        self._reduce_hook = None  # set by ddp: callable(flat_grad) performing the all-reduce(sum)
         # autograd-free evaluation of the iteration when the configuration allows it (nesvor_amd.direct)
         from . import direct
 
         self.direct = direct.DirectStep(model, self.flat, self.weights) if direct.supported(model) else None
         if getattr(args, "mlp_bf16", False) and self.direct is None:
             raise RuntimeError("args.mlp_bf16 needs the autograd-free step (fused fp32 model, MLPs of at most two hidden layers)")
+
+    @property
+    def reduce_hook(self):
+        return self._reduce_hook
+
+    @reduce_hook.setter
+    def reduce_hook(self, hook) -> None:
+        self._reduce_hook = hook
+        if self.direct is not None:
+            self.direct.set_overlap(hook is not None)
 
     def decay_lr(self, gamma: float) -> None:
         self.lr *= gamma
