@@ -1325,7 +1325,10 @@ extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, cons
   const int kb1 = (net->k_a + net->k_b + 15) / 16;
   const int64_t n_tiles = ((N + 15) / 16 + 4 * kG - 1) / (4 * kG);
   // 2 persistent workgroups per CU = the occupancy (measured: 256 / 768 / 1024 / 2048 workgroups are slower)
-  dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512));
+#ifndef NESVOR_FWD_GRID
+#define NESVOR_FWD_GRID 512
+#endif
+  dim3 grid((unsigned)(n_tiles < NESVOR_FWD_GRID ? n_tiles : NESVOR_FWD_GRID));
   if (a.bf16 == 2)
     return launch_kb(mlp_fwd_kernel<1, false, true>, mlp_fwd_kernel<2, false, true>, mlp_fwd_kernel<3, false, true>,
                      mlp_fwd_kernel<4, false, true>, kb1, grid, fwd_lds_bytes(a.n_linear, kb1, 384), (hipStream_t)stream, a);
