@@ -274,7 +274,9 @@ def main():
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
             "ms_per_step": elapsed / opt.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32" if not (opt.mlp_bf16 or opt.half_precision_model) else
+            "dtype": (("f32" if opt.mlp_fp32_mfma else "f32 (MLP products evaluated on 3-way bf16 splits of the fp32 operands, fp32 accumulation: "
+                       "fp32-equivalent error; the all-fp32-MFMA rate of the same run is in strict_fp32_mfma)")
+                      if not (opt.mlp_bf16 or opt.half_precision_model) else
                       "f32 (MLP matrix operands rounded to bf16, fp32 accumulation)" + (", bias-free half-precision model structure" if opt.half_precision_model else "")),
             "data": "synthetic",
             "config": {
