@@ -36,6 +36,7 @@
 //   result is exact for any input distribution.  The legacy all-atomics
 //   kernel is kept as hashgrid_bwd (used for tiny N and as a cross-check).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "common.h"
 #include "../../include/nesvor_hip.h"
 
@@ -560,7 +561,9 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
     // Second half of a level, specialised on the number NR of records a thread can hold (table slots per thread in
     // merge mode, the 8 corners otherwise) so that the merge path does not carry 8 record registers sets through the
     // next level's prepare(): reserve queue space, prepare the next level, write the records.
-    auto finish_level = [&](auto& rkey, auto& rank, auto& rval, uint32_t rmask) __attribute__((always_inline)) {
+    // in_place: the current level's idx / val are dead (merge path: the records were drained from the table), so the
+    // next level is prepared straight into them - no copy at the end of the level
+    auto finish_level = [&](auto& rkey, auto& rank, auto& rval, uint32_t rmask, auto in_place) __attribute__((always_inline)) {
       constexpr int NR = sizeof(rkey) / sizeof(rkey[0]);
       __syncthreads();
       // reserve queue space: one returning (memory-side, ~2 us) atomic per non-empty chunk ...
@@ -586,7 +589,8 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
 #pragma unroll
         for (int f = 0; f < F; ++f) dy_a[f] = dy_b[f];
         if (level + 2 < level_end) load_dy(level + 2, dy_b);
-        prepare(level + 1, dy_a, idx_n, val_n, tail_n);
+        if constexpr (decltype(in_place)::value) prepare(level + 1, dy_a, idx, val, tail);
+        else prepare(level + 1, dy_a, idx_n, val_n, tail_n);
       }
       if (tid < nb) bbase[level & 1][tid] = my_base;
       __syncthreads();
@@ -652,7 +656,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
           // (the clamp only matters for NaN coordinates, which fall outside every box: keeps the adds inside the table)
           const uint32_t slot = min(s0 + (k & 1) + ((k >> 1) & 1) * bnx + (k >> 2) * bnxy, (uint32_t)kSlots - 1u);
 #pragma unroll
-          for (int f = 0; f < F; ++f) atomicAdd(&tvals[slot * F + f], to_fixed(val[k][f] * fscale));
+          for (int f = 0; f < F; ++f) atomicAdd(&tvals[f * kSlots + slot], to_fixed(val[k][f] * fscale));
         }
       } else if (tail) {
         uint32_t h[8];
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
             for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + idx[k]) * F + f, val[k][f]);
           } else {
 #pragma unroll
-            for (int f = 0; f < F; ++f) atomicAdd(&tvals[h[k] * F + f], to_fixed(val[k][f] * fscale));
+            for (int f = 0; f < F; ++f) atomicAdd(&tvals[f * kSlots + h[k]], to_fixed(val[k][f] * fscale));
           }
         }
       }
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
           key = corner_index(pl, bx0 + (r - y * bnx), by0 + y, bz0 + z);
           occupied = false;
 #pragma unroll
-          for (int f = 0; f < F; ++f) occupied = occupied || tvals[slot * F + f] != 0ull;
+          for (int f = 0; f < F; ++f) occupied = occupied || tvals[f * kSlots + slot] != 0ull;
         } else {
           key = tkeys[slot];
           occupied = key != kEmpty;
@@ -725,8 +729,8 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
           rmask |= 1u << j; rkey[j] = key;
 #pragma unroll
           for (int f = 0; f < F; ++f) {
-            rval[j][f] = from_fixed(tvals[slot * F + f]) * finv;
-            tvals[slot * F + f] = 0ull;
+            rval[j][f] = from_fixed(tvals[f * kSlots + slot]) * finv;
+            tvals[f * kSlots + slot] = 0ull;
           }
           rank[j] = atomicAdd(&bcount[key >> plan.chunk_shift], 1u);
           ++mine;
@@ -734,8 +738,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       }
       const uint32_t wave_mine = (uint32_t)wave_sum_u32(mine);
       if (lane == 0 && wave_mine) atomicAdd(&merge_stat[1], wave_mine);
-      finish_level(rkey, rank, rval, rmask);
-      advance();
+      finish_level(rkey, rank, rval, rmask, std::true_type{});
      }
     }
     merge = false;
@@ -744,7 +747,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       uint32_t rank[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) rank[k] = tail ? atomicAdd(&bcount[idx[k] >> plan.chunk_shift], 1u) : 0u;
-      finish_level(idx, rank, val, tail ? 0xFFu : 0u);
+      finish_level(idx, rank, val, tail ? 0xFFu : 0u, std::false_type{});
       advance();
     }
   }
