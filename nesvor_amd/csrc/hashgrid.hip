@@ -533,10 +533,16 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       if constexpr (F >= 4) { NESVOR_FENCE8(2); NESVOR_FENCE8(3); }
       if constexpr (F >= 8) { NESVOR_FENCE8(4); NESVOR_FENCE8(5); NESVOR_FENCE8(6); NESVOR_FENCE8(7); }
 #undef NESVOR_FENCE8
+      // a step only does something for lanes that have not yet seen the head of their run: at the fine levels runs
+      // are one to three lanes long and the wide steps are skipped (wave-uniform test)
       NESVOR_SCAN_STEP(1, 0x111)
-      NESVOR_SCAN_STEP(2, 0x112)
-      NESVOR_SCAN_STEP(4, 0x114)
-      NESVOR_SCAN_STEP(8, 0x118)
+      if (__ballot(flag == 0)) {
+        NESVOR_SCAN_STEP(2, 0x112)
+        if (__ballot(flag == 0)) {
+          NESVOR_SCAN_STEP(4, 0x114)
+          if (__ballot(flag == 0)) NESVOR_SCAN_STEP(8, 0x118)
+        }
+      }
     }
 #undef NESVOR_SCAN_STEP
   };
