@@ -374,6 +374,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
                                       // the drain only walks what can be occupied
   __shared__ uint32_t merge_off;      // set once merging stops paying: finer levels skip the table
   __shared__ float ubox[4][6];        // per wave min / max of the samples' coordinates
+  __shared__ uint32_t lbox[NESVOR_MAX_LEVELS][6];  // per level: first cell (x,y,z) and cells spanned - 1 of the workgroup's samples
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t base = (int64_t)blockIdx.x * 256;
   const int E = g.n_levels * F;
@@ -449,6 +450,14 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       ulo[d] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ulo[d])));
       uhi[d] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, uhi[d])));
     }
+    // the lattice boxes of all levels at once (thread l: level l) instead of two locate() per level in every thread
+    if (tid < g.n_levels) {
+      const LevelParams p = load_level(g, tid);
+      const CellPos blo = locate(p, ulo[0], ulo[1], ulo[2]), bhi = locate(p, uhi[0], uhi[1], uhi[2]);
+      lbox[tid][0] = blo.gx; lbox[tid][1] = blo.gy; lbox[tid][2] = blo.gz;
+      lbox[tid][3] = bhi.gx - blo.gx; lbox[tid][4] = bhi.gy - blo.gy; lbox[tid][5] = bhi.gz - blo.gz;  // (wrap if out of range)
+    }
+    __syncthreads();
   }
 
   auto load_dy = [&](int level, float (&dy)[F]) __attribute__((always_inline)) {
@@ -644,10 +653,9 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       // the vertex's position inside the box - no keys, no compare-and-swap claims, no probing (a third of the LDS
       // atomics of the hashed table); the drain recomputes the entry index from the slot number.
       const LevelParams pl = load_level(g, level);
-      const CellPos blo = locate(pl, ulo[0], ulo[1], ulo[2]), bhi = locate(pl, uhi[0], uhi[1], uhi[2]);
       auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };  // wave-uniform values
-      bx0 = sgpr(blo.gx); by0 = sgpr(blo.gy); bz0 = sgpr(blo.gz);
-      const uint32_t ex = sgpr(bhi.gx) - bx0, ey = sgpr(bhi.gy) - by0, ez = sgpr(bhi.gz) - bz0;  // cells spanned - 1 (wraps if out of range)
+      bx0 = sgpr(lbox[level][0]); by0 = sgpr(lbox[level][1]); bz0 = sgpr(lbox[level][2]);
+      const uint32_t ex = sgpr(lbox[level][3]), ey = sgpr(lbox[level][4]), ez = sgpr(lbox[level][5]);  // cells spanned - 1
       const uint32_t bdx = ex + 2u, bdy = ey + 2u, bdz = ez + 2u;
       box = plan.box_slots != 0u && ex < (uint32_t)kSlots && ey < (uint32_t)kSlots && ez < (uint32_t)kSlots &&
             (uint64_t)bdx * bdy * bdz <= (uint64_t)kSlots;
