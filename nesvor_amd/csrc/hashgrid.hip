@@ -46,6 +46,9 @@
 #define NESVOR_ABLATE 0
 #endif
 #define NESVOR_ABL(bit) ((NESVOR_ABLATE & (bit)) != 0)
+#ifndef NESVOR_SORT_SPAN
+#define NESVOR_SORT_SPAN 256  // samples sorted together by Morton code: the whole workgroup (64 = per wave and 128: same time within 1 %)
+#endif
 
 namespace {
 
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
 #pragma unroll 1
     for (int rep = 0; rep < (NESVOR_ABL(1) ? 2 : 1); ++rep)
 #pragma unroll 1
-    for (int k = 2; k <= 256; k <<= 1) {
+    for (int k = 2; k <= NESVOR_SORT_SPAN; k <<= 1) {
 #pragma unroll 1
       for (int j = k >> 1; j > 0; j >>= 1) {
         uint32_t other;
