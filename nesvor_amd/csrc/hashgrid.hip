@@ -691,9 +691,12 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         for (int k = 0; k < 8; ++k) {
           if (pending & (1u << k)) {
             bool done = false;
+            // double hashing (key-dependent odd step): at level 15 the table is two thirds full and linear probing
+            // clusters (level 15: 0.067 -> 0.050 ms; probing all unresolved corners of a lane per round was slower)
+            const uint32_t step = ((idx[k] * 0x9E3779B1u) >> 20) | 1u;
 #pragma unroll 1
             for (int probe = 0; probe < 64 && !done; ++probe) {
-              h[k] = (h[k] + 1) & smask;
+              h[k] = (h[k] + step) & smask;
               const uint32_t pv = atomicCAS(&tkeys[h[k]], kEmpty, idx[k]);
               done = pv == kEmpty || pv == idx[k];
             }
