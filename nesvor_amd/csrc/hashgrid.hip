@@ -10,10 +10,11 @@
 //   SGPRs, and the dispatcher walks the levels one after another: at any time
 //   the chip works on one or two levels whose table slice (<= 4 MiB at
 //   T = 2^19, F = 2) is what the per-XCD L2s hold.
-// * one thread per (sample, level); the 8 corner fetches are 8 independent
-//   F*4-byte loads in flight per lane; samples of one pixel are contiguous
-//   (layout (B,S,.)), so a 64-lane wave covers one PSF cloud: coarse levels
-//   collapse to a handful of distinct cache lines per load instruction.
+// * one thread per (sample, level); samples of one pixel are contiguous
+//   (layout (B,S,.)), so a 256-thread workgroup covers one PSF cloud.  Where
+//   the lattice box of its cells at the level has <= 1024 vertices, the box is
+//   copied into LDS once and the 8 corner fetches are LDS reads; otherwise
+//   they are 8 independent F*4-byte global loads in flight per lane.
 // * encoded features are produced/consumed FEATURE-MAJOR (L*F, N) on the fused
 //   path so that each lane writes/reads consecutive addresses (coalesced
 //   dwordx1/x2 streams); the row-major (N, L*F) layout tinycudann hands to
@@ -24,10 +25,14 @@
 //   The backward is therefore an owner-computes scatter in two launches:
 //     (1) hashgrid_bwd_aggregate: one workgroup per 256 consecutive samples
 //         (= one PSF cloud), sorted once by Morton code; per level a segmented
-//         wave scan on the VALU sums runs of lanes in the same cell, and the
-//         run tails' (entry, grad) records are binned by table chunk and
-//         appended to that chunk's queue in HBM (one LDS counter op per record,
-//         one returning atomic per non-empty (workgroup, chunk) pair);
+//         wave scan on the VALU sums runs of lanes in the same cell; the run
+//         tails go through a workgroup-wide merge table in LDS (64-bit fixed
+//         point; slots addressed by position in the cloud's lattice box where it
+//         fits, hashed with double hashing otherwise), and the merged (entry,
+//         grad) records are binned by table chunk and appended to that chunk's
+//         queue in HBM (one LDS counter op per record, one returning atomic per
+//         non-empty (workgroup, chunk) pair, on a counter set private to the
+//         XCC the workgroup runs on);
 //     (2) hashgrid_bwd_owner: one workgroup per table chunk accumulates its
 //         queue into LDS (integer-CAS adds: ds_add_f32 retires only ~1 lane
 //         per 3 cycles on gfx950) and adds the chunk to grad_table with
