@@ -217,8 +217,8 @@ class DirectStep:
             L = enc.spec.n_levels
             _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR,
                                       levels=(self.split_level, L))
-            a, b = self._early_range
-            self._early = (ddp.allreduce_flat_(self.flat.grad[a:b]), a, b)  # async: RCCL's stream, behind the launch above
+            lo, hi = self._early_range
+            self._early = (ddp.allreduce_flat_(self.flat.grad[lo:hi]), lo, hi)  # async: RCCL's stream, behind the launch above
             _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR,
                                       levels=(0, self.split_level), grad_u=du, first=False)
         else:

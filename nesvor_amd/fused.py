@@ -84,10 +84,10 @@ class FusedTrainer:
     def decay_lr(self, gamma: float) -> None:
         self.lr *= gamma
 
-    def _forward_backward(self, xyz, v, slice_idx) -> Dict[str, torch.Tensor]:
+    def _forward_backward(self, xyz, v, slice_idx, noise=None) -> Dict[str, torch.Tensor]:
         if self.direct is not None:
-            return self.direct.run(xyz, v, slice_idx)
-        losses = self.model(xyz, v, slice_idx)
+            return self.direct.run(xyz, v, slice_idx, noise)
+        losses = self.model(xyz, v, slice_idx) if noise is None else self.model.forward_with_noise(xyz, v, slice_idx, noise)
         loss = 0
         for k, val in losses.items():
             if k in self.weights and self.weights[k]:
@@ -95,8 +95,8 @@ class FusedTrainer:
         loss.backward()
         return losses
 
-    def step(self, xyz, v, slice_idx) -> Dict[str, torch.Tensor]:
-        losses = self._forward_backward(xyz, v, slice_idx)
+    def step(self, xyz, v, slice_idx, noise=None) -> Dict[str, torch.Tensor]:
+        losses = self._forward_backward(xyz, v, slice_idx, noise)
         self.optimizer_step()
         return losses
 

@@ -84,15 +84,19 @@ def load_nii_volume(path: str) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """image.py:274-294 -> (volume (D,H,W) float32, resolutions (x,y,z), affine (4,4))."""
     data, pixdim, sform, qform, hdr = nifti.load(path)
     dim = hdr["dim"]
-    if not (dim[0] == 3 or (dim[0] > 3 and all(d == 1 for d in dim[4 : 1 + dim[0]]))):
+    if not (dim[0] == 3 or (dim[0] > 3 and all(d == 1 for d in dim[4:]))):
         raise AssertionError("Expect a 3D volume but the input is %dD" % dim[0])
     while data.ndim > 3:
         data = data.squeeze(-1)
     affine = sform
     if np.any(np.isnan(affine)):
-        if qform is None:
-            raise ValueError(f"{path}: neither sform nor qform is set")
         affine = qform
+    if affine is None:
+        # neither sform nor qform coded (common for masks and converted data): the header's base affine, as nibabel's
+        # ``img.affine`` falls back to - voxel sizes on the diagonal, origin at the centre voxel
+        zooms = np.asarray(pixdim, dtype=np.float64)
+        affine = np.diag(np.append(zooms, 1.0))
+        affine[:3, 3] = -(np.asarray(data.shape[:3], dtype=np.float64) - 1) / 2 * zooms
     return np.ascontiguousarray(data.transpose(2, 1, 0)), pixdim, affine
 
 
@@ -155,16 +159,22 @@ def load_volume(path_vol: str, path_mask: Optional[str] = None, device=torch.dev
 
 # ---- checkpoint layout of `nesvor reconstruct --output-model` (cli/io.py:33-59) ------------------------------------
 def save_model(path: str, model, mask: Volume, args) -> None:
-    """torch.save({'model': state_dict, 'mask': Volume, 'args': Namespace}) as the reference writes it."""
-    torch.save({"model": model.state_dict(), "mask": mask, "args": args}, path)
+    """torch.save({'model': state_dict, 'mask': Volume, 'args': Namespace}) as the reference writes it (cli/io.py:38-47).
+    The mask's classes are recorded under the reference's import paths (``_ckpt_pickle``), so the file also loads in an
+    environment that has the reference installed."""
+    from . import _ckpt_pickle
+
+    torch.save({"model": model.state_dict(), "mask": mask, "args": args}, path, pickle_module=_ckpt_pickle)
 
 
 def load_model(path: str, device, args=None):
     """-> (INR with the stored weights, mask Volume moved to `device`, stored args (device / dtype overridden as the
-    reference does in cli/io.py:36-45))."""
+    reference does in cli/io.py:36-45)).  Accepts checkpoints written by the reference (its ``nesvor.image`` /
+    ``nesvor.transform`` classes resolve to this package's) as well as this package's own."""
+    from . import _ckpt_pickle
     from .models import INR
 
-    cp = torch.load(path, map_location=device, weights_only=False)
+    cp = torch.load(path, map_location=device, weights_only=False, pickle_module=_ckpt_pickle)
     stored = cp["args"]
     stored.device = device
     if args is not None:

@@ -261,3 +261,62 @@ def fused_mlp(seq: nn.Sequential, xa, xb, b_row0: int, k_b: int, samples_per_pix
     layers = linear_layers(seq)
     params = [l.weight for l in layers] + [l.bias for l in layers]
     return FusedMLPFunction.apply(xa, xb.contiguous(), b_row0, k_b, samples_per_pixel, len(layers), *params)
+
+
+class FlatNetworkFunction(Function):
+    """``tinycudann.Network`` (one flat bias-free parameter vector) on the fused kernels, bf16 matrix operands:
+    x (N, k) row-major -> y (N, n_output_dims).  The kernels read a feature-major input and write a feature-major
+    output; the two transposes are the price of tinycudann's row-major module interface (the training step proper
+    never pays it: nesvor_amd.direct feeds the kernels feature-major tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, params, net):
+        p = NetParams(net)
+        n = x.shape[0]
+        n_pad = (n + 15) // 16 * 16  # the bf16 backward exists for whole 16-sample groups only: pad with zero rows
+        xb = torch.zeros((x.shape[1], n_pad), dtype=torch.float32, device=x.device)
+        xb[:, :n] = x.detach().t()
+        need = any(ctx.needs_input_grad)
+        if need and (p.n_hidden() > 2 or (p.n_hidden() == 2 and x.shape[1] > 32)):
+            raise NotImplementedError("half-precision Network backward: built for 1-2 hidden layers (<= 32 inputs with 2)")
+        y, saved = forward_raw(p.weights, p.biases, None, xb, 0, xb.shape[0], 16, need, True)
+        ctx.net, ctx.n = net, n
+        ctx.save_for_backward(xb, *saved)
+        return y[:, :n].t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, *saved = ctx.saved_tensors
+        net, n = ctx.net, ctx.n
+        p = NetParams(net)
+        dyb = torch.zeros((dy.shape[1], xb.shape[1]), dtype=torch.float32, device=xb.device)
+        dyb[:, :n] = dy.t()
+        dxb = torch.empty_like(xb) if ctx.needs_input_grad[0] else None
+        _, partial = backward_raw(p.weights, p.biases, None, xb, dyb, saved, 0, xb.shape[0], 16, dxb, False, True)
+        g = None
+        if ctx.needs_input_grad[1]:
+            g = torch.zeros_like(net.params)
+            col, flat = 0, partial.sum(0)
+            for w, off in zip(p.weights, p.w_off):  # padding rows of the last layer keep a zero gradient
+                g[off : off + w.numel()] = flat[col : col + w.numel()]
+                col += w.numel() + w.shape[0]
+        return (None if dxb is None else dxb[:, :n].t()), g, None
+
+
+def flat_network(net, x):
+    _lib.require_device(x, name="tinycudann.Network input")
+    return FlatNetworkFunction.apply(x, net.params, net)
+
+
+def inference_operands(inr, args):
+    """How the density network's products are evaluated at inference (the `bf16` argument of ``forward_raw``) -
+    the same choice the training step makes (nesvor_amd.direct): bf16 operands for the half-precision model structure
+    and for ``args.mlp_bf16``, otherwise fp32 (split-bf16 evaluation, or the fp32 MFMAs with ``args.mlp_fp32_mfma``)."""
+    from .tinycudann import Network
+
+    net = inr.density_net
+    if not supported(net):
+        raise NotImplementedError("density network outside the fused MLP kernels' shapes (width 64, 1-3 hidden layers)")
+    if isinstance(net, Network) or getattr(args, "mlp_bf16", False):
+        return True
+    return MFMA_FP32 if getattr(args, "mlp_fp32_mfma", False) else False

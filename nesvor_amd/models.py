@@ -63,6 +63,13 @@ def build_network(**config):
         )
     if dtype != torch.float32:
         raise ValueError("unknown dtype")
+    if not (config["activation"] == "ReLU" and config["output_activation"] == "None" and config["n_neurons"] == 64
+            and 1 <= config["n_hidden_layers"] <= 3 and config["n_input_dims"] <= 64 and config["n_output_dims"] <= 16):
+        # the reference accepts any --width / --depth (cli/main.py:68-73) and runs them on library GEMMs; here a shape
+        # outside the fused kernels is refused up front instead of silently training 20x slower on rocBLAS
+        raise NotImplementedError(
+            "the fused MLP kernels cover ReLU networks of width 64 with 1-3 hidden layers, <= 64 inputs and <= 16 "
+            f"outputs; got {config}")
     act = None if config["activation"] == "None" else getattr(nn, config["activation"])
     out_act = None if config["output_activation"] == "None" else getattr(nn, config["output_activation"])
     dims = [config["n_input_dims"]] + [config["n_neurons"]] * config["n_hidden_layers"] + [config["n_output_dims"]]

@@ -1,59 +1,127 @@
-"""Classical super-resolution reconstruction on the slice-acquisition operator: conjugate gradients on
-A^T A and the gradient-descent SRR of the reference (nesvor/svort/srr.py:12-160).  Pure host logic on top
-of the native A / A^T ops."""
+"""Classical super-resolution reconstruction (SRR) on the native slice-acquisition operator - the solver family of
+``nesvor.svort.srr`` (nesvor/svort/srr.py:12-160) behind the same names: ``CG``, ``PSFreconstruction``, ``SRR``.
+
+Built around ``AcquisitionOperator``: the linear map A (volume -> slices, PSF-weighted sampling at the slices' poses)
+with its exact adjoint A^T, both native HIP kernels (csrc/slice_acq.hip).  On top of it
+* ``conjugate_gradient`` solves the (weighted, optionally Tikhonov-damped) normal equations; every scalar of the
+  recurrence stays a 0-d device tensor, so an n-iteration solve issues no host synchronisation unless ``tol`` > 0;
+* ``SRR`` with ``use_CG=False`` runs the reference's gradient descent with the edge-preserving prior; the prior's
+  gradient is evaluated for all 26 neighbours at once instead of one sliced pass per neighbour.
+Host logic only; SURVEY.md 8(f) rank 1.
+"""
+from typing import Callable, Optional
+
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .slice_acquisition import slice_acquisition, slice_acquisition_adjoint
 from .transform import axisangle2mat
 
 
-def dot(x, y):
-    return torch.dot(x.flatten(), y.flatten())
+class AcquisitionOperator:
+    """y = A x for one set of slice poses: ``forward`` (A), ``adjoint`` (A^T), ``normal`` (A^T W A + mu I)."""
+
+    def __init__(self, transforms: torch.Tensor, params: dict, vol_mask=None, slices_mask=None) -> None:
+        self.transforms = transforms
+        self.psf = params["psf"]
+        self.slice_shape = params["slice_shape"]
+        self.volume_shape = params["volume_shape"]
+        self.ratio = params["res_s"] / params["res_r"]  # slice pixel size in volume voxels
+        self.interp_psf = params["interp_psf"]
+        self.vol_mask, self.slices_mask = vol_mask, slices_mask
+
+    def forward(self, volume: torch.Tensor) -> torch.Tensor:
+        return slice_acquisition(self.transforms, volume, self.vol_mask, self.slices_mask, self.psf, self.slice_shape,
+                                 self.ratio, False, self.interp_psf)
+
+    def adjoint(self, slices: torch.Tensor, equalize: bool = False) -> torch.Tensor:
+        return slice_acquisition_adjoint(self.transforms, self.psf, slices, self.slices_mask, self.vol_mask,
+                                         self.volume_shape, self.ratio, self.interp_psf, equalize)
+
+    def normal(self, volume: torch.Tensor, weight: Optional[torch.Tensor] = None, mu: float = 0.0) -> torch.Tensor:
+        y = self.forward(volume)
+        if weight is not None:
+            y = y * weight
+        out = self.adjoint(y)
+        return out + mu * volume if mu else out
 
 
-def _safe_div(a, b):
-    """a / b with 0 where b == 0 (no host sync).  The native A / A^T here are deterministic, so a CG started
-    at the exact solution has a residual of exactly 0 where the reference (atomic adds) has round-off;
-    0/0 must then mean "no update" instead of NaN (SURVEY.md §4 gotcha)."""
-    return torch.where(b != 0, a / torch.where(b != 0, b, torch.ones_like(b)), torch.zeros_like(b))
+def _inner(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return (a * b).sum()
+
+
+def _ratio(num: torch.Tensor, den: torch.Tensor) -> torch.Tensor:
+    """num / den as a 0-d device tensor, 0 where den == 0.  The native A / A^T are deterministic (no atomics), so a
+    solve started at the exact solution has a residual of exactly zero where the reference sees round-off noise; a
+    vanished search direction must then mean "stay", not NaN."""
+    ok = den != 0
+    return torch.where(ok, num / torch.where(ok, den, torch.ones_like(den)), torch.zeros_like(den))
+
+
+def conjugate_gradient(apply: Callable[[torch.Tensor], torch.Tensor], rhs: torch.Tensor, start: Optional[torch.Tensor],
+                       n_iter: int, tol: float = 0.0) -> torch.Tensor:
+    """``n_iter`` conjugate-gradient steps on ``apply(x) = rhs`` (``apply`` symmetric positive definite), from ``start``
+    (``None``: from zero).  Stops early once the squared residual norm drops to ``tol`` (checked only when tol > 0: the
+    check reads a device scalar)."""
+    if start is None:
+        x = torch.zeros_like(rhs)
+        residual = rhs.clone()
+    else:
+        x = start.clone()
+        residual = rhs - apply(start)
+    direction = residual.clone()
+    rr = _inner(residual, residual)
+    for it in range(n_iter):
+        a_dir = apply(direction)
+        step = _ratio(rr, _inner(direction, a_dir))
+        x.addcmul_(direction, step)
+        if it + 1 == n_iter:
+            break
+        residual.addcmul_(a_dir, -step)
+        rr_next = _inner(residual, residual)
+        if tol > 0 and float(rr_next) <= tol:
+            break
+        direction.mul_(_ratio(rr_next, rr)).add_(residual)
+        rr = rr_next
+    return x
 
 
 def CG(A, b, x0, n_iter, tol=0.0):
-    """Conjugate gradients for A x = b (A symmetric positive definite, given as a callable); srr.py:12-34."""
-    if x0 is None:
-        x, r = 0, b
-    else:
-        x, r = x0, b - A(x0)
-    p = r
-    rr = dot(r, r)
-    i = 0
-    while True:
-        Ap = A(p)
-        alpha = _safe_div(rr, dot(p, Ap))
-        x = x + alpha * p
-        i += 1
-        if i == n_iter:
-            return x
-        r = r - alpha * Ap
-        rr_new = dot(r, r)
-        if rr_new <= tol:
-            return x
-        p = r + _safe_div(rr_new, rr) * p
-        rr = rr_new
+    """The reference's entry point (srr.py:12-34): ``A`` callable, ``x0`` may be None."""
+    return conjugate_gradient(A, b, x0, n_iter, tol)
 
 
 def PSFreconstruction(transforms, slices, slices_mask, vol_mask, params):
     """Equalised back-projection A^T y / A^T 1 (srr.py:37-48)."""
-    return slice_acquisition_adjoint(
-        transforms, params["psf"], slices, slices_mask, vol_mask, params["volume_shape"],
-        params["res_s"] / params["res_r"], params["interp_psf"], True)
+    return AcquisitionOperator(transforms, params, vol_mask, slices_mask).adjoint(slices, equalize=True)
+
+
+# the 26 neighbour offsets (dz, dy, dx) and their squared lengths
+_OFFSETS = [(dz, dy, dx) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dz, dy, dx) != (0, 0, 0)]
+
+
+def edge_prior_gradient(volume: torch.Tensor, delta: float) -> torch.Tensor:
+    """Gradient of sum over neighbour pairs of delta^2 (sqrt(1 + (d / (|o| delta))^2) - 1)-type edge-preserving
+    penalty as the reference defines it (srr.py:134-160): for every interior voxel the sum over its 26 neighbours of
+    t / sqrt(1 + d t), d = v - v_neighbour, t = d / (|o|^2 delta^2); border voxels get 0."""
+    out = torch.zeros_like(volume)
+    D, H, W = volume.shape[-3:]
+    if min(D, H, W) < 3:
+        return out
+    core = volume[..., 1 : D - 1, 1 : H - 1, 1 : W - 1]
+    shifted = torch.stack([volume[..., 1 + dz : D - 1 + dz, 1 + dy : H - 1 + dy, 1 + dx : W - 1 + dx] for dz, dy, dx in _OFFSETS])
+    inv = torch.tensor([1.0 / ((dz * dz + dy * dy + dx * dx) * delta * delta) for dz, dy, dx in _OFFSETS],
+                       dtype=volume.dtype, device=volume.device).view(-1, *([1] * volume.ndim))
+    diff = core[None] - shifted
+    scaled = diff * inv
+    out[..., 1 : D - 1, 1 : H - 1, 1 : W - 1] = (scaled * torch.rsqrt(1 + diff * scaled)).sum(0)
+    return out
 
 
 class SRR(nn.Module):
-    """min_x |A x - y|^2 (+ edge-preserving prior), by CG on the normal equations or by gradient descent
-    (srr.py:51-160)."""
+    """min_x |A x - y|_W^2 (+ mu |x - z|^2) by CG on the normal equations (``use_CG``), or ``n_iter`` steps of gradient
+    descent x -= alpha (A^T W (A x - y) + beta delta^2 dR(x)) with the edge-preserving prior; result clamped at 0
+    (srr.py:51-132).  ``theta``: (n, 6) axis-angle poses or (n, 3, 4) matrices, in voxel units of the volume."""
 
     def __init__(self, n_iter=10, use_CG=False, alpha=0.5, beta=0.02, delta=0.1, tol=0.0):
         super().__init__()
@@ -61,56 +129,23 @@ class SRR(nn.Module):
         self.beta = beta * delta * delta
 
     def forward(self, theta, slices, volume, params, p=None, mu=0, z=None, vol_mask=None, slices_mask=None):
-        transforms = axisangle2mat(theta) if theta.ndim == 2 else theta
-        rs = params["res_s"] / params["res_r"]
-
-        def A(x):
-            return slice_acquisition(transforms, x, vol_mask, slices_mask, params["psf"], params["slice_shape"], rs,
-                                     False, params["interp_psf"])
-
-        def At(y):
-            return slice_acquisition_adjoint(transforms, params["psf"], y, slices_mask, vol_mask, params["volume_shape"],
-                                             rs, params["interp_psf"], False)
-
-        def AtA(x):
-            y = A(x)
-            if p is not None:
-                y = y * p
-            v = At(y)
-            if mu and z is not None:
-                v = v + mu * x
-            return v
-
-        x = volume
+        op = AcquisitionOperator(axisangle2mat(theta) if theta.ndim == 2 else theta, params, vol_mask, slices_mask)
+        damped = bool(mu) and z is not None
         if self.use_CG:
-            b = At(slices * p if p is not None else slices)
-            if mu and z is not None:
-                b = b + mu * z
-            x = CG(AtA, b, volume, self.n_iter, self.tol)
+            rhs = op.adjoint(slices if p is None else slices * p)
+            if damped:
+                rhs = rhs + mu * z
+            x = conjugate_gradient(lambda v: op.normal(v, p, mu if damped else 0.0), rhs, volume, self.n_iter, self.tol)
         else:
+            x = volume  # updated in place, as the reference does
             for _ in range(self.n_iter):
-                err = A(x) - slices
-                if p is not None:
-                    err = p * err
-                g = At(err)
+                misfit = op.forward(x) - slices
+                grad = op.adjoint(misfit if p is None else misfit * p)
                 if self.beta:
-                    g.add_(self.dR(x, self.delta), alpha=self.beta)
-                x.add_(g, alpha=-self.alpha)
-        return F.relu(x, True)
+                    grad.add_(edge_prior_gradient(x, self.delta), alpha=self.beta)
+                x.sub_(grad, alpha=self.alpha)
+        return x.clamp_(min=0)
 
     @staticmethod
     def dR(v, delta):
-        """Gradient of the edge-preserving (Charbonnier-like) prior over the 26-neighbourhood (srr.py:134-160)."""
-        g = torch.zeros_like(v)
-        D, H, W = v.shape[-3:]
-        core = v[:, :, 1 : D - 1, 1 : H - 1, 1 : W - 1]
-        for dz in (-1, 0, 1):
-            for dy in (-1, 0, 1):
-                for dx in (-1, 0, 1):
-                    if dx == 0 and dy == 0 and dz == 0:
-                        continue
-                    nb = v[:, :, 1 + dz : D - 1 + dz, 1 + dy : H - 1 + dy, 1 + dx : W - 1 + dx]
-                    dv = core - nb
-                    dv_ = dv * (1 / (dx * dx + dy * dy + dz * dz) / (delta * delta))
-                    g[:, :, 1 : D - 1, 1 : H - 1, 1 : W - 1] += dv_ / torch.sqrt(1 + dv * dv_)
-        return g
+        return edge_prior_gradient(v, delta)

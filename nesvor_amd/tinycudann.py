@@ -7,8 +7,10 @@
 Both are ``nn.Module``s with one flat fp32 ``params`` Parameter, as in
 tinycudann's PyTorch binding.  ``Encoding`` runs the gfx950 hash-grid kernels.
 ``Network`` is the bias-free MLP tinycudann provides ("CutlassMLP" /
-"FullyFusedMLP"); here its GEMMs run through rocBLAS (torch.matmul) on views of
-the flat parameter tensor — a plain library GEMM.
+"FullyFusedMLP"); it runs on the fused MFMA kernels of ``csrc/mlp.hip`` with
+half-precision (bf16) matrix operands and fp32 accumulation.  There is no
+library-GEMM or CPU path: shapes the kernels do not cover are refused when the
+module is constructed.
 """
 import math
 
@@ -64,6 +66,13 @@ class Network(nn.Module):
         pad_out = (n_output_dims + 15) // 16 * 16
         dims = [n_input_dims] + [width] * depth + [pad_out]
         self.shapes = [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]
+        from . import mlp as mlp_mod
+
+        if not mlp_mod.supported(self):
+            raise NotImplementedError(
+                f"tinycudann.Network {dims} ({self.activation}/{self.output_activation}): the fused MLP kernels cover "
+                "ReLU networks of width 64 with 1-3 hidden layers, at most 64 inputs and 16 outputs; no library-GEMM "
+                "fallback is provided")
         g = torch.Generator().manual_seed(seed)
         chunks = []
         for o, i in self.shapes:  # xavier-uniform, tinycudann's default
@@ -71,17 +80,8 @@ class Network(nn.Module):
             chunks.append(((torch.rand(o * i, generator=g) * 2 - 1) * bound))
         self.params = nn.Parameter(torch.cat(chunks))
 
-    def _act(self, name, x):
-        if name == "None":
-            return x
-        return getattr(F, name.lower())(x)
-
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        off = 0
-        h = x.to(self.params.dtype)
-        for li, (o, i) in enumerate(self.shapes):
-            w = self.params[off : off + o * i].view(o, i)
-            off += o * i
-            h = h @ w.t()
-            h = self._act(self.activation if li < len(self.shapes) - 1 else self.output_activation, h)
-        return h[..., : self.n_output_dims]
+        """(N, n_input_dims) -> (N, n_output_dims) fp32 (tinycudann returns half; every consumer here casts up)."""
+        from . import mlp as mlp_mod
+
+        return mlp_mod.flat_network(self, x)

@@ -61,11 +61,14 @@ class Dataset(object):
         q1, q2 = torch.quantile(sample, q)
         return self.v[torch.logical_and(self.v > q1, self.v < q2)].mean().item()
 
-    def get_batch(self, batch_size: int, device, generator=None) -> Dict[str, torch.Tensor]:
+    def get_batch(self, batch_size: int, device, generator=None, host_rng: bool = False) -> Dict[str, torch.Tensor]:
         if self.count + batch_size > self.xyz.shape[0]:  # epoch boundary: reshuffle, drop the partial batch
             self.count = 0
             self.epoch += 1
-            perm = torch.randperm(self.xyz.shape[0], device=device, generator=generator)
+            if host_rng:  # the permutation a CPU run of the reference draws (train.py:64), then moved to the device
+                perm = torch.randperm(self.xyz.shape[0], generator=generator).to(device)
+            else:
+                perm = torch.randperm(self.xyz.shape[0], device=device, generator=generator)
             self.xyz, self.v, self.slice_idx = self.xyz[perm], self.v[perm], self.slice_idx[perm]
         sl = slice(self.count, self.count + batch_size)
         self.count += batch_size
@@ -112,7 +115,11 @@ def build_optimizer(model: NeSVoR, args: Namespace):
     return opt, sched
 
 
-def train(slices: List[Slice], args: Namespace) -> Tuple[INR, List[Slice], Volume]:
+def train(slices: List[Slice], args: Namespace, on_iteration=None) -> Tuple[INR, List[Slice], Volume]:
+    """``on_iteration(i, losses)`` (optional, not in the reference) sees every iteration's loss dict (0-d device tensors).
+    ``args.host_rng = True`` draws the batch permutation and the PSF noise from the HOST generator in the order a CPU run
+    of the reference does (train.py:64, models.py:270) and uploads them: with the same ``torch.manual_seed`` the run then
+    replays the reference's trajectory (tests/test_gpu_model.py holds it to the reference's own 20-iteration fixture)."""
     dataset = Dataset(slices, args)
     model = NeSVoR(dataset.transformation, dataset.resolution, dataset.mean, dataset.bounding_box, args)
     from . import direct
@@ -144,7 +151,7 @@ def train(slices: List[Slice], args: Namespace) -> Tuple[INR, List[Slice], Volum
         perm_gen = torch.Generator(device=args.device)
         perm_gen.manual_seed(torch.initial_seed())
         torch.manual_seed(torch.initial_seed() + 7919 * (rank + 1))
-    else:
+    if not use_fused:
         optimizer, scheduler = build_optimizer(model, args)
     decay_milestones = [int(m * args.n_iter) for m in args.milestones]
     weights = loss_weights(args)
@@ -152,12 +159,18 @@ def train(slices: List[Slice], args: Namespace) -> Tuple[INR, List[Slice], Volum
     average = MovingAverage(1 - 0.001)
     logging.info("NeSVoR training starts.")
     t0 = time.time()
+    host_rng = bool(getattr(args, "host_rng", False))
+    if host_rng and world > 1:
+        raise RuntimeError("args.host_rng replays a single-process CPU run; it is not defined under data parallelism")
     for i in range(1, args.n_iter + 1):
-        batch = ddp.shard_batch(dataset.get_batch(args.batch_size, args.device, perm_gen), rank, world)
+        batch = ddp.shard_batch(dataset.get_batch(args.batch_size, args.device, perm_gen, host_rng), rank, world)
+        noise = None
+        if host_rng:
+            noise = torch.randn(batch["xyz"].shape[0], args.n_samples, 3, dtype=batch["xyz"].dtype).to(args.device)
         if use_fused:
-            losses = trainer.step(**batch)
+            losses = trainer.step(**batch, noise=noise)
         else:
-            losses = model(**batch)
+            losses = model(**batch) if noise is None else model.forward_with_noise(batch["xyz"], batch["v"], batch["slice_idx"], noise)
             loss = 0
             for k in losses:
                 if k in weights and weights[k]:
@@ -166,6 +179,8 @@ def train(slices: List[Slice], args: Namespace) -> Tuple[INR, List[Slice], Volum
             optimizer.step()
             optimizer.zero_grad()
         average.update_all(losses)  # stays on the device: no per-iteration sync, two small launches
+        if on_iteration is not None:
+            on_iteration(i, losses)
         if (decay_milestones and i >= decay_milestones[0]) or i == args.n_iter:
             logging.info(
                 "time %.1fs epoch %d iter %d %s", time.time() - t0, dataset.epoch, i,

@@ -352,9 +352,11 @@ def test_hashgrid_fwd_bwd_vs_oracle(device, F, layout, method):
     torch.testing.assert_close(gt2.cpu(), 2 * gt_ref, rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("method", ["owner", "atomic"])
-def test_hashgrid_headline_config_vs_oracle(device, method):
-    """L=16, F=2, T=2^19, base 9, scale 1.26 on both mandated distributions, oracle-sized N."""
+def test_hashgrid_headline_config_vs_oracle(device, method, layout):
+    """L=16, F=2, T=2^19, base 9, scale 1.26 on both mandated distributions, oracle-sized N, in the
+    row-major layout of tinycudann (0) and in the feature-major layout the training step uses (1)."""
     from nesvor_amd.encoding import hashgrid_backward, hashgrid_forward
     from nesvor_amd.grid import HashGridSpec
     from oracle import hashgrid as O
@@ -366,10 +368,11 @@ def test_hashgrid_headline_config_vs_oracle(device, method):
     for name, u in (("U", torch.rand(8192, 3, generator=torch.Generator().manual_seed(0))), ("P", _psf_cloud(32, 256, 0))):
         dy = torch.randn(u.shape[0], 32, generator=torch.Generator().manual_seed(1))
         ref = O.encode(u, table, lv, 2)
-        pe = hashgrid_forward(spec, u.to(device), table.to(device), 0).cpu()
-        torch.testing.assert_close(pe, ref, rtol=1e-5, atol=1e-9, msg=name)
+        pe = hashgrid_forward(spec, u.to(device), table.to(device), layout).cpu()
+        torch.testing.assert_close(pe if layout == 0 else pe.t(), ref, rtol=1e-5, atol=1e-9, msg=name)
         gt_ref, gu_ref = O.encode_backward(u, table, lv, 2, dy)
-        gt, gu = hashgrid_backward(spec, u.to(device), table.to(device), dy.to(device), None, True, 0, method)
+        dyk = (dy if layout == 0 else dy.t().contiguous()).to(device)
+        gt, gu = hashgrid_backward(spec, u.to(device), table.to(device), dyk, None, True, layout, method)
         torch.testing.assert_close(gt.cpu(), gt_ref, rtol=1e-4, atol=1e-4, msg=name)
         torch.testing.assert_close(gu.cpu(), gu_ref, rtol=1e-3, atol=1e-5, msg=name)
 

@@ -213,3 +213,56 @@ def test_cg_vs_scipy_reference_test():
     # started at the exact solution the residual is exactly zero: no NaN (deterministic operators)
     x2 = CG(lambda v: At @ v, At @ torch.tensor(x_ref), torch.tensor(x_ref), 3, 0.0)
     assert torch.isfinite(x2).all()
+
+
+def test_volume_resample_vs_reference_fixture(golden, oracle_backend):
+    """``Volume.resample`` (image/image.py:134-177) as ``sample_volume`` uses it: the reference resampled the mask of
+    its trained data set (slices at the optimised poses, ``train_out_tf``) to ``output_resolution`` = 2 mm; lattice
+    shape, boolean mask and pose of the result are fixtures (``train_volume*``)."""
+    from nesvor_amd.image import Slice
+    from nesvor_amd.train import Dataset
+    from nesvor_amd.transform import RigidTransform
+
+    vs, res, res_s, s_thick, gap, n_slice, ss = golden["sim_geom"]
+    imgs = _t(golden["sim_stacks"])
+    tf = RigidTransform(_t(golden["train_out_tf"]), trans_first=True)
+    slices = [Slice(imgs[k], imgs[k] > 0, tf[k], float(res_s), float(res_s), float(s_thick)) for k in range(imgs.shape[0])]
+    args = small_args()
+    out = Dataset(slices, args).mask.resample(args.output_resolution, None)
+    assert tuple(out.image.shape) == golden["train_volume"].shape
+    np.testing.assert_array_equal(out.mask.numpy(), golden["train_volume_mask"])
+    np.testing.assert_allclose(out.transformation.matrix().numpy(), golden["train_volume_tf"], rtol=1e-6, atol=1e-5)
+    assert float(out.resolution_x) == float(out.resolution_y) == float(out.resolution_z) == 2.0
+    # an explicit target orientation: the lattice is rebuilt in that frame and still covers every masked voxel
+    rot = RigidTransform(torch.tensor([[0.3, -0.2, 0.5, 0.0, 0.0, 0.0]]), trans_first=True)
+    turned = out.resample(None, rot)
+    np.testing.assert_allclose(turned.transformation.matrix()[0, :, :3].numpy(), rot.matrix()[0, :, :3].numpy(), atol=1e-6)
+    back = turned.sample_points(out.xyz_masked)
+    assert float((back > 0).float().mean()) > 0.95
+
+
+def test_edge_prior_gradient_is_the_derivative_of_the_charbonnier_penalty():
+    """``SRR.dR`` (svort/srr.py:134-160): for every interior voxel a, sum over the 26 neighbours o of
+    d/dv_a sqrt(1 + (v_a - v_(a+o))^2 / (|o|^2 delta^2)) with the neighbour held fixed; border voxels get 0.
+    Checked against autograd of exactly that expression in fp64."""
+    from nesvor_amd.srr import SRR, edge_prior_gradient
+
+    torch.manual_seed(0)
+    v = torch.rand(2, 1, 6, 7, 8, dtype=torch.float64)
+    delta = 0.3
+    g = edge_prior_gradient(v, delta)
+    va = v.clone().requires_grad_(True)
+    D, H, W = v.shape[-3:]
+    energy = 0
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if (dz, dy, dx) == (0, 0, 0):
+                    continue
+                w = 1.0 / ((dz * dz + dy * dy + dx * dx) * delta * delta)
+                nb = v[..., 1 + dz : D - 1 + dz, 1 + dy : H - 1 + dy, 1 + dx : W - 1 + dx]  # constant
+                energy = energy + torch.sqrt(1 + w * (va[..., 1:-1, 1:-1, 1:-1] - nb) ** 2).sum()
+    energy.backward()
+    torch.testing.assert_close(g, va.grad, rtol=1e-12, atol=1e-12)
+    assert float(g[..., 0, :, :].abs().max()) == 0.0 and float(g[..., :, :, -1].abs().max()) == 0.0
+    torch.testing.assert_close(SRR.dR(v, delta), g)

@@ -253,3 +253,25 @@ def test_train_trajectory_and_sample_volume_vs_reference(golden):
         np.testing.assert_allclose(P[k].numpy(), ref, rtol=2e-4, atol=2e-6, err_msg=k)
     got_tf = tc.axisangle2mat_forward(P["axisangle"])
     np.testing.assert_allclose(got_tf.numpy(), golden["train_out_tf"], rtol=1e-4, atol=1e-4)
+
+
+def test_sample_volume_values_vs_reference(golden):
+    """``sample_volume`` (nesvor/nesvor/sample.py:10-33) of the reference's trained INR: the oracle's ``sample_points``
+    on the masked voxel centres of the reference's output lattice, ``torch.manual_seed(5)``, reproduces the reference's
+    intensities (fp32, same operations: rtol 1e-5)."""
+    args = small_args()
+    P = {"inr." + k[len("train_sd::"):]: torch.tensor(golden[k]) for k in golden.files if k.startswith("train_sd::")}
+    bb = P.pop("inr.bounding_box")
+    base, L = nm.grid_config(bb, args)
+    levels = hg.make_levels(L, args.log2_hashmap_size, base, args.level_scale)
+    mask = torch.tensor(golden["train_volume_mask"])
+    mat = torch.tensor(golden["train_volume_tf"])
+    shape_xyz = torch.tensor(mask.shape[::-1])
+    kji = torch.flip(torch.nonzero(mask), (-1,))
+    local = (kji - (shape_xyz - 1) / 2) * args.output_resolution
+    xyz = nm.transform_points_trans_first(mat, local)
+    torch.manual_seed(5)
+    got = otl.sample_points(P, levels, args, bb, xyz)
+    ref = torch.tensor(golden["train_volume"])[mask]
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-6)
+    assert float(torch.tensor(golden["train_volume"])[~mask].abs().max()) == 0.0
