@@ -356,6 +356,13 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) {
   return fmaf((float)(int32_t)(q >> 32), 0x1p32f, (float)(uint32_t)q);
 }
 
+// NESVOR_FIXED32 (build macro, F == 2 only): a merge-table slot holds both features as two 32-bit fixed-point fields of one
+// 64-bit word (one ds_add_u64 per corner, 3 VALU instructions per value) instead of one 64-bit fixed-point word per
+// feature.  Resolution: 2^-22 of 256 max|dy| of the workgroup and level (the 64-bit form resolves 2^-52).  Off by default.
+#ifndef NESVOR_FIXED32
+#define NESVOR_FIXED32 0
+#endif
+
 template <int F, int LAYOUT, bool INPUT_GRAD, bool MERGE>
 __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_bwd_aggregate(const nesvor_grid_t g, const BwdPlan plan,
                                                               const float* __restrict__ u,
@@ -364,8 +371,10 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
                                                               float* __restrict__ grad_table,
                                                               float* __restrict__ grad_u, uint32_t* __restrict__ tails,
                                                               uint32_t* __restrict__ records, int64_t N) {
+  constexpr bool kPack = (F == 2) && (NESVOR_FIXED32 != 0);
+  constexpr int kWords = kPack ? 1 : F;  // 64-bit words per slot
   __shared__ uint32_t bcount[kMaxChunks];
-  __shared__ uint32_t bbase[2][kMaxChunks];  // double-buffered by level parity: no barrier between a level's record writes and the next level
+  __shared__ uint2 bbase[2][kMaxChunks];  // per chunk: (reserved position in the sub-queue, first record of the sub-queue); double-buffered by level parity
   __shared__ uint32_t sortbuf[256];
   // workgroup-wide merge table (open addressing, keyed by the level-local entry index)
   constexpr int kSlots = F <= 2 ? 1024 : (F == 4 ? 512 : 256);
@@ -374,7 +383,9 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
   // slot values are 64-bit fixed point: integer LDS atomics are returnless and resolve same-address lanes in
   // hardware (ds_add_f32 retires ~3 cycles per lane on gfx950, a compare-and-swap loop pays a round trip per
   // retry), and the sum no longer depends on the order of the adds
-  __shared__ __attribute__((aligned(16))) unsigned long long tvals[kSlots * F];
+  __shared__ __attribute__((aligned(16))) unsigned long long tvals[kSlots * kWords];
+  // box levels: the table entries of the workgroup's lattice box ([slot][F]); the input gradient reads its 8 corners here
+  __shared__ __attribute__((aligned(16))) float tcache[INPUT_GRAD && MERGE ? kSlots * F : 1];
   __shared__ float wmax[2][4];        // per wave max |dy| of the level (double-buffered: written one level ahead)
   __shared__ uint32_t merge_stat[2];  // records inserted / drained at the current level
   __shared__ uint32_t slots_log2;     // slots of the table used at the current level: 256 .. kSlots, ~4x the
@@ -382,7 +393,10 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
                                       // the drain only walks what can be occupied
   __shared__ uint32_t merge_off;      // set once merging stops paying: finer levels skip the table
   __shared__ float ubox[4][6];        // per wave min / max of the samples' coordinates
-  __shared__ uint32_t lbox[NESVOR_MAX_LEVELS][6];  // per level: first cell (x,y,z) and cells spanned - 1 of the workgroup's samples
+  // per level: first cell (x,y,z), cells spanned - 1 (x,y,z), vertices of the lattice box (0: the box does not fit the
+  // table), largest slot a sample's first corner may take
+  __shared__ uint32_t lbox[NESVOR_MAX_LEVELS + 1][8];
+  __shared__ int32_t box_end_s;       // levels [level_begin, box_end) address the table by box slot
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t base = (int64_t)blockIdx.x * 256;
   const int E = g.n_levels * F;
@@ -393,7 +407,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
   const uint32_t sub = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & (plan.n_sub - 1u);
   if (tid < kMaxChunks) bcount[tid] = 0;
   for (int t = tid; t < kSlots; t += 256) tkeys[t] = kEmpty;
-  for (int t = tid; t < kSlots * F; t += 256) tvals[t] = 0ull;
+  for (int t = tid; t < kSlots * kWords; t += 256) tvals[t] = 0ull;
   if (tid < 2) merge_stat[tid] = 0;
   if (tid == 0) { merge_off = MERGE ? 0u : 1u; slots_log2 = __builtin_ctz(kSlots); }
 
@@ -459,14 +473,31 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       uhi[d] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, uhi[d])));
     }
     // the lattice boxes of all levels at once (thread l: level l) instead of two locate() per level in every thread
-    if (tid < g.n_levels) {
-      const LevelParams p = load_level(g, tid);
-      const CellPos blo = locate(p, ulo[0], ulo[1], ulo[2]), bhi = locate(p, uhi[0], uhi[1], uhi[2]);
-      lbox[tid][0] = blo.gx; lbox[tid][1] = blo.gy; lbox[tid][2] = blo.gz;
-      lbox[tid][3] = bhi.gx - blo.gx; lbox[tid][4] = bhi.gy - blo.gy; lbox[tid][5] = bhi.gz - blo.gz;  // (wrap if out of range)
+    if (tid <= g.n_levels) {
+      uint32_t b[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+      if (tid < g.n_levels) {
+        const LevelParams p = load_level(g, tid);
+        const CellPos blo = locate(p, ulo[0], ulo[1], ulo[2]), bhi = locate(p, uhi[0], uhi[1], uhi[2]);
+        const uint32_t ex = bhi.gx - blo.gx, ey = bhi.gy - blo.gy, ez = bhi.gz - blo.gz;  // cells spanned - 1 (wrap if out of range)
+        const bool fits = plan.box_slots != 0u && ex < (uint32_t)kSlots && ey < (uint32_t)kSlots && ez < (uint32_t)kSlots &&
+                          (uint64_t)(ex + 2u) * (ey + 2u) * (ez + 2u) <= (uint64_t)kSlots;
+        const uint32_t nx = ex + 2u, nxy = nx * (ey + 2u), vol = fits ? nxy * (ez + 2u) : 0u;
+        b[0] = blo.gx; b[1] = blo.gy; b[2] = blo.gz; b[3] = ex; b[4] = ey; b[5] = ez; b[6] = vol;
+        b[7] = fits ? vol - 2u - nx - nxy : 0u;  // = slot of the first corner of the box's last cell
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) lbox[tid][q] = b[q];  // row n_levels: all zero (a level past the end is "not a box")
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int e = plan.level_begin;
+      while (e < plan.level_end && lbox[e][6] != 0u) ++e;
+      box_end_s = e;
     }
     __syncthreads();
   }
+  const int box_end = MERGE ? __builtin_amdgcn_readfirstlane(box_end_s) : plan.level_begin;
+  auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };  // wave-uniform values
 
   auto load_dy = [&](int level, float (&dy)[F]) __attribute__((always_inline)) {
     if constexpr (LAYOUT == NESVOR_LAYOUT_ROW_MAJOR) {
@@ -479,10 +510,56 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
     }
   };
 
-  // Everything of a level that needs no shared state: corner indices, run-summed corner values, tail flag.
+  // Table entries of the box of `level` -> tcache (input gradient) and entry index of each of this thread's slots
+  // (thread t owns slots t, t + 256, ...: the same slots it drains).  Split in two so that the global loads are in
+  // flight while other work runs.
+  constexpr int NRB = kSlots / 256;
+  // The entry index of a slot lives in tkeys[slot] (idle at box levels); a slot is read and written by its owner thread
+  // only, so no barrier orders these accesses.  Returns the PREVIOUS content of the thread's tkeys slots in `old_key`.
+  auto box_keys = [&](int level, uint32_t (&old_key)[NRB], float (&feat)[NRB][F]) __attribute__((always_inline)) {
+    const LevelParams pl = load_level(g, level);
+    const uint32_t x0 = sgpr(lbox[level][0]), y0 = sgpr(lbox[level][1]), z0 = sgpr(lbox[level][2]);
+    const uint32_t nx = sgpr(lbox[level][3]) + 2u, nxy = nx * (sgpr(lbox[level][4]) + 2u), vol = sgpr(lbox[level][6]);
+    const float inv_nxy = 1.f / (float)nxy, inv_nx = 1.f / (float)nx;
+    const float* tab = table + (size_t)pl.offset * F;
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) {
+      const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
+      old_key[j] = tkeys[slot];
+#pragma unroll
+      for (int f = 0; f < F; ++f) feat[j][f] = 0.f;
+      if (slot < vol) {
+        // slot -> lattice point (slot < 1024: the float quotients are exact after truncation)
+        const uint32_t z = (uint32_t)(((float)slot + 0.5f) * inv_nxy);
+        const uint32_t r = slot - z * nxy;
+        const uint32_t y = (uint32_t)(((float)r + 0.5f) * inv_nx);
+        const uint32_t key = corner_index(pl, x0 + (r - y * nx), y0 + y, z0 + z);
+        tkeys[slot] = key;
+        if constexpr (INPUT_GRAD) load_feat<F>(tab + (size_t)key * F, feat[j]);
+      }
+    }
+  };
+  auto box_store = [&](int level, const float (&feat)[NRB][F]) __attribute__((always_inline)) {
+    if constexpr (INPUT_GRAD) {
+      const uint32_t vol = sgpr(lbox[level][6]);
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) {
+        const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
+        if (slot < vol) {
+#pragma unroll
+          for (int f = 0; f < F; ++f) tcache[slot * F + f] = feat[j][f];
+        }
+      }
+    }
+  };
+
+  // Everything of a level that needs no shared state beyond the box cache: corner slots / indices, run-summed corner
+  // values, tail flag.  BOX: the level's vertices are addressed by their position in the workgroup's lattice box (s0 =
+  // slot of the first corner); otherwise by table entry index (idx).
   // (always_inline: with the inline-asm scan the inliner otherwise leaves this a real function - closure, kernel
   // arguments and the value arrays then live in scratch memory: 6x slower)
-  auto prepare = [&](int level, const float (&dy)[F], uint32_t (&idx)[8], float (&val)[8][F], bool& tail) __attribute__((always_inline)) {
+  auto prepare = [&](auto box_c, int level, const float (&dy)[F], uint32_t (&idx)[8], uint32_t& s0, float (&val)[8][F], bool& tail) __attribute__((always_inline)) {
+    constexpr bool BOX = decltype(box_c)::value;
     const LevelParams p = load_level(g, level);
     if constexpr (MERGE) {
       float m = 0.f;
@@ -492,31 +569,56 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       if (lane == 0) wmax[level & 1][tid >> 6] = m;
     }
     const CellPos c = locate(p, ux, uy, uz);
+    uint32_t nx = 1u, nxy = 1u;
+    if constexpr (BOX) {
+      const uint32_t x0 = sgpr(lbox[level][0]), y0 = sgpr(lbox[level][1]), z0 = sgpr(lbox[level][2]);
+      const uint32_t ny = sgpr(lbox[level][4]) + 2u;
+      nx = sgpr(lbox[level][3]) + 2u; nxy = nx * ny;
+      // (the clamp only matters for NaN coordinates, which fall outside every box: keeps all eight corners inside the table)
+      s0 = min(((c.gz - z0) * ny + (c.gy - y0)) * nx + (c.gx - x0), sgpr(lbox[level][7]));
+    } else {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) idx[k] = corner_index(p, c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + (k >> 2));
+      for (int k = 0; k < 8; ++k) idx[k] = corner_index(p, c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + (k >> 2));
+    }
     if constexpr (INPUT_GRAD) {
-      const float* tab = table + (size_t)p.offset * F;
       float v[8][F];
+      if constexpr (BOX) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) load_feat<F>(tab + (size_t)idx[k] * F, v[k]);
-      float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t s = s0 + (k & 1) + ((k >> 1) & 1) * nx + (k >> 2) * nxy;
+#pragma unroll
+          for (int f = 0; f < F; ++f) v[k][f] = tcache[s * F + f];
+        }
+      } else {
+        const float* tab = table + (size_t)p.offset * F;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) load_feat<F>(tab + (size_t)idx[k] * F, v[k]);
+      }
+      // d/du of the trilinear blend of q_k = <table[corner k], dy>: differences along one axis, blended along the others
+      float q[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        float fd = 0.f;
+        q[k] = v[k][0] * dy[0];
 #pragma unroll
-        for (int f = 0; f < F; ++f) fd = fmaf(v[k][f], dy[f], fd);
-        const float wxk = (k & 1) ? c.wx : 1.f - c.wx, wyk = ((k >> 1) & 1) ? c.wy : 1.f - c.wy, wzk = (k >> 2) ? c.wz : 1.f - c.wz;
-        sx += ((k & 1) ? fd : -fd) * wyk * wzk;
-        sy += (((k >> 1) & 1) ? fd : -fd) * wxk * wzk;
-        sz += ((k >> 2) ? fd : -fd) * wxk * wyk;
+        for (int f = 1; f < F; ++f) q[k] = fmaf(v[k][f], dy[f], q[k]);
       }
+      float dxl[4], lx[4];  // along x at the four (y, z) edges: difference and blend
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dxl[e] = q[2 * e + 1] - q[2 * e]; lx[e] = fmaf(c.wx, dxl[e], q[2 * e]); }
+      const float sx = fmaf(c.wz, fmaf(c.wy, dxl[3] - dxl[2], dxl[2]) - fmaf(c.wy, dxl[1] - dxl[0], dxl[0]), fmaf(c.wy, dxl[1] - dxl[0], dxl[0]));
+      const float dy0 = lx[1] - lx[0], dy1 = lx[3] - lx[2];  // along y at z = 0, 1
+      const float sy = fmaf(c.wz, dy1 - dy0, dy0);
+      const float sz = fmaf(c.wy, dy1, lx[2]) - fmaf(c.wy, dy0, lx[0]);
       gux = fmaf(p.scale, sx, gux); guy = fmaf(p.scale, sy, guy); guz = fmaf(p.scale, sz, guz);
     }
+    {
+      const float ax[2] = {1.f - c.wx, c.wx}, ay[2] = {1.f - c.wy, c.wy}, az[2] = {1.f - c.wz, c.wz};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float w = ((k & 1) ? c.wx : 1.f - c.wx) * (((k >> 1) & 1) ? c.wy : 1.f - c.wy) * ((k >> 2) ? c.wz : 1.f - c.wz);
+      for (int k = 0; k < 8; ++k) {
+        const float w = ax[k & 1] * ay[(k >> 1) & 1] * az[k >> 2];
 #pragma unroll
-      for (int f = 0; f < F; ++f) val[k][f] = w * dy[f];
+        for (int f = 0; f < F; ++f) val[k][f] = w * dy[f];
+      }
     }
     // Segmented inclusive scan (a run = consecutive lanes of a 16-lane row in the same cell), on the VALU:
     // Hillis-Steele with DPP row_shr (out-of-row sources read 0).  `flag` = a run head lies between the row
@@ -567,30 +669,42 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
   float dy_a[F], dy_b[F];
   uint32_t idx[8], idx_n[8];
   float val[8][F], val_n[8][F];
+  uint32_t s0 = 0, s0_n = 0;
   bool tail, tail_n = false;
   const int level_end = plan.level_end;
   load_dy(plan.level_begin, dy_a);
   if (plan.level_begin + 1 < level_end) load_dy(plan.level_begin + 1, dy_b);
-  prepare(plan.level_begin, dy_a, idx, val, tail);
+  if (plan.level_begin < box_end) {
+    float feat[NRB][F];
+    uint32_t unused[NRB];
+    box_keys(plan.level_begin, unused, feat);
+    box_store(plan.level_begin, feat);
+    if constexpr (INPUT_GRAD) __syncthreads();
+    prepare(std::true_type{}, plan.level_begin, dy_a, idx, s0, val, tail);
+  } else {
+    prepare(std::false_type{}, plan.level_begin, dy_a, idx, s0, val, tail);
+  }
   if constexpr (MERGE) __syncthreads();  // wmax of the first level must be visible to the other waves
-  // Merging is on for a prefix of the levels (merge_off is set once, workgroup-uniformly, before a barrier): two
-  // loops in sequence rather than a branch inside one loop, so that the compiler cannot hoist the common second
-  // half of the two paths above the branch (which made everything of the next level live during the insertion).
+  // Three loops in sequence - box-slot levels, hashed-table levels, direct levels - rather than branches inside one
+  // loop, so that the compiler cannot hoist the common second half of the paths above the branch (which made
+  // everything of the next level live during the insertion).  Merging into the hashed table is on until it stops
+  // paying (merge_off is set once, workgroup-uniformly, before a barrier).
   int level = plan.level_begin;
   bool merge = MERGE;
   bool box = false;
-  uint32_t bvol = 0, bx0 = 0, by0 = 0, bz0 = 0, bnx = 1, bnxy = 1;
   {
     // Second half of a level, specialised on the number NR of records a thread can hold (table slots per thread in
     // merge mode, the 8 corners otherwise) so that the merge path does not carry 8 record registers sets through the
     // next level's prepare(): reserve queue space, prepare the next level, write the records.
     // in_place: the current level's idx / val are dead (merge path: the records were drained from the table), so the
     // next level is prepared straight into them - no copy at the end of the level
-    auto finish_level = [&](auto& rkey, auto& rank, auto& rval, uint32_t rmask, auto in_place) __attribute__((always_inline)) {
+    // next_may_box: the next level may still be a box level (loop A only; prunes the box variant of prepare() elsewhere)
+    auto finish_level = [&](auto& rkey, auto& rank, auto& rval, uint32_t rmask, auto in_place, auto next_may_box) __attribute__((always_inline)) {
       constexpr int NR = sizeof(rkey) / sizeof(rkey[0]);
       __syncthreads();
       // reserve queue space: one returning (memory-side, ~2 us) atomic per non-empty chunk ...
       const uint32_t nb = plan.n_chunks[level];
+      const uint32_t cap = plan.cap[level];
       uint32_t my_base = 0;
       if (tid < nb) {
         const uint32_t cnt = bcount[tid];
@@ -601,7 +715,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         // merging stops paying once fewer than a quarter of the records collapse, and (hashed table) must stop
         // before the table gets crowded
         const uint32_t drained = merge_stat[1];
-        if (drained * 4u > merge_stat[0] * 3u || (!box && drained * 10u > (uint32_t)kSlots * 7u)) merge_off = 1u;
+        if (!box && (drained * 4u > merge_stat[0] * 3u || drained * 10u > (uint32_t)kSlots * 7u)) merge_off = 1u;
         uint32_t lg = 8;
         while ((1u << lg) < 4u * drained && (1u << lg) < (uint32_t)kSlots) ++lg;
         slots_log2 = lg;
@@ -612,19 +726,24 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
 #pragma unroll
         for (int f = 0; f < F; ++f) dy_a[f] = dy_b[f];
         if (level + 2 < level_end) load_dy(level + 2, dy_b);
-        if constexpr (decltype(in_place)::value) prepare(level + 1, dy_a, idx, val, tail);
-        else prepare(level + 1, dy_a, idx_n, val_n, tail_n);
+        if constexpr (decltype(in_place)::value) {
+          if (decltype(next_may_box)::value && level + 1 < box_end) prepare(std::true_type{}, level + 1, dy_a, idx, s0, val, tail);
+          else prepare(std::false_type{}, level + 1, dy_a, idx, s0, val, tail);
+        } else {
+          prepare(std::false_type{}, level + 1, dy_a, idx_n, s0_n, val_n, tail_n);
+        }
       }
-      if (tid < nb) bbase[level & 1][tid] = my_base;
+      if (tid < nb) bbase[level & 1][tid] = make_uint2(my_base, (tid * plan.n_sub + sub) * cap);
       __syncthreads();
-      const uint32_t cap = plan.cap[level];
+      // records of the level: (entry, grad...) = (1 + F) words each; a level's queues stay below 2^32 bytes (make_plan)
+      char* const level_rec = reinterpret_cast<char*>(records) + plan.rec_off[level] * (uint64_t)(4 * (1 + F));
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
         if (NESVOR_ABL(8) || !(rmask & (1u << k))) continue;
-        const uint32_t b = rkey[k] >> plan.chunk_shift;
-        const uint32_t pos = bbase[level & 1][b] + rank[k];
+        const uint2 bb = bbase[level & 1][rkey[k] >> plan.chunk_shift];
+        const uint32_t pos = bb.x + rank[k];
         if (pos < cap) {
-          uint32_t* r = records + (plan.rec_off[level] + ((uint64_t)b * plan.n_sub + sub) * cap + pos) * (1 + F);
+          uint32_t* r = reinterpret_cast<uint32_t*>(level_rec + (bb.y + pos) * (uint32_t)(4 * (1 + F)));
           r[0] = rkey[k];
 #pragma unroll
           for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(rval[k][f]);
@@ -643,136 +762,182 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       }
       tail = tail_n;
     };
-    if constexpr (MERGE) {
-     for (; level < level_end && merge_off == 0u; ++level) {
-      constexpr int NR = kSlots / 256;
-      uint32_t rkey[NR], rank[NR], rmask = 0;
-      float rval[NR][F];
-      // (a) run tails go through the workgroup's table: duplicates of a vertex reached from neighbouring
-      //     cells, from other runs and from other waves collapse into one record
-      // fixed-point scale of the level: the adds of one slot sum to at most 256 max|dy| (corner weights of a
-      // sample sum to 1), which is mapped below 2^61
-      const float mx = 256.f * fmaxf(fmaxf(wmax[level & 1][0], wmax[level & 1][1]), fmaxf(wmax[level & 1][2], wmax[level & 1][3]));
-      int sexp = 60 - ((int)((__float_as_uint(mx) >> 23) & 0xFFu) - 127);
+    // fixed-point scale of a level: the adds of one slot sum to at most 256 max|dy| (corner weights of a sample sum to
+    // 1), which is mapped below 2^61 (2^30 for the packed 32-bit fields)
+    auto level_scale = [&](int lv, float& fscale, float& finv) __attribute__((always_inline)) {
+      const float mx = 256.f * fmaxf(fmaxf(wmax[lv & 1][0], wmax[lv & 1][1]), fmaxf(wmax[lv & 1][2], wmax[lv & 1][3]));
+      int sexp = (kPack ? 29 : 60) - ((int)((__float_as_uint(mx) >> 23) & 0xFFu) - 127);
       sexp = sexp > 100 ? 100 : sexp;
-      const float fscale = __uint_as_float((uint32_t)(sexp + 127) << 23), finv = __uint_as_float((uint32_t)(127 - sexp) << 23);
-      const uint32_t slog = slots_log2, smask = (1u << slog) - 1u;
-      // Box mode: when the lattice box of the workgroup's vertices at this level has at most kSlots points, a slot is
-      // the vertex's position inside the box - no keys, no compare-and-swap claims, no probing (a third of the LDS
-      // atomics of the hashed table); the drain recomputes the entry index from the slot number.
-      const LevelParams pl = load_level(g, level);
-      auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };  // wave-uniform values
-      bx0 = sgpr(lbox[level][0]); by0 = sgpr(lbox[level][1]); bz0 = sgpr(lbox[level][2]);
-      const uint32_t ex = sgpr(lbox[level][3]), ey = sgpr(lbox[level][4]), ez = sgpr(lbox[level][5]);  // cells spanned - 1
-      const uint32_t bdx = ex + 2u, bdy = ey + 2u, bdz = ez + 2u;
-      box = plan.box_slots != 0u && ex < (uint32_t)kSlots && ey < (uint32_t)kSlots && ez < (uint32_t)kSlots &&
-            (uint64_t)bdx * bdy * bdz <= (uint64_t)kSlots;
-      bvol = box ? bdx * bdy * bdz : 0u;
-      bnx = bdx; bnxy = bdx * bdy;
-      if (NESVOR_ABL(4)) {
-      } else if (tail && box) {
-        const CellPos c = locate(pl, ux, uy, uz);
-        const uint32_t s0 = ((c.gz - bz0) * bdy + (c.gy - by0)) * bdx + (c.gx - bx0);
+      fscale = __uint_as_float((uint32_t)(sexp + 127) << 23);
+      finv = __uint_as_float((uint32_t)(127 - sexp) << 23);
+    };
+    // one corner's F values -> the slot's fixed-point words
+    auto slot_add = [&](uint32_t slot, const float (&v)[F], float fscale) __attribute__((always_inline)) {
+      if constexpr (kPack) {
+        const int32_t q0 = __float2int_rn(v[0] * fscale), q1 = __float2int_rn(v[1] * fscale);
+        // ((int64)q1 << 32) + (int64)q0: the low field's sign borrows from the high field; undone when the slot is read
+        atomicAdd(&tvals[slot], ((unsigned long long)(uint32_t)(q1 + (q0 >> 31)) << 32) | (unsigned long long)(uint32_t)q0);
+      } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          // (the clamp only matters for NaN coordinates, which fall outside every box: keeps the adds inside the table)
-          const uint32_t slot = min(s0 + (k & 1) + ((k >> 1) & 1) * bnx + (k >> 2) * bnxy, (uint32_t)kSlots - 1u);
-#pragma unroll
-          for (int f = 0; f < F; ++f) atomicAdd(&tvals[f * kSlots + slot], to_fixed(val[k][f] * fscale));
+        for (int f = 0; f < F; ++f) atomicAdd(&tvals[f * kSlots + slot], to_fixed(v[f] * fscale));
+      }
+    };
+    // read + clear one slot; false: nothing was added (or everything cancelled exactly)
+    auto slot_take = [&](uint32_t slot, float (&v)[F], float finv) __attribute__((always_inline)) -> bool {
+      bool any = false;
+      if constexpr (kPack) {
+        const unsigned long long w = tvals[slot];
+        any = w != 0ull;
+        if (any) {
+          const int32_t lo = (int32_t)(uint32_t)w;
+          const int32_t hi = (int32_t)(uint32_t)(w >> 32) - (lo >> 31);
+          v[0] = (float)lo * finv; v[1] = (float)hi * finv;
+          tvals[slot] = 0ull;
         }
-      } else if (tail) {
-        uint32_t h[8];
-        uint32_t pending = 0;
-        // claim / find the 8 slots: first probes issued together, collisions walked one by one
+      } else {
+        unsigned long long w[F];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) h[k] = (idx[k] * 2654435761u) >> (32 - slog);
-        uint32_t prev[8];
+        for (int f = 0; f < F; ++f) { w[f] = tvals[f * kSlots + slot]; any = any || w[f] != 0ull; }
+        if (any) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) prev[k] = atomicCAS(&tkeys[h[k]], kEmpty, idx[k]);
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (prev[k] != kEmpty && prev[k] != idx[k]) pending |= 1u << k;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if (pending & (1u << k)) {
-            bool done = false;
-            // double hashing (key-dependent odd step): at level 15 the table is two thirds full and linear probing
-            // clusters (level 15: 0.067 -> 0.050 ms; probing all unresolved corners of a lane per round was slower)
-            const uint32_t step = ((idx[k] * 0x9E3779B1u) >> 20) | 1u;
-#pragma unroll 1
-            for (int probe = 0; probe < 64 && !done; ++probe) {
-              h[k] = (h[k] + step) & smask;
-              const uint32_t pv = atomicCAS(&tkeys[h[k]], kEmpty, idx[k]);
-              done = pv == kEmpty || pv == idx[k];
-            }
-            if (done) pending &= ~(1u << k);
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if (pending & (1u << k)) {  // table crowded: exact fallback
-#pragma unroll
-            for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + idx[k]) * F + f, val[k][f]);
-          } else {
-#pragma unroll
-            for (int f = 0; f < F; ++f) atomicAdd(&tvals[f * kSlots + h[k]], to_fixed(val[k][f] * fscale));
-          }
+          for (int f = 0; f < F; ++f) { v[f] = from_fixed(w[f]) * finv; tvals[f * kSlots + slot] = 0ull; }
         }
       }
-      const uint32_t n_tail = __builtin_popcountll(__ballot(tail));
-      if (lane == 0 && n_tail) atomicAdd(&merge_stat[0], 8u * n_tail);
-      __syncthreads();
-      // (b) drain: slot -> register record, slot cleared for the next level
-      uint32_t mine = 0;
-      const uint32_t n_slots = box ? bvol : (1u << slog);  // slots in use at this level: thread t drains t, t + 256, ...
-      const float inv_nxy = 1.f / (float)bnxy, inv_nx = 1.f / (float)bnx;
+      return any;
+    };
+
+    if constexpr (MERGE) {
+      // ---- (A) box-slot levels: a slot is the vertex's position inside the lattice box of the workgroup's samples -
+      //      no keys, no compare-and-swap claims, no probing; the entry index of a slot is known to the thread that
+      //      drains it (box_keys), which also fetched the entry for the input gradient's LDS copy of the box
+      box = true;
+      for (; level < box_end; ++level) {
+        uint32_t rkey[NRB], rank[NRB], rmask = 0;
+        float rval[NRB][F];
+        float fscale, finv;
+        level_scale(level, fscale, finv);
+        const uint32_t nx = sgpr(lbox[level][3]) + 2u, nxy = nx * (sgpr(lbox[level][4]) + 2u);
+        const bool next_box = level + 1 < box_end;
+        if (!NESVOR_ABL(4) && tail) {
 #pragma unroll
-      for (int j = 0; j < NR; ++j) {
-        rkey[j] = 0; rank[j] = 0;
-#pragma unroll
-        for (int f = 0; f < F; ++f) rval[j][f] = 0.f;
-        const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
-        if (slot >= n_slots) continue;
-        uint32_t key;
-        bool occupied;
-        if (box) {
-          // slot -> lattice point (slot < 1024: the float quotients are exact after truncation); a vertex whose
-          // contributions sum to exactly zero needs no record
-          const uint32_t z = (uint32_t)(((float)slot + 0.5f) * inv_nxy);
-          const uint32_t r = slot - z * bnxy;
-          const uint32_t y = (uint32_t)(((float)r + 0.5f) * inv_nx);
-          key = corner_index(pl, bx0 + (r - y * bnx), by0 + y, bz0 + z);
-          occupied = false;
-#pragma unroll
-          for (int f = 0; f < F; ++f) occupied = occupied || tvals[f * kSlots + slot] != 0ull;
+          for (int k = 0; k < 8; ++k) slot_add(s0 + (k & 1) + ((k >> 1) & 1) * nx + (k >> 2) * nxy, val[k], fscale);
+        }
+        // this thread's slots: entry indices of the current level (from tkeys); the next level's indices replace them
+        // and its table entries are fetched now - the loads fly during the barrier and the drain
+        float nfeat[NRB][F];
+        if (next_box) {
+          box_keys(level + 1, rkey, nfeat);
         } else {
-          key = tkeys[slot];
-          occupied = key != kEmpty;
-          if (occupied) tkeys[slot] = kEmpty;
-        }
-        if (occupied) {
-          rmask |= 1u << j; rkey[j] = key;
 #pragma unroll
-          for (int f = 0; f < F; ++f) {
-            rval[j][f] = from_fixed(tvals[f * kSlots + slot]) * finv;
-            tvals[f * kSlots + slot] = 0ull;
+          for (int j = 0; j < NRB; ++j) {
+            rkey[j] = tkeys[j * 256 + tid];
+            tkeys[j * 256 + tid] = kEmpty;  // the hashed table of the next level starts empty
           }
-          rank[j] = atomicAdd(&bcount[key >> plan.chunk_shift], 1u);
-          ++mine;
         }
+        __syncthreads();
+        // drain: slot -> register record, slot cleared for the next level
+        const uint32_t n_slots = sgpr(lbox[level][6]);
+#pragma unroll
+        for (int j = 0; j < NRB; ++j) {
+          rank[j] = 0;
+#pragma unroll
+          for (int f = 0; f < F; ++f) rval[j][f] = 0.f;
+          const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
+          if (slot < n_slots && slot_take(slot, rval[j], finv)) {
+            rmask |= 1u << j;
+            rank[j] = atomicAdd(&bcount[rkey[j] >> plan.chunk_shift], 1u);
+          }
+        }
+        if (next_box) {
+          box_store(level + 1, nfeat);  // every read of the current level's copy happened before the barrier above
+        } else {  // the hashed table of the next level is sized from this level's vertex count
+          const uint32_t wave_mine = (uint32_t)wave_sum_u32(__builtin_popcount(rmask));
+          if (lane == 0 && wave_mine) atomicAdd(&merge_stat[1], wave_mine);
+        }
+        finish_level(rkey, rank, rval, rmask, std::true_type{}, std::true_type{});
       }
-      const uint32_t wave_mine = (uint32_t)wave_sum_u32(mine);
-      if (lane == 0 && wave_mine) atomicAdd(&merge_stat[1], wave_mine);
-      finish_level(rkey, rank, rval, rmask, std::true_type{});
-     }
+      box = false;
+      // ---- (B) hashed merge table
+      for (; level < level_end && merge_off == 0u; ++level) {
+        constexpr int NR = kSlots / 256;
+        uint32_t rkey[NR], rank[NR], rmask = 0;
+        float rval[NR][F];
+        float fscale, finv;
+        level_scale(level, fscale, finv);
+        const uint32_t slog = slots_log2, smask = (1u << slog) - 1u;
+        if (!NESVOR_ABL(4) && tail) {
+          uint32_t h[8];
+          uint32_t pending = 0;
+          // claim / find the 8 slots: first probes issued together, collisions walked one by one
+#pragma unroll
+          for (int k = 0; k < 8; ++k) h[k] = (idx[k] * 2654435761u) >> (32 - slog);
+          uint32_t prev[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) prev[k] = atomicCAS(&tkeys[h[k]], kEmpty, idx[k]);
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (prev[k] != kEmpty && prev[k] != idx[k]) pending |= 1u << k;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (pending & (1u << k)) {
+              bool done = false;
+              // double hashing (key-dependent odd step): at level 15 the table is two thirds full and linear probing
+              // clusters (level 15: 0.067 -> 0.050 ms; probing all unresolved corners of a lane per round was slower)
+              const uint32_t step = ((idx[k] * 0x9E3779B1u) >> 20) | 1u;
+#pragma unroll 1
+              for (int probe = 0; probe < 64 && !done; ++probe) {
+                h[k] = (h[k] + step) & smask;
+                const uint32_t pv = atomicCAS(&tkeys[h[k]], kEmpty, idx[k]);
+                done = pv == kEmpty || pv == idx[k];
+              }
+              if (done) pending &= ~(1u << k);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (pending & (1u << k)) {  // table crowded: exact fallback
+#pragma unroll
+              for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + idx[k]) * F + f, val[k][f]);
+            } else {
+              slot_add(h[k], val[k], fscale);
+            }
+          }
+        }
+        const uint32_t n_tail = __builtin_popcountll(__ballot(tail));
+        if (lane == 0 && n_tail) atomicAdd(&merge_stat[0], 8u * n_tail);
+        __syncthreads();
+        // drain: slot -> register record, slot cleared for the next level
+        uint32_t mine = 0;
+        const uint32_t n_slots = 1u << slog;  // slots in use at this level: thread t drains t, t + 256, ...
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          rkey[j] = 0; rank[j] = 0;
+#pragma unroll
+          for (int f = 0; f < F; ++f) rval[j][f] = 0.f;
+          const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
+          if (slot >= n_slots) continue;
+          const uint32_t key = tkeys[slot];
+          if (key != kEmpty) {
+            tkeys[slot] = kEmpty;
+            rmask |= 1u << j; rkey[j] = key;
+            slot_take(slot, rval[j], finv);
+            rank[j] = atomicAdd(&bcount[key >> plan.chunk_shift], 1u);
+            ++mine;
+          }
+        }
+        const uint32_t wave_mine = (uint32_t)wave_sum_u32(mine);
+        if (lane == 0 && wave_mine) atomicAdd(&merge_stat[1], wave_mine);
+        finish_level(rkey, rank, rval, rmask, std::true_type{}, std::false_type{});
+      }
     }
     merge = false;
+    // ---- (C) direct: every run tail's 8 corners become records
     for (; level < level_end; ++level) {
       // rank of every record inside its chunk's span (LDS integer atomics: ~6 cycles / wave-instruction)
       uint32_t rank[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) rank[k] = tail ? atomicAdd(&bcount[idx[k] >> plan.chunk_shift], 1u) : 0u;
-      finish_level(idx, rank, val, tail ? 0xFFu : 0u, std::false_type{});
+      finish_level(idx, rank, val, tail ? 0xFFu : 0u, std::false_type{}, std::false_type{});
       advance();
     }
   }
@@ -958,6 +1123,7 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
     uint64_t cap = per + per / 8 + 1024;
     if (cap_scale > 0.0) cap = (uint64_t)((double)cap * cap_scale) + 1;  // test knob: force the overflow path
     if (cap * n_sub > 0x7FFFFFFFull) return false;
+    if (cap * n_sub * nc * (uint64_t)(4 * (1 + F)) > 0xFFFFFFFFull) return false;  // a level's queues are addressed by 32-bit byte offsets
     plan->cap[l] = (uint32_t)cap;
     // small (coarse, dense) levels collect very many records on few entries: split their queue over many
     // workgroups (the closing atomics are then only entries x slices); big chunks keep one sole writer

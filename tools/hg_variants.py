@@ -1,0 +1,63 @@
+"""A/B builds of csrc/hashgrid.hip on the GPU box: every variant = extra -D flags; for each one the aggregation pass,
+the owner pass and the forward are timed on the PSF-cloud distribution (N = 2^20, feature-major) and the table gradient
+is checked against the atomic kernel of the same build.
+
+    python tools/hg_variants.py base: fixed32:-DNESVOR_FIXED32=1
+"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] != "run":
+    variants = [a.split(":", 1) for a in sys.argv[1:]]
+    src = os.path.join(ROOT, "nesvor_amd", "csrc")
+    out = "/tmp/nesvor_variants"
+    os.makedirs(out, exist_ok=True)
+    libdir = os.path.join(ROOT, "nesvor_amd", "lib")
+    others = [os.path.join(libdir, f) for f in os.listdir(libdir) if f.endswith(".o") and f != "hashgrid.o"]
+    procs = []
+    for name, flags in variants:
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off",
+               *[f for f in flags.split(",") if f], "-I", os.path.join(ROOT, "include"), "-c", os.path.join(src, "hashgrid.hip"), "-o", f"{out}/{name}.o"]
+        procs.append(subprocess.Popen(cmd, stderr=subprocess.DEVNULL))
+    for p in procs:
+        assert p.wait() == 0
+    for name, _ in variants:
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", f"{out}/{name}.o", *others, "-o", f"{out}/lib{name}.so"])
+    for name, flags in variants:
+        r = subprocess.run([sys.executable, __file__, "run"], env={**os.environ, "NESVOR_HIP_LIB": f"{out}/lib{name}.so"}, capture_output=True, text=True)
+        print(f"{name:14s} {flags:34s} {r.stdout.strip()} {r.stderr.strip()[-300:]}", flush=True)
+else:
+    sys.path.insert(0, ROOT)
+    import ctypes
+    import torch
+    from nesvor_amd import _lib
+    from nesvor_amd.encoding import _workspace, hashgrid_backward, hashgrid_forward
+    from nesvor_amd.grid import HashGridSpec
+    dev = torch.device("cuda:0")
+    spec = HashGridSpec(16, 2, 19, 9, 1.26)
+    N = 1 << 20
+    g = torch.Generator().manual_seed(0)
+    c = torch.rand(4096, 1, 3, generator=g) * 110 + 10
+    u = ((c + torch.randn(4096, 256, 3, generator=g) * torch.tensor([0.77, 0.77, 1.27])).reshape(-1, 3) / 130.0).clamp(0, 1).contiguous().to(dev)
+    table = ((torch.rand(spec.n_params, generator=torch.Generator().manual_seed(1337)) * 2 - 1) * 1e-4).to(dev)
+    dy = torch.randn(32, N, device=dev); gt = torch.zeros_like(table); gu = torch.empty(N, 3, device=dev)
+    ws = _workspace(spec, N, dev)
+    lib = _lib.load()
+    def run(stage, gin=True):
+        return lib.nesvor_hashgrid_backward(ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(dy), _lib.ptr(gt), _lib.ptr(gu if gin else None), N, 1, _lib.ptr(ws), stage, _lib.stream_ptr())
+    def timeit(fn, n=20):
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(True), torch.cuda.Event(True)
+        s.record()
+        for _ in range(n): fn()
+        e.record(); torch.cuda.synchronize()
+        return s.elapsed_time(e) / n
+    t_agg = timeit(lambda: run(1)); t_agg_noin = timeit(lambda: run(1, False)); t_own = timeit(lambda: run(2))
+    t_fwd = timeit(lambda: hashgrid_forward(spec, u, table, 1))
+    g1, gu1 = hashgrid_backward(spec, u, table, dy, None, True, 1, "owner")
+    g2, gu2 = hashgrid_backward(spec, u, table, dy, None, True, 1, "atomic")
+    err = float((g1 - g2).abs().max() / g2.abs().max()); erru = float((gu1 - gu2).abs().max() / gu2.abs().max())
+    # small gradients next to large ones: relative error of the entries below 1e-4 of the maximum
+    small = (g2.abs() < 1e-4 * g2.abs().max()) & (g2 != 0)
+    rel_small = float(((g1 - g2).abs()[small] / g2.abs()[small]).median()) if bool(small.any()) else 0.0
+    print(f"aggregate {t_agg:.3f} ms (no input grad {t_agg_noin:.3f})  owner {t_own:.3f}  fwd {t_fwd:.3f}  | owner vs atomic: table {err:.1e} (median rel of small entries {rel_small:.1e}), grad_u {erru:.1e}")

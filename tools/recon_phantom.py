@@ -33,3 +33,12 @@ inside = truth > 0
 s = float((rec[inside] * truth[inside]).sum() / (rec[inside] ** 2).sum())  # slices were normalised by their 0.99 quantile
 mse = float(((rec[inside] * s - truth[inside]) ** 2).mean())
 print(f"iters {n_iter}  train wall {dt:.1f} s ({n_iter / dt:.1f} it/s incl. setup)  PSNR {10 * math.log10(float(truth.max()) ** 2 / mse):.2f} dB  (scale {s:.3f}, motion {motion})")
+# is the evaluation lattice aligned with the acquisition geometry?  PSNR when the evaluation points are shifted by half a voxel
+for sh in ((0, 0, 0), (0.5, 0.5, 0.5), (-0.5, -0.5, -0.5), (0.5, 0, 0), (0, 0, 0.5)):
+    with torch.no_grad():
+        r = torch.cat([inr(pts[i : i + (1 << 18), None] + torch.tensor(sh, device=dev), False).mean(-1) for i in range(0, pts.shape[0], 1 << 18)])
+    s_ = float((r[inside] * truth[inside]).sum() / (r[inside] ** 2).sum())
+    print(f"  shift {sh}: PSNR {10 * math.log10(float(truth.max()) ** 2 / float(((r[inside] * s_ - truth[inside]) ** 2).mean())):.2f} dB")
+# and with the brightest structure (skull shell, intensity 1.0) excluded
+soft = inside & (truth < 0.5)
+print(f"  soft tissue only (0 < truth < 0.5): PSNR {10 * math.log10(float(truth.max()) ** 2 / float(((rec[soft] * s - truth[soft]) ** 2).mean())):.2f} dB")
