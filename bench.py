@@ -82,11 +82,83 @@ def cpu_baseline(ds, args, seconds_budget=25.0):
     }
 
 
+def _events_ms(fn, n=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+def measure_extras(model, args, device, opt):
+    """Side measurements of the same process (rank 0, outside the timed region):
+    * achievable HBM rates of this box: a 1 GiB device-to-device copy (read + write) and a 1 GiB fill;
+    * SURVEY 8d micro-benchmark of the hash-grid kernels at N = 2^20 on BOTH mandated distributions - the
+      PSF-cloud one by the strict definition (forward + parameter-gradient bytes, timed with the input gradient the
+      training step needs) and the uniform one (which defeats the per-cloud aggregation);
+    * inference: sample_points on one chunk of 32768 points x 512 PSF samples."""
+    from nesvor_amd import _lib
+    from nesvor_amd.encoding import hashgrid_backward, hashgrid_forward
+    from nesvor_amd.sample import sample_points
+
+    out = {}
+    a = torch.empty(1 << 28, dtype=torch.float32, device=device)
+    b = torch.empty_like(a)
+    out["copy_peak_GBps"] = 2 * a.numel() * 4 / (_events_ms(lambda: b.copy_(a)) * 1e-3) / 1e9
+    out["fill_peak_GBps"] = a.numel() * 4 / (_events_ms(lambda: a.zero_()) * 1e-3) / 1e9
+    del a, b
+    enc = model.inr.encoding
+    spec, table = enc.spec, enc.params.detach()
+    L, F, N = spec.n_levels, spec.n_features, 1 << 20
+    fwd_b, bwd_b, bwd_in_b = N * (12 + 32 * F * L + 4 * F * L), N * (12 + 4 * F * L + 32 * F * L), N * (32 * F * L + 12)
+    g = torch.Generator().manual_seed(0)
+    u_uniform = torch.rand(N, 3, generator=g).to(device)
+    c = torch.rand(4096, 1, 3, generator=g) * 110 + 10
+    u_cloud = ((c + torch.randn(4096, 256, 3, generator=g) * torch.tensor([0.77, 0.77, 1.27])).reshape(-1, 3) / 130.0).clamp(0, 1).contiguous().to(device)
+    dy = torch.randn(L * F, N, generator=torch.Generator().manual_seed(1)).to(device)
+    gt = torch.zeros_like(table)
+    res = {}
+    for name, u in (("uniform", u_uniform), ("psf_cloud", u_cloud)):
+        tf = _events_ms(lambda: hashgrid_forward(spec, u, table, _lib.LAYOUT_FEATURE_MAJOR))
+        tb = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR))
+        res[name] = (tf, tb)
+    tf, tb = res["uniform"]
+    out["roofline_uniform"] = {
+        "bound": "hbm", "kernel": "hashgrid_bwd (aggregate + owner), u ~ U[0,1)^3, N = 2^20", "achieved": (bwd_b + bwd_in_b) / (tb * 1e-3) / 1e9,
+        "peak": 8000.0, "unit": "GB/s", "frac": (bwd_b + bwd_in_b) / (tb * 1e-3) / 1e9 / 8000.0, "launch_ms": tb, "forward_ms": tf,
+        "note": "uniform points share no lattice vertices inside a 256-sample workgroup at the fine levels: the per-cloud merge "
+                "table collapses nothing there and the pass is bound by the record stream (8 records of 12 B per point and level) "
+                "and the owner pass's LDS compare-and-swap adds; the training distribution is the PSF-cloud one"}
+    tf, tb = res["psf_cloud"]
+    out["roofline_fwd_bwd_strict"] = {
+        "bound": "hbm", "kernel": "hashgrid_fwd + hashgrid_bwd, PSF-cloud points, N = 2^20 (SURVEY 8d definition: forward + "
+                                  "parameter-gradient bytes = 2328 B/point at L=16; the backward is timed WITH the input gradient)",
+        "achieved": (fwd_b + bwd_b) / ((tf + tb) * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+        "frac": (fwd_b + bwd_b) / ((tf + tb) * 1e-3) / 1e9 / 8000.0, "forward_ms": tf, "backward_ms": tb}
+    # inference: one chunk of the reference's default size (inference_batch_size = 8 x 4096 points, 2 x 256 samples)
+    iargs = argparse.Namespace(**vars(args))
+    iargs.inference_batch_size, iargs.n_inference_samples = 32768, 512
+    pts = model.inr.bounding_box[0] + (model.inr.bounding_box[1] - model.inr.bounding_box[0]) * torch.rand(32768, 3, device=device)
+    ms = _events_ms(lambda: sample_points(model.inr, pts, iargs), n=5, warm=1)
+    out["inference"] = {"metric": "sample_points throughput", "value": 32768 * 512 / (ms * 1e-3), "unit": "PSF sample points/s",
+                        "voxels_per_s": 32768 / (ms * 1e-3), "chunk": "32768 points x 512 samples", "ms_per_chunk": ms}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch-size pixels PER GPU (2^20 points per GPU and iteration, the headline); strong: --batch-size "
+                         "pixels in TOTAL, split over the GPUs (BASELINE config 3 read literally: 2^20 samples per iteration). "
+                         "A weak multi-GPU run also times the strong split and reports it as strong_scaling in the same line")
     ap.add_argument("--batch-size", type=int, default=4096, help="slice pixels per GPU per iteration")
     ap.add_argument("--n-samples", type=int, default=256)
     ap.add_argument("--depth", type=int, default=2)
@@ -144,18 +216,35 @@ def main():
     torch.manual_seed(1234 + rank)  # per-rank PSF noise stream; the permutation below is rank-independent
     perm_gen = torch.Generator(device=device).manual_seed(0)
 
-    global_b = opt.batch_size * world  # weak scaling: per-GPU work fixed
+    if opt.scaling == "strong" and opt.batch_size % world:
+        raise SystemExit("--scaling strong: --batch-size must be a multiple of the number of GPUs")
+    # weak scaling: per-GPU work fixed; strong scaling: the global batch is fixed and split over the ranks
+    global_b = opt.batch_size * world if opt.scaling == "weak" else opt.batch_size
     M = ds.v.shape[0]
 
-    def next_batch():
+    def next_batch(gb=None):
         # the reference's Dataset.get_batch (train.py:60-75): arrays reshuffled once per epoch, batches are
         # contiguous windows; every rank draws the same permutation and takes its slice of the global batch
-        b = ddp.shard_batch(ds.get_batch(global_b, device, perm_gen), rank, world)
+        b = ddp.shard_batch(ds.get_batch(global_b if gb is None else gb, device, perm_gen), rank, world)
         return b["xyz"], b["v"], b["slice_idx"]
 
-    def step():
-        xyz, v, sidx = next_batch()
+    def step(gb=None):
+        xyz, v, sidx = next_batch(gb)
         return trainer.step(xyz, v, sidx)
+
+    def timed(n, gb=None):
+        """n steps bracketed by barrier + synchronize on both sides; max over ranks (seconds)."""
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = step(gb)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
 
     def sync():
         torch.cuda.synchronize(device)
@@ -169,23 +258,15 @@ def main():
         for _ in range(2):
             step()
         _lib.kernel_timer.reset(enabled=True)
-        for _ in range(opt.steps):
+        k_steps = min(opt.steps, 50)
+        for _ in range(k_steps):
             step()
         torch.cuda.synchronize(device)
         ktimes = _lib.kernel_timer.summary()
         _lib.kernel_timer.reset(enabled=False)
     for _ in range(opt.warmup):
         step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(opt.steps):
-        losses = step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, losses = timed(opt.steps)
     final_loss = {k: float(val.detach()) for k, val in losses.items()}
 
     # the same K steps with the MLP products evaluated by fp32 MFMAs (the default evaluates the same fp32 products as
@@ -197,24 +278,28 @@ def main():
         trainer.direct.bf16 = _mlp.MFMA_FP32
         for _ in range(opt.warmup):
             step()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(opt.steps):
-            step()
-        sync()
-        e2 = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([e2], device=device, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            e2 = float(t.item())
-        strict = {"value": opt.steps * (opt.batch_size * opt.n_samples * world / float(1 << 20)) / e2,
+        e2, _ = timed(opt.steps)
+        strict = {"value": opt.steps * (global_b * opt.n_samples / float(1 << 20)) / e2,
                   "ms_per_step": e2 / opt.steps * 1e3,
                   "note": "same run, MLP products as v_mfma_f32_16x16x4_f32 (python bench.py --mlp-fp32-mfma)"}
         trainer.direct.bf16 = False
 
+    # BASELINE config 3 as written (2^20 samples per iteration in total): the same job with the batch split over the ranks
+    strong = None
+    if world > 1 and opt.scaling == "weak" and opt.batch_size % world == 0:
+        for _ in range(opt.warmup):
+            step(opt.batch_size)
+        e3, _ = timed(opt.steps, opt.batch_size)
+        strong = {"scaling": "strong", "value": opt.steps * (opt.batch_size * opt.n_samples / float(1 << 20)) / e3,
+                  "ms_per_step": e3 / opt.steps * 1e3, "global_batch_pixels": opt.batch_size,
+                  "points_per_gpu_per_iter": opt.batch_size * opt.n_samples // world,
+                  "note": "same run; python bench.py --scaling strong makes this the headline value"}
+
+    extras = measure_extras(model, args, device, opt) if rank == 0 else None
+
     if rank == 0:
-        n_points = opt.batch_size * opt.n_samples  # per GPU per step
-        iters_per_s = opt.steps * (n_points * world / float(1 << 20)) / elapsed
+        n_points = global_b * opt.n_samples // world  # per GPU per step
+        iters_per_s = opt.steps * (global_b * opt.n_samples / float(1 << 20)) / elapsed
         F = args.n_features_per_level
         # algorithmic bytes per sample point: fwd 12+64L+8L ; bwd(params) 12+8L+64L ; bwd(input) 64L+12
         bytes_pt = {
@@ -234,19 +319,26 @@ def main():
             dom = max((k for k in kt if k in bytes_pt), key=lambda k: kt[k])
             ms = kt[dom]
             achieved = bytes_pt[dom] * n_points / (ms * 1e-3) / 1e9
-            traffic = None
-            try:  # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                    traffic = json.load(fh).get(dom, {}).get("traffic_bytes")
-                if traffic is not None and n_points != (1 << 20):
-                    traffic = None  # the counters were collected at 2^20 points per launch
-            except OSError:
-                pass
+            traffic, traffic_src = None, None
+            # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE per the microarch
+            # guide); they cannot be collected inside this process, so the number carries the file and commit it was
+            # measured at and is dropped when this run's launch shape differs
+            for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", fn)) as fh:
+                        tj = json.load(fh)
+                except OSError:
+                    continue
+                if dom in tj and n_points == (1 << 20):
+                    traffic = tj[dom].get("traffic_bytes")
+                    traffic_src = f"profiles/{fn} (kernels at commit {tj.get('commit', 'round-1 closing commit 867681e')})"
+                break
             roof = {
                 "bound": "hbm", "kernel": dom + (" (hashgrid_bwd_aggregate + hashgrid_bwd_owner launches)" if dom == "hashgrid_bwd" else ""),
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": traffic, "launch_ms": ms,
-                "timing": f"HIP events on the launch stream over {opt.steps} steps of this run, before the timed region",
+                "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src, "launch_ms": ms,
+                "timing": f"HIP events on the launch stream over {k_steps} steps of this run, before the timed region",
+                "copy_peak_GBps": extras["copy_peak_GBps"], "fill_peak_GBps": extras["fill_peak_GBps"],
                 "algorithmic_bytes_per_launch": bytes_pt[dom] * n_points,
                 "other_kernels_ms": {k: round(v[1], 4) for k, v in ktimes.items() if k != dom},
             }
@@ -273,7 +365,7 @@ def main():
             "unit": "iters/s (2^20-sample iterations, whole job)",
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
             "ms_per_step": elapsed / opt.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": opt.scaling, "vs_baseline": None,
             "dtype": (("f32" if opt.mlp_fp32_mfma else "f32 (MLP products evaluated on 3-way bf16 splits of the fp32 operands, fp32 accumulation: "
                        "fp32-equivalent error; the all-fp32-MFMA rate of the same run is in strict_fp32_mfma)")
                       if not (opt.mlp_bf16 or opt.half_precision_model) else
@@ -281,7 +373,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"phantom3d({opt.phantom}) {opt.stacks}-stack, L={L} T=2^19 F=2 hash + {opt.depth}x64 MLPs, "
-                            f"{opt.batch_size} px x {opt.n_samples} samples = 2^{(n_points).bit_length() - 1} points/iter/GPU, "
+                            f"{global_b // world} px x {opt.n_samples} samples = 2^{(n_points).bit_length() - 1} points/iter/GPU, "
                             f"fp32, poses optimised, edge regulariser",
                 "global_batch_pixels": global_b, "n_levels": L, "parallelism": f"dp{world}",
                 "masked_pixels": int(M), "n_slices": len(slices),
@@ -292,8 +384,12 @@ def main():
                              "against fp64 equal to the fp32 MFMA chain's (tests/test_gpu_ops.py::"
                              "test_fused_mlp_split_operands_keep_fp32_accuracy); dW products are fp32 MFMAs"),
             "strict_fp32_mfma": strict,
+            "strong_scaling": strong,
             "roofline": roof,
+            "roofline_uniform": extras["roofline_uniform"],
+            "roofline_fwd_bwd_strict": extras["roofline_fwd_bwd_strict"],
             "roofline_mlp": roof_mlp,
+            "inference": extras["inference"],
             "final_losses": final_loss,
         }
         if world == 1 and not opt.no_cpu_baseline:

@@ -17,25 +17,30 @@ constexpr int kMaxTaps = 1024;
 
 struct Tap { float x, y, z, w; };
 
-template <bool INTERP_PSF>
+// LDS_TAPS: the PSF's non-zero taps fit the LDS list (every PSF get_PSF builds for clinical geometries: (9,5,5) = 153
+// taps for 1.5 x 1.5 x 3 mm slices on a 1 mm grid); larger PSFs (thick slices on a fine grid, e.g. 6 mm on 0.5 mm = 1813
+// taps) walk the dense PSF array in global memory instead - same arithmetic, same order.
+template <bool INTERP_PSF, bool LDS_TAPS>
 __global__ __launch_bounds__(256) void slice_acq_fwd(
     const float* __restrict__ transforms, const float* __restrict__ vol, const uint8_t* __restrict__ vol_mask,
     const uint8_t* __restrict__ slices_mask, const float* __restrict__ psf, float* __restrict__ slices,
     float* __restrict__ slices_weight, int D, int H, int W, int d_p, int h_p, int w_p, int n, int h, int w,
     float res_slice) {
-  __shared__ Tap taps[kMaxTaps];
+  __shared__ Tap taps[LDS_TAPS ? kMaxTaps : 1];
   __shared__ int n_taps;
-  if (threadIdx.x == 0) {
-    int cnt = 0, ip = 0;
-    for (int iz = -d_p / 2; iz < (d_p + 1) / 2; ++iz)
-      for (int iy = -h_p / 2; iy < (h_p + 1) / 2; ++iy)
-        for (int ix = -w_p / 2; ix < (w_p + 1) / 2; ++ix, ++ip) {
-          float pv = psf[ip];
-          if (pv != 0.f && cnt < kMaxTaps) taps[cnt++] = Tap{(float)ix, (float)iy, (float)iz, pv};
-        }
-    n_taps = cnt;
+  if constexpr (LDS_TAPS) {
+    if (threadIdx.x == 0) {
+      int cnt = 0, ip = 0;
+      for (int iz = -d_p / 2; iz < (d_p + 1) / 2; ++iz)
+        for (int iy = -h_p / 2; iy < (h_p + 1) / 2; ++iy)
+          for (int ix = -w_p / 2; ix < (w_p + 1) / 2; ++ix, ++ip) {
+            float pv = psf[ip];
+            if (pv != 0.f) taps[cnt++] = Tap{(float)ix, (float)iy, (float)iz, pv};  // the host checked d_p h_p w_p <= kMaxTaps
+          }
+      n_taps = cnt;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)n * h * w) return;
   if (slices_mask != nullptr && !slices_mask[idx]) return;
@@ -51,9 +56,18 @@ __global__ __launch_bounds__(256) void slice_acq_fwd(
   const float zc = r31 * px + r32 * py + r33 * pz + (D - 1) / 2.f;
   const int Sy = W, Sz = H * W;
   float val = 0.f, wsum = 0.f;
-  const int nt = n_taps;
+  const int nt = LDS_TAPS ? n_taps : d_p * h_p * w_p;
+  const int tx0 = -w_p / 2, ty0 = -h_p / 2, tz0 = -d_p / 2;
   for (int k = 0; k < nt; ++k) {
-    const Tap tp = taps[k];
+    Tap tp;
+    if constexpr (LDS_TAPS) {
+      tp = taps[k];
+    } else {
+      const float pv = psf[k];
+      if (pv == 0.f) continue;
+      const int kz = k / (h_p * w_p), kr = k - kz * (h_p * w_p), ky = kr / w_p;
+      tp = Tap{(float)(tx0 + kr - ky * w_p), (float)(ty0 + ky), (float)(tz0 + kz), pv};
+    }
     const float x = xc + r11 * tp.x + r12 * tp.y + r13 * tp.z;
     const float y = yc + r21 * tp.x + r22 * tp.y + r23 * tp.z;
     const float z = zc + r31 * tp.x + r32 * tp.y + r33 * tp.z;
@@ -394,7 +408,6 @@ extern "C" int nesvor_slice_acq_adjoint_backward(const float* transforms, float*
                                                  float* grad_transforms, int D, int H, int W, int d_p, int h_p, int w_p,
                                                  int n, int h, int w, float res_slice, int equalize, void* stream) {
   if ((int64_t)n * h * w <= 0) return 0;
-  if ((int64_t)d_p * h_p * w_p > kMaxTaps) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   if (equalize) {
     if (vol_weight == nullptr || vol == nullptr) return (int)hipErrorInvalidValue;
@@ -413,14 +426,14 @@ extern "C" int nesvor_slice_acq_forward(const float* transforms, const float* vo
                                         int h, int w, float res_slice, int interp_psf, void* stream) {
   const int64_t total = (int64_t)n * h * w;
   if (total <= 0) return 0;
-  if ((int64_t)d_p * h_p * w_p > kMaxTaps) return (int)hipErrorInvalidValue;
+  const bool lds = (int64_t)d_p * h_p * w_p <= kMaxTaps;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  if (interp_psf)
-    hipLaunchKernelGGL(slice_acq_fwd<true>, grid, block, 0, (hipStream_t)stream, transforms, vol, vol_mask, slices_mask,
-                       psf, slices, slices_weight, D, H, W, d_p, h_p, w_p, n, h, w, res_slice);
-  else
-    hipLaunchKernelGGL(slice_acq_fwd<false>, grid, block, 0, (hipStream_t)stream, transforms, vol, vol_mask, slices_mask,
-                       psf, slices, slices_weight, D, H, W, d_p, h_p, w_p, n, h, w, res_slice);
+#define NESVOR_LAUNCH_FWD(I, L)                                                                                           \
+  hipLaunchKernelGGL((slice_acq_fwd<I, L>), grid, block, 0, (hipStream_t)stream, transforms, vol, vol_mask, slices_mask, psf, \
+                     slices, slices_weight, D, H, W, d_p, h_p, w_p, n, h, w, res_slice)
+  if (interp_psf) { if (lds) NESVOR_LAUNCH_FWD(true, true); else NESVOR_LAUNCH_FWD(true, false); }
+  else { if (lds) NESVOR_LAUNCH_FWD(false, true); else NESVOR_LAUNCH_FWD(false, false); }
+#undef NESVOR_LAUNCH_FWD
   return (int)hipGetLastError();
 }
 
@@ -430,7 +443,6 @@ extern "C" int nesvor_slice_acq_adjoint_forward(const float* transforms, const f
                                                 int w_p, int n, int h, int w, float res_slice, int equalize, void* stream) {
   const int64_t np = (int64_t)n * h * w, nv = (int64_t)D * H * W;
   if (nv <= 0) return 0;
-  if ((int64_t)d_p * h_p * w_p > kMaxTaps) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   float* coef = scratch;
   float* cw = scratch + np;
@@ -449,7 +461,6 @@ extern "C" int nesvor_slice_acq_backward(const float* transforms, const float* v
                                          int d_p, int h_p, int w_p, int n, int h, int w, float res_slice, void* stream) {
   const int64_t np = (int64_t)n * h * w, nv = (int64_t)D * H * W;
   if (np <= 0 || nv <= 0) return 0;
-  if ((int64_t)d_p * h_p * w_p > kMaxTaps) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   float* coef = scratch;
   hipLaunchKernelGGL(slice_acq_pixel_coef, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, transforms, psf, grad_slices,

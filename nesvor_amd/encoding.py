@@ -1,4 +1,5 @@
-"""Hash-grid encoding op: autograd Function over the HIP kernels."""
+"""Hash-grid encoding: raw launches of the HIP kernels (used by the fused training step and by the dispatcher ops of
+``nesvor_amd.ops``) and the differentiable ``hashgrid_encode``."""
 import ctypes
 
 import torch
@@ -83,27 +84,30 @@ def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True
     return grad_table, grad_u
 
 
-class HashGridFunction(Function):
-    """pe = encode(u, table);  row-major (N, L*F) output like tinycudann."""
+def hashgrid_encode(u, table, spec, layout=_lib.LAYOUT_ROW_MAJOR, grad_accum=None):
+    """pe = encode(u, table), differentiable in both: the dispatcher op ``torch.ops.nesvor.hashgrid_encode``
+    (``nesvor_amd.ops``; row-major (N, L*F) output like tinycudann, or feature-major).  ``grad_accum``: a tensor the
+    table gradient is accumulated into by the backward (the fused trainer's flat gradient buffer) instead of a fresh
+    30 MB tensor that autograd then adds."""
+    cfg = (spec.n_levels, spec.n_features, spec.log2_hashmap_size, spec.base_resolution, spec.per_level_scale, layout)
+    if grad_accum is None:
+        return torch.ops.nesvor.hashgrid_encode(u.contiguous(), table, *cfg)
+    return _AccumulatingEncode.apply(u.contiguous(), table, cfg, grad_accum)
+
+
+class _AccumulatingEncode(Function):
+    """The same two ops with the in-place backward variant (``hashgrid_encode_backward_``): used where the caller owns
+    the gradient buffer."""
 
     @staticmethod
-    def forward(ctx, u, table, spec, layout, grad_accum):
-        u = u.contiguous()
+    def forward(ctx, u, table, cfg, grad_accum):
         ctx.save_for_backward(u, table)
-        ctx.spec, ctx.layout, ctx.grad_accum = spec, layout, grad_accum
-        return hashgrid_forward(spec, u, table, layout)
+        ctx.cfg, ctx.grad_accum = cfg, grad_accum
+        with torch.no_grad():
+            return torch.ops.nesvor.hashgrid_encode(u, table, *cfg)
 
     @staticmethod
     def backward(ctx, dpe):
         u, table = ctx.saved_tensors
-        # grad_accum: scatter straight into the caller's (flat) grad buffer instead of
-        # materialising a fresh 30 MB zero tensor per iteration and adding it afterwards
-        grad_table, grad_u = hashgrid_backward(
-            ctx.spec, u, table, dpe.contiguous(), ctx.grad_accum, ctx.needs_input_grad[0], ctx.layout
-        )
-        ret_table = grad_table if (ctx.needs_input_grad[1] and ctx.grad_accum is None) else None
-        return grad_u, ret_table, None, None, None
-
-
-def hashgrid_encode(u, table, spec, layout=_lib.LAYOUT_ROW_MAJOR, grad_accum=None):
-    return HashGridFunction.apply(u, table, spec, layout, grad_accum)
+        gu = torch.ops.nesvor.hashgrid_encode_backward_(u, table, dpe.contiguous(), ctx.grad_accum, *ctx.cfg, ctx.needs_input_grad[0])
+        return (gu if ctx.needs_input_grad[0] else None), None, None, None

@@ -12,7 +12,7 @@ from typing import Dict
 
 import torch
 
-from . import _lib
+from . import ops as _ops  # noqa: F401  (registers torch.ops.nesvor)
 from .models import NeSVoR
 from .train import loss_weights
 
@@ -114,15 +114,9 @@ class FusedTrainer:
             else:
                 self.reduce_hook(self.flat.grad)
         self.t += 1
-        b1, b2 = self.betas
         f = self.flat
-        with torch.cuda.device(f.param.device):
-            err = _lib.load().nesvor_adamw_step(
-                _lib.ptr(f.param), _lib.ptr(f.grad), _lib.ptr(f.exp_avg), _lib.ptr(f.exp_avg_sq), f.numel,
-                self.lr, b1, b2, self.eps, self.weight_decay, 1 - b1**self.t, 1 - b2**self.t,
-                1.0 / self.world_size, 1, _lib.stream_ptr(),
-            )
-        _lib.check(err, "adamw step")
+        torch.ops.nesvor.adamw_step_(f.param, f.grad, f.exp_avg, f.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
+                                     self.weight_decay, self.t, 1.0 / self.world_size, True)
 
     def finish(self) -> None:
         self.model.inr.encoding.grad_accum = None

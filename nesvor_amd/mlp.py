@@ -214,53 +214,15 @@ def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_d
     return dxa, partial
 
 
-class FusedMLPFunction(Function):
-    @staticmethod
-    def forward(ctx, xa, xb, b_row0, k_b, S, n_layers, *params):
-        weights, biases = params[:n_layers], params[n_layers:]
-        y, saved = forward_raw(weights, biases, xa, xb, b_row0, k_b, S, any(ctx.needs_input_grad))
-        ctx.save_for_backward(xa, xb, *params, *saved)
-        ctx.cfg = (b_row0, k_b, S, n_layers)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        b_row0, k_b, S, n_layers = ctx.cfg
-        t = ctx.saved_tensors
-        xa, xb = t[0], t[1]
-        params = t[2 : 2 + 2 * n_layers]
-        saved = list(t[2 + 2 * n_layers :])
-        weights, biases = params[:n_layers], params[n_layers:]
-        # the kernel writes rows [b_row0, b_row0+k_b) of the full-size gradient directly; only the other rows
-        # (row 0 of z for sigma_net) need a zero-fill
-        g_xb = dxb = None
-        if ctx.needs_input_grad[1]:
-            g_xb = torch.empty_like(xb)
-            if b_row0 > 0:
-                g_xb[:b_row0].zero_()
-            if b_row0 + k_b < xb.shape[0]:
-                g_xb[b_row0 + k_b :].zero_()
-            dxb = g_xb[b_row0 : b_row0 + k_b]
-        dxa, partial = backward_raw(weights, biases, xa, xb, dy.contiguous(), saved, b_row0, k_b, S, dxb,
-                                    ctx.needs_input_grad[0])
-        flat = partial.sum(0)
-        gw, gb, off = [], [], 0
-        for w, b in zip(weights, biases):
-            gw.append(flat[off : off + w.numel()].view_as(w))
-            off += w.numel()
-            gb.append(flat[off : off + b.numel()])
-            off += b.numel()
-        g_xa = None
-        if dxa is not None:
-            g_xa = dxa.view(xa.shape[0], -1, dxa.shape[1]).sum(1)
-        return (g_xa, g_xb, None, None, None, None, *gw, *gb)
-
-
 def fused_mlp(seq: nn.Sequential, xa, xb, b_row0: int, k_b: int, samples_per_pixel: int):
-    """Evaluate `seq` on [xa broadcast | xb rows] -> (out_dim, N) feature-major."""
+    """Evaluate `seq` on [xa broadcast | xb rows] -> (out_dim, N) feature-major; differentiable in xa, xb and the
+    parameters: the dispatcher op ``torch.ops.nesvor.fused_mlp`` (``nesvor_amd.ops``)."""
     layers = linear_layers(seq)
-    params = [l.weight for l in layers] + [l.bias for l in layers]
-    return FusedMLPFunction.apply(xa, xb.contiguous(), b_row0, k_b, samples_per_pixel, len(layers), *params)
+    need = torch.is_grad_enabled() and (xb.requires_grad or (xa is not None and xa.requires_grad) or any(
+        p.requires_grad for l in layers for p in (l.weight, l.bias)))
+    y, _ = torch.ops.nesvor.fused_mlp(xa, xb.contiguous(), [l.weight for l in layers], [l.bias for l in layers], b_row0, k_b,
+                                      samples_per_pixel, -1, need)
+    return y
 
 
 class FlatNetworkFunction(Function):

@@ -1,6 +1,5 @@
-"""PSF sampling + rigid transform op (autograd Function over the HIP sampler kernels)."""
+"""PSF sampling + rigid transform: raw launches of the HIP sampler kernels and the differentiable ``psf_transform``."""
 import torch
-from torch.autograd import Function
 
 from . import _lib
 
@@ -32,28 +31,8 @@ def backward_raw(mat, slice_idx, xyz, psf_sigma, noise, bb, dx, du):
     return dpix
 
 
-class PsfTransformFunction(Function):
-    """(mat (n,3,4), slice_idx, xyz, psf_sigma (n,3), noise (B,S,3), bounding_box (2,3)) -> x (B,S,3), u (B*S,3)."""
-
-    @staticmethod
-    def forward(ctx, mat, slice_idx, xyz, psf_sigma, noise, bounding_box):
-        mat_c, xyz, psf_sigma, noise, bb = (t.contiguous() for t in (mat, xyz, psf_sigma, noise, bounding_box))
-        slice_idx = slice_idx.contiguous()
-        x, u = forward_raw(mat_c, slice_idx, xyz, psf_sigma, noise, bb)
-        ctx.save_for_backward(mat_c, slice_idx, xyz, psf_sigma, noise, bb)
-        return x, u
-
-    @staticmethod
-    def backward(ctx, dx, du):
-        mat, slice_idx, xyz, psf_sigma, noise, bb = ctx.saved_tensors
-        if not ctx.needs_input_grad[0]:
-            return None, None, None, None, None, None
-        dx = None if dx is None else dx.contiguous()
-        du = None if du is None else du.contiguous()
-        dpix = backward_raw(mat, slice_idx, xyz, psf_sigma, noise, bb, dx, du)
-        dmat = torch.zeros_like(mat).index_add_(0, slice_idx, dpix)
-        return dmat, None, None, None, None, None
-
-
 def psf_transform(mat, slice_idx, xyz, psf_sigma, noise, bounding_box):
-    return PsfTransformFunction.apply(mat, slice_idx, xyz, psf_sigma, noise, bounding_box)
+    """(mat (n,3,4), slice_idx, xyz, psf_sigma (n,3), noise (B,S,3), bounding_box (2,3)) -> x (B,S,3), u (B*S,3);
+    differentiable in ``mat``: the dispatcher op ``torch.ops.nesvor.psf_transform`` (``nesvor_amd.ops``)."""
+    return torch.ops.nesvor.psf_transform(mat.contiguous(), slice_idx.contiguous(), xyz.contiguous(), psf_sigma.contiguous(),
+                                          noise.contiguous(), bounding_box.contiguous())

@@ -7,8 +7,8 @@ Conventions (identical to the reference):
 * ``trans_first=True``  means  x' = R (x + t);  ``False`` means x' = R x + t;
 * all algebra (inv/compose/cat) is done on trans_first matrices.
 
-The two conversions are autograd Functions over the native HIP ops
-(``nesvor_amd.transform_convert_cuda``); there is no CPU implementation here.
+The two conversions are the differentiable dispatcher ops ``torch.ops.nesvor.axisangle2mat_forward`` /
+``mat2axisangle_forward`` (``nesvor_amd.ops``); there is no CPU implementation here.
 """
 from __future__ import annotations
 
@@ -16,45 +16,17 @@ import math
 from typing import Iterable
 
 import torch
-from torch.autograd import Function
-
-from . import transform_convert_cuda as _backend
-
-
-class _Axisangle2Mat(Function):
-    """transform_convert.py:20-34"""
-
-    @staticmethod
-    def forward(ctx, axisangle):
-        ctx.save_for_backward(axisangle)
-        return _backend.axisangle2mat_forward(axisangle)[0]
-
-    @staticmethod
-    def backward(ctx, grad_mat):
-        (axisangle,) = ctx.saved_tensors
-        return _backend.axisangle2mat_backward(grad_mat.contiguous(), axisangle)[0]
-
-
-class _Mat2Axisangle(Function):
-    """transform_convert.py:36-49"""
-
-    @staticmethod
-    def forward(ctx, mat):
-        ctx.save_for_backward(mat)
-        return _backend.mat2axisangle_forward(mat)[0]
-
-    @staticmethod
-    def backward(ctx, grad_axisangle):
-        (mat,) = ctx.saved_tensors
-        return _backend.mat2axisangle_backward(mat, grad_axisangle.contiguous())[0]
+from . import transform_convert_cuda as _backend  # noqa: F401  (the reference's module name; registers torch.ops.nesvor)
 
 
 def axisangle2mat(axisangle: torch.Tensor) -> torch.Tensor:
-    return _Axisangle2Mat.apply(axisangle.contiguous())
+    """(n,6) -> (n,3,4); differentiable (transform_convert.py:20-34,52)."""
+    return torch.ops.nesvor.axisangle2mat_forward(axisangle.contiguous())
 
 
 def mat2axisangle(mat: torch.Tensor) -> torch.Tensor:
-    return _Mat2Axisangle.apply(mat.contiguous())
+    """(n,3,4) -> (n,6); differentiable (transform_convert.py:36-49,53)."""
+    return torch.ops.nesvor.mat2axisangle_forward(mat.contiguous())
 
 
 def trans_loss_raw(axisangle, axisangle_init):
@@ -72,24 +44,9 @@ def trans_loss_raw(axisangle, axisangle_init):
     return per, grad
 
 
-class _TransLoss(Function):
-    """mean(err_R^2) + 1e-3 mean(err_T^2), err = axisangle(inv(init) o cur): one fused launch
-    (models.py:357-363)."""
-
-    @staticmethod
-    def forward(ctx, axisangle, axisangle_init):
-        per, grad = trans_loss_raw(axisangle, axisangle_init)
-        ctx.save_for_backward(grad)
-        return per.sum()
-
-    @staticmethod
-    def backward(ctx, g):
-        (grad,) = ctx.saved_tensors
-        return grad * g, None
-
-
 def trans_loss_fused(axisangle: torch.Tensor, axisangle_init: torch.Tensor) -> torch.Tensor:
-    return _TransLoss.apply(axisangle, axisangle_init)
+    """mean(err_R^2) + 1e-3 mean(err_T^2), err = axisangle(inv(init) o cur): one fused launch (models.py:357-363)."""
+    return torch.ops.nesvor.trans_loss(axisangle.contiguous(), axisangle_init.contiguous())[0]
 
 
 def _split(mat):

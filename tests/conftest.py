@@ -29,21 +29,21 @@ def device():
 
 
 @pytest.fixture()
-def oracle_backend(monkeypatch):
-    """CPU tests of HOST logic only: stand the oracle in for the native transform ops
-    (the product itself has no CPU path)."""
+def oracle_backend():
+    """CPU tests of HOST logic only: for the duration of a test the oracle is registered as the CPU kernel of the
+    rigid-transform dispatcher ops (the product registers none: it has no CPU path).  The registration is dropped
+    again when the test ends."""
     from oracle import transform_convert as o
 
-    import nesvor_amd.transform as T
+    import nesvor_amd.ops  # noqa: F401
 
-    shim = types.SimpleNamespace(
-        axisangle2mat_forward=lambda ax: [o.axisangle2mat_forward(ax)],
-        axisangle2mat_backward=lambda g, ax: [o.axisangle2mat_backward(g, ax)],
-        mat2axisangle_forward=lambda m: [o.mat2axisangle_forward(m)],
-        mat2axisangle_backward=lambda m, g: [o.mat2axisangle_backward(m, g)],
-    )
-    monkeypatch.setattr(T, "_backend", shim)
-    return shim
+    lib = torch.library.Library("nesvor", "IMPL")
+    lib.impl("axisangle2mat_forward", o.axisangle2mat_forward, "CPU")
+    lib.impl("axisangle2mat_backward", o.axisangle2mat_backward, "CPU")
+    lib.impl("mat2axisangle_forward", o.mat2axisangle_forward, "CPU")
+    lib.impl("mat2axisangle_backward", o.mat2axisangle_backward, "CPU")
+    yield lib
+    lib._destroy()
 
 
 def small_args(**over):

@@ -30,23 +30,56 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_no_cpu_fallback():
+    """Host tensors are refused: by the dispatcher for the registered ops (only a CUDA-key = HIP kernel exists), by the
+    raw launch helpers the fused step uses."""
     from nesvor_amd import slice_acq_cuda, transform_convert_cuda
-    from nesvor_amd.encoding import hashgrid_forward
+    from nesvor_amd.encoding import hashgrid_encode, hashgrid_forward
     from nesvor_amd.grid import HashGridSpec
 
-    with pytest.raises(RuntimeError, match="device"):
+    no_cpu_kernel = "Could not run 'nesvor::"
+    with pytest.raises(NotImplementedError, match=no_cpu_kernel):
         transform_convert_cuda.axisangle2mat_forward(torch.zeros(2, 6))
-    with pytest.raises(RuntimeError, match="device"):
+    with pytest.raises(NotImplementedError, match=no_cpu_kernel):
         slice_acq_cuda.forward(torch.zeros(1, 3, 4), torch.zeros(1, 1, 4, 4, 4), torch.empty(0), torch.empty(0),
                                torch.ones(1, 1, 1), (2, 2), 1.0, False, False)
     spec = HashGridSpec(2, 2, 8, 4, 1.5)
     with pytest.raises(RuntimeError, match="device"):
         hashgrid_forward(spec, torch.rand(4, 3), torch.zeros(spec.n_params))
-    with pytest.raises(NotImplementedError):  # the PSF-interpolation mode is not built: it raises, it never falls back
-        slice_acq_cuda.adjoint_backward(None, None, None, None, None, None, None, None, 1.0, True, False, True, True)
-    with pytest.raises(RuntimeError, match="device"):
+    with pytest.raises(NotImplementedError, match=no_cpu_kernel):
+        hashgrid_encode(torch.rand(4, 3), torch.zeros(spec.n_params), spec)
+    with pytest.raises(NotImplementedError, match=no_cpu_kernel):
         slice_acq_cuda.adjoint_forward(torch.zeros(1, 3, 4), torch.ones(1, 1, 1), torch.zeros(1, 1, 2, 2), torch.empty(0),
                                        torch.empty(0), (4, 4, 4), 1.0, False, False)
+
+
+def test_custom_ops_are_registered_with_schemas_and_meta_kernels():
+    """north_star: "exposed as PyTorch-ROCm custom ops".  Every op of nesvor_amd.ops is a dispatcher op in the ``nesvor``
+    namespace with a schema; only the CUDA (= HIP) key has a kernel; the fake kernels give shapes on meta tensors."""
+    import nesvor_amd.ops as ops
+
+    names = ops.op_names()
+    for required in ("axisangle2mat_forward", "axisangle2mat_backward", "mat2axisangle_forward", "mat2axisangle_backward",
+                     "slice_acq_forward", "slice_acq_backward", "slice_acq_adjoint_forward", "slice_acq_adjoint_backward",
+                     "hashgrid_encode", "hashgrid_encode_backward", "fused_mlp", "fused_mlp_backward", "psf_transform",
+                     "psf_transform_backward", "imaging_loss", "imaging_loss_backward", "trans_loss", "adamw_step_"):
+        assert required in names, required
+        op = getattr(torch.ops.nesvor, required).default
+        assert str(op._schema).startswith(f"nesvor::{required}(")
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f"nesvor::{required}", "CUDA")
+        assert not torch._C._dispatch_has_kernel_for_dispatch_key(f"nesvor::{required}", "CPU")
+    m = lambda *s, dtype=torch.float32: torch.empty(*s, dtype=dtype, device="meta")
+    assert torch.ops.nesvor.axisangle2mat_forward(m(5, 6)).shape == (5, 3, 4)
+    assert torch.ops.nesvor.mat2axisangle_forward(m(5, 3, 4, dtype=torch.float64)).dtype == torch.float64
+    out = torch.ops.nesvor.slice_acq_forward(m(7, 3, 4), m(1, 1, 8, 9, 10), m(0), m(0), m(3, 3, 3), [11, 12], 1.5, True, False)
+    assert [tuple(t.shape) for t in out] == [(7, 1, 11, 12)] * 2
+    vol, wgt = torch.ops.nesvor.slice_acq_adjoint_forward(m(7, 3, 4), m(3, 3, 3), m(7, 1, 11, 12), m(0), m(0), [8, 9, 10], 1.5, False, True)
+    assert tuple(vol.shape) == tuple(wgt.shape) == (1, 1, 8, 9, 10)
+    assert torch.ops.nesvor.hashgrid_encode(m(100, 3), m(1000), 4, 2, 8, 4, 1.5, 0).shape == (100, 8)
+    assert torch.ops.nesvor.hashgrid_encode(m(100, 3), m(1000), 4, 2, 8, 4, 1.5, 1).shape == (8, 100)
+    x, u = torch.ops.nesvor.psf_transform(m(3, 3, 4), m(10, dtype=torch.int64), m(10, 3), m(3, 3), m(10, 16, 3), m(2, 3))
+    assert x.shape == (10, 16, 3) and u.shape == (160, 3)
+    y, saved = torch.ops.nesvor.fused_mlp(None, m(32, 160), [m(64, 32), m(64, 64), m(16, 64)], [m(64), m(64), m(16)], 0, 32, 16, -1, True)
+    assert y.shape == (16, 160) and len(saved) == 2
 
 
 def test_product_does_not_import_oracle():

@@ -54,10 +54,35 @@ else:
         return s.elapsed_time(e) / n
     t_agg = timeit(lambda: run(1)); t_agg_noin = timeit(lambda: run(1, False)); t_own = timeit(lambda: run(2))
     t_fwd = timeit(lambda: hashgrid_forward(spec, u, table, 1))
+    def truth64():
+        """fp64 scatter of the fp32 corner weights (the kernels' own fmaf / floor / fp32 weights, products and sums in fp64)."""
+        import numpy as np
+        gt = torch.zeros(spec.n_entries, 2, dtype=torch.float64, device=dev)
+        P1, P2, M = 2654435761, 805459861, 0xFFFFFFFF
+        for li, lv in enumerate(spec.levels):
+            pos = (u.double() * float(np.float32(lv.scale)) + 0.5).float()
+            cell = torch.floor(pos)
+            w = (pos - cell)
+            g = cell.long()
+            d = dy[2 * li : 2 * li + 2].t().double()
+            for c in range(8):
+                cx, cy, cz = c & 1, (c >> 1) & 1, c >> 2
+                wk = ((w[:, 0] if cx else 1 - w[:, 0]) * (w[:, 1] if cy else 1 - w[:, 1])).float() * (w[:, 2] if cz else 1 - w[:, 2])
+                x, y, z = g[:, 0] + cx, g[:, 1] + cy, g[:, 2] + cz
+                idx = (((x & M) ^ ((y * P1) & M) ^ ((z * P2) & M)) % lv.size) if lv.hashed else ((x + y * lv.res + z * lv.res * lv.res) % lv.size)
+                gt.index_add_(0, idx + lv.offset, (wk.float().double()[:, None] * d.float().double()).float().double())  # fp32 product w * dy, as every kernel forms it
+        return gt.view(-1)
+    g64 = truth64()
+    def acc(gx):
+        e = (gx.double() - g64).abs()
+        nz = g64 != 0
+        rel = (e[nz] / g64[nz].abs())
+        return f"max {float(e.max() / g64.abs().max()):.1e} L2 {float(e.norm() / g64.norm()):.1e} rel-median {float(rel.median()):.1e} rel-p99 {float(rel.quantile(0.99)) if rel.numel() < 16e6 else float(rel[:16000000].quantile(0.99)):.1e}"
     g1, gu1 = hashgrid_backward(spec, u, table, dy, None, True, 1, "owner")
     g2, gu2 = hashgrid_backward(spec, u, table, dy, None, True, 1, "atomic")
     err = float((g1 - g2).abs().max() / g2.abs().max()); erru = float((gu1 - gu2).abs().max() / gu2.abs().max())
     # small gradients next to large ones: relative error of the entries below 1e-4 of the maximum
     small = (g2.abs() < 1e-4 * g2.abs().max()) & (g2 != 0)
     rel_small = float(((g1 - g2).abs()[small] / g2.abs()[small]).median()) if bool(small.any()) else 0.0
+    print(f"error against fp64: owner [{acc(g1)}]  atomic fp32 [{acc(g2)}]")
     print(f"aggregate {t_agg:.3f} ms (no input grad {t_agg_noin:.3f})  owner {t_own:.3f}  fwd {t_fwd:.3f}  | owner vs atomic: table {err:.1e} (median rel of small entries {rel_small:.1e}), grad_u {erru:.1e}")
