@@ -20,7 +20,8 @@ from .train import loss_weights
 class FlatParams:
     """Re-home every parameter of `module` into one flat buffer (params become views)."""
 
-    def __init__(self, module: torch.nn.Module):
+    def __init__(self, module: torch.nn.Module, pad_to: int = 4):
+        """``pad_to``: the buffers' length is rounded up to a multiple of it (4 W for W ranks sharding the optimizer)."""
         named = [(n, p) for n, p in module.named_parameters() if p.numel() > 0]
         # everything in definition order (so each MLP's W0,b0,W1,b1,... stay adjacent: nesvor_amd.direct sums the
         # kernels' partial gradients straight into that segment), the big table LAST: its fine levels - the end of the
@@ -34,6 +35,7 @@ class FlatParams:
             self.names.append(n)
             total += (p.numel() + 3) // 4 * 4
         dev = named[0][1].device
+        total = -(-total // pad_to) * pad_to
         self.param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -55,7 +57,12 @@ class FusedTrainer:
         if next(model.parameters()).device.type != "cuda":
             raise RuntimeError("FusedTrainer needs the model on a HIP device (no CPU path)")
         self.model, self.args = model, args
-        self.flat = FlatParams(model)
+        # optimizer-state sharding over the ranks (ddp.ShardedExchange): opt-in, args.ddp_sharded_optimizer / NESVOR_DDP_SHARDED=1
+        import os
+
+        self.sharded = world_size > 1 and bool(getattr(args, "ddp_sharded_optimizer", os.environ.get("NESVOR_DDP_SHARDED") == "1"))
+        self.flat = FlatParams(model, 4 * world_size if self.sharded else 4)
+        self._exchange = None
         enc = model.inr.encoding
         enc.grad_accum = self.flat.grad_view("inr.encoding.params")
         self.weights = loss_weights(args)
@@ -78,8 +85,8 @@ class FusedTrainer:
     @reduce_hook.setter
     def reduce_hook(self, hook) -> None:
         self._reduce_hook = hook
-        if self.direct is not None:
-            self.direct.set_overlap(hook is not None)
+        if self.direct is not None:  # the sharded exchange is one reduce-scatter after the step: no early all-reduce
+            self.direct.set_overlap(hook is not None and not self.sharded)
 
     def decay_lr(self, gamma: float) -> None:
         self.lr *= gamma
@@ -100,7 +107,25 @@ class FusedTrainer:
         self.optimizer_step()
         return losses
 
+    def _adamw(self, lo: int, hi: int, grad=None) -> None:
+        f = self.flat
+        torch.ops.nesvor.adamw_step_(f.param[lo:hi], f.grad[lo:hi] if grad is None else grad, f.exp_avg[lo:hi], f.exp_avg_sq[lo:hi],
+                                     self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
+                                     1.0 / self.world_size, True)
+
     def optimizer_step(self) -> None:
+        if self.sharded:
+            from . import ddp
+
+            if self._exchange is None:
+                self._exchange = ddp.ShardedExchange(self.flat.numel)
+            ex = self._exchange
+            mine = ex.reduce_scatter(self.flat.grad)
+            self.t += 1
+            self._adamw(ex.lo, ex.hi, mine)
+            self.flat.grad.zero_()  # this rank's partial sums: the next step accumulates from zero
+            ex.all_gather_(self.flat.param)
+            return
         if self.reduce_hook is not None:
             early = self.direct.take_early_reduce() if self.direct is not None else None
             if early is not None:  # [start, end) of the flat gradient is already being all-reduced (nesvor_amd.direct)
@@ -114,9 +139,7 @@ class FusedTrainer:
             else:
                 self.reduce_hook(self.flat.grad)
         self.t += 1
-        f = self.flat
-        torch.ops.nesvor.adamw_step_(f.param, f.grad, f.exp_avg, f.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
-                                     self.weight_decay, self.t, 1.0 / self.world_size, True)
+        self._adamw(0, self.flat.numel)
 
     def finish(self) -> None:
         self.model.inr.encoding.grad_accum = None

@@ -87,3 +87,39 @@ def test_shard_batch_rows():
     assert shard_batch(b, 0, 1) is b
     with pytest.raises(AssertionError):
         shard_batch(b, 0, 3)
+
+
+def _sharded_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from nesvor_amd import ddp
+
+    ddp.init_distributed("gloo")
+    n = 8 * world * 5
+    ex = ddp.ShardedExchange(n)
+    assert ex.shard == n // world and (ex.lo, ex.hi) == (rank * ex.shard, (rank + 1) * ex.shard)
+    g = torch.Generator().manual_seed(7)
+    grads = [torch.randn(n, generator=g) for _ in range(world)]  # every rank can rebuild every rank's gradient
+    mine = ex.reduce_scatter(grads[rank].clone())
+    torch.testing.assert_close(mine, sum(grads)[ex.lo : ex.hi])
+    # "optimizer": every rank updates its own slice only, then the slices are gathered
+    param = torch.zeros(n)
+    param[ex.lo : ex.hi] = -0.1 * mine
+    ex.all_gather_(param)
+    torch.testing.assert_close(param, -0.1 * sum(grads))
+    if rank == 0:
+        torch.save(param, out)
+    with pytest.raises(ValueError):
+        ddp.ShardedExchange(n + 1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_exchange_equals_allreduce_then_full_update(tmp_path):
+    """reduce-scatter -> per-rank update of its slice -> all-gather == all-reduce -> full update (ddp.ShardedExchange; gloo
+    has no reduce-scatter, so this exercises the all-reduce-based fallback of the same interface)."""
+    port = _free_port()
+    out = str(tmp_path / "param.pt")
+    mp.spawn(_sharded_worker, args=(2, port, out), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(7)
+    grads = [torch.randn(80, generator=g) for _ in range(2)]
+    torch.testing.assert_close(torch.load(out), -0.1 * sum(grads))

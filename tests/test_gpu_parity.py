@@ -41,8 +41,9 @@ def test_train_replays_reference_trajectory(device, golden):
     ``torch.manual_seed(0)`` (AdamW, lr decays at iterations 10 / 15 / 18); its final INR state_dict and slice poses
     are fixtures.  The HIP ``train()`` replays it with the same host random stream (initialisers, batch permutation,
     PSF noise).  Tolerance: fp32 with another summation order through 20 AdamW steps - AdamW divides by sqrt(v) + 1e-15,
-    so a table entry whose tiny gradient changes sign under reordering moves by up to 2 x lr per step: the bulk must
-    agree to 1e-3 of the tensor's range, a small fraction of entries may deviate, none by more than the 20-step bound."""
+    so a table entry whose tiny gradient changes sign under reordering can move by up to 2 x lr per step.  Measured on
+    MI355X: hash table within 2.6e-4 of its range (no entry beyond 1e-3), MLP weights within 5e-7; asserted: every tensor
+    within 2e-3 of its range, the MLPs within 1e-5."""
     from nesvor_amd.train import train
     from nesvor_amd.transform import RigidTransform
 
@@ -60,9 +61,7 @@ def test_train_replays_reference_trajectory(device, golden):
         report[k] = _deviation(got, ref)
     print("train() replay: max deviation / outlier fraction per tensor:", report)
     for k, (dmax, frac) in report.items():
-        assert frac <= 2e-3, (k, dmax, frac)
-        # 20 steps of at most lr each, relative to the range of the tensor (the table is O(1e-2) after 20 steps)
-        assert dmax <= 0.5, (k, dmax, frac)
+        assert dmax <= (2e-3 if k == "encoding.params" else 1e-5), (k, dmax, frac)
     np.testing.assert_allclose(np.asarray(sd["bounding_box"].cpu()), golden["train_sd::bounding_box"], rtol=1e-6, atol=1e-5)
     tf = RigidTransform.cat([s.transformation for s in out_slices]).matrix().cpu().numpy()
     np.testing.assert_allclose(tf, golden["train_out_tf"], rtol=1e-4, atol=2e-4)
