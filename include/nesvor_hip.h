@@ -66,7 +66,19 @@ int nesvor_slice_acq_forward(const float* transforms, const float* vol, const ui
                              int D, int H, int W, int d_p, int h_p, int w_p, int n, int h, int w,
                              float res_slice, int interp_psf, void* stream);
 
-/* Adjoint operator A^T (+ optional equalisation) and backward of A, linear-interpolation mode.
+/* EXCLUSIONS of the slice-acquisition group, against the reference's kernels:
+ *   * interp_psf != 0 (nearest-voxel sampling with a re-interpolated PSF) exists in all four reference kernels
+ *     (slice_acq_cuda_kernel.cu:72-109 forward, :229-279 and :316-366 backward, :526-572 adjoint, :754-800 adjoint
+ *     backward).  Built here: forward only.  No caller in the reference tree ever passes interp_psf=True to the other
+ *     three (slice_acq.py:40-160, svort/srr.py:37-128 and svort/models.py read it from params["interp_psf"], which every
+ *     configuration sets to False); the host layer raises NotImplementedError for them - nothing falls back.
+ *   * double precision: the reference dispatches float and double (AT_DISPATCH_FLOATING_TYPES at
+ *     slice_acq_cuda_kernel.cu:970, :1010, :1046, :1114).  Built here: float.  No caller in the reference tree passes
+ *     double volumes; the host layer raises on any other dtype.
+ *   * PSF size: any (the forward kernel keeps PSFs of up to 1024 taps as an LDS list of their non-zero taps and walks
+ *     larger ones in global memory; the other three read the dense PSF array).
+ *
+ * Adjoint operator A^T (+ optional equalisation) and backward of A, linear-interpolation mode.
  * Replace `nesvor.slice_acq_cuda.adjoint_forward` / `.backward`
  * (slice_acq_cuda.cpp:156-161; kernels slice_acq_cuda_kernel.cu:472-693 and :173-470).
  * Evaluated as a gather over voxels (no atomics, see csrc/slice_acq.hip).

@@ -80,7 +80,10 @@ __device__ __forceinline__ uint32_t corner_index(const LevelParams& p, uint32_t 
     const uint32_t h = x ^ (y * kPrimeY) ^ (z * kPrimeZ);
     return ((p.size & (p.size - 1)) == 0) ? (h & (p.size - 1)) : (h % p.size);
   }
-  uint32_t idx = x + y * p.res + z * p.res * p.res;
+  // a dense level has res^3 <= size < 2^32, i.e. res^2 < 2^22: the full-rate 24-bit multiplies are exact for every
+  // in-range vertex (v_mul_lo_u32 issues at a quarter of the rate); out-of-range inputs get a different - but in every
+  // kernel the same - garbage index before the modulo
+  uint32_t idx = x + __umul24(y, p.res) + __umul24(z, p.res * p.res);
   if (idx >= p.size) idx %= p.size;  // only on the u == 1 face / out-of-range inputs
   return idx;
 }
@@ -164,16 +167,16 @@ __global__ __launch_bounds__(256) void hashgrid_fwd(const nesvor_grid_t g, const
       const float inv_nxy = 1.f / (float)nxy, inv_nx = 1.f / (float)nx;
       for (uint32_t s = tid; s < vol; s += 256) {
         const uint32_t z = (uint32_t)(((float)s + 0.5f) * inv_nxy);
-        const uint32_t r = s - z * nxy;
+        const uint32_t r = s - __umul24(z, nxy);
         const uint32_t y = (uint32_t)(((float)r + 0.5f) * inv_nx);
-        const uint32_t idx = corner_index(p, lo[0] - 1u + (r - y * nx), lo[1] - 1u + y, lo[2] - 1u + z);
+        const uint32_t idx = corner_index(p, lo[0] - 1u + (r - __umul24(y, nx)), lo[1] - 1u + y, lo[2] - 1u + z);
         float t[F];
         load_feat<F>(tab + (size_t)idx * F, t);
 #pragma unroll
         for (int f = 0; f < F; ++f) cache[s * F + f] = t[f];
       }
       __syncthreads();
-      const uint32_t s0 = ((bz - lo[2]) * ny + (by - lo[1])) * nx + (bx - lo[0]);
+      const uint32_t s0 = __umul24(__umul24(bz - lo[2], ny) + (by - lo[1]), nx) + (bx - lo[0]);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const uint32_t s = s0 + (k & 1) + ((k >> 1) & 1) * nx + (k >> 2) * nxy;
@@ -531,9 +534,9 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       if (slot < vol) {
         // slot -> lattice point (slot < 1024: the float quotients are exact after truncation)
         const uint32_t z = (uint32_t)(((float)slot + 0.5f) * inv_nxy);
-        const uint32_t r = slot - z * nxy;
+        const uint32_t r = slot - __umul24(z, nxy);
         const uint32_t y = (uint32_t)(((float)r + 0.5f) * inv_nx);
-        const uint32_t key = corner_index(pl, x0 + (r - y * nx), y0 + y, z0 + z);
+        const uint32_t key = corner_index(pl, x0 + (r - __umul24(y, nx)), y0 + y, z0 + z);
         tkeys[slot] = key;
         if constexpr (INPUT_GRAD) load_feat<F>(tab + (size_t)key * F, feat[j]);
       }
@@ -575,7 +578,8 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       const uint32_t ny = sgpr(lbox[level][4]) + 2u;
       nx = sgpr(lbox[level][3]) + 2u; nxy = nx * ny;
       // (the clamp only matters for NaN coordinates, which fall outside every box: keeps all eight corners inside the table)
-      s0 = min(((c.gz - z0) * ny + (c.gy - y0)) * nx + (c.gx - x0), sgpr(lbox[level][7]));
+      // (24-bit multiplies: box coordinates are below 2^10; a NaN sample's garbage is clamped either way)
+      s0 = min(__umul24(__umul24(c.gz - z0, ny) + (c.gy - y0), nx) + (c.gx - x0), sgpr(lbox[level][7]));
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) idx[k] = corner_index(p, c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + (k >> 2));
@@ -744,9 +748,15 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         const uint32_t pos = bb.x + rank[k];
         if (pos < cap) {
           uint32_t* r = reinterpret_cast<uint32_t*>(level_rec + (bb.y + pos) * (uint32_t)(4 * (1 + F)));
+#if defined(NESVOR_REC_NT) && NESVOR_REC_NT
+          __builtin_nontemporal_store(rkey[k], r);
+#pragma unroll
+          for (int f = 0; f < F; ++f) __builtin_nontemporal_store(__float_as_uint(rval[k][f]), r + 1 + f);
+#else
           r[0] = rkey[k];
 #pragma unroll
           for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(rval[k][f]);
+#endif
         } else {  // queue full: exact fallback
 #pragma unroll
           for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + rkey[k]) * F + f, rval[k][f]);
@@ -1019,7 +1029,10 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
   // coalesced walk is 2x slower from compare-and-swap retries): each thread walks its own contiguous
   // sub-range, which spreads the lanes over the whole slice.
   // (sub-ranges are multiples of 32 records = 3 x 128 B so that a cache line is fetched by one thread only)
-  constexpr int kUnroll = 8;  // records in flight per thread
+#ifndef NESVOR_OWNER_UNROLL
+#define NESVOR_OWNER_UNROLL 8
+#endif
+  constexpr int kUnroll = NESVOR_OWNER_UNROLL;  // records in flight per thread
   if constexpr (COALESCED) {
     // merged queues: a workgroup of the aggregation pass emits every vertex once per level, so neighbouring
     // records no longer repeat a table entry and neighbouring lanes can take neighbouring records

@@ -78,7 +78,10 @@ class DirectStep:
         self.d_net = mlp_mod.NetParams(model.inr.density_net)
         self.s_net = mlp_mod.NetParams(model.sigma_net) if self.has_lv else None
         self.b_net = mlp_mod.NetParams(model.b_net) if self.has_b else None
-        self.side = torch.cuda.Stream(device=dev) if self.opt_T else None
+        # side stream: the pose regulariser (a serial chain per slice) at the start of the step; at its end the owner pass of
+        # the hash-grid backward (latency-bound, finishes the table gradient only) while the main stream runs the
+        # sampler backward and the per-slice bookkeeping
+        self.side = torch.cuda.Stream(device=dev)
         # evaluation of the MLP matrix products (mlp.operand_mode): bf16-rounded operands for the half-precision model
         # structure and, opt-in, for the fp32 model (args.mlp_bf16); otherwise fp32 - the split-bf16 default, or the
         # plain fp32 MFMAs with args.mlp_fp32_mfma
@@ -131,8 +134,8 @@ class DirectStep:
 
         # pose regulariser (a long serial chain per slice, independent of the batch): on a side stream, joined
         # where its gradient is added
+        main = torch.cuda.current_stream(dev)
         if self.opt_T:
-            main = torch.cuda.current_stream(dev)
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
                 per, g_t = trans_loss_raw(m.axisangle, m.axisangle_init)
@@ -222,7 +225,9 @@ class DirectStep:
             _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR,
                                       levels=(0, self.split_level), grad_u=du, first=False)
         else:
-            _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR)
+            overlap_owner = not _lib.kernel_timer.enabled  # (per-kernel event timing needs both launches on one stream)
+            _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR,
+                                      owner_stream=self.side if overlap_owner else None)
         dpix = sampler.backward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb, dxl, du) if self.opt_T else None
 
         # ---- per-slice parameters ---------------------------------------------------------------------------
@@ -242,8 +247,7 @@ class DirectStep:
         vals = torch.empty(5, dtype=torch.float32, device=dev)
         img_scale = (self.delta if self.reg_type == 0 else 1.0) / (B * S)
         img_off = -self.delta if self.reg_type == 0 else 0.0
-        if self.opt_T:
-            main.wait_stream(self.side)
+        main.wait_stream(self.side)  # pose regulariser (start of the step) and owner pass: both done before the epilogue
         with torch.cuda.device(dev):
             err = lib.nesvor_step_epilogue(
                 _lib.ptr(dc if self.has_c else None), _lib.ptr(c), _lib.ptr(m.logit_coef.grad if self.has_c else None),

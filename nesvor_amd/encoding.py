@@ -42,12 +42,14 @@ def _workspace(spec, N, device):
 
 
 def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True, layout=_lib.LAYOUT_ROW_MAJOR,
-                      method="owner", levels=None, grad_u=None, first=True):
+                      method="owner", levels=None, grad_u=None, first=True, owner_stream=None):
     """Accumulates into grad_table (allocated zero-filled if None); returns (grad_table, grad_u|None).
     method: "owner" (LDS aggregation + per-chunk owners, the MI355X path) or "atomic" (per-corner atomics).
     levels = (begin, end): only these levels ("owner" method) - a data-parallel step splits the backward in two so
     that the all-reduce of the first part overlaps the second; later parts pass the first part's ``grad_u`` and
-    ``first=False`` (queue tails are not reset, the input gradient is added)."""
+    ``first=False`` (queue tails are not reset, the input gradient is added).
+    owner_stream: launch the owner pass (which only finishes ``grad_table``) on this stream, behind the aggregation pass;
+    ``grad_u`` is complete on the current stream, the caller joins ``owner_stream`` before it reads ``grad_table``."""
     _lib.require_device(u, table, dpe, dtype=torch.float32, name="hashgrid backward input")
     N = u.shape[0]
     if grad_table is None:
@@ -73,6 +75,11 @@ def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True
                 if err == 0:
                     with _lib.kernel_timer.span("hashgrid_bwd_owner"):
                         err = call(2)
+            elif owner_stream is not None:
+                err = call(1)
+                if err == 0:
+                    owner_stream.wait_stream(torch.cuda.current_stream(u.device))
+                    err = lib.nesvor_hashgrid_backward_levels(*args, 2 | extra, l0, l1, ctypes.c_void_p(owner_stream.cuda_stream))
             else:
                 err = call(3)
         else:
