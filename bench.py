@@ -313,7 +313,7 @@ def main():
             if "hashgrid_bwd_aggregate" in kt:
                 # per step: under torch.distributed the backward is split by levels into two aggregation + two owner
                 # launches (the all-reduce of the first part overlaps the second), so sum the launches of one step
-                per_step = lambda k: ktimes[k][0] * ktimes[k][1] / opt.steps if k in ktimes else 0.0
+                per_step = lambda k: ktimes[k][0] * ktimes[k][1] / k_steps if k in ktimes else 0.0
                 kt["hashgrid_bwd_aggregate"], kt["hashgrid_bwd_owner"] = per_step("hashgrid_bwd_aggregate"), per_step("hashgrid_bwd_owner")
                 kt["hashgrid_bwd"] = kt["hashgrid_bwd_aggregate"] + kt["hashgrid_bwd_owner"]
             dom = max((k for k in kt if k in bytes_pt), key=lambda k: kt[k])

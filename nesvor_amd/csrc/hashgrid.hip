@@ -377,21 +377,28 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
   constexpr bool kPack = (F == 2) && (NESVOR_FIXED32 != 0);
   constexpr int kWords = kPack ? 1 : F;  // 64-bit words per slot
   __shared__ uint32_t bcount[kMaxChunks];
-  __shared__ uint2 bbase[2][kMaxChunks];  // per chunk: (reserved position in the sub-queue, first record of the sub-queue); double-buffered by level parity
+  // per bucket of the current round: box rounds hold uint4 (reserved position, first record of the sub-queue, capacity,
+  // level); the single-level rounds hold uint2 (position, first record) double-buffered by level parity
+  __shared__ __attribute__((aligned(16))) uint32_t bb_raw[4 * kMaxChunks];
+  uint4* const bbase4 = reinterpret_cast<uint4*>(bb_raw);
+  uint2(*const bbase)[kMaxChunks] = reinterpret_cast<uint2(*)[kMaxChunks]>(bb_raw);
   __shared__ uint32_t sortbuf[256];
-  // workgroup-wide merge table (open addressing, keyed by the level-local entry index)
+  // workgroup-wide merge table: slots addressed by position in the lattice box (box rounds; tkeys then holds
+  // level << 27 | entry index of every slot) or by open addressing keyed by the level-local entry index
   constexpr int kSlots = F <= 2 ? 1024 : (F == 4 ? 512 : 256);
   constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+  constexpr uint32_t kKeyMask = (1u << 27) - 1u;
+  constexpr int kMaxGroup = 8;  // levels per box round
   __shared__ __attribute__((aligned(16))) uint32_t tkeys[kSlots];
   // slot values are 64-bit fixed point: integer LDS atomics are returnless and resolve same-address lanes in
   // hardware (ds_add_f32 retires ~3 cycles per lane on gfx950, a compare-and-swap loop pays a round trip per
   // retry), and the sum no longer depends on the order of the adds
   __shared__ __attribute__((aligned(16))) unsigned long long tvals[kSlots * kWords];
-  // box levels: the table entries of the workgroup's lattice box ([slot][F]); the input gradient reads its 8 corners here
+  // box rounds: the table entries of the round's lattice boxes ([slot][F]); the input gradient reads its 8 corners here
   __shared__ __attribute__((aligned(16))) float tcache[INPUT_GRAD && MERGE ? kSlots * F : 1];
-  __shared__ float wmax[2][4];        // per wave max |dy| of the level (double-buffered: written one level ahead)
-  __shared__ uint32_t merge_stat[2];  // records inserted / drained at the current level
-  __shared__ uint32_t slots_log2;     // slots of the table used at the current level: 256 .. kSlots, ~4x the
+  __shared__ float gmax[4];           // per wave max |dy| over all levels of this launch
+  __shared__ uint32_t merge_stat[2];  // records inserted / drained at the current level (hashed table)
+  __shared__ uint32_t slots_log2;     // slots of the hashed table used at the current level: 256 .. kSlots, ~4x the
                                       // previous level's distinct vertices (they grow ~1.3-1.5x per level), so that
                                       // the drain only walks what can be occupied
   __shared__ uint32_t merge_off;      // set once merging stops paying: finer levels skip the table
@@ -399,10 +406,17 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
   // per level: first cell (x,y,z), cells spanned - 1 (x,y,z), vertices of the lattice box (0: the box does not fit the
   // table), largest slot a sample's first corner may take
   __shared__ uint32_t lbox[NESVOR_MAX_LEVELS + 1][8];
+  // box rounds (groups of consecutive levels whose boxes share the table): per level the first slot of its box, the
+  // first (round-local) bucket of its chunks, and the end of its round
+  __shared__ uint32_t slot_off[NESVOR_MAX_LEVELS + 1], bkt_off[NESVOR_MAX_LEVELS + 1], grp_end[NESVOR_MAX_LEVELS + 1];
+  // per level, for code that indexes levels per LANE (kernel arguments can only be indexed uniformly without a trip
+  // through scratch memory): res, size, offset, hashed, queue capacity, first bucket, first record, chunks
+  __shared__ uint32_t lpar[NESVOR_MAX_LEVELS + 1][8];
   __shared__ int32_t box_end_s;       // levels [level_begin, box_end) address the table by box slot
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t base = (int64_t)blockIdx.x * 256;
   const int E = g.n_levels * F;
+  const int level_end = plan.level_end;
   // Queue tails are hot counters (every workgroup reserves space in ~100 of them per level).  The L2s of the eight
   // XCCs are kept coherent by hardware, so a counter shared by all workgroups migrates between L2s on every
   // reservation; a counter set per XCC stays in its own L2 (measured, tools/atomic_scope_probe.hip: 2.1x the
@@ -451,56 +465,6 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
   const int64_t ii = valid ? i : N - 1;
   const float ux = u[3 * ii], uy = u[3 * ii + 1], uz = u[3 * ii + 2];
   float gux = 0.f, guy = 0.f, guz = 0.f;
-  if constexpr (MERGE) {
-    // bounding box of the workgroup's samples: locate() is monotone in u, so the lattice box of every level follows
-    // from these six numbers
-    float lo[3] = {ux, uy, uz}, hi[3] = {ux, uy, uz};
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      lo[d] = -wave_max(-lo[d]);
-      hi[d] = wave_max(hi[d]);
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int d = 0; d < 3; ++d) { ubox[tid >> 6][d] = lo[d]; ubox[tid >> 6][3 + d] = hi[d]; }
-    }
-  }
-  __syncthreads();
-  float ulo[3] = {0.f, 0.f, 0.f}, uhi[3] = {0.f, 0.f, 0.f};
-  if constexpr (MERGE) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      ulo[d] = fminf(fminf(ubox[0][d], ubox[1][d]), fminf(ubox[2][d], ubox[3][d]));
-      uhi[d] = fmaxf(fmaxf(ubox[0][3 + d], ubox[1][3 + d]), fmaxf(ubox[2][3 + d], ubox[3][3 + d]));
-      ulo[d] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ulo[d])));
-      uhi[d] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, uhi[d])));
-    }
-    // the lattice boxes of all levels at once (thread l: level l) instead of two locate() per level in every thread
-    if (tid <= g.n_levels) {
-      uint32_t b[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-      if (tid < g.n_levels) {
-        const LevelParams p = load_level(g, tid);
-        const CellPos blo = locate(p, ulo[0], ulo[1], ulo[2]), bhi = locate(p, uhi[0], uhi[1], uhi[2]);
-        const uint32_t ex = bhi.gx - blo.gx, ey = bhi.gy - blo.gy, ez = bhi.gz - blo.gz;  // cells spanned - 1 (wrap if out of range)
-        const bool fits = plan.box_slots != 0u && ex < (uint32_t)kSlots && ey < (uint32_t)kSlots && ez < (uint32_t)kSlots &&
-                          (uint64_t)(ex + 2u) * (ey + 2u) * (ez + 2u) <= (uint64_t)kSlots;
-        const uint32_t nx = ex + 2u, nxy = nx * (ey + 2u), vol = fits ? nxy * (ez + 2u) : 0u;
-        b[0] = blo.gx; b[1] = blo.gy; b[2] = blo.gz; b[3] = ex; b[4] = ey; b[5] = ez; b[6] = vol;
-        b[7] = fits ? vol - 2u - nx - nxy : 0u;  // = slot of the first corner of the box's last cell
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) lbox[tid][q] = b[q];  // row n_levels: all zero (a level past the end is "not a box")
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int e = plan.level_begin;
-      while (e < plan.level_end && lbox[e][6] != 0u) ++e;
-      box_end_s = e;
-    }
-    __syncthreads();
-  }
-  const int box_end = MERGE ? __builtin_amdgcn_readfirstlane(box_end_s) : plan.level_begin;
-  auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };  // wave-uniform values
 
   auto load_dy = [&](int level, float (&dy)[F]) __attribute__((always_inline)) {
     if constexpr (LAYOUT == NESVOR_LAYOUT_ROW_MAJOR) {
@@ -513,73 +477,125 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
     }
   };
 
-  // Table entries of the box of `level` -> tcache (input gradient) and entry index of each of this thread's slots
-  // (thread t owns slots t, t + 256, ...: the same slots it drains).  Split in two so that the global loads are in
-  // flight while other work runs.
-  constexpr int NRB = kSlots / 256;
-  // The entry index of a slot lives in tkeys[slot] (idle at box levels); a slot is read and written by its owner thread
-  // only, so no barrier orders these accesses.  Returns the PREVIOUS content of the thread's tkeys slots in `old_key`.
-  auto box_keys = [&](int level, uint32_t (&old_key)[NRB], float (&feat)[NRB][F]) __attribute__((always_inline)) {
-    const LevelParams pl = load_level(g, level);
-    const uint32_t x0 = sgpr(lbox[level][0]), y0 = sgpr(lbox[level][1]), z0 = sgpr(lbox[level][2]);
-    const uint32_t nx = sgpr(lbox[level][3]) + 2u, nxy = nx * (sgpr(lbox[level][4]) + 2u), vol = sgpr(lbox[level][6]);
-    const float inv_nxy = 1.f / (float)nxy, inv_nx = 1.f / (float)nx;
-    const float* tab = table + (size_t)pl.offset * F;
+  if constexpr (MERGE) {
+    // bounding box of the workgroup's samples: locate() is monotone in u, so the lattice box of every level follows
+    // from these six numbers
+    float lo[3] = {ux, uy, uz}, hi[3] = {ux, uy, uz};
 #pragma unroll
-    for (int j = 0; j < NRB; ++j) {
-      const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
-      old_key[j] = tkeys[slot];
-#pragma unroll
-      for (int f = 0; f < F; ++f) feat[j][f] = 0.f;
-      if (slot < vol) {
-        // slot -> lattice point (slot < 1024: the float quotients are exact after truncation)
-        const uint32_t z = (uint32_t)(((float)slot + 0.5f) * inv_nxy);
-        const uint32_t r = slot - __umul24(z, nxy);
-        const uint32_t y = (uint32_t)(((float)r + 0.5f) * inv_nx);
-        const uint32_t key = corner_index(pl, x0 + (r - __umul24(y, nx)), y0 + y, z0 + z);
-        tkeys[slot] = key;
-        if constexpr (INPUT_GRAD) load_feat<F>(tab + (size_t)key * F, feat[j]);
-      }
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = -wave_max(-lo[d]);
+      hi[d] = wave_max(hi[d]);
     }
-  };
-  auto box_store = [&](int level, const float (&feat)[NRB][F]) __attribute__((always_inline)) {
-    if constexpr (INPUT_GRAD) {
-      const uint32_t vol = sgpr(lbox[level][6]);
+    // ONE fixed-point scale for the whole launch of this workgroup: max |dy| over its samples and all levels (eight
+    // levels' loads in flight at a time).  The adds of one slot sum to at most 256 max|dy| (corner weights of a sample
+    // sum to 1), which is mapped below 2^61 (2^30 for the packed 32-bit fields); 64-bit words then resolve
+    // max|dy| 2^-52, far below an fp32 ulp of any gradient that matters next to the largest one.
+    float m = 0.f;
+    for (int l0 = plan.level_begin; l0 < level_end; l0 += 8) {
+      float d[8][F];
 #pragma unroll
-      for (int j = 0; j < NRB; ++j) {
-        const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
-        if (slot < vol) {
+      for (int q = 0; q < 8; ++q) {
+        if (l0 + q < level_end) load_dy(l0 + q, d[q]);
+        else {
 #pragma unroll
-          for (int f = 0; f < F; ++f) tcache[slot * F + f] = feat[j][f];
+          for (int f = 0; f < F; ++f) d[q][f] = 0.f;
         }
       }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int f = 0; f < F; ++f) m = fmaxf(m, fabsf(d[q][f]));
     }
-  };
+    m = wave_max(m);
+    if (lane == 0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { ubox[tid >> 6][d] = lo[d]; ubox[tid >> 6][3 + d] = hi[d]; }
+      gmax[tid >> 6] = m;
+    }
+  }
+  __syncthreads();
+  float ulo[3] = {0.f, 0.f, 0.f}, uhi[3] = {0.f, 0.f, 0.f};
+  float fscale = 1.f, finv = 1.f;
+  if constexpr (MERGE) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      ulo[d] = fminf(fminf(ubox[0][d], ubox[1][d]), fminf(ubox[2][d], ubox[3][d]));
+      uhi[d] = fmaxf(fmaxf(ubox[0][3 + d], ubox[1][3 + d]), fmaxf(ubox[2][3 + d], ubox[3][3 + d]));
+      ulo[d] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ulo[d])));
+      uhi[d] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, uhi[d])));
+    }
+    {
+      float mx = 256.f * fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
+      mx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mx)));
+      int sexp = (kPack ? 29 : 60) - ((int)((__float_as_uint(mx) >> 23) & 0xFFu) - 127);
+      sexp = sexp > 100 ? 100 : (sexp < -100 ? -100 : sexp);
+      fscale = __uint_as_float((uint32_t)(sexp + 127) << 23);
+      finv = __uint_as_float((uint32_t)(127 - sexp) << 23);
+    }
+    // the lattice boxes of all levels at once (thread l: level l) instead of two locate() per level in every thread
+    if (tid <= g.n_levels) {
+      uint32_t b[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+      if (tid < g.n_levels) {
+        const LevelParams p = load_level(g, tid);
+        const CellPos blo = locate(p, ulo[0], ulo[1], ulo[2]), bhi = locate(p, uhi[0], uhi[1], uhi[2]);
+        const uint32_t ex = bhi.gx - blo.gx, ey = bhi.gy - blo.gy, ez = bhi.gz - blo.gz;  // cells spanned - 1 (wrap if out of range)
+        const bool fits = plan.box_slots != 0u && ex < (uint32_t)kSlots && ey < (uint32_t)kSlots && ez < (uint32_t)kSlots &&
+                          (uint64_t)(ex + 2u) * (ey + 2u) * (ez + 2u) <= (uint64_t)kSlots;
+        const uint32_t nx = ex + 2u, nxy = nx * (ey + 2u), vol = fits ? nxy * (ez + 2u) : 0u;
+        b[0] = blo.gx; b[1] = blo.gy; b[2] = blo.gz; b[3] = ex; b[4] = ey; b[5] = ez; b[6] = vol;
+        b[7] = fits ? vol - 2u - nx - nxy : 0u;  // = slot (inside the box) of the first corner of the box's last cell
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) lbox[tid][q] = b[q];  // row n_levels: all zero (a level past the end is "not a box")
+      if (tid < g.n_levels) {
+        lpar[tid][0] = g.res[tid]; lpar[tid][1] = g.size[tid]; lpar[tid][2] = g.offset[tid]; lpar[tid][3] = g.hashed[tid];
+        lpar[tid][4] = plan.cap[tid]; lpar[tid][5] = plan.bucket_base[tid]; lpar[tid][6] = (uint32_t)plan.rec_off[tid];
+        lpar[tid][7] = plan.n_chunks[tid];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      // box levels = the longest prefix of levels whose box fits the table; consecutive box levels share a round
+      // while their boxes fit the table together and their chunks the bucket counters
+      int e = plan.level_begin;
+      while (e < level_end && lbox[e][6] != 0u) ++e;
+      box_end_s = e;
+      int a = plan.level_begin;
+      while (a < e) {
+        uint32_t slots = 0, bk = 0;
+        int b = a;
+        while (b < e && b - a < kMaxGroup && slots + lbox[b][6] <= (uint32_t)kSlots && bk + plan.n_chunks[b] <= (uint32_t)kMaxChunks) {
+          slot_off[b] = slots; bkt_off[b] = bk;
+          slots += lbox[b][6]; bk += plan.n_chunks[b];
+          ++b;
+        }
+        for (int l = a; l < b; ++l) grp_end[l] = (uint32_t)b;
+        slot_off[b] = slots; bkt_off[b] = bk;  // totals of the round, overwritten if level b opens the next round
+        a = b;
+      }
+    }
+    __syncthreads();
+  }
+  const int box_end = MERGE ? __builtin_amdgcn_readfirstlane(box_end_s) : plan.level_begin;
+  auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };  // wave-uniform values
 
   // Everything of a level that needs no shared state beyond the box cache: corner slots / indices, run-summed corner
-  // values, tail flag.  BOX: the level's vertices are addressed by their position in the workgroup's lattice box (s0 =
-  // slot of the first corner); otherwise by table entry index (idx).
+  // values, tail flag.  BOX: the level's vertices are addressed by their slot in the round's table (s0 = slot of the
+  // first corner); otherwise by table entry index (idx).
   // (always_inline: with the inline-asm scan the inliner otherwise leaves this a real function - closure, kernel
   // arguments and the value arrays then live in scratch memory: 6x slower)
-  auto prepare = [&](auto box_c, int level, const float (&dy)[F], uint32_t (&idx)[8], uint32_t& s0, float (&val)[8][F], bool& tail) __attribute__((always_inline)) {
+  auto prepare = [&](auto box_c, int level, const float (&dy)[F], uint32_t (&idx)[8], uint32_t& s0, uint32_t& nx, uint32_t& nxy,
+                     float (&val)[8][F], bool& tail) __attribute__((always_inline)) {
     constexpr bool BOX = decltype(box_c)::value;
     const LevelParams p = load_level(g, level);
-    if constexpr (MERGE) {
-      float m = 0.f;
-#pragma unroll
-      for (int f = 0; f < F; ++f) m = fmaxf(m, fabsf(dy[f]));
-      m = wave_max(m);
-      if (lane == 0) wmax[level & 1][tid >> 6] = m;
-    }
     const CellPos c = locate(p, ux, uy, uz);
-    uint32_t nx = 1u, nxy = 1u;
     if constexpr (BOX) {
       const uint32_t x0 = sgpr(lbox[level][0]), y0 = sgpr(lbox[level][1]), z0 = sgpr(lbox[level][2]);
       const uint32_t ny = sgpr(lbox[level][4]) + 2u;
       nx = sgpr(lbox[level][3]) + 2u; nxy = nx * ny;
-      // (the clamp only matters for NaN coordinates, which fall outside every box: keeps all eight corners inside the table)
-      // (24-bit multiplies: box coordinates are below 2^10; a NaN sample's garbage is clamped either way)
-      s0 = min(__umul24(__umul24(c.gz - z0, ny) + (c.gy - y0), nx) + (c.gx - x0), sgpr(lbox[level][7]));
+      // (24-bit multiplies: box coordinates are below 2^10; the clamp only matters for NaN coordinates, which fall
+      // outside every box: it keeps all eight corners inside the level's part of the table)
+      s0 = min(__umul24(__umul24(c.gz - z0, ny) + (c.gy - y0), nx) + (c.gx - x0), sgpr(lbox[level][7])) + sgpr(slot_off[level]);
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) idx[k] = corner_index(p, c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + (k >> 2));
@@ -609,7 +625,8 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       float dxl[4], lx[4];  // along x at the four (y, z) edges: difference and blend
 #pragma unroll
       for (int e = 0; e < 4; ++e) { dxl[e] = q[2 * e + 1] - q[2 * e]; lx[e] = fmaf(c.wx, dxl[e], q[2 * e]); }
-      const float sx = fmaf(c.wz, fmaf(c.wy, dxl[3] - dxl[2], dxl[2]) - fmaf(c.wy, dxl[1] - dxl[0], dxl[0]), fmaf(c.wy, dxl[1] - dxl[0], dxl[0]));
+      const float sx0 = fmaf(c.wy, dxl[1] - dxl[0], dxl[0]), sx1 = fmaf(c.wy, dxl[3] - dxl[2], dxl[2]);
+      const float sx = fmaf(c.wz, sx1 - sx0, sx0);
       const float dy0 = lx[1] - lx[0], dy1 = lx[3] - lx[2];  // along y at z = 0, 1
       const float sy = fmaf(c.wz, dy1 - dy0, dy0);
       const float sz = fmaf(c.wy, dy1, lx[2]) - fmaf(c.wy, dy0, lx[0]);
@@ -670,40 +687,242 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
 #undef NESVOR_SCAN_STEP
   };
 
+  // one corner's F values -> the slot's fixed-point words
+  auto slot_add = [&](uint32_t slot, const float (&v)[F]) __attribute__((always_inline)) {
+    if constexpr (kPack) {
+      const int32_t q0 = __float2int_rn(v[0] * fscale), q1 = __float2int_rn(v[1] * fscale);
+      // ((int64)q1 << 32) + (int64)q0: the low field's sign borrows from the high field; undone when the slot is read
+      atomicAdd(&tvals[slot], ((unsigned long long)(uint32_t)(q1 + (q0 >> 31)) << 32) | (unsigned long long)(uint32_t)q0);
+    } else {
+#pragma unroll
+      for (int f = 0; f < F; ++f) atomicAdd(&tvals[f * kSlots + slot], to_fixed(v[f] * fscale));
+    }
+  };
+  // read + clear one slot; false: nothing was added (or everything cancelled exactly)
+  auto slot_take = [&](uint32_t slot, float (&v)[F]) __attribute__((always_inline)) -> bool {
+    bool any = false;
+    if constexpr (kPack) {
+      const unsigned long long w = tvals[slot];
+      any = w != 0ull;
+      if (any) {
+        const int32_t lo = (int32_t)(uint32_t)w;
+        const int32_t hi = (int32_t)(uint32_t)(w >> 32) - (lo >> 31);
+        v[0] = (float)lo * finv; v[1] = (float)hi * finv;
+        tvals[slot] = 0ull;
+      }
+    } else {
+      unsigned long long w[F];
+#pragma unroll
+      for (int f = 0; f < F; ++f) { w[f] = tvals[f * kSlots + slot]; any = any || w[f] != 0ull; }
+      if (any) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) { v[f] = from_fixed(w[f]) * finv; tvals[f * kSlots + slot] = 0ull; }
+      }
+    }
+    return any;
+  };
+
   float dy_a[F], dy_b[F];
-  uint32_t idx[8], idx_n[8];
-  float val[8][F], val_n[8][F];
-  uint32_t s0 = 0, s0_n = 0;
-  bool tail, tail_n = false;
-  const int level_end = plan.level_end;
-  load_dy(plan.level_begin, dy_a);
-  if (plan.level_begin + 1 < level_end) load_dy(plan.level_begin + 1, dy_b);
-  if (plan.level_begin < box_end) {
-    float feat[NRB][F];
-    uint32_t unused[NRB];
-    box_keys(plan.level_begin, unused, feat);
-    box_store(plan.level_begin, feat);
-    if constexpr (INPUT_GRAD) __syncthreads();
-    prepare(std::true_type{}, plan.level_begin, dy_a, idx, s0, val, tail);
-  } else {
-    prepare(std::false_type{}, plan.level_begin, dy_a, idx, s0, val, tail);
-  }
-  if constexpr (MERGE) __syncthreads();  // wmax of the first level must be visible to the other waves
-  // Three loops in sequence - box-slot levels, hashed-table levels, direct levels - rather than branches inside one
-  // loop, so that the compiler cannot hoist the common second half of the paths above the branch (which made
-  // everything of the next level live during the insertion).  Merging into the hashed table is on until it stops
-  // paying (merge_off is set once, workgroup-uniformly, before a barrier).
   int level = plan.level_begin;
-  bool merge = MERGE;
-  bool box = false;
-  {
+  load_dy(level, dy_a);
+  if (level + 1 < level_end) load_dy(level + 1, dy_b);
+
+  // ======================================================================================================== (A)
+  // Box rounds.  A round = consecutive levels whose lattice boxes fit the table together (for a PSF cloud: levels
+  // 0-5, 6-8, 9-10, then one level per round): ONE insertion / drain / queue reservation / record write sequence and
+  // two barriers for all of them.  The table work of a level costs the same latency chain whether its box has 27
+  // or 700 vertices, so sharing it is what shortens the pass.  Pipeline (one barrier between the lines):
+  //     W(r-1) write the previous round's records | D(r) drain the table into records, count them per bucket,
+  //                                                 fill the keys and the table copy of round r+1
+  //     R(r) reserve queue space (returning global atomics, ~2 us, hidden behind:)
+  //                                               | P(r+1) per level of round r+1: prepare + insert the run tails
+  constexpr int NRB = kSlots / 256;  // slots per thread: thread t owns slots t, t + 256, ... (fill and drain)
+  if constexpr (MERGE) {
+    // keys (tkeys) and table entries (tcache) of the slots of round [ra, rb): a slot is read and written by its owner
+    // thread only, so only the table copy needs the barrier that follows.  The loads are returned in `feat` so that
+    // they can fly while the caller does other work; store_feat() puts them into tcache.
+    auto fill_keys = [&](int ra, int rb, float (&feat)[NRB][F]) __attribute__((always_inline)) {
+      const uint32_t total = sgpr(slot_off[rb]);
+#pragma unroll
+      for (int j = 0; j < NRB; ++j) {
+        const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
+#pragma unroll
+        for (int f = 0; f < F; ++f) feat[j][f] = 0.f;
+        if (slot < total) {
+          int lv = ra;
+          for (int l = ra + 1; l < rb; ++l) lv = slot >= slot_off[l] ? l : lv;
+          const uint32_t local = slot - slot_off[lv];
+          const uint32_t nx = lbox[lv][3] + 2u, nxy = nx * (lbox[lv][4] + 2u);
+          // local slot -> lattice point (local < 1024: the float quotients are exact after truncation)
+          const uint32_t z = (uint32_t)(((float)local + 0.5f) * (1.f / (float)nxy));
+          const uint32_t r = local - __umul24(z, nxy);
+          const uint32_t y = (uint32_t)(((float)r + 0.5f) * (1.f / (float)nx));
+          LevelParams pl;
+          pl.scale = 0.f; pl.res = lpar[lv][0]; pl.size = lpar[lv][1]; pl.offset = lpar[lv][2]; pl.hashed = lpar[lv][3];
+          const uint32_t key = corner_index(pl, lbox[lv][0] + (r - __umul24(y, nx)), lbox[lv][1] + y, lbox[lv][2] + z);
+          tkeys[slot] = ((uint32_t)lv << 27) | key;
+          if constexpr (INPUT_GRAD) load_feat<F>(table + ((size_t)pl.offset + key) * F, feat[j]);
+        }
+      }
+    };
+    auto store_feat = [&](int rb, const float (&feat)[NRB][F]) __attribute__((always_inline)) {
+      if constexpr (INPUT_GRAD) {
+        const uint32_t total = sgpr(slot_off[rb]);
+#pragma unroll
+        for (int j = 0; j < NRB; ++j) {
+          const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
+          if (slot < total) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) tcache[slot * F + f] = feat[j][f];
+          }
+        }
+      }
+    };
+    // P: prepare + insert every level of round [ra, rb)
+    auto insert_round = [&](int ra, int rb) __attribute__((always_inline)) {
+#pragma unroll 1
+      for (int lv = ra; lv < rb; ++lv) {
+        uint32_t idx_unused[8], s0, nx, nxy;
+        float val[8][F];
+        bool tail;
+        prepare(std::true_type{}, lv, dy_a, idx_unused, s0, nx, nxy, val, tail);
+#pragma unroll
+        for (int f = 0; f < F; ++f) dy_a[f] = dy_b[f];
+        if (lv + 2 < level_end) load_dy(lv + 2, dy_b);
+        if (!NESVOR_ABL(4) && tail) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) slot_add(s0 + (k & 1) + ((k >> 1) & 1) * nx + (k >> 2) * nxy, val[k]);
+        }
+      }
+    };
+
+    if (level < box_end) {
+      int ra = level, rb = (int)sgpr(grp_end[level]);
+      {
+        float feat[NRB][F];
+        fill_keys(ra, rb, feat);
+        store_feat(rb, feat);
+      }
+      if constexpr (INPUT_GRAD) __syncthreads();
+      insert_round(ra, rb);
+      uint32_t rkey[NRB], rmeta[NRB], rank[NRB], rmask = 0;  // records of the round being finished: entry index,
+      float rval[NRB][F];                                    // level << 8 | round-local bucket, rank inside the bucket
+      bool have_prev = false;
+      for (;;) {
+        __syncthreads();  // -- insertions of round [ra, rb) complete; bbase4 of the previous round published
+        // W(r-1)
+        if (have_prev && !NESVOR_ABL(8)) {
+#pragma unroll
+          for (int j = 0; j < NRB; ++j) {
+            if (!(rmask & (1u << j))) continue;
+            const uint4 bb = bbase4[rmeta[j] & 0xFFu];
+            const uint32_t pos = bb.x + rank[j];
+            if (pos < bb.z) {
+              uint32_t* r = records + ((size_t)bb.y + pos) * (1 + F);
+              r[0] = rkey[j];
+#pragma unroll
+              for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(rval[j][f]);
+            } else {  // queue full: exact fallback
+#pragma unroll
+              for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)lpar[rmeta[j] >> 8][2] + rkey[j]) * F + f, rval[j][f]);
+            }
+          }
+        }
+        // D(r): this thread's slots -> records; the next round's keys replace the current ones and its table entries are
+        // fetched meanwhile
+        const int na = rb, nb_ = na < box_end ? (int)sgpr(grp_end[na]) : na;
+        const bool next_box = na < box_end;
+        const uint32_t n_slots = sgpr(slot_off[rb]);
+        uint32_t lk[NRB];
+#pragma unroll
+        for (int j = 0; j < NRB; ++j) lk[j] = tkeys[j * 256 + tid];
+        float nfeat[NRB][F];
+        if (next_box) {
+          fill_keys(na, nb_, nfeat);
+        } else {
+#pragma unroll
+          for (int j = 0; j < NRB; ++j) tkeys[j * 256 + tid] = kEmpty;  // the hashed table of the next level starts empty
+        }
+        rmask = 0;
+#pragma unroll
+        for (int j = 0; j < NRB; ++j) {
+          rank[j] = 0; rkey[j] = 0; rmeta[j] = 0;
+#pragma unroll
+          for (int f = 0; f < F; ++f) rval[j][f] = 0.f;
+          const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
+          if (slot < n_slots && slot_take(slot, rval[j])) {
+            const uint32_t lv = lk[j] >> 27;
+            rkey[j] = lk[j] & kKeyMask;
+            const uint32_t bucket = bkt_off[lv] + (rkey[j] >> plan.chunk_shift);
+            rmeta[j] = (lv << 8) | bucket;
+            rmask |= 1u << j;
+            rank[j] = atomicAdd(&bcount[bucket], 1u);
+          }
+        }
+        if (next_box) store_feat(nb_, nfeat);  // every read of the current round's copy happened before the barrier above
+        have_prev = true;
+        __syncthreads();  // -- bucket counts of round [ra, rb) complete, table drained, next round's copy in place
+        // R(r): one returning (memory-side, ~2 us) atomic per non-empty bucket of the round
+        const uint32_t nbk = sgpr(bkt_off[rb]);
+        uint4 mine = make_uint4(0u, 0u, 0u, 0u);
+        if ((uint32_t)tid < nbk) {
+          int lv = ra;
+          for (int l = ra + 1; l < rb; ++l) lv = (uint32_t)tid >= bkt_off[l] ? l : lv;
+          const uint32_t chunk = (uint32_t)tid - bkt_off[lv], cap = lpar[lv][4];
+          const uint32_t cnt = bcount[tid];
+          bcount[tid] = 0;
+          uint32_t pos0 = 0;
+          if (cnt && !NESVOR_ABL(16)) pos0 = atomicAdd(&tails[sub * kTailStride + lpar[lv][5] + chunk], cnt);
+          mine = make_uint4(pos0, lpar[lv][6] + (chunk * plan.n_sub + sub) * cap, cap, (uint32_t)lv);
+        }
+        // ... hidden behind P(r+1)
+        level = rb;
+        if (next_box) insert_round(na, nb_);
+        if ((uint32_t)tid < nbk) bbase4[tid] = mine;
+        if (!next_box) break;
+        ra = na; rb = nb_;
+      }
+      __syncthreads();
+      // W(last box round)
+      if (!NESVOR_ABL(8)) {
+#pragma unroll
+        for (int j = 0; j < NRB; ++j) {
+          if (!(rmask & (1u << j))) continue;
+          const uint4 bb = bbase4[rmeta[j] & 0xFFu];
+          const uint32_t pos = bb.x + rank[j];
+          if (pos < bb.z) {
+            uint32_t* r = records + ((size_t)bb.y + pos) * (1 + F);
+            r[0] = rkey[j];
+#pragma unroll
+            for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(rval[j][f]);
+          } else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)lpar[rmeta[j] >> 8][2] + rkey[j]) * F + f, rval[j][f]);
+          }
+        }
+      }
+      __syncthreads();  // bb_raw is re-used (as bbase) by the single-level rounds below
+    }
+  }
+
+  // ================================================================================================= (B), (C)
+  // Single-level rounds: hashed merge table while it pays (merge_off is set once, workgroup-uniformly, before a
+  // barrier), then direct records.  Two loops in sequence rather than a branch inside one loop, so that the compiler
+  // cannot hoist the common second half of the two paths above the branch (which made everything of the next level live
+  // during the insertion).
+  if (level < level_end) {
+    uint32_t idx[8], idx_n[8];
+    float val[8][F], val_n[8][F];
+    uint32_t su = 0, nxu = 1, nxyu = 1;  // (box-only outputs of prepare)
+    bool tail, tail_n = false;
+    prepare(std::false_type{}, level, dy_a, idx, su, nxu, nxyu, val, tail);
+    bool merge = MERGE;
     // Second half of a level, specialised on the number NR of records a thread can hold (table slots per thread in
     // merge mode, the 8 corners otherwise) so that the merge path does not carry 8 record registers sets through the
     // next level's prepare(): reserve queue space, prepare the next level, write the records.
     // in_place: the current level's idx / val are dead (merge path: the records were drained from the table), so the
     // next level is prepared straight into them - no copy at the end of the level
-    // next_may_box: the next level may still be a box level (loop A only; prunes the box variant of prepare() elsewhere)
-    auto finish_level = [&](auto& rkey, auto& rank, auto& rval, uint32_t rmask, auto in_place, auto next_may_box) __attribute__((always_inline)) {
+    auto finish_level = [&](auto& rkey, auto& rank, auto& rval, uint32_t rmask, auto in_place) __attribute__((always_inline)) {
       constexpr int NR = sizeof(rkey) / sizeof(rkey[0]);
       __syncthreads();
       // reserve queue space: one returning (memory-side, ~2 us) atomic per non-empty chunk ...
@@ -716,10 +935,10 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         bcount[tid] = 0;
       }
       if (merge && tid == 255) {
-        // merging stops paying once fewer than a quarter of the records collapse, and (hashed table) must stop
-        // before the table gets crowded
+        // merging stops paying once fewer than a quarter of the records collapse, and must stop before the table gets
+        // crowded
         const uint32_t drained = merge_stat[1];
-        if (!box && (drained * 4u > merge_stat[0] * 3u || drained * 10u > (uint32_t)kSlots * 7u)) merge_off = 1u;
+        if (drained * 4u > merge_stat[0] * 3u || drained * 10u > (uint32_t)kSlots * 7u) merge_off = 1u;
         uint32_t lg = 8;
         while ((1u << lg) < 4u * drained && (1u << lg) < (uint32_t)kSlots) ++lg;
         slots_log2 = lg;
@@ -730,12 +949,8 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
 #pragma unroll
         for (int f = 0; f < F; ++f) dy_a[f] = dy_b[f];
         if (level + 2 < level_end) load_dy(level + 2, dy_b);
-        if constexpr (decltype(in_place)::value) {
-          if (decltype(next_may_box)::value && level + 1 < box_end) prepare(std::true_type{}, level + 1, dy_a, idx, s0, val, tail);
-          else prepare(std::false_type{}, level + 1, dy_a, idx, s0, val, tail);
-        } else {
-          prepare(std::false_type{}, level + 1, dy_a, idx_n, s0_n, val_n, tail_n);
-        }
+        if constexpr (decltype(in_place)::value) prepare(std::false_type{}, level + 1, dy_a, idx, su, nxu, nxyu, val, tail);
+        else prepare(std::false_type{}, level + 1, dy_a, idx_n, su, nxu, nxyu, val_n, tail_n);
       }
       if (tid < nb) bbase[level & 1][tid] = make_uint2(my_base, (tid * plan.n_sub + sub) * cap);
       __syncthreads();
@@ -748,15 +963,9 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         const uint32_t pos = bb.x + rank[k];
         if (pos < cap) {
           uint32_t* r = reinterpret_cast<uint32_t*>(level_rec + (bb.y + pos) * (uint32_t)(4 * (1 + F)));
-#if defined(NESVOR_REC_NT) && NESVOR_REC_NT
-          __builtin_nontemporal_store(rkey[k], r);
-#pragma unroll
-          for (int f = 0; f < F; ++f) __builtin_nontemporal_store(__float_as_uint(rval[k][f]), r + 1 + f);
-#else
           r[0] = rkey[k];
 #pragma unroll
           for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(rval[k][f]);
-#endif
         } else {  // queue full: exact fallback
 #pragma unroll
           for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + rkey[k]) * F + f, rval[k][f]);
@@ -772,108 +981,11 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       }
       tail = tail_n;
     };
-    // fixed-point scale of a level: the adds of one slot sum to at most 256 max|dy| (corner weights of a sample sum to
-    // 1), which is mapped below 2^61 (2^30 for the packed 32-bit fields)
-    auto level_scale = [&](int lv, float& fscale, float& finv) __attribute__((always_inline)) {
-      const float mx = 256.f * fmaxf(fmaxf(wmax[lv & 1][0], wmax[lv & 1][1]), fmaxf(wmax[lv & 1][2], wmax[lv & 1][3]));
-      int sexp = (kPack ? 29 : 60) - ((int)((__float_as_uint(mx) >> 23) & 0xFFu) - 127);
-      sexp = sexp > 100 ? 100 : sexp;
-      fscale = __uint_as_float((uint32_t)(sexp + 127) << 23);
-      finv = __uint_as_float((uint32_t)(127 - sexp) << 23);
-    };
-    // one corner's F values -> the slot's fixed-point words
-    auto slot_add = [&](uint32_t slot, const float (&v)[F], float fscale) __attribute__((always_inline)) {
-      if constexpr (kPack) {
-        const int32_t q0 = __float2int_rn(v[0] * fscale), q1 = __float2int_rn(v[1] * fscale);
-        // ((int64)q1 << 32) + (int64)q0: the low field's sign borrows from the high field; undone when the slot is read
-        atomicAdd(&tvals[slot], ((unsigned long long)(uint32_t)(q1 + (q0 >> 31)) << 32) | (unsigned long long)(uint32_t)q0);
-      } else {
-#pragma unroll
-        for (int f = 0; f < F; ++f) atomicAdd(&tvals[f * kSlots + slot], to_fixed(v[f] * fscale));
-      }
-    };
-    // read + clear one slot; false: nothing was added (or everything cancelled exactly)
-    auto slot_take = [&](uint32_t slot, float (&v)[F], float finv) __attribute__((always_inline)) -> bool {
-      bool any = false;
-      if constexpr (kPack) {
-        const unsigned long long w = tvals[slot];
-        any = w != 0ull;
-        if (any) {
-          const int32_t lo = (int32_t)(uint32_t)w;
-          const int32_t hi = (int32_t)(uint32_t)(w >> 32) - (lo >> 31);
-          v[0] = (float)lo * finv; v[1] = (float)hi * finv;
-          tvals[slot] = 0ull;
-        }
-      } else {
-        unsigned long long w[F];
-#pragma unroll
-        for (int f = 0; f < F; ++f) { w[f] = tvals[f * kSlots + slot]; any = any || w[f] != 0ull; }
-        if (any) {
-#pragma unroll
-          for (int f = 0; f < F; ++f) { v[f] = from_fixed(w[f]) * finv; tvals[f * kSlots + slot] = 0ull; }
-        }
-      }
-      return any;
-    };
-
     if constexpr (MERGE) {
-      // ---- (A) box-slot levels: a slot is the vertex's position inside the lattice box of the workgroup's samples -
-      //      no keys, no compare-and-swap claims, no probing; the entry index of a slot is known to the thread that
-      //      drains it (box_keys), which also fetched the entry for the input gradient's LDS copy of the box
-      box = true;
-      for (; level < box_end; ++level) {
-        uint32_t rkey[NRB], rank[NRB], rmask = 0;
-        float rval[NRB][F];
-        float fscale, finv;
-        level_scale(level, fscale, finv);
-        const uint32_t nx = sgpr(lbox[level][3]) + 2u, nxy = nx * (sgpr(lbox[level][4]) + 2u);
-        const bool next_box = level + 1 < box_end;
-        if (!NESVOR_ABL(4) && tail) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) slot_add(s0 + (k & 1) + ((k >> 1) & 1) * nx + (k >> 2) * nxy, val[k], fscale);
-        }
-        // this thread's slots: entry indices of the current level (from tkeys); the next level's indices replace them
-        // and its table entries are fetched now - the loads fly during the barrier and the drain
-        float nfeat[NRB][F];
-        if (next_box) {
-          box_keys(level + 1, rkey, nfeat);
-        } else {
-#pragma unroll
-          for (int j = 0; j < NRB; ++j) {
-            rkey[j] = tkeys[j * 256 + tid];
-            tkeys[j * 256 + tid] = kEmpty;  // the hashed table of the next level starts empty
-          }
-        }
-        __syncthreads();
-        // drain: slot -> register record, slot cleared for the next level
-        const uint32_t n_slots = sgpr(lbox[level][6]);
-#pragma unroll
-        for (int j = 0; j < NRB; ++j) {
-          rank[j] = 0;
-#pragma unroll
-          for (int f = 0; f < F; ++f) rval[j][f] = 0.f;
-          const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
-          if (slot < n_slots && slot_take(slot, rval[j], finv)) {
-            rmask |= 1u << j;
-            rank[j] = atomicAdd(&bcount[rkey[j] >> plan.chunk_shift], 1u);
-          }
-        }
-        if (next_box) {
-          box_store(level + 1, nfeat);  // every read of the current level's copy happened before the barrier above
-        } else {  // the hashed table of the next level is sized from this level's vertex count
-          const uint32_t wave_mine = (uint32_t)wave_sum_u32(__builtin_popcount(rmask));
-          if (lane == 0 && wave_mine) atomicAdd(&merge_stat[1], wave_mine);
-        }
-        finish_level(rkey, rank, rval, rmask, std::true_type{}, std::true_type{});
-      }
-      box = false;
-      // ---- (B) hashed merge table
       for (; level < level_end && merge_off == 0u; ++level) {
         constexpr int NR = kSlots / 256;
         uint32_t rkey[NR], rank[NR], rmask = 0;
         float rval[NR][F];
-        float fscale, finv;
-        level_scale(level, fscale, finv);
         const uint32_t slog = slots_log2, smask = (1u << slog) - 1u;
         if (!NESVOR_ABL(4) && tail) {
           uint32_t h[8];
@@ -909,7 +1021,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
 #pragma unroll
               for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + idx[k]) * F + f, val[k][f]);
             } else {
-              slot_add(h[k], val[k], fscale);
+              slot_add(h[k], val[k]);
             }
           }
         }
@@ -930,24 +1042,23 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
           if (key != kEmpty) {
             tkeys[slot] = kEmpty;
             rmask |= 1u << j; rkey[j] = key;
-            slot_take(slot, rval[j], finv);
+            slot_take(slot, rval[j]);
             rank[j] = atomicAdd(&bcount[key >> plan.chunk_shift], 1u);
             ++mine;
           }
         }
         const uint32_t wave_mine = (uint32_t)wave_sum_u32(mine);
         if (lane == 0 && wave_mine) atomicAdd(&merge_stat[1], wave_mine);
-        finish_level(rkey, rank, rval, rmask, std::true_type{}, std::false_type{});
+        finish_level(rkey, rank, rval, rmask, std::true_type{});
       }
     }
     merge = false;
-    // ---- (C) direct: every run tail's 8 corners become records
     for (; level < level_end; ++level) {
       // rank of every record inside its chunk's span (LDS integer atomics: ~6 cycles / wave-instruction)
       uint32_t rank[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) rank[k] = tail ? atomicAdd(&bcount[idx[k] >> plan.chunk_shift], 1u) : 0u;
-      finish_level(idx, rank, val, tail ? 0xFFu : 0u, std::false_type{}, std::false_type{});
+      finish_level(idx, rank, val, tail ? 0xFFu : 0u, std::false_type{});
       advance();
     }
   }
@@ -1155,6 +1266,7 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
   static const uint32_t box = []() { const char* e = getenv("NESVOR_HASHGRID_BOX"); return (e == nullptr || atoi(e) != 0) ? 1u : 0u; }();
   plan->box_slots = box;
   plan->level_begin = 0; plan->level_end = g->n_levels; plan->accumulate_u = 0;
+  if (off > 0xFFFFFFFFull) return false;  // records are addressed by 32-bit record numbers
   *n_records = off;
   return true;
 }
