@@ -409,6 +409,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
   // box rounds (groups of consecutive levels whose boxes share the table): per level the first slot of its box, the
   // first (round-local) bucket of its chunks, and the end of its round
   __shared__ uint32_t slot_off[NESVOR_MAX_LEVELS + 1], bkt_off[NESVOR_MAX_LEVELS + 1], grp_end[NESVOR_MAX_LEVELS + 1];
+  __shared__ uint32_t rnd_slots[NESVOR_MAX_LEVELS + 1], rnd_bkts[NESVOR_MAX_LEVELS + 1];  // totals of a round, at its first level
   // per level, for code that indexes levels per LANE (kernel arguments can only be indexed uniformly without a trip
   // through scratch memory): res, size, offset, hashed, queue capacity, first bucket, first record, chunks
   __shared__ uint32_t lpar[NESVOR_MAX_LEVELS + 1][8];
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
           ++b;
         }
         for (int l = a; l < b; ++l) grp_end[l] = (uint32_t)b;
-        slot_off[b] = slots; bkt_off[b] = bk;  // totals of the round, overwritten if level b opens the next round
+        rnd_slots[a] = slots; rnd_bkts[a] = bk;
         a = b;
       }
     }
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
     // thread only, so only the table copy needs the barrier that follows.  The loads are returned in `feat` so that
     // they can fly while the caller does other work; store_feat() puts them into tcache.
     auto fill_keys = [&](int ra, int rb, float (&feat)[NRB][F]) __attribute__((always_inline)) {
-      const uint32_t total = sgpr(slot_off[rb]);
+      const uint32_t total = sgpr(rnd_slots[ra]);
 #pragma unroll
       for (int j = 0; j < NRB; ++j) {
         const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
@@ -765,9 +766,9 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         }
       }
     };
-    auto store_feat = [&](int rb, const float (&feat)[NRB][F]) __attribute__((always_inline)) {
+    auto store_feat = [&](int ra, const float (&feat)[NRB][F]) __attribute__((always_inline)) {
       if constexpr (INPUT_GRAD) {
-        const uint32_t total = sgpr(slot_off[rb]);
+        const uint32_t total = sgpr(rnd_slots[ra]);
 #pragma unroll
         for (int j = 0; j < NRB; ++j) {
           const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
@@ -801,7 +802,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       {
         float feat[NRB][F];
         fill_keys(ra, rb, feat);
-        store_feat(rb, feat);
+        store_feat(ra, feat);
       }
       if constexpr (INPUT_GRAD) __syncthreads();
       insert_round(ra, rb);
@@ -832,7 +833,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         // fetched meanwhile
         const int na = rb, nb_ = na < box_end ? (int)sgpr(grp_end[na]) : na;
         const bool next_box = na < box_end;
-        const uint32_t n_slots = sgpr(slot_off[rb]);
+        const uint32_t n_slots = sgpr(rnd_slots[ra]);
         uint32_t lk[NRB];
 #pragma unroll
         for (int j = 0; j < NRB; ++j) lk[j] = tkeys[j * 256 + tid];
@@ -859,11 +860,11 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
             rank[j] = atomicAdd(&bcount[bucket], 1u);
           }
         }
-        if (next_box) store_feat(nb_, nfeat);  // every read of the current round's copy happened before the barrier above
+        if (next_box) store_feat(na, nfeat);  // every read of the current round's copy happened before the barrier above
         have_prev = true;
         __syncthreads();  // -- bucket counts of round [ra, rb) complete, table drained, next round's copy in place
         // R(r): one returning (memory-side, ~2 us) atomic per non-empty bucket of the round
-        const uint32_t nbk = sgpr(bkt_off[rb]);
+        const uint32_t nbk = sgpr(rnd_bkts[ra]);
         uint4 mine = make_uint4(0u, 0u, 0u, 0u);
         if ((uint32_t)tid < nbk) {
           int lv = ra;
