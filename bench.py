@@ -174,6 +174,7 @@ def main():
                     help="the reference's default model structure (args.dtype float16: bias-free networks), evaluated with bf16 "
                          "matrix operands and fp32 accumulation: NOT the headline configuration")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (copy peak, micro-benchmarks, inference)")
     opt = ap.parse_args()
 
     import __graft_entry__ as ge
@@ -295,7 +296,9 @@ def main():
                   "points_per_gpu_per_iter": opt.batch_size * opt.n_samples // world,
                   "note": "same run; python bench.py --scaling strong makes this the headline value"}
 
-    extras = measure_extras(model, args, device, opt) if rank == 0 else None
+    extras = measure_extras(model, args, device, opt) if (rank == 0 and not opt.no_extras) else None
+    if extras is None:
+        extras = {"copy_peak_GBps": None, "fill_peak_GBps": None, "roofline_uniform": None, "roofline_fwd_bwd_strict": None, "inference": None}
 
     if rank == 0:
         n_points = global_b * opt.n_samples // world  # per GPU per step

@@ -533,9 +533,11 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       fscale = __uint_as_float((uint32_t)(sexp + 127) << 23);
       finv = __uint_as_float((uint32_t)(127 - sexp) << 23);
     }
-    // the lattice boxes of all levels at once (thread l: level l) instead of two locate() per level in every thread
-    if (tid <= g.n_levels) {
+    // the lattice boxes of all levels at once (wave 0, lane l: level l) instead of two locate() per level in every
+    // thread, and the round schedule from them (uniform loop over the levels, v_readlane picks a level's numbers)
+    if (tid < 64) {
       uint32_t b[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+      uint32_t nch = 0u;
       if (tid < g.n_levels) {
         const LevelParams p = load_level(g, tid);
         const CellPos blo = locate(p, ulo[0], ulo[1], ulo[2]), bhi = locate(p, uhi[0], uhi[1], uhi[2]);
@@ -545,34 +547,36 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         const uint32_t nx = ex + 2u, nxy = nx * (ey + 2u), vol = fits ? nxy * (ez + 2u) : 0u;
         b[0] = blo.gx; b[1] = blo.gy; b[2] = blo.gz; b[3] = ex; b[4] = ey; b[5] = ez; b[6] = vol;
         b[7] = fits ? vol - 2u - nx - nxy : 0u;  // = slot (inside the box) of the first corner of the box's last cell
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) lbox[tid][q] = b[q];  // row n_levels: all zero (a level past the end is "not a box")
-      if (tid < g.n_levels) {
-        lpar[tid][0] = g.res[tid]; lpar[tid][1] = g.size[tid]; lpar[tid][2] = g.offset[tid]; lpar[tid][3] = g.hashed[tid];
+        nch = plan.n_chunks[tid];
+        lpar[tid][0] = p.res; lpar[tid][1] = p.size; lpar[tid][2] = p.offset; lpar[tid][3] = p.hashed;
         lpar[tid][4] = plan.cap[tid]; lpar[tid][5] = plan.bucket_base[tid]; lpar[tid][6] = (uint32_t)plan.rec_off[tid];
-        lpar[tid][7] = plan.n_chunks[tid];
+        lpar[tid][7] = nch;
       }
-    }
-    __syncthreads();
-    if (tid == 0) {
+      if (tid <= g.n_levels) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lbox[tid][q] = b[q];  // row n_levels: all zero (a level past the end is "not a box")
+      }
       // box levels = the longest prefix of levels whose box fits the table; consecutive box levels share a round
       // while their boxes fit the table together and their chunks the bucket counters
+      auto vol_of = [&](int l) { return (uint32_t)__builtin_amdgcn_readlane((int)b[6], l); };
+      auto nch_of = [&](int l) { return (uint32_t)__builtin_amdgcn_readlane((int)nch, l); };
       int e = plan.level_begin;
-      while (e < level_end && lbox[e][6] != 0u) ++e;
-      box_end_s = e;
+      while (e < level_end && vol_of(e) != 0u) ++e;
+      if (tid == 0) box_end_s = e;
       int a = plan.level_begin;
       while (a < e) {
         uint32_t slots = 0, bk = 0;
-        int b = a;
-        while (b < e && b - a < kMaxGroup && slots + lbox[b][6] <= (uint32_t)kSlots && bk + plan.n_chunks[b] <= (uint32_t)kMaxChunks) {
-          slot_off[b] = slots; bkt_off[b] = bk;
-          slots += lbox[b][6]; bk += plan.n_chunks[b];
-          ++b;
+        int bnd = a;
+        while (bnd < e && bnd - a < kMaxGroup && slots + vol_of(bnd) <= (uint32_t)kSlots && bk + nch_of(bnd) <= (uint32_t)kMaxChunks) {
+          if (tid == 0) { slot_off[bnd] = slots; bkt_off[bnd] = bk; }
+          slots += vol_of(bnd); bk += nch_of(bnd);
+          ++bnd;
         }
-        for (int l = a; l < b; ++l) grp_end[l] = (uint32_t)b;
-        rnd_slots[a] = slots; rnd_bkts[a] = bk;
-        a = b;
+        if (tid == 0) {
+          for (int l = a; l < bnd; ++l) grp_end[l] = (uint32_t)bnd;
+          rnd_slots[a] = slots; rnd_bkts[a] = bk;
+        }
+        a = bnd;
       }
     }
     __syncthreads();
@@ -1117,7 +1121,7 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
   if (r0 >= n) return;
   const uint32_t r1 = min(n, r0 + plan.slice[level]);
   const bool sole_writer = n <= plan.slice[level];
-  for (int t = tid; t < kOwnerLdsFloats; t += kOwnerThreads) acc[t] = 0.f;
+  for (int t = tid; t < kOwnerLdsFloats / 4; t += kOwnerThreads) reinterpret_cast<float4*>(acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   const uint32_t mask = (1u << plan.chunk_shift) - 1u;
   const uint32_t* rec = records + (plan.rec_off[level] + (uint64_t)chunk * plan.n_sub * plan.cap[level]) * (1 + F);
@@ -1148,6 +1152,28 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
   if constexpr (COALESCED) {
     // merged queues: a workgroup of the aggregation pass emits every vertex once per level, so neighbouring
     // records no longer repeat a table entry and neighbouring lanes can take neighbouring records
+#if defined(NESVOR_OWNER_PRED) && NESVOR_OWNER_PRED
+    // batches of kUnroll predicated loads per thread: a bucket of a few thousand records (the common case) is one or two
+    // batches - one or two memory latencies - instead of a batch loop plus a one-record-at-a-time tail loop
+    for (uint32_t r = r0 + tid; r < r1; r += kUnroll * kOwnerThreads) {
+      uint32_t key[kUnroll];
+      float v[kUnroll][F];
+#pragma unroll
+      for (int j = 0; j < kUnroll; ++j) {
+        const uint32_t rr = r + j * kOwnerThreads;
+        key[j] = 0xFFFFFFFFu;
+        if (rr < r1) {
+          const uint32_t* q = rec + (size_t)slot_of(rr) * (1 + F);
+          key[j] = q[0];
+#pragma unroll
+          for (int f = 0; f < F; ++f) v[j][f] = __uint_as_float(q[1 + f]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kUnroll; ++j)
+        if (key[j] != 0xFFFFFFFFu) add_record(key[j], v[j]);
+    }
+#else
     uint32_t r = r0 + tid;
     for (; r + (kUnroll - 1) * kOwnerThreads < r1; r += kUnroll * kOwnerThreads) {
       uint32_t key[kUnroll];
@@ -1169,6 +1195,7 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
       for (int f = 0; f < F; ++f) v[f] = __uint_as_float(q[1 + f]);
       add_record(q[0], v);
     }
+#endif
   } else {
   const uint32_t per = (((r1 - r0 + kOwnerThreads - 1) / kOwnerThreads) + 31u) & ~31u;
   uint32_t r = r0 + tid * per;
@@ -1198,11 +1225,29 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
   const uint32_t e0 = chunk << plan.chunk_shift;
   const uint32_t ne = min((uint32_t)(1u << plan.chunk_shift), g.size[level] - e0);
   float* out = grad_table + ((size_t)g.offset[level] + e0) * F;
-  for (uint32_t t = tid; t < ne * F; t += kOwnerThreads) {
-    const float a = acc[t];
-    if (a != 0.f) {
-      if (sole_writer) out[t] += a;  // only writer of the chunk: plain read-modify-write
-      else atomicAdd(out + t, a);    // long queue shared by several slices (rare: coarse level, un-clustered input)
+#ifndef NESVOR_OWNER_F4
+#define NESVOR_OWNER_F4 1
+#endif
+  if (NESVOR_OWNER_F4 && sole_writer && (ne * F) % 4u == 0u) {
+    // only writer of the chunk: plain read-modify-write, four floats at a time where any of them is non-zero (chunks and
+    // level offsets are multiples of 8 entries, so the float4 accesses are aligned)
+    const float4* a4 = reinterpret_cast<const float4*>(acc);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    for (uint32_t t = tid; t < ne * F / 4u; t += kOwnerThreads) {
+      const float4 a = a4[t];
+      if (a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f) {
+        float4 o = o4[t];
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        o4[t] = o;
+      }
+    }
+  } else {
+    for (uint32_t t = tid; t < ne * F; t += kOwnerThreads) {
+      const float a = acc[t];
+      if (a != 0.f) {
+        if (sole_writer) out[t] += a;
+        else atomicAdd(out + t, a);  // long queue shared by several slices (rare: coarse level, un-clustered input)
+      }
     }
   }
 }

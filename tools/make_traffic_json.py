@@ -15,7 +15,13 @@ def avg(root, counter):
 
 
 fetch, write = avg(sys.argv[1], "FETCH_SIZE"), avg(sys.argv[2], "WRITE_SIZE")
+import subprocess
+try:
+    commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+except Exception:
+    commit = "working tree of the gpurun snapshot"
 out = {
+    "commit": commit,
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python tools/prof_hashgrid.py P ; "
               "N=2^20, L=16, F=2, T=2^19, PSF-cloud points, input grad on",
     "unit": "bytes per launch",
