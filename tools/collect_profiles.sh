@@ -2,6 +2,7 @@
 # Round profiles on the GPU box (run from the repo root through gpurun): everything lands in gpurun_out/$TAG/ and is
 # copied into profiles/ by hand afterwards.   bash tools/collect_profiles.sh r02
 TAG=${1:-r02}
+export NESVOR_COMMIT=${2:-unknown}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT

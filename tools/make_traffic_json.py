@@ -15,11 +15,8 @@ def avg(root, counter):
 
 
 fetch, write = avg(sys.argv[1], "FETCH_SIZE"), avg(sys.argv[2], "WRITE_SIZE")
-import subprocess
-try:
-    commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
-except Exception:
-    commit = "working tree of the gpurun snapshot"
+import os
+commit = os.environ.get("NESVOR_COMMIT", "unknown")  # the gpurun snapshot carries no .git: the caller passes the commit
 out = {
     "commit": commit,
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python tools/prof_hashgrid.py P ; "
