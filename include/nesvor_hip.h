@@ -137,6 +137,10 @@ int nesvor_hashgrid_forward(const nesvor_grid_t* grid, const float* u, const flo
  * 1 = aggregation launch only, 2 = owner launch only (so a caller can bracket
  * each launch with its own events; 1 then 2 on one stream == 3). */
 int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t* grid, int64_t N);
+/* The first nesvor_hashgrid_backward_workspace_zero_bytes() bytes of a workspace (its two queue-tail regions) must be
+ * zero-filled ONCE after the workspace is allocated; the backward keeps them consistent afterwards (every aggregation
+ * pass zero-fills the region the next backward will use, so no memset launch is needed per call). */
+int64_t nesvor_hashgrid_backward_workspace_zero_bytes(void);
 int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* u, const float* table, const float* dpe,
                              float* grad_table, float* grad_u, int64_t N, int layout, void* workspace, int stages,
                              void* stream);

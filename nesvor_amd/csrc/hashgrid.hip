@@ -41,7 +41,9 @@
 //   result is exact for any input distribution.  The legacy all-atomics
 //   kernel is kept as hashgrid_bwd (used for tiny N and as a cross-check).
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 #include "common.h"
 #include "../../include/nesvor_hip.h"
 
@@ -373,7 +375,11 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
                                                               const float* __restrict__ dpe,
                                                               float* __restrict__ grad_table,
                                                               float* __restrict__ grad_u, uint32_t* __restrict__ tails,
+                                                              uint32_t* __restrict__ tails_next,
                                                               uint32_t* __restrict__ records, int64_t N) {
+  // the queue tails of the NEXT backward (the other of the workspace's two tail regions) are zero-filled here, so that
+  // no launch of its own is needed for it
+  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < (uint32_t)kSubQueues * kTailStride; t += gridDim.x * 256u) tails_next[t] = 0u;
   constexpr bool kPack = (F == 2) && (NESVOR_FIXED32 != 0);
   constexpr int kWords = kPack ? 1 : F;  // 64-bit words per slot
   __shared__ uint32_t bcount[kMaxChunks];
@@ -1317,7 +1323,19 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
   return true;
 }
 
-constexpr uint64_t kTailBytes = (uint64_t)kSubQueues * kTailStride * sizeof(uint32_t);  // tails region at the start of the workspace
+constexpr uint64_t kTailBytes = (uint64_t)kSubQueues * kTailStride * sizeof(uint32_t);  // one tails region; the workspace starts with two
+
+// Which of a workspace's two tail regions the current backward uses.  A fresh backward (not a later launch of a split
+// one) switches to the region the previous aggregation pass zero-filled; the caller zero-fills both once after
+// allocating the workspace (nesvor_hashgrid_backward_workspace_zero_bytes).
+inline int tails_parity(void* workspace, bool advance) {
+  static std::mutex mu;
+  static std::unordered_map<void*, int> parity;
+  std::lock_guard<std::mutex> lock(mu);
+  int& p = parity[workspace];
+  if (advance) p ^= 1;
+  return p;
+}
 
 template <int F, int LAYOUT>
 int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table, const float* dpe, float* gt,
@@ -1327,20 +1345,19 @@ int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table,
   if (!make_plan(g, N, &plan, &n_rec)) return (int)hipErrorInvalidValue;
   plan.level_begin = level_begin; plan.level_end = level_end;
   plan.accumulate_u = (stages & 8) ? 1 : 0;
-  uint32_t* tails = reinterpret_cast<uint32_t*>(workspace);
-  uint32_t* records = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + kTailBytes);
+  // bit 4: a later launch of a split backward - same region, the queue tails of its levels are still zero
+  const int par = tails_parity(workspace, (stages & 1) && !(stages & 4));
+  uint32_t* tails = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + (par ? kTailBytes : 0));
+  uint32_t* tails_next = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + (par ? 0 : kTailBytes));
+  uint32_t* records = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + 2 * kTailBytes);
   dim3 grid((unsigned)((N + 255) / 256)), block(256);
   hipError_t e;
   if (!(stages & 1)) goto owner_stage;
-  if (!(stages & 4)) {  // bit 4: a later launch of a split backward - the queue tails of its levels are still zero
-    e = hipMemsetAsync(tails, 0, kTailBytes, st);
-    if (e != hipSuccess) return (int)e;
-  }
   {
     static const bool merge = []() { const char* e = getenv("NESVOR_HASHGRID_MERGE"); return e == nullptr || atoi(e) != 0; }();
 #define NESVOR_LAUNCH_AGG(IG, MG)                                                                                     \
     hipLaunchKernelGGL((hashgrid_bwd_aggregate<F, LAYOUT, IG, MG>), grid, block, 0, st, *g, plan, u, table, dpe, gt, gu, \
-                       tails, records, N)
+                       tails, tails_next, records, N)
     if (gu != nullptr) { if (merge) NESVOR_LAUNCH_AGG(true, true); else NESVOR_LAUNCH_AGG(true, false); }
     else { if (merge) NESVOR_LAUNCH_AGG(false, true); else NESVOR_LAUNCH_AGG(false, false); }
 #undef NESVOR_LAUNCH_AGG
@@ -1421,8 +1438,10 @@ extern "C" int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t*
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return -1;
   if (!make_plan(grid, N, &plan, &n_rec)) return -1;
   if (plan.n_buckets > kTailStride) return -1;
-  return (int64_t)(kTailBytes + n_rec * (1 + grid->n_features) * sizeof(uint32_t));
+  return (int64_t)(2 * kTailBytes + n_rec * (1 + grid->n_features) * sizeof(uint32_t));
 }
+
+extern "C" int64_t nesvor_hashgrid_backward_workspace_zero_bytes(void) { return (int64_t)(2 * kTailBytes); }
 
 extern "C" int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* u, const float* table,
                                         const float* dpe, float* grad_table, float* grad_u, int64_t N, int layout,

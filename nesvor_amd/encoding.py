@@ -37,6 +37,7 @@ def _workspace(spec, N, device):
         for k in [k for k in _WORKSPACES if k[0] == device]:
             del _WORKSPACES[k]  # one live workspace per device
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        ws[: _lib.load().nesvor_hashgrid_backward_workspace_zero_bytes()].zero_()  # queue tails: zero once, kept by the kernels
         _WORKSPACES[key] = ws
     return ws
 

@@ -25,10 +25,10 @@ python $ROOT/tools/pmc_summary.py owner $OUT/pmc_sq1 $OUT/pmc_sq2 > $OUT/pmc_sq_
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/step_$c -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-extras > /dev/null 2>&1
 done
-python $ROOT/tools/step_traffic.py $OUT/step_FETCH_SIZE $OUT/step_WRITE_SIZE 12 > $OUT/step_traffic.json
+python $ROOT/tools/step_traffic.py $OUT/step_FETCH_SIZE $OUT/step_WRITE_SIZE 24 > $OUT/step_traffic.json
 # 4. micro-benchmarks
 python $ROOT/tools/bench_hashgrid.py > $OUT/hashgrid_microbench.log 2>&1
 python $ROOT/tools/bench_hg_levels.py > $OUT/hashgrid_per_level.log 2>&1
-python $ROOT/tools/hg_variants.py r1:src=tools/hashgrid_r1.hip.txt r2: fixed32:-DNESVOR_FIXED32=1 noinsert:-DNESVOR_ABLATE=4 nowrite:-DNESVOR_ABLATE=8 noscan:-DNESVOR_ABLATE=2 > $OUT/hashgrid_ab.log 2>&1
+python $ROOT/tools/hg_variants.py r2: fixed32:-DNESVOR_FIXED32=1 noinsert:-DNESVOR_ABLATE=4 nowrite:-DNESVOR_ABLATE=8 noscan:-DNESVOR_ABLATE=2 > $OUT/hashgrid_ab.log 2>&1
 rm -rf $OUT/kstats $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/step_FETCH_SIZE $OUT/step_WRITE_SIZE
 ls -la $OUT
