@@ -124,7 +124,7 @@ def measure_extras(model, args, device, opt):
     gt = torch.zeros_like(table)
     res = {}
     for name, u in (("uniform", u_uniform), ("psf_cloud", u_cloud)):
-        tf = _events_ms(lambda: hashgrid_forward(spec, u, table, _lib.LAYOUT_FEATURE_MAJOR))
+        tf = _events_ms(lambda: hashgrid_forward(spec, u, table, _lib.LAYOUT_FEATURE_MAJOR, clustered=name == "psf_cloud"))
         tb = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR))
         res[name] = (tf, tb)
     tf, tb = res["uniform"]

@@ -124,6 +124,9 @@ typedef struct {
 /* layout of the encoded matrix pe / dpe */
 #define NESVOR_LAYOUT_ROW_MAJOR 0     /* (N, L*F): what tcnn returns to PyTorch */
 #define NESVOR_LAYOUT_FEATURE_MAJOR 1 /* (L*F, N): coalesced producer/consumer layout */
+#define NESVOR_LAYOUT_CLUSTERED 4     /* forward only, OR-ed into `layout`: every 256 consecutive points are spatially
+                                         clustered (the S PSF samples of a slice pixel are contiguous) - selects the
+                                         one-workgroup-per-cloud forward kernel; results do not depend on the hint */
 
 /* u (N,3) in [0,1]; table flat fp32; pe out. */
 int nesvor_hashgrid_forward(const nesvor_grid_t* grid, const float* u, const float* table, float* pe,

@@ -18,6 +18,7 @@ ABI_VERSION = 19
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
+LAYOUT_CLUSTERED = 4  # forward hint, OR-ed into the layout: 256 consecutive points are one spatial cluster
 
 
 class GridT(Structure):

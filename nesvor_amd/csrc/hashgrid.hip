@@ -215,6 +215,202 @@ __global__ __launch_bounds__(256) void hashgrid_fwd(const nesvor_grid_t g, const
   }
 }
 
+// ------------------------------------------------------- forward, all levels of a PSF cloud in one workgroup
+// One workgroup = 256 consecutive samples (for S = 256: one PSF cloud), ALL levels.  The per-(cloud, level) blocks of
+// hashgrid_fwd are bound by two serialised memory latencies each (coordinates, then the box copy); here the coordinates
+// are read once, the lattice boxes of all levels follow from one bounding box, consecutive levels whose boxes fit the
+// LDS copy together share a round (levels 0-7, 8-9, 10-11, 12, 13 for the bench's clouds), and the next round's table
+// entries are in flight while the current round interpolates (two copies, one barrier per round).  Levels whose box
+// does not fit (the finest one or two of a cloud; almost all for unclustered points) gather from global memory.
+template <int F, int LAYOUT>
+__global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g, const float* __restrict__ u,
+                                                          const float* __restrict__ table, float* __restrict__ pe, int64_t N) {
+  constexpr int kSlots = F <= 2 ? 1024 : (F == 4 ? 512 : 256);
+  constexpr int kMaxGroup = 8;
+  constexpr int NRB = kSlots / 256;
+  __shared__ __attribute__((aligned(16))) float tcache[2][kSlots * F];
+  __shared__ float ubox[4][6];
+  __shared__ uint32_t lbox[NESVOR_MAX_LEVELS + 1][8];   // as in hashgrid_bwd_aggregate
+  __shared__ uint32_t lpar[NESVOR_MAX_LEVELS + 1][4];   // res, size, offset, hashed
+  __shared__ uint32_t slot_off[NESVOR_MAX_LEVELS + 1], grp_end[NESVOR_MAX_LEVELS + 1], rnd_slots[NESVOR_MAX_LEVELS + 1];
+  __shared__ int32_t box_end_s;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  const bool valid = i < N;
+  const int64_t ii = valid ? i : N - 1;
+  const int L = g.n_levels, E = L * F;
+  const float ux = u[3 * ii], uy = u[3 * ii + 1], uz = u[3 * ii + 2];
+  {
+    float lo[3] = {ux, uy, uz}, hi[3] = {ux, uy, uz};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { lo[d] = -wave_max(-lo[d]); hi[d] = wave_max(hi[d]); }
+    if (lane == 0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { ubox[tid >> 6][d] = lo[d]; ubox[tid >> 6][3 + d] = hi[d]; }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float ulo[3], uhi[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      ulo[d] = fminf(fminf(ubox[0][d], ubox[1][d]), fminf(ubox[2][d], ubox[3][d]));
+      uhi[d] = fmaxf(fmaxf(ubox[0][3 + d], ubox[1][3 + d]), fmaxf(ubox[2][3 + d], ubox[3][3 + d]));
+    }
+    uint32_t b[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (tid < L) {
+      const LevelParams p = load_level(g, tid);
+      const CellPos blo = locate(p, ulo[0], ulo[1], ulo[2]), bhi = locate(p, uhi[0], uhi[1], uhi[2]);
+      const uint32_t ex = bhi.gx - blo.gx, ey = bhi.gy - blo.gy, ez = bhi.gz - blo.gz;
+      const bool fits = ex < (uint32_t)kSlots && ey < (uint32_t)kSlots && ez < (uint32_t)kSlots &&
+                        (uint64_t)(ex + 2u) * (ey + 2u) * (ez + 2u) <= (uint64_t)kSlots;
+      const uint32_t nx = ex + 2u, nxy = nx * (ey + 2u), vol = fits ? nxy * (ez + 2u) : 0u;
+      b[0] = blo.gx; b[1] = blo.gy; b[2] = blo.gz; b[3] = ex; b[4] = ey; b[5] = ez; b[6] = vol;
+      b[7] = fits ? vol - 2u - nx - nxy : 0u;
+      lpar[tid][0] = p.res; lpar[tid][1] = p.size; lpar[tid][2] = p.offset; lpar[tid][3] = p.hashed;
+    }
+    if (tid <= L) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) lbox[tid][q] = b[q];
+    }
+    auto vol_of = [&](int l) { return (uint32_t)__builtin_amdgcn_readlane((int)b[6], l); };
+    int e = 0;
+    while (e < L && vol_of(e) != 0u) ++e;
+    if (tid == 0) box_end_s = e;
+    int a = 0;
+    while (a < e) {
+      uint32_t slots = 0;
+      int bnd = a;
+      while (bnd < e && bnd - a < kMaxGroup && slots + vol_of(bnd) <= (uint32_t)kSlots) {
+        if (tid == 0) slot_off[bnd] = slots;
+        slots += vol_of(bnd);
+        ++bnd;
+      }
+      if (tid == 0) {
+        for (int l = a; l < bnd; ++l) grp_end[l] = (uint32_t)bnd;
+        rnd_slots[a] = slots;
+      }
+      a = bnd;
+    }
+  }
+  __syncthreads();
+  const int box_end = __builtin_amdgcn_readfirstlane(box_end_s);
+  auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+  auto store_pe = [&](int level, const float (&acc)[F]) __attribute__((always_inline)) {
+    if (!valid) return;
+    if constexpr (LAYOUT == NESVOR_LAYOUT_ROW_MAJOR) {
+      float* o = pe + (size_t)i * E + level * F;
+#pragma unroll
+      for (int f = 0; f < F; ++f) o[f] = acc[f];
+    } else {
+#pragma unroll
+      for (int f = 0; f < F; ++f) pe[(size_t)(level * F + f) * N + i] = acc[f];
+    }
+  };
+  auto blend = [&](const CellPos& c, const float (&v)[8][F], float (&acc)[F]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float w = ((k & 1) ? c.wx : 1.f - c.wx) * (((k >> 1) & 1) ? c.wy : 1.f - c.wy) * ((k >> 2) ? c.wz : 1.f - c.wz);
+#pragma unroll
+      for (int f = 0; f < F; ++f) acc[f] = fmaf(w, v[k][f], acc[f]);
+    }
+  };
+  // table entries of the slots of round [ra, rb) this thread owns (slots t, t + 256, ...)
+  auto fetch_round = [&](int ra, int rb, float (&feat)[NRB][F]) __attribute__((always_inline)) {
+    const uint32_t total = sgpr(rnd_slots[ra]);
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) {
+      const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
+#pragma unroll
+      for (int f = 0; f < F; ++f) feat[j][f] = 0.f;
+      if (slot < total) {
+        int lv = ra;
+        for (int l = ra + 1; l < rb; ++l) lv = slot >= slot_off[l] ? l : lv;
+        const uint32_t local = slot - slot_off[lv];
+        const uint32_t nx = lbox[lv][3] + 2u, nxy = nx * (lbox[lv][4] + 2u);
+        const uint32_t z = (uint32_t)(((float)local + 0.5f) * (1.f / (float)nxy));
+        const uint32_t r = local - __umul24(z, nxy);
+        const uint32_t y = (uint32_t)(((float)r + 0.5f) * (1.f / (float)nx));
+        LevelParams pl;
+        pl.scale = 0.f; pl.res = lpar[lv][0]; pl.size = lpar[lv][1]; pl.offset = lpar[lv][2]; pl.hashed = lpar[lv][3];
+        const uint32_t key = corner_index(pl, lbox[lv][0] + (r - __umul24(y, nx)), lbox[lv][1] + y, lbox[lv][2] + z);
+        load_feat<F>(table + ((size_t)pl.offset + key) * F, feat[j]);
+      }
+    }
+  };
+  auto stash_round = [&](int ra, int buf, const float (&feat)[NRB][F]) __attribute__((always_inline)) {
+    const uint32_t total = sgpr(rnd_slots[ra]);
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) {
+      const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
+      if (slot < total) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) tcache[buf][slot * F + f] = feat[j][f];
+      }
+    }
+  };
+  if (box_end > 0) {
+    int ra = 0, rb = (int)sgpr(grp_end[0]), buf = 0;
+    {
+      float feat[NRB][F];
+      fetch_round(ra, rb, feat);
+      stash_round(ra, 0, feat);
+    }
+    __syncthreads();
+    for (;;) {
+      const int na = rb, nb = na < box_end ? (int)sgpr(grp_end[na]) : na;
+      const bool more = na < box_end;
+      float nfeat[NRB][F];
+      if (more) fetch_round(na, nb, nfeat);  // in flight while this round interpolates
+#pragma unroll 1
+      for (int lv = ra; lv < rb; ++lv) {
+        const LevelParams p = load_level(g, lv);
+        const CellPos c = locate(p, ux, uy, uz);
+        const uint32_t x0 = sgpr(lbox[lv][0]), y0 = sgpr(lbox[lv][1]), z0 = sgpr(lbox[lv][2]);
+        const uint32_t ny = sgpr(lbox[lv][4]) + 2u, nx = sgpr(lbox[lv][3]) + 2u, nxy = nx * ny;
+        const uint32_t s0 = min(__umul24(__umul24(c.gz - z0, ny) + (c.gy - y0), nx) + (c.gx - x0), sgpr(lbox[lv][7])) + sgpr(slot_off[lv]);
+        float v[8][F], acc[F];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t sl = s0 + (k & 1) + ((k >> 1) & 1) * nx + (k >> 2) * nxy;
+#pragma unroll
+          for (int f = 0; f < F; ++f) v[k][f] = tcache[buf][sl * F + f];
+        }
+        blend(c, v, acc);
+        store_pe(lv, acc);
+      }
+      if (!more) break;
+      stash_round(na, buf ^ 1, nfeat);  // the other copy: last read before the previous barrier
+      __syncthreads();
+      buf ^= 1; ra = na; rb = nb;
+    }
+  }
+  // levels whose box does not fit the copy: two levels at a time, 16 independent gathers per lane in flight
+#pragma unroll 1
+  for (int lv = box_end; lv < L; lv += 2) {
+    const bool two = lv + 1 < L;
+    const LevelParams p0 = load_level(g, lv), p1 = load_level(g, two ? lv + 1 : lv);
+    const CellPos c0 = locate(p0, ux, uy, uz), c1 = locate(p1, ux, uy, uz);
+    const float* tab0 = table + (size_t)p0.offset * F;
+    const float* tab1 = table + (size_t)p1.offset * F;
+    float v0[8][F], v1[8][F], acc[F];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) load_feat<F>(tab0 + (size_t)corner_index(p0, c0.gx + (k & 1), c0.gy + ((k >> 1) & 1), c0.gz + (k >> 2)) * F, v0[k]);
+    if (two) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) load_feat<F>(tab1 + (size_t)corner_index(p1, c1.gx + (k & 1), c1.gy + ((k >> 1) & 1), c1.gz + (k >> 2)) * F, v1[k]);
+    }
+    blend(c0, v0, acc);
+    store_pe(lv, acc);
+    if (two) {
+      blend(c1, v1, acc);
+      store_pe(lv + 1, acc);
+    }
+  }
+}
+
 // ----------------------------------------------------------------- backward
 // grad_table += scatter(w * dy);  optionally grad_u[i] += d/du (per level, atomics)
 template <int F, int LAYOUT, bool INPUT_GRAD, bool MERGE>
@@ -1376,10 +1572,23 @@ owner_stage:
 }
 
 template <int F, int LAYOUT>
-int launch_fwd(const nesvor_grid_t* g, const float* u, const float* table, float* pe, int64_t N, hipStream_t st) {
+int launch_fwd(const nesvor_grid_t* g, const float* u, const float* table, float* pe, int64_t N, int clustered, hipStream_t st) {
+  // Two kernels, identical results: "cloud" (one workgroup per 256 samples, all levels: the fastest on spatially
+  // clustered batches - PSF clouds - and 1.4x slower than the other on unclustered points) is taken when the caller
+  // says its batch is clustered (NESVOR_LAYOUT_CLUSTERED); "level" (one block per 256 samples and level) otherwise.
+  // NESVOR_HASHGRID_FWD=cloud|level|gather forces one (gather = level without the LDS box copy).
+  static const int forced = []() {
+    const char* e = getenv("NESVOR_HASHGRID_FWD");
+    if (e == nullptr) return -1;
+    return e[0] == 'c' ? 0 : (e[0] == 'g' ? 2 : 1);
+  }();
+  const int mode = forced >= 0 ? forced : (clustered ? 0 : 1);
+  if (mode == 0) {
+    hipLaunchKernelGGL((hashgrid_fwd_cloud<F, LAYOUT>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, *g, u, table, pe, N);
+    return (int)hipGetLastError();
+  }
   dim3 grid((unsigned)((N + 255) / 256), g->n_levels), block(256);
-  static const int box_cache = []() { const char* e = getenv("NESVOR_HASHGRID_FWD_CACHE"); return (e == nullptr || atoi(e) != 0) ? 1 : 0; }();
-  hipLaunchKernelGGL((hashgrid_fwd<F, LAYOUT>), grid, block, 0, st, *g, u, table, pe, N, box_cache);
+  hipLaunchKernelGGL((hashgrid_fwd<F, LAYOUT>), grid, block, 0, st, *g, u, table, pe, N, mode == 1 ? 1 : 0);
   return (int)hipGetLastError();
 }
 
@@ -1420,7 +1629,9 @@ extern "C" int nesvor_hashgrid_forward(const nesvor_grid_t* grid, const float* u
                                        int64_t N, int layout, void* stream) {
   if (N <= 0) return 0;
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
-  DISPATCH_F_LAYOUT(launch_fwd, grid, u, table, pe, N, (hipStream_t)stream);
+  const int clustered = (layout & NESVOR_LAYOUT_CLUSTERED) ? 1 : 0;
+  layout &= ~NESVOR_LAYOUT_CLUSTERED;
+  DISPATCH_F_LAYOUT(launch_fwd, grid, u, table, pe, N, clustered, (hipStream_t)stream);
 }
 
 extern "C" int nesvor_hashgrid_backward_atomic(const nesvor_grid_t* grid, const float* u, const float* table,

@@ -155,7 +155,7 @@ class DirectStep:
                                            _lib.ptr(mat), _lib.ptr(acc), 13 * n, n, _lib.stream_ptr())
         _lib.check(err, "step prologue")
         x, u = sampler.forward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb)
-        pe = hashgrid_forward(enc.spec, u, enc.params, _lib.LAYOUT_FEATURE_MAJOR)  # (E, N)
+        pe = hashgrid_forward(enc.spec, u, enc.params, _lib.LAYOUT_FEATURE_MAJOR, clustered=S >= 128)  # (E, N)
         dW, dB = self.d_net.weights, self.d_net.biases
         z, saved_d = mlp_mod.forward_raw(dW, dB, None, pe, 0, pe.shape[0], S, True, self.bf16)  # (1 + n_features_z, N)
         log_var = log_bias = lb_mean = None

@@ -9,7 +9,9 @@ from . import _lib
 from .grid import HashGridSpec
 
 
-def hashgrid_forward(spec: HashGridSpec, u: torch.Tensor, table: torch.Tensor, layout=_lib.LAYOUT_ROW_MAJOR):
+def hashgrid_forward(spec: HashGridSpec, u: torch.Tensor, table: torch.Tensor, layout=_lib.LAYOUT_ROW_MAJOR, clustered=False):
+    """clustered: the caller's promise that every 256 consecutive points are spatially clustered (the PSF samples of a
+    slice pixel are contiguous): picks the one-workgroup-per-cloud kernel.  A performance hint only."""
     _lib.require_device(u, table, dtype=torch.float32, name="hashgrid input/table")
     N = u.shape[0]
     E = spec.n_output_dims
@@ -17,7 +19,8 @@ def hashgrid_forward(spec: HashGridSpec, u: torch.Tensor, table: torch.Tensor, l
     pe = torch.empty(shape, dtype=torch.float32, device=u.device)
     with torch.cuda.device(u.device), _lib.kernel_timer.span("hashgrid_fwd"):
         err = _lib.load().nesvor_hashgrid_forward(
-            ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(pe), N, layout, _lib.stream_ptr()
+            ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(pe), N,
+            layout | (_lib.LAYOUT_CLUSTERED if clustered else 0), _lib.stream_ptr()
         )
     _lib.check(err, "hashgrid forward")
     return pe

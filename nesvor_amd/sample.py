@@ -67,7 +67,7 @@ class PsfAveragedDensity:
             m = pts.shape[0]
             which = torch.zeros(m, dtype=torch.int64, device=dev)
             _, u = sampler.forward_raw(mat, which, pts, sig, self._noise(m, s), bb)
-            pe = hashgrid_forward(enc.spec, u, enc.params, _lib.LAYOUT_FEATURE_MAJOR)
+            pe = hashgrid_forward(enc.spec, u, enc.params, _lib.LAYOUT_FEATURE_MAJOR, clustered=s >= 128)
             z, _ = mlp_mod.forward_raw(self.net.weights, self.net.biases, None, pe, 0, pe.shape[0], s, False, self.operands)
             out[begin : begin + m] = F.softplus(z[0].view(m, s)).mean(-1)
         return out

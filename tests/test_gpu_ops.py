@@ -337,7 +337,10 @@ def test_hashgrid_fwd_bwd_vs_oracle(device, F, layout, method):
     dy = torch.randn(N, spec.n_output_dims)
     ref = O.encode(u, table, lv, F)
     gt_ref, gu_ref = O.encode_backward(u, table, lv, F, dy)
-    pe = hashgrid_forward(spec, u.to(device), table.to(device), layout).cpu()
+    pe_dev = hashgrid_forward(spec, u.to(device), table.to(device), layout)
+    # the one-workgroup-per-cloud kernel (taken for clustered batches) computes the same numbers
+    assert torch.equal(hashgrid_forward(spec, u.to(device), table.to(device), layout, clustered=True), pe_dev)
+    pe = pe_dev.cpu()
     pe = pe if layout == 0 else pe.t()
     # fp32, 8-term interpolation: same pos (fma) and indices; only summation order differs
     torch.testing.assert_close(pe, ref, rtol=1e-5, atol=1e-5)
@@ -368,8 +371,9 @@ def test_hashgrid_headline_config_vs_oracle(device, method, layout):
     for name, u in (("U", torch.rand(8192, 3, generator=torch.Generator().manual_seed(0))), ("P", _psf_cloud(32, 256, 0))):
         dy = torch.randn(u.shape[0], 32, generator=torch.Generator().manual_seed(1))
         ref = O.encode(u, table, lv, 2)
-        pe = hashgrid_forward(spec, u.to(device), table.to(device), layout).cpu()
-        torch.testing.assert_close(pe if layout == 0 else pe.t(), ref, rtol=1e-5, atol=1e-9, msg=name)
+        for clustered in (False, True):
+            pe = hashgrid_forward(spec, u.to(device), table.to(device), layout, clustered=clustered).cpu()
+            torch.testing.assert_close(pe if layout == 0 else pe.t(), ref, rtol=1e-5, atol=1e-9, msg=name)
         gt_ref, gu_ref = O.encode_backward(u, table, lv, 2, dy)
         dyk = (dy if layout == 0 else dy.t().contiguous()).to(device)
         gt, gu = hashgrid_backward(spec, u.to(device), table.to(device), dyk, None, True, layout, method)
@@ -388,8 +392,9 @@ def test_hashgrid_full_size_properties(device):
     N = 1 << 20
     u = _psf_cloud(4096, 256, 3).to(device)
     table = torch.full((spec.n_params,), 0.75, device=device)
-    pe = hashgrid_forward(spec, u, table, 1)
-    torch.testing.assert_close(pe, torch.full_like(pe, 0.75), rtol=1e-6, atol=1e-6)
+    for clustered in (False, True):
+        pe = hashgrid_forward(spec, u, table, 1, clustered=clustered)
+        torch.testing.assert_close(pe, torch.full_like(pe, 0.75), rtol=1e-6, atol=1e-6)
     dy = torch.ones(32, N, device=device)
     gt, gu = hashgrid_backward(spec, u, table, dy, None, True, 1)
     assert float(gu.abs().max()) < 1e-3
@@ -493,6 +498,7 @@ def test_hashgrid_points_outside_unit_cube(device):
     table = (torch.randn(spec.n_params, generator=g) * 0.1).to(device)
     dy = torch.randn(32, N, generator=g).to(device)
     pe = hashgrid_forward(spec, u, table, 1)
+    assert torch.equal(hashgrid_forward(spec, u, table, 1, clustered=True), pe)  # per-level blocks == per-cloud workgroups
     g_own, gu_own = hashgrid_backward(spec, u, table, dy, None, True, 1, "owner")
     g_atm, gu_atm = hashgrid_backward(spec, u, table, dy, None, True, 1, "atomic")
     scale = float(g_atm.abs().max())

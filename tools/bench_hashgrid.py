@@ -38,7 +38,7 @@ for name, u in (("U", uU), ("P", uP)):
     for layout in (0, 1):
         dy = torch.randn((N, 32) if layout == 0 else (32, N), device=dev)
         gt = torch.zeros_like(table)
-        tf = timeit(lambda: hashgrid_forward(spec, u, table, layout))
+        tf = timeit(lambda: hashgrid_forward(spec, u, table, layout, clustered=name == "P"))
         for method in ("owner", "atomic"):
             n = 20 if method == "owner" else 3
             tb = timeit(lambda: hashgrid_backward(spec, u, table, dy, gt, False, layout, method), n)

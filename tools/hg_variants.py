@@ -61,7 +61,7 @@ else:
         e.record(); torch.cuda.synchronize()
         return s.elapsed_time(e) / n
     t_agg = timeit(lambda: run(1)); t_agg_noin = timeit(lambda: run(1, False)); t_own = timeit(lambda: run(2))
-    t_fwd = timeit(lambda: hashgrid_forward(spec, u, table, 1))
+    t_fwd = timeit(lambda: hashgrid_forward(spec, u, table, 1, clustered=True))
     def truth64():
         """fp64 scatter of the fp32 corner weights (the kernels' own fmaf / floor / fp32 weights, products and sums in fp64)."""
         import numpy as np

@@ -31,6 +31,7 @@ for case in range(n_cases):
     E = spec.n_output_dims
     dy = torch.randn((N, E) if layout == 0 else (E, N), generator=g).to(dev)
     pe = hashgrid_forward(spec, u, table, layout)
+    assert torch.equal(hashgrid_forward(spec, u, table, layout, clustered=True), pe), "cloud forward != level forward"
     g_atm, gu_atm = hashgrid_backward(spec, u, table, dy, None, True, layout, "atomic")
     from nesvor_amd.encoding import _workspace
     if L > 1 and ri(0, 1) and _workspace(spec, N, dev) is not None:  # (tables beyond the plan's 256 chunks per level use the atomic kernel)
