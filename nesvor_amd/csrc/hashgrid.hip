@@ -512,7 +512,7 @@ constexpr int kOwnerLdsFloats = 8192;         // 32 KiB accumulator per owner wo
                                               // fewer, hotter queue counters on one side, more reservations per workgroup on the other)
 
 struct BwdPlan {
-  uint32_t chunk_shift;                        // chunk = 2^chunk_shift entries = kOwnerLdsFloats / F
+  uint32_t shift[NESVOR_MAX_LEVELS];           // per level: chunk = 2^shift entries (at most kOwnerLdsFloats / F; the finest levels take half)
   uint32_t n_buckets;
   uint32_t n_chunks[NESVOR_MAX_LEVELS];
   uint32_t bucket_base[NESVOR_MAX_LEVELS];     // first global bucket id of the level
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         nch = plan.n_chunks[tid];
         lpar[tid][0] = p.res; lpar[tid][1] = p.size; lpar[tid][2] = p.offset; lpar[tid][3] = p.hashed;
         lpar[tid][4] = plan.cap[tid]; lpar[tid][5] = plan.bucket_base[tid]; lpar[tid][6] = (uint32_t)plan.rec_off[tid];
-        lpar[tid][7] = nch;
+        lpar[tid][7] = plan.shift[tid];
       }
       if (tid <= g.n_levels) {
 #pragma unroll
@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
           if (slot < n_slots && slot_take(slot, rval[j])) {
             const uint32_t lv = lk[j] >> 27;
             rkey[j] = lk[j] & kKeyMask;
-            const uint32_t bucket = bkt_off[lv] + (rkey[j] >> plan.chunk_shift);
+            const uint32_t bucket = bkt_off[lv] + (rkey[j] >> lpar[lv][7]);
             rmeta[j] = (lv << 8) | bucket;
             rmask |= 1u << j;
             rank[j] = atomicAdd(&bcount[bucket], 1u);
@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
         if (NESVOR_ABL(8) || !(rmask & (1u << k))) continue;
-        const uint2 bb = bbase[level & 1][rkey[k] >> plan.chunk_shift];
+        const uint2 bb = bbase[level & 1][rkey[k] >> plan.shift[level]];
         const uint32_t pos = bb.x + rank[k];
         if (pos < cap) {
           uint32_t* r = reinterpret_cast<uint32_t*>(level_rec + (bb.y + pos) * (uint32_t)(4 * (1 + F)));
@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
             tkeys[slot] = kEmpty;
             rmask |= 1u << j; rkey[j] = key;
             slot_take(slot, rval[j]);
-            rank[j] = atomicAdd(&bcount[key >> plan.chunk_shift], 1u);
+            rank[j] = atomicAdd(&bcount[key >> plan.shift[level]], 1u);
             ++mine;
           }
         }
@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       // rank of every record inside its chunk's span (LDS integer atomics: ~6 cycles / wave-instruction)
       uint32_t rank[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) rank[k] = tail ? atomicAdd(&bcount[idx[k] >> plan.chunk_shift], 1u) : 0u;
+      for (int k = 0; k < 8; ++k) rank[k] = tail ? atomicAdd(&bcount[idx[k] >> plan.shift[level]], 1u) : 0u;
       finish_level(idx, rank, val, tail ? 0xFFu : 0u, std::false_type{});
       advance();
     }
@@ -1325,7 +1325,7 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
   const bool sole_writer = n <= plan.slice[level];
   for (int t = tid; t < kOwnerLdsFloats / 4; t += kOwnerThreads) reinterpret_cast<float4*>(acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
-  const uint32_t mask = (1u << plan.chunk_shift) - 1u;
+  const uint32_t mask = (1u << plan.shift[level]) - 1u;
   const uint32_t* rec = records + (plan.rec_off[level] + (uint64_t)chunk * plan.n_sub * plan.cap[level]) * (1 + F);
   auto add_record = [&](uint32_t key, const float (&v)[F]) __attribute__((always_inline)) {
     const uint32_t local = key & mask;
@@ -1424,8 +1424,8 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
   }
   }
   __syncthreads();
-  const uint32_t e0 = chunk << plan.chunk_shift;
-  const uint32_t ne = min((uint32_t)(1u << plan.chunk_shift), g.size[level] - e0);
+  const uint32_t e0 = chunk << plan.shift[level];
+  const uint32_t ne = min((uint32_t)(1u << plan.shift[level]), g.size[level] - e0);
   float* out = grad_table + ((size_t)g.offset[level] + e0) * F;
 #ifndef NESVOR_OWNER_F4
 #define NESVOR_OWNER_F4 1
@@ -1463,9 +1463,12 @@ inline uint32_t owner_grid(const nesvor_grid_t* g, const BwdPlan& plan) {
 // host: chunking / queue plan.  Returns false if the grid does not fit the plan's limits.
 inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t* n_records) {
   const int F = g->n_features;
-  uint32_t shift = 0;
-  while ((1u << (shift + 1)) * (uint32_t)F <= (uint32_t)kOwnerLdsFloats) ++shift;
-  plan->chunk_shift = shift;
+  uint32_t shift0 = 0;
+  while ((1u << (shift0 + 1)) * (uint32_t)F <= (uint32_t)kOwnerLdsFloats) ++shift0;
+  // NESVOR_HASHGRID_FINE_LEVELS (tuning hook, default 0): that many of the finest levels take half-size chunks (twice the
+  // owner workgroups, half as long queues).  Measured on PSF clouds at N = 2^20: owner pass 0.050-0.054 ms for 0..4,
+  // aggregation pass +1-3 % - the longest queues are not what sets the owner pass's duration.
+  static const int fine_levels = []() { const char* e = getenv("NESVOR_HASHGRID_FINE_LEVELS"); return e ? atoi(e) : 0; }();
   // XCCs of the current device (partition): 32 CUs each on gfx950
   static const uint32_t n_xcc = []() {
     int dev = 0, cus = 0;
@@ -1483,6 +1486,9 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
   uint32_t nb = 0;
   uint64_t off = 0;
   for (int l = 0; l < g->n_levels; ++l) {
+    uint32_t shift = shift0;
+    if (l >= g->n_levels - fine_levels && shift > 8 && ((g->size[l] + (1u << (shift - 1)) - 1) >> (shift - 1)) <= (uint32_t)kMaxChunks) --shift;
+    plan->shift[l] = shift;
     const uint32_t nc = (g->size[l] + (1u << shift) - 1) >> shift;
     if (nc > (uint32_t)kMaxChunks) return false;
     plan->n_chunks[l] = nc;
@@ -1508,6 +1514,7 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
     off += cap * n_sub * nc;
   }
   for (int l = g->n_levels; l < NESVOR_MAX_LEVELS; ++l) {
+    plan->shift[l] = shift0;
     plan->n_chunks[l] = 0; plan->bucket_base[l] = nb; plan->cap[l] = 0; plan->slice[l] = kOwnerSlice; plan->rec_off[l] = off;
   }
   plan->n_buckets = nb;
