@@ -128,11 +128,26 @@ def test_direct_step_equals_autograd_step(device, golden, over):
 
 
 @pytest.mark.parametrize("over", [{}, {"depth": 2}, {"n_levels_bias": 2, "n_features_z": 7}])
-def test_direct_step_half_precision_model_structure(device, golden, over):
+def test_direct_step_half_precision_model_structure(device, golden, over, monkeypatch):
     """args.dtype == float16 (the reference's default: bias-free tinycudann networks with one flat parameter vector,
     models.py:28-41) on the autograd-free step: bf16 matrix operands, fp32 accumulation.  Checked against autograd over
-    the module path of the same model (fp16 encoding output, fp32 rocBLAS GEMMs on the same flat parameters):
+    the op-by-op path of the same model with the networks evaluated in plain fp32 torch (``h @ W.T`` on the same flat
+    parameters - a test-local stand-in for ``Network.forward``, whose product implementation runs the bf16 kernels too):
     tolerance = the bf16 operand rounding (2^-9 per operand through <= 3 layers): losses 2%, gradients 5% in norm (pose: 15%)."""
+    import torch.nn.functional as F_
+
+    import nesvor_amd.tinycudann as tcnn
+
+    def fp32_reference_forward(self, x):
+        off, h = 0, x.to(self.params.dtype)
+        for li, (o, i) in enumerate(self.shapes):
+            h = h @ self.params[off : off + o * i].view(o, i).t()
+            off += o * i
+            if li < len(self.shapes) - 1:
+                h = F_.relu(h)
+        return h[..., : self.n_output_dims]
+
+    monkeypatch.setattr(tcnn.Network, "forward", fp32_reference_forward)
     from nesvor_amd import direct
     from nesvor_amd.fused import FusedTrainer
     from nesvor_amd.models import NeSVoR
