@@ -125,7 +125,8 @@ def measure_extras(model, args, device, opt):
     res = {}
     for name, u in (("uniform", u_uniform), ("psf_cloud", u_cloud)):
         tf = _events_ms(lambda: hashgrid_forward(spec, u, table, _lib.LAYOUT_FEATURE_MAJOR, clustered=name == "psf_cloud"))
-        tb = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR))
+        # (warm-up long enough for the queue sizer to have grown the levels this distribution fills)
+        tb = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR), warm=10)
         res[name] = (tf, tb)
     tf, tb = res["uniform"]
     out["roofline_uniform"] = {

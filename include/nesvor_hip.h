@@ -135,18 +135,25 @@ int nesvor_hashgrid_forward(const nesvor_grid_t* grid, const float* u, const flo
  * grad_u (N,3) is OVERWRITTEN, or NULL to skip the input gradient.
  * Owner-computes scatter (LDS aggregation per 256 samples -> per-chunk queues ->
  * one owner workgroup per table chunk); `workspace` is scratch device memory of
- * nesvor_hashgrid_backward_workspace_bytes(grid, N) bytes (-1: grid outside the
+ * nesvor_hashgrid_backward_workspace_bytes(grid, N, queue_scale) bytes (-1: grid outside the
  * plan's limits, use the _atomic variant).  `stages`: 3 = whole backward;
  * 1 = aggregation launch only, 2 = owner launch only (so a caller can bracket
- * each launch with its own events; 1 then 2 on one stream == 3). */
-int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t* grid, int64_t N);
+ * each launch with its own events; 1 then 2 on one stream == 3).
+ * `queue_scale`: HOST array of one float per level in (0, 1], or NULL (= 1 everywhere): the fraction of the worst-case
+ * queue capacity (8 records per point and level) to provide for each level.  A record that finds its queue full is added
+ * with a global atomic instead - the result is exact for any scale - and counted: 32 uint32 counters (one per level) of
+ * the latest backward sit at byte nesvor_hashgrid_backward_overflow_offset(workspace) of the workspace, so that a caller
+ * can start small (a PSF-cloud batch fills a few percent of the worst case at most levels) and grow the levels that
+ * overflow.  The same `queue_scale` must be passed to the size query and to every launch on that workspace. */
+int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t* grid, int64_t N, const float* queue_scale);
 /* The first nesvor_hashgrid_backward_workspace_zero_bytes() bytes of a workspace (its two queue-tail regions) must be
  * zero-filled ONCE after the workspace is allocated; the backward keeps them consistent afterwards (every aggregation
  * pass zero-fills the region the next backward will use, so no memset launch is needed per call). */
 int64_t nesvor_hashgrid_backward_workspace_zero_bytes(void);
+int64_t nesvor_hashgrid_backward_overflow_offset(void* workspace);
 int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* u, const float* table, const float* dpe,
                              float* grad_table, float* grad_u, int64_t N, int layout, void* workspace, int stages,
-                             void* stream);
+                             const float* queue_scale, void* stream);
 
 /* The same backward restricted to levels [level_begin, level_end): a data-parallel step runs the fine levels first,
  * starts their all-reduce and overlaps it with the remaining levels.  Extra `stages` bits: 4 = do not reset the
@@ -154,7 +161,7 @@ int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* u, const fl
  * instead of overwriting it.  The launches of one backward share `workspace`. */
 int nesvor_hashgrid_backward_levels(const nesvor_grid_t* grid, const float* u, const float* table, const float* dpe,
                                     float* grad_table, float* grad_u, int64_t N, int layout, void* workspace, int stages,
-                                    int level_begin, int level_end, void* stream);
+                                    int level_begin, int level_end, const float* queue_scale, void* stream);
 /* Same contract, tcnn-style per-corner global atomics (slow on MI355X: memory-side atomics). */
 int nesvor_hashgrid_backward_atomic(const nesvor_grid_t* grid, const float* u, const float* table, const float* dpe,
                                     float* grad_table, float* grad_u, int64_t N, int layout, void* stream);

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NESVOR_HIP_LIB: load another build of the same ABI (tools/ablate_hashgrid.py times variants of one kernel this way)
 LIB_PATH = os.environ.get("NESVOR_HIP_LIB") or os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -77,10 +77,11 @@ _SIGNATURES = {
     "nesvor_slice_acq_backward": ([_P] * 9 + [c_int] * 9 + [c_float, _P], c_int),
     "nesvor_slice_acq_adjoint_backward": ([_P] * 10 + [c_int] * 9 + [c_float, c_int, _P], c_int),
     "nesvor_hashgrid_forward": ([POINTER(GridT), _P, _P, _P, c_int64, c_int, _P], c_int),
-    "nesvor_hashgrid_backward_workspace_bytes": ([POINTER(GridT), c_int64], c_int64),
+    "nesvor_hashgrid_backward_workspace_bytes": ([POINTER(GridT), c_int64, _P], c_int64),
     "nesvor_hashgrid_backward_workspace_zero_bytes": ([], c_int64),
-    "nesvor_hashgrid_backward": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P], c_int),
-    "nesvor_hashgrid_backward_levels": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, c_int, c_int, _P], c_int),
+    "nesvor_hashgrid_backward_overflow_offset": ([_P], c_int64),
+    "nesvor_hashgrid_backward": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P, _P], c_int),
+    "nesvor_hashgrid_backward_levels": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, c_int, c_int, _P, _P], c_int),
     "nesvor_hashgrid_backward_atomic": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
     "nesvor_psf_transform_forward": ([_P] * 8 + [c_int, c_int, _P], c_int),
     "nesvor_psf_transform_backward": ([_P] * 9 + [c_int, c_int, _P], c_int),

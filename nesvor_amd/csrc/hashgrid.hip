@@ -508,6 +508,7 @@ __global__ __launch_bounds__(256) void hashgrid_bwd(const nesvor_grid_t g, const
 constexpr int kMaxChunks = 256;               // table chunks (queues) per level
 constexpr int kSubQueues = 8;                 // every queue is split by the XCC the producing workgroup runs on (see below); plan.n_sub <= 8 are used
 constexpr uint32_t kTailStride = 4096;        // counters per sub-queue set (>= kMaxChunks * NESVOR_MAX_LEVELS)
+constexpr uint32_t kOverflowBase = kTailStride - NESVOR_MAX_LEVELS;  // last words of counter set 0: records per level that found their queue full
 constexpr int kOwnerLdsFloats = 8192;         // 32 KiB accumulator per owner workgroup: 4096-entry chunks (measured: 16 / 64 / 128 KiB are slower -
                                               // fewer, hotter queue counters on one side, more reservations per workgroup on the other)
 
@@ -1029,7 +1030,8 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
               r[0] = rkey[j];
 #pragma unroll
               for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(rval[j][f]);
-            } else {  // queue full: exact fallback
+            } else {  // queue full: exact fallback (counted: the host grows the level's queues when it sees it)
+              atomicAdd(&tails[kOverflowBase + (rmeta[j] >> 8)], 1u);
 #pragma unroll
               for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)lpar[rmeta[j] >> 8][2] + rkey[j]) * F + f, rval[j][f]);
             }
@@ -1103,6 +1105,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
 #pragma unroll
             for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(rval[j][f]);
           } else {
+            atomicAdd(&tails[kOverflowBase + (rmeta[j] >> 8)], 1u);
 #pragma unroll
             for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)lpar[rmeta[j] >> 8][2] + rkey[j]) * F + f, rval[j][f]);
           }
@@ -1174,6 +1177,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
 #pragma unroll
           for (int f = 0; f < F; ++f) r[1 + f] = __float_as_uint(rval[k][f]);
         } else {  // queue full: exact fallback
+          atomicAdd(&tails[kOverflowBase + level], 1u);
 #pragma unroll
           for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + rkey[k]) * F + f, rval[k][f]);
         }
@@ -1461,7 +1465,7 @@ inline uint32_t owner_grid(const nesvor_grid_t* g, const BwdPlan& plan) {
 }
 
 // host: chunking / queue plan.  Returns false if the grid does not fit the plan's limits.
-inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t* n_records) {
+inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t* n_records, const float* queue_scale = nullptr) {
   const int F = g->n_features;
   uint32_t shift0 = 0;
   while ((1u << (shift0 + 1)) * (uint32_t)F <= (uint32_t)kOwnerLdsFloats) ++shift0;
@@ -1497,8 +1501,13 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
     // worst case 8N records per level; a chunk's share is split over kSubQueues producer groups (the XCCs, which
     // the dispatcher feeds round-robin): 1/n_sub each plus slack for the imbalance.  Overflow is handled exactly
     // (atomic fallback in the aggregation pass), so the capacity only has to make it rare.
+    // queue_scale[l] in (0, 1] (host array, optional): the fraction of that worst case to provide for level l - a
+    // PSF-cloud batch fills well under a tenth of it at most levels; the caller grows a level when its overflow counter
+    // (nesvor_hashgrid_backward_overflow_offset) turns non-zero
     const uint64_t per = (uint64_t)(8 * N) / nc / n_sub;
-    uint64_t cap = per + per / 8 + 1024;
+    double qs = queue_scale ? (double)queue_scale[l] : 1.0;
+    if (!(qs > 0.0) || qs > 1.0) qs = 1.0;
+    uint64_t cap = (uint64_t)((double)(per + per / 8) * qs) + 1024;
     if (cap_scale > 0.0) cap = (uint64_t)((double)cap * cap_scale) + 1;  // test knob: force the overflow path
     if (cap * n_sub > 0x7FFFFFFFull) return false;
     if (cap * n_sub * nc * (uint64_t)(4 * (1 + F)) > 0xFFFFFFFFull) return false;  // a level's queues are addressed by 32-bit byte offsets
@@ -1542,10 +1551,11 @@ inline int tails_parity(void* workspace, bool advance) {
 
 template <int F, int LAYOUT>
 int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table, const float* dpe, float* gt,
-                     float* gu, int64_t N, void* workspace, int stages, int level_begin, int level_end, hipStream_t st) {
+                     float* gu, int64_t N, void* workspace, int stages, int level_begin, int level_end, const float* queue_scale,
+                     hipStream_t st) {
   BwdPlan plan;
   uint64_t n_rec;
-  if (!make_plan(g, N, &plan, &n_rec)) return (int)hipErrorInvalidValue;
+  if (!make_plan(g, N, &plan, &n_rec, queue_scale)) return (int)hipErrorInvalidValue;
   plan.level_begin = level_begin; plan.level_end = level_end;
   plan.accumulate_u = (stages & 8) ? 1 : 0;
   // bit 4: a later launch of a split backward - same region, the queue tails of its levels are still zero
@@ -1649,35 +1659,40 @@ extern "C" int nesvor_hashgrid_backward_atomic(const nesvor_grid_t* grid, const 
   DISPATCH_F_LAYOUT(launch_bwd, grid, u, table, dpe, grad_table, grad_u, N, (hipStream_t)stream);
 }
 
-extern "C" int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t* grid, int64_t N) {
+extern "C" int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t* grid, int64_t N, const float* queue_scale) {
   if (N <= 0) return 0;
   BwdPlan plan;
   uint64_t n_rec;
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return -1;
-  if (!make_plan(grid, N, &plan, &n_rec)) return -1;
-  if (plan.n_buckets > kTailStride) return -1;
+  if (!make_plan(grid, N, &plan, &n_rec, queue_scale)) return -1;
+  if (plan.n_buckets > kOverflowBase) return -1;
   return (int64_t)(2 * kTailBytes + n_rec * (1 + grid->n_features) * sizeof(uint32_t));
 }
 
 extern "C" int64_t nesvor_hashgrid_backward_workspace_zero_bytes(void) { return (int64_t)(2 * kTailBytes); }
 
+extern "C" int64_t nesvor_hashgrid_backward_overflow_offset(void* workspace) {
+  return (int64_t)(tails_parity(workspace, false) ? kTailBytes : 0) + (int64_t)kOverflowBase * (int64_t)sizeof(uint32_t);
+}
+
 extern "C" int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* u, const float* table,
                                         const float* dpe, float* grad_table, float* grad_u, int64_t N, int layout,
-                                        void* workspace, int stages, void* stream) {
+                                        void* workspace, int stages, const float* queue_scale, void* stream) {
   if (N <= 0) return 0;
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
   if (workspace == nullptr || (stages & 3) == 0) return (int)hipErrorInvalidValue;
   DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages & 3, 0, grid->n_levels,
-                    (hipStream_t)stream);
+                    queue_scale, (hipStream_t)stream);
 }
 
 extern "C" int nesvor_hashgrid_backward_levels(const nesvor_grid_t* grid, const float* u, const float* table,
                                                const float* dpe, float* grad_table, float* grad_u, int64_t N, int layout,
-                                               void* workspace, int stages, int level_begin, int level_end, void* stream) {
+                                               void* workspace, int stages, int level_begin, int level_end,
+                                               const float* queue_scale, void* stream) {
   if (N <= 0) return 0;
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
   if (workspace == nullptr || (stages & 3) == 0) return (int)hipErrorInvalidValue;
   if (level_begin < 0 || level_end > grid->n_levels || level_begin >= level_end) return (int)hipErrorInvalidValue;
   DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages, level_begin, level_end,
-                    (hipStream_t)stream);
+                    queue_scale, (hipStream_t)stream);
 }

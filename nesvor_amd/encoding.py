@@ -29,9 +29,70 @@ def hashgrid_forward(spec: HashGridSpec, u: torch.Tensor, table: torch.Tensor, l
 _WORKSPACES = {}
 
 
-def _workspace(spec, N, device):
+class QueueSizer:
+    """Capacity of the backward's record queues, per level, as a fraction of the worst case (8 records per point and
+    level = 1.8 GB at N = 2^20, L = 16).  A PSF-cloud batch fills a few percent of that at most levels, uniform points
+    fill the fine levels completely: the sizer starts every level at ``START`` of the worst case and grows (x4, up to 1)
+    the levels whose overflow counter the kernels raised.  An overflowing record is added with a global atomic, so the
+    result is exact at any capacity; only the first iterations of a run - until the capacities have settled, two growth
+    steps at most - pay for the atomics.  The counters are read without synchronising: an asynchronous copy into pinned
+    memory after a backward, looked at before a later one (every call for the first 32 calls, every 32nd afterwards).
+
+    ``NESVOR_HASHGRID_QUEUE=worst`` (or ``QueueSizer.policy = "worst"``) allocates the worst case once and never looks."""
+
+    START = 1.0 / 16
+    policy = __import__("os").environ.get("NESVOR_HASHGRID_QUEUE", "adaptive")
+
+    def __init__(self, n_levels: int) -> None:
+        start = 1.0 if QueueSizer.policy == "worst" else QueueSizer.START
+        self.scale = (ctypes.c_float * _lib.MAX_LEVELS)(*([start] * _lib.MAX_LEVELS))
+        self.n_levels = n_levels
+        self.calls = 0
+        self.pending = None  # (event, pinned int32[32])
+
+    def poll(self) -> bool:
+        """Look at a finished counter copy; True if a level was grown (the workspace must then be re-made)."""
+        if self.pending is None or not self.pending[0].query():
+            return False
+        counts = self.pending[1].tolist()
+        self.pending = None
+        grown = False
+        for l in range(self.n_levels):
+            if counts[l] > 0 and self.scale[l] < 1.0:
+                self.scale[l] = min(1.0, self.scale[l] * 4)
+                grown = True
+        return grown
+
+    def snapshot(self, ws: torch.Tensor) -> None:
+        """Queue an asynchronous copy of the latest backward's overflow counters (current stream)."""
+        self.calls += 1
+        if QueueSizer.policy == "worst" or self.pending is not None or not (self.calls <= 32 or self.calls % 32 == 0):
+            return
+        if all(self.scale[l] >= 1.0 for l in range(self.n_levels)):
+            return
+        off = _lib.load().nesvor_hashgrid_backward_overflow_offset(_lib.ptr(ws))
+        host = torch.empty(_lib.MAX_LEVELS, dtype=torch.int32, pin_memory=True)
+        host.copy_(ws[off : off + 4 * _lib.MAX_LEVELS].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending = (ev, host)
+
+
+_SIZERS = {}
+
+
+def queue_sizer(spec, N, device) -> QueueSizer:
+    key = (device, N, spec.n_levels, spec.n_features, spec.log2_hashmap_size, spec.base_resolution, spec.per_level_scale)
+    sz = _SIZERS.get(key)
+    if sz is None:
+        sz = _SIZERS[key] = QueueSizer(spec.n_levels)
+    return sz
+
+
+def _workspace(spec, N, device, sizer=None):
     """Scratch for the owner-computes backward (queues of (entry, grad) records), cached per (device, size)."""
-    nbytes = _lib.load().nesvor_hashgrid_backward_workspace_bytes(ctypes.byref(spec.c_struct), N)
+    sizer = sizer or queue_sizer(spec, N, device)
+    nbytes = _lib.load().nesvor_hashgrid_backward_workspace_bytes(ctypes.byref(spec.c_struct), N, sizer.scale)
     if nbytes < 0:
         return None
     key = (device, nbytes)
@@ -63,7 +124,10 @@ def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True
             raise RuntimeError("a later part of a split backward needs the first part's grad_u")
         grad_u = torch.empty_like(u) if need_input_grad else None
     lib = _lib.load()
-    ws = _workspace(spec, N, u.device) if method == "owner" else None
+    sizer = queue_sizer(spec, N, u.device) if method == "owner" else None
+    if sizer is not None and first:
+        sizer.poll()  # grows the queues of levels that overflowed in an earlier backward (the workspace is then re-made)
+    ws = _workspace(spec, N, u.device, sizer) if method == "owner" else None
     if levels is not None and ws is None:
         raise RuntimeError("level ranges exist for the owner method only")
     with torch.cuda.device(u.device):
@@ -72,7 +136,7 @@ def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True
                     _lib.ptr(grad_u), N, layout, _lib.ptr(ws))
             l0, l1 = (0, spec.n_levels) if levels is None else levels
             extra = 0 if first else (4 | 8)  # keep the queue tails, add to grad_u
-            call = lambda stage: lib.nesvor_hashgrid_backward_levels(*args, stage | extra, l0, l1, _lib.stream_ptr())
+            call = lambda stage: lib.nesvor_hashgrid_backward_levels(*args, stage | extra, l0, l1, sizer.scale, _lib.stream_ptr())
             if _lib.kernel_timer.enabled:  # bracket each of the two launches with its own events
                 with _lib.kernel_timer.span("hashgrid_bwd_aggregate"):
                     err = call(1)
@@ -83,7 +147,7 @@ def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True
                 err = call(1)
                 if err == 0:
                     owner_stream.wait_stream(torch.cuda.current_stream(u.device))
-                    err = lib.nesvor_hashgrid_backward_levels(*args, 2 | extra, l0, l1, ctypes.c_void_p(owner_stream.cuda_stream))
+                    err = lib.nesvor_hashgrid_backward_levels(*args, 2 | extra, l0, l1, sizer.scale, ctypes.c_void_p(owner_stream.cuda_stream))
             else:
                 err = call(3)
         else:
@@ -92,6 +156,8 @@ def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True
                 _lib.ptr(grad_u), N, layout, _lib.stream_ptr(),
             )
     _lib.check(err, "hashgrid backward")
+    if sizer is not None and ws is not None:
+        sizer.snapshot(ws)
     return grad_table, grad_u
 
 

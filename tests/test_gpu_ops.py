@@ -434,6 +434,46 @@ def test_hashgrid_owner_equals_atomic_full_size_uniform(device):
     torch.testing.assert_close(gu_own, gu_atm, rtol=1e-3, atol=1e-3)
 
 
+def test_hashgrid_queue_sizer_grows_only_what_overflows(device, monkeypatch):
+    """The record queues start at 1/16 of the worst case per level (encoding.QueueSizer); a level whose overflow counter
+    the kernels raise is grown x4 before a later backward.  Every backward on the way is exact (overflowing records take
+    the atomic path).  PSF clouds: the coarse levels never grow and the workspace settles far below the worst case;
+    uniform points: the fine levels reach the worst case."""
+    from nesvor_amd import encoding
+    from nesvor_amd.encoding import QueueSizer, hashgrid_backward
+    from nesvor_amd.grid import HashGridSpec
+
+    monkeypatch.setattr(QueueSizer, "policy", "adaptive")
+    spec = HashGridSpec(16, 2, 19, 9, 1.26)
+    N = 1 << 18
+    g = torch.Generator().manual_seed(0)
+    table = (torch.randn(spec.n_params, generator=g) * 0.1).to(device)
+    dy = torch.randn(32, N, generator=g).to(device)
+    lib = encoding._lib.load()
+    worst = lib.nesvor_hashgrid_backward_workspace_bytes(__import__("ctypes").byref(spec.c_struct), N, None)
+    for dist in ("P", "U"):
+        encoding._SIZERS.clear()
+        encoding._WORKSPACES.clear()
+        u = (_psf_cloud(N // 256, 256, 3) if dist == "P" else torch.rand(N, 3, generator=g)).to(device)
+        ref, _ = hashgrid_backward(spec, u, table, dy, None, False, 1, "atomic")
+        scale = float(ref.abs().max())
+        sizer = encoding.queue_sizer(spec, N, device)
+        assert all(abs(sizer.scale[l] - QueueSizer.START) < 1e-9 for l in range(16))
+        for it in range(12):
+            got, _ = hashgrid_backward(spec, u, table, dy, None, False, 1, "owner")
+            torch.cuda.synchronize()  # (lets every queued counter copy finish, so that each call can act on the previous one)
+            assert float((got - ref).abs().max()) < 2e-4 * scale, (dist, it)
+        scales = [round(sizer.scale[l], 4) for l in range(16)]
+        nbytes = next(k[1] for k in encoding._WORKSPACES)
+        print(dist, scales, f"{nbytes / worst:.3f} of the worst-case workspace")
+        if dist == "P":
+            assert all(s == round(QueueSizer.START, 4) for s in scales[:8]) and nbytes < 0.4 * worst
+        else:
+            assert all(s == 1.0 for s in scales[8:]) and nbytes > 0.5 * worst
+    encoding._SIZERS.clear()
+    encoding._WORKSPACES.clear()
+
+
 @pytest.mark.parametrize("dist", ["P", "U"])
 def test_hashgrid_queue_overflow_fallback_is_exact(device, dist, monkeypatch):
     """Queue capacities shrunk to 2 % (test knob NESVOR_HASHGRID_CAP_SCALE): most records of the fine levels no longer

@@ -5,6 +5,7 @@ Results of the ablated variants are wrong by construction; this is a timing tool
     python tools/ablate_hashgrid.py            # on a gfx950 box
 """
 import os, subprocess, sys
+os.environ.setdefault("NESVOR_HASHGRID_QUEUE", "worst")  # timing tool: worst-case queues from the first call
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = [(0, "full kernel"), (1, "Morton sort done twice (=> cost of one sort)"), (2, "without the DPP run scan"),
             (4, "without table insertion (=> empty drain, no records)"), (8, "without record writes"),
@@ -42,8 +43,9 @@ else:
     table = ((torch.rand(spec.n_params, generator=torch.Generator().manual_seed(1337)) * 2 - 1) * 1e-4).to(dev)
     dy = torch.randn(32, N, device=dev); gt = torch.zeros_like(table); gu = torch.empty(N, 3, device=dev)
     ws = _workspace(spec, N, dev)
+    _SCALE = __import__('nesvor_amd.encoding', fromlist=['queue_sizer']).queue_sizer(spec, N, dev).scale
     lib = _lib.load()
-    run = lambda: lib.nesvor_hashgrid_backward(ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(dy), _lib.ptr(gt), _lib.ptr(gu), N, 1, _lib.ptr(ws), 1, _lib.stream_ptr())
+    run = lambda: lib.nesvor_hashgrid_backward(ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(dy), _lib.ptr(gt), _lib.ptr(gu), N, 1, _lib.ptr(ws), 1, _SCALE, _lib.stream_ptr())
     for _ in range(3): run()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(True), torch.cuda.Event(True)

@@ -2,6 +2,8 @@
 on the two mandated point distributions: U = uniform, P = PSF clouds."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+_os.environ.setdefault("NESVOR_HASHGRID_QUEUE", "worst")  # timing tool: worst-case queues from the first call
 import torch
 from nesvor_amd.encoding import hashgrid_backward, hashgrid_forward
 from nesvor_amd.grid import HashGridSpec

@@ -2,6 +2,8 @@
 nesvor_hashgrid_backward_levels, differences of consecutive prefixes."""
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+_os.environ.setdefault("NESVOR_HASHGRID_QUEUE", "worst")  # timing tool: worst-case queues from the first call
 import torch
 from nesvor_amd import _lib
 from nesvor_amd.encoding import _workspace
@@ -15,9 +17,10 @@ u = ((c + torch.randn(4096, 256, 3, generator=g) * torch.tensor([0.77, 0.77, 1.2
 table = ((torch.rand(spec.n_params, generator=torch.Generator().manual_seed(1337)) * 2 - 1) * 1e-4).to(dev)
 dy = torch.randn(32, N, device=dev); gt = torch.zeros_like(table); gu = torch.empty(N, 3, device=dev)
 ws = _workspace(spec, N, dev)
+_SCALE = __import__('nesvor_amd.encoding', fromlist=['queue_sizer']).queue_sizer(spec, N, dev).scale
 lib = _lib.load()
 def run(l0, l1, stage=1):
-    return lib.nesvor_hashgrid_backward_levels(ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(dy), _lib.ptr(gt), _lib.ptr(gu), N, 1, _lib.ptr(ws), stage, l0, l1, _lib.stream_ptr())
+    return lib.nesvor_hashgrid_backward_levels(ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(dy), _lib.ptr(gt), _lib.ptr(gu), N, 1, _lib.ptr(ws), stage, l0, l1, _SCALE, _lib.stream_ptr())
 def timeit(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()

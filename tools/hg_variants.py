@@ -5,6 +5,7 @@ is checked against the atomic kernel of the same build.
     python tools/hg_variants.py base: fixed32:-DNESVOR_FIXED32=1
 """
 import os, subprocess, sys
+os.environ.setdefault("NESVOR_HASHGRID_QUEUE", "worst")  # timing tool: worst-case queues from the first call
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] != "run":
     variants = [a.split(":", 1) for a in sys.argv[1:]]
@@ -49,9 +50,10 @@ else:
     table = ((torch.rand(spec.n_params, generator=torch.Generator().manual_seed(1337)) * 2 - 1) * 1e-4).to(dev)
     dy = torch.randn(32, N, device=dev); gt = torch.zeros_like(table); gu = torch.empty(N, 3, device=dev)
     ws = _workspace(spec, N, dev)
+    _SCALE = __import__('nesvor_amd.encoding', fromlist=['queue_sizer']).queue_sizer(spec, N, dev).scale
     lib = _lib.load()
     def run(stage, gin=True):
-        return lib.nesvor_hashgrid_backward(ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(dy), _lib.ptr(gt), _lib.ptr(gu if gin else None), N, 1, _lib.ptr(ws), stage, _lib.stream_ptr())
+        return lib.nesvor_hashgrid_backward(ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(dy), _lib.ptr(gt), _lib.ptr(gu if gin else None), N, 1, _lib.ptr(ws), stage, _SCALE, _lib.stream_ptr())
     def timeit(fn, n=20):
         for _ in range(3): fn()
         torch.cuda.synchronize()

@@ -1,6 +1,8 @@
 """A few passes of the hash-grid owner-backward at N=2^20 (for rocprofv3 --pmc / --kernel-trace)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+_os.environ.setdefault("NESVOR_HASHGRID_QUEUE", "worst")  # timing tool: worst-case queues from the first call
 import torch
 from nesvor_amd.encoding import hashgrid_backward, hashgrid_forward
 from nesvor_amd.grid import HashGridSpec
