@@ -125,8 +125,10 @@ def measure_extras(model, args, device, opt):
     res = {}
     for name, u in (("uniform", u_uniform), ("psf_cloud", u_cloud)):
         tf = _events_ms(lambda: hashgrid_forward(spec, u, table, _lib.LAYOUT_FEATURE_MAJOR, clustered=name == "psf_cloud"))
-        # (warm-up long enough for the queue sizer to have grown the levels this distribution fills)
-        tb = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR), warm=10)
+        for _ in range(6):  # synchronised warm-up: lets the queue sizer grow the levels this distribution fills
+            hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR)
+            torch.cuda.synchronize()
+        tb = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR))
         res[name] = (tf, tb)
     tf, tb = res["uniform"]
     out["roofline_uniform"] = {
@@ -254,6 +256,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
+    # settle: the record queues of the hash-grid backward start small and grow where the kernels count overflows
+    # (encoding.QueueSizer); the counters are read asynchronously, so a few synchronised iterations let the capacities
+    # reach their final values before anything is timed
+    for _ in range(8):
+        step()
+        torch.cuda.synchronize(device)
     # per-kernel HIP-event timing runs over its own K steps before the timed region (same process, data, kernels)
     ktimes = {}
     if not opt.no_kernel_timing:
