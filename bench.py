@@ -125,7 +125,7 @@ def measure_extras(model, args, device, opt):
     res = {}
     for name, u in (("uniform", u_uniform), ("psf_cloud", u_cloud)):
         tf = _events_ms(lambda: hashgrid_forward(spec, u, table, _lib.LAYOUT_FEATURE_MAJOR, clustered=name == "psf_cloud"))
-        for _ in range(6):  # synchronised warm-up: lets the queue sizer grow the levels this distribution fills
+        for _ in range(12):  # synchronised warm-up: lets the queue sizer grow the levels this distribution fills
             hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR)
             torch.cuda.synchronize()
         tb = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR))

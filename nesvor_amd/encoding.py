@@ -36,7 +36,8 @@ class QueueSizer:
     the levels whose overflow counter the kernels raised.  An overflowing record is added with a global atomic, so the
     result is exact at any capacity; only the first iterations of a run - until the capacities have settled, two growth
     steps at most - pay for the atomics.  The counters are read without synchronising: an asynchronous copy into pinned
-    memory after a backward, looked at before a later one (every call for the first 32 calls, every 32nd afterwards).
+    memory after a backward, looked at before a later one (every call for the first 64 calls, every 4th afterwards, so
+    that a change of the point distribution is noticed within a few calls).
 
     ``NESVOR_HASHGRID_QUEUE=worst`` (or ``QueueSizer.policy = "worst"``) allocates the worst case once and never looks."""
 
@@ -48,13 +49,14 @@ class QueueSizer:
         self.scale = (ctypes.c_float * _lib.MAX_LEVELS)(*([start] * _lib.MAX_LEVELS))
         self.n_levels = n_levels
         self.calls = 0
-        self.pending = None  # (event, pinned int32[32])
+        self.pending = None  # event of the counter copy in flight
+        self.host = None  # pinned int32[32] the counters are copied into
 
     def poll(self) -> bool:
         """Look at a finished counter copy; True if a level was grown (the workspace must then be re-made)."""
-        if self.pending is None or not self.pending[0].query():
+        if self.pending is None or not self.pending.query():
             return False
-        counts = self.pending[1].tolist()
+        counts = self.host.tolist()
         self.pending = None
         grown = False
         for l in range(self.n_levels):
@@ -66,16 +68,16 @@ class QueueSizer:
     def snapshot(self, ws: torch.Tensor) -> None:
         """Queue an asynchronous copy of the latest backward's overflow counters (current stream)."""
         self.calls += 1
-        if QueueSizer.policy == "worst" or self.pending is not None or not (self.calls <= 32 or self.calls % 32 == 0):
+        if QueueSizer.policy == "worst" or self.pending is not None or not (self.calls <= 64 or self.calls % 4 == 0):
             return
         if all(self.scale[l] >= 1.0 for l in range(self.n_levels)):
             return
         off = _lib.load().nesvor_hashgrid_backward_overflow_offset(_lib.ptr(ws))
-        host = torch.empty(_lib.MAX_LEVELS, dtype=torch.int32, pin_memory=True)
-        host.copy_(ws[off : off + 4 * _lib.MAX_LEVELS].view(torch.int32), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.pending = (ev, host)
+        if self.host is None:
+            self.host = torch.empty(_lib.MAX_LEVELS, dtype=torch.int32, pin_memory=True)
+        self.host.copy_(ws[off : off + 4 * _lib.MAX_LEVELS].view(torch.int32), non_blocking=True)
+        self.pending = torch.cuda.Event()
+        self.pending.record()
 
 
 _SIZERS = {}
