@@ -72,9 +72,7 @@ int nesvor_slice_acq_forward(const float* transforms, const float* vol, const ui
  *     backward).  Built here: forward only.  No caller in the reference tree ever passes interp_psf=True to the other
  *     three (slice_acq.py:40-160, svort/srr.py:37-128 and svort/models.py read it from params["interp_psf"], which every
  *     configuration sets to False); the host layer raises NotImplementedError for them - nothing falls back.
- *   * double precision: the reference dispatches float and double (AT_DISPATCH_FLOATING_TYPES at
- *     slice_acq_cuda_kernel.cu:970, :1010, :1046, :1114).  Built here: float.  No caller in the reference tree passes
- *     double volumes; the host layer raises on any other dtype.
+ *   * double precision is built (the *_f64 entry points below; the reference dispatches float and double).
  *   * PSF size: any (the forward kernel keeps PSFs of up to 1024 taps as an LDS list of their non-zero taps and walks
  *     larger ones in global memory; the other three read the dense PSF array).
  *
@@ -105,6 +103,25 @@ int nesvor_slice_acq_backward(const float* transforms, const float* vol, const u
                               const float* grad_slices, const uint8_t* slices_mask, float* grad_vol,
                               float* grad_transforms, float* scratch, int D, int H, int W, int d_p, int h_p, int w_p,
                               int n, int h, int w, float res_slice, void* stream);
+/* double-precision variants of the four entry points (the reference dispatches float and double,
+ * slice_acq_cuda_kernel.cu:970, :1010, :1046, :1114): same contracts, every float* a double*, res_slice a double. */
+int nesvor_slice_acq_forward_f64(const double* transforms, const double* vol, const uint8_t* vol_mask,
+                                 const uint8_t* slices_mask, const double* psf, double* slices, double* slices_weight,
+                                 int D, int H, int W, int d_p, int h_p, int w_p, int n, int h, int w,
+                                 double res_slice, int interp_psf, void* stream);
+int nesvor_slice_acq_adjoint_forward_f64(const double* transforms, const double* psf, const double* slices,
+                                         const uint8_t* slices_mask, const uint8_t* vol_mask, double* vol, double* vol_weight,
+                                         double* scratch, int D, int H, int W, int d_p, int h_p, int w_p, int n, int h, int w,
+                                         double res_slice, int equalize, void* stream);
+int nesvor_slice_acq_backward_f64(const double* transforms, const double* vol, const uint8_t* vol_mask, const double* psf,
+                                  const double* grad_slices, const uint8_t* slices_mask, double* grad_vol,
+                                  double* grad_transforms, double* scratch, int D, int H, int W, int d_p, int h_p, int w_p,
+                                  int n, int h, int w, double res_slice, void* stream);
+int nesvor_slice_acq_adjoint_backward_f64(const double* transforms, double* grad_vol, const double* vol_weight,
+                                          const uint8_t* vol_mask, const double* psf, const double* slices,
+                                          const uint8_t* slices_mask, const double* vol, double* grad_slices,
+                                          double* grad_transforms, int D, int H, int W, int d_p, int h_p, int w_p, int n, int h,
+                                          int w, double res_slice, int equalize, void* stream);
 
 /* ------------------------------------------------------------------------
  * Multi-resolution hash-grid encoding.  Replaces `tinycudann.Encoding`

@@ -6,7 +6,7 @@ every op wrapper raises on non-device tensors.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 import torch
 
@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NESVOR_HIP_LIB: load another build of the same ABI (tools/ablate_hashgrid.py times variants of one kernel this way)
 LIB_PATH = os.environ.get("NESVOR_HIP_LIB") or os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -76,6 +76,10 @@ _SIGNATURES = {
     "nesvor_slice_acq_adjoint_forward": ([_P] * 8 + [c_int] * 9 + [c_float, c_int, _P], c_int),
     "nesvor_slice_acq_backward": ([_P] * 9 + [c_int] * 9 + [c_float, _P], c_int),
     "nesvor_slice_acq_adjoint_backward": ([_P] * 10 + [c_int] * 9 + [c_float, c_int, _P], c_int),
+    "nesvor_slice_acq_forward_f64": ([_P, _P, _P, _P, _P, _P, _P] + [c_int] * 9 + [c_double, c_int, _P], c_int),
+    "nesvor_slice_acq_adjoint_forward_f64": ([_P] * 8 + [c_int] * 9 + [c_double, c_int, _P], c_int),
+    "nesvor_slice_acq_backward_f64": ([_P] * 9 + [c_int] * 9 + [c_double, _P], c_int),
+    "nesvor_slice_acq_adjoint_backward_f64": ([_P] * 10 + [c_int] * 9 + [c_double, c_int, _P], c_int),
     "nesvor_hashgrid_forward": ([POINTER(GridT), _P, _P, _P, c_int64, c_int, _P], c_int),
     "nesvor_hashgrid_backward_workspace_bytes": ([POINTER(GridT), c_int64, _P], c_int64),
     "nesvor_hashgrid_backward_workspace_zero_bytes": ([], c_int64),

@@ -150,14 +150,14 @@ def _sa_dims(vol_shape, psf):
 
 
 def _sa_symbol(name, t, interp_psf=False):
-    """fp32, linear-interpolation mode.  The reference also dispatches double (slice_acq_cuda_kernel.cu:970-1114) and
-    has a PSF-interpolating mode in all four kernels (:229-279, :526-572, :754); neither is used by any caller in the
-    reference tree and neither is built, except interp_psf in the forward operator (recorded in include/nesvor_hip.h)."""
-    if t.dtype != torch.float32:
-        raise NotImplementedError(f"slice_acq: only float32 is built (got {t.dtype}); no fallback")
+    """float32 / float64 (the reference's AT_DISPATCH_FLOATING_TYPES, slice_acq_cuda_kernel.cu:970-1114), linear
+    interpolation.  The PSF-interpolating mode of the reference (:229-279, :526-572, :754) exists in the forward operator
+    only; no caller in the reference tree uses it (exclusion recorded in include/nesvor_hip.h)."""
+    if t.dtype not in (torch.float32, torch.float64):
+        raise NotImplementedError(f"slice_acq: float32 or float64 expected, got {t.dtype}")
     if interp_psf:
         raise NotImplementedError("slice_acq backward / adjoint: interp_psf=True is not built (no fallback)")
-    return getattr(_lib.load(), name)
+    return getattr(_lib.load(), name + ("_f64" if t.dtype == torch.float64 else ""))
 
 
 def _sa_forward(transforms, vol, vol_mask, slices_mask, psf, slice_shape, res_slice, need_weight, interp_psf):

@@ -243,6 +243,68 @@ def test_slice_acq_backward_vs_oracle(device, masks):
 
 
 @pytest.mark.parametrize("masks", [False, True])
+def test_slice_acq_double_precision_all_four_entry_points(device, masks):
+    """The reference dispatches its four slice-acquisition kernels for float AND double (AT_DISPATCH_FLOATING_TYPES,
+    slice_acq_cuda_kernel.cu:970, 1010, 1046, 1114).  The *_f64 entry points against the oracle evaluated in float64:
+    operators to 1e-10, gradients to 1e-9 of their range; autograd through the public wrappers in double; a large PSF
+    (more taps than the forward's LDS tap list holds) and the no-fallback guard for other dtypes."""
+    from nesvor_amd import slice_acq_cuda as K
+    from nesvor_amd.slice_acquisition import slice_acquisition, slice_acquisition_adjoint
+    from nesvor_amd.utils import get_PSF
+    from oracle import slice_acq as O
+
+    vol, psf, tf, vm, sm = _sa_setup(masks, seed=11)
+    vol, psf, tf = vol.double(), psf.double(), tf.double()
+    dims = (18, 20, 22)
+    e = torch.empty(0, device=device)
+    d = lambda t: e if t is None else t.to(device)
+    # A
+    ref, wref = O.slice_acquisition_forward(tf, vol, vm, sm, psf, (14, 12), 1.5, True, False)
+    got, wgot = K.forward(d(tf), d(vol), d(vm), d(sm), d(psf), (14, 12), 1.5, True, False)
+    assert got.dtype == torch.float64
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-10, atol=1e-12)
+    torch.testing.assert_close(wgot.cpu(), wref, rtol=1e-10, atol=1e-12)
+    # backward of A
+    g = torch.randn(6, 1, 14, 12, dtype=torch.float64)
+    gv_ref, gt_ref = O.slice_acquisition_backward(tf, vol, vm, psf, g, sm, 1.5)
+    gv, gt = K.backward(d(tf), d(vol), d(vm), d(psf), d(g), d(sm), 1.5, False, True, True)
+    torch.testing.assert_close(gv.cpu(), gv_ref, rtol=1e-9, atol=1e-11)
+    assert float((gt.cpu() - gt_ref).abs().max()) <= 1e-9 * float(gt_ref.abs().max())
+    # A^T (+ equalisation) and its backward
+    y = torch.rand(6, 1, 14, 12, dtype=torch.float64)
+    G = torch.randn(1, 1, *dims, dtype=torch.float64)
+    for equalize in (False, True):
+        v_ref, w_ref = O.slice_acquisition_adjoint_forward(tf, psf, y, sm, vm, dims, 1.5, False, equalize)
+        v, w = K.adjoint_forward(d(tf), d(psf), d(y), d(sm), d(vm), dims, 1.5, False, equalize)
+        torch.testing.assert_close(v.cpu(), v_ref, rtol=1e-10, atol=1e-12)
+        gs_ref, gt2_ref = O.slice_acquisition_adjoint_backward(tf, G, w_ref if equalize else None, vm, psf, y, sm,
+                                                               v_ref if equalize else None, 1.5, False, equalize)
+        gs, gt2 = K.adjoint_backward(d(tf), d(G).clone(), d(w_ref) if equalize else None, d(vm), d(psf), d(y), d(sm),
+                                     d(v_ref) if equalize else None, 1.5, False, equalize, True, True)
+        torch.testing.assert_close(gs.cpu(), gs_ref, rtol=1e-9, atol=1e-11)
+        assert float((gt2.cpu() - gt2_ref).abs().max()) <= 1e-9 * float(gt2_ref.abs().max())
+    # autograd through the wrappers, in double
+    t = tf.to(device).requires_grad_(True)
+    vv = vol.to(device).requires_grad_(True)
+    out = slice_acquisition(t, vv, None if vm is None else vm.to(device), None if sm is None else sm.to(device), psf.to(device),
+                            (14, 12), 1.5, False, False)
+    (out * g.to(device)).sum().backward()
+    torch.testing.assert_close(vv.grad.cpu(), gv_ref, rtol=1e-9, atol=1e-11)
+    back = slice_acquisition_adjoint(tf.to(device), psf.to(device), y.to(device), None, None, dims, 1.5, False, False)
+    assert back.dtype == torch.float64 and back.shape == (1, 1) + dims
+    # a PSF of 1813 taps (6 mm slices on a 0.5 mm grid): beyond the forward's LDS tap list, walked in global memory
+    big = get_PSF(res_ratio=(3.0, 3.0, 12.0)).double()
+    assert big.numel() > 1024
+    ref_b = O.slice_acquisition_forward(tf, vol, None, None, big, (14, 12), 1.5, False, False)
+    got_b = K.forward(d(tf), d(vol), e, e, d(big), (14, 12), 1.5, False, False)[0]
+    torch.testing.assert_close(got_b.cpu(), ref_b, rtol=1e-10, atol=1e-12)
+    got_b32 = K.forward(d(tf.float()), d(vol.float()), e, e, d(big.float()), (14, 12), 1.5, False, False)[0]
+    torch.testing.assert_close(got_b32.cpu().double(), ref_b, rtol=1e-4, atol=1e-5)
+    with pytest.raises(NotImplementedError):
+        K.forward(d(tf.half()), d(vol.half()), e, e, d(psf.half()), (14, 12), 1.5, False, False)
+
+
+@pytest.mark.parametrize("masks", [False, True])
 @pytest.mark.parametrize("equalize", [False, True])
 def test_slice_acq_adjoint_backward_vs_oracle(device, masks, equalize):
     """Backward of A^T (gather per pixel, per-slice reduction instead of the reference's atomics) vs the oracle,
