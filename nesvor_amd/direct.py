@@ -82,6 +82,7 @@ class DirectStep:
         # the hash-grid backward (latency-bound, finishes the table gradient only) while the main stream runs the
         # sampler backward and the per-slice bookkeeping
         self.side = torch.cuda.Stream(device=dev)
+        self._overlap_owner = __import__("os").environ.get("NESVOR_OWNER_OVERLAP", "1") != "0"
         # evaluation of the MLP matrix products (mlp.operand_mode): bf16-rounded operands for the half-precision model
         # structure and, opt-in, for the fp32 model (args.mlp_bf16); otherwise fp32 - the split-bf16 default, or the
         # plain fp32 MFMAs with args.mlp_fp32_mfma
@@ -225,7 +226,8 @@ class DirectStep:
             _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR,
                                       levels=(0, self.split_level), grad_u=du, first=False)
         else:
-            overlap_owner = not _lib.kernel_timer.enabled  # (per-kernel event timing needs both launches on one stream)
+            # (per-kernel event timing needs both launches on one stream; NESVOR_OWNER_OVERLAP=0: the same for a kernel trace)
+            overlap_owner = not _lib.kernel_timer.enabled and self._overlap_owner
             _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR,
                                       owner_stream=self.side if overlap_owner else None)
         dpix = sampler.backward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb, dxl, du) if self.opt_T else None
