@@ -27,7 +27,7 @@ python $ROOT/tools/pmc_summary.py owner $OUT/pmc_sq1 $OUT/pmc_sq2 > $OUT/pmc_sq_
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/step_$c -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-extras > /dev/null 2>&1
 done
-python $ROOT/tools/step_traffic.py $OUT/step_FETCH_SIZE $OUT/step_WRITE_SIZE 24 > $OUT/step_traffic.json
+python $ROOT/tools/step_traffic.py $OUT/step_FETCH_SIZE $OUT/step_WRITE_SIZE 32 > $OUT/step_traffic.json
 # 4. micro-benchmarks
 python $ROOT/tools/bench_hashgrid.py > $OUT/hashgrid_microbench.log 2>&1
 python $ROOT/tools/bench_hg_levels.py > $OUT/hashgrid_per_level.log 2>&1
