@@ -356,21 +356,38 @@ def main():
             }
         roof_mlp = None
         if ktimes and "mlp_bwd" in ktimes and not args.n_levels_bias and not args.no_pixel_variance:
-            # second-largest consumer: the two fused MLP backward launches (dX + dW + db), fp32 matrix cores
+            # second-largest consumer: the two fused MLP backward launches (dX chain + dW + db).  Two matrix pipes are in
+            # play, so one flops / peak ratio fits neither: the busy fraction of each pipe is stated instead, from the
+            # kernels' MFMA counts per 16-sample group (block products of the layer shapes), the issue cost of each MFMA
+            # (v_mfma_f32_16x16x4_f32: 32 cycles, v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16: 16; tools/mfma_valu_overlap.hip
+            # and the SQ_VALU_MFMA_BUSY_CYCLES counters under profiles/) and the device's engine clock
             nz, ns, W = args.n_features_z, args.n_features_slice, args.width
-            hid = (opt.depth - 1) * W * W
-            fl = 2 * n_points * ((L * F * W + hid + W * (1 + nz)) + ((ns + nz) * W + hid + W))  # one forward of both nets
+            blocks = lambda dims: sum(-(-o // 16) * -(-i // 16) for i, o in zip(dims[:-1], dims[1:]))
+            dens = [L * F] + [W] * opt.depth + [1 + nz]
+            sig = [ns + nz] + [W] * opt.depth + [1]
+            bp = blocks(dens) + blocks(sig)              # 16x16x16 block products of one forward of both networks
+            groups = n_points / 16
+            clock_hz = torch.cuda.get_device_properties(device).clock_rate * 1e3
+            n_simd = torch.cuda.get_device_properties(device).multi_processor_count * 4
             ms2 = 2 * ktimes["mlp_bwd"][1]
             bf16_ops = opt.mlp_bf16 or opt.half_precision_model
-            peak = 2500.0 if bf16_ops else 157.3
-            note = ("bf16 MFMA (v_mfma_f32_16x16x16_bf16) dense peak; the kernel is bound by its LDS/VALU work around the MFMAs "
-                    "in this mode, not by the matrix pipe" if bf16_ops else
-                    "fp32 MFMA (v_mfma_f32_16x16x4_f32) dense peak" if opt.mlp_fp32_mfma else
-                    "fp32-equivalent flops against the fp32 MFMA (v_mfma_f32_16x16x4_f32) dense peak; the dW products run on that "
-                    "pipe, the dX chain as split-bf16 MFMAs (6 x v_mfma_f32_16x16x32_bf16 per 2 k-blocks)")
-            roof_mlp = {"bound": "mfma", "kernel": "mlp_bwd_fused (density_net + sigma_net launches)", "achieved": 2 * fl / (ms2 * 1e-3) / 1e12,
-                        "peak": peak, "unit": "TFLOP/s", "frac": 2 * fl / (ms2 * 1e-3) / 1e12 / peak, "traffic": None,
-                        "launch_ms": ms2, "note": note + "; flops = 2x forward (dX and dW), padding excluded"}
+            if bf16_ops:      # dX chain and dW on the bf16 pipe: one 16-k MFMA per block product and role
+                fp32_mfma, bf16_mfma = 0, 2 * bp
+            elif opt.mlp_fp32_mfma:  # four 4-k fp32 MFMAs per block product and role
+                fp32_mfma, bf16_mfma = 8 * bp, 0
+            else:             # default: dW on the fp32 pipe, the dX chain as six 32-k bf16 MFMAs per pair of block products
+                fp32_mfma, bf16_mfma = 4 * bp, 3 * bp
+            busy = lambda n, cyc: n * cyc * groups / n_simd / (ms2 * 1e-3 * clock_hz)
+            fl = 2 * n_points * sum(i * o for d in (dens, sig) for i, o in zip(d[:-1], d[1:]))  # one forward of both nets
+            roof_mlp = {"bound": "mfma", "kernel": "mlp_bwd_ws (density_net + sigma_net launches)", "launch_ms": ms2,
+                        "fp32_pipe_busy_frac": busy(fp32_mfma, 32), "bf16_pipe_busy_frac": busy(bf16_mfma, 16),
+                        "matrix_pipe_busy_frac": busy(fp32_mfma, 32) + busy(bf16_mfma, 16),
+                        "mfma_per_16_sample_group": {"fp32_16x16x4": fp32_mfma, "bf16": bf16_mfma},
+                        "engine_clock_MHz": clock_hz / 1e6, "fp32_equivalent_TFLOPs": 2 * fl / (ms2 * 1e-3) / 1e12,
+                        "note": "busy fractions = MFMA issue cycles per SIMD / (launch time x engine clock): an upper-clock estimate "
+                                "(the counters of profiles/r01_pmc_sq_mlp_split_pass*.csv measure 50 % for the default mode); the "
+                                "kernel runs two waves per SIMD and is bound by what sits between the MFMAs (operand splitting on "
+                                "the VALU, LDS tile traffic, the saved-activation stream), see DESIGN.md"}
         out = {
             "metric": "INR train iters/sec (2^20 samples, L=16 hash, 64-wide MLP)",
             "value": iters_per_s,
