@@ -367,8 +367,9 @@ def main():
             sig = [ns + nz] + [W] * opt.depth + [1]
             bp = blocks(dens) + blocks(sig)              # 16x16x16 block products of one forward of both networks
             groups = n_points / 16
-            clock_hz = torch.cuda.get_device_properties(device).clock_rate * 1e3
-            n_simd = torch.cuda.get_device_properties(device).multi_processor_count * 4
+            props = torch.cuda.get_device_properties(device)
+            clock_hz = float(getattr(props, "clock_rate", 2.4e6)) * 1e3  # kHz; MI355X maximum engine clock 2400 MHz (MI355X_MICROARCH.md)
+            n_simd = props.multi_processor_count * 4
             ms2 = 2 * ktimes["mlp_bwd"][1]
             bf16_ops = opt.mlp_bf16 or opt.half_precision_model
             if bf16_ops:      # dX chain and dW on the bf16 pipe: one 16-k MFMA per block product and role

@@ -118,11 +118,135 @@ __global__ __launch_bounds__(256) void imaging_loss_kernel(const nesvor_loss_t a
   }
 }
 
+
+// The same computation for S = 64 K samples per pixel (K = 1, 2, 4, 8: the training default S = 256 is K = 4): one pass.
+// A lane keeps its K samples (z0, density, bias, exp(log_var), x) in registers; the mirror sample S-1-s of sample
+// s = lane + 64 i is sample 63-lane, K-1-i of the same wave, so its density and coordinates come through a wave
+// permute instead of a second softplus and a second read; the gradient pass re-uses everything.  Same formulas in the
+// same order as imaging_loss_kernel: the two kernels agree bit for bit.
+template <int REG, int K>
+__global__ __launch_bounds__(256) void imaging_loss_cached_kernel(const nesvor_loss_t a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  constexpr int S = 64 * K;
+  const int64_t k = a.slice_idx[b];
+  const size_t base = (size_t)b * S;
+  const float c = a.c != nullptr ? a.c[k] : 1.f;
+  const bool has_lv = a.log_var != nullptr, has_lb = a.log_bias != nullptr;
+  const float inv_d2 = 1.f / (a.delta * a.delta);
+  float z[K], dens[K], bias[K], elv[K], xs[K][3];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const size_t s = base + lane + 64 * i;
+    z[i] = a.z0[s];
+    bias[i] = has_lb ? a.log_bias[s] : 0.f;
+    elv[i] = has_lv ? a.log_var[s] : 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) xs[i][d] = a.x[s * 3 + d];
+  }
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    dens[i] = softplus_f(z[i]);
+    bias[i] = has_lb ? expf(bias[i]) : 1.f;
+    elv[i] = has_lv ? expf(elv[i]) : 0.f;
+  }
+  float dd[K], ex[K][3], dx2[K];
+  float s1 = 0.f, s2 = 0.f, sreg = 0.f;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const float dm = __shfl(dens[K - 1 - i], 63 - lane, 64);
+    dd[i] = dens[i] - dm;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) ex[i][d] = xs[i][d] - __shfl(xs[K - 1 - i][d], 63 - lane, 64);
+    dx2[i] = (ex[i][0] * ex[i][0] + ex[i][1] * ex[i][1] + ex[i][2] * ex[i][2]) + 1e-6f;
+    s1 += bias[i] * dens[i];
+    if (has_lv) s2 += bias[i] * elv[i];
+    if (REG == 0) sreg += sqrtf(1.f + dd[i] * dd[i] / dx2[i] * inv_d2);
+    if (REG == 1) sreg += fabsf(dd[i] / sqrtf(dx2[i]));
+    if (REG == 2) sreg += dd[i] * dd[i] / dx2[i];
+  }
+  s1 = wave_sum_dpp(s1); s2 = wave_sum_dpp(s2); sreg = wave_sum_dpp(sreg);
+  const float m1 = s1 / S, m2 = s2 / S;
+  const float v_out = c * m1;
+  float var = 1.f, pv = 0.f;
+  if (has_lv) { pv = c * m2; var = pv * pv; }
+  const float slice_var = a.log_var_slice != nullptr ? expf(a.log_var_slice[k]) : 0.f;
+  var += slice_var;
+  const bool has_var = has_lv || a.log_var_slice != nullptr;
+  const float e = v_out - a.v[b];
+  const float invB = 1.f / a.B;
+  if (a.loss_pix != nullptr && lane == 0) {
+    a.loss_pix[3 * b + 0] = e * e / (2.f * var);
+    a.loss_pix[3 * b + 1] = has_var ? 0.5f * logf(var) : 0.f;
+    a.loss_pix[3 * b + 2] = sreg;
+  }
+  if (a.gw == nullptr) return;
+  const float gw_mse = a.gw[0], gw_lv = a.gw[1], gw_img = a.gw[2], gw_bias = a.gw[3];
+  const float g_vout = gw_mse * e / var * invB;
+  const float g_var = has_var ? (gw_mse * (-e * e / (2.f * var * var)) + gw_lv * 0.5f / var) * invB : 0.f;
+  const float g_m2 = has_lv ? g_var * 2.f * pv * c : 0.f;
+  if (lane == 0) {
+    if (a.dc_pix != nullptr) a.dc_pix[b] = g_vout * m1;
+    if (a.dlvs_pix != nullptr) a.dlvs_pix[b] = g_var * slice_var;
+  }
+  const float reg_scale = (REG == 0 ? a.delta : 1.f) * gw_img / ((float)a.B * S);
+  const float g_lb_reg = has_lb ? gw_bias * 2.f * a.log_bias_mean[0] / ((float)a.B * S) : 0.f;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const size_t s = base + lane + 64 * i;
+    float g_dens = g_vout * c * bias[i] / S;
+    float g_dd, g_dx2;
+    if (REG == 0) {
+      const float term = sqrtf(1.f + dd[i] * dd[i] / dx2[i] * inv_d2);
+      g_dd = dd[i] / dx2[i] * inv_d2 / term;
+      g_dx2 = -0.5f * dd[i] * dd[i] / (dx2[i] * dx2[i]) * inv_d2 / term;
+    } else if (REG == 1) {
+      const float r = sqrtf(dx2[i]);
+      g_dd = (dd[i] > 0.f ? 1.f : (dd[i] < 0.f ? -1.f : 0.f)) / r;
+      g_dx2 = -0.5f * fabsf(dd[i]) / (dx2[i] * r);
+    } else {
+      g_dd = 2.f * dd[i] / dx2[i];
+      g_dx2 = -dd[i] * dd[i] / (dx2[i] * dx2[i]);
+    }
+    g_dens += 2.f * reg_scale * g_dd;
+    a.dz0[s] = g_dens * sigmoid_f(z[i]);
+    if (a.dx != nullptr) {
+      const float gx = 2.f * reg_scale * g_dx2 * 2.f;
+      float* o = a.dx + s * 3;
+      o[0] = gx * ex[i][0]; o[1] = gx * ex[i][1]; o[2] = gx * ex[i][2];
+    }
+    if (has_lv) a.dlog_var[s] = g_m2 * bias[i] * elv[i] / S;
+    if (has_lb) a.dlog_bias[s] = g_vout * c * dens[i] * bias[i] / S + g_lb_reg;
+  }
+}
+
 }  // namespace
 
 extern "C" int nesvor_imaging_loss(const nesvor_loss_t* args, void* stream) {
   if (args->B <= 0 || args->S <= 0) return 0;
   dim3 grid((args->B + 3) / 4), block(256);
+  if (args->reg_type < 0 || args->reg_type > 2) return (int)hipErrorInvalidValue;
+  // S = 64, 128, 256, 512: the single-pass kernel (NESVOR_LOSS_TWO_PASS=1: the general one, an A/B switch - the two agree
+  // bit for bit)
+  static const bool two_pass = []() { const char* e = getenv("NESVOR_LOSS_TWO_PASS"); return e != nullptr && atoi(e) != 0; }();
+  const int K = (args->S % 64 == 0) ? args->S / 64 : 0;
+  if (!two_pass && (K == 1 || K == 2 || K == 4 || K == 8)) {
+#define NESVOR_LAUNCH_LOSS(R, KK) hipLaunchKernelGGL((imaging_loss_cached_kernel<R, KK>), grid, block, 0, (hipStream_t)stream, *args)
+#define NESVOR_LAUNCH_LOSS_K(R)                                   \
+  switch (K) {                                                    \
+    case 1: NESVOR_LAUNCH_LOSS(R, 1); break;                      \
+    case 2: NESVOR_LAUNCH_LOSS(R, 2); break;                      \
+    case 4: NESVOR_LAUNCH_LOSS(R, 4); break;                      \
+    default: NESVOR_LAUNCH_LOSS(R, 8); break;                     \
+  }
+    if (args->reg_type == 0) { NESVOR_LAUNCH_LOSS_K(0) }
+    else if (args->reg_type == 1) { NESVOR_LAUNCH_LOSS_K(1) }
+    else { NESVOR_LAUNCH_LOSS_K(2) }
+#undef NESVOR_LAUNCH_LOSS_K
+#undef NESVOR_LAUNCH_LOSS
+    return (int)hipGetLastError();
+  }
   if (args->reg_type == 0) hipLaunchKernelGGL(imaging_loss_kernel<0>, grid, block, 0, (hipStream_t)stream, *args);
   else if (args->reg_type == 1) hipLaunchKernelGGL(imaging_loss_kernel<1>, grid, block, 0, (hipStream_t)stream, *args);
   else if (args->reg_type == 2) hipLaunchKernelGGL(imaging_loss_kernel<2>, grid, block, 0, (hipStream_t)stream, *args);

@@ -1,12 +1,14 @@
 """GPU (-m gpu): parity of every HIP op with the CPU oracle on the same seeded inputs,
 through the C ABI (ctypes).  Tolerances are stated per test; index/byte work is exact."""
 import math
+import os
+import sys
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import scipy_table
+from conftest import ROOT, scipy_table
 
 pytestmark = pytest.mark.gpu
 
@@ -669,14 +671,16 @@ def test_psf_transform_vs_oracle(device, B, S):
 @pytest.mark.parametrize("pix_var,slice_var,bias,scale", [(True, True, False, True), (True, True, True, True),
                                                           (False, True, False, False), (True, False, True, True),
                                                           (False, False, False, True)])
-def test_imaging_loss_vs_reference_math(device, reg, pix_var, slice_var, bias, scale):
+@pytest.mark.parametrize("S", [24, 64, 256])
+def test_imaging_loss_vs_reference_math(device, reg, pix_var, slice_var, bias, scale, S):
     """Fused loss kernel (values + every gradient) vs the reference's formulas (models.py:286-325,366-384)
-    evaluated with PyTorch autograd in fp64 on the CPU.  fp32 kernel: rtol 2e-4 on values, 5e-4 x max|grad|."""
+    evaluated with PyTorch autograd in fp64 on the CPU.  fp32 kernel: rtol 2e-4 on values, 5e-4 x max|grad|.
+    S = 24 runs the general two-pass kernel, S = 64 and 256 the single-pass one (csrc/loss.hip)."""
     from nesvor_amd.loss import imaging_loss
     from oracle import nesvor_model as nm
 
     torch.manual_seed(7)
-    B, S, n = 37, 24, 5
+    B, n = 37, 5
     idx = torch.randint(0, n, (B,))
     f64 = lambda *sh: torch.randn(*sh, dtype=torch.float64)
     z0 = (f64(B, S) * 2).requires_grad_(True)
@@ -720,6 +724,52 @@ def test_imaging_loss_vs_reference_math(device, reg, pix_var, slice_var, bias, s
         gotg = a_.grad.cpu().double() if a_.grad is not None else torch.zeros_like(ref)
         scale_ = float(ref.abs().max()) + 1e-9
         assert float((gotg - ref).abs().max()) <= 5e-4 * scale_, (name, float((gotg - ref).abs().max()), scale_)
+
+
+_LOSS_AB = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from nesvor_amd.loss import imaging_loss
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(11)
+B, S, n = 301, int(sys.argv[3]), 7
+r = lambda *sh: torch.randn(*sh, generator=g)
+leaf = lambda t: t.to(dev).requires_grad_(True)
+z0, lv, lb = leaf(r(B * S) * 2), leaf(r(B * S) * 0.3), leaf(r(B * S) * 0.1)
+x = leaf(r(B, 1, 3) * 20 + r(B, S, 3))
+c, lvs = leaf(torch.rand(n, generator=g) + 0.5), leaf(r(n) * 0.2)
+v, idx = torch.rand(B, generator=g).to(dev), torch.randint(0, n, (B,), generator=g).to(dev)
+out = {}
+for reg in ("edge", "TV", "L2"):
+    for t in (z0, lv, lb, x, c, lvs):
+        t.grad = None
+    got = imaging_loss(z0, lv, lb, x, v, idx, c, lvs, reg, 0.2)
+    (got[0] + got[1] + 2 * got[2] + 100 * got[3]).backward()
+    out[reg] = [t.detach().cpu() for t in got] + [t.grad.cpu() for t in (z0, lv, lb, x, c, lvs)]
+torch.save(out, sys.argv[2])
+"""
+
+
+@pytest.mark.parametrize("S", [64, 128, 256, 512])
+def test_imaging_loss_single_pass_kernel_equals_two_pass_kernel(device, tmp_path, S):
+    """csrc/loss.hip has two kernels: the general two-pass one and a single-pass one for S = 64 K that keeps a pixel's
+    samples in registers.  Same formulas in the same order: every output and every gradient must agree BIT FOR BIT
+    (the switch NESVOR_LOSS_TWO_PASS is read once per process, hence the two subprocesses)."""
+    import subprocess
+
+    outs = []
+    for two_pass in ("0", "1"):
+        path = str(tmp_path / f"loss{two_pass}.pt")
+        env = {**os.environ, "NESVOR_LOSS_TWO_PASS": two_pass}
+        subprocess.run([sys.executable, "-c", _LOSS_AB, ROOT, path, str(S)], check=True, env=env, timeout=300)
+        outs.append(torch.load(path))
+    names = ["mse", "logvar", "ireg", "breg", "d_z0", "d_log_var", "d_log_bias", "d_x", "d_c", "d_log_var_slice"]
+    for reg in outs[0]:
+        for name, a_, b_ in zip(names, outs[0][reg], outs[1][reg]):
+            if name in ("d_c", "d_log_var_slice"):  # per-slice sums of per-pixel terms: index_add atomics, order not fixed
+                torch.testing.assert_close(a_, b_, rtol=1e-5, atol=1e-8, msg=f"{reg} {name}")
+            else:
+                assert torch.equal(a_, b_), (reg, name, float((a_ - b_).abs().max()))
 
 
 def _bf(x):
