@@ -388,6 +388,162 @@ __device__ __forceinline__ f32x4 load_dy_fast(const MlpArgs& a, int64_t gi, int 
   return g;
 }
 
+// Loads whose issue point the compiler cannot move: written as source-level "prefetch into registers" the loads of
+// the next group get sunk to their first use (register pressure) and their latency is paid in full each group.
+// The compiler does not know these registers are pending, so every consumer must sit behind await_loads().
+__device__ __forceinline__ void issue_load_b128(f32x4& dst, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void issue_load_b32(float& dst, const float* p) {
+  asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void issue_load_b64(f32x2& dst, const void* p) {
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void issue_load_u16(float& dst, const void* p) {  // zero-extended 16 bits in a 32-bit register
+  asm volatile("global_load_ushort %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void pin(f32x2& x) { asm volatile("" : "+v"(x)); }
+// four bf16 packed in two dwords -> fp32 (exact)
+__device__ __forceinline__ f32x4 unpack_bf16(const f32x2& v) {
+  const uint32_t u0 = __float_as_uint(v[0]), u1 = __float_as_uint(v[1]);
+  return f32x4{__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xFFFF0000u), __uint_as_float(u1 << 16),
+               __uint_as_float(u1 & 0xFFFF0000u)};
+}
+__device__ __forceinline__ void await_loads() {
+  __builtin_amdgcn_sched_barrier(0);  // nothing (in particular no MFMA) may be scheduled across the wait
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// an empty volatile asm that "modifies" x: volatile asms keep their order, so a consumer of x cannot be scheduled
+// above the await_loads() that precedes this call
+__device__ __forceinline__ void pin(f32x4& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
+
+// ---------------------------------------------------- forward, software-pipelined
+// mlp_fwd_kernel below loads a tile's inputs at the top of its loop and uses them at once: loads and stores retire
+// through one in-order counter (vmcnt), so that wait also drains every store of the previous tile, and a tile costs
+// [store drain + load latency] + [compute] in sequence (measured: the density network's launch moved 0.74 GB in
+// 0.176 ms = 4.2 TB/s).  Here the loads of the NEXT tile are issued (inline asm: the compiler would sink them to their
+// first use) before the layer products of the current one, all stores of a tile (saved hidden fragments, outputs) are
+// held back to the end of the tile, and the prefetch is awaited right before them: the wait covers loads that are one
+// whole tile of MFMAs old, the stores drain under the next tile's MFMAs.
+// Requires the fast input path, whole tiles (n_groups % (4 kG) == 0) and NH = 1 or 2 hidden layers.
+template <int KB1, int NH, bool X6, bool SAVE>
+__global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_pf_kernel(const MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int k_in = a.k_a + a.k_b;
+  constexpr int kBlk = X6 ? 384 : 256;
+  float* img1 = lds;
+  float* imgh = img1 + kHB * KB1 * kBlk;
+  float* imgo = imgh + (NH - 1) * kHB * kHB * kBlk;
+  float* bias = imgo + 1 * kHB * kBlk;
+  build_image<false, X6>(img1, a.W[0], kWidth, k_in, kHB, KB1);
+  for (int l = 1; l < NH; ++l) build_image<false, X6>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, kHB, kHB);
+  build_image<false, X6>(imgo, a.W[NH], a.out_dim, kWidth, 1, kHB);
+  for (int e = threadIdx.x; e < (NH + 1) * kWidth; e += blockDim.x) {
+    const int l = e / kWidth, o = e % kWidth;
+    bias[e] = (l < NH || o < a.out_dim) ? a.b[l][o] : 0.f;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const int64_t n_tiles = (a.N >> 4) / (4 * kG);
+  const int ka_blocks = a.k_a >> 4;
+  // every element of an input block is one dword load; a pixel-feature block and a row block differ only in the address
+  auto issue_x = [&](int64_t tile, float (&xr)[kG][KB1][4]) __attribute__((always_inline)) {
+    const int64_t g0 = (tile * 4 + wave) * kG;
+#pragma unroll
+    for (int g = 0; g < kG; ++g) {
+      const int64_t gi = g0 + g, n = gi * 16 + j;
+      const int64_t pixel = a.spg_shift >= 0 ? (gi >> a.spg_shift) : gi / (a.S >> 4);
+#pragma unroll
+      for (int kb = 0; kb < KB1; ++kb) {
+        const bool is_a = kb < ka_blocks;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = min(16 * (kb - ka_blocks) + 4 * q + r, a.k_b - 1);
+          const float* p = is_a ? a.xa + (size_t)pixel * a.k_a + 16 * kb + 4 * q + r
+                                : a.xb + (size_t)(a.b_row0 + max(row, 0)) * a.N + n;
+          issue_load_b32(xr[g][kb][r], p);
+        }
+      }
+    }
+  };
+  auto settle_x = [&](float (&xr)[kG][KB1][4]) __attribute__((always_inline)) {
+    await_loads();
+#pragma unroll
+    for (int g = 0; g < kG; ++g)
+#pragma unroll
+      for (int kb = 0; kb < KB1; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pin(xr[g][kb][r]);
+  };
+  float xr[kG][KB1][4];
+#pragma unroll
+  for (int g = 0; g < kG; ++g)
+#pragma unroll
+    for (int kb = 0; kb < KB1; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xr[g][kb][r] = 0.f;
+  if ((int64_t)blockIdx.x < n_tiles) { issue_x(blockIdx.x, xr); settle_x(xr); }
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t g0 = (tile * 4 + wave) * kG;
+    f32x4 x[kG][KB1];
+#pragma unroll
+    for (int g = 0; g < kG; ++g)
+#pragma unroll
+      for (int kb = 0; kb < KB1; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          x[g][kb][r] = (kb < ka_blocks || 16 * (kb - ka_blocks) + 4 * q + r < a.k_b) ? xr[g][kb][r] : 0.f;
+    // the last tile of a workgroup re-requests a valid tile (no control flow between an issue and its settle)
+    issue_x(min(tile + (int64_t)gridDim.x, n_tiles - 1), xr);
+    f32x4 h[NH][kG][kHB];
+#pragma unroll
+    for (int l = 0; l < NH; ++l) {
+#pragma unroll
+      for (int ob = 0; ob < kHB; ++ob) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + l * kWidth + 16 * ob + 4 * q);
+#pragma unroll
+        for (int g = 0; g < kG; ++g) h[l][g][ob] = bq;
+      }
+      if (l == 0) apply_layer<KB1, kHB, false, X6>(img1, x, h[0], lane);
+      else apply_layer<kHB, kHB, false, X6>(imgh + (l - 1) * kHB * kHB * kBlk, h[l - 1], h[l], lane);
+#pragma unroll
+      for (int g = 0; g < kG; ++g)
+#pragma unroll
+        for (int ob = 0; ob < kHB; ++ob)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[l][g][ob][r] = fmaxf(h[l][g][ob][r], 0.f);
+    }
+    f32x4 o[kG][1];
+    {
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + NH * kWidth + 4 * q);
+#pragma unroll
+      for (int g = 0; g < kG; ++g) o[g][0] = bq;
+    }
+    apply_layer<kHB, 1, false, X6>(imgo, h[NH - 1], o, lane);
+    settle_x(xr);
+    if constexpr (SAVE) {
+#pragma unroll
+      for (int l = 0; l < NH; ++l)
+#pragma unroll
+        for (int g = 0; g < kG; ++g)
+#pragma unroll
+          for (int ob = 0; ob < kHB; ++ob)
+            __builtin_nontemporal_store(h[l][g][ob], reinterpret_cast<f32x4*>(a.H[l] + (((size_t)(g0 + g) * kHB + ob) * 64 + lane) * 4));
+    }
+#pragma unroll
+    for (int g = 0; g < kG; ++g) {
+      const int64_t n = (g0 + g) * 16 + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * q + r < a.out_dim) a.y[(size_t)(4 * q + r) * a.N + n] = o[g][0][r];
+    }
+  }
+}
+
 // ------------------------------------------------------------------- forward
 template <int KB1, bool BF16 = false, bool X6 = false>
 __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_kernel(const MlpArgs a) {  // split mode: keep two workgroups per CU (the grid is sized for that)
@@ -972,36 +1128,6 @@ __device__ __forceinline__ void accumulate_dw_regs(const float* tiles, const f32
       for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma4(av[ob][t], bv[ib][t], acc[ob][ib]);
 }
 
-// Loads whose issue point the compiler cannot move: written as source-level "prefetch into registers" the loads of
-// the next group get sunk to their first use (register pressure) and their latency is paid in full each group.
-// The compiler does not know these registers are pending, so every consumer must sit behind await_loads().
-__device__ __forceinline__ void issue_load_b128(f32x4& dst, const float* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void issue_load_b32(float& dst, const float* p) {
-  asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void issue_load_b64(f32x2& dst, const void* p) {
-  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void issue_load_u16(float& dst, const void* p) {  // zero-extended 16 bits in a 32-bit register
-  asm volatile("global_load_ushort %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void pin(f32x2& x) { asm volatile("" : "+v"(x)); }
-// four bf16 packed in two dwords -> fp32 (exact)
-__device__ __forceinline__ f32x4 unpack_bf16(const f32x2& v) {
-  const uint32_t u0 = __float_as_uint(v[0]), u1 = __float_as_uint(v[1]);
-  return f32x4{__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xFFFF0000u), __uint_as_float(u1 << 16),
-               __uint_as_float(u1 & 0xFFFF0000u)};
-}
-__device__ __forceinline__ void await_loads() {
-  __builtin_amdgcn_sched_barrier(0);  // nothing (in particular no MFMA) may be scheduled across the wait
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-// an empty volatile asm that "modifies" x: volatile asms keep their order, so a consumer of x cannot be scheduled
-// above the await_loads() that precedes this call
-__device__ __forceinline__ void pin(f32x4& x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 
 // X6: the dX chain (contraction over features, 32 at a time) runs on split-bf16 operands - see split3(); the dW waves
 // contract over the 16 samples of a group, where the split would not pay, and keep the fp32 MFMAs.
@@ -1329,6 +1455,22 @@ extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, cons
 #define NESVOR_FWD_GRID 512
 #endif
   dim3 grid((unsigned)(n_tiles < NESVOR_FWD_GRID ? n_tiles : NESVOR_FWD_GRID));
+  // software-pipelined kernel: fp32 data (both evaluation modes), fast inputs, whole tiles, one or two hidden layers
+  static const bool use_pf = []() { const char* e = getenv("NESVOR_MLP_FWD_PF"); return e == nullptr || atoi(e) != 0; }();
+  bool save_all = saved_hidden != nullptr, save_none = saved_hidden == nullptr;
+  if (use_pf && a.bf16 != 1 && a.fast && net->n_hidden <= 2 && ((N >> 4) % (4 * kG)) == 0 && (save_all || save_none)) {
+    const bool x6 = a.bf16 == 2;
+    const size_t lds = fwd_lds_bytes(a.n_linear, kb1, x6 ? 384 : 256);
+#define NESVOR_PF(NH, X6, SAVE) launch_kb(mlp_fwd_pf_kernel<1, NH, X6, SAVE>, mlp_fwd_pf_kernel<2, NH, X6, SAVE>, \
+      mlp_fwd_pf_kernel<3, NH, X6, SAVE>, mlp_fwd_pf_kernel<4, NH, X6, SAVE>, kb1, grid, lds, (hipStream_t)stream, a)
+    if (net->n_hidden == 1) {
+      if (x6) return save_all ? NESVOR_PF(1, true, true) : NESVOR_PF(1, true, false);
+      return save_all ? NESVOR_PF(1, false, true) : NESVOR_PF(1, false, false);
+    }
+    if (x6) return save_all ? NESVOR_PF(2, true, true) : NESVOR_PF(2, true, false);
+    return save_all ? NESVOR_PF(2, false, true) : NESVOR_PF(2, false, false);
+#undef NESVOR_PF
+  }
   if (a.bf16 == 2)
     return launch_kb(mlp_fwd_kernel<1, false, true>, mlp_fwd_kernel<2, false, true>, mlp_fwd_kernel<3, false, true>,
                      mlp_fwd_kernel<4, false, true>, kb1, grid, fwd_lds_bytes(a.n_linear, kb1, 384), (hipStream_t)stream, a);
