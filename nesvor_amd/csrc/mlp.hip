@@ -44,6 +44,15 @@ constexpr int kHB = kWidth / 16;  // feature blocks per hidden layer
 constexpr int kG = NESVOR_MLP_G;  // 16-sample groups per wave per tile; 2 keeps the kernels under 128 VGPRs (>= 4 waves/SIMD)
 constexpr int kMaxLayers = NESVOR_MAX_MLP_LAYERS;  // linear layers incl. the output layer
 
+// Timing experiments only (tools/mlp_variants.py; results are wrong by construction): NESVOR_MLP_ABLATE bit 1 wraps every
+// access to the saved hidden activations into the first 4096 groups (a 16 MiB window per layer that stays in L2 / MALL),
+// bit 2 does the same to the sample index of the input / output / gradient streams.
+#ifndef NESVOR_MLP_ABLATE
+#define NESVOR_MLP_ABLATE 0
+#endif
+__device__ __forceinline__ int64_t hgroup(int64_t gi) { return (NESVOR_MLP_ABLATE & 1) ? (gi & 4095) : gi; }
+__device__ __forceinline__ int64_t sgroup(int64_t gi) { return (NESVOR_MLP_ABLATE & 2) ? (gi & 4095) : gi; }
+
 struct MlpArgs {
   const float* W[kMaxLayers];   // nn.Linear weights, (out, in) row-major
   const float* b[kMaxLayers];   // biases (out)
@@ -101,6 +110,7 @@ __device__ __forceinline__ f32x4 widen_bf16(const s16x4& v) {  // four bf16 -> f
 __device__ __forceinline__ Split3 split3(const f32x4& v) {
   Split3 s;
   s.hi = pack_bf16(v);
+  if (NESVOR_MLP_ABLATE & 4) { s.mid = s.hi; s.lo = s.hi; return s; }  // timing experiment: the split's VALU work removed
   const f32x4 r1 = v - widen_bf16(s.hi);
   s.mid = pack_bf16(r1);
   s.lo = pack_bf16(r1 - widen_bf16(s.mid));
@@ -121,6 +131,7 @@ __device__ __forceinline__ f32x4 mfma32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ f32x4 mfma_split2(const Split3& a0, const Split3& a1, const Split3& b0, const Split3& b1, f32x4 c) {
   const bf16x8 ah = join8(a0.hi, a1.hi), am = join8(a0.mid, a1.mid), al = join8(a0.lo, a1.lo);
   const bf16x8 bh = join8(b0.hi, b1.hi), bm = join8(b0.mid, b1.mid), bl = join8(b0.lo, b1.lo);
+  if (NESVOR_MLP_ABLATE & 8) return mfma32_bf16(ah, bh, c);  // timing experiment: one MFMA instead of six
   c = mfma32_bf16(al, bh, c);
   c = mfma32_bf16(ah, bl, c);
   c = mfma32_bf16(am, bm, c);
@@ -194,16 +205,32 @@ __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const
       a.lo = *reinterpret_cast<const s16x4*>(pa + 2 * plane);
       return a;
     };
+    // Six MFMAs accumulate into one fragment; issued back to back they wait for one another (a dependent bf16 MFMA
+    // issues ~1.5-2x later than an independent one).  The terms are therefore walked in the outer loop and the
+    // independent accumulators (two output blocks x kG groups) in the inner one; every accumulator still receives
+    // its six terms in the same order.
 #pragma unroll
     for (int kb = 0; kb + 1 < KB; kb += 2) {
-      Split3 pb0[kG], pb1[kG];
+      bf16x8 bh[kG], bm[kG], bl[kG];
 #pragma unroll
-      for (int g = 0; g < kG; ++g) { pb0[g] = split3(x[g][kb]); pb1[g] = split3(x[g][kb + 1]); }
+      for (int g = 0; g < kG; ++g) {
+        const Split3 p0 = split3(x[g][kb]), p1 = split3(x[g][kb + 1]);
+        bh[g] = join8(p0.hi, p1.hi); bm[g] = join8(p0.mid, p1.mid); bl[g] = join8(p0.lo, p1.lo);
+      }
 #pragma unroll
-      for (int ob = 0; ob < OB; ++ob) {
-        const Split3 a0 = load_a(ob, kb), a1 = load_a(ob, kb + 1);
+      for (int ob = 0; ob < OB; ob += 2) {
+        constexpr int kPair = OB >= 2 ? 2 : 1;
+        bf16x8 ah[kPair], am[kPair], al[kPair];
 #pragma unroll
-        for (int g = 0; g < kG; ++g) y[g][ob] = mfma_split2(a0, a1, pb0[g], pb1[g], y[g][ob]);
+        for (int o = 0; o < kPair; ++o) {
+          const Split3 a0 = load_a(ob + o, kb), a1 = load_a(ob + o, kb + 1);
+          ah[o] = join8(a0.hi, a1.hi); am[o] = join8(a0.mid, a1.mid); al[o] = join8(a0.lo, a1.lo);
+        }
+#define NESVOR_TERM(A, B)                                                                       \
+  _Pragma("unroll") for (int o = 0; o < kPair; ++o)                                             \
+    _Pragma("unroll") for (int g = 0; g < kG; ++g) y[g][ob + o] = mfma32_bf16(A[o], B[g], y[g][ob + o]);
+        NESVOR_TERM(al, bh) NESVOR_TERM(ah, bl) NESVOR_TERM(am, bm) NESVOR_TERM(am, bh) NESVOR_TERM(ah, bm) NESVOR_TERM(ah, bh)
+#undef NESVOR_TERM
       }
     }
     if constexpr (KB % 2 == 1) {
@@ -277,11 +304,20 @@ __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, co
       a.lo = *reinterpret_cast<const s16x4*>(pa + 2 * plane);
       return a;
     };
+    // term-major over the OB independent accumulators (see apply_layer)
 #pragma unroll
     for (int kb = 0; kb + 1 < KB; kb += 2) {
-      const Split3 pb0 = split3(x[kb]), pb1 = split3(x[kb + 1]);
+      const Split3 p0 = split3(x[kb]), p1 = split3(x[kb + 1]);
+      const bf16x8 bh = join8(p0.hi, p1.hi), bm = join8(p0.mid, p1.mid), bl = join8(p0.lo, p1.lo);
+      bf16x8 ah[OB], am[OB], al[OB];
 #pragma unroll
-      for (int ob = 0; ob < OB; ++ob) y[ob] = mfma_split2(load_a(ob, kb), load_a(ob, kb + 1), pb0, pb1, y[ob]);
+      for (int ob = 0; ob < OB; ++ob) {
+        const Split3 a0 = load_a(ob, kb), a1 = load_a(ob, kb + 1);
+        ah[ob] = join8(a0.hi, a1.hi); am[ob] = join8(a0.mid, a1.mid); al[ob] = join8(a0.lo, a1.lo);
+      }
+#define NESVOR_TERM(A, B) _Pragma("unroll") for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_bf16(A[ob], B, y[ob]);
+      NESVOR_TERM(al, bh) NESVOR_TERM(ah, bl) NESVOR_TERM(am, bm) NESVOR_TERM(am, bh) NESVOR_TERM(ah, bm) NESVOR_TERM(ah, bh)
+#undef NESVOR_TERM
     }
     if constexpr (KB % 2 == 1) {
       const Split3 pb = split3(x[KB - 1]);
@@ -335,7 +371,7 @@ __device__ __forceinline__ float fetch_input(const MlpArgs& a, int kk, int64_t n
 template <int KB1>
 __device__ __forceinline__ void load_x_fast(const MlpArgs& a, int64_t gi, int j, int q, f32x4 (&x)[KB1]) {
   const int ka_blocks = a.k_a >> 4;
-  const int64_t n = gi * 16 + j;
+  const int64_t n = sgroup(gi) * 16 + j;
 #pragma unroll
   for (int kb = 0; kb < KB1; ++kb) {
     if (kb < ka_blocks) {
@@ -355,7 +391,7 @@ __device__ __forceinline__ void load_x_fast(const MlpArgs& a, int64_t gi, int j,
 template <int KB1>
 __device__ __forceinline__ void store_dx_fast(const MlpArgs& a, int64_t gi, int j, int q, const f32x4 (&dx)[KB1]) {
   const int ka_blocks = a.k_a >> 4;
-  const int64_t n = gi * 16 + j;
+  const int64_t n = sgroup(gi) * 16 + j;
 #pragma unroll
   for (int kb = 0; kb < KB1; ++kb) {
     if (kb < ka_blocks) {
@@ -378,7 +414,7 @@ __device__ __forceinline__ void store_dx_fast(const MlpArgs& a, int64_t gi, int 
   }
 }
 __device__ __forceinline__ f32x4 load_dy_fast(const MlpArgs& a, int64_t gi, int j, int q) {
-  const int64_t n = gi * 16 + j;
+  const int64_t n = sgroup(gi) * 16 + j;
   f32x4 g;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -455,7 +491,7 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_pf_kern
     const int64_t g0 = (tile * 4 + wave) * kG;
 #pragma unroll
     for (int g = 0; g < kG; ++g) {
-      const int64_t gi = g0 + g, n = gi * 16 + j;
+      const int64_t gi = g0 + g, n = sgroup(gi) * 16 + j;
       const int64_t pixel = a.spg_shift >= 0 ? (gi >> a.spg_shift) : gi / (a.S >> 4);
 #pragma unroll
       for (int kb = 0; kb < KB1; ++kb) {
@@ -532,11 +568,11 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_pf_kern
         for (int g = 0; g < kG; ++g)
 #pragma unroll
           for (int ob = 0; ob < kHB; ++ob)
-            __builtin_nontemporal_store(h[l][g][ob], reinterpret_cast<f32x4*>(a.H[l] + (((size_t)(g0 + g) * kHB + ob) * 64 + lane) * 4));
+            __builtin_nontemporal_store(h[l][g][ob], reinterpret_cast<f32x4*>(a.H[l] + (((size_t)hgroup(g0 + g) * kHB + ob) * 64 + lane) * 4));
     }
 #pragma unroll
     for (int g = 0; g < kG; ++g) {
-      const int64_t n = (g0 + g) * 16 + j;
+      const int64_t n = sgroup(g0 + g) * 16 + j;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (4 * q + r < a.out_dim) a.y[(size_t)(4 * q + r) * a.N + n] = o[g][0][r];
@@ -1128,9 +1164,49 @@ __device__ __forceinline__ void accumulate_dw_regs(const float* tiles, const f32
       for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma4(av[ob][t], bv[ib][t], acc[ob][ib]);
 }
 
+// dW accumulation on the bf16 pipe at fp32 accuracy (split mode).  The contraction runs over the 16 samples of ONE
+// group, half of what v_mfma_f32_16x16x32_bf16 contracts - but the split product is a sum of six 16-sample products,
+// and the k index of the instruction may be numbered freely: k-slots 0..3 of a lane carry one term's operands and
+// slots 4..7 another's, so one instruction evaluates TWO terms,
+//     (a_lo | a_hi) . (b_hi | b_lo)  =  a_lo b_hi + a_hi b_lo
+//     (a_mid| a_mid). (b_mid| b_hi)  =  a_mid b_mid + a_mid b_hi
+//     (a_hi | a_hi) . (b_mid| b_hi)  =  a_hi b_mid + a_hi b_hi
+// three instructions (48 matrix-pipe cycles) per 16x16x16 block product instead of four v_mfma_f32_16x16x4_f32 (128
+// cycles during which the SIMD issues no VALU work at all), smallest terms first.  The operands are split here: the A
+// tiles come out of LDS as fp32 (the bias gradient needs them anyway), the B operands are the prefetched fp32 registers.
+template <int OB, int IB>
+__device__ __forceinline__ void accumulate_dw_split(const float* tiles, const f32x4 (&bv)[IB], f32x4 (&acc)[OB][IB],
+                                                    float (&db)[OB], int i, int q) {
+  bf16x8 b_hl[IB], b_mh[IB];
+#pragma unroll
+  for (int ib = 0; ib < IB; ++ib) {
+    const Split3 sb = split3(bv[ib]);
+    b_hl[ib] = join8(sb.hi, sb.lo);
+    b_mh[ib] = join8(sb.mid, sb.hi);
+  }
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob) {
+    float av[4];
+    read_operand(tiles + ob * kTileFloats, i, q, av);
+    db[ob] += (av[0] + av[1]) + (av[2] + av[3]);
+    const Split3 sa = split3(f32x4{av[0], av[1], av[2], av[3]});
+    const bf16x8 a_lh = join8(sa.lo, sa.hi), a_mm = join8(sa.mid, sa.mid), a_hh = join8(sa.hi, sa.hi);
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma32_bf16(a_lh, b_hl[ib], acc[ob][ib]);
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma32_bf16(a_mm, b_mh[ib], acc[ob][ib]);
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma32_bf16(a_hh, b_mh[ib], acc[ob][ib]);
+  }
+}
+
 
 // X6: the dX chain (contraction over features, 32 at a time) runs on split-bf16 operands - see split3(); the dW waves
 // contract over the 16 samples of a group, where the split would not pay, and keep the fp32 MFMAs.
+#ifndef NESVOR_MLP_SPLIT_DW
+#define NESVOR_MLP_SPLIT_DW 1
+#endif
+constexpr bool kSplitDw = NESVOR_MLP_SPLIT_DW != 0;  // 0: the dW products of the split mode stay on v_mfma_f32_16x16x4_f32 (A/B builds)
 template <int KB1, int NH, bool BF16 = false, bool X6 = false>
 __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1166,14 +1242,14 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     // saved activations: fp32 fragments (16 B per lane) or, in the bf16 mode, bf16 fragments (8 B per lane)
     using RawH = typename std::conditional<BF16, f32x2, f32x4>::type;
     auto issue_group = [&](int64_t gi, float (&gy)[4], RawH (&hs)[NH][kHB]) {
-      const int64_t n = gi * 16 + j;
+      const int64_t n = sgroup(gi) * 16 + j;
 #pragma unroll
       for (int r = 0; r < 4; ++r) issue_load_b32(gy[r], a.y + (size_t)min(4 * q + r, a.out_dim - 1) * a.N + n);
 #pragma unroll
       for (int l = 0; l < NH; ++l)
 #pragma unroll
         for (int ib = 0; ib < kHB; ++ib) {
-          const size_t e = (((size_t)gi * kHB + ib) * 64 + lane) * 4;
+          const size_t e = (((size_t)hgroup(gi) * kHB + ib) * 64 + lane) * 4;
           if constexpr (BF16) issue_load_b64(hs[l][ib], reinterpret_cast<const __bf16*>(a.H[l]) + e);
           else issue_load_b128(hs[l][ib], a.H[l] + e);
         }
@@ -1275,7 +1351,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
       for (int l = 0; l < NH; ++l)
 #pragma unroll
         for (int ib = 0; ib < kHB; ++ib) {
-          const size_t e = (((size_t)gi * kHB + ib) * 64 + (j >> 2) * 16 + 4 * q) * 4 + (j & 3);
+          const size_t e = (((size_t)hgroup(gi) * kHB + ib) * 64 + (j >> 2) * 16 + 4 * q) * 4 + (j & 3);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             if constexpr (BF16) issue_load_u16(hraw[l][ib][t], reinterpret_cast<const __bf16*>(a.H[l]) + e + 4 * t);
@@ -1291,7 +1367,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         const int row = is_a ? 0 : min(16 * (kb - ka_blocks) + j, a.k_b - 1);
         const float* pa = is_a ? a.xa + (size_t)pixel * a.k_a + 16 * kb + j : a.xb + (size_t)a.b_row0 * a.N;
         issue_load_b32(xsraw[kb], pa);
-        issue_load_b128(xraw[kb], a.xb + (size_t)(a.b_row0 + row) * a.N + gi * 16 + 4 * q);
+        issue_load_b128(xraw[kb], a.xb + (size_t)(a.b_row0 + row) * a.N + sgroup(gi) * 16 + 4 * q);
       }
     };
     auto settle_b = [&](float (&hraw)[NH][kHB][4], f32x4 (&xraw)[KB1], float (&xsraw)[KB1]) {
@@ -1339,12 +1415,22 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         }
         issue_b(min(gi + gstride, n_groups - 1), hraw, xraw, xsraw);  // one group ahead (see the chain waves)
         const float* buf = my_tiles + ((it - 1) & 1) * kT * kTileFloats;
-        accumulate_dw_regs<1, kHB, BF16>(buf, hb[NH - 1], acc_o, db_o, j, q);
+        if constexpr (X6 && kSplitDw) {
+          accumulate_dw_split<1, kHB>(buf, hb[NH - 1], acc_o, db_o, j, q);
 #pragma unroll
-        for (int l = NH - 1; l >= 0; --l) {
-          const float* dt = buf + (1 + (NH - 1 - l) * kHB) * kTileFloats;
-          if (l > 0) accumulate_dw_regs<kHB, kHB, BF16>(dt, hb[l - 1], acc_h[l - 1], db_h[l - 1], j, q);
-          else accumulate_dw_regs<kHB, KB1, BF16>(dt, xb_, acc_1, db_1, j, q);
+          for (int l = NH - 1; l >= 0; --l) {
+            const float* dt = buf + (1 + (NH - 1 - l) * kHB) * kTileFloats;
+            if (l > 0) accumulate_dw_split<kHB, kHB>(dt, hb[l - 1], acc_h[l - 1], db_h[l - 1], j, q);
+            else accumulate_dw_split<kHB, KB1>(dt, xb_, acc_1, db_1, j, q);
+          }
+        } else {
+          accumulate_dw_regs<1, kHB, BF16>(buf, hb[NH - 1], acc_o, db_o, j, q);
+#pragma unroll
+          for (int l = NH - 1; l >= 0; --l) {
+            const float* dt = buf + (1 + (NH - 1 - l) * kHB) * kTileFloats;
+            if (l > 0) accumulate_dw_regs<kHB, kHB, BF16>(dt, hb[l - 1], acc_h[l - 1], db_h[l - 1], j, q);
+            else accumulate_dw_regs<kHB, KB1, BF16>(dt, xb_, acc_1, db_1, j, q);
+          }
         }
         settle_b(hraw, xraw, xsraw);
       }
