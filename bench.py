@@ -376,8 +376,9 @@ def main():
                 fp32_mfma, bf16_mfma = 0, 2 * bp
             elif opt.mlp_fp32_mfma:  # four 4-k fp32 MFMAs per block product and role
                 fp32_mfma, bf16_mfma = 8 * bp, 0
-            else:             # default: dW on the fp32 pipe, the dX chain as six 32-k bf16 MFMAs per pair of block products
-                fp32_mfma, bf16_mfma = 4 * bp, 3 * bp
+            else:             # default (split): three 32-k bf16 MFMAs per block product for dW (two split terms per instruction) and
+                              # per block product of the dX chain (six per pair), six 16-k ones for the chain's unpaired output-layer blocks
+                fp32_mfma, bf16_mfma = 0, 6 * bp + 2 * 3 * (W // 16)
             busy = lambda n, cyc: n * cyc * groups / n_simd / (ms2 * 1e-3 * clock_hz)
             fl = 2 * n_points * sum(i * o for d in (dens, sig) for i, o in zip(d[:-1], d[1:]))  # one forward of both nets
             roof_mlp = {"bound": "mfma", "kernel": "mlp_bwd_ws (density_net + sigma_net launches)", "launch_ms": ms2,
@@ -386,9 +387,10 @@ def main():
                         "mfma_per_16_sample_group": {"fp32_16x16x4": fp32_mfma, "bf16": bf16_mfma},
                         "engine_clock_MHz": clock_hz / 1e6, "fp32_equivalent_TFLOPs": 2 * fl / (ms2 * 1e-3) / 1e12,
                         "note": "busy fractions = MFMA issue cycles per SIMD / (launch time x engine clock): an upper-clock estimate "
-                                "(the counters of profiles/r01_pmc_sq_mlp_split_pass*.csv measure 50 % for the default mode); the "
-                                "kernel runs two waves per SIMD and is bound by what sits between the MFMAs (operand splitting on "
-                                "the VALU, LDS tile traffic, the saved-activation stream), see DESIGN.md"}
+                                "(profiles/r02_pmc_sq_mlp_summary.txt: SQ_VALU_MFMA_BUSY_CYCLES = 33 % and VALU issue = 53 % of the "
+                                "kernel's SIMD time, 23 % of the MFMA time overlapped with VALU work); the kernel runs two waves per "
+                                "SIMD and is issue-bound on operand splitting (VALU) plus MFMAs, not on the activation streams "
+                                "(profiles/r02_mlp_ablation.log), see DESIGN.md"}
         out = {
             "metric": "INR train iters/sec (2^20 samples, L=16 hash, 64-wide MLP)",
             "value": iters_per_s,

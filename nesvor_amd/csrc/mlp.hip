@@ -46,7 +46,7 @@ constexpr int kMaxLayers = NESVOR_MAX_MLP_LAYERS;  // linear layers incl. the ou
 
 // Timing experiments only (tools/mlp_variants.py; results are wrong by construction): NESVOR_MLP_ABLATE bit 1 wraps every
 // access to the saved hidden activations into the first 4096 groups (a 16 MiB window per layer that stays in L2 / MALL),
-// bit 2 does the same to the sample index of the input / output / gradient streams.
+// bit 2 does the same to the sample index of the input / output / gradient streams, bit 4 removes the VALU work of split3().
 #ifndef NESVOR_MLP_ABLATE
 #define NESVOR_MLP_ABLATE 0
 #endif
@@ -131,7 +131,6 @@ __device__ __forceinline__ f32x4 mfma32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ f32x4 mfma_split2(const Split3& a0, const Split3& a1, const Split3& b0, const Split3& b1, f32x4 c) {
   const bf16x8 ah = join8(a0.hi, a1.hi), am = join8(a0.mid, a1.mid), al = join8(a0.lo, a1.lo);
   const bf16x8 bh = join8(b0.hi, b1.hi), bm = join8(b0.mid, b1.mid), bl = join8(b0.lo, b1.lo);
-  if (NESVOR_MLP_ABLATE & 8) return mfma32_bf16(ah, bh, c);  // timing experiment: one MFMA instead of six
   c = mfma32_bf16(al, bh, c);
   c = mfma32_bf16(ah, bl, c);
   c = mfma32_bf16(am, bm, c);
