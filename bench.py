@@ -191,7 +191,8 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the native ops have no CPU path)")
     if rank == 0:
         ge.build()
-    if world > 1:
+    parallel = ddp.active()  # more than one rank, or NESVOR_DDP_FORCE=1 (the exchange on in a group of one: RCCL smoke on a 1-GPU box)
+    if parallel:
         torch.distributed.barrier()
     device = ddp.local_device(local_rank)
     torch.cuda.set_device(device)
@@ -213,8 +214,8 @@ def main():
     ds = Dataset(slices, args)
     model = NeSVoR(ds.transformation, ds.resolution, ds.mean, ds.bounding_box, args)
     L = model.inr.n_levels
-    trainer = FusedTrainer(model, args, world_size=world)
-    if world > 1:
+    trainer = FusedTrainer(model, args, world_size=world, distributed=parallel)
+    if parallel:
         ddp.broadcast_params_(trainer.flat.param)
         trainer.reduce_hook = ddp.make_reduce_hook()
     torch.manual_seed(1234 + rank)  # per-rank PSF noise stream; the permutation below is rank-independent
@@ -244,7 +245,7 @@ def main():
             out = step(gb)
         sync()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if parallel:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
@@ -252,7 +253,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if parallel:
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
@@ -429,7 +430,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if parallel:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

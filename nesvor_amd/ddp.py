@@ -24,13 +24,24 @@ import torch
 import torch.distributed as dist
 
 
+def forced() -> bool:
+    """NESVOR_DDP_FORCE=1: run the data-parallel exchange even in a group of ONE rank (every collective is then the
+    identity).  Lets the production backend - "nccl" = RCCL - be exercised end to end on a 1-GPU box."""
+    return os.environ.get("NESVOR_DDP_FORCE") == "1"
+
+
+def active(group=None) -> bool:
+    """The data-parallel exchange is on: a process group exists and has more than one rank (or forced())."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or forced())
+
+
 def init_distributed(backend: Optional[str] = None):
     """Initialise from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
     Returns (rank, local_rank, world_size).  No-op single-process fallback when WORLD_SIZE is unset."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -66,7 +77,7 @@ def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[s
 def allreduce_flat_(flat_grad: torch.Tensor, group=None, n_buckets: int = 1):
     """Sum-all-reduce the flat gradient buffer in place.  Returns the list of async work handles
     (one per bucket) so the caller may overlap; call .wait() on each (or use wait_all)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not active(group):
         return []
     n = flat_grad.numel()
     n_buckets = max(1, min(n_buckets, n))
@@ -94,7 +105,7 @@ def make_reduce_hook(group=None, n_buckets: int = 1):
 
 def broadcast_params_(flat_param: torch.Tensor, src: int = 0, group=None) -> None:
     """Make every rank start from rank `src`'s parameters."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active(group):
         dist.broadcast(flat_param, src=src, group=group)
 
 

@@ -95,13 +95,16 @@ class DirectStep:
         import torch.distributed as dist
 
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        from . import ddp
+
+        self.parallel = ddp.active()
         # Data parallel: the hash-grid backward runs in two launches - the fine levels (about half of the table's bytes,
         # the END of the flat buffer) first; their all-reduce is started at once and overlaps the coarse levels' launch
         # (NESVOR_DDP_OVERLAP=0: one launch, one all-reduce after the step)
         self._early = None
         self.split_level = 0  # 0 = one launch; set by set_overlap() once a gradient all-reduce is installed
         self._split_candidate = 0
-        if self.world > 1 and os.environ.get("NESVOR_DDP_OVERLAP", "1") != "0":
+        if self.parallel and os.environ.get("NESVOR_DDP_OVERLAP", "1") != "0":
             spec = model.inr.encoding.spec
             F = spec.n_features
             total = spec.n_params // F
@@ -165,7 +168,7 @@ class DirectStep:
             bW, bB = self.b_net.weights, self.b_net.biases
             log_bias, saved_b = mlp_mod.forward_raw(bW, bB, se, pe, 0, self.kb_bias, S, True, self.bf16)  # (1, N)
             lb_mean = log_bias.mean().reshape(1)
-            if self.world > 1:  # biasReg = (mean log_bias)^2 is not a mean of per-sample terms: use the GLOBAL mean, so that
+            if self.parallel:  # biasReg = (mean log_bias)^2 is not a mean of per-sample terms: use the GLOBAL mean, so that
                 # the averaged gradients and the loss value are exactly those of the undivided batch (SURVEY.md 8e caveat 1)
                 torch.distributed.all_reduce(lb_mean)
                 lb_mean /= self.world

@@ -8,7 +8,7 @@ buffer with matching flat gradient and Adam-moment buffers, so that
 * the hash-grid backward scatters straight into the flat gradient.
 """
 from argparse import Namespace
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 
@@ -53,14 +53,15 @@ class FlatParams:
 
 
 class FusedTrainer:
-    def __init__(self, model: NeSVoR, args: Namespace, world_size: int = 1):
+    def __init__(self, model: NeSVoR, args: Namespace, world_size: int = 1, distributed: Optional[bool] = None):
         if next(model.parameters()).device.type != "cuda":
             raise RuntimeError("FusedTrainer needs the model on a HIP device (no CPU path)")
         self.model, self.args = model, args
         # optimizer-state sharding over the ranks (ddp.ShardedExchange): opt-in, args.ddp_sharded_optimizer / NESVOR_DDP_SHARDED=1
         import os
 
-        self.sharded = world_size > 1 and bool(getattr(args, "ddp_sharded_optimizer", os.environ.get("NESVOR_DDP_SHARDED") == "1"))
+        distributed = world_size > 1 if distributed is None else distributed
+        self.sharded = distributed and bool(getattr(args, "ddp_sharded_optimizer", os.environ.get("NESVOR_DDP_SHARDED") == "1"))
         self.flat = FlatParams(model, 4 * world_size if self.sharded else 4)
         self._exchange = None
         enc = model.inr.encoding

@@ -135,17 +135,18 @@ def train(slices: List[Slice], args: Namespace, on_iteration=None) -> Tuple[INR,
 
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
-    if world > 1 and not use_fused:
+    parallel = ddp.active()  # world > 1, or a forced single-rank group (ddp.forced)
+    if parallel and not use_fused:
         raise RuntimeError("data-parallel training needs the fused trainer (flat gradient buffer)")
     if use_fused:
         from .fused import FusedTrainer
 
-        trainer = FusedTrainer(model, args, world_size=world)
-        if world > 1:
+        trainer = FusedTrainer(model, args, world_size=world, distributed=parallel)
+        if parallel:
             ddp.broadcast_params_(trainer.flat.param)
             trainer.reduce_hook = ddp.make_reduce_hook()
     perm_gen = None
-    if world > 1:
+    if parallel:
         # identical batch permutations on every rank from a dedicated generator; the global stream (PSF
         # noise) becomes rank-specific
         perm_gen = torch.Generator(device=args.device)

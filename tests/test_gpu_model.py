@@ -309,12 +309,12 @@ def test_sample_volume_runs_and_matches_inr(device, golden):
     torch.testing.assert_close(v, ref)
 
 
-def _ddp_train_worker(rank, world, port, out_dir, overlap="1", backend="gloo", sharded="0"):
+def _ddp_train_worker(rank, world, port, out_dir, overlap="1", backend="gloo", sharded="0", force="0"):
     import os
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), NESVOR_DIST_BACKEND=backend, NESVOR_SINGLE_DEVICE="1" if backend == "gloo" else "0",
-                      NESVOR_DDP_OVERLAP=overlap, NESVOR_DDP_SHARDED=sharded)
+                      NESVOR_DDP_OVERLAP=overlap, NESVOR_DDP_SHARDED=sharded, NESVOR_DDP_FORCE=force)
     import torch.distributed as dist
 
     from nesvor_amd import ddp
@@ -391,6 +391,25 @@ def test_train_data_parallel_sharded_optimizer_matches_allreduce(device, tmp_pat
     for k in ref:
         assert torch.equal(a[k], b[k]), k
         torch.testing.assert_close(a[k], ref[k], rtol=2e-3, atol=2e-5, msg=k)
+
+
+def test_train_data_parallel_rccl_single_rank(device, tmp_path):
+    """Backend "nccl" (= RCCL) on the one GPU of the test box: NESVOR_DDP_FORCE=1 keeps the whole data-parallel exchange
+    on in a group of ONE rank - communicator set-up, parameter broadcast, the early all-reduce of the fine hash-grid
+    levels on RCCL's stream + the final all-reduce, and (second run) reduce-scatter -> sharded AdamW -> all-gather - where
+    every collective is the identity.  The trained model must equal the same forced single-rank run over gloo (one launch,
+    one all-reduce: the path the two-rank tests cover), up to the run-to-run variation of a training run."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_ddp_train_worker, args=(1, _free_port(), str(tmp_path), "0", "gloo", "0", "1"), nprocs=1, join=True)
+    ref = torch.load(tmp_path / "rank0_overlap0.pt")
+    assert all(torch.isfinite(v).all() for v in ref.values())
+    for sharded in ("0", "1"):
+        mp.spawn(_ddp_train_worker, args=(1, _free_port(), str(tmp_path), "1", "nccl", sharded, "1"), nprocs=1, join=True)
+        got = torch.load(tmp_path / f"rank0_overlap1{'_sharded' if sharded == '1' else ''}_nccl.pt")
+        assert got.keys() == ref.keys()
+        for k in ref:
+            torch.testing.assert_close(got[k], ref[k], rtol=2e-3, atol=2e-5, msg=k)
 
 
 def test_train_data_parallel_rccl_two_gpus(tmp_path):
