@@ -219,13 +219,16 @@ __global__ __launch_bounds__(256) void hashgrid_fwd(const nesvor_grid_t g, const
 // One workgroup = 256 consecutive samples (for S = 256: one PSF cloud), ALL levels.  The per-(cloud, level) blocks of
 // hashgrid_fwd are bound by two serialised memory latencies each (coordinates, then the box copy); here the coordinates
 // are read once, the lattice boxes of all levels follow from one bounding box, consecutive levels whose boxes fit the
-// LDS copy together share a round (levels 0-7, 8-9, 10-11, 12, 13 for the bench's clouds), and the next round's table
+// LDS copy (512 slots) together share a round (levels 0-6, 7-8, 9-10, 11 for the bench's clouds), and the next round's table
 // entries are in flight while the current round interpolates (two copies, one barrier per round).  Levels whose box
 // does not fit (the finest one or two of a cloud; almost all for unclustered points) gather from global memory.
 template <int F, int LAYOUT>
 __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g, const float* __restrict__ u,
                                                           const float* __restrict__ table, float* __restrict__ pe, int64_t N) {
-  constexpr int kSlots = F <= 2 ? 1024 : (F == 4 ? 512 : 256);
+#ifndef NESVOR_FWD_CLOUD_SLOTS
+#define NESVOR_FWD_CLOUD_SLOTS 512
+#endif
+  constexpr int kSlots = F <= 2 ? NESVOR_FWD_CLOUD_SLOTS : (F == 4 ? 512 : 256);  // slots per copy (two copies).  Measured at F = 2 (N = 2^20 cloud points): 256/512: 0.075 ms, 1024: 0.079, 2048: 0.101, 4096: 0.193 - the finer levels gather from L2 as fast as a bigger copy serves them, and the copy costs occupancy
   constexpr int kMaxGroup = 8;
   constexpr int NRB = kSlots / 256;
   __shared__ __attribute__((aligned(16))) float tcache[2][kSlots * F];
