@@ -38,6 +38,10 @@ class PsfAveragedDensity:
             raise RuntimeError("inference runs on the HIP kernels: the INR must live on a HIP device (no CPU path)")
         self.operands = mlp_mod.inference_operands(model, args)  # raises for networks the kernels do not cover
         self.net = mlp_mod.NetParams(model.density_net)
+        # only output 0 (the density logit) of the density network is used here: its other rows (the features of the
+        # variance / bias networks) are neither computed into HBM nor stored
+        self.weights = list(self.net.weights[:-1]) + [self.net.weights[-1][:1].contiguous()]
+        self.biases = list(self.net.biases[:-1]) + [self.net.biases[-1][:1].contiguous()]
 
     def _noise(self, m: int, s: int) -> torch.Tensor:
         if s <= 1:
@@ -68,7 +72,7 @@ class PsfAveragedDensity:
             which = torch.zeros(m, dtype=torch.int64, device=dev)
             _, u = sampler.forward_raw(mat, which, pts, sig, self._noise(m, s), bb)
             pe = hashgrid_forward(enc.spec, u, enc.params, _lib.LAYOUT_FEATURE_MAJOR, clustered=s >= 128)
-            z, _ = mlp_mod.forward_raw(self.net.weights, self.net.biases, None, pe, 0, pe.shape[0], s, False, self.operands)
+            z, _ = mlp_mod.forward_raw(self.weights, self.biases, None, pe, 0, pe.shape[0], s, False, self.operands)
             out[begin : begin + m] = F.softplus(z[0].view(m, s)).mean(-1)
         return out
 
