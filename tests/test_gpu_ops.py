@@ -833,16 +833,19 @@ def test_fused_mlp_bf16_operand_mode(device, k_a, k_b, b_row0, rows, out_dim):
     assert float((y_mfma - y_split).abs().max()) < 2e-6 * float(y_mfma.abs().max())
 
 
+@pytest.mark.parametrize("N", [8192, 1 << 20])
 @pytest.mark.parametrize("k_a,k_b,b_row0,rows,out_dim", [(0, 32, 0, 32, 16), (16, 15, 1, 16, 1)])
-def test_fused_mlp_split_operands_keep_fp32_accuracy(device, k_a, k_b, b_row0, rows, out_dim):
+def test_fused_mlp_split_operands_keep_fp32_accuracy(device, k_a, k_b, b_row0, rows, out_dim, N):
     """The default evaluation of the fp32 products (three-way bf16 split, six MFMAs, nesvor_mlp_t.bf16_operands == 2)
     against an fp64 evaluation of the same network: its error must not exceed that of the fp32-MFMA evaluation
-    (an fp32 FMA chain) by more than a factor 1.5 - forward output, input gradient and parameter gradients."""
+    (an fp32 FMA chain) by more than a factor 1.5 - forward output, input gradient and parameter gradients (the dW
+    products of the split mode pack two split terms per 32-k bf16 MFMA).  N = 2^20 is the bench's size: the pipelined
+    forward and the wave-specialised backward at full scale."""
     from nesvor_amd import mlp
     from nesvor_amd.models import build_network
 
     torch.manual_seed(1)
-    N, S = 8192, 256
+    S = 256
     net = build_network(n_input_dims=k_a + k_b, n_output_dims=out_dim, activation="ReLU", output_activation="None",
                         n_neurons=64, n_hidden_layers=2, dtype=torch.float32).to(device)
     L = mlp.linear_layers(net)
@@ -871,9 +874,32 @@ def test_fused_mlp_split_operands_keep_fp32_accuracy(device, k_a, k_b, b_row0, r
         _, partial = mlp.backward_raw(W, Bs, xa, xb, dy, saved, b_row0, k_b, S, dxb, xa is not None, mode)
         rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
         err[mode] = (rel(y, y_ref), rel(dxb, dxb_ref), rel(partial.double().sum(0), dW_ref))
+        if N > 100000:
+            # a million samples x 128 hidden units: a few pre-activations lie within rounding of zero and their ReLU
+            # mask differs between ANY fp32 evaluation and fp64 (both modes hit the same samples); such a sample's input
+            # gradient differs by O(1) and moves every dW entry by one sample's share (1 / sqrt(N) of its magnitude).
+            # The max norm is therefore replaced by: samples whose input gradient is off, and the error of the rest.
+            bad = ((dxb.double() - dxb_ref).abs().amax(0) > 1e-5 * dxb_ref.abs().max())
+            assert int(bad.sum()) <= 64, int(bad.sum())
+            good = ~bad
+            err[mode] = (err[mode][0], float((dxb.double() - dxb_ref)[:, good].abs().max() / dxb_ref.abs().max()),
+                         float((partial.double().sum(0) - dW_ref).norm() / dW_ref.norm()))
+            assert err[mode][2] < 2e-3
     print("max error / max|ref|  (y, dx, dW):  fp32 MFMA %s   split %s" % (err[mlp.MFMA_FP32], err[mlp.SPLIT]))
-    for e_split, e_mfma in zip(err[mlp.SPLIT], err[mlp.MFMA_FP32]):
+    for e_split, e_mfma in zip(err[mlp.SPLIT][: 3 if N <= 100000 else 2], err[mlp.MFMA_FP32]):
         assert e_split <= 1.5 * e_mfma + 1e-7
+    if N > 100000:
+        # size-independent property that pins dW at full scale: with the saved activations (= the masks) fixed the backward
+        # is linear in dY
+        dy2 = torch.randn(out_dim, N, device=device)
+        y, saved = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, True, mlp.SPLIT)
+        outs = []
+        for g in (dy, dy2, dy + dy2):
+            dxb = torch.empty(k_b, N, device=device)
+            _, partial = mlp.backward_raw(W, Bs, xa, xb, g, saved, b_row0, k_b, S, dxb, xa is not None, mlp.SPLIT)
+            outs.append((dxb.double(), partial.double().sum(0)))
+        for a_, b_, c_ in zip(outs[0], outs[1], outs[2]):
+            assert float((a_ + b_ - c_).norm() / c_.norm()) < 2e-6
 
 
 # -------------------------------------------------------------------- fused MLP
