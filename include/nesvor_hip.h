@@ -66,15 +66,16 @@ int nesvor_slice_acq_forward(const float* transforms, const float* vol, const ui
                              int D, int H, int W, int d_p, int h_p, int w_p, int n, int h, int w,
                              float res_slice, int interp_psf, void* stream);
 
-/* EXCLUSIONS of the slice-acquisition group, against the reference's kernels:
+/* Coverage of the slice-acquisition group against the reference's kernels:
  *   * interp_psf != 0 (nearest-voxel sampling with a re-interpolated PSF) exists in all four reference kernels
  *     (slice_acq_cuda_kernel.cu:72-109 forward, :229-279 and :316-366 backward, :526-572 adjoint, :754-800 adjoint
- *     backward).  Built here: forward only.  No caller in the reference tree ever passes interp_psf=True to the other
- *     three (slice_acq.py:40-160, svort/srr.py:37-128 and svort/models.py read it from params["interp_psf"], which every
- *     configuration sets to False); the host layer raises NotImplementedError for them - nothing falls back.
+ *     backward) and is built for all four: the forward through its `interp_psf` argument, the other three through the
+ *     `*_interp` entry points further down (per-pixel scatter as the reference formulates it).  No caller in the reference
+ *     tree ever switches the mode on (slice_acq.py:40-160, svort/srr.py:37-128 and svort/models.py read it from
+ *     params["interp_psf"], which every configuration sets to False).
  *   * double precision is built (the *_f64 entry points below; the reference dispatches float and double).
  *   * PSF size: any (the forward kernel keeps PSFs of up to 1024 taps as an LDS list of their non-zero taps and walks
- *     larger ones in global memory; the other three read the dense PSF array).
+ *     larger ones in global memory; the others read the dense PSF array).
  *
  * Adjoint operator A^T (+ optional equalisation) and backward of A, linear-interpolation mode.
  * Replace `nesvor.slice_acq_cuda.adjoint_forward` / `.backward`
@@ -103,6 +104,36 @@ int nesvor_slice_acq_backward(const float* transforms, const float* vol, const u
                               const float* grad_slices, const uint8_t* slices_mask, float* grad_vol,
                               float* grad_transforms, float* scratch, int D, int H, int W, int d_p, int h_p, int w_p,
                               int n, int h, int w, float res_slice, void* stream);
+/* interp_psf = true for the three operators above (slice_acq_cuda_kernel.cu:229-370, :526-606, :754-836): same argument
+ * meaning, no scratch.  The kernels ACCUMULATE (atomics): vol / vol_weight, grad_vol / grad_transforms, grad_slices /
+ * grad_transforms must be zero-filled by the caller (as the reference's host functions allocate them); any may be NULL where
+ * the operator allows it.  adjoint_forward: equalize != 0 needs vol_weight. */
+int nesvor_slice_acq_adjoint_forward_interp(const float* transforms, const float* psf, const float* slices,
+                                            const uint8_t* slices_mask, const uint8_t* vol_mask, float* vol, float* vol_weight,
+                                            int D, int H, int W, int d_p, int h_p, int w_p, int n, int h, int w,
+                                            float res_slice, int equalize, void* stream);
+int nesvor_slice_acq_backward_interp(const float* transforms, const float* vol, const uint8_t* vol_mask, const float* psf,
+                                     const float* grad_slices, const uint8_t* slices_mask, float* grad_vol,
+                                     float* grad_transforms, int D, int H, int W, int d_p, int h_p, int w_p, int n, int h, int w,
+                                     float res_slice, void* stream);
+int nesvor_slice_acq_adjoint_backward_interp(const float* transforms, float* grad_vol, const float* vol_weight,
+                                             const uint8_t* vol_mask, const float* psf, const float* slices,
+                                             const uint8_t* slices_mask, const float* vol, float* grad_slices,
+                                             float* grad_transforms, int D, int H, int W, int d_p, int h_p, int w_p, int n,
+                                             int h, int w, float res_slice, int equalize, void* stream);
+int nesvor_slice_acq_adjoint_forward_interp_f64(const double* transforms, const double* psf, const double* slices,
+                                                const uint8_t* slices_mask, const uint8_t* vol_mask, double* vol,
+                                                double* vol_weight, int D, int H, int W, int d_p, int h_p, int w_p, int n, int h,
+                                                int w, double res_slice, int equalize, void* stream);
+int nesvor_slice_acq_backward_interp_f64(const double* transforms, const double* vol, const uint8_t* vol_mask,
+                                         const double* psf, const double* grad_slices, const uint8_t* slices_mask,
+                                         double* grad_vol, double* grad_transforms, int D, int H, int W, int d_p, int h_p,
+                                         int w_p, int n, int h, int w, double res_slice, void* stream);
+int nesvor_slice_acq_adjoint_backward_interp_f64(const double* transforms, double* grad_vol, const double* vol_weight,
+                                                 const uint8_t* vol_mask, const double* psf, const double* slices,
+                                                 const uint8_t* slices_mask, const double* vol, double* grad_slices,
+                                                 double* grad_transforms, int D, int H, int W, int d_p, int h_p, int w_p,
+                                                 int n, int h, int w, double res_slice, int equalize, void* stream);
 /* double-precision variants of the four entry points (the reference dispatches float and double,
  * slice_acq_cuda_kernel.cu:970, :1010, :1046, :1114): same contracts, every float* a double*, res_slice a double. */
 int nesvor_slice_acq_forward_f64(const double* transforms, const double* vol, const uint8_t* vol_mask,

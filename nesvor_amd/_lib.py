@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NESVOR_HIP_LIB: load another build of the same ABI (tools/ablate_hashgrid.py times variants of one kernel this way)
 LIB_PATH = os.environ.get("NESVOR_HIP_LIB") or os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -80,6 +80,13 @@ _SIGNATURES = {
     "nesvor_slice_acq_adjoint_forward_f64": ([_P] * 8 + [c_int] * 9 + [c_double, c_int, _P], c_int),
     "nesvor_slice_acq_backward_f64": ([_P] * 9 + [c_int] * 9 + [c_double, _P], c_int),
     "nesvor_slice_acq_adjoint_backward_f64": ([_P] * 10 + [c_int] * 9 + [c_double, c_int, _P], c_int),
+    # interp_psf = true (no scratch; outputs zero-filled by the caller)
+    "nesvor_slice_acq_adjoint_forward_interp": ([_P] * 7 + [c_int] * 9 + [c_float, c_int, _P], c_int),
+    "nesvor_slice_acq_backward_interp": ([_P] * 8 + [c_int] * 9 + [c_float, _P], c_int),
+    "nesvor_slice_acq_adjoint_backward_interp": ([_P] * 10 + [c_int] * 9 + [c_float, c_int, _P], c_int),
+    "nesvor_slice_acq_adjoint_forward_interp_f64": ([_P] * 7 + [c_int] * 9 + [c_double, c_int, _P], c_int),
+    "nesvor_slice_acq_backward_interp_f64": ([_P] * 8 + [c_int] * 9 + [c_double, _P], c_int),
+    "nesvor_slice_acq_adjoint_backward_interp_f64": ([_P] * 10 + [c_int] * 9 + [c_double, c_int, _P], c_int),
     "nesvor_hashgrid_forward": ([POINTER(GridT), _P, _P, _P, c_int64, c_int, _P], c_int),
     "nesvor_hashgrid_backward_workspace_bytes": ([POINTER(GridT), c_int64, _P], c_int64),
     "nesvor_hashgrid_backward_workspace_zero_bytes": ([], c_int64),

@@ -490,6 +490,269 @@ int slice_acq_backward_impl(const T* transforms, const T* vol, const uint8_t* vo
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------ interp_psf mode of A^T and of both backwards
+// `interp_psf = true` (nearest voxel + the PSF re-interpolated at the voxel's offset from the pixel centre) exists in all
+// four reference kernels (slice_acq_cuda_kernel.cu:71-109 forward, :229-257 / :279-370 backward, :526-572 / :582-606
+// adjoint, :754-836 adjoint backward), and no caller of the reference ever switches it on.  It is built here for
+// completeness of the module, one thread per slice pixel exactly as the reference formulates it; the scatters are
+// global atomics (memory-side on MI355X, ~16 G/s: fine for a mode nothing iterates on - the linear mode above is the
+// one that was re-formulated as a gather).
+template <typename T> struct InterpTap { int iv, xr, yr, zr; T pw, gx, gy, gz; };
+
+// One PSF tap at (x, y, z) already known to lie inside the volume.  false: the rounded voxel's offset falls outside the
+// PSF support.  GRAD: also d pw / d (x_psf, y_psf, z_psf), the corner sums of the reference (.cu:311-352).
+template <typename T, bool GRAD>
+__device__ __forceinline__ bool interp_tap(const T* __restrict__ t, const PixelGeom<T>& g, const T* __restrict__ psf, int d_p,
+                                           int h_p, int w_p, T x, T y, T z, int Sy, int Sz, InterpTap<T>& o) {
+  o.xr = (int)floor(x + (T)0.5); o.yr = (int)floor(y + (T)0.5); o.zr = (int)floor(z + (T)0.5);
+  o.iv = o.zr * Sz + o.yr * Sy + o.xr;
+  const T dx = o.xr - g.xc, dy = o.yr - g.yc, dz = o.zr - g.zc;
+  const T xp = t[0] * dx + t[4] * dy + t[8] * dz + (w_p - 1) / (T)2.0;
+  const T yp = t[1] * dx + t[5] * dy + t[9] * dz + (h_p - 1) / (T)2.0;
+  const T zp = t[2] * dx + t[6] * dy + t[10] * dz + (d_p - 1) / (T)2.0;
+  if (xp < 0 || yp < 0 || zp < 0 || xp >= w_p - 1 || yp >= h_p - 1 || zp >= d_p - 1) return false;
+  const int xf = (int)floor(xp), yf = (int)floor(yp), zf = (int)floor(zp);
+  const T wx = xp - xf, wy = yp - yf, wz = zp - zf;
+  const T* p0 = psf + (zf * h_p + yf) * w_p + xf;
+  const int py = w_p, pz = w_p * h_p;
+  const T c000 = p0[0], c100 = p0[1], c010 = p0[py], c001 = p0[pz], c110 = p0[1 + py], c101 = p0[1 + pz], c011 = p0[py + pz],
+          c111 = p0[1 + py + pz];
+  T pw = (T)0.0;  // corner order of the reference: 000, 100, 010, 001, 110, 101, 011, 111
+  pw += (1 - wx) * (1 - wy) * (1 - wz) * c000;
+  pw += wx * (1 - wy) * (1 - wz) * c100;
+  pw += (1 - wx) * wy * (1 - wz) * c010;
+  pw += (1 - wx) * (1 - wy) * wz * c001;
+  pw += wx * wy * (1 - wz) * c110;
+  pw += wx * (1 - wy) * wz * c101;
+  pw += (1 - wx) * wy * wz * c011;
+  pw += wx * wy * wz * c111;
+  o.pw = pw;
+  if constexpr (GRAD) {
+    T gx = (T)0.0, gy = (T)0.0, gz = (T)0.0;
+    gx -= (1 - wy) * (1 - wz) * c000; gy -= (1 - wx) * (1 - wz) * c000; gz -= (1 - wx) * (1 - wy) * c000;
+    gx += (1 - wy) * (1 - wz) * c100; gy -= wx * (1 - wz) * c100;       gz -= wx * (1 - wy) * c100;
+    gx -= wy * (1 - wz) * c010;       gy += (1 - wx) * (1 - wz) * c010; gz -= (1 - wx) * wy * c010;
+    gx -= (1 - wy) * wz * c001;       gy -= (1 - wx) * wz * c001;       gz += (1 - wx) * (1 - wy) * c001;
+    gx += wy * (1 - wz) * c110;       gy += wx * (1 - wz) * c110;       gz -= wx * wy * c110;
+    gx += (1 - wy) * wz * c101;       gy -= wx * wz * c101;             gz += wx * (1 - wy) * c101;
+    gx -= wy * wz * c011;             gy += (1 - wx) * wz * c011;       gz += (1 - wx) * wy * c011;
+    gx += wy * wz * c111;             gy += wx * wz * c111;             gz += wx * wy * c111;
+    o.gx = gx; o.gy = gy; o.gz = gz;
+  }
+  return true;
+}
+
+// the taps of a pixel: body(tap) for every non-zero PSF tap whose position lies inside the volume and whose rounded voxel
+// lies inside the PSF support
+template <typename T, bool GRAD, typename Body>
+__device__ __forceinline__ void for_interp_taps(const T* __restrict__ t, const PixelGeom<T>& g, const T* __restrict__ psf, int d_p,
+                                                int h_p, int w_p, int D, int H, int W, Body body) {
+  const int Sy = W, Sz = H * W;
+  int ip = 0;
+  for (int iz = -d_p / 2; iz < (d_p + 1) / 2; ++iz)
+    for (int iyp = -h_p / 2; iyp < (h_p + 1) / 2; ++iyp)
+      for (int ixp = -w_p / 2; ixp < (w_p + 1) / 2; ++ixp, ++ip) {
+        if (psf[ip] == (T)0.0) continue;
+        const T x = g.xc + t[0] * ixp + t[1] * iyp + t[2] * iz;
+        const T y = g.yc + t[4] * ixp + t[5] * iyp + t[6] * iz;
+        const T z = g.zc + t[8] * ixp + t[9] * iyp + t[10] * iz;
+        if (x < 0 || y < 0 || z < 0 || x >= W - 1 || y >= H - 1 || z >= D - 1) continue;
+        InterpTap<T> tap;
+        if (!interp_tap<T, GRAD>(t, g, psf, d_p, h_p, w_p, x, y, z, Sy, Sz, tap)) continue;
+        body(tap);
+      }
+}
+
+// the 12 pose sums of a pixel -> grad_transforms of its slice (wave reduction, one atomic per wave and entry)
+template <typename T>
+__device__ __forceinline__ void add_pose_grad(T* __restrict__ grad_transforms, int in, const T (&gt)[12], bool uniform_slice) {
+  if (uniform_slice) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const T s = wave_sum_any(gt[k]);
+      if ((threadIdx.x & 63) == 0 && s != (T)0.0) atomicAdd(grad_transforms + (size_t)in * 12 + k, s);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+      if (gt[k] != (T)0.0) atomicAdd(grad_transforms + (size_t)in * 12 + k, gt[k]);
+  }
+}
+
+// backward of A (.cu:173-470, interp branch): grad_vol[voxel] += pw gs,  grad_transforms from d pw / d pose
+template <typename T>
+__global__ __launch_bounds__(256) void slice_acq_bwd_interp(const T* __restrict__ transforms, const T* __restrict__ vol,
+                                                            const uint8_t* __restrict__ vol_mask, const T* __restrict__ psf,
+                                                            const T* __restrict__ grad_slices, const uint8_t* __restrict__ slices_mask,
+                                                            T* __restrict__ grad_vol, T* __restrict__ grad_transforms, int D, int H,
+                                                            int W, int d_p, int h_p, int w_p, int n, int h, int w, T res_slice) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)n * h * w;
+  const int64_t cidx = idx < total ? idx : total - 1;
+  const int ix = cidx % w, iy = (cidx / w) % h, in = cidx / ((int64_t)h * w);
+  const T* t = transforms + (size_t)in * 12;
+  T gt[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) gt[k] = (T)0.0;
+  T gs = idx < total && (slices_mask == nullptr || slices_mask[idx]) ? grad_slices[idx] : (T)0.0;
+  if (gs != (T)0.0) {
+    const PixelGeom<T> g = pixel_geom(t, ix, iy, h, w, res_slice, D, H, W);
+    T weight = (T)0.0;  // pass 1: no vol_mask here (.cu:229-257)
+    for_interp_taps<T, false>(t, g, psf, d_p, h_p, w_p, D, H, W, [&](const InterpTap<T>& tap) { weight += tap.pw; });
+    if (weight != (T)0.0) {
+      gs /= weight;
+      const T cx = (W - 1) / (T)2.0, cy = (H - 1) / (T)2.0, cz = (D - 1) / (T)2.0;
+      for_interp_taps<T, true>(t, g, psf, d_p, h_p, w_p, D, H, W, [&](const InterpTap<T>& tap) {
+        if (vol_mask != nullptr && !vol_mask[tap.iv]) return;
+        if (grad_vol != nullptr) atomicAdd(grad_vol + tap.iv, tap.pw * gs);
+        if (grad_transforms != nullptr) {
+          const T tmp = gs * vol[tap.iv];
+          const T dx = tap.gx * tmp, dy = tap.gy * tmp, dz = tap.gz * tmp;
+          gt[0] += dx * (tap.xr - cx); gt[1] += dy * (tap.xr - cx); gt[2] += dz * (tap.xr - cx); gt[3] -= dx;
+          gt[4] += dx * (tap.yr - cy); gt[5] += dy * (tap.yr - cy); gt[6] += dz * (tap.yr - cy); gt[7] -= dy;
+          gt[8] += dx * (tap.zr - cz); gt[9] += dy * (tap.zr - cz); gt[10] += dz * (tap.zr - cz); gt[11] -= dz;
+        }
+      });
+    }
+  }
+  if (grad_transforms != nullptr) {
+    // a wave lies in one slice iff its first and last pixel do (then one atomic per wave instead of 64)
+    const int64_t first = idx - (threadIdx.x & 63), last = first + 63;
+    const bool uniform = last < total && first / ((int64_t)h * w) == last / ((int64_t)h * w);
+    add_pose_grad(grad_transforms, in, gt, uniform);
+  }
+}
+
+// A^T (.cu:472-670, interp branch): vol[voxel] += pw / weight s, vol_weight[voxel] += pw / weight for weight >= 0.5
+template <typename T>
+__global__ __launch_bounds__(256) void slice_acq_adjoint_interp(const T* __restrict__ transforms, const T* __restrict__ psf,
+                                                                const T* __restrict__ slices, const uint8_t* __restrict__ slices_mask,
+                                                                const uint8_t* __restrict__ vol_mask, T* __restrict__ vol,
+                                                                T* __restrict__ vol_weight, int D, int H, int W, int d_p, int h_p,
+                                                                int w_p, int n, int h, int w, T res_slice) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n * h * w) return;
+  if (slices_mask != nullptr && !slices_mask[idx]) return;
+  const T s = slices[idx];
+  const int ix = idx % w, iy = (idx / w) % h, in = idx / ((int64_t)h * w);
+  const T* t = transforms + (size_t)in * 12;
+  const PixelGeom<T> g = pixel_geom(t, ix, iy, h, w, res_slice, D, H, W);
+  T weight = (T)0.0;
+  for_interp_taps<T, false>(t, g, psf, d_p, h_p, w_p, D, H, W, [&](const InterpTap<T>& tap) { weight += tap.pw; });
+  if (weight < (T)0.5) return;  // border
+  for_interp_taps<T, false>(t, g, psf, d_p, h_p, w_p, D, H, W, [&](const InterpTap<T>& tap) {
+    if (vol_mask != nullptr && !vol_mask[tap.iv]) return;
+    const T pn = tap.pw / weight;
+    atomicAdd(vol + tap.iv, pn * s);
+    if (vol_weight != nullptr) atomicAdd(vol_weight + tap.iv, pn);
+  });
+}
+
+template <typename T>
+__global__ void slice_acq_equalize_vol(T* __restrict__ vol, const T* __restrict__ vol_weight, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && vol_weight[i] > (T)0.0) vol[i] /= vol_weight[i];
+}
+
+// backward of A^T (.cu:695-950, interp branch): grad_slices = sum pw g[voxel] / sum pw,  pose gradient from d pw / d pose
+template <typename T>
+__global__ __launch_bounds__(256) void slice_acq_adjoint_bwd_interp(const T* __restrict__ transforms, const T* __restrict__ grad_vol,
+                                                                    const T* __restrict__ psf, const T* __restrict__ slices,
+                                                                    const uint8_t* __restrict__ slices_mask, const T* __restrict__ vol,
+                                                                    const uint8_t* __restrict__ vol_mask, T* __restrict__ grad_slices,
+                                                                    T* __restrict__ grad_transforms, int D, int H, int W, int d_p,
+                                                                    int h_p, int w_p, int n, int h, int w, T res_slice) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)n * h * w;
+  const int64_t cidx = idx < total ? idx : total - 1;
+  const int ix = cidx % w, iy = (cidx / w) % h, in = cidx / ((int64_t)h * w);
+  const T* t = transforms + (size_t)in * 12;
+  T gt[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) gt[k] = (T)0.0;
+  if (idx < total && (slices_mask == nullptr || slices_mask[idx])) {
+    const PixelGeom<T> g = pixel_geom(t, ix, iy, h, w, res_slice, D, H, W);
+    const T sv = slices[idx];
+    const T cx = (W - 1) / (T)2.0, cy = (H - 1) / (T)2.0, cz = (D - 1) / (T)2.0;
+    T val = (T)0.0, weight = (T)0.0;
+    T acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = (T)0.0;
+    // the reference tests the voxel mask before the PSF support; both only skip the tap, the order does not matter
+    for_interp_taps<T, true>(t, g, psf, d_p, h_p, w_p, D, H, W, [&](const InterpTap<T>& tap) {
+      if (vol_mask != nullptr && !vol_mask[tap.iv]) return;
+      const T gv = grad_vol[tap.iv];
+      if (grad_transforms != nullptr) {
+        const T s = (vol == nullptr ? sv : sv - vol[tap.iv]) * gv;
+        const T dx = tap.gx * s, dy = tap.gy * s, dz = tap.gz * s;
+        acc[0] += dx * (tap.xr - cx); acc[1] += dy * (tap.xr - cx); acc[2] += dz * (tap.xr - cx); acc[3] -= dx;
+        acc[4] += dx * (tap.yr - cy); acc[5] += dy * (tap.yr - cy); acc[6] += dz * (tap.yr - cy); acc[7] -= dy;
+        acc[8] += dx * (tap.zr - cz); acc[9] += dy * (tap.zr - cz); acc[10] += dz * (tap.zr - cz); acc[11] -= dz;
+      }
+      val += tap.pw * gv;
+      weight += tap.pw;
+    });
+    if (weight > (T)0.0) {
+      if (grad_slices != nullptr) grad_slices[idx] = val / weight;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) gt[k] = acc[k] / weight;
+    }
+  }
+  if (grad_transforms != nullptr) {
+    const int64_t first = idx - (threadIdx.x & 63), last = first + 63;
+    const bool uniform = last < total && first / ((int64_t)h * w) == last / ((int64_t)h * w);
+    add_pose_grad(grad_transforms, in, gt, uniform);
+  }
+}
+
+// host side of the interp_psf mode.  Outputs are accumulated into: the callers pass zero-filled vol / vol_weight /
+// grad_vol / grad_transforms / grad_slices (as the reference's host functions allocate them, .cu:1000-1120)
+template <typename T>
+int slice_acq_backward_interp_impl(const T* transforms, const T* vol, const uint8_t* vol_mask, const T* psf, const T* grad_slices,
+                                   const uint8_t* slices_mask, T* grad_vol, T* grad_transforms, int D, int H, int W, int d_p,
+                                   int h_p, int w_p, int n, int h, int w, T res_slice, void* stream) {
+  const int64_t np = (int64_t)n * h * w;
+  if (np <= 0 || (int64_t)D * H * W <= 0) return 0;
+  if (d_p < 2 || h_p < 2 || w_p < 2) return 0;  // no interior cell in the PSF: every tap is skipped
+  hipLaunchKernelGGL(slice_acq_bwd_interp<T>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, (hipStream_t)stream, transforms, vol,
+                     vol_mask, psf, grad_slices, slices_mask, grad_vol, grad_transforms, D, H, W, d_p, h_p, w_p, n, h, w, res_slice);
+  return (int)hipGetLastError();
+}
+template <typename T>
+int slice_acq_adjoint_forward_interp_impl(const T* transforms, const T* psf, const T* slices, const uint8_t* slices_mask,
+                                          const uint8_t* vol_mask, T* vol, T* vol_weight, int D, int H, int W, int d_p, int h_p,
+                                          int w_p, int n, int h, int w, T res_slice, int equalize, void* stream) {
+  const int64_t np = (int64_t)n * h * w, nv = (int64_t)D * H * W;
+  if (np <= 0 || nv <= 0) return 0;
+  if (equalize && vol_weight == nullptr) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  if (d_p >= 2 && h_p >= 2 && w_p >= 2)
+    hipLaunchKernelGGL(slice_acq_adjoint_interp<T>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, transforms, psf, slices,
+                       slices_mask, vol_mask, vol, vol_weight, D, H, W, d_p, h_p, w_p, n, h, w, res_slice);
+  if (equalize)
+    hipLaunchKernelGGL(slice_acq_equalize_vol<T>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, vol, (const T*)vol_weight, nv);
+  return (int)hipGetLastError();
+}
+template <typename T>
+int slice_acq_adjoint_backward_interp_impl(const T* transforms, T* grad_vol, const T* vol_weight, const uint8_t* vol_mask,
+                                           const T* psf, const T* slices, const uint8_t* slices_mask, const T* vol, T* grad_slices,
+                                           T* grad_transforms, int D, int H, int W, int d_p, int h_p, int w_p, int n, int h, int w,
+                                           T res_slice, int equalize, void* stream) {
+  const int64_t np = (int64_t)n * h * w;
+  if (np <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (equalize) {
+    if (vol_weight == nullptr || vol == nullptr) return (int)hipErrorInvalidValue;
+    const int64_t nv = (int64_t)D * H * W;
+    hipLaunchKernelGGL(slice_acq_equalize_grad<T>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, grad_vol, vol_weight, nv);
+  }
+  if (d_p < 2 || h_p < 2 || w_p < 2) return (int)hipGetLastError();
+  hipLaunchKernelGGL(slice_acq_adjoint_bwd_interp<T>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, transforms,
+                     (const T*)grad_vol, psf, slices, slices_mask, equalize ? vol : (const T*)nullptr, vol_mask, grad_slices,
+                     grad_transforms, D, H, W, d_p, h_p, w_p, n, h, w, res_slice);
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
 // ---- C entry points: float (the path every caller of the reference uses) and double (AT_DISPATCH_FLOATING_TYPES,
@@ -525,6 +788,31 @@ int slice_acq_backward_impl(const T* transforms, const T* vol, const uint8_t* vo
     return slice_acq_adjoint_backward_impl<T>(transforms, grad_vol, vol_weight, vol_mask, psf, slices, slices_mask, vol,        \
                                               grad_slices, grad_transforms, D, H, W, d_p, h_p, w_p, n, h, w, res_slice,         \
                                               equalize, stream);                                                                \
+  }                                                                                                                            \
+  /* interp_psf = true: same arguments (no scratch), outputs zero-filled by the caller and accumulated into */                 \
+  extern "C" int nesvor_slice_acq_adjoint_forward_interp##SUFFIX(const T* transforms, const T* psf, const T* slices,           \
+                                                                 const uint8_t* slices_mask, const uint8_t* vol_mask, T* vol,   \
+                                                                 T* vol_weight, int D, int H, int W, int d_p, int h_p, int w_p, \
+                                                                 int n, int h, int w, T res_slice, int equalize, void* stream) {\
+    return slice_acq_adjoint_forward_interp_impl<T>(transforms, psf, slices, slices_mask, vol_mask, vol, vol_weight, D, H, W,   \
+                                                    d_p, h_p, w_p, n, h, w, res_slice, equalize, stream);                       \
+  }                                                                                                                            \
+  extern "C" int nesvor_slice_acq_backward_interp##SUFFIX(const T* transforms, const T* vol, const uint8_t* vol_mask,          \
+                                                          const T* psf, const T* grad_slices, const uint8_t* slices_mask,       \
+                                                          T* grad_vol, T* grad_transforms, int D, int H, int W, int d_p,        \
+                                                          int h_p, int w_p, int n, int h, int w, T res_slice, void* stream) {   \
+    return slice_acq_backward_interp_impl<T>(transforms, vol, vol_mask, psf, grad_slices, slices_mask, grad_vol,                \
+                                             grad_transforms, D, H, W, d_p, h_p, w_p, n, h, w, res_slice, stream);              \
+  }                                                                                                                            \
+  extern "C" int nesvor_slice_acq_adjoint_backward_interp##SUFFIX(const T* transforms, T* grad_vol, const T* vol_weight,       \
+                                                                  const uint8_t* vol_mask, const T* psf, const T* slices,       \
+                                                                  const uint8_t* slices_mask, const T* vol, T* grad_slices,     \
+                                                                  T* grad_transforms, int D, int H, int W, int d_p, int h_p,    \
+                                                                  int w_p, int n, int h, int w, T res_slice, int equalize,      \
+                                                                  void* stream) {                                               \
+    return slice_acq_adjoint_backward_interp_impl<T>(transforms, grad_vol, vol_weight, vol_mask, psf, slices, slices_mask, vol, \
+                                                     grad_slices, grad_transforms, D, H, W, d_p, h_p, w_p, n, h, w, res_slice,  \
+                                                     equalize, stream);                                                         \
   }
 NESVOR_SLICE_ACQ_ENTRY(, float)
 NESVOR_SLICE_ACQ_ENTRY(_f64, double)

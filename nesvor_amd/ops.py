@@ -150,14 +150,12 @@ def _sa_dims(vol_shape, psf):
 
 
 def _sa_symbol(name, t, interp_psf=False):
-    """float32 / float64 (the reference's AT_DISPATCH_FLOATING_TYPES, slice_acq_cuda_kernel.cu:970-1114), linear
-    interpolation.  The PSF-interpolating mode of the reference (:229-279, :526-572, :754) exists in the forward operator
-    only; no caller in the reference tree uses it (exclusion recorded in include/nesvor_hip.h)."""
+    """float32 / float64 (the reference's AT_DISPATCH_FLOATING_TYPES, slice_acq_cuda_kernel.cu:970-1114).  The
+    PSF-interpolating mode of the backward / adjoint operators (:229-279, :526-572, :754) has its own entry points
+    (``*_interp``: per-pixel scatter as the reference formulates it; no caller in the reference tree uses the mode)."""
     if t.dtype not in (torch.float32, torch.float64):
         raise NotImplementedError(f"slice_acq: float32 or float64 expected, got {t.dtype}")
-    if interp_psf:
-        raise NotImplementedError("slice_acq backward / adjoint: interp_psf=True is not built (no fallback)")
-    return getattr(_lib.load(), name + ("_f64" if t.dtype == torch.float64 else ""))
+    return getattr(_lib.load(), name + ("_interp" if interp_psf else "") + ("_f64" if t.dtype == torch.float64 else ""))
 
 
 def _sa_forward(transforms, vol, vol_mask, slices_mask, psf, slice_shape, res_slice, need_weight, interp_psf):
@@ -178,13 +176,14 @@ def _sa_backward(transforms, vol, vol_mask, psf, grad_slices, slices_mask, res_s
     _lib.require_device(transforms, vol, psf, grad_slices, dtype=vol.dtype, name="slice_acq backward input")
     vm, sm = _mask(vol_mask), _mask(slices_mask)
     n, h, w = grad_slices.shape[0], grad_slices.shape[-2], grad_slices.shape[-1]
-    grad_vol = torch.empty_like(vol) if need_vol_grad else None
-    grad_tf = torch.empty_like(transforms) if need_transforms_grad else None
-    scratch = torch.empty(n * h * w, dtype=vol.dtype, device=vol.device)
+    new = torch.zeros_like if interp_psf else torch.empty_like  # the interp kernels accumulate (atomics) into their outputs
+    grad_vol = new(vol) if need_vol_grad else None
+    grad_tf = new(transforms) if need_transforms_grad else None
+    scratch = () if interp_psf else (_lib.ptr(torch.empty(n * h * w, dtype=vol.dtype, device=vol.device)),)
     with torch.cuda.device(vol.device):
         err = _sa_symbol("nesvor_slice_acq_backward", vol, interp_psf)(
             _lib.ptr(transforms), _lib.ptr(vol), _lib.ptr(vm), _lib.ptr(psf), _lib.ptr(grad_slices), _lib.ptr(sm),
-            _lib.ptr(grad_vol), _lib.ptr(grad_tf), _lib.ptr(scratch), *_sa_dims(vol.shape, psf), n, h, w, float(res_slice),
+            _lib.ptr(grad_vol), _lib.ptr(grad_tf), *scratch, *_sa_dims(vol.shape, psf), n, h, w, float(res_slice),
             _lib.stream_ptr())
     _lib.check(err, "slice_acq backward")
     return [grad_vol if need_vol_grad else _empty(vol), grad_tf if need_transforms_grad else _empty(vol)]
@@ -195,13 +194,14 @@ def _sa_adjoint_forward(transforms, psf, slices, slices_mask, vol_mask, vol_shap
     vm, sm = _mask(vol_mask), _mask(slices_mask)
     n, h, w = slices.shape[0], slices.shape[-2], slices.shape[-1]
     D, H, W = (int(s) for s in vol_shape)
-    vol = torch.empty((1, 1, D, H, W), dtype=slices.dtype, device=slices.device)
-    vol_weight = torch.empty_like(vol) if equalize else None
-    scratch = torch.empty(2 * n * h * w, dtype=slices.dtype, device=slices.device)
+    new = torch.zeros if interp_psf else torch.empty  # the interp kernel accumulates (atomics) into its outputs
+    vol = new((1, 1, D, H, W), dtype=slices.dtype, device=slices.device)
+    vol_weight = new((1, 1, D, H, W), dtype=slices.dtype, device=slices.device) if equalize else None
+    scratch = () if interp_psf else (_lib.ptr(torch.empty(2 * n * h * w, dtype=slices.dtype, device=slices.device)),)
     with torch.cuda.device(slices.device):
         err = _sa_symbol("nesvor_slice_acq_adjoint_forward", slices, interp_psf)(
             _lib.ptr(transforms), _lib.ptr(psf), _lib.ptr(slices), _lib.ptr(sm), _lib.ptr(vm), _lib.ptr(vol), _lib.ptr(vol_weight),
-            _lib.ptr(scratch), *_sa_dims((D, H, W), psf), n, h, w, float(res_slice), int(bool(equalize)), _lib.stream_ptr())
+            *scratch, *_sa_dims((D, H, W), psf), n, h, w, float(res_slice), int(bool(equalize)), _lib.stream_ptr())
     _lib.check(err, "slice_acq adjoint_forward")
     return [vol, vol_weight if equalize else _empty(slices)]
 
@@ -214,7 +214,7 @@ def _sa_adjoint_backward(transforms, grad_vol, vol_weight, vol_mask, psf, slices
     vm, sm = _mask(vol_mask), _mask(slices_mask)
     n, h, w = slices.shape[0], slices.shape[-2], slices.shape[-1]
     grad_slices = torch.zeros_like(slices) if need_slices_grad else None
-    grad_tf = torch.empty_like(transforms) if need_transforms_grad else None
+    grad_tf = (torch.zeros_like if interp_psf else torch.empty_like)(transforms) if need_transforms_grad else None
     with torch.cuda.device(slices.device):
         err = _sa_symbol("nesvor_slice_acq_adjoint_backward", slices, interp_psf)(
             _lib.ptr(transforms), _lib.ptr(grad_vol), _lib.ptr(vol_weight if equalize else None), _lib.ptr(vm), _lib.ptr(psf),

@@ -4,8 +4,8 @@
 
 The functions are the dispatcher ops ``torch.ops.nesvor.slice_acq_*`` (``nesvor_amd.ops``).  "None" masks are passed as
 empty tensors (slice_acq.py:36-39); a result that was not requested is ``None`` in the returned list where the
-reference returns an undefined Tensor.  float32, linear interpolation; ``interp_psf=True`` exists in ``forward`` only
-and raises elsewhere (exclusion recorded in include/nesvor_hip.h) - nothing ever falls back.
+reference returns an undefined Tensor.  float32 and float64; both interpolation modes (``interp_psf=True`` runs the
+``*_interp`` kernels of the backward / adjoint operators) - nothing ever falls back.
 """
 import torch
 

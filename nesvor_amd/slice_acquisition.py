@@ -1,7 +1,7 @@
 """Differentiable slice acquisition A and its adjoint A^T: the functions of ``nesvor.slice_acquisition``
 (slice_acquisition/slice_acq.py:22-211) on the dispatcher ops ``torch.ops.nesvor.slice_acq_forward`` /
 ``slice_acq_adjoint_forward``, whose autograd formulas (``nesvor_amd.ops``) call the matching backward ops.
-float32, linear-interpolation mode (``interp_psf=True``: forward operator only).
+float32 / float64, both interpolation modes.
 """
 import torch
 

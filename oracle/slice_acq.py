@@ -133,8 +133,8 @@ def slice_acquisition_forward(
 
 
 # --------------------------------------------------------------------------- adjoint and backward
-# SURVEY.md §8(f) rank 1.  Linear (default) interpolation mode only — `interp_psf=True` is never used by
-# the reference's own callers (svort/srr.py, svort/models.py, svort/inference.py all pass False).
+# SURVEY.md §8(f) rank 1.  Both interpolation modes; `interp_psf=True` is never used by the reference's own callers
+# (svort/srr.py, svort/models.py, svort/inference.py all pass False) and is restated from the kernels alone.
 def _geometry(transforms, shape_dhw, slice_shape, res_slice, dt):
     """Pixel centres in voxel units (n,h,w) x 3 and q = pixel + t in the slice frame."""
     n = transforms.shape[0]
@@ -190,17 +190,73 @@ def _psf_weight(R, centre, psf, dims):
     return wsum
 
 
+def _interp_tap(R, centre, psf, x, y, z, ok, dims, need_grad=False):
+    """The interp_psf branch shared by the kernels (.cu:229-257, :279-308, :553-600, :754-783): the tap position is rounded
+    to the nearest voxel and the PSF is re-interpolated (trilinear) at that voxel's offset from the pixel centre, taken back
+    to the slice frame with R^T.  -> (ok, voxel index, pw, (xr, yr, zr), (d pw/d x_psf, d/d y_psf, d/d z_psf) | None);
+    pw and the derivatives are 0 where not ok."""
+    D, H, W = dims
+    d_p, h_p, w_p = psf.shape
+    psff = psf.reshape(-1)
+    xc, yc, zc = centre
+    zero = torch.zeros_like(x)
+    xs, ys, zs = (torch.where(ok, t, zero) for t in (x, y, z))
+    xr, yr, zr = torch.floor(xs + 0.5), torch.floor(ys + 0.5), torch.floor(zs + 0.5)
+    iv = (zr * (H * W) + yr * W + xr).long()
+    dx_, dy_, dz_ = xr - xc, yr - yc, zr - zc
+    r = lambda a, b: R[:, a, b, None, None]
+    xp = r(0, 0) * dx_ + r(1, 0) * dy_ + r(2, 0) * dz_ + (w_p - 1) / 2.0
+    yp = r(0, 1) * dx_ + r(1, 1) * dy_ + r(2, 1) * dz_ + (h_p - 1) / 2.0
+    zp = r(0, 2) * dx_ + r(1, 2) * dy_ + r(2, 2) * dz_ + (d_p - 1) / 2.0
+    ok = ok & (xp >= 0) & (yp >= 0) & (zp >= 0) & (xp < w_p - 1) & (yp < h_p - 1) & (zp < d_p - 1)
+    xp, yp, zp = (torch.where(ok, t, zero) for t in (xp, yp, zp))
+    xf, yf, zf = torch.floor(xp), torch.floor(yp), torch.floor(zp)
+    wx, wy, wz = xp - xf, yp - yf, zp - zf
+    ip = (zf * (w_p * h_p) + yf * w_p + xf).long()
+    pw, gx, gy, gz = zero.clone(), zero.clone(), zero.clone(), zero.clone()
+    for cx, cy, cz in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1)):  # .cu order
+        ax, ay, az = (wx if cx else 1 - wx), (wy if cy else 1 - wy), (wz if cz else 1 - wz)
+        c = psff[ip + cx + cy * w_p + cz * w_p * h_p]
+        pw = pw + ax * ay * az * c
+        if need_grad:
+            gx = gx + (1.0 if cx else -1.0) * ay * az * c
+            gy = gy + (1.0 if cy else -1.0) * ax * az * c
+            gz = gz + (1.0 if cz else -1.0) * ax * ay * c
+    pw = torch.where(ok, pw, zero)
+    grads = tuple(torch.where(ok, t, zero) for t in (gx, gy, gz)) if need_grad else None
+    return ok, iv, pw, (xr, yr, zr), grads
+
+
+def _psf_weight_interp(R, centre, psf, dims):
+    """pass 1 of the backward / adjoint kernels in interp_psf mode (.cu:229-257, :526-558): sum of the re-interpolated
+    PSF values of the taps inside the volume; vol_mask is ignored."""
+    D, H, W = dims
+    wsum = torch.zeros_like(centre[0])
+    for ix, iy, iz, _ in _taps(psf):
+        x, y, z = _tap_pos(R, centre, ix, iy, iz)
+        ok = (x >= 0) & (y >= 0) & (z >= 0) & (x < W - 1) & (y < H - 1) & (z < D - 1)
+        wsum = wsum + _interp_tap(R, centre, psf, x, y, z, ok, dims)[2]
+    return wsum
+
+
+def _pose_terms_interp(dx, dy, dz, voxel, dims):
+    """(..., 12) pose-gradient terms of one tap in interp_psf mode (.cu:354-361, :822-829), row-major (3, 4)."""
+    D, H, W = dims
+    xr, yr, zr = voxel
+    ox, oy, oz = xr - (W - 1) / 2.0, yr - (H - 1) / 2.0, zr - (D - 1) / 2.0
+    return torch.stack([dx * ox, dy * ox, dz * ox, -dx, dx * oy, dy * oy, dz * oy, -dy, dx * oz, dy * oz, dz * oz, -dz], -1)
+
+
 def slice_acquisition_adjoint_forward(transforms, psf, slices, slices_mask, vol_mask, vol_shape, res_slice,
                                       interp_psf=False, equalize=False):
     """A^T: slices (n,1,h,w) -> (vol (1,1,D,H,W), vol_weight | None).
     Restates slice_acquisition_adjoint_forward_cuda_kernel (.cu:472-670) + equalize (.cu:672-693):
     every pixel with PSF weight >= 0.5 scatters s * psf/weight * trilinear into the volume."""
-    assert not interp_psf, "oracle restates the linear mode only"
     dt = slices.dtype
     D, H, W = (int(s) for s in vol_shape)
     n, _, h, w = slices.shape
     R, _, centre = _geometry(transforms, (D, H, W), (h, w), res_slice, dt)
-    weight = _psf_weight(R, centre, psf, (D, H, W))
+    weight = (_psf_weight_interp if interp_psf else _psf_weight)(R, centre, psf, (D, H, W))
     active = weight >= 0.5
     if slices_mask is not None and slices_mask.numel() > 0:
         active = active & slices_mask.reshape(n, h, w)
@@ -212,6 +268,13 @@ def slice_acquisition_adjoint_forward(transforms, psf, slices, slices_mask, vol_
     for ix, iy, iz, pv in _taps(psf):
         x, y, z = _tap_pos(R, centre, ix, iy, iz)
         ok = active & (x >= 0) & (y >= 0) & (z >= 0) & (x < W - 1) & (y < H - 1) & (z < D - 1)
+        if interp_psf:  # .cu:582-606: one voxel per tap
+            ok, iv, pw, _, _ = _interp_tap(R, centre, psf, x, y, z, ok, (D, H, W))
+            okm = ok if vm is None else (ok & vm[iv])
+            wgt = torch.where(okm, pw / wsafe, torch.zeros_like(pw))
+            vol.index_add_(0, iv.reshape(-1), (wgt * s).reshape(-1))
+            vw.index_add_(0, iv.reshape(-1), wgt.reshape(-1))
+            continue
         xs, ys, zs = (torch.where(ok, t, torch.zeros_like(t)) for t in (x, y, z))
         xf, yf, zf = torch.floor(xs), torch.floor(ys), torch.floor(zs)
         wx, wy, wz = xs - xf, ys - yf, zs - zf
@@ -236,12 +299,11 @@ def slice_acquisition_backward(transforms, vol, vol_mask, psf, grad_slices, slic
                                interp_psf=False, need_vol_grad=True, need_transforms_grad=True):
     """Backward of A as the reference computes it (.cu:173-470): gs = grad / sum(psf in bounds) is
     distributed with psf * trilinear weights; the normalising weight is treated as constant."""
-    assert not interp_psf, "oracle restates the linear mode only"
     dt = vol.dtype
     D, H, W = vol.shape[-3:]
     n, _, h, w = grad_slices.shape
     R, q, centre = _geometry(transforms, (D, H, W), (h, w), res_slice, dt)
-    weight = _psf_weight(R, centre, psf, (D, H, W))
+    weight = (_psf_weight_interp if interp_psf else _psf_weight)(R, centre, psf, (D, H, W))
     g = grad_slices.reshape(n, h, w)
     active = (weight != 0) & (g != 0)
     if slices_mask is not None and slices_mask.numel() > 0:
@@ -256,6 +318,18 @@ def slice_acquisition_backward(transforms, vol, vol_mask, psf, grad_slices, slic
     for ix, iy, iz, pv in _taps(psf):
         x, y, z = _tap_pos(R, centre, ix, iy, iz)
         ok = active & (x >= 0) & (y >= 0) & (z >= 0) & (x < W - 1) & (y < H - 1) & (z < D - 1)
+        if interp_psf:  # .cu:279-370
+            ok, iv, pw, voxel, (gx, gy, gz) = _interp_tap(R, centre, psf, x, y, z, ok, (D, H, W), need_grad=True)
+            okm = ok if vm is None else (ok & vm[iv])
+            zero = torch.zeros_like(pw)
+            if need_vol_grad:
+                gvol.index_add_(0, iv.reshape(-1), torch.where(okm, pw * gs, zero).reshape(-1))
+            if need_transforms_grad:
+                tmp = torch.where(okm, gs * volf[iv], zero)
+                terms = _pose_terms_interp(gx * tmp, gy * tmp, gz * tmp, voxel, (D, H, W)).sum((1, 2)).view(n, 3, 4)
+                gR += terms[:, :, :3]
+                gT += terms[:, :, 3]
+            continue
         xs, ys, zs = (torch.where(ok, t, torch.zeros_like(t)) for t in (x, y, z))
         xf, yf, zf = torch.floor(xs), torch.floor(ys), torch.floor(zs)
         wx, wy, wz = xs - xf, ys - yf, zs - zf
@@ -298,7 +372,6 @@ def slice_acquisition_adjoint_backward(transforms, grad_vol, vol_weight, vol_mas
       grad_slices[p] = sum_taps psf * trilinear(g) / sum_taps psf          (taps inside the volume, masked corners dropped)
       grad_T: the same expression differentiated w.r.t. the tap position, corner values weighted by
               (slices[p] - vol[corner]) when equalising, by slices[p] otherwise."""
-    assert not interp_psf, "oracle restates the linear mode only"
     dt = slices.dtype
     D, H, W = grad_vol.shape[-3:]
     n, h, w = slices.shape[0], slices.shape[-2], slices.shape[-1]
@@ -318,6 +391,16 @@ def slice_acquisition_adjoint_backward(transforms, grad_vol, vol_weight, vol_mas
     for ix, iy, iz, pv in _taps(psf):
         x, y, z = _tap_pos(R, centre, ix, iy, iz)
         inb = (x >= 0) & (y >= 0) & (z >= 0) & (x < W - 1) & (y < H - 1) & (z < D - 1)
+        if interp_psf:  # .cu:754-836
+            ok, iv, pw, voxel, (gx, gy, gz) = _interp_tap(R, centre, psf, x, y, z, inb, (D, H, W), need_grad=True)
+            okm = ok if vm is None else (ok & vm[iv])
+            zero = torch.zeros_like(pw)
+            gv = torch.where(okm, g[iv], zero)
+            sfac = torch.where(okm, (sv - volf[iv] if equalize else sv) * g[iv], zero)
+            gT = gT + _pose_terms_interp(gx * sfac, gy * sfac, gz * sfac, voxel, (D, H, W))
+            val = val + torch.where(okm, pw, zero) * gv
+            weight = weight + torch.where(okm, pw, zero)
+            continue
         xf, yf, zf = x.floor().clamp(0, W - 2), y.floor().clamp(0, H - 2), z.floor().clamp(0, D - 2)
         wx, wy, wz = x - xf, y - yf, z - zf
         i0 = (zf * Sz + yf * Sy + xf).long()
