@@ -51,7 +51,8 @@ def supported(model: NeSVoR) -> bool:
             return False
     elif not model.use_fused_mlp():
         return False
-    return all(mlp_mod.n_hidden_layers(n) <= 2 for n in _nets(model))
+    # (narrower networks run zero-padded on the module path: mlp.kernel_params)
+    return all(mlp_mod.n_hidden_layers(n) <= 2 and mlp_mod.native_width(n) for n in _nets(model))
 
 
 class DirectStep:

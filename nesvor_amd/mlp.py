@@ -62,9 +62,39 @@ def supported(seq) -> bool:
         return False
     if not 2 <= len(layers) <= 4:
         return False
-    if any(l.out_features != 64 for l in layers[:-1]) or any(l.in_features != 64 for l in layers[1:]):
+    if any(not 1 <= l.out_features <= 64 for l in layers[:-1]) or any(a.out_features != b.in_features for a, b in zip(layers, layers[1:])):
         return False
     return layers[-1].out_features <= 16 and layers[0].in_features <= 64 and all(l.bias is not None for l in layers)
+
+
+def native_width(seq) -> bool:
+    """Hidden width exactly 64: the kernels run on the module's own parameters.  Narrower Linear/ReLU stacks
+    (``--width`` < 64) are covered too, by zero padding - see ``kernel_params``."""
+    from .tinycudann import Network
+
+    if isinstance(seq, Network):
+        return True
+    return all(l.out_features == 64 for l in linear_layers(seq)[:-1])
+
+
+def kernel_params(layers):
+    """Per-layer (weights, biases) in the shape the kernels are built for (hidden width 64).  A narrower network is the
+    same function as its zero-padded 64-wide twin - hidden units width..63 get zero weights and zero bias, stay at
+    ReLU(0) = 0 and feed nothing forward - so it is evaluated EXACTLY by the same kernels (at the 64-wide cost).  The
+    padding is a differentiable ``F.pad``: autograd hands the parameter gradients back as slices."""
+    import torch.nn.functional as F
+
+    ws, bs = [l.weight for l in layers], [l.bias for l in layers]
+    if all(l.out_features == 64 for l in layers[:-1]):
+        return ws, bs
+    out_w, out_b = [], []
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        last = i == len(ws) - 1
+        pad_in = 0 if i == 0 else 64 - w.shape[1]
+        pad_out = 0 if last else 64 - w.shape[0]
+        out_w.append(F.pad(w, (0, pad_in, 0, pad_out)))
+        out_b.append(b if last else F.pad(b, (0, pad_out)))
+    return out_w, out_b
 
 
 def n_hidden_layers(net) -> int:
@@ -104,6 +134,12 @@ class NetParams:
             self.segment = None
         else:
             layers = linear_layers(net)
+            if not native_width(net):
+                # narrower than 64: zero-padded copies (inference; the autograd-free training step takes 64-wide networks only)
+                with torch.no_grad():
+                    self.weights, self.biases = (list(t) for t in kernel_params(layers))
+                self.segment = None
+                return
             self.weights = [l.weight for l in layers]
             self.biases = [l.bias for l in layers]
             # one contiguous gradient segment in the partial sums' column order? (the flat layout of fused.FlatParams)
@@ -220,8 +256,8 @@ def fused_mlp(seq: nn.Sequential, xa, xb, b_row0: int, k_b: int, samples_per_pix
     layers = linear_layers(seq)
     need = torch.is_grad_enabled() and (xb.requires_grad or (xa is not None and xa.requires_grad) or any(
         p.requires_grad for l in layers for p in (l.weight, l.bias)))
-    y, _ = torch.ops.nesvor.fused_mlp(xa, xb.contiguous(), [l.weight for l in layers], [l.bias for l in layers], b_row0, k_b,
-                                      samples_per_pixel, -1, need)
+    weights, biases = kernel_params(layers)  # the layers' own parameters at width 64, zero-padded twins below
+    y, _ = torch.ops.nesvor.fused_mlp(xa, xb.contiguous(), weights, biases, b_row0, k_b, samples_per_pixel, -1, need)
     return y
 
 
@@ -278,7 +314,7 @@ def inference_operands(inr, args):
 
     net = inr.density_net
     if not supported(net):
-        raise NotImplementedError("density network outside the fused MLP kernels' shapes (width 64, 1-3 hidden layers)")
+        raise NotImplementedError("density network outside the fused MLP kernels' shapes (width <= 64, 1-3 hidden layers)")
     if isinstance(net, Network) or getattr(args, "mlp_bf16", False):
         return True
     return MFMA_FP32 if getattr(args, "mlp_fp32_mfma", False) else False

@@ -63,12 +63,13 @@ def build_network(**config):
         )
     if dtype != torch.float32:
         raise ValueError("unknown dtype")
-    if not (config["activation"] == "ReLU" and config["output_activation"] == "None" and config["n_neurons"] == 64
+    if not (config["activation"] == "ReLU" and config["output_activation"] == "None" and 1 <= config["n_neurons"] <= 64
             and 1 <= config["n_hidden_layers"] <= 3 and config["n_input_dims"] <= 64 and config["n_output_dims"] <= 16):
-        # the reference accepts any --width / --depth (cli/main.py:68-73) and runs them on library GEMMs; here a shape
-        # outside the fused kernels is refused up front instead of silently training 20x slower on rocBLAS
+        # the reference accepts any --width / --depth (cli/main.py:68-73) and runs them on library GEMMs; here widths
+        # below 64 run zero-padded on the 64-wide kernels (exact: nesvor_amd.mlp.kernel_params) and a shape outside the
+        # kernels is refused up front instead of silently training 20x slower on rocBLAS
         raise NotImplementedError(
-            "the fused MLP kernels cover ReLU networks of width 64 with 1-3 hidden layers, <= 64 inputs and <= 16 "
+            "the fused MLP kernels cover ReLU networks of width <= 64 with 1-3 hidden layers, <= 64 inputs and <= 16 "
             f"outputs; got {config}")
     act = None if config["activation"] == "None" else getattr(nn, config["activation"])
     out_act = None if config["output_activation"] == "None" else getattr(nn, config["output_activation"])
