@@ -1224,6 +1224,27 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;               // chain: sample j, feature quad q;  dW: feature j, sample quad q
   const int role = wave >> 2, pair = wave & 3;
+#ifndef NESVOR_MLP_PAIR_SYNC
+#define NESVOR_MLP_PAIR_SYNC 1
+#endif
+  // The tiles are private to a pair (chain wave w, dW wave w + 4): the per-group hand-over needs the two waves of the
+  // pair to meet, not all eight.  A two-party barrier on LDS flags (each side publishes the iteration it has finished and
+  // waits for the other's; LDS operations of a wave complete in order, so the flag follows the tile traffic) keeps the four
+  // pairs of a workgroup out of lockstep.  NESVOR_MLP_PAIR_SYNC=0: the workgroup barrier.
+  __shared__ int arrive[2][4];
+  if (threadIdx.x < 8) arrive[threadIdx.x >> 2][threadIdx.x & 3] = 0;
+  __syncthreads();
+  auto pair_sync = [&](int it) __attribute__((always_inline)) {
+    if (NESVOR_MLP_PAIR_SYNC) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&arrive[role][pair], it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (__hip_atomic_load(&arrive[1 - role][pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1)
+        __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+      __syncthreads();
+    }
+  };
   float* my_tiles = tiles + pair * 2 * kT * kTileFloats;
   const int64_t n_groups = a.N >> 4;
   const int64_t gstride = (int64_t)gridDim.x * 4;
@@ -1326,7 +1347,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           }
         }
       }
-      __syncthreads();
+      pair_sync(it);
     }
   } else {
     // ------------------------------------------------------------------ dW waves
@@ -1433,7 +1454,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         }
         settle_b(hraw, xraw, xsraw);
       }
-      __syncthreads();
+      pair_sync(it);
     }
   }
   // epilogue: per-workgroup partial sums in nn.Linear parameter order W0,b0,W1,b1,... (accumulators live in waves 4-7)
