@@ -76,6 +76,10 @@ struct MlpArgs {
   int bf16;                     // 1: matrix operands rounded to bf16 (fp32 accumulation); 2: operands split into three bf16 (fp32-equivalent)
 };
 
+// ReLU as an integer max: negative floats (and -0) are negative integers.  fmaxf() compiles to TWO instructions
+// (v_max_f32 x, x to quiet a signalling NaN, then the max), this is one.
+__device__ __forceinline__ float relu_f(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_pf_kern
 #pragma unroll
         for (int ob = 0; ob < kHB; ++ob)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[l][g][ob][r] = fmaxf(h[l][g][ob][r], 0.f);
+          for (int r = 0; r < 4; ++r) h[l][g][ob][r] = relu_f(h[l][g][ob][r]);
     }
     f32x4 o[kG][1];
     {
@@ -634,7 +638,7 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_kernel(
 #pragma unroll
         for (int ob = 0; ob < kHB; ++ob) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[g][ob][r] = fmaxf(h[g][ob][r], 0.f);
+          for (int r = 0; r < 4; ++r) h[g][ob][r] = relu_f(h[g][ob][r]);
           if (a.H[l] != nullptr && g0 + g < n_groups) {
             const size_t e = (((size_t)(g0 + g) * kHB + ob) * 64 + lane) * 4;
             // written once, read by the backward many kernels later: streaming stores (no L2 allocation)
