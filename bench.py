@@ -181,6 +181,7 @@ def main():
                          "matrix operands and fp32 accumulation: NOT the headline configuration")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (copy peak, micro-benchmarks, inference)")
+    ap.add_argument("--no-strict", action="store_true", help="skip the second pass with the MLP products on fp32 MFMAs (kernel timelines)")
     opt = ap.parse_args()
 
     import __graft_entry__ as ge
@@ -286,7 +287,7 @@ def main():
     # the same K steps with the MLP products evaluated by fp32 MFMAs (the default evaluates the same fp32 products as
     # six bf16 MFMAs on split operands, with the same error against fp64): reported next to the headline value
     strict = None
-    if trainer.direct is not None and trainer.direct.bf16 is False:
+    if trainer.direct is not None and trainer.direct.bf16 is False and not opt.no_strict:
         from nesvor_amd import mlp as _mlp
 
         trainer.direct.bf16 = _mlp.MFMA_FP32

@@ -103,6 +103,7 @@ class DirectStep:
         # the END of the flat buffer) first; their all-reduce is started at once and overlaps the coarse levels' launch
         # (NESVOR_DDP_OVERLAP=0: one launch, one all-reduce after the step)
         self._early = None
+        self._owner_pending = False  # an owner pass of the hash-grid backward is running on the side stream
         self.split_level = 0  # 0 = one launch; set by set_overlap() once a gradient all-reduce is installed
         self._split_candidate = 0
         if self.parallel and os.environ.get("NESVOR_DDP_OVERLAP", "1") != "0":
@@ -125,7 +126,15 @@ class DirectStep:
         return early
 
     @torch.no_grad()
-    def run(self, xyz, v, slice_idx, noise=None) -> Dict[str, torch.Tensor]:
+    def join_owner(self) -> None:
+        """Make the current stream wait for an owner pass still running on the side stream (the flat gradient of the hash
+        table is complete only behind it).  ``run(defer_owner_join=True)`` leaves that to the caller - the fused trainer joins
+        right before the optimizer / the gradient exchange, so the step's epilogue launch is not held back."""
+        if self._owner_pending:
+            torch.cuda.current_stream(self.flat.param.device).wait_stream(self.side)
+            self._owner_pending = False
+
+    def run(self, xyz, v, slice_idx, noise=None, defer_owner_join: bool = False) -> Dict[str, torch.Tensor]:
         m, a = self.model, self.model.args
         lib = _lib.load()
         dev = xyz.device
@@ -144,6 +153,7 @@ class DirectStep:
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
                 per, g_t = trans_loss_raw(m.axisangle, m.axisangle_init)
+                pose_reg_done = self.side.record_event()
             for t in (per, g_t):
                 t.record_stream(main)
 
@@ -234,6 +244,7 @@ class DirectStep:
             overlap_owner = not _lib.kernel_timer.enabled and self._overlap_owner
             _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR,
                                       owner_stream=self.side if overlap_owner else None)
+            self._owner_pending = overlap_owner
         dpix = sampler.backward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb, dxl, du) if self.opt_T else None
 
         # ---- per-slice parameters ---------------------------------------------------------------------------
@@ -253,7 +264,8 @@ class DirectStep:
         vals = torch.empty(5, dtype=torch.float32, device=dev)
         img_scale = (self.delta if self.reg_type == 0 else 1.0) / (B * S)
         img_off = -self.delta if self.reg_type == 0 else 0.0
-        main.wait_stream(self.side)  # pose regulariser (start of the step) and owner pass: both done before the epilogue
+        if self.opt_T:
+            main.wait_event(pose_reg_done)  # the pose regulariser from the start of the step; NOT the owner pass behind it
         with torch.cuda.device(dev):
             err = lib.nesvor_step_epilogue(
                 _lib.ptr(dc if self.has_c else None), _lib.ptr(c), _lib.ptr(m.logit_coef.grad if self.has_c else None),
@@ -270,4 +282,6 @@ class DirectStep:
         if self.has_b:
             losses[B_REG] = lb_mean[0] ** 2
         losses[I_REG] = vals[4]
+        if not defer_owner_join:
+            self.join_owner()
         return losses

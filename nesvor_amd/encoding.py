@@ -159,7 +159,11 @@ def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True
             )
     _lib.check(err, "hashgrid backward")
     if sizer is not None and ws is not None:
-        sizer.snapshot(ws)
+        if owner_stream is not None:  # off the main stream: behind the owner pass (the counters are final after the aggregation)
+            with torch.cuda.stream(owner_stream):
+                sizer.snapshot(ws)
+        else:
+            sizer.snapshot(ws)
     return grad_table, grad_u
 
 

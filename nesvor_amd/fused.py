@@ -72,6 +72,7 @@ class FusedTrainer:
         self.t = 0
         self.world_size = world_size
         self._reduce_hook = None  # set by ddp: callable(flat_grad) performing the all-reduce(sum)
+        self._late_join = os.environ.get("NESVOR_OWNER_JOIN_LATE", "1") != "0"  # 0: join the owner pass before the step's epilogue (A/B)
         # autograd-free evaluation of the iteration when the configuration allows it (nesvor_amd.direct)
         from . import direct
 
@@ -94,7 +95,7 @@ class FusedTrainer:
 
     def _forward_backward(self, xyz, v, slice_idx, noise=None) -> Dict[str, torch.Tensor]:
         if self.direct is not None:
-            return self.direct.run(xyz, v, slice_idx, noise)
+            return self.direct.run(xyz, v, slice_idx, noise, defer_owner_join=self._late_join)  # joined in optimizer_step
         losses = self.model(xyz, v, slice_idx) if noise is None else self.model.forward_with_noise(xyz, v, slice_idx, noise)
         loss = 0
         for k, val in losses.items():
@@ -115,6 +116,8 @@ class FusedTrainer:
                                      1.0 / self.world_size, True)
 
     def optimizer_step(self) -> None:
+        if self.direct is not None:
+            self.direct.join_owner()  # the table gradient is complete behind the owner pass on the side stream
         if self.sharded:
             from . import ddp
 
