@@ -66,7 +66,9 @@ class QueueSizer:
         return grown
 
     def snapshot(self, ws: torch.Tensor) -> None:
-        """Queue an asynchronous copy of the latest backward's overflow counters (current stream)."""
+        """Queue an asynchronous copy of the latest backward's overflow counters, on a stream of its own behind the
+        current one: nothing but ``poll`` ever waits for it (on the training step's streams it sat in front of the
+        optimizer)."""
         self.calls += 1
         if QueueSizer.policy == "worst" or self.pending is not None or not (self.calls <= 64 or self.calls % 4 == 0):
             return
@@ -75,9 +77,12 @@ class QueueSizer:
         off = _lib.load().nesvor_hashgrid_backward_overflow_offset(_lib.ptr(ws))
         if self.host is None:
             self.host = torch.empty(_lib.MAX_LEVELS, dtype=torch.int32, pin_memory=True)
-        self.host.copy_(ws[off : off + 4 * _lib.MAX_LEVELS].view(torch.int32), non_blocking=True)
-        self.pending = torch.cuda.Event()
-        self.pending.record()
+            self.stream = torch.cuda.Stream(device=ws.device)
+        self.stream.wait_stream(torch.cuda.current_stream(ws.device))
+        with torch.cuda.stream(self.stream):
+            self.host.copy_(ws[off : off + 4 * _lib.MAX_LEVELS].view(torch.int32), non_blocking=True)
+            self.pending = torch.cuda.Event()
+            self.pending.record()
 
 
 _SIZERS = {}
@@ -159,11 +164,7 @@ def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True
             )
     _lib.check(err, "hashgrid backward")
     if sizer is not None and ws is not None:
-        if owner_stream is not None:  # off the main stream: behind the owner pass (the counters are final after the aggregation)
-            with torch.cuda.stream(owner_stream):
-                sizer.snapshot(ws)
-        else:
-            sizer.snapshot(ws)
+        sizer.snapshot(ws)  # (behind the aggregation pass, which wrote the counters; on the sizer's own stream)
     return grad_table, grad_u
 
 
