@@ -230,6 +230,17 @@ int nesvor_psf_transform_forward(const float* mat, const int64_t* slice_idx, con
 int nesvor_psf_transform_backward(const float* mat, const int64_t* slice_idx, const float* xyz, const float* sigma,
                                   const float* noise, const float* bb, const float* dx, const float* du, float* dmat,
                                   int B, int S, void* stream);
+/* The same two operators with the PSF noise drawn inside the kernels: xi[b,s] = the three N(0,1) draws of a counter-based
+ * generator (Philox4x32-10) keyed by `seed`, counter = (sample index b*S+s, `offset`) - nothing is stored, the backward
+ * evaluates the same function.  The reference draws torch.randn (models.py:270); any N(0,1) stream is the same model.
+ * x (and u) may be NULL when not needed.  nesvor_psf_noise writes the draws themselves, (n_samples, 3). */
+int nesvor_psf_transform_forward_rng(const float* mat, const int64_t* slice_idx, const float* xyz, const float* sigma,
+                                     uint64_t seed, uint64_t offset, const float* bb, float* x, float* u, int B, int S,
+                                     void* stream);
+int nesvor_psf_transform_backward_rng(const float* mat, const int64_t* slice_idx, const float* xyz, const float* sigma,
+                                      uint64_t seed, uint64_t offset, const float* bb, const float* dx, const float* du,
+                                      float* dmat, int B, int S, void* stream);
+int nesvor_psf_noise(uint64_t seed, uint64_t offset, float* out, int64_t n_samples, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused small MLP (fp32 matrix cores).  Replaces the nn.Linear/ReLU stacks that

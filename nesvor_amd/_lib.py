@@ -6,7 +6,7 @@ every op wrapper raises on non-device tensors.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+from ctypes import POINTER, Structure, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 import torch
 
@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NESVOR_HIP_LIB: load another build of the same ABI (tools/ablate_hashgrid.py times variants of one kernel this way)
 LIB_PATH = os.environ.get("NESVOR_HIP_LIB") or os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -96,6 +96,9 @@ _SIGNATURES = {
     "nesvor_hashgrid_backward_atomic": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
     "nesvor_psf_transform_forward": ([_P] * 8 + [c_int, c_int, _P], c_int),
     "nesvor_psf_transform_backward": ([_P] * 9 + [c_int, c_int, _P], c_int),
+    "nesvor_psf_transform_forward_rng": ([_P] * 4 + [c_uint64, c_uint64] + [_P] * 3 + [c_int, c_int, _P], c_int),
+    "nesvor_psf_transform_backward_rng": ([_P] * 4 + [c_uint64, c_uint64] + [_P] * 4 + [c_int, c_int, _P], c_int),
+    "nesvor_psf_noise": ([c_uint64, c_uint64, _P, c_int64, _P], c_int),
     "nesvor_mlp_forward": ([POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), c_int64, _P], c_int),
     "nesvor_mlp_backward": (
         [POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), POINTER(c_void_p), _P, _P, _P, c_int, c_int64, _P],

@@ -104,6 +104,8 @@ class DirectStep:
         # (NESVOR_DDP_OVERLAP=0: one launch, one all-reduce after the step)
         self._early = None
         self._owner_pending = False  # an owner pass of the hash-grid backward is running on the side stream
+        self._kernel_noise = os.environ.get("NESVOR_PSF_NOISE", "kernel") != "tensor"
+        self._noise_stream, self._noise_calls = 0x5851F42D4C957F2D, 0  # stream id of the training draws, calls so far
         self.split_level = 0  # 0 = one launch; set by set_overlap() once a gradient all-reduce is installed
         self._split_candidate = 0
         if self.parallel and os.environ.get("NESVOR_DDP_OVERLAP", "1") != "0":
@@ -158,8 +160,15 @@ class DirectStep:
                 t.record_stream(main)
 
         # ---- forward ----------------------------------------------------------------------------------
+        # PSF noise: explicit draws (replay mode), or drawn inside the sampler kernels from (seed, step counter) - the seed is
+        # torch's current one, so torch.manual_seed() governs the run as before (NESVOR_PSF_NOISE=tensor: torch.randn)
+        rng = None
         if noise is None:
-            noise = torch.randn(B, S, 3, dtype=xyz.dtype, device=dev)
+            if self._kernel_noise:
+                rng = (torch.initial_seed() ^ self._noise_stream, self._noise_calls)
+                self._noise_calls += 1
+            else:
+                noise = torch.randn(B, S, 3, dtype=xyz.dtype, device=dev)
         # per-slice small tensors in one launch: c = n softmax(logit_coef), pose matrices, zeroed accumulators
         small = torch.empty(n * (1 + 12 + 13), dtype=torch.float32, device=dev)
         c = small[:n] if self.has_c else None
@@ -169,7 +178,7 @@ class DirectStep:
             err = lib.nesvor_step_prologue(_lib.ptr(m.logit_coef if self.has_c else None), _lib.ptr(c), _lib.ptr(m.axisangle),
                                            _lib.ptr(mat), _lib.ptr(acc), 13 * n, n, _lib.stream_ptr())
         _lib.check(err, "step prologue")
-        x, u = sampler.forward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb)
+        x, u = sampler.forward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb, rng, S)
         pe = hashgrid_forward(enc.spec, u, enc.params, _lib.LAYOUT_FEATURE_MAJOR, clustered=S >= 128)  # (E, N)
         dW, dB = self.d_net.weights, self.d_net.biases
         z, saved_d = mlp_mod.forward_raw(dW, dB, None, pe, 0, pe.shape[0], S, True, self.bf16)  # (1 + n_features_z, N)
@@ -245,7 +254,7 @@ class DirectStep:
             _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR,
                                       owner_stream=self.side if overlap_owner else None)
             self._owner_pending = overlap_owner
-        dpix = sampler.backward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb, dxl, du) if self.opt_T else None
+        dpix = sampler.backward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb, dxl, du, rng, S) if self.opt_T else None
 
         # ---- per-slice parameters ---------------------------------------------------------------------------
         g_se = m.slice_embedding.weight.grad if self.ks else None

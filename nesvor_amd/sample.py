@@ -22,6 +22,8 @@ from .utils import meshgrid, resolution2sigma
 
 
 class PsfAveragedDensity:
+    _chunks = 0  # chunks evaluated so far in this process: the offset of the next chunk's noise stream
+
     """v(p) = mean_s softplus(density_net(encode(T (p + sigma * xi_s))))[0] for chunks of points.
 
     ``args.n_inference_samples`` cloud samples per point (one noiseless sample with ``args.no_output_psf``),
@@ -34,6 +36,7 @@ class PsfAveragedDensity:
         self.n_samples = 0 if args.no_output_psf else int(args.n_inference_samples)
         self.chunk = int(args.inference_batch_size)
         self.host_rng = bool(getattr(args, "host_rng", False))
+        self.kernel_noise = __import__("os").environ.get("NESVOR_PSF_NOISE", "kernel") != "tensor"
         if self.device.type != "cuda":
             raise RuntimeError("inference runs on the HIP kernels: the INR must live on a HIP device (no CPU path)")
         self.operands = mlp_mod.inference_operands(model, args)  # raises for networks the kernels do not cover
@@ -43,12 +46,17 @@ class PsfAveragedDensity:
         self.weights = list(self.net.weights[:-1]) + [self.net.weights[-1][:1].contiguous()]
         self.biases = list(self.net.biases[:-1]) + [self.net.biases[-1][:1].contiguous()]
 
-    def _noise(self, m: int, s: int) -> torch.Tensor:
+    def _noise(self, m: int, s: int):
+        """-> (noise tensor | None, rng | None): explicit draws (no PSF: zeros; replay mode: the host generator's), or the
+        (seed, offset) pair the sampler kernel draws from itself (one offset per chunk)."""
         if s <= 1:
-            return torch.zeros((m, 1, 3), dtype=torch.float32, device=self.device)
+            return torch.zeros((m, 1, 3), dtype=torch.float32, device=self.device), None
         if self.host_rng:
-            return torch.randn(m, s, 3, dtype=torch.float32).to(self.device)
-        return torch.randn(m, s, 3, dtype=torch.float32, device=self.device)
+            return torch.randn(m, s, 3, dtype=torch.float32).to(self.device), None
+        if not self.kernel_noise:
+            return torch.randn(m, s, 3, dtype=torch.float32, device=self.device), None
+        PsfAveragedDensity._chunks += 1
+        return None, (torch.initial_seed() ^ 0x2545F4914F6CDD1D, PsfAveragedDensity._chunks)
 
     @torch.no_grad()
     def __call__(self, xyz: torch.Tensor, pose: Optional[RigidTransform], sigma: Union[float, Sequence, torch.Tensor]) -> torch.Tensor:
@@ -70,7 +78,8 @@ class PsfAveragedDensity:
             pts = xyz[begin : begin + self.chunk]
             m = pts.shape[0]
             which = torch.zeros(m, dtype=torch.int64, device=dev)
-            _, u = sampler.forward_raw(mat, which, pts, sig, self._noise(m, s), bb)
+            noise, rng = self._noise(m, s)
+            _, u = sampler.forward_raw(mat, which, pts, sig, noise, bb, rng, s, need_x=False)
             pe = hashgrid_forward(enc.spec, u, enc.params, _lib.LAYOUT_FEATURE_MAJOR, clustered=s >= 128)
             z, _ = mlp_mod.forward_raw(self.weights, self.biases, None, pe, 0, pe.shape[0], s, False, self.operands)
             out[begin : begin + m] = F.softplus(z[0].view(m, s)).mean(-1)

@@ -738,6 +738,62 @@ def test_psf_transform_vs_oracle(device, B, S):
     assert float((mat_d.grad.cpu() - mat.grad).abs().max()) < 2e-4 * scale
 
 
+def test_psf_noise_generator_statistics_and_streams(device):
+    """The counter-based N(0,1) generator of the sampler kernels (Philox4x32-10 + Box-Muller, csrc/sampler.hip), 2^22 x 3
+    draws: moments of a standard normal (mean, variance, skewness, kurtosis within a few standard errors), no correlation
+    between the three components of a sample nor between neighbouring samples, tails present; the same (seed, offset)
+    reproduces the draws bit for bit, another offset or seed gives an unrelated stream."""
+    from nesvor_amd.sampler import psf_noise
+
+    n = 1 << 22
+    a = psf_noise(1234, 7, n, device).double()
+    assert a.shape == (n, 3) and bool(torch.isfinite(a).all())
+    flat = a.reshape(-1)
+    m, v = float(flat.mean()), float(flat.var())
+    z = (flat - m) / v**0.5
+    skew, kurt = float((z**3).mean()), float((z**4).mean())
+    se = (1.0 / flat.numel()) ** 0.5
+    assert abs(m) < 5 * se and abs(v - 1) < 5 * (2 ** 0.5) * se and abs(skew) < 5 * (6 ** 0.5) * se and abs(kurt - 3) < 5 * (24 ** 0.5) * se
+    c = torch.corrcoef(a.t())
+    assert float((c - torch.eye(3, device=device, dtype=torch.float64)).abs().max()) < 5 / n**0.5
+    for k in range(3):
+        assert abs(float((a[1:, k] * a[:-1, k]).mean())) < 5 / n**0.5
+    assert float(flat.abs().max()) > 4.5  # 12.6 M draws: the 4.5 sigma tail is populated
+    assert float((flat.abs() < 1).double().mean()) == pytest.approx(0.682689, abs=1e-3)
+    assert torch.equal(psf_noise(1234, 7, 4096, device), a[:4096].float())
+    b = psf_noise(1234, 8, n, device).double()
+    c2 = psf_noise(1235, 7, n, device).double()
+    for other in (b, c2):
+        assert not torch.equal(other[:16], a[:16])
+        assert abs(float((other.reshape(-1) * flat).mean())) < 5 * se
+
+
+def test_psf_transform_kernel_noise_equals_explicit_noise(device):
+    """The sampler with the noise drawn in the kernel == the sampler fed the materialised draws of the same (seed, offset):
+    forward (x, u) and the pose gradient, bit for bit (same arithmetic on the same numbers)."""
+    from nesvor_amd import sampler
+    from oracle import transform_convert as tc
+
+    torch.manual_seed(3)
+    B, S, n = 203, 40, 9
+    mat = tc.axisangle2mat_forward(torch.randn(n, 6) * torch.tensor([0.3, 0.3, 0.3, 5.0, 5.0, 5.0])).to(device)
+    idx = torch.randint(0, n, (B,), device=device)
+    xyz = (torch.randn(B, 3) * 20).to(device)
+    sigma = (torch.rand(n, 3) + 0.5).to(device)
+    bb = torch.tensor([[-60.0, -60, -60], [60, 60, 60]], device=device)
+    rng = (99, 5)
+    noise = sampler.psf_noise(*rng, B * S, device).view(B, S, 3)
+    x1, u1 = sampler.forward_raw(mat, idx, xyz, sigma, noise, bb)
+    x2, u2 = sampler.forward_raw(mat, idx, xyz, sigma, None, bb, rng, S)
+    assert torch.equal(x1, x2) and torch.equal(u1, u2)
+    x3, u3 = sampler.forward_raw(mat, idx, xyz, sigma, None, bb, rng, S, need_x=False)
+    assert x3 is None and torch.equal(u3, u1)
+    dx, du = torch.randn_like(x1), torch.randn_like(u1)
+    g1 = sampler.backward_raw(mat, idx, xyz, sigma, noise, bb, dx, du)
+    g2 = sampler.backward_raw(mat, idx, xyz, sigma, None, bb, dx, du, rng, S)
+    assert torch.equal(g1, g2)
+
+
 # ------------------------------------------------------------------ imaging loss
 @pytest.mark.parametrize("reg", ["edge", "TV", "L2"])
 @pytest.mark.parametrize("pix_var,slice_var,bias,scale", [(True, True, False, True), (True, True, True, True),
