@@ -2,12 +2,13 @@
 reference's Python.  The native transform ops are stood in by the oracle (fixture
 `oracle_backend`) — the product itself has no CPU path."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import scipy_table, small_args
+from conftest import ROOT, scipy_table, small_args
 
 
 def _t(a):
@@ -266,3 +267,29 @@ def test_edge_prior_gradient_is_the_derivative_of_the_charbonnier_penalty():
     torch.testing.assert_close(g, va.grad, rtol=1e-12, atol=1e-12)
     assert float(g[..., 0, :, :].abs().max()) == 0.0 and float(g[..., :, :, -1].abs().max()) == 0.0
     torch.testing.assert_close(SRR.dR(v, delta), g)
+
+
+def test_committed_bench_line_carries_the_contract_fields():
+    """The JSON line `bench.py` printed for the committed round profile (profiles/r02_bench_n1.json, produced by
+    tools/collect_profiles.sh on the GPU box): every field the measurement contract names, with consistent arithmetic."""
+    import json
+
+    path = os.path.join(ROOT, "profiles", "r02_bench_n1.json")
+    d = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=1e-6)  # 2^20-point iterations per second on one GPU
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9, rel=1e-6)
+    assert 0 < r["traffic"] < r["algorithmic_bytes_per_launch"]  # PMC bytes: the table is cache-resident, the scatter merged on chip
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
