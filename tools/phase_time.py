@@ -18,3 +18,11 @@ m = t(lambda: NeSVoR(ds.transformation, ds.resolution, ds.mean, ds.bounding_box,
 t(lambda: ds.mask, "dataset.mask")
 t(lambda: train(slices, args), "train(200 it)")
 t(lambda: train(slices, args), "train(200 it) again")
+from nesvor_amd.sample import sample_slices, sample_volume
+args2 = make_args(dev, 4096, 256, 2, 2000)
+inr, out_slices, mask = t(lambda: train(slices, args2), "train(2000 it)")
+args2.output_resolution = 0.8
+v = t(lambda: sample_volume(inr, mask, args2), "sample_volume (0.8 mm)")
+print("   volume", tuple(v.image.shape), int(v.mask.sum()), "voxels in mask")
+v = t(lambda: sample_volume(inr, mask, args2), "sample_volume again")
+s2 = t(lambda: sample_slices(inr, out_slices[:40], mask, args2), "sample_slices (40 slices)")
