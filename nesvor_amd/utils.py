@@ -117,17 +117,23 @@ def gaussian_blur(x: torch.Tensor, sigma, truncated: float) -> torch.Tensor:
             x = conv(x, k, padding=pad, groups=c)
         return x
     for d, s in enumerate(sigma):
-        taps = gaussian_1d_kernel(float(s), truncated, "cpu").tolist()  # a few numbers: computed on the host, no device sync
-        r = (len(taps) - 1) // 2
-        dim, n = d + 2, x.shape[d + 2]
-        out = torch.zeros_like(x)
-        for j, w in enumerate(taps):
-            shift = j - r
-            lo, hi = max(0, -shift), min(n, n - shift)
-            if lo < hi and w != 0.0:
-                out.narrow(dim, lo, hi - lo).add_(x.narrow(dim, lo + shift, hi - lo), alpha=w)
-        x = out
+        # (a few numbers: computed on the host, no device sync)
+        x = _filter_axis(x, gaussian_1d_kernel(float(s), truncated, "cpu").tolist(), d + 2)
     return x
+
+
+def _filter_axis(x: torch.Tensor, taps, dim: int) -> torch.Tensor:
+    """out[i] = sum_j taps[j] x[i + j - r] along ``dim`` with zero padding (r = len(taps) // 2): a 1-D cross-correlation as
+    len(taps) shifted multiply-adds of the whole array - no convolution library involved."""
+    r = (len(taps) - 1) // 2
+    n = x.shape[dim]
+    out = torch.zeros_like(x)
+    for j, w in enumerate(taps):
+        shift = j - r
+        lo, hi = max(0, -shift), min(n, n - shift)
+        if lo < hi and w != 0.0:
+            out.narrow(dim, lo, hi - lo).add_(x.narrow(dim, lo + shift, hi - lo), alpha=w)
+    return out
 
 
 def ncc_loss(I: torch.Tensor, J: torch.Tensor, mask: Optional[torch.Tensor] = None, win: Optional[int] = 9, level: int = 0,
@@ -149,9 +155,16 @@ def ncc_loss(I: torch.Tensor, J: torch.Tensor, mask: Optional[torch.Tensor] = No
     else:
         I, J = I.reshape(-1, 1, *I.shape[2:]), J.reshape(-1, 1, *J.shape[2:])
         w = 2 * int(win / 2**level / 2) + 1
-        box = torch.ones([1, 1] + [w] * nd, device=I.device, dtype=I.dtype) / w**nd
-        conv = [F.conv1d, F.conv2d, F.conv3d][nd - 1]
-        avg = lambda t: conv(t, box, stride=1, padding=w // 2)
+        if I.is_cuda:  # the box window is separable: w shifted adds per axis instead of a convolution (see gaussian_blur)
+
+            def avg(t):
+                for d in range(nd):
+                    t = _filter_axis(t, [1.0 / w] * w, d + 2)
+                return t
+        else:
+            box = torch.ones([1, 1] + [w] * nd, device=I.device, dtype=I.dtype) / w**nd
+            conv = [F.conv1d, F.conv2d, F.conv3d][nd - 1]
+            avg = lambda t: conv(t, box, stride=1, padding=w // 2)
     mi, mj = avg(I), avg(J)
     cross = avg(I * J) - mi * mj
     cc = cross * cross / ((avg(I * I) - mi * mi) * (avg(J * J) - mj * mj) + eps)

@@ -48,6 +48,23 @@ def test_ncc_loss_properties():
 
 
 @pytest.mark.gpu
+def test_device_filters_without_a_convolution_library_match_the_cpu_convolutions(device):
+    """On a HIP device `gaussian_blur` and the box window of `ncc_loss` run as shifted multiply-adds (the first MIOpen
+    convolution of a process costs seconds of kernel search); on the CPU they are the reference's depthwise convolutions.
+    Same numbers up to fp32 summation order, in 2-D and 3-D, zero padding at the borders included."""
+    from nesvor_amd.utils import gaussian_blur, ncc_loss
+
+    g = torch.Generator().manual_seed(5)
+    x3, y3 = torch.rand(2, 1, 11, 13, 17, generator=g), torch.rand(2, 1, 11, 13, 17, generator=g)
+    x2 = torch.rand(3, 2, 19, 23, generator=g)
+    for x, sig, tr in ((x3, 2.0, 3), (x3, [0.7, 1.3, 2.9], 4.0), (x2, 1.5, 3)):
+        torch.testing.assert_close(gaussian_blur(x.to(device), sig, tr).cpu(), gaussian_blur(x, sig, tr), rtol=1e-5, atol=1e-6)
+    for win, level in ((5, 0), (9, 1), (9, 0)):
+        torch.testing.assert_close(ncc_loss(x3.to(device), y3.to(device), win=win, level=level).cpu(),
+                                   ncc_loss(x3, y3, win=win, level=level), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.gpu
 def test_vvr_reference_test(device):
     """tests/svort/test_vvr.py:16-44: the 128^3 phantom registered to itself from a known offset (3 levels, 8 rounds,
     finite-difference gradient, momentum 0.1, global NCC) must come back to the target pose: atol 1e-5, rtol 1e-3."""
