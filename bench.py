@@ -46,39 +46,49 @@ def make_args(device, batch_size, n_samples, depth, n_iter):
     return a
 
 
-def cpu_baseline(ds, args, seconds_budget=25.0):
-    """The CPU oracle (kind "port") on a bounded sample of the same workload: same model/config,
-    batch 256 pixels x 256 samples (2^16 points/iter), a few iterations on the host cores."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(ds, args, seconds_budget=40.0):
+    """The CPU oracle (kind "port": oracle/train_loop.py restates the reference's train loop, nesvor/nesvor/train.py:123-232)
+    on a bounded sample of the same workload: same data, same model/config, batch 256 pixels x 256 samples (2^16 points per
+    iteration), up to 20 iterations on the host cores (BASELINE.md's C1 plan asks for 200 iterations of the CPU path; the
+    sample is time-boxed so that the default bench run stays within minutes - the first iteration is warm-up and not timed)."""
     from argparse import Namespace
 
     from oracle import train_loop as otl
 
     cargs = Namespace(**{**vars(args), "device": torch.device("cpu"), "batch_size": 256})
-    cds = otl.ArrayDataset(ds.xyz.cpu(), ds.v.cpu(), ds.slice_idx.cpu(), ds.transformation.matrix().cpu(), ds.resolution.cpu())
+    mk = lambda: otl.ArrayDataset(ds.xyz.cpu(), ds.v.cpu(), ds.slice_idx.cpu(), ds.transformation.matrix().cpu(), ds.resolution.cpu())
     torch.manual_seed(0)
     t0 = time.time()
-    iters = []
-
-    def log(i, _):
-        iters.append(time.time())
-
-    n_iter = 1
-    otl.train(cds, cargs, n_iter=1, log=log)  # warm-up / first-touch
+    otl.train(mk(), cargs, n_iter=1)  # warm-up / first-touch
     per = max(time.time() - t0, 1e-3)
-    n_iter = int(max(2, min(20, seconds_budget / per)))
-    iters.clear()
-    cds = otl.ArrayDataset(ds.xyz.cpu(), ds.v.cpu(), ds.slice_idx.cpu(), ds.transformation.matrix().cpu(), ds.resolution.cpu())
-    t1 = time.time()
-    otl.train(cds, cargs, n_iter=n_iter, log=log)
-    dt = time.time() - t1
-    pts_per_s = n_iter * cargs.batch_size * cargs.n_samples / dt
+    n_iter = int(max(3, min(20, seconds_budget / per)))
+    last = {}
+    _, _, _, info = otl.train(mk(), cargs, n_iter=n_iter, log=lambda i, l: last.update(l), time_from_iter=1)
+    rate = info["iters_per_s"]  # iterations 2..n_iter
+    pts_per_s = rate * cargs.batch_size * cargs.n_samples
     return {
         "value": pts_per_s / float(1 << 20),
         "unit": "iters/s (2^20-sample iterations)",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"{n_iter} iterations of the CPU oracle train loop at batch 256 px x 256 samples (2^16 points/iter), "
-                  f"same model/config, {dt:.1f} s wall; rate scaled to 2^20-point iterations",
+        "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(),
+        "iterations_timed": n_iter - 1, "iters_per_s_at_sample_batch": rate, "points_per_s": pts_per_s,
+        "final_losses": {k: float(v) for k, v in last.items()},
+        "sample": f"iterations 2..{n_iter} of the CPU oracle train loop at batch 256 px x 256 samples (2^16 points/iter), same data "
+                  f"and model/config as the GPU run, {(n_iter - 1) / rate:.1f} s wall; rate scaled to 2^20-point iterations",
     }
 
 
@@ -181,6 +191,8 @@ def main():
                          "matrix operands and fp32 accumulation: NOT the headline configuration")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (copy peak, micro-benchmarks, inference)")
+    ap.add_argument("--small-batches", default="2048,1024,512",
+                    help="pixel batch sizes of the small_batch block (strong-scaling regime on one GPU); empty string: skip")
     ap.add_argument("--no-strict", action="store_true", help="skip the second pass with the MLP products on fp32 MFMAs (kernel timelines)")
     opt = ap.parse_args()
 
@@ -310,6 +322,42 @@ def main():
                   "points_per_gpu_per_iter": opt.batch_size * opt.n_samples // world,
                   "note": "same run; python bench.py --scaling strong makes this the headline value"}
 
+    # The strong-scaling regime on ONE GPU (BASELINE C2 = 2^18 points per iteration; C3 read literally = 2^19 / 2^18 / 2^17
+    # points per GPU at 2 / 4 / 8 GPUs): wall time per step, the host's issue time per step (the Python loop without the
+    # final synchronisation - when it equals the wall time the host is the bottleneck) and the HIP-event sum of the timed
+    # native launches.  With NESVOR_DDP_FORCE=1 the gradient exchange runs too (RCCL, group of one rank).
+    small = None
+    if world == 1 and not opt.no_extras and opt.small_batches:
+        small = {"exchange": "RCCL all-reduce in a group of one rank (NESVOR_DDP_FORCE=1)" if parallel else "off (single process)",
+                 "runs": []}
+        for gb in [int(x) for x in opt.small_batches.split(",") if x]:
+            for _ in range(8):
+                step(gb)
+                torch.cuda.synchronize(device)
+            _lib.kernel_timer.reset(enabled=True)
+            for _ in range(20):
+                step(gb)
+            torch.cuda.synchronize(device)
+            kt_small = _lib.kernel_timer.summary()
+            _lib.kernel_timer.reset(enabled=False)
+            for _ in range(opt.warmup):
+                step(gb)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(opt.steps):
+                step(gb)
+            t_issue = time.perf_counter() - t0
+            sync()
+            t_all = time.perf_counter() - t0
+            small["runs"].append({
+                "batch_pixels": gb, "points_per_iter": gb * opt.n_samples, "ms_per_step": t_all / opt.steps * 1e3,
+                "iters_per_s": opt.steps / t_all, "host_issue_ms_per_step": t_issue / opt.steps * 1e3,
+                "timed_kernels_ms_per_step": sum(c * m for c, m in kt_small.values()) / 20,
+                "kernels_ms_per_step": {k: round(c * m / 20, 4) for k, (c, m) in sorted(kt_small.items())}})
+        for _ in range(3):  # back to the headline shape (the side measurements below use the model, not the trainer)
+            step()
+        torch.cuda.synchronize(device)
+
     extras = measure_extras(model, args, device, opt) if (rank == 0 and not opt.no_extras) else None
     if extras is None:
         extras = {"copy_peak_GBps": None, "fill_peak_GBps": None, "roofline_uniform": None, "roofline_fwd_bwd_strict": None, "inference": None}
@@ -324,40 +372,56 @@ def main():
             "hashgrid_bwd": (12 + 4 * F * L + 32 * F * L) + (32 * F * L + 12),
         }
         roof = None
+        dominant = None
         if ktimes:
-            # the hash-grid backward is two launches (aggregation pass + owner pass): one operation, one roofline entry
-            kt = {k: v[1] for k, v in ktimes.items()}
-            if "hashgrid_bwd_aggregate" in kt:
-                # per step: under torch.distributed the backward is split by levels into two aggregation + two owner
-                # launches (the all-reduce of the first part overlaps the second), so sum the launches of one step
-                per_step = lambda k: ktimes[k][0] * ktimes[k][1] / k_steps if k in ktimes else 0.0
-                kt["hashgrid_bwd_aggregate"], kt["hashgrid_bwd_owner"] = per_step("hashgrid_bwd_aggregate"), per_step("hashgrid_bwd_owner")
-                kt["hashgrid_bwd"] = kt["hashgrid_bwd_aggregate"] + kt["hashgrid_bwd_owner"]
-            dom = max((k for k in kt if k in bytes_pt), key=lambda k: kt[k])
-            ms = kt[dom]
-            achieved = bytes_pt[dom] * n_points / (ms * 1e-3) / 1e9
+            # per step: under torch.distributed the backward is split by levels into two aggregation + two owner launches
+            # (the all-reduce of the first part overlaps the second), so sum the launches of one step
+            per_step = lambda k: ktimes[k][0] * ktimes[k][1] / k_steps if k in ktimes else 0.0
+            kt = {k: per_step(k) for k in ktimes}
+            kt["hashgrid_bwd"] = kt.get("hashgrid_bwd_aggregate", 0.0) + kt.get("hashgrid_bwd_owner", 0.0)
+            # which native operation costs the step most (all spans compared, the two launches of an operation together)
+            ops_ms = {k: v for k, v in kt.items() if k not in ("hashgrid_bwd_aggregate", "hashgrid_bwd_owner")}
+            dominant = max(ops_ms, key=lambda k: ops_ms[k])
+            # the operation the north-star prices: hash-grid forward + backward as launched INSIDE the training step
+            # (PSF-cloud points, input gradient on: poses are optimised).  Three accountings, SURVEY 8d's first:
+            t_f, t_b = kt.get("hashgrid_fwd", 0.0), kt["hashgrid_bwd"]
+            fwd_B, bwd_B, bwd_in_B = (12 + 32 * F * L + 4 * F * L), (12 + 4 * F * L + 32 * F * L), (32 * F * L + 12)
+            gbps = lambda nbytes, ms: nbytes * n_points / (ms * 1e-3) / 1e9 if ms > 0 else None
+            strict_bw = gbps(fwd_B + bwd_B, t_f + t_b)
             traffic, traffic_src = None, None
             # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE per the microarch
             # guide); they cannot be collected inside this process, so the number carries the file and commit it was
             # measured at and is dropped when this run's launch shape differs
-            for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", fn)) as fh:
                         tj = json.load(fh)
                 except OSError:
                     continue
-                if dom in tj and n_points == (1 << 20):
-                    traffic = tj[dom].get("traffic_bytes")
-                    traffic_src = f"profiles/{fn} (kernels at commit {tj.get('commit', 'round-1 closing commit 867681e')})"
+                if n_points == (1 << 20) and "hashgrid_bwd" in tj:
+                    traffic = tj["hashgrid_bwd"].get("traffic_bytes", 0) + tj.get("hashgrid_fwd", {}).get("traffic_bytes", 0)
+                    traffic_src = f"profiles/{fn} (hashgrid_fwd + hashgrid_bwd launches, kernels at commit {tj.get('commit')})"
                 break
             roof = {
-                "bound": "hbm", "kernel": dom + (" (hashgrid_bwd_aggregate + hashgrid_bwd_owner launches)" if dom == "hashgrid_bwd" else ""),
-                "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src, "launch_ms": ms,
+                "bound": "hbm",
+                "kernel": "hashgrid_fwd + hashgrid_bwd (aggregate + owner launches) inside the training step, PSF-cloud points, input gradient on",
+                "achieved": strict_bw, "peak": 8000.0, "unit": "GB/s", "frac": None if strict_bw is None else strict_bw / 8000.0,
+                "definition": "SURVEY 8d: forward + parameter-gradient bytes (12+72L)+(12+72L) = 2328 B/point at L=16, divided by the time "
+                              "of ALL hash-grid launches of the step (the backward also produces the input gradient)",
+                "traffic": traffic, "traffic_source": traffic_src,
+                "launch_ms": t_f + t_b, "forward_ms": t_f, "backward_ms": t_b,
+                "algorithmic_bytes_per_launch": (fwd_B + bwd_B) * n_points,
+                "accountings": {
+                    "strict_8d_bytes_over_all_time": None if strict_bw is None else strict_bw / 8000.0,
+                    "all_bytes_incl_input_grad_over_all_time": gbps(fwd_B + bwd_B + bwd_in_B, t_f + t_b) / 8000.0,
+                    "backward_only_incl_input_grad": gbps(bwd_B + bwd_in_B, t_b) / 8000.0,  # rounds 1-2 reported this one as frac
+                    "forward_only": (gbps(fwd_B, t_f) / 8000.0) if t_f > 0 else None,
+                },
                 "timing": f"HIP events on the launch stream over {k_steps} steps of this run, before the timed region",
                 "copy_peak_GBps": extras["copy_peak_GBps"], "fill_peak_GBps": extras["fill_peak_GBps"],
-                "algorithmic_bytes_per_launch": bytes_pt[dom] * n_points,
-                "other_kernels_ms": {k: round(v[1], 4) for k, v in ktimes.items() if k != dom},
+                "dominant_operation_of_the_step": {"name": dominant, "ms_per_step": ops_ms[dominant],
+                                                   "note": "largest per-step time among the timed native operations; roofline_mlp prices the MLP backward"},
+                "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(kt.items())},
             }
         roof_mlp = None
         if ktimes and "mlp_bwd" in ktimes and not args.n_levels_bias and not args.no_pixel_variance:
@@ -375,7 +439,7 @@ def main():
             props = torch.cuda.get_device_properties(device)
             clock_hz = float(getattr(props, "clock_rate", 2.4e6)) * 1e3  # kHz; MI355X maximum engine clock 2400 MHz (MI355X_MICROARCH.md)
             n_simd = props.multi_processor_count * 4
-            ms2 = 2 * ktimes["mlp_bwd"][1]
+            ms2 = ktimes["mlp_bwd"][0] * ktimes["mlp_bwd"][1] / k_steps
             bf16_ops = opt.mlp_bf16 or opt.half_precision_model
             if bf16_ops:      # dX chain and dW on the bf16 pipe: one 16-k MFMA per block product and role
                 fp32_mfma, bf16_mfma = 0, 2 * bp
@@ -419,9 +483,11 @@ def main():
                              "bf16-rounded operands" if (opt.mlp_bf16 or opt.half_precision_model) else
                              "fp32 operands split into three bf16 terms, six bf16 MFMAs per product, fp32 accumulation: error "
                              "against fp64 equal to the fp32 MFMA chain's (tests/test_gpu_ops.py::"
-                             "test_fused_mlp_split_operands_keep_fp32_accuracy); dW products are fp32 MFMAs"),
+                             "test_fused_mlp_split_operands_keep_fp32_accuracy); forward, dX chain and dW all run on the bf16 "
+                             "matrix pipe (roofline_mlp.fp32_pipe_busy_frac = 0)"),
             "strict_fp32_mfma": strict,
             "strong_scaling": strong,
+            "small_batch": small,
             "roofline": roof,
             "roofline_uniform": extras["roofline_uniform"],
             "roofline_fwd_bwd_strict": extras["roofline_fwd_bwd_strict"],

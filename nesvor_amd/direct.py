@@ -127,7 +127,6 @@ class DirectStep:
         early, self._early = self._early, None
         return early
 
-    @torch.no_grad()
     def join_owner(self) -> None:
         """Make the current stream wait for an owner pass still running on the side stream (the flat gradient of the hash
         table is complete only behind it).  ``run(defer_owner_join=True)`` leaves that to the caller - the fused trainer joins
@@ -136,6 +135,7 @@ class DirectStep:
             torch.cuda.current_stream(self.flat.param.device).wait_stream(self.side)
             self._owner_pending = False
 
+    @torch.no_grad()
     def run(self, xyz, v, slice_idx, noise=None, defer_owner_join: bool = False) -> Dict[str, torch.Tensor]:
         m, a = self.model, self.model.args
         lib = _lib.load()

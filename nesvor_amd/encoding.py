@@ -105,7 +105,13 @@ def _workspace(spec, N, device, sizer=None):
     key = (device, nbytes)
     ws = _WORKSPACES.get(key)
     if ws is None:
-        for k in [k for k in _WORKSPACES if k[0] == device]:
+        stale = [k for k in _WORKSPACES if k[0] == device]
+        if stale:
+            # the old workspace may still be read on streams the caching allocator knows nothing about (an owner pass on
+            # the caller's side stream, the sizer's counter copy): let the device drain before its memory is recycled.
+            # Happens a handful of times per run (first iterations, while the queue capacities settle)
+            torch.cuda.synchronize(device)
+        for k in stale:
             del _WORKSPACES[k]  # one live workspace per device
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         ws[: _lib.load().nesvor_hashgrid_backward_workspace_zero_bytes()].zero_()  # queue tails: zero once, kept by the kernels

@@ -261,6 +261,63 @@ def fused_mlp(seq: nn.Sequential, xa, xb, b_row0: int, k_b: int, samples_per_pix
     return y
 
 
+_warned_library = set()
+
+
+def library_mlp(seq: nn.Sequential, xa, xb, b_row0: int, k_b: int, samples_per_pixel: int):
+    """A Linear/activation stack of ANY width / depth / activation on library GEMMs (rocBLAS through ``torch.matmul``),
+    evaluated feature-major like the fused kernels: h = W x + b with x (k, N).  The per-pixel features enter as
+    ``W[:, :k_a] xa^T`` computed once per pixel and repeated over the pixel's samples, so neither the expanded slice
+    embedding nor a concatenated input matrix exists (models.py:339-353 builds both).  Differentiable by autograd."""
+    mods = list(seq)
+    first = mods[0]
+    if not isinstance(first, nn.Linear):
+        raise ValueError("network must start with a Linear layer")
+    k_a = 0 if xa is None else xa.shape[1]
+    w0 = first.weight
+    h = w0[:, k_a:] @ xb[b_row0 : b_row0 + k_b]
+    if xa is not None:
+        h = h + (w0[:, :k_a] @ xa.t()).repeat_interleave(samples_per_pixel, dim=1)
+    if first.bias is not None:
+        h = h + first.bias[:, None]
+    for m in mods[1:]:
+        if isinstance(m, nn.Linear):
+            h = m.weight @ h
+            if m.bias is not None:
+                h = h + m.bias[:, None]
+        else:
+            h = m(h)  # elementwise activation: layout-agnostic
+    return h
+
+
+def apply_net(net, xa, xb, b_row0: int, k_b: int, samples_per_pixel: int):
+    """One network of the model on [xa (P, k_a) broadcast over each pixel's samples | rows [b_row0, b_row0 + k_b) of the
+    feature-major xb] -> (out_dim, N) feature-major, differentiable.  Picks the evaluation:
+
+    * Linear/ReLU stacks inside the fused kernels' shapes: ``fused_mlp`` (the dispatcher op);
+    * other ``nn.Sequential`` stacks (``--width`` > 64, ``--depth`` > 3, ...: the reference accepts any,
+      cli/main.py:68-73): ``library_mlp`` - correct, but several times slower, and the autograd-free step does not apply;
+    * the half-precision structure (``tinycudann.Network``): its row-major module interface."""
+    from .tinycudann import Network
+
+    if isinstance(net, Network):
+        x = xb[b_row0 : b_row0 + k_b].t()
+        if xa is not None:
+            x = torch.cat([xa.repeat_interleave(samples_per_pixel, dim=0), x], 1)
+        return net(x).t()
+    if supported(net):
+        return fused_mlp(net, xa, xb, b_row0, k_b, samples_per_pixel)
+    key = tuple((type(m).__name__, getattr(m, "in_features", 0), getattr(m, "out_features", 0)) for m in net)
+    if key not in _warned_library:
+        _warned_library.add(key)
+        import logging
+
+        logging.warning("MLP %s is outside the fused HIP kernels (ReLU, width <= 64, 1-3 hidden layers, <= 64 inputs, <= 16 "
+                        "outputs): its products run on library GEMMs - expect a several times slower iteration",
+                        [k[1:] for k in key if k[0] == "Linear"])
+    return library_mlp(net, xa, xb, b_row0, k_b, samples_per_pixel)
+
+
 class FlatNetworkFunction(Function):
     """``tinycudann.Network`` (one flat bias-free parameter vector) on the fused kernels, bf16 matrix operands:
     x (N, k) row-major -> y (N, n_output_dims).  The kernels read a feature-major input and write a feature-major
@@ -314,7 +371,7 @@ def inference_operands(inr, args):
 
     net = inr.density_net
     if not supported(net):
-        raise NotImplementedError("density network outside the fused MLP kernels' shapes (width <= 64, 1-3 hidden layers)")
+        return None  # library GEMMs (apply_net)
     if isinstance(net, Network) or getattr(args, "mlp_bf16", False):
         return True
     return MFMA_FP32 if getattr(args, "mlp_fp32_mfma", False) else False

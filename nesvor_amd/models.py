@@ -8,10 +8,13 @@ binds to this module unchanged.  The native backend is swapped in exactly where
 the reference reaches tinycudann: ``build_encoding`` / ``build_network``.
 
 Two execution paths share the parameters:
-* ``NeSVoR.forward`` — op-by-op autograd graph (HIP hash-grid / transform ops +
-  rocBLAS linears), structurally what the reference runs; this is the parity
-  surface for the loss dict and every gradient.
-* ``nesvor_amd.fused`` — the fused training step used by ``train()``.
+* ``NeSVoR.forward`` — autograd over the dispatcher ops (fused sampler, hash grid, fused MLPs,
+  fused imaging loss): the parity surface for the loss dict and every gradient;
+* ``nesvor_amd.fused`` / ``nesvor_amd.direct`` — the autograd-free training step used by ``train()``.
+
+Networks outside the fused kernels' shapes (``--width`` > 64, ``--depth`` > 3, ...; the reference accepts
+any, cli/main.py:68-73) keep every other stage on the HIP kernels and evaluate their matrix products on
+library GEMMs (``nesvor_amd.mlp.apply_net``), with a warning about speed.
 """
 from argparse import Namespace
 from math import log2
@@ -63,14 +66,9 @@ def build_network(**config):
         )
     if dtype != torch.float32:
         raise ValueError("unknown dtype")
-    if not (config["activation"] == "ReLU" and config["output_activation"] == "None" and 1 <= config["n_neurons"] <= 64
-            and 1 <= config["n_hidden_layers"] <= 3 and config["n_input_dims"] <= 64 and config["n_output_dims"] <= 16):
-        # the reference accepts any --width / --depth (cli/main.py:68-73) and runs them on library GEMMs; here widths
-        # below 64 run zero-padded on the 64-wide kernels (exact: nesvor_amd.mlp.kernel_params) and a shape outside the
-        # kernels is refused up front instead of silently training 20x slower on rocBLAS
-        raise NotImplementedError(
-            "the fused MLP kernels cover ReLU networks of width <= 64 with 1-3 hidden layers, <= 64 inputs and <= 16 "
-            f"outputs; got {config}")
+    # any --width / --depth builds (cli/main.py:68-73): shapes the fused kernels cover (ReLU, width <= 64 - narrower
+    # ones zero-padded, exact -, 1-3 hidden layers, <= 64 inputs, <= 16 outputs) run on them, the rest on library GEMMs
+    # through nesvor_amd.mlp.apply_net, which says so once
     act = None if config["activation"] == "None" else getattr(nn, config["activation"])
     out_act = None if config["output_activation"] == "None" else getattr(nn, config["output_activation"])
     dims = [config["n_input_dims"]] + [config["n_neurons"]] * config["n_hidden_layers"] + [config["n_output_dims"]]
@@ -120,36 +118,24 @@ class INR(nn.Module):
             dtype=args.dtype,
         )
 
-    def use_fused_mlp(self) -> bool:
-        return (self.bounding_box.is_cuda and self.encoding.dtype == torch.float32
-                and getattr(self, "fused_mlp", True) and fused_mlp_mod.supported(self.density_net))
-
     def forward(self, x: torch.Tensor, return_all: bool = True):
         x = (x - self.bounding_box[0]) / (self.bounding_box[1] - self.bounding_box[0])
         prefix_shape = x.shape[:-1]
-        if self.use_fused_mlp():
-            # feature-major hash grid -> fused fp32-MFMA MLP; (N,E)/(N,16) views are returned for API parity
-            enc = self.encoding
-            pe_fm = hashgrid_encode(x.reshape(-1, 3), enc.params, enc.spec, _lib.LAYOUT_FEATURE_MAJOR, enc.grad_accum)
-            z_fm = fused_mlp_mod.fused_mlp(self.density_net, None, pe_fm, 0, pe_fm.shape[0], 1)
-            density = F.softplus(z_fm[0].view(prefix_shape))
-            return (density, pe_fm.t(), z_fm.t()) if return_all else density
-        if (not torch.is_grad_enabled() and self.bounding_box.is_cuda and self.encoding.dtype == torch.float16
-                and getattr(self, "fused_mlp", True) and fused_mlp_mod.supported(self.density_net)):
+        enc = self.encoding
+        if (not torch.is_grad_enabled() and enc.dtype == torch.float16 and fused_mlp_mod.supported(self.density_net)):
             # half-precision model structure at inference (sample_volume / sample_slices): the same two kernels with
             # bf16 matrix operands; outputs stay fp32
             from .encoding import hashgrid_forward
 
-            enc = self.encoding
             pe_fm = hashgrid_forward(enc.spec, x.reshape(-1, 3).float().contiguous(), enc.params, _lib.LAYOUT_FEATURE_MAJOR)
             net = fused_mlp_mod.NetParams(self.density_net)
             z_fm, _ = fused_mlp_mod.forward_raw(net.weights, net.biases, None, pe_fm, 0, pe_fm.shape[0], 1, False, bf16=True)
-            density = F.softplus(z_fm[0].view(prefix_shape))
-            return (density, pe_fm.t(), z_fm.t()) if return_all else density
-        pe = self.encoding(x.reshape(-1, x.shape[-1]))
-        z = self.density_net(pe)
-        density = F.softplus(z[..., 0].view(prefix_shape))
-        return (density, pe, z) if return_all else density
+        else:
+            # feature-major hash grid -> fused MLP; (N,E)/(N,16) views are returned for API parity
+            pe_fm = hashgrid_encode(x.reshape(-1, 3).float(), enc.params, enc.spec, _lib.LAYOUT_FEATURE_MAJOR, enc.grad_accum)
+            z_fm = fused_mlp_mod.apply_net(self.density_net, None, pe_fm, 0, pe_fm.shape[0], 1)
+        density = F.softplus(z_fm[0].view(prefix_shape))
+        return (density, pe_fm.t(), z_fm.t()) if return_all else density
 
     def sample_batch(
         self,
@@ -234,47 +220,11 @@ class NeSVoR(nn.Module):
         return self.forward_with_noise(xyz, v, slice_idx, noise)
 
     def forward_with_noise(self, xyz, v, slice_idx, noise) -> Dict[str, Any]:
-        a = self.args
-        S = noise.shape[1]
-        if self.use_fused_mlp():
-            # fused sampler: per-slice matrices (n is a few hundred) -> x and the normalised u in one launch
-            mat = axisangle2mat(self.axisangle)
-            x, u = psf_transform(mat, slice_idx, xyz, self.psf_sigma, noise, self.inr.bounding_box)
-            if getattr(a, "fused_loss", True):
-                return self.fused_losses(x, u, v, slice_idx)
-            results = self.net_forward_fused(x, slice_idx, u)
-        else:
-            sigma = self.psf_sigma[slice_idx][:, None]
-            pose = self.axisangle[slice_idx][:, None]
-            x = ax_transform_points(pose, xyz[:, None] + noise * sigma, self.trans_first)
-            se = self.slice_embedding(slice_idx)[:, None].expand(-1, S, -1) if a.n_features_slice else None
-            results = self.net_forward(x, se)
-        density = results["density"]
-        if "log_bias" in results:
-            log_bias = results["log_bias"]
-            bias = log_bias.exp()
-            bias_detach = bias.detach()
-        else:
-            log_bias, bias, bias_detach = 0, 1, 1
-        var = results["log_var"].exp() if "log_var" in results else 1
-        c: Any = F.softmax(self.logit_coef, 0)[slice_idx] * self.n_slices if not a.no_slice_scale else 1
-        v_out = c * (bias * density).mean(-1)
-        if not a.no_pixel_variance:
-            var = (bias_detach * var).mean(-1)
-            var = (c.detach() if torch.is_tensor(c) else c) * var
-            var = var**2
-        if not a.no_slice_variance:
-            var = var + self.log_var_slice.exp()[slice_idx]
-        losses = {D_LOSS: ((v_out - v) ** 2 / (2 * var)).mean()}
-        if not (a.no_pixel_variance and a.no_slice_variance):
-            losses[S_LOSS] = 0.5 * var.log().mean()
-            losses[DS_LOSS] = losses[D_LOSS] + losses[S_LOSS]
-        if not a.no_transformation_optimization:
-            losses[T_REG] = self.trans_loss(trans_first=self.trans_first)
-        if a.n_levels_bias:
-            losses[B_REG] = log_bias.mean() ** 2
-        losses[I_REG] = self.image_regularization(density, x, self.delta)
-        return losses
+        """``forward`` with the PSF draws handed in (B, S, 3): the fused sampler turns the per-slice matrices (n is a few
+        hundred) into x and the box-normalised u in one launch, then hash grid + networks + fused imaging loss."""
+        mat = axisangle2mat(self.axisangle)
+        x, u = psf_transform(mat, slice_idx, xyz, self.psf_sigma, noise, self.inr.bounding_box)
+        return self.fused_losses(x, u, v, slice_idx)
 
     def fused_losses(self, x, u, v, slice_idx) -> Dict[str, Any]:
         """Imaging model + losses (models.py:286-325) through the fused loss kernel; same dict, same order."""
@@ -296,7 +246,8 @@ class NeSVoR(nn.Module):
         return losses
 
     def use_fused_mlp(self) -> bool:
-        """Fused fp32-MFMA evaluation of the three MLPs (default on a HIP device in single precision)."""
+        """Every network of the single-precision model inside the fused kernels' shapes (then the autograd-free step
+        applies, nesvor_amd.direct); otherwise ``apply_net`` picks per network."""
         a = self.args
         nets = [self.inr.density_net]
         if not a.no_pixel_variance:
@@ -314,43 +265,15 @@ class NeSVoR(nn.Module):
         inr = self.inr
         enc = inr.encoding
         pe = hashgrid_encode(u, enc.params, enc.spec, _lib.LAYOUT_FEATURE_MAJOR, enc.grad_accum)  # (E, N)
-        z = fused_mlp_mod.fused_mlp(inr.density_net, None, pe, 0, pe.shape[0], S)
+        z = fused_mlp_mod.apply_net(inr.density_net, None, pe, 0, pe.shape[0], S)
         se = self.slice_embedding(slice_idx) if a.n_features_slice else None  # (B, n_features_slice)
         log_bias = log_var = None
         if a.n_levels_bias:
             kb = a.n_levels_bias * a.n_features_per_level
-            log_bias = fused_mlp_mod.fused_mlp(self.b_net, se, pe, 0, kb, S)[0]
+            log_bias = fused_mlp_mod.apply_net(self.b_net, se, pe, 0, kb, S)[0]
         if not a.no_pixel_variance:
-            log_var = fused_mlp_mod.fused_mlp(self.sigma_net, se, z, 1, a.n_features_z, S)[0]
+            log_var = fused_mlp_mod.apply_net(self.sigma_net, se, z, 1, a.n_features_z, S)[0]
         return z, log_var, log_bias
-
-    def net_forward_fused(self, x: torch.Tensor, slice_idx: torch.Tensor, u: Optional[torch.Tensor] = None) -> Dict[str, Any]:
-        """net_forward (models.py:329-355) on the fused kernels; same result dict."""
-        inr = self.inr
-        B, S = x.shape[0], x.shape[1]
-        if u is None:
-            u = ((x - inr.bounding_box[0]) / (inr.bounding_box[1] - inr.bounding_box[0])).reshape(-1, 3)
-        z, log_var, log_bias = self.fused_outputs(u, slice_idx, S)
-        results = {"density": F.softplus(z[0]).view(B, S)}
-        if log_bias is not None:
-            results["log_bias"] = log_bias.view(B, S)
-        if log_var is not None:
-            results["log_var"] = log_var.view(B, S)
-        return results
-
-    def net_forward(self, x: torch.Tensor, se: Optional[torch.Tensor] = None) -> Dict[str, Any]:
-        a = self.args
-        density, pe, z = self.inr(x)
-        shape = density.shape
-        results = {"density": density}
-        feats = [] if se is None else [se.reshape(-1, se.shape[-1])]
-        if a.n_levels_bias:
-            pe_bias = pe[..., : a.n_levels_bias * a.n_features_per_level]
-            results["log_bias"] = self.b_net(torch.cat(feats + [pe_bias], -1)).view(shape)
-        if not a.no_pixel_variance:
-            feats.append(z[..., 1:])
-            results["log_var"] = self.sigma_net(torch.cat(feats, -1)).view(shape)
-        return results
 
     def trans_loss(self, trans_first: bool = True) -> torch.Tensor:
         if trans_first and self.axisangle.is_cuda and self.axisangle.dtype == torch.float32 and getattr(self.args, "fused_mlp", True):

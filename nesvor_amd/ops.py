@@ -373,6 +373,8 @@ def _mlp_backward_formula(ctx, dy, d_saved):
     xb = t.pop(0)
     n = ctx.n_layers
     weights, biases, saved = t[:n], t[n : 2 * n], t[2 * n :]
+    if len(saved) != n - 1:
+        raise RuntimeError("fused_mlp was called with save=False but a gradient is requested: pass save=True")
     b_row0, k_b, S, operands = ctx.cfg
     need_xa, need_xb = ctx.has_xa and ctx.needs_input_grad[0], ctx.needs_input_grad[1]
     dxa, dxb, partial = torch.ops.nesvor.fused_mlp_backward(xa, xb, dy.contiguous(), weights, biases, saved, b_row0, k_b, S, operands,
@@ -476,8 +478,9 @@ def _loss_backward(z0, log_var, log_bias, x, v, slice_idx, c, log_var_slice, lb_
     _lib.check(err, "imaging loss backward")
     dc = torch.zeros_like(c).index_add_(0, slice_idx, dc_pix) if c is not None else _empty(x)
     dlvs = torch.zeros_like(log_var_slice).index_add_(0, slice_idx, dlvs_pix) if log_var_slice is not None else _empty(x)
-    e = _empty(x)
-    return dz0, dlv if dlv is not None else e, dlb if dlb is not None else e, dx if dx is not None else e, dc, dlvs
+    # (a fresh empty tensor per absent output: custom-op outputs must not alias each other)
+    return (dz0, dlv if dlv is not None else _empty(x), dlb if dlb is not None else _empty(x),
+            dx if dx is not None else _empty(x), dc, dlvs)
 
 
 def _loss_setup(ctx, inputs, output):

@@ -39,7 +39,9 @@ class PsfAveragedDensity:
         self.kernel_noise = __import__("os").environ.get("NESVOR_PSF_NOISE", "kernel") != "tensor"
         if self.device.type != "cuda":
             raise RuntimeError("inference runs on the HIP kernels: the INR must live on a HIP device (no CPU path)")
-        self.operands = mlp_mod.inference_operands(model, args)  # raises for networks the kernels do not cover
+        self.operands = mlp_mod.inference_operands(model, args)  # None: a network the kernels do not cover (library GEMMs)
+        if self.operands is None:
+            return
         self.net = mlp_mod.NetParams(model.density_net)
         # only output 0 (the density logit) of the density network is used here: its other rows (the features of the
         # variance / bias networks) are neither computed into HBM nor stored
@@ -81,7 +83,10 @@ class PsfAveragedDensity:
             noise, rng = self._noise(m, s)
             _, u = sampler.forward_raw(mat, which, pts, sig, noise, bb, rng, s, need_x=False)
             pe = hashgrid_forward(enc.spec, u, enc.params, _lib.LAYOUT_FEATURE_MAJOR, clustered=s >= 128)
-            z, _ = mlp_mod.forward_raw(self.weights, self.biases, None, pe, 0, pe.shape[0], s, False, self.operands)
+            if self.operands is None:
+                z = mlp_mod.apply_net(model.density_net, None, pe, 0, pe.shape[0], s)
+            else:
+                z, _ = mlp_mod.forward_raw(self.weights, self.biases, None, pe, 0, pe.shape[0], s, False, self.operands)
             out[begin : begin + m] = F.softplus(z[0].view(m, s)).mean(-1)
         return out
 

@@ -8,9 +8,9 @@ Both are ``nn.Module``s with one flat fp32 ``params`` Parameter, as in
 tinycudann's PyTorch binding.  ``Encoding`` runs the gfx950 hash-grid kernels.
 ``Network`` is the bias-free MLP tinycudann provides ("CutlassMLP" /
 "FullyFusedMLP"); it runs on the fused MFMA kernels of ``csrc/mlp.hip`` with
-half-precision (bf16) matrix operands and fp32 accumulation.  There is no
-library-GEMM or CPU path: shapes the kernels do not cover are refused when the
-module is constructed.
+half-precision (bf16) matrix operands and fp32 accumulation; shapes the kernels
+do not cover (other widths, more than three hidden layers) are evaluated on
+library GEMMs over the same flat parameters, with a warning.  No CPU path.
 """
 import math
 
@@ -66,13 +66,6 @@ class Network(nn.Module):
         pad_out = (n_output_dims + 15) // 16 * 16
         dims = [n_input_dims] + [width] * depth + [pad_out]
         self.shapes = [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]
-        from . import mlp as mlp_mod
-
-        if not mlp_mod.supported(self):
-            raise NotImplementedError(
-                f"tinycudann.Network {dims} ({self.activation}/{self.output_activation}): the fused MLP kernels cover "
-                "ReLU networks of width 64 with 1-3 hidden layers, at most 64 inputs and 16 outputs; no library-GEMM "
-                "fallback is provided")
         g = torch.Generator().manual_seed(seed)
         chunks = []
         for o, i in self.shapes:  # xavier-uniform, tinycudann's default
@@ -84,4 +77,22 @@ class Network(nn.Module):
         """(N, n_input_dims) -> (N, n_output_dims) fp32 (tinycudann returns half; every consumer here casts up)."""
         from . import mlp as mlp_mod
 
-        return mlp_mod.flat_network(self, x)
+        if mlp_mod.supported(self):
+            return mlp_mod.flat_network(self, x)
+        # shapes outside the fused kernels (tinycudann takes any n_neurons / n_hidden_layers its CutlassMLP supports): library
+        # GEMMs on the same flat parameters, fp32
+        if not Network._warned:
+            Network._warned = True
+            import logging
+
+            logging.warning("tinycudann.Network %s is outside the fused HIP kernels: evaluated on library GEMMs", self.shapes)
+        act = {"ReLU": torch.relu, "None": lambda t: t}[self.activation]
+        off, h = 0, x.to(self.params.dtype)
+        for li, (o, i) in enumerate(self.shapes):
+            h = h @ self.params[off : off + o * i].view(o, i).t()
+            off += o * i
+            if li < len(self.shapes) - 1:
+                h = act(h)
+        return h[..., : self.n_output_dims]
+
+    _warned = False

@@ -155,7 +155,9 @@ def ncc_loss(I: torch.Tensor, J: torch.Tensor, mask: Optional[torch.Tensor] = No
     else:
         I, J = I.reshape(-1, 1, *I.shape[2:]), J.reshape(-1, 1, *J.shape[2:])
         w = 2 * int(win / 2**level / 2) + 1
-        if I.is_cuda:  # the box window is separable: w shifted adds per axis instead of a convolution (see gaussian_blur)
+        if I.is_cuda and not (torch.is_grad_enabled() and (I.requires_grad or J.requires_grad)):
+            # the box window is separable: w shifted adds per axis instead of a convolution (see gaussian_blur).  Under
+            # autograd the convolution below is kept: one graph node per window instead of one per tap
 
             def avg(t):
                 for d in range(nd):

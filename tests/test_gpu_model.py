@@ -428,3 +428,33 @@ def test_train_data_parallel_rccl_two_gpus(tmp_path):
         for k in a:
             assert torch.equal(a[k], b[k]), k
         assert all(torch.isfinite(v).all() for v in a.values())
+
+
+def test_direct_step_runs_without_autograd(device, golden):
+    """The autograd-free step must not record a graph (it writes gradients itself): grad mode is off inside ``run`` and
+    the returned losses carry no grad_fn; the caller's grad mode is untouched."""
+    from nesvor_amd.fused import FusedTrainer
+
+    m, args = _load_model(golden, "", {}, device)
+    t = FusedTrainer(m, args)
+    assert t.direct is not None
+    seen = []
+    import nesvor_amd.sampler as sampler_mod
+
+    orig = sampler_mod.forward_raw
+
+    def spy(*a, **k):
+        seen.append(torch.is_grad_enabled())
+        return orig(*a, **k)
+
+    sampler_mod.forward_raw = spy
+    try:
+        d = lambda k: torch.tensor(golden[f"fw_{k}"]).to(device)
+        assert torch.is_grad_enabled()
+        losses = t.direct.run(d("xyz"), d("v"), d("idx"), d("noise"))
+        assert torch.is_grad_enabled()
+    finally:
+        sampler_mod.forward_raw = orig
+    assert seen == [False]
+    assert all(v.grad_fn is None and not v.requires_grad for v in losses.values())
+    t.optimizer_step()

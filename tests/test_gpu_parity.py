@@ -209,12 +209,14 @@ def test_shared_noise_training_matches_oracle_within_0p1_db(device):
     assert p_hip > 8.0 and abs(p_hip - p_cpu) <= 0.1
 
 
-@pytest.mark.parametrize("width,depth", [(40, 1), (32, 2), (64, 3)])
+@pytest.mark.parametrize("width,depth", [(40, 1), (32, 2), (64, 3), (128, 1), (64, 4), (96, 5)])
 def test_other_widths_and_depths_match_oracle_losses(device, width, depth):
     """``--width`` / ``--depth`` are free in the reference (cli/main.py:68-73).  Widths below 64 run zero-padded on the
     64-wide kernels (nesvor_amd.mlp.kernel_params: the same function, evaluated exactly), three hidden layers run on the
-    separate dX / dW kernels; both train through the autograd path.  Held to the oracle's restatement of the reference
-    loop from the same random stream: every loss of the first 10 iterations to rtol 1e-4."""
+    separate dX / dW kernels; wider / deeper networks (128 x 1, 64 x 4, 96 x 5) keep sampler, hash grid and loss on the HIP
+    kernels and evaluate their matrix products on library GEMMs (nesvor_amd.mlp.library_mlp).  All train through the
+    autograd path.  Held to the oracle's restatement of the reference loop from the same random stream: every loss of the
+    first 10 iterations to rtol 1e-4."""
     from nesvor_amd.phantom import phantom3d, simulate_stacks
     from nesvor_amd.train import Dataset, train
     from oracle import train_loop as otl

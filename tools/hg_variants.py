@@ -19,7 +19,7 @@ if len(sys.argv) > 1 and sys.argv[1] != "run":
         source = os.path.join(src, "hashgrid.hip")
         flist = [f for f in flags.split(",") if f]
         for f in list(flist):
-            if f.startswith("src="):  # another version of the source file (e.g. tools/hashgrid_r1.hip.txt: the round-1 kernel)
+            if f.startswith("src="):  # another version of the source file (e.g. an older kernel written out of the history: git show <rev>:nesvor_amd/csrc/hashgrid.hip > /tmp/old.hip)
                 flist.remove(f)
                 source = f"{out}/{name}.hip"
                 text = open(os.path.join(ROOT, f[4:])).read().replace('"../../include/nesvor_hip.h"', '"nesvor_hip.h"').replace('"common.h"', f'"{src}/common.h"')
