@@ -212,11 +212,17 @@ def mat2point(mat: torch.Tensor, sx, sy, rs) -> torch.Tensor:
 
 # -- applying transforms to points -----------------------------------------
 def mat_transform_points(mat: torch.Tensor, x: torch.Tensor, trans_first: bool) -> torch.Tensor:
-    """mat (*,3,4), x (*,3) with broadcasting (transform.py:259-271)."""
-    R, T = mat[..., :-1], mat[..., -1:]
-    x = x[..., None]
-    x = R @ (x + T) if trans_first else R @ x + T
-    return x[..., 0]
+    """mat (*,3,4), x (*,3) with broadcasting (transform.py:259-271): R (x + T) for ``trans_first``, else R x + T.
+    Evaluated without the broadcast batched matmul the formula suggests: one 3x3 matrix for all points is a plain
+    (n,3) x (3,3) product, per-point matrices are nine broadcast multiply-adds.  (rocBLAS runs a batch of 3x3 by 3x1
+    products at ~7 ms per million and faults at batch counts beyond ~2^24 - the 0.5 mm lattice of a 128^3 volume.)"""
+    R, T = mat[..., :3], mat[..., 3]
+    y = x + T if trans_first else x
+    if R.numel() == 9:
+        out = y @ R.reshape(3, 3).t()
+    else:
+        out = torch.stack([(R[..., i, :] * y).sum(-1) for i in range(3)], -1)
+    return out if trans_first else out + T
 
 
 def ax_transform_points(ax: torch.Tensor, x: torch.Tensor, trans_first: bool) -> torch.Tensor:

@@ -1,0 +1,163 @@
+// fp32 -> three bf16 planes (hi, mid, lo; x = hi + mid + lo up to 2^-24 |x|): instruction count and exactness of
+// alternative formulations of split3() (csrc/mlp.hip).
+//   A  cvt_pk_bf16 / shift+and widen / v_sub                                  (22 VALU per 4 values)
+//   B  cvt_pk_bf16 / residual by v_dot2_f32_bf16 (x - hi in ONE instruction:  (14 VALU per 4 values)
+//      dot2((hi_lo, hi_hi), (-1, 0)) + x picks and subtracts one half of the packed pair)
+//   C  as B with v_dot2c_f32_bf16 (VOP2 accumulate form)
+// Every variant's planes are compared bit for bit with A's on random, tiny, huge and special inputs.
+// hipcc --offload-arch=gfx950 -O3 tools/split_probe.hip -o /tmp/splitp && /tmp/splitp
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cmath>
+#include <vector>
+#include <cstring>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+struct Split3 { s16x4 hi, mid, lo; };
+
+__device__ __forceinline__ s16x4 pack_bf16(const f32x4& v) { return __builtin_bit_cast(s16x4, __builtin_convertvector(v, bf16x4)); }
+__device__ __forceinline__ f32x4 widen_bf16(const s16x4& v) {
+  const uint2 u = __builtin_bit_cast(uint2, v);
+  return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
+}
+__device__ __forceinline__ Split3 split_a(const f32x4& v) {
+  Split3 s;
+  s.hi = pack_bf16(v);
+  const f32x4 r1 = v - widen_bf16(s.hi);
+  s.mid = pack_bf16(r1);
+  s.lo = pack_bf16(r1 - widen_bf16(s.mid));
+  return s;
+}
+// x - (one half of a packed bf16 pair): v_dot2_f32_bf16 D = S0.lo S1.lo + S0.hi S1.hi + S2
+__device__ __forceinline__ float sub_lo(float x, uint32_t pair) {
+  float d;
+  asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(d) : "v"(pair), "s"(0x0000BF80u), "v"(x));
+  return d;
+}
+__device__ __forceinline__ float sub_hi(float x, uint32_t pair) {
+  float d;
+  asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(d) : "v"(pair), "s"(0xBF800000u), "v"(x));
+  return d;
+}
+__device__ __forceinline__ Split3 split_b(const f32x4& v) {
+  Split3 s;
+  s.hi = pack_bf16(v);
+  uint2 h = __builtin_bit_cast(uint2, s.hi);
+  const f32x4 r1 = f32x4{sub_lo(v[0], h.x), sub_hi(v[1], h.x), sub_lo(v[2], h.y), sub_hi(v[3], h.y)};
+  s.mid = pack_bf16(r1);
+  uint2 m = __builtin_bit_cast(uint2, s.mid);
+  const f32x4 r2 = f32x4{sub_lo(r1[0], m.x), sub_hi(r1[1], m.x), sub_lo(r1[2], m.y), sub_hi(r1[3], m.y)};
+  s.lo = pack_bf16(r2);
+  return s;
+}
+__device__ __forceinline__ float subc_lo(float x, uint32_t pair) {
+  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(x) : "v"(pair), "v"(0x0000BF80u));
+  return x;
+}
+__device__ __forceinline__ float subc_hi(float x, uint32_t pair) {
+  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(x) : "v"(pair), "v"(0xBF800000u));
+  return x;
+}
+__device__ __forceinline__ Split3 split_c(const f32x4& v) {
+  Split3 s;
+  s.hi = pack_bf16(v);
+  uint2 h = __builtin_bit_cast(uint2, s.hi);
+  const f32x4 r1 = f32x4{subc_lo(v[0], h.x), subc_hi(v[1], h.x), subc_lo(v[2], h.y), subc_hi(v[3], h.y)};
+  s.mid = pack_bf16(r1);
+  uint2 m = __builtin_bit_cast(uint2, s.mid);
+  const f32x4 r2 = f32x4{subc_lo(r1[0], m.x), subc_hi(r1[1], m.x), subc_lo(r1[2], m.y), subc_hi(r1[3], m.y)};
+  s.lo = pack_bf16(r2);
+  return s;
+}
+
+template <int V> __device__ __forceinline__ Split3 split(const f32x4& v) {
+  if constexpr (V == 0) return split_a(v);
+  else if constexpr (V == 1) return split_b(v);
+  else return split_c(v);
+}
+
+template <int V>
+__global__ void check(const float* x, uint32_t* out, int n) {  // out: 6 words per 4 inputs
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (4 * i + 3 >= n) return;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+  const Split3 s = split<V>(v);
+  const uint2 a = __builtin_bit_cast(uint2, s.hi), b = __builtin_bit_cast(uint2, s.mid), c = __builtin_bit_cast(uint2, s.lo);
+  uint32_t* o = out + 6 * i;
+  o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; o[4] = c.x; o[5] = c.y;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void timeit(float* out, int rounds) {
+  f32x4 v[4];
+  for (int i = 0; i < 4; ++i) v[i] = f32x4{threadIdx.x * 0.001f + i, 1.f + i, 2.f - i, 0.5f * i + 0.25f};
+  uint32_t acc = 0;
+  for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const Split3 sp = split<V>(v[s & 3]);
+      const uint2 a = __builtin_bit_cast(uint2, sp.hi), b = __builtin_bit_cast(uint2, sp.mid), c = __builtin_bit_cast(uint2, sp.lo);
+      acc ^= a.x ^ a.y ^ b.x ^ b.y ^ c.x ^ c.y;              // 6 xor: keeps the planes live
+      const uint32_t t = acc & 0x7u;                         // + 5 ops: all four inputs of this register's next split depend on this one
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[s & 3][k] = __uint_as_float(__float_as_uint(v[s & 3][k]) ^ t);
+    }
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = __uint_as_float(acc);
+}
+
+template <int V> float time_variant() {
+  float* out; hipMalloc(&out, sizeof(float) * 256 * 1024);
+  hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
+  hipLaunchKernelGGL(timeit<V>, dim3(1024), dim3(256), 0, 0, out, 10); hipDeviceSynchronize();
+  hipEventRecord(s); hipLaunchKernelGGL(timeit<V>, dim3(1024), dim3(256), 0, 0, out, 4000); hipEventRecord(e); hipEventSynchronize(e);
+  float ms; hipEventElapsedTime(&ms, s, e);
+  hipFree(out);
+  return ms * 1e6f / (4000.f * 16.f);  // ns per split (+ 11 bookkeeping ops) at one wave per SIMD
+}
+
+int main() {
+  const int n = 1 << 22;
+  std::vector<float> h(n);
+  uint64_t st = 88172645463325252ull;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+  for (int i = 0; i < n; ++i) {
+    const uint32_t bits = (uint32_t)rnd();
+    float f;
+    if (i < n / 2) { memcpy(&f, &bits, 4); if (std::isnan(f) || std::isinf(f)) f = 1.f; }  // every exponent, incl. denormals
+    else f = (float)((double)(int32_t)bits / 2147483648.0) * std::pow(10.f, (float)((int)(rnd() % 13) - 8));
+    h[i] = f;
+  }
+  h[0] = 0.f; h[1] = -0.f; h[2] = 1.f; h[3] = -1.f; h[4] = 1.00390625f; h[5] = 3.3895314e38f; h[6] = 1.17549435e-38f; h[7] = 1e-45f;
+  float* dx; uint32_t *da, *db; hipMalloc(&dx, 4 * n); hipMalloc(&da, 6 * n); hipMalloc(&db, 6 * n);
+  hipMemcpy(dx, h.data(), 4 * n, hipMemcpyHostToDevice);
+  std::vector<uint32_t> ra(6 * (n / 4)), rb(6 * (n / 4));
+  hipLaunchKernelGGL(check<0>, dim3(n / 4 / 256), dim3(256), 0, 0, dx, da, n);
+  hipMemcpy(ra.data(), da, 4 * ra.size(), hipMemcpyDeviceToHost);
+  const char* names[3] = {"A widen + sub", "B v_dot2_f32_bf16", "C v_dot2c_f32_bf16"};
+  for (int var = 1; var < 3; ++var) {
+    if (var == 1) hipLaunchKernelGGL(check<1>, dim3(n / 4 / 256), dim3(256), 0, 0, dx, db, n);
+    else hipLaunchKernelGGL(check<2>, dim3(n / 4 / 256), dim3(256), 0, 0, dx, db, n);
+    hipMemcpy(rb.data(), db, 4 * rb.size(), hipMemcpyDeviceToHost);
+    long bad = 0, bad_normal = 0; int first = -1;
+    for (size_t w = 0; w < ra.size(); ++w) if (ra[w] != rb[w]) {
+      ++bad;
+      const size_t quad = w / 6; bool normal = true;
+      for (int k = 0; k < 4; ++k) normal = normal && std::fabs(h[4 * quad + k]) > 1e-30f;   // planes of tiny inputs reach denormals
+      if (normal) { ++bad_normal; if (first < 0) first = (int)w; }
+    }
+    printf("%-22s words differing from A: %ld of %zu (%ld of them with all four inputs above 1e-30)\n", names[var], bad, ra.size(), bad_normal);
+    if (first >= 0) {
+      const size_t quad = first / 6;
+      printf("   first: inputs %.9g %.9g %.9g %.9g  word %d: A %08x vs %08x\n", h[4 * quad], h[4 * quad + 1], h[4 * quad + 2], h[4 * quad + 3], first % 6, ra[first], rb[first]);
+    }
+  }
+  printf("A widen + sub      : %.2f ns per split\n", time_variant<0>());
+  printf("B v_dot2_f32_bf16  : %.2f ns per split\n", time_variant<1>());
+  printf("C v_dot2c_f32_bf16 : %.2f ns per split\n", time_variant<2>());
+  return 0;
+}
