@@ -354,6 +354,63 @@ int nesvor_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_
  * ld > cols, a column range of it (one layer's weights when the model keeps no biases, tinycudann.Network). */
 int nesvor_sum_rows(const float* in, float* out, int rows, int cols, int ld, void* stream);
 
+/* ------------------------------------------------------------------------
+ * One training iteration behind one entry point (csrc/step.hip).  Replaces the loop body of the reference's train()
+ * (nesvor/nesvor/train.py:179-197: NeSVoR.forward models.py:260-327, loss.backward(), optimizer.step(), zero_grad()):
+ * the host enqueues every launch of the iteration - sampler, hash grid, MLPs, imaging loss, the backwards, per-slice
+ * gradients, AdamW - with one call, into workspace buffers the caller allocated once for (B, S).  All pointers are device
+ * pointers unless stated; gradients go straight into the caller's (flat) gradient buffer, which the AdamW step zero-fills.
+ *   switches   : opt_T = !no_transformation_optimization, has_lv = !no_pixel_variance, has_c = !no_slice_scale,
+ *                has_lvs = !no_slice_variance, has_b = n_levels_bias > 0 (cli/main.py:61,86-110)
+ *   small      : n (1 + 12 + 13) floats: slice scale c | pose matrices | zeroed accumulators [dc | dmat]
+ *   saved_*    : per hidden layer N_pad16 * 64 floats (nesvor_mlp_forward);  partial: NESVOR_STEP_MLP_PARTIALS x (largest
+ *                network's parameter count) floats;  losses (run argument): 6 floats {MSE, logVar, MSE+logVar, transReg,
+ *                imageReg, biasReg} (models.py:14-19)
+ *   queue_scale: HOST array (nesvor_hashgrid_backward);  side_stream: a second stream of the same device (pose regulariser,
+ *                owner pass of the hash-grid backward); with overlap_owner the table gradient is complete only behind the
+ *                side stream - the step joins it itself before its own AdamW, a caller that runs the optimizer makes
+ *                its stream wait for side_stream
+ * nesvor_step_run(phase = 0): the whole iteration.  Data parallel: phase 1 = everything up to and including the hash-grid
+ * backward of levels [split_level, L) (the host then starts the all-reduce of that part of the table gradient), phase 2 =
+ * the remaining levels and the rest of the iteration.  adam == NULL: no optimizer step (the caller reduces gradients first).
+ * The PSF noise is drawn inside the sampler kernels from (seed, offset) as in nesvor_psf_transform_forward_rng.
+ * ---------------------------------------------------------------------- */
+#define NESVOR_STEP_MLP_PARTIALS 256
+typedef struct {
+  nesvor_grid_t grid;
+  nesvor_mlp_t density, sigma, bias_net;   /* weights / biases: the model's parameters; bf16_operands: evaluation mode */
+  int32_t B, S, n_slices;
+  int32_t opt_T, has_lv, has_c, has_lvs, has_b;
+  int32_t n_features_z, ks, kb_bias;       /* ks: slice-embedding width fed to sigma_net / b_net (0: none); kb_bias: rows of pe b_net sees */
+  int32_t reg_type;                        /* 0 edge, 1 TV, 2 L2 */
+  int32_t overlap_owner;                   /* owner pass of the hash-grid backward on side_stream */
+  float delta, w_T;
+  const float *axisangle, *axisangle_init, *psf_sigma, *bounding_box, *logit_coef, *log_var_slice, *slice_embedding, *table;
+  float *g_axisangle, *g_logit_coef, *g_log_var_slice, *g_slice_embedding, *g_table, *g_density, *g_sigma, *g_bias_net;
+  int32_t n_density_params, n_sigma_params, n_bias_params;
+  const float* gw;                         /* 4 upstream gradients d total / d {MSE, logVar, imageReg, biasReg} */
+  float *flat_param, *flat_grad, *flat_exp_avg, *flat_exp_avg_sq;
+  int64_t flat_numel;
+  float *small, *x, *u, *pe, *z, *log_var, *log_bias, *se, *dz, *dlv, *dlb, *dxl, *loss_pix, *pix, *dpe, *dpe_b, *du, *dpix,
+      *dxa, *dxa_b, *trans_terms, *g_trans, *lb_mean, *mean_scratch, *partial;
+  float* saved_d[NESVOR_MAX_MLP_LAYERS];
+  float* saved_s[NESVOR_MAX_MLP_LAYERS];
+  float* saved_b[NESVOR_MAX_MLP_LAYERS];
+  void* hg_workspace;
+  const float* queue_scale;
+  void* side_stream;
+} nesvor_step_t;
+
+typedef struct {
+  float lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2, grad_scale;
+} nesvor_adamw_t;
+
+void* nesvor_step_create(const nesvor_step_t* desc);                 /* NULL on failure */
+int nesvor_step_update(void* step, const nesvor_step_t* desc);       /* pointers / sizes changed (e.g. a re-made workspace) */
+void nesvor_step_destroy(void* step);
+int nesvor_step_run(void* step, const float* xyz, const float* v, const int64_t* slice_idx, uint64_t seed, uint64_t offset,
+                    float* losses, int phase, int split_level, const nesvor_adamw_t* adam, void* stream);
+
 /* ----------------------------------------------------------------------
  * Similarity sums of the stack registration.  Replaces, per optimisation step of `VVR`
  * (nesvor/svort/registration.py:143-247), the K = 1 + 2 x 6 successive evaluations of

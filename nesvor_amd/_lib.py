@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NESVOR_HIP_LIB: load another build of the same ABI (tools/ablate_hashgrid.py times variants of one kernel this way)
 LIB_PATH = os.environ.get("NESVOR_HIP_LIB") or os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -53,6 +53,36 @@ class LossT(Structure):
         "z0", "log_var", "log_bias", "x", "v", "slice_idx", "c", "log_var_slice", "log_bias_mean", "gw",
         "loss_pix", "dz0", "dlog_var", "dlog_bias", "dx", "dc_pix", "dlvs_pix")] + [
         ("B", c_int32), ("S", c_int32), ("reg_type", c_int32), ("delta", c_float)]
+
+
+class StepT(Structure):
+    """Mirror of nesvor_step_t (one training iteration behind one entry point, csrc/step.hip)."""
+
+    _fields_ = (
+        [("grid", GridT), ("density", MlpT), ("sigma", MlpT), ("bias_net", MlpT)]
+        + [(n, c_int32) for n in ("B", "S", "n_slices", "opt_T", "has_lv", "has_c", "has_lvs", "has_b", "n_features_z", "ks", "kb_bias",
+                                  "reg_type", "overlap_owner")]
+        + [("delta", c_float), ("w_T", c_float)]
+        + [(n, c_void_p) for n in ("axisangle", "axisangle_init", "psf_sigma", "bounding_box", "logit_coef", "log_var_slice",
+                                   "slice_embedding", "table")]
+        + [(n, c_void_p) for n in ("g_axisangle", "g_logit_coef", "g_log_var_slice", "g_slice_embedding", "g_table", "g_density", "g_sigma",
+                                   "g_bias_net")]
+        + [(n, c_int32) for n in ("n_density_params", "n_sigma_params", "n_bias_params")]
+        + [("gw", c_void_p)]
+        + [(n, c_void_p) for n in ("flat_param", "flat_grad", "flat_exp_avg", "flat_exp_avg_sq")]
+        + [("flat_numel", c_int64)]
+        + [(n, c_void_p) for n in ("small", "x", "u", "pe", "z", "log_var", "log_bias", "se", "dz", "dlv", "dlb", "dxl", "loss_pix", "pix",
+                                   "dpe", "dpe_b", "du", "dpix", "dxa", "dxa_b", "trans_terms", "g_trans", "lb_mean", "mean_scratch",
+                                   "partial")]
+        + [("saved_d", c_void_p * 4), ("saved_s", c_void_p * 4), ("saved_b", c_void_p * 4)]
+        + [("hg_workspace", c_void_p), ("queue_scale", c_void_p), ("side_stream", c_void_p)]
+    )
+
+
+class AdamwT(Structure):
+    """Mirror of nesvor_adamw_t."""
+
+    _fields_ = [(n, c_float) for n in ("lr", "beta1", "beta2", "eps", "weight_decay", "bias_correction1", "bias_correction2", "grad_scale")]
 
 
 _lib = None
@@ -113,6 +143,10 @@ _SIGNATURES = {
         c_int,
     ),
     "nesvor_sum_rows": ([_P, _P, c_int, c_int, c_int, _P], c_int),
+    "nesvor_step_create": ([POINTER(StepT)], c_void_p),
+    "nesvor_step_update": ([_P, POINTER(StepT)], c_int),
+    "nesvor_step_destroy": ([_P], None),
+    "nesvor_step_run": ([_P, _P, _P, _P, c_uint64, c_uint64, _P, c_int, c_int, POINTER(AdamwT), _P], c_int),
     "nesvor_vvr_similarity": ([_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P], c_int),
 }
 

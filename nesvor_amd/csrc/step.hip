@@ -1,0 +1,234 @@
+// One NeSVoR training iteration behind ONE entry point.
+//
+// Replaces the loop body of the reference's train() (nesvor/nesvor/train.py:179-197: NeSVoR.forward
+// models.py:260-327, loss.backward(), optimizer.step(), zero_grad()) as a fixed sequence of the native launches of
+// this library.  nesvor_amd/direct.py issues the same sequence from Python - ~27 ctypes calls and ~20 tensor
+// allocations per iteration, 0.42 ms of host time - which is what bounds the iteration once a GPU's share of the batch
+// is small (BASELINE C2: 2^18 points; C3 read literally: 2^17 points per GPU on 8 GPUs need 0.2 ms of GPU time).
+// Here the host enqueues everything in one call, into workspace buffers the caller allocated once:
+//
+//   side stream : pose regulariser (serial chain per slice)           ...            owner pass of the hash-grid backward
+//   main stream : prologue | sampler | hash grid | MLPs | loss | MLP backwards | aggregation pass | sampler backward
+//                 | per-slice gradients | epilogue | [AdamW]
+//
+// The configuration switches are those of the reference's args (no_transformation_optimization, no_pixel_variance,
+// no_slice_scale, no_slice_variance, n_levels_bias).  Data-parallel runs call the step in two phases so that the host
+// can start the all-reduce of the fine levels' gradient in between (nesvor_amd/ddp.py).
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <new>
+#include "../../include/nesvor_hip.h"
+
+namespace {
+
+struct StepCtx {
+  nesvor_step_t d;
+  hipEvent_t ev_fork, ev_pose, ev_agg, ev_owner;
+};
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx,
+                                                          float* __restrict__ out, int B, int k) {
+  const int i = blockIdx.x * 256 + threadIdx.x;  // one float per thread
+  if (i >= B * k) return;
+  const int b = i / k, c = i - b * k;
+  out[i] = table[(size_t)idx[b] * k + c];
+}
+
+// out[0] = mean(x[0..n)) in two launches (deterministic order): partial sums of 256 workgroups, then one wave
+__global__ __launch_bounds__(256) void mean_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void mean_final_kernel(const float* __restrict__ partial, int n_partial, float scale, float* __restrict__ out) {
+  __shared__ float red[256];
+  red[threadIdx.x] = (int)threadIdx.x < n_partial ? partial[threadIdx.x] : 0.f;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 a = *reinterpret_cast<float4*>(dst + i);
+    const float4 b = *reinterpret_cast<const float4*>(src + i);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    *reinterpret_cast<float4*>(dst + i) = a;
+  } else {
+    for (int64_t k = i; k < n; ++k) dst[k] += src[k];
+  }
+}
+
+// biasReg = (mean log_bias)^2 (models.py:322-323) into losses[5]
+__global__ void square_kernel(const float* __restrict__ m, float* __restrict__ out) { out[0] = m[0] * m[0]; }
+
+#define NESVOR_TRY(expr)            \
+  do {                              \
+    const int e_ = (int)(expr);     \
+    if (e_ != 0) return e_;         \
+  } while (0)
+
+int mlp_backward_into(const nesvor_mlp_t& net, int group_sums, const float* xa, const float* xb, const float* dy,
+                      float* const* saved, float* dxa, float* dxb, float* partial, float* grad_segment, int n_params,
+                      int64_t N, hipStream_t st) {
+  nesvor_mlp_t d = net;
+  d.dxa_group_sums = group_sums;
+  float* no_scratch[NESVOR_MAX_MLP_LAYERS] = {nullptr, nullptr, nullptr, nullptr};  // fused dX + dW + db kernel: no dpre scratch
+  NESVOR_TRY(nesvor_mlp_backward(&d, xa, xb, dy, saved, no_scratch, dxa, dxb, partial, NESVOR_STEP_MLP_PARTIALS, N, st));
+  // per-workgroup partial sums (columns W0,b0,W1,b1,...) -> the network's segment of the flat gradient
+  return nesvor_sum_rows(partial, grad_segment, NESVOR_STEP_MLP_PARTIALS, n_params, n_params, st);
+}
+
+}  // namespace
+
+extern "C" void* nesvor_step_create(const nesvor_step_t* desc) {
+  if (desc == nullptr) return nullptr;
+  StepCtx* c = new (std::nothrow) StepCtx;
+  if (c == nullptr) return nullptr;
+  c->d = *desc;
+  hipEvent_t* evs[4] = {&c->ev_fork, &c->ev_pose, &c->ev_agg, &c->ev_owner};
+  for (hipEvent_t* e : evs) {
+    if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
+  }
+  return c;
+}
+
+extern "C" int nesvor_step_update(void* handle, const nesvor_step_t* desc) {
+  if (handle == nullptr || desc == nullptr) return (int)hipErrorInvalidValue;
+  static_cast<StepCtx*>(handle)->d = *desc;
+  return 0;
+}
+
+extern "C" void nesvor_step_destroy(void* handle) {
+  if (handle == nullptr) return;
+  StepCtx* c = static_cast<StepCtx*>(handle);
+  (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_pose); (void)hipEventDestroy(c->ev_agg); (void)hipEventDestroy(c->ev_owner);
+  delete c;
+}
+
+extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, const int64_t* slice_idx, uint64_t seed,
+                               uint64_t offset, float* losses, int phase, int split_level, const nesvor_adamw_t* adam,
+                               void* stream) {
+  if (handle == nullptr || xyz == nullptr || v == nullptr || slice_idx == nullptr || losses == nullptr) return (int)hipErrorInvalidValue;
+  StepCtx* ctx = static_cast<StepCtx*>(handle);
+  const nesvor_step_t& d = ctx->d;
+  hipStream_t main = (hipStream_t)stream, side = (hipStream_t)d.side_stream;
+  const int B = d.B, S = d.S, n = d.n_slices, L = d.grid.n_levels;
+  const int64_t N = (int64_t)B * S;
+  if (phase < 0 || phase > 2 || (phase != 0) != (split_level > 0 && split_level < L)) return (int)hipErrorInvalidValue;
+  if (d.has_b && phase != 0) return (int)hipErrorInvalidValue;  // the bias field's global mean needs the host's all-reduce: Python path
+  float* c = d.has_c ? d.small : nullptr;       // slice scale n softmax(logit_coef)
+  float* mat = d.small + n;                      // (n,3,4) pose matrices
+  float* acc = d.small + 13 * n;                 // [dc (n) | dmat (n,12)], zero-filled by the prologue
+  float* dc = acc;
+  float* dmat = acc + n;
+  const int layout = NESVOR_LAYOUT_FEATURE_MAJOR;
+
+  if (phase != 2) {
+    // pose regulariser: a serial chain per slice, independent of the batch -> side stream, joined at the epilogue
+    if (d.opt_T) {
+      if (hipEventRecord(ctx->ev_fork, main) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_fork, 0) != hipSuccess) return (int)hipGetLastError();
+      NESVOR_TRY(nesvor_trans_loss(d.axisangle, d.axisangle_init, d.trans_terms, d.g_trans, n, side));
+      if (hipEventRecord(ctx->ev_pose, side) != hipSuccess) return (int)hipGetLastError();
+    }
+    // ---- forward
+    NESVOR_TRY(nesvor_step_prologue(d.has_c ? d.logit_coef : nullptr, c, d.axisangle, mat, acc, 13 * n, n, main));
+    NESVOR_TRY(nesvor_psf_transform_forward_rng(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.x, d.u, B, S, main));
+    NESVOR_TRY(nesvor_hashgrid_forward(&d.grid, d.u, d.table, d.pe, N, layout | (S >= 128 ? NESVOR_LAYOUT_CLUSTERED : 0), main));
+    NESVOR_TRY(nesvor_mlp_forward(&d.density, nullptr, d.pe, d.z, d.saved_d, N, main));
+    if (d.ks > 0) {
+      hipLaunchKernelGGL(gather_rows_kernel, dim3((B * d.ks + 255) / 256), dim3(256), 0, main, d.slice_embedding, slice_idx, d.se, B, d.ks);
+    }
+    if (d.has_b) {
+      NESVOR_TRY(nesvor_mlp_forward(&d.bias_net, d.se, d.pe, d.log_bias, d.saved_b, N, main));
+      hipLaunchKernelGGL(mean_partial_kernel, dim3(256), dim3(256), 0, main, d.log_bias, N, d.mean_scratch);
+      hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(256), 0, main, d.mean_scratch, 256, 1.f / (float)N, d.lb_mean);
+    }
+    if (d.has_lv) NESVOR_TRY(nesvor_mlp_forward(&d.sigma, d.se, d.z, d.log_var, d.saved_s, N, main));
+    // ---- losses: values and gradients in one launch
+    const int z_rows = 1 + d.n_features_z, written = 1 + (d.has_lv ? d.n_features_z : 0);
+    if (written < z_rows) {
+      if (hipMemsetAsync(d.dz + (size_t)written * N, 0, sizeof(float) * (size_t)(z_rows - written) * N, main) != hipSuccess) return (int)hipGetLastError();
+    }
+    nesvor_loss_t la;
+    std::memset(&la, 0, sizeof(la));
+    la.z0 = d.z; la.log_var = d.has_lv ? d.log_var : nullptr; la.log_bias = d.has_b ? d.log_bias : nullptr;
+    la.x = d.x; la.v = v; la.slice_idx = slice_idx; la.c = c; la.log_var_slice = d.has_lvs ? d.log_var_slice : nullptr;
+    la.log_bias_mean = d.has_b ? d.lb_mean : nullptr;
+    la.gw = d.gw; la.loss_pix = d.loss_pix; la.dz0 = d.dz; la.dlog_var = d.has_lv ? d.dlv : nullptr;
+    la.dlog_bias = d.has_b ? d.dlb : nullptr; la.dx = d.opt_T ? d.dxl : nullptr;
+    la.dc_pix = d.has_c ? d.pix : nullptr; la.dlvs_pix = d.has_lvs ? d.pix + B : nullptr;
+    la.B = B; la.S = S; la.reg_type = d.reg_type; la.delta = d.delta;
+    NESVOR_TRY(nesvor_imaging_loss(&la, main));
+    // ---- backward through the networks
+    const int group_sums = (N % 16 == 0 && S % 16 == 0 && d.ks % 16 == 0) ? 1 : 0;
+    if (d.has_lv)
+      NESVOR_TRY(mlp_backward_into(d.sigma, group_sums, d.se, d.z, d.dlv, d.saved_s, d.ks ? d.dxa : nullptr, d.dz + N, d.partial,
+                                   d.g_sigma, d.n_sigma_params, N, main));
+    NESVOR_TRY(mlp_backward_into(d.density, 0, nullptr, d.pe, d.dz, d.saved_d, nullptr, d.dpe, d.partial, d.g_density,
+                                 d.n_density_params, N, main));
+    if (d.has_b) {
+      NESVOR_TRY(mlp_backward_into(d.bias_net, group_sums, d.se, d.pe, d.dlb, d.saved_b, d.ks ? d.dxa_b : nullptr, d.dpe_b, d.partial,
+                                   d.g_bias_net, d.n_bias_params, N, main));
+      const int64_t nb = (int64_t)d.kb_bias * N;
+      hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((nb / 4 + 255) / 256 + 1)), dim3(256), 0, main, d.dpe, d.dpe_b, nb);
+    }
+  }
+  // ---- hash-grid backward (+ input gradient when the poses are optimised)
+  float* du = d.opt_T ? d.du : nullptr;
+  if (phase == 0) {
+    NESVOR_TRY(nesvor_hashgrid_backward_levels(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 1, 0, L,
+                                               d.queue_scale, main));
+    if (d.overlap_owner) {
+      // the owner pass only finishes grad_table: it runs under the sampler backward and the per-slice bookkeeping
+      if (hipEventRecord(ctx->ev_agg, main) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_agg, 0) != hipSuccess) return (int)hipGetLastError();
+      NESVOR_TRY(nesvor_hashgrid_backward_levels(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 2, 0, L,
+                                                 d.queue_scale, side));
+      if (hipEventRecord(ctx->ev_owner, side) != hipSuccess) return (int)hipGetLastError();
+    } else {
+      NESVOR_TRY(nesvor_hashgrid_backward_levels(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 2, 0, L,
+                                                 d.queue_scale, main));
+    }
+  } else if (phase == 1) {
+    // fine levels first (the end of the flat gradient): the host starts their all-reduce when this call returns
+    return nesvor_hashgrid_backward_levels(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 3, split_level, L,
+                                           d.queue_scale, main);
+  } else {
+    NESVOR_TRY(nesvor_hashgrid_backward_levels(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 3 | 4 | 8, 0,
+                                               split_level, d.queue_scale, main));
+  }
+  if (d.opt_T)
+    NESVOR_TRY(nesvor_psf_transform_backward_rng(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.dxl, du, d.dpix, B, S, main));
+  // ---- per-slice parameters
+  const int group_sums = (N % 16 == 0 && S % 16 == 0 && d.ks % 16 == 0) ? 1 : 0;
+  const int rows_per_pixel = group_sums ? S / 16 : S;
+  const float* dxa_first = (d.has_lv && d.ks) ? d.dxa : ((d.has_b && d.ks) ? d.dxa_b : nullptr);
+  NESVOR_TRY(nesvor_slice_grads(slice_idx, d.has_c ? d.pix : nullptr, d.has_lvs ? d.pix + B : nullptr, dxa_first, d.opt_T ? d.dpix : nullptr, dc,
+                                d.has_lvs ? d.g_log_var_slice : nullptr, d.ks ? d.g_slice_embedding : nullptr, dmat, B, rows_per_pixel, d.ks, main));
+  if (d.has_lv && d.has_b && d.ks)  // second consumer of the slice embedding
+    NESVOR_TRY(nesvor_slice_grads(slice_idx, nullptr, nullptr, d.dxa_b, nullptr, nullptr, nullptr, d.g_slice_embedding, nullptr, B, rows_per_pixel,
+                                  d.ks, main));
+  if (d.opt_T && hipStreamWaitEvent(main, ctx->ev_pose, 0) != hipSuccess) return (int)hipGetLastError();
+  const float img_scale = (d.reg_type == 0 ? d.delta : 1.f) / (float)N, img_off = d.reg_type == 0 ? -d.delta : 0.f;
+  NESVOR_TRY(nesvor_step_epilogue(d.has_c ? dc : nullptr, c, d.has_c ? d.g_logit_coef : nullptr, d.opt_T ? dmat : nullptr, d.axisangle,
+                                  d.opt_T ? d.g_trans : nullptr, d.w_T, d.opt_T ? d.g_axisangle : nullptr, d.loss_pix,
+                                  d.opt_T ? d.trans_terms : nullptr, losses, n, B, img_scale, img_off, main));
+  if (d.has_b) hipLaunchKernelGGL(square_kernel, dim3(1), dim3(1), 0, main, d.lb_mean, losses + 5);
+  if (adam != nullptr) {
+    if (phase == 0 && d.overlap_owner && hipStreamWaitEvent(main, ctx->ev_owner, 0) != hipSuccess) return (int)hipGetLastError();
+    NESVOR_TRY(nesvor_adamw_step(d.flat_param, d.flat_grad, d.flat_exp_avg, d.flat_exp_avg_sq, d.flat_numel, adam->lr, adam->beta1, adam->beta2,
+                                 adam->eps, adam->weight_decay, adam->bias_correction1, adam->bias_correction2, adam->grad_scale, 1, main));
+  }
+  return (int)hipGetLastError();
+}

@@ -7,6 +7,12 @@ zero-fills, the loss weighting) and the host falls behind the GPU.  Here the sam
 back-to-back in a fixed order and every parameter gradient is written straight into the flat gradient
 buffer.  Results equal the autograd path up to summation order (tests/test_gpu_model.py).
 
+Two issue paths for the same sequence of launches: ``_run_native`` hands the whole iteration to ONE C entry point
+(``nesvor_step_run``, csrc/step.hip: every launch enqueued by the library into buffers allocated once - the host side
+of an iteration drops from ~0.42 ms to a few tens of microseconds, which is what bounds the small per-GPU batches of
+BASELINE C2 / C3); ``run`` issues the launches from Python one by one (explicit PSF noise = the replay mode of the parity
+tests, per-kernel event timing, the half-precision model structure, NESVOR_STEP_NATIVE=0).
+
 Supported configurations: the fused single-precision model and the half-precision model structure (bias-free
 tinycudann networks, evaluated with bf16 matrix operands), MLPs of at most two hidden layers; anything else keeps the
 autograd path (FusedTrainer decides through ``supported``).
@@ -106,6 +112,8 @@ class DirectStep:
         self._owner_pending = False  # an owner pass of the hash-grid backward is running on the side stream
         self._kernel_noise = os.environ.get("NESVOR_PSF_NOISE", "kernel") != "tensor"
         self._noise_stream, self._noise_calls = 0x5851F42D4C957F2D, 0  # stream id of the training draws, calls so far
+        self._native = {}  # batch size -> (StepT, handle, buffers) of the one-call iteration (csrc/step.hip)
+        self._native_on = os.environ.get("NESVOR_STEP_NATIVE", "1") != "0"
         self.split_level = 0  # 0 = one launch; set by set_overlap() once a gradient all-reduce is installed
         self._split_candidate = 0
         if self.parallel and os.environ.get("NESVOR_DDP_OVERLAP", "1") != "0":
@@ -127,6 +135,167 @@ class DirectStep:
         early, self._early = self._early, None
         return early
 
+    # ------------------------------------------------------------------------------------------------ one-call iteration
+    def native_ready(self, noise=None) -> bool:
+        """The iteration can go through ``nesvor_step_run``: PSF noise drawn in the kernels, no per-kernel event timing, every
+        network's gradient one contiguous segment of the flat buffer (the single-precision model under FusedTrainer), and - for
+        the bias field under data parallelism, whose global mean needs the host's all-reduce mid-step - not that combination."""
+        if not (self._native_on and noise is None and self._kernel_noise and not _lib.kernel_timer.enabled):
+            return False
+        if self.bf16 is True and half_precision_model(self.model):
+            return False
+        nets = [self.d_net] + ([self.s_net] if self.has_lv else []) + ([self.b_net] if self.has_b else [])
+        if not all((not p.flat_params) and p.segment is not None and p.segment.numel() == sum(
+                w.numel() + b.numel() for w, b in zip(p.weights, p.biases)) for p in nets):
+            return False
+        return not (self.has_b and self.parallel)
+
+    def _native_state(self, B: int):
+        key = (B, mlp_mod.operand_mode(self.bf16), self._overlap_owner)  # (bench.py switches the evaluation mode of a live trainer)
+        st = self._native.get(key)
+        if st is not None:
+            return st
+        m, a, f = self.model, self.model.args, self.flat
+        dev = f.param.device
+        S, n = a.n_samples, m.n_slices
+        N = B * S
+        n_pad = (N + 15) // 16 * 16
+        enc = m.inr.encoding
+        E = enc.spec.n_output_dims
+        zr = 1 + a.n_features_z
+        buf = {}
+
+        def new(name, *shape):
+            buf[name] = torch.empty(shape, dtype=torch.float32, device=dev)
+            return buf[name].data_ptr()
+
+        d = _lib.StepT()
+        d.grid = enc.spec.c_struct
+        mode = self.bf16
+        d.density = mlp_mod._desc(self.d_net.weights, self.d_net.biases, 0, E, 0, S, mode)
+        n_par = lambda p: sum(w.numel() + b.numel() for w, b in zip(p.weights, p.biases))
+        d.n_density_params, d.g_density = n_par(self.d_net), self.d_net.segment.data_ptr()
+        largest = d.n_density_params
+        if self.has_lv:
+            d.sigma = mlp_mod._desc(self.s_net.weights, self.s_net.biases, self.ks, a.n_features_z, 1, S, mode)
+            d.n_sigma_params, d.g_sigma = n_par(self.s_net), self.s_net.segment.data_ptr()
+            largest = max(largest, d.n_sigma_params)
+        if self.has_b:
+            d.bias_net = mlp_mod._desc(self.b_net.weights, self.b_net.biases, self.ks, self.kb_bias, 0, S, mode)
+            d.n_bias_params, d.g_bias_net = n_par(self.b_net), self.b_net.segment.data_ptr()
+            largest = max(largest, d.n_bias_params)
+        d.B, d.S, d.n_slices = B, S, n
+        d.opt_T, d.has_lv, d.has_c, d.has_lvs, d.has_b = (int(x) for x in (self.opt_T, self.has_lv, self.has_c, self.has_lvs, self.has_b))
+        d.n_features_z, d.ks, d.kb_bias, d.reg_type = a.n_features_z, self.ks, self.kb_bias, self.reg_type
+        d.overlap_owner = int(self._overlap_owner)
+        d.delta, d.w_T = self.delta, self.w_T
+        ptr = lambda t: None if t is None else t.data_ptr()
+        d.axisangle, d.axisangle_init = ptr(m.axisangle), ptr(m.axisangle_init)
+        d.psf_sigma, d.bounding_box = ptr(m.psf_sigma), ptr(m.inr.bounding_box)
+        d.logit_coef = ptr(m.logit_coef) if self.has_c else None
+        d.log_var_slice = ptr(m.log_var_slice) if self.has_lvs else None
+        d.slice_embedding = ptr(m.slice_embedding.weight) if self.ks else None
+        d.table = ptr(enc.params)
+        d.g_axisangle = ptr(m.axisangle.grad) if self.opt_T else None
+        d.g_logit_coef = ptr(m.logit_coef.grad) if self.has_c else None
+        d.g_log_var_slice = ptr(m.log_var_slice.grad) if self.has_lvs else None
+        d.g_slice_embedding = ptr(m.slice_embedding.weight.grad) if self.ks else None
+        d.g_table = ptr(enc.params.grad)
+        d.gw = self.gw.data_ptr()
+        d.flat_param, d.flat_grad, d.flat_exp_avg, d.flat_exp_avg_sq = (t.data_ptr() for t in (f.param, f.grad, f.exp_avg, f.exp_avg_sq))
+        d.flat_numel = f.numel
+        d.small = new("small", n * 26)
+        d.x, d.u, d.pe, d.z, d.dz, d.dpe = new("x", B, S, 3), new("u", N, 3), new("pe", E, N), new("z", zr, N), new("dz", zr, N), new("dpe", E, N)
+        d.loss_pix, d.pix = new("loss_pix", B, 3), new("pix", 2, B)
+        d.partial = new("partial", 256, largest)
+        for i in range(len(self.d_net.weights) - 1):
+            d.saved_d[i] = new(f"saved_d{i}", n_pad * 64)
+        if self.ks:
+            d.se = new("se", B, self.ks)
+        rows = N // 16 if (N % 16 == 0 and S % 16 == 0 and self.ks % 16 == 0) else N
+        if self.has_lv:
+            d.log_var, d.dlv = new("log_var", N), new("dlv", N)
+            for i in range(len(self.s_net.weights) - 1):
+                d.saved_s[i] = new(f"saved_s{i}", n_pad * 64)
+            if self.ks:
+                d.dxa = new("dxa", rows, self.ks)
+        if self.has_b:
+            d.log_bias, d.dlb, d.dpe_b = new("log_bias", N), new("dlb", N), new("dpe_b", self.kb_bias, N)
+            d.lb_mean, d.mean_scratch = new("lb_mean", 1), new("mean_scratch", 256)
+            for i in range(len(self.b_net.weights) - 1):
+                d.saved_b[i] = new(f"saved_b{i}", n_pad * 64)
+            if self.ks:
+                d.dxa_b = new("dxa_b", rows, self.ks)
+        if self.opt_T:
+            d.dxl, d.du, d.dpix = new("dxl", B, S, 3), new("du", N, 3), new("dpix", B, 3, 4)
+            d.trans_terms, d.g_trans = new("trans_terms", n), new("g_trans", n, 6)
+        d.side_stream = self.side.cuda_stream
+        handle = _lib.load().nesvor_step_create(ctypes.byref(d))
+        if not handle:
+            raise RuntimeError("nesvor_step_create failed")
+        st = self._native[key] = {"desc": d, "handle": ctypes.c_void_p(handle), "buf": buf, "ws": None}
+        return st
+
+    def _run_native(self, xyz, v, slice_idx, adam=None) -> Dict[str, torch.Tensor]:
+        from .encoding import _workspace, queue_sizer
+
+        m = self.model
+        lib = _lib.load()
+        dev = xyz.device
+        B = xyz.shape[0]
+        st = self._native_state(B)
+        d = st["desc"]
+        spec = m.inr.encoding.spec
+        N = B * d.S
+        sizer = queue_sizer(spec, N, dev)
+        sizer.poll()  # grows the queues of levels that overflowed in an earlier backward (the workspace is then re-made)
+        ws = _workspace(spec, N, dev, sizer)
+        if ws is None:
+            raise RuntimeError("hash grid outside the owner-computes backward's plan")
+        if st["ws"] is not ws:
+            st["ws"] = ws
+            d.hg_workspace, d.queue_scale = ws.data_ptr(), ctypes.addressof(sizer.scale)
+            _lib.check(lib.nesvor_step_update(st["handle"], ctypes.byref(d)), "step update")
+        xyz, v, slice_idx = xyz.contiguous(), v.contiguous(), slice_idx.contiguous()
+        seed = (torch.initial_seed() ^ self._noise_stream) & 0xFFFFFFFFFFFFFFFF
+        offset = self._noise_calls
+        self._noise_calls += 1
+        vals = torch.empty(6, dtype=torch.float32, device=dev)
+        a_ptr = None if adam is None else ctypes.byref(adam)
+        stream = _lib.stream_ptr()
+        args = (st["handle"], _lib.ptr(xyz), _lib.ptr(v), _lib.ptr(slice_idx), seed, offset, _lib.ptr(vals))
+        with torch.cuda.device(dev):
+            if self.split_level:
+                from . import ddp
+
+                _lib.check(lib.nesvor_step_run(*args, 1, self.split_level, None, stream), "training step (fine levels)")
+                lo, hi = self._early_range
+                self._early = (ddp.allreduce_flat_(self.flat.grad[lo:hi]), lo, hi)  # async: RCCL's stream, behind the launches above
+                _lib.check(lib.nesvor_step_run(*args, 2, self.split_level, None, stream), "training step (coarse levels)")
+                self._owner_pending = False
+            else:
+                _lib.check(lib.nesvor_step_run(*args, 0, 0, a_ptr, stream), "training step")
+                self._owner_pending = bool(d.overlap_owner) and adam is None  # with its own AdamW the step has joined the owner pass
+        sizer.snapshot(ws)
+        losses = {D_LOSS: vals[0]}
+        if self.has_var:
+            losses[S_LOSS] = vals[1]
+            losses[DS_LOSS] = vals[2]
+        if self.opt_T:
+            losses[T_REG] = vals[3]
+        if self.has_b:
+            losses[B_REG] = vals[5]
+        losses[I_REG] = vals[4]
+        return losses
+
+    def __del__(self):
+        try:
+            lib = _lib.load()
+            for st in self._native.values():
+                lib.nesvor_step_destroy(st["handle"])
+        except Exception:
+            pass
+
     def join_owner(self) -> None:
         """Make the current stream wait for an owner pass still running on the side stream (the flat gradient of the hash
         table is complete only behind it).  ``run(defer_owner_join=True)`` leaves that to the caller - the fused trainer joins
@@ -136,7 +305,16 @@ class DirectStep:
             self._owner_pending = False
 
     @torch.no_grad()
-    def run(self, xyz, v, slice_idx, noise=None, defer_owner_join: bool = False) -> Dict[str, torch.Tensor]:
+    def run(self, xyz, v, slice_idx, noise=None, defer_owner_join: bool = False, adam=None) -> Dict[str, torch.Tensor]:
+        """``adam`` (an ``_lib.AdamwT``): the one-call iteration also runs the optimizer (single process only); ignored - and
+        left to the caller - on the Python issue path.  Returns the loss dict; ``self.ran_optimizer`` says who owns the step."""
+        self.ran_optimizer = False
+        if self.native_ready(noise):
+            losses = self._run_native(xyz, v, slice_idx, adam)
+            self.ran_optimizer = adam is not None
+            if not defer_owner_join:
+                self.join_owner()
+            return losses
         m, a = self.model, self.model.args
         lib = _lib.load()
         dev = xyz.device

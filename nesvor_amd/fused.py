@@ -105,6 +105,19 @@ class FusedTrainer:
         return losses
 
     def step(self, xyz, v, slice_idx, noise=None) -> Dict[str, torch.Tensor]:
+        if self.direct is not None and self.reduce_hook is None and not self.sharded and self.direct.native_ready(noise):
+            # single process: forward, backward AND AdamW behind one native call (csrc/step.hip)
+            from . import _lib
+
+            t = self.t + 1
+            adam = _lib.AdamwT(self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, 1 - self.betas[0] ** t,
+                               1 - self.betas[1] ** t, 1.0 / self.world_size)
+            losses = self.direct.run(xyz, v, slice_idx, None, defer_owner_join=self._late_join, adam=adam)
+            if self.direct.ran_optimizer:
+                self.t = t
+                return losses
+            self.optimizer_step()
+            return losses
         losses = self._forward_backward(xyz, v, slice_idx, noise)
         self.optimizer_step()
         return losses

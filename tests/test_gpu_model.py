@@ -458,3 +458,56 @@ def test_direct_step_runs_without_autograd(device, golden):
     assert seen == [False]
     assert all(v.grad_fn is None and not v.requires_grad for v in losses.values())
     t.optimizer_step()
+
+
+@pytest.mark.parametrize("over", [
+    {}, {"depth": 2}, {"no_transformation_optimization": True}, {"no_pixel_variance": True},
+    {"no_slice_scale": True, "no_slice_variance": True}, {"image_regularization": "TV"},
+    {"n_levels_bias": 2, "depth": 2}, {"n_levels_bias": 2, "no_pixel_variance": True}, {"n_samples": 24}, {"mlp_bf16": True, "n_samples": 16},
+])
+def test_one_call_step_equals_python_issued_step(device, golden, over):
+    """``nesvor_step_run`` (csrc/step.hip: the whole iteration + AdamW enqueued by one C call into buffers allocated once)
+    against the same launches issued from Python one by one (``NESVOR_STEP_NATIVE=0``): same kernels, same order, same PSF
+    noise stream (seed, step counter) -> losses, gradients and updated parameters must agree BIT FOR BIT over three steps -
+    except where a partial-sum reduction runs as a torch op on one path and as a kernel on the other (the bias field's mean):
+    rtol 1e-6 there."""
+    from nesvor_amd.fused import FusedTrainer
+    from nesvor_amd.models import NeSVoR
+    from nesvor_amd.transform import RigidTransform
+
+    args = small_args(device=device, **over)
+    tf = RigidTransform(torch.tensor(golden["fw_sd::axisangle_init"]).to(device), trans_first=True)
+    res = torch.tensor(golden["ds_resolution"]).to(device)
+    bbox = torch.tensor(golden["fw_sd::inr.bounding_box"]).to(device)
+    torch.manual_seed(3)
+    m1 = NeSVoR(tf, res, float(golden["ds_mean"]), bbox, args)
+    with torch.no_grad():  # per-slice parameters start at 0 / identity: move them so every gradient path is live
+        for name, p in m1.named_parameters():
+            if name in ("logit_coef", "log_var_slice"):
+                p.add_(0.3 * torch.randn_like(p))
+            if name == "axisangle":
+                p.add_(0.02 * torch.randn_like(p))
+            if name == "inr.encoding.params":
+                p.mul_(1e3)
+    m2 = NeSVoR(tf, res, float(golden["ds_mean"]), bbox, args)
+    m2.load_state_dict(m1.state_dict())
+    t1, t2 = FusedTrainer(m1, args), FusedTrainer(m2, args)
+    assert t1.direct is not None and t2.direct is not None
+    t2.direct._native_on = False
+    assert t1.direct.native_ready() and not t2.direct.native_ready()
+    d = lambda k: torch.tensor(golden[f"fw_{k}"]).to(device)
+    exact = not over.get("n_levels_bias")
+    for it in range(3):
+        torch.manual_seed(11)
+        l1 = t1.step(d("xyz"), d("v"), d("idx"))
+        l2 = t2.step(d("xyz"), d("v"), d("idx"))
+        assert list(l1.keys()) == list(l2.keys())
+        for k in l1:
+            a, b = float(l1[k]), float(l2[k])
+            assert (a == b) if exact else abs(a - b) <= 1e-6 * abs(b) + 1e-9, (it, k, a, b)
+        assert t1.t == t2.t == it + 1
+        if exact:
+            assert torch.equal(t1.flat.param, t2.flat.param), it
+        else:
+            torch.testing.assert_close(t1.flat.param, t2.flat.param, rtol=1e-5, atol=1e-7)
+    assert float(t1.flat.grad.abs().max()) == 0.0  # zero-filled by the fused AdamW
