@@ -74,10 +74,59 @@ __device__ __forceinline__ Split3 split_c(const f32x4& v) {
   return s;
 }
 
+// D: as B with the selector constants in VGPRs; E: as B with the operands swapped (S0 = selector, S1 = the pair)
+__device__ __forceinline__ float sub_sel(float x, uint32_t pair, uint32_t sel) {
+  float d;
+  asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(d) : "v"(pair), "v"(sel), "v"(x));
+  return d;
+}
+__device__ __forceinline__ float sub_sel_swapped(float x, uint32_t pair, uint32_t sel) {
+  float d;
+  asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(d) : "v"(sel), "v"(pair), "v"(x));
+  return d;
+}
+template <bool SWAP>
+__device__ __forceinline__ Split3 split_de(const f32x4& v) {
+  const uint32_t klo = 0x0000BF80u, khi = 0xBF800000u;
+  auto sub = [&](float x, uint32_t pair, uint32_t sel) { return SWAP ? sub_sel_swapped(x, pair, sel) : sub_sel(x, pair, sel); };
+  Split3 s;
+  s.hi = pack_bf16(v);
+  uint2 h = __builtin_bit_cast(uint2, s.hi);
+  const f32x4 r1 = f32x4{sub(v[0], h.x, klo), sub(v[1], h.x, khi), sub(v[2], h.y, klo), sub(v[3], h.y, khi)};
+  s.mid = pack_bf16(r1);
+  uint2 m = __builtin_bit_cast(uint2, s.mid);
+  const f32x4 r2 = f32x4{sub(r1[0], m.x, klo), sub(r1[1], m.x, khi), sub(r1[2], m.y, klo), sub(r1[3], m.y, khi)};
+  s.lo = pack_bf16(r2);
+  return s;
+}
+// F: x - widen(hi) with the widening done by v_perm_b32 / v_lshlrev and v_pk_add_f32 with a negated operand (two values
+// per subtraction)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ Split3 split_f(const f32x4& v) {
+  Split3 s;
+  s.hi = pack_bf16(v);
+  const f32x4 w = widen_bf16(s.hi);
+  const f32x2 r1a = pk_sub(f32x2{v[0], v[1]}, f32x2{w[0], w[1]}), r1b = pk_sub(f32x2{v[2], v[3]}, f32x2{w[2], w[3]});
+  const f32x4 r1 = f32x4{r1a[0], r1a[1], r1b[0], r1b[1]};
+  s.mid = pack_bf16(r1);
+  const f32x4 w2 = widen_bf16(s.mid);
+  const f32x2 r2a = pk_sub(r1a, f32x2{w2[0], w2[1]}), r2b = pk_sub(r1b, f32x2{w2[2], w2[3]});
+  s.lo = pack_bf16(f32x4{r2a[0], r2a[1], r2b[0], r2b[1]});
+  return s;
+}
+
 template <int V> __device__ __forceinline__ Split3 split(const f32x4& v) {
   if constexpr (V == 0) return split_a(v);
   else if constexpr (V == 1) return split_b(v);
-  else return split_c(v);
+  else if constexpr (V == 2) return split_c(v);
+  else if constexpr (V == 3) return split_de<false>(v);
+  else if constexpr (V == 4) return split_de<true>(v);
+  else return split_f(v);
 }
 
 template <int V>
@@ -111,13 +160,13 @@ __global__ __launch_bounds__(256) void timeit(float* out, int rounds) {
 }
 
 template <int V> float time_variant() {
-  float* out; hipMalloc(&out, sizeof(float) * 256 * 1024);
+  float* out; hipMalloc(&out, sizeof(float) * 256 * 1024);  // 1024 workgroups of 4 waves on 256 CUs: 4 waves per SIMD
   hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
   hipLaunchKernelGGL(timeit<V>, dim3(1024), dim3(256), 0, 0, out, 10); hipDeviceSynchronize();
   hipEventRecord(s); hipLaunchKernelGGL(timeit<V>, dim3(1024), dim3(256), 0, 0, out, 4000); hipEventRecord(e); hipEventSynchronize(e);
   float ms; hipEventElapsedTime(&ms, s, e);
   hipFree(out);
-  return ms * 1e6f / (4000.f * 16.f);  // ns per split (+ 11 bookkeeping ops) at one wave per SIMD
+  return ms * 1e6f / (4000.f * 16.f * 4.f);  // ns per split (+ 11 bookkeeping ops) per SIMD at four waves per SIMD (throughput)
 }
 
 int main() {
@@ -138,26 +187,48 @@ int main() {
   std::vector<uint32_t> ra(6 * (n / 4)), rb(6 * (n / 4));
   hipLaunchKernelGGL(check<0>, dim3(n / 4 / 256), dim3(256), 0, 0, dx, da, n);
   hipMemcpy(ra.data(), da, 4 * ra.size(), hipMemcpyDeviceToHost);
-  const char* names[3] = {"A widen + sub", "B v_dot2_f32_bf16", "C v_dot2c_f32_bf16"};
-  for (int var = 1; var < 3; ++var) {
+  const char* names[6] = {"A widen + sub", "B v_dot2_f32_bf16 (sgpr selector)", "C v_dot2c_f32_bf16", "D v_dot2_f32_bf16 (vgpr selector)",
+                          "E v_dot2_f32_bf16 (operands swapped)", "F v_pk_add_f32 residuals"};
+  auto bf = [](uint32_t w, int half) { uint32_t b = (half ? (w & 0xFFFF0000u) : (w << 16)); float f; memcpy(&f, &b, 4); return f; };
+  for (int var = 1; var < 6; ++var) {
     if (var == 1) hipLaunchKernelGGL(check<1>, dim3(n / 4 / 256), dim3(256), 0, 0, dx, db, n);
-    else hipLaunchKernelGGL(check<2>, dim3(n / 4 / 256), dim3(256), 0, 0, dx, db, n);
+    else if (var == 2) hipLaunchKernelGGL(check<2>, dim3(n / 4 / 256), dim3(256), 0, 0, dx, db, n);
+    else if (var == 3) hipLaunchKernelGGL(check<3>, dim3(n / 4 / 256), dim3(256), 0, 0, dx, db, n);
+    else if (var == 4) hipLaunchKernelGGL(check<4>, dim3(n / 4 / 256), dim3(256), 0, 0, dx, db, n);
+    else hipLaunchKernelGGL(check<5>, dim3(n / 4 / 256), dim3(256), 0, 0, dx, db, n);
     hipMemcpy(rb.data(), db, 4 * rb.size(), hipMemcpyDeviceToHost);
-    long bad = 0, bad_normal = 0; int first = -1;
-    for (size_t w = 0; w < ra.size(); ++w) if (ra[w] != rb[w]) {
+    long bad = 0, bad_normal = 0, shown = 0;
+    double worst = 0;  // largest |x - (hi + mid + lo)| / |x| over normal inputs
+    for (size_t quad = 0; quad < (size_t)n / 4; ++quad) {
+      bool differs = false;
+      for (int w = 0; w < 6; ++w) differs = differs || ra[6 * quad + w] != rb[6 * quad + w];
+      bool normal = true;
+      for (int k = 0; k < 4; ++k) normal = normal && std::fabs(h[4 * quad + k]) > 1e-30f && std::fabs(h[4 * quad + k]) < 1e30f;
+      if (normal) {
+        for (int k = 0; k < 4; ++k) {
+          const double x = h[4 * quad + k];
+          const double sum = (double)bf(rb[6 * quad + k / 2], k & 1) + (double)bf(rb[6 * quad + 2 + k / 2], k & 1) + (double)bf(rb[6 * quad + 4 + k / 2], k & 1);
+          worst = std::fmax(worst, std::fabs(x - sum) / std::fabs(x));
+        }
+      }
+      if (!differs) continue;
       ++bad;
-      const size_t quad = w / 6; bool normal = true;
-      for (int k = 0; k < 4; ++k) normal = normal && std::fabs(h[4 * quad + k]) > 1e-30f;   // planes of tiny inputs reach denormals
-      if (normal) { ++bad_normal; if (first < 0) first = (int)w; }
+      if (normal) {
+        ++bad_normal;
+        if (shown < 4) {
+          ++shown;
+          for (int k = 0; k < 4; ++k)
+            printf("     x %.9g : A (%.9g, %.9g, %.9g)  this (%.9g, %.9g, %.9g)\n", h[4 * quad + k],
+                   bf(ra[6 * quad + k / 2], k & 1), bf(ra[6 * quad + 2 + k / 2], k & 1), bf(ra[6 * quad + 4 + k / 2], k & 1),
+                   bf(rb[6 * quad + k / 2], k & 1), bf(rb[6 * quad + 2 + k / 2], k & 1), bf(rb[6 * quad + 4 + k / 2], k & 1));
+        }
+      }
     }
-    printf("%-22s words differing from A: %ld of %zu (%ld of them with all four inputs above 1e-30)\n", names[var], bad, ra.size(), bad_normal);
-    if (first >= 0) {
-      const size_t quad = first / 6;
-      printf("   first: inputs %.9g %.9g %.9g %.9g  word %d: A %08x vs %08x\n", h[4 * quad], h[4 * quad + 1], h[4 * quad + 2], h[4 * quad + 3], first % 6, ra[first], rb[first]);
-    }
+    printf("%-40s quads differing from A: %ld of %d (%ld with all inputs in [1e-30, 1e30]); worst |x - (hi+mid+lo)| / |x| = %.3g\n", names[var], bad,
+           n / 4, bad_normal, worst);
   }
-  printf("A widen + sub      : %.2f ns per split\n", time_variant<0>());
-  printf("B v_dot2_f32_bf16  : %.2f ns per split\n", time_variant<1>());
-  printf("C v_dot2c_f32_bf16 : %.2f ns per split\n", time_variant<2>());
+  printf("throughput, ns per split (+ 11 bookkeeping VALU ops) per SIMD, four waves per SIMD:\n");
+  printf("  A %.2f   B %.2f   C %.2f   D %.2f   E %.2f   F %.2f\n", time_variant<0>(), time_variant<1>(), time_variant<2>(), time_variant<3>(),
+         time_variant<4>(), time_variant<5>());
   return 0;
 }
