@@ -496,18 +496,29 @@ def test_one_call_step_equals_python_issued_step(device, golden, over):
     t2.direct._native_on = False
     assert t1.direct.native_ready() and not t2.direct.native_ready()
     d = lambda k: torch.tensor(golden[f"fw_{k}"]).to(device)
-    exact = not over.get("n_levels_bias")
+    # (1) gradients of one iteration, no optimizer: the owner pass of the hash-grid backward sums records in arrival order,
+    # so even two runs of ONE path differ in the last bits of the table gradient - 1e-5 of the largest entry
+    torch.manual_seed(11)
+    l1 = t1.direct.run(d("xyz"), d("v"), d("idx"))
+    l2 = t2.direct.run(d("xyz"), d("v"), d("idx"))
+    assert list(l1.keys()) == list(l2.keys())
+    for k in l1:
+        a, b = float(l1[k]), float(l2[k])
+        assert abs(a - b) <= 1e-6 * abs(b) + 1e-9, (k, a, b)
+    torch.cuda.synchronize()
+    scale = float(t2.flat.grad.abs().max())
+    assert scale > 0 and float((t1.flat.grad - t2.flat.grad).abs().max()) <= 1e-5 * scale
+    t1.flat.grad.zero_(); t2.flat.grad.zero_()
+    t1.direct._noise_calls = t2.direct._noise_calls = 0
+    # (2) three full steps, AdamW fused into the native call.  AdamW (eps 1e-15) turns a last-bit difference of a vanishing
+    # gradient into a full +-lr move of that entry: compare by the fraction of entries that moved apart
     for it in range(3):
-        torch.manual_seed(11)
         l1 = t1.step(d("xyz"), d("v"), d("idx"))
         l2 = t2.step(d("xyz"), d("v"), d("idx"))
-        assert list(l1.keys()) == list(l2.keys())
         for k in l1:
             a, b = float(l1[k]), float(l2[k])
-            assert (a == b) if exact else abs(a - b) <= 1e-6 * abs(b) + 1e-9, (it, k, a, b)
+            assert abs(a - b) <= 1e-4 * abs(b) + 1e-7, (it, k, a, b)
         assert t1.t == t2.t == it + 1
-        if exact:
-            assert torch.equal(t1.flat.param, t2.flat.param), it
-        else:
-            torch.testing.assert_close(t1.flat.param, t2.flat.param, rtol=1e-5, atol=1e-7)
+        apart = ((t1.flat.param - t2.flat.param).abs() > 1e-5 * (1 + t2.flat.param.abs())).float().mean()
+        assert float(apart) < 2e-3, (it, float(apart))
     assert float(t1.flat.grad.abs().max()) == 0.0  # zero-filled by the fused AdamW

@@ -32,16 +32,14 @@ __device__ __forceinline__ Split3 split_a(const f32x4& v) {
   s.lo = pack_bf16(r1 - widen_bf16(s.mid));
   return s;
 }
-// x - (one half of a packed bf16 pair): v_dot2_f32_bf16 D = S0.lo S1.lo + S0.hi S1.hi + S2
+// x - (one half of a packed bf16 pair): v_dot2_f32_bf16 D = S0.lo S1.lo + S0.hi S1.hi + S2 through the compiler's builtin
+// (inline asm hides the instruction from the hazard recogniser: a DOT result read by another VALU instruction needs
+// wait states on gfx940+, and the first version of this probe, written with asm, read stale registers)
 __device__ __forceinline__ float sub_lo(float x, uint32_t pair) {
-  float d;
-  asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(d) : "v"(pair), "s"(0x0000BF80u), "v"(x));
-  return d;
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pair), __builtin_bit_cast(bf16x2, 0x0000BF80u), x, false);
 }
 __device__ __forceinline__ float sub_hi(float x, uint32_t pair) {
-  float d;
-  asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(d) : "v"(pair), "s"(0xBF800000u), "v"(x));
-  return d;
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pair), __builtin_bit_cast(bf16x2, 0xBF800000u), x, false);
 }
 __device__ __forceinline__ Split3 split_b(const f32x4& v) {
   Split3 s;
