@@ -35,11 +35,15 @@ __device__ __forceinline__ Split3 split_a(const f32x4& v) {
 // x - (one half of a packed bf16 pair): v_dot2_f32_bf16 D = S0.lo S1.lo + S0.hi S1.hi + S2 through the compiler's builtin
 // (inline asm hides the instruction from the hazard recogniser: a DOT result read by another VALU instruction needs
 // wait states on gfx940+, and the first version of this probe, written with asm, read stale registers)
+// The selector constants are hidden from the optimiser (an SGPR it cannot see through): folded, the low-half selector
+// 0x0000BF80 becomes the inline constant "-1.0", which the hardware reads as the 32-bit pattern 0xBF800000 = the HIGH half
+// (measured: the first builtin version subtracted the wrong element).
+__device__ __forceinline__ uint32_t opaque(uint32_t v) { asm volatile("" : "+s"(v)); return v; }
 __device__ __forceinline__ float sub_lo(float x, uint32_t pair) {
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pair), __builtin_bit_cast(bf16x2, 0x0000BF80u), x, false);
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pair), __builtin_bit_cast(bf16x2, opaque(0x0000BF80u)), x, false);
 }
 __device__ __forceinline__ float sub_hi(float x, uint32_t pair) {
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pair), __builtin_bit_cast(bf16x2, 0xBF800000u), x, false);
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pair), __builtin_bit_cast(bf16x2, opaque(0xBF800000u)), x, false);
 }
 __device__ __forceinline__ Split3 split_b(const f32x4& v) {
   Split3 s;
