@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <map>
 #include <type_traits>
+#include <utility>
 #include <mutex>
 #include "common.h"
 #include "../../include/nesvor_hip.h"
@@ -111,13 +112,44 @@ __device__ __forceinline__ f32x4 widen_bf16(const s16x4& v) {  // four bf16 -> f
   return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
                __uint_as_float(u.y & 0xFFFF0000u)};
 }
+// How the residuals x - widen(hi) are formed (NESVOR_SPLIT; planes are bit-identical in all variants, tools/split_probe.hip):
+//   0: v_lshlrev / v_and widen + v_sub_f32                                            22 VALU instructions per 4 values
+//   1: the same widening, two residuals per v_pk_add_f32 (neg modifiers)               18
+//   2: v_dot2c_f32_bf16: x += <(hi_even, hi_odd), (-1, 0) or (0, -1)> - widening and subtraction in one instruction; the
+//      selector must not be a compile-time constant (the inline constant -1.0 would address the HIGH half)   14
+#ifndef NESVOR_SPLIT
+#define NESVOR_SPLIT 2
+#endif
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t opaque_sgpr(uint32_t v) { asm("" : "+s"(v)); return v; }  // (not volatile: hoisted out of the loops)
+__device__ __forceinline__ f32x4 residual(const f32x4& x, const s16x4& planes) {
+#if NESVOR_SPLIT == 2
+  const uint2 p = __builtin_bit_cast(uint2, planes);
+  const bf16x2 even = __builtin_bit_cast(bf16x2, opaque_sgpr(0x0000BF80u)), odd = __builtin_bit_cast(bf16x2, opaque_sgpr(0xBF800000u));
+  return f32x4{__builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p.x), even, x[0], false),
+               __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p.x), odd, x[1], false),
+               __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p.y), even, x[2], false),
+               __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p.y), odd, x[3], false)};
+#elif NESVOR_SPLIT == 1
+  const f32x4 w = widen_bf16(planes);
+  const f32x2 a = pk_sub(f32x2{x[0], x[1]}, f32x2{w[0], w[1]}), b = pk_sub(f32x2{x[2], x[3]}, f32x2{w[2], w[3]});
+  return f32x4{a[0], a[1], b[0], b[1]};
+#else
+  return x - widen_bf16(planes);
+#endif
+}
 __device__ __forceinline__ Split3 split3(const f32x4& v) {
   Split3 s;
   s.hi = pack_bf16(v);
   if (NESVOR_MLP_ABLATE & 4) { s.mid = s.hi; s.lo = s.hi; return s; }  // timing experiment: the split's VALU work removed
-  const f32x4 r1 = v - widen_bf16(s.hi);
+  const f32x4 r1 = residual(v, s.hi);
   s.mid = pack_bf16(r1);
-  s.lo = pack_bf16(r1 - widen_bf16(s.mid));
+  s.lo = pack_bf16(residual(r1, s.mid));
   return s;
 }
 // gfx950's full-rate bf16 shape contracts 32 k-values per instruction: lane (j, q) supplies k-slots (q, 0..7).  The
@@ -457,6 +489,27 @@ __device__ __forceinline__ void await_loads() {
 // above the await_loads() that precedes this call
 __device__ __forceinline__ void pin(f32x4& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
+// The same issue-now loads in the scalar-base form: address = SGPR pair (wave-uniform base) + 32-bit VGPR offset + 13-bit
+// immediate.  A saved-activation fragment of group gi sits at H + gi * 4096 bytes (+ block * 1024): with the group's base in
+// SGPRs (two scalar instructions per group and layer) the 32 loads of a group need no per-load 64-bit vector address
+// arithmetic at all (the flat form cost one v_lshl_add_u64 per load and ~150 scalar instructions per group).
+template <int IMM> __device__ __forceinline__ void issue_load_b32_s(float& dst, const void* sbase, uint32_t voff) {
+  asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
+}
+template <int IMM> __device__ __forceinline__ void issue_load_b64_s(f32x2& dst, const void* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
+}
+template <int IMM> __device__ __forceinline__ void issue_load_b128_s(f32x4& dst, const void* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
+}
+template <int IMM> __device__ __forceinline__ void issue_load_u16_s(float& dst, const void* sbase, uint32_t voff) {
+  asm volatile("global_load_ushort %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
+}
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., so that loop indices can be asm immediates
+template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // ---------------------------------------------------- forward, software-pipelined
 // mlp_fwd_kernel below loads a tile's inputs at the top of its loop and uses them at once: loads and stores retire
@@ -1104,8 +1157,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const MlpArgs a) {
 // is covered by the other.  One workgroup barrier per group; both roles stay under 256 registers.
 // Requires the fast input path (a.fast).
 template <int OB, int IB>
-__device__ void flush_dw_ws(float* red /* 4 x kHB*256 floats */, const f32x4 (&acc)[OB][IB], const float (&db)[OB],
-                            float* out, int out_dim, int in_dim, int slot /* 0..3: accumulator wave, -1: none */) {
+__device__ void flush_dw_ws(float* red /* 4 x kHB*256 floats */, const f32x4 (&acc)[OB][IB], const f32x4 (&dbc)[OB],
+                            float* out, int out_dim, int in_dim, int slot /* 0..3: accumulator (dW) wave, -1: none */,
+                            int chain /* 0..3: chain wave (owns the bias-gradient sums), -1: none */) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int ob = 0; ob < OB; ++ob) {
@@ -1122,31 +1176,31 @@ __device__ void flush_dw_ws(float* red /* 4 x kHB*256 floats */, const f32x4 (&a
       if (o < out_dim && in < in_dim) out[o * in_dim + in] = s;
     }
   }
+  // bias gradient: the chain waves summed dpre per lane (sample j, features 4q..4q+3 of block ob) over their groups;
+  // sum the 16 sample lanes of a row, then the four pairs
   __syncthreads();
-  if (slot >= 0) {
+  if (chain >= 0) {
 #pragma unroll
-    for (int ob = 0; ob < OB; ++ob) red[slot * kHB * 256 + ob * 64 + lane] = db[ob];
+    for (int ob = 0; ob < OB; ++ob) {
+      f32x4 t;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[r] = row_sum_dpp(dbc[ob][r]);
+      if ((lane & 15) == 0) *reinterpret_cast<f32x4*>(&red[chain * kWidth + 16 * ob + 4 * (lane >> 4)]) = t;
+    }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < OB * 16; e += blockDim.x) {
-    const int ob = e >> 4, ii = e & 15;
-    float s = 0.f;
-    for (int w = 0; w < 4; ++w)
-      for (int qq = 0; qq < 4; ++qq) s += red[w * kHB * 256 + ob * 64 + qq * 16 + ii];
-    if (16 * ob + ii < out_dim) out[out_dim * in_dim + 16 * ob + ii] = s;
+    const float s = (red[e] + red[kWidth + e]) + (red[2 * kWidth + e] + red[3 * kWidth + e]);
+    if (e < out_dim) out[out_dim * in_dim + e] = s;
   }
 }
 
 // dW accumulation from a staged A tile set and B operands already in registers
 template <int OB, int IB, bool BF16 = false>
-__device__ __forceinline__ void accumulate_dw_regs(const float* tiles, const f32x4 (&bv)[IB], f32x4 (&acc)[OB][IB],
-                                                   float (&db)[OB], int i, int q) {
+__device__ __forceinline__ void accumulate_dw_regs(const float* tiles, const f32x4 (&bv)[IB], f32x4 (&acc)[OB][IB], int i, int q) {
   float av[OB][4];
 #pragma unroll
-  for (int ob = 0; ob < OB; ++ob) {
-    read_operand(tiles + ob * kTileFloats, i, q, av[ob]);
-    db[ob] += (av[ob][0] + av[ob][1]) + (av[ob][2] + av[ob][3]);
-  }
+  for (int ob = 0; ob < OB; ++ob) read_operand(tiles + ob * kTileFloats, i, q, av[ob]);
   if constexpr (BF16) {
     s16x4 pb[IB];
 #pragma unroll
@@ -1176,10 +1230,10 @@ __device__ __forceinline__ void accumulate_dw_regs(const float* tiles, const f32
 //     (a_hi | a_hi) . (b_mid| b_hi)  =  a_hi b_mid + a_hi b_hi
 // three instructions (48 matrix-pipe cycles) per 16x16x16 block product instead of four v_mfma_f32_16x16x4_f32 (128
 // cycles during which the SIMD issues no VALU work at all), smallest terms first.  The operands are split here: the A
-// tiles come out of LDS as fp32 (the bias gradient needs them anyway), the B operands are the prefetched fp32 registers.
+// tiles come out of LDS as fp32, the B operands are the prefetched fp32 registers.  (The bias gradients - sums of the A
+// operands over the samples - are accumulated by the chain waves, which hold the same values and have registers to spare.)
 template <int OB, int IB>
-__device__ __forceinline__ void accumulate_dw_split(const float* tiles, const f32x4 (&bv)[IB], f32x4 (&acc)[OB][IB],
-                                                    float (&db)[OB], int i, int q) {
+__device__ __forceinline__ void accumulate_dw_split(const float* tiles, const f32x4 (&bv)[IB], f32x4 (&acc)[OB][IB], int i, int q) {
   bf16x8 b_hl[IB], b_mh[IB];
 #pragma unroll
   for (int ib = 0; ib < IB; ++ib) {
@@ -1191,7 +1245,6 @@ __device__ __forceinline__ void accumulate_dw_split(const float* tiles, const f3
   for (int ob = 0; ob < OB; ++ob) {
     float av[4];
     read_operand(tiles + ob * kTileFloats, i, q, av);
-    db[ob] += (av[0] + av[1]) + (av[2] + av[3]);
     const Split3 sa = split3(f32x4{av[0], av[1], av[2], av[3]});
     const bf16x8 a_lh = join8(sa.lo, sa.hi), a_mm = join8(sa.mid, sa.mid), a_hh = join8(sa.hi, sa.hi);
 #pragma unroll
@@ -1259,26 +1312,39 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   f32x4 acc_o[1][kHB];
   f32x4 acc_h[NH > 1 ? NH - 1 : 1][kHB][kHB];
   f32x4 acc_1[kHB][KB1];
-  float db_o[1] = {0.f}, db_h[NH > 1 ? NH - 1 : 1][kHB], db_1[kHB];
+  // bias-gradient sums, kept by the chain waves in their own layout: lane (sample j, q) adds dpre[features 4q..4q+3]
+  f32x4 dbc_o[1], dbc_h[NH > 1 ? NH - 1 : 1][kHB], dbc_1[kHB];
+  dbc_o[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int x = 0; x < kHB; ++x) {
+    dbc_1[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < (NH > 1 ? NH - 1 : 1); ++l) dbc_h[l][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
+  // Both roles prefetch the next group's global inputs into a second register set while they work on the current one and
+  // swap the two sets every iteration (the loop is unrolled by two): no register-to-register copies of the prefetch.
+  constexpr int kHBytes = BF16 ? 2 : 4;                 // bytes per saved activation
   if (role == 0) {
     // ------------------------------------------------------------------ chain waves
     // saved activations: fp32 fragments (16 B per lane) or, in the bf16 mode, bf16 fragments (8 B per lane)
     using RawH = typename std::conditional<BF16, f32x2, f32x4>::type;
-    auto issue_group = [&](int64_t gi, float (&gy)[4], RawH (&hs)[NH][kHB]) {
+    auto issue_group = [&](int64_t gi, float (&gy)[4], RawH (&hs)[NH][kHB]) __attribute__((always_inline)) {
       const int64_t n = sgroup(gi) * 16 + j;
 #pragma unroll
       for (int r = 0; r < 4; ++r) issue_load_b32(gy[r], a.y + (size_t)min(4 * q + r, a.out_dim - 1) * a.N + n);
+      const uint32_t voff = (uint32_t)lane * (4u * kHBytes);
 #pragma unroll
-      for (int l = 0; l < NH; ++l)
-#pragma unroll
-        for (int ib = 0; ib < kHB; ++ib) {
-          const size_t e = (((size_t)hgroup(gi) * kHB + ib) * 64 + lane) * 4;
-          if constexpr (BF16) issue_load_b64(hs[l][ib], reinterpret_cast<const __bf16*>(a.H[l]) + e);
-          else issue_load_b128(hs[l][ib], a.H[l] + e);
-        }
+      for (int l = 0; l < NH; ++l) {
+        const char* base = reinterpret_cast<const char*>(a.H[l]) + hgroup(gi) * (int64_t)(kHB * 256 * kHBytes);  // wave-uniform
+        static_for<kHB>([&](auto IB) {
+          constexpr int ib = decltype(IB)::value;
+          if constexpr (BF16) issue_load_b64_s<ib * 256 * kHBytes>(hs[l][ib], base, voff);
+          else issue_load_b128_s<ib * 256 * kHBytes>(hs[l][ib], base, voff);
+        });
+      }
     };
-    auto settle_group = [&](float (&gy)[4], RawH (&hs)[NH][kHB]) {
+    auto settle_group = [&](float (&gy)[4], RawH (&hs)[NH][kHB]) __attribute__((always_inline)) {
       await_loads();
 #pragma unroll
       for (int r = 0; r < 4; ++r) pin(gy[r]);
@@ -1287,29 +1353,20 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
         for (int ib = 0; ib < kHB; ++ib) pin(hs[l][ib]);
     };
-    float gy_n[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 hs[NH][kHB];
-    RawH hs_n[NH][kHB];
-#pragma unroll
-    for (int l = 0; l < NH; ++l)
-#pragma unroll
-      for (int ib = 0; ib < kHB; ++ib) {
-        if constexpr (BF16) hs_n[l][ib] = f32x2{0.f, 0.f};
-        else hs_n[l][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    if (g_first < n_groups) { issue_group(g_first, gy_n, hs_n); settle_group(gy_n, hs_n); }
-    for (int it = 0; it <= n_it; ++it) {
+    // one iteration: the group whose inputs sit in (gy_c, hs_c); the next group's inputs are requested into (gy_n, hs_n)
+    auto chain_iter = [&](int it, float (&gy_c)[4], RawH (&hs_c)[NH][kHB], float (&gy_n)[4], RawH (&hs_n)[NH][kHB]) __attribute__((always_inline)) {
       const int64_t gi = g_first + (int64_t)it * gstride;
       if (it < n_it && gi < n_groups) {
         f32x4 go;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) go[r] = 4 * q + r < a.out_dim ? gy_n[r] : 0.f;
+        for (int r = 0; r < 4; ++r) go[r] = 4 * q + r < a.out_dim ? gy_c[r] : 0.f;
+        f32x4 hs[NH][kHB];
 #pragma unroll
         for (int l = 0; l < NH; ++l)
 #pragma unroll
           for (int ib = 0; ib < kHB; ++ib) {
-            if constexpr (BF16) hs[l][ib] = unpack_bf16(hs_n[l][ib]);
-            else hs[l][ib] = hs_n[l][ib];
+            if constexpr (BF16) hs[l][ib] = unpack_bf16(hs_c[l][ib]);
+            else hs[l][ib] = hs_c[l][ib];
           }
         // next group's inputs, one whole group of MFMAs ahead of their settle_group().  No control flow may merge
         // between an issue and its settle (a register copy at the merge would read the in-flight registers), so the
@@ -1317,6 +1374,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         issue_group(min(gi + gstride, n_groups - 1), gy_n, hs_n);
         float* buf = my_tiles + (it & 1) * kT * kTileFloats;
         stage_tile(buf, go, j, q);
+        dbc_o[0] += go;
         f32x4 gov[1] = {go};
         f32x4 d[kHB];
 #pragma unroll
@@ -1329,6 +1387,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) d[ib][r] = hs[l][ib][r] > 0.f ? d[ib][r] : 0.f;
             stage_tile(buf + (1 + (NH - 1 - l) * kHB + ib) * kTileFloats, d[ib], j, q);
+            if (l > 0) dbc_h[l > 0 ? l - 1 : 0][ib] += d[ib];
+            else dbc_1[ib] += d[ib];
           }
           if (l > 0) {
             f32x4 d2[kHB];
@@ -1352,36 +1412,50 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         }
       }
       pair_sync(it);
+    };
+    float gy_a[4] = {0.f, 0.f, 0.f, 0.f}, gy_b[4] = {0.f, 0.f, 0.f, 0.f};
+    RawH hs_a[NH][kHB], hs_b[NH][kHB];
+#pragma unroll
+    for (int l = 0; l < NH; ++l)
+#pragma unroll
+      for (int ib = 0; ib < kHB; ++ib) {
+        if constexpr (BF16) { hs_a[l][ib] = f32x2{0.f, 0.f}; hs_b[l][ib] = f32x2{0.f, 0.f}; }
+        else { hs_a[l][ib] = f32x4{0.f, 0.f, 0.f, 0.f}; hs_b[l][ib] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      }
+    if (g_first < n_groups) { issue_group(g_first, gy_a, hs_a); settle_group(gy_a, hs_a); }
+    for (int it = 0; it <= n_it; it += 2) {
+      chain_iter(it, gy_a, hs_a, gy_b, hs_b);
+      if (it + 1 <= n_it) chain_iter(it + 1, gy_b, hs_b, gy_a, hs_a);
     }
   } else {
     // ------------------------------------------------------------------ dW waves
 #pragma unroll
     for (int x = 0; x < kHB; ++x) {
       acc_o[0][x] = f32x4{0.f, 0.f, 0.f, 0.f};
-      db_1[x] = 0.f;
 #pragma unroll
       for (int y = 0; y < KB1; ++y) acc_1[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int l = 0; l < (NH > 1 ? NH - 1 : 1); ++l) {
-        db_h[l][x] = 0.f;
 #pragma unroll
         for (int y = 0; y < kHB; ++y) acc_h[l][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
     // B operands (layer inputs) of one group: lane (feature j, sample quad q) holds feature j of samples 4q..4q+3
     const int ka_blocks = a.k_a >> 4;
-    auto issue_b = [&](int64_t gi, float (&hraw)[NH][kHB][4], f32x4 (&xraw)[KB1], float (&xsraw)[KB1]) {
+    auto issue_b = [&](int64_t gi, float (&hraw)[NH][kHB][4], f32x4 (&xraw)[KB1], float (&xsraw)[KB1]) __attribute__((always_inline)) {
+      // element (sample 4q + t, feature j of block ib) of the fragment layout [block][lane = (f >> 2) * 16 + sample][f & 3]
+      const uint32_t voff = (uint32_t)((((j >> 2) * 16 + 4 * q) * 4 + (j & 3)) * kHBytes);
 #pragma unroll
-      for (int l = 0; l < NH; ++l)
-#pragma unroll
-        for (int ib = 0; ib < kHB; ++ib) {
-          const size_t e = (((size_t)hgroup(gi) * kHB + ib) * 64 + (j >> 2) * 16 + 4 * q) * 4 + (j & 3);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            if constexpr (BF16) issue_load_u16(hraw[l][ib][t], reinterpret_cast<const __bf16*>(a.H[l]) + e + 4 * t);
-            else issue_load_b32(hraw[l][ib][t], a.H[l] + e + 4 * t);
-          }
-        }
+      for (int l = 0; l < NH; ++l) {
+        const char* base = reinterpret_cast<const char*>(a.H[l]) + hgroup(gi) * (int64_t)(kHB * 256 * kHBytes);  // wave-uniform
+        static_for<kHB>([&](auto IB) {
+          static_for<4>([&](auto T) {
+            constexpr int ib = decltype(IB)::value, t = decltype(T)::value;
+            if constexpr (BF16) issue_load_u16_s<(ib * 256 + 4 * t) * kHBytes>(hraw[l][ib][t], base, voff);
+            else issue_load_b32_s<(ib * 256 + 4 * t) * kHBytes>(hraw[l][ib][t], base, voff);
+          });
+        });
+      }
       // both candidate sources of every input block are requested (no branch between issue and settle); the block
       // type picks one after the loads have landed
       const int64_t pixel = a.spg_shift >= 0 ? (gi >> a.spg_shift) : gi / (a.S >> 4);
@@ -1394,7 +1468,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         issue_load_b128(xraw[kb], a.xb + (size_t)(a.b_row0 + row) * a.N + sgroup(gi) * 16 + 4 * q);
       }
     };
-    auto settle_b = [&](float (&hraw)[NH][kHB][4], f32x4 (&xraw)[KB1], float (&xsraw)[KB1]) {
+    auto settle_b = [&](float (&hraw)[NH][kHB][4], f32x4 (&xraw)[KB1], float (&xsraw)[KB1]) __attribute__((always_inline)) {
       await_loads();
 #pragma unroll
       for (int l = 0; l < NH; ++l)
@@ -1405,19 +1479,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
       for (int kb = 0; kb < KB1; ++kb) { pin(xraw[kb]); pin(xsraw[kb]); }
     };
-    float hraw[NH][kHB][4];
-    f32x4 xraw[KB1];
-    float xsraw[KB1];
-#pragma unroll
-    for (int l = 0; l < NH; ++l)
-#pragma unroll
-      for (int ib = 0; ib < kHB; ++ib)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) hraw[l][ib][t] = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < KB1; ++kb) { xraw[kb] = f32x4{0.f, 0.f, 0.f, 0.f}; xsraw[kb] = 0.f; }
-    if (g_first < n_groups) { issue_b(g_first, hraw, xraw, xsraw); settle_b(hraw, xraw, xsraw); }
-    for (int it = 0; it <= n_it; ++it) {
+    // one iteration: the group (one behind the chain wave) whose B operands sit in the _c set; the next group's go into _n
+    auto dw_iter = [&](int it, float (&hraw_c)[NH][kHB][4], f32x4 (&xraw_c)[KB1], float (&xsraw_c)[KB1],
+                       float (&hraw_n)[NH][kHB][4], f32x4 (&xraw_n)[KB1], float (&xsraw_n)[KB1]) __attribute__((always_inline)) {
       const int64_t gi = g_first + (int64_t)(it - 1) * gstride;
       if (it > 0 && gi < n_groups) {
         f32x4 hb[NH][kHB], xb_[KB1];
@@ -1427,53 +1491,73 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           for (int ib = 0; ib < kHB; ++ib)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-              hb[l][ib][t] = BF16 ? __uint_as_float(__float_as_uint(hraw[l][ib][t]) << 16) : hraw[l][ib][t];
+              hb[l][ib][t] = BF16 ? __uint_as_float(__float_as_uint(hraw_c[l][ib][t]) << 16) : hraw_c[l][ib][t];
 #pragma unroll
         for (int kb = 0; kb < KB1; ++kb) {
           if (kb < ka_blocks) {
-            const float v = xsraw[kb];
+            const float v = xsraw_c[kb];
             xb_[kb] = f32x4{v, v, v, v};
           } else {
-            xb_[kb] = (16 * (kb - ka_blocks) + j) < a.k_b ? xraw[kb] : f32x4{0.f, 0.f, 0.f, 0.f};
+            xb_[kb] = (16 * (kb - ka_blocks) + j) < a.k_b ? xraw_c[kb] : f32x4{0.f, 0.f, 0.f, 0.f};
           }
         }
-        issue_b(min(gi + gstride, n_groups - 1), hraw, xraw, xsraw);  // one group ahead (see the chain waves)
+        issue_b(min(gi + gstride, n_groups - 1), hraw_n, xraw_n, xsraw_n);  // one group ahead (see the chain waves)
         const float* buf = my_tiles + ((it - 1) & 1) * kT * kTileFloats;
         if constexpr (X6 && kSplitDw) {
-          accumulate_dw_split<1, kHB>(buf, hb[NH - 1], acc_o, db_o, j, q);
+          accumulate_dw_split<1, kHB>(buf, hb[NH - 1], acc_o, j, q);
 #pragma unroll
           for (int l = NH - 1; l >= 0; --l) {
             const float* dt = buf + (1 + (NH - 1 - l) * kHB) * kTileFloats;
-            if (l > 0) accumulate_dw_split<kHB, kHB>(dt, hb[l - 1], acc_h[l - 1], db_h[l - 1], j, q);
-            else accumulate_dw_split<kHB, KB1>(dt, xb_, acc_1, db_1, j, q);
+            if (l > 0) accumulate_dw_split<kHB, kHB>(dt, hb[l - 1], acc_h[l - 1], j, q);
+            else accumulate_dw_split<kHB, KB1>(dt, xb_, acc_1, j, q);
           }
         } else {
-          accumulate_dw_regs<1, kHB, BF16>(buf, hb[NH - 1], acc_o, db_o, j, q);
+          accumulate_dw_regs<1, kHB, BF16>(buf, hb[NH - 1], acc_o, j, q);
 #pragma unroll
           for (int l = NH - 1; l >= 0; --l) {
             const float* dt = buf + (1 + (NH - 1 - l) * kHB) * kTileFloats;
-            if (l > 0) accumulate_dw_regs<kHB, kHB, BF16>(dt, hb[l - 1], acc_h[l - 1], db_h[l - 1], j, q);
-            else accumulate_dw_regs<kHB, KB1, BF16>(dt, xb_, acc_1, db_1, j, q);
+            if (l > 0) accumulate_dw_regs<kHB, kHB, BF16>(dt, hb[l - 1], acc_h[l - 1], j, q);
+            else accumulate_dw_regs<kHB, KB1, BF16>(dt, xb_, acc_1, j, q);
           }
         }
-        settle_b(hraw, xraw, xsraw);
+        settle_b(hraw_n, xraw_n, xsraw_n);
       }
       pair_sync(it);
+    };
+    float hraw_a[NH][kHB][4], hraw_b[NH][kHB][4];
+    f32x4 xraw_a[KB1], xraw_b[KB1];
+    float xsraw_a[KB1], xsraw_b[KB1];
+#pragma unroll
+    for (int l = 0; l < NH; ++l)
+#pragma unroll
+      for (int ib = 0; ib < kHB; ++ib)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { hraw_a[l][ib][t] = 0.f; hraw_b[l][ib][t] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < KB1; ++kb) {
+      xraw_a[kb] = f32x4{0.f, 0.f, 0.f, 0.f}; xraw_b[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      xsraw_a[kb] = 0.f; xsraw_b[kb] = 0.f;
+    }
+    // iteration it works on group it - 1: its operands must sit in the set that iteration reads (odd iterations read set b)
+    if (g_first < n_groups) { issue_b(g_first, hraw_b, xraw_b, xsraw_b); settle_b(hraw_b, xraw_b, xsraw_b); }
+    for (int it = 0; it <= n_it; it += 2) {
+      dw_iter(it, hraw_a, xraw_a, xsraw_a, hraw_b, xraw_b, xsraw_b);
+      if (it + 1 <= n_it) dw_iter(it + 1, hraw_b, xraw_b, xsraw_b, hraw_a, xraw_a, xsraw_a);
     }
   }
   // epilogue: per-workgroup partial sums in nn.Linear parameter order W0,b0,W1,b1,... (accumulators live in waves 4-7)
-  const int slot = role == 1 ? pair : -1;
+  const int slot = role == 1 ? pair : -1, chain = role == 0 ? pair : -1;
   float* out = a.dW_partial + (size_t)blockIdx.x * a.total_params;
   float* red = tiles;
   int poff = 0;
-  flush_dw_ws<kHB, KB1>(red, acc_1, db_1, out + poff, kWidth, k_in, slot);
+  flush_dw_ws<kHB, KB1>(red, acc_1, dbc_1, out + poff, kWidth, k_in, slot, chain);
   poff += kWidth * k_in + kWidth;
 #pragma unroll
   for (int l = 1; l < NH; ++l) {
-    flush_dw_ws<kHB, kHB>(red, acc_h[l - 1], db_h[l - 1], out + poff, kWidth, kWidth, slot);
+    flush_dw_ws<kHB, kHB>(red, acc_h[l - 1], dbc_h[l - 1], out + poff, kWidth, kWidth, slot, chain);
     poff += kWidth * kWidth + kWidth;
   }
-  flush_dw_ws<1, kHB>(red, acc_o, db_o, out + poff, a.out_dim, kWidth, slot);
+  flush_dw_ws<1, kHB>(red, acc_o, dbc_o, out + poff, a.out_dim, kWidth, slot, chain);
 }
 
 size_t ws_bwd_lds_bytes(int n_hidden, int kb1, int blk = 256) {
