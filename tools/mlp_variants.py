@@ -15,8 +15,16 @@ if len(sys.argv) > 1 and sys.argv[1] != "run":
     others = [os.path.join(libdir, f) for f in os.listdir(libdir) if f.endswith(".o") and f != "mlp.o"]
     procs = []
     for name, flags in variants:
+        source = os.path.join(src, "mlp.hip")
+        flist = [f for f in flags.split(",") if f]
+        for f in list(flist):
+            if f.startswith("src="):  # another version of the source file (e.g. an older kernel written out of the history)
+                flist.remove(f)
+                source = f"{out}/{name}.hip"
+                text = open(os.path.join(ROOT, f[4:])).read().replace('"../../include/nesvor_hip.h"', '"nesvor_hip.h"').replace('"common.h"', f'"{src}/common.h"')
+                open(source, "w").write(text)
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off",
-               *[f for f in flags.split(",") if f], "-I", os.path.join(ROOT, "include"), "-c", os.path.join(src, "mlp.hip"), "-o", f"{out}/{name}.o"]
+               *flist, "-I", os.path.join(ROOT, "include"), "-c", source, "-o", f"{out}/{name}.o"]
         procs.append(subprocess.Popen(cmd, stderr=subprocess.DEVNULL))
     for p in procs:
         assert p.wait() == 0
