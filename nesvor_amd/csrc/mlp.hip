@@ -1233,8 +1233,14 @@ __device__ __forceinline__ void accumulate_dw_regs(const float* tiles, const f32
 // cycles during which the SIMD issues no VALU work at all), smallest terms first.  The operands are split here: the A
 // tiles come out of LDS as fp32, the B operands are the prefetched fp32 registers.  (The bias gradients - sums of the A
 // operands over the samples - are accumulated by the chain waves, which hold the same values and have registers to spare.)
+// The A operand of an output block comes out of the staging tiles (LDS, four ds_read_b32 per lane) and is needed a few
+// instructions later by its split: left to the scheduler the read sits right in front of its use and every one of the nine
+// operand fragments of a group pays the LDS latency in full (this wave has ONE partner on its SIMD).  The reads are therefore
+// issued one fragment ahead - `av` arrives requested, the next fragment (of this layer, or `next_tile` = the first of the
+// next layer) is requested before the current one is multiplied - and a scheduling barrier keeps LDS reads from sinking.
 template <int OB, int IB>
-__device__ __forceinline__ void accumulate_dw_split(const float* tiles, const f32x4 (&bv)[IB], f32x4 (&acc)[OB][IB], int i, int q) {
+__device__ __forceinline__ void accumulate_dw_split(const float* tiles, const f32x4 (&bv)[IB], f32x4 (&acc)[OB][IB], int i, int q,
+                                                    float (&av)[4], const float* next_tile) {
   bf16x8 b_hl[IB], b_mh[IB];
 #pragma unroll
   for (int ib = 0; ib < IB; ++ib) {
@@ -1244,8 +1250,10 @@ __device__ __forceinline__ void accumulate_dw_split(const float* tiles, const f3
   }
 #pragma unroll
   for (int ob = 0; ob < OB; ++ob) {
-    float av[4];
-    read_operand(tiles + ob * kTileFloats, i, q, av);
+    float an[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* nt = ob + 1 < OB ? tiles + (ob + 1) * kTileFloats : next_tile;
+    if (nt != nullptr) read_operand(nt, i, q, an);
+    __builtin_amdgcn_sched_barrier(0x047F);  // everything but LDS instructions may cross: the read above stays above
     const Split3 sa = split3(f32x4{av[0], av[1], av[2], av[3]});
     const bf16x8 a_lh = join8(sa.lo, sa.hi), a_mm = join8(sa.mid, sa.mid), a_hh = join8(sa.hi, sa.hi);
 #pragma unroll
@@ -1254,6 +1262,8 @@ __device__ __forceinline__ void accumulate_dw_split(const float* tiles, const f3
     for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma32_bf16(a_mm, b_mh[ib], acc[ob][ib]);
 #pragma unroll
     for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma32_bf16(a_hh, b_mh[ib], acc[ob][ib]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) av[t] = an[t];
   }
 }
 
@@ -1457,8 +1467,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
       xoff[kb] = (uint32_t)(((int64_t)(a.b_row0 + row) * a.N + 4 * q) * 4);
     }
     // The saved activations are prefetched a whole group ahead into a second register set (32 registers each, swapped every
-    // iteration).  The network input - the operand an iteration uses LAST - has one set: it is re-requested right after its
-    // use and awaited (loads retire in order: vmcnt(loads issued after it)) right before its next use, a whole iteration later.
+    // iteration).  The network input - the operand an iteration uses LAST, two thirds of an iteration (~3 us) after its top -
+    // has one register set: it is requested at the top of the iteration that uses it, BEFORE the next group's activations, and
+    // awaited with vmcnt(activation loads) - loads retire in order, the younger ones may stay in flight.  (Issue and settle of
+    // a register always sit in the same straight-line region: at a control-flow merge the compiler may copy registers, and a
+    // copy of a register with a load in flight reads stale data.)
     auto issue_h = [&](int64_t gi, float (&hraw)[NH][kHB][4]) __attribute__((always_inline)) {
       // element (sample 4q + t, feature j of block ib) of the fragment layout [block][lane = (f >> 2) * 16 + sample][f & 3]
       const uint32_t voff = (uint32_t)((((j >> 2) * 16 + 4 * q) * 4 + (j & 3)) * kHBytes);
@@ -1474,7 +1487,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         });
       }
     };
-    constexpr int kHLoads = NH * kHB * 4, kXLoads = 2 * KB1;  // loads per group of the two kinds
+    constexpr int kHLoads = NH * kHB * 4;  // activation loads per group
     auto issue_x = [&](int64_t gi, f32x4 (&xraw)[KB1], float (&xsraw)[KB1]) __attribute__((always_inline)) {
       // both candidate sources of every input block are requested (no branch between issue and settle); the block
       // type picks one after the loads have landed
@@ -1517,11 +1530,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
               hb[l][ib][t] = BF16 ? __uint_as_float(__float_as_uint(hraw_c[l][ib][t]) << 16) : hraw_c[l][ib][t];
-        const int64_t gnext = min(gi + gstride, n_groups - 1);  // (the last iteration re-requests its own group: no control flow between an issue and its settle)
+        const int64_t gnext = min(gi + gstride, n_groups - 1);  // (the last iteration re-requests a valid group: no control flow between an issue and its settle)
+        issue_x(gi, xraw, xsraw);
         issue_h(gnext, hraw_n);
         const float* buf = my_tiles + ((it - 1) & 1) * kT * kTileFloats;
         auto input_operands = [&](f32x4 (&xb_)[KB1]) __attribute__((always_inline)) {
-          settle_x(xraw, xsraw, std::integral_constant<int, kHLoads>{});  // requested one iteration ago; the kHLoads of this iteration may fly on
+          settle_x(xraw, xsraw, std::integral_constant<int, kHLoads>{});  // requested at the top, before the kHLoads that may fly on
 #pragma unroll
           for (int kb = 0; kb < KB1; ++kb) {
             if (kb < ka_blocks) {
@@ -1533,16 +1547,18 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           }
         };
         if constexpr (X6 && kSplitDw) {
-          accumulate_dw_split<1, kHB>(buf, hb[NH - 1], acc_o, j, q);
+          float av[4];
+          read_operand(buf, j, q, av);  // dY tile; every later A fragment is requested one fragment ahead (accumulate_dw_split)
+          accumulate_dw_split<1, kHB>(buf, hb[NH - 1], acc_o, j, q, av, buf + kTileFloats);
 #pragma unroll
           for (int l = NH - 1; l >= 0; --l) {
             const float* dt = buf + (1 + (NH - 1 - l) * kHB) * kTileFloats;
             if (l > 0) {
-              accumulate_dw_split<kHB, kHB>(dt, hb[l - 1], acc_h[l - 1], j, q);
+              accumulate_dw_split<kHB, kHB>(dt, hb[l - 1], acc_h[l - 1], j, q, av, dt + kHB * kTileFloats);
             } else {
               f32x4 xb_[KB1];
               input_operands(xb_);
-              accumulate_dw_split<kHB, KB1>(dt, xb_, acc_1, j, q);
+              accumulate_dw_split<kHB, KB1>(dt, xb_, acc_1, j, q, av, nullptr);
             }
           }
         } else {
@@ -1559,8 +1575,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             }
           }
         }
-        issue_x(gnext, xraw, xsraw);                                     // used at the end of the next iteration
-        settle_h(hraw_n, std::integral_constant<int, kXLoads>{});       // issued at the top of this one
+        settle_h(hraw_n, std::integral_constant<int, 0>{});
       }
       pair_sync(it);
     };
@@ -1576,9 +1591,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     // iteration it works on group it - 1: its activations must sit in the set that iteration reads (odd iterations read set b)
     if (g_first < n_groups) {
       issue_h(g_first, hraw_b);
-      issue_x(g_first, xraw, xsraw);
       settle_h(hraw_b, std::integral_constant<int, 0>{});
-      settle_x(xraw, xsraw, std::integral_constant<int, 0>{});
     }
     for (int it = 0; it <= n_it; it += 2) {
       dw_iter(it, hraw_a, hraw_b);
