@@ -340,20 +340,42 @@ __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, co
       a.lo = *reinterpret_cast<const s16x4*>(pa + 2 * plane);
       return a;
     };
-    // term-major over the OB independent accumulators (see apply_layer)
-#pragma unroll
-    for (int kb = 0; kb + 1 < KB; kb += 2) {
-      const Split3 p0 = split3(x[kb]), p1 = split3(x[kb + 1]);
-      const bf16x8 bh = join8(p0.hi, p1.hi), bm = join8(p0.mid, p1.mid), bl = join8(p0.lo, p1.lo);
-      bf16x8 ah[OB], am[OB], al[OB];
+    // term-major over the OB independent accumulators (see apply_layer).  The weight planes of a k-block pair are read from
+    // LDS while the activations of that pair are being split (NESVOR_MLP_APREFETCH: and those of the NEXT pair before the
+    // products of the current one), not right in front of the first product that needs them.
+#ifndef NESVOR_MLP_APREFETCH
+#define NESVOR_MLP_APREFETCH 1
+#endif
+    auto load_pair = [&](int kb, bf16x8 (&ah)[OB], bf16x8 (&am)[OB], bf16x8 (&al)[OB]) __attribute__((always_inline)) {
 #pragma unroll
       for (int ob = 0; ob < OB; ++ob) {
         const Split3 a0 = load_a(ob, kb), a1 = load_a(ob, kb + 1);
         ah[ob] = join8(a0.hi, a1.hi); am[ob] = join8(a0.mid, a1.mid); al[ob] = join8(a0.lo, a1.lo);
       }
+    };
+    bf16x8 ah[OB], am[OB], al[OB];
+    if constexpr (KB >= 2) {
+      load_pair(0, ah, am, al);
+      __builtin_amdgcn_sched_barrier(0x047F);  // LDS reads stay above, everything else may cross
+    }
+#pragma unroll
+    for (int kb = 0; kb + 1 < KB; kb += 2) {
+      const Split3 p0 = split3(x[kb]), p1 = split3(x[kb + 1]);
+      const bf16x8 bh = join8(p0.hi, p1.hi), bm = join8(p0.mid, p1.mid), bl = join8(p0.lo, p1.lo);
+      bf16x8 nh[OB], nm[OB], nl[OB];
+      const bool more = kb + 3 < KB;
+      if (NESVOR_MLP_APREFETCH && more) {
+        load_pair(kb + 2, nh, nm, nl);
+        __builtin_amdgcn_sched_barrier(0x047F);
+      }
 #define NESVOR_TERM(A, B) _Pragma("unroll") for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_bf16(A[ob], B, y[ob]);
       NESVOR_TERM(al, bh) NESVOR_TERM(ah, bl) NESVOR_TERM(am, bm) NESVOR_TERM(am, bh) NESVOR_TERM(ah, bm) NESVOR_TERM(ah, bh)
 #undef NESVOR_TERM
+      if (more) {
+        if (!NESVOR_MLP_APREFETCH) load_pair(kb + 2, nh, nm, nl);
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) { ah[ob] = nh[ob]; am[ob] = nm[ob]; al[ob] = nl[ob]; }
+      }
     }
     if constexpr (KB % 2 == 1) {
       const Split3 pb = split3(x[KB - 1]);
