@@ -140,20 +140,25 @@ def measure_extras(model, args, device, opt):
             torch.cuda.synchronize()
         tb = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR))
         tb0 = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, False, _lib.LAYOUT_FEATURE_MAJOR))  # parameter gradient only
-        res[name] = (tf, tb, tb0)
-    tf, tb, _ = res["uniform"]
+        # as inside the training step: the producer of dy (the MLP backward) hands over max |dy|, the pass over dy is skipped
+        bound = dy.abs().max().reshape(1)
+        tbb = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR, dy_bound=bound))
+        res[name] = (tf, tb, tb0, tbb)
+    tf, tb, _, _ = res["uniform"]
     out["roofline_uniform"] = {
         "bound": "hbm", "kernel": "hashgrid_bwd (aggregate + owner), u ~ U[0,1)^3, N = 2^20", "achieved": (bwd_b + bwd_in_b) / (tb * 1e-3) / 1e9,
         "peak": 8000.0, "unit": "GB/s", "frac": (bwd_b + bwd_in_b) / (tb * 1e-3) / 1e9 / 8000.0, "launch_ms": tb, "forward_ms": tf,
         "note": "uniform points share no lattice vertices inside a 256-sample workgroup at the fine levels: the per-cloud merge "
                 "table collapses nothing there and the pass is bound by the record stream (8 records of 12 B per point and level) "
                 "and the owner pass's LDS compare-and-swap adds; the training distribution is the PSF-cloud one"}
-    tf, tb, tb0 = res["psf_cloud"]
+    tf, tb, tb0, tbb = res["psf_cloud"]
     out["roofline_fwd_bwd_strict"] = {
         "bound": "hbm", "kernel": "hashgrid_fwd + hashgrid_bwd, PSF-cloud points, N = 2^20 (SURVEY 8d definition: forward + "
                                   "parameter-gradient bytes = 2328 B/point at L=16; the backward is timed WITH the input gradient)",
         "achieved": (fwd_b + bwd_b) / ((tf + tb) * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
         "frac": (fwd_b + bwd_b) / ((tf + tb) * 1e-3) / 1e9 / 8000.0, "forward_ms": tf, "backward_ms": tb,
+        "backward_with_producer_bound_ms": tbb,  # max |dy| supplied by the producer of dy, as in the training step
+        "frac_with_producer_bound": (fwd_b + bwd_b) / ((tf + tbb) * 1e-3) / 1e9 / 8000.0,
         "backward_param_grad_only_ms": tb0,  # the pass those bytes describe: the input gradient (poses) switched off
         "frac_param_grad_only": (fwd_b + bwd_b) / ((tf + tb0) * 1e-3) / 1e9 / 8000.0}
     # inference: one chunk of the reference's default size (inference_batch_size = 8 x 4096 points, 2 x 256 samples)

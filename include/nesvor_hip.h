@@ -210,6 +210,13 @@ int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* u, const fl
 int nesvor_hashgrid_backward_levels(const nesvor_grid_t* grid, const float* u, const float* table, const float* dpe,
                                     float* grad_table, float* grad_u, int64_t N, int layout, void* workspace, int stages,
                                     int level_begin, int level_end, const float* queue_scale, void* stream);
+/* nesvor_hashgrid_backward_levels with a caller-supplied bound: dy_bound = device scalar >= max |dpe| over the batch (any
+ * upper bound within ~2^20 of the true maximum keeps fp32 accuracy: the merge table sums in 64-bit fixed point scaled by
+ * it), or NULL = the kernel determines each workgroup's maximum itself by reading dpe once more (134 MB at N = 2^20). */
+int nesvor_hashgrid_backward_bounded(const nesvor_grid_t* grid, const float* u, const float* table, const float* dpe,
+                                     float* grad_table, float* grad_u, int64_t N, int layout, void* workspace, int stages,
+                                     int level_begin, int level_end, const float* queue_scale, const float* dy_bound,
+                                     void* stream);
 /* Same contract, tcnn-style per-corner global atomics (slow on MI355X: memory-side atomics). */
 int nesvor_hashgrid_backward_atomic(const nesvor_grid_t* grid, const float* u, const float* table, const float* dpe,
                                     float* grad_table, float* grad_u, int64_t N, int layout, void* stream);
@@ -286,6 +293,12 @@ int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, const float* xb
 int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, const float* xb, const float* dy,
                         float* const* saved_hidden, float* const* dpre_scratch, float* dxa, float* dxb,
                         float* dw_partial, int n_partial, int64_t N, void* stream);
+/* The same backward; additionally raises the device scalar *dxb_absmax (atomic max; the caller zero-fills it) to max |dxb|
+ * when dxb_absmax and dxb are non-NULL: the consumer of dxb - the hash-grid backward, nesvor_hashgrid_backward_bounded -
+ * then needs no pass of its own over the gradient to scale its fixed-point sums. */
+int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float* xa, const float* xb, const float* dy,
+                                float* const* saved_hidden, float* const* dpre_scratch, float* dxa, float* dxb,
+                                float* dw_partial, int n_partial, int64_t N, float* dxb_absmax, void* stream);
 
 /* ------------------------------------------------------------------------
  * Imaging model + losses, value and gradient in one launch.  Replaces the tail of
@@ -362,7 +375,7 @@ int nesvor_sum_rows(const float* in, float* out, int rows, int cols, int ld, voi
  * pointers unless stated; gradients go straight into the caller's (flat) gradient buffer, which the AdamW step zero-fills.
  *   switches   : opt_T = !no_transformation_optimization, has_lv = !no_pixel_variance, has_c = !no_slice_scale,
  *                has_lvs = !no_slice_variance, has_b = n_levels_bias > 0 (cli/main.py:61,86-110)
- *   small      : n (1 + 12 + 13) floats: slice scale c | pose matrices | zeroed accumulators [dc | dmat]
+ *   small      : n (1 + 12 + 13) + 1 floats: slice scale c | pose matrices | zeroed accumulators [dc | dmat] | max |dpe|
  *   saved_*    : per hidden layer N_pad16 * 64 floats (nesvor_mlp_forward);  partial: NESVOR_STEP_MLP_PARTIALS x (largest
  *                network's parameter count) floats;  losses (run argument): 6 floats {MSE, logVar, MSE+logVar, transReg,
  *                imageReg, biasReg} (models.py:14-19)

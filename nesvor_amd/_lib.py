@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NESVOR_HIP_LIB: load another build of the same ABI (tools/ablate_hashgrid.py times variants of one kernel this way)
 LIB_PATH = os.environ.get("NESVOR_HIP_LIB") or os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -123,6 +123,7 @@ _SIGNATURES = {
     "nesvor_hashgrid_backward_overflow_offset": ([_P], c_int64),
     "nesvor_hashgrid_backward": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P, _P], c_int),
     "nesvor_hashgrid_backward_levels": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, c_int, c_int, _P, _P], c_int),
+    "nesvor_hashgrid_backward_bounded": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, c_int, c_int, _P, _P, _P], c_int),
     "nesvor_hashgrid_backward_atomic": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
     "nesvor_psf_transform_forward": ([_P] * 8 + [c_int, c_int, _P], c_int),
     "nesvor_psf_transform_backward": ([_P] * 9 + [c_int, c_int, _P], c_int),
@@ -132,6 +133,10 @@ _SIGNATURES = {
     "nesvor_mlp_forward": ([POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), c_int64, _P], c_int),
     "nesvor_mlp_backward": (
         [POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), POINTER(c_void_p), _P, _P, _P, c_int, c_int64, _P],
+        c_int,
+    ),
+    "nesvor_mlp_backward_bounded": (
+        [POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), POINTER(c_void_p), _P, _P, _P, c_int, c_int64, _P, _P],
         c_int,
     ),
     "nesvor_imaging_loss": ([POINTER(LossT), _P], c_int),

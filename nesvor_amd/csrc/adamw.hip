@@ -106,4 +106,4 @@ extern "C" int nesvor_sum_rows(const float* in, float* out, int rows, int cols, 
   return (int)hipGetLastError();
 }
 
-extern "C" int nesvor_hip_abi_version(void) { return 24; }
+extern "C" int nesvor_hip_abi_version(void) { return 25; }

@@ -527,6 +527,7 @@ struct BwdPlan {
   uint32_t box_slots;                          // 0: the merge table is always hashed (A/B switch NESVOR_HASHGRID_BOX=0)
   int32_t level_begin, level_end;              // this launch handles levels [level_begin, level_end) (all by default)
   int32_t accumulate_u;                        // input gradient: add to grad_u instead of overwriting (later launches of a split backward)
+  const float* dy_bound;                       // device scalar >= max |dy| over the whole batch, or null: the kernel reads all dy itself first
 };
 
 __device__ __forceinline__ uint32_t spread3(uint32_t x) {  // 8 bits -> every third bit
@@ -697,7 +698,12 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
     // levels' loads in flight at a time).  The adds of one slot sum to at most 256 max|dy| (corner weights of a sample
     // sum to 1), which is mapped below 2^61 (2^30 for the packed 32-bit fields); 64-bit words then resolve
     // max|dy| 2^-52, far below an fp32 ulp of any gradient that matters next to the largest one.
+    // With a caller-supplied bound (the producer of dy knows its largest magnitude: nesvor_mlp_backward_bounded) that pass
+    // over dy - 134 MB at N = 2^20, read a second time level by level below - is skipped: 64-bit words leave room for a
+    // bound that is orders of magnitude above this workgroup's own maximum.
     float m = 0.f;
+    if (plan.dy_bound != nullptr) m = *plan.dy_bound;
+    else
     for (int l0 = plan.level_begin; l0 < level_end; l0 += 8) {
       float d[8][F];
 #pragma unroll
@@ -1555,11 +1561,12 @@ inline int tails_parity(void* workspace, bool advance) {
 template <int F, int LAYOUT>
 int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table, const float* dpe, float* gt,
                      float* gu, int64_t N, void* workspace, int stages, int level_begin, int level_end, const float* queue_scale,
-                     hipStream_t st) {
+                     const float* dy_bound, hipStream_t st) {
   BwdPlan plan;
   uint64_t n_rec;
   if (!make_plan(g, N, &plan, &n_rec, queue_scale)) return (int)hipErrorInvalidValue;
   plan.level_begin = level_begin; plan.level_end = level_end;
+  plan.dy_bound = dy_bound;
   plan.accumulate_u = (stages & 8) ? 1 : 0;
   // bit 4: a later launch of a split backward - same region, the queue tails of its levels are still zero
   const int par = tails_parity(workspace, (stages & 1) && !(stages & 4));
@@ -1685,7 +1692,7 @@ extern "C" int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* 
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
   if (workspace == nullptr || (stages & 3) == 0) return (int)hipErrorInvalidValue;
   DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages & 3, 0, grid->n_levels,
-                    queue_scale, (hipStream_t)stream);
+                    queue_scale, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int nesvor_hashgrid_backward_levels(const nesvor_grid_t* grid, const float* u, const float* table,
@@ -1697,5 +1704,17 @@ extern "C" int nesvor_hashgrid_backward_levels(const nesvor_grid_t* grid, const 
   if (workspace == nullptr || (stages & 3) == 0) return (int)hipErrorInvalidValue;
   if (level_begin < 0 || level_end > grid->n_levels || level_begin >= level_end) return (int)hipErrorInvalidValue;
   DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages, level_begin, level_end,
-                    queue_scale, (hipStream_t)stream);
+                    queue_scale, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int nesvor_hashgrid_backward_bounded(const nesvor_grid_t* grid, const float* u, const float* table,
+                                                const float* dpe, float* grad_table, float* grad_u, int64_t N, int layout,
+                                                void* workspace, int stages, int level_begin, int level_end,
+                                                const float* queue_scale, const float* dy_bound, void* stream) {
+  if (N <= 0) return 0;
+  if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
+  if (workspace == nullptr || (stages & 3) == 0) return (int)hipErrorInvalidValue;
+  if (level_begin < 0 || level_end > grid->n_levels || level_begin >= level_end) return (int)hipErrorInvalidValue;
+  DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages, level_begin, level_end,
+                    queue_scale, dy_bound, (hipStream_t)stream);
 }

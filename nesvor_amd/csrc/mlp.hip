@@ -76,7 +76,25 @@ struct MlpArgs {
   int dxa_group;                // dxa holds one row per 16-sample GROUP (sum over its samples) instead of one per sample
   int bf16;                     // 1: matrix operands rounded to bf16 (fp32 accumulation); 2: operands split into three bf16 (fp32-equivalent)
   int off32;                    // every row of xb / y starts below 2^32 bytes: lane offsets fit the 32-bit VGPR offset of scalar-base loads
+  float* dx_absmax;             // bwd, optional: device scalar raised (atomic max) to max |dxb| - the consumer of dxb (the hash-grid
+                                // backward) scales its fixed-point sums by it instead of reading dxb an extra time
 };
+
+// max |dx| over the xb blocks of a lane's dX fragments, folded into `mx`
+template <int KB1>
+__device__ __forceinline__ void track_absmax(const MlpArgs& a, const f32x4 (&dx)[KB1], float& mx) {
+  const int ka_blocks = a.k_a >> 4;
+#pragma unroll
+  for (int kb = 0; kb < KB1; ++kb)
+    if (kb >= ka_blocks) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(dx[kb][r]));
+    }
+}
+__device__ __forceinline__ void publish_absmax(const MlpArgs& a, float mx) {
+  mx = wave_max(mx);  // rows beyond k_b hold exact zeros (zero weight columns): they cannot raise the maximum
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(a.dx_absmax), __float_as_uint(mx));
+}
 
 // ReLU as an integer max: negative floats (and -0) are negative integers.  fmaxf() compiles to TWO instructions
 // (v_max_f32 x, x to quiet a signalling NaN, then the max), this is one.
@@ -344,7 +362,7 @@ __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, co
     // LDS while the activations of that pair are being split (NESVOR_MLP_APREFETCH: and those of the NEXT pair before the
     // products of the current one), not right in front of the first product that needs them.
 #ifndef NESVOR_MLP_APREFETCH
-#define NESVOR_MLP_APREFETCH 1
+#define NESVOR_MLP_APREFETCH 0  // measured (tools/mlp_variants.py, same box): 0.268 / 0.227 ms without, 0.275 / 0.233 ms with the read-ahead of the next pair
 #endif
     auto load_pair = [&](int kb, bf16x8 (&ah)[OB], bf16x8 (&am)[OB], bf16x8 (&al)[OB]) __attribute__((always_inline)) {
 #pragma unroll
@@ -775,6 +793,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_dx_kernel(const MlpArgs a) {
   const int j = lane & 15, q = lane >> 4;
   const int64_t n_groups = (a.N + 15) / 16;
   const int64_t n_tiles = (n_groups + 4 * kG - 1) / (4 * kG);
+  float dx_mx = 0.f;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t g0 = (tile * 4 + wave) * kG;
     f32x4 go[kG][1];
@@ -829,6 +848,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_dx_kernel(const MlpArgs a) {
       for (int g = 0; g < kG; ++g) {
         const int64_t n = (g0 + g) * 16 + j;
         if (n >= a.N) continue;
+        if (a.dx_absmax != nullptr) track_absmax<KB1>(a, dx[g], dx_mx);
 #pragma unroll
         for (int ib = 0; ib < KB1; ++ib)
 #pragma unroll
@@ -843,6 +863,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_dx_kernel(const MlpArgs a) {
       }
     }
   }
+  if (a.dx_absmax != nullptr) publish_absmax(a, dx_mx);
 }
 
 // ----------------------------------------------------------- backward: dW, db
@@ -1088,6 +1109,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const MlpArgs a) {
   };
   const int64_t gstride = (int64_t)gridDim.x * 4;
   f32x4 go[1], go_n[1], hs[NH][kHB], hs_n[NH][kHB], x[KB1], x_n[KB1];
+  float dx_mx = 0.f;
   int64_t gi = (int64_t)blockIdx.x * 4 + wave;
   if (gi < n_groups) load_group(gi, go, hs, x);
   for (; gi < n_groups; gi += gstride) {
@@ -1121,6 +1143,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const MlpArgs a) {
 #pragma unroll
           for (int ib = 0; ib < KB1; ++ib) dx[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
           apply_layer_g1<kHB, KB1>(img1, d, dx, lane);
+          if (a.dx_absmax != nullptr && nv) track_absmax<KB1>(a, dx, dx_mx);
           // gfx9 counts loads and stores in one vmcnt and the compiler waits for vmcnt(0) once both kinds are
           // pending: drain the prefetch loads (issued a whole group of MFMAs ago) HERE, before the stores below,
           // so that the next iteration does not stall on the latency of these stores when it first touches the
@@ -1153,6 +1176,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const MlpArgs a) {
 #pragma unroll
     for (int kb = 0; kb < KB1; ++kb) x[kb] = x_n[kb];
   }
+  if (a.dx_absmax != nullptr) publish_absmax(a, dx_mx);
   // epilogue: per-workgroup partial sums in nn.Linear parameter order W0,b0,W1,b1,...
   float* out = a.dW_partial + (size_t)blockIdx.x * a.total_params;
   float* red = scratch_all;
@@ -1390,6 +1414,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
         for (int ib = 0; ib < kHB; ++ib) pin(hs[l][ib]);
     };
+    float dx_mx = 0.f;
     // one iteration: the group whose inputs sit in (gy_c, hs_c); the next group's inputs are requested into (gy_n, hs_n)
     auto chain_iter = [&](int it, float (&gy_c)[4], RawH (&hs_c)[NH][kHB], float (&gy_n)[4], RawH (&hs_n)[NH][kHB]) __attribute__((always_inline)) {
       const int64_t gi = g_first + (int64_t)it * gstride;
@@ -1439,6 +1464,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
             for (int ib = 0; ib < KB1; ++ib) dx[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
             apply_layer_g1<kHB, KB1, BF16, X6>(img1, d, dx, lane);
+            if (a.dx_absmax != nullptr) track_absmax<KB1>(a, dx, dx_mx);
             // drain the prefetch BEFORE the stores below: loads and stores share vmcnt, and the wait would otherwise
             // also cover the latency of these stores
             settle_group(gy_n, hs_n);
@@ -1464,6 +1490,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
       chain_iter(it, gy_a, hs_a, gy_b, hs_b);
       if (it + 1 <= n_it) chain_iter(it + 1, gy_b, hs_b, gy_a, hs_a);
     }
+    if (a.dx_absmax != nullptr) publish_absmax(a, dx_mx);
   } else {
     // ------------------------------------------------------------------ dW waves
 #pragma unroll
@@ -1757,10 +1784,17 @@ extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, cons
 extern "C" int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, const float* xb, const float* dy,
                                    float* const* saved_hidden, float* const* dpre_scratch, float* dxa, float* dxb,
                                    float* dw_partial, int n_partial, int64_t N, void* stream) {
+  return nesvor_mlp_backward_bounded(net, xa, xb, dy, saved_hidden, dpre_scratch, dxa, dxb, dw_partial, n_partial, N, nullptr, stream);
+}
+
+extern "C" int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float* xa, const float* xb, const float* dy,
+                                           float* const* saved_hidden, float* const* dpre_scratch, float* dxa, float* dxb,
+                                           float* dw_partial, int n_partial, int64_t N, float* dxb_absmax, void* stream) {
   if (N <= 0) return 0;
   MlpArgs a{};
   int e = fill_args(&a, net, N);
   if (e) return e;
+  a.dx_absmax = dxb != nullptr ? dxb_absmax : nullptr;
   if (saved_hidden == nullptr || dpre_scratch == nullptr || dw_partial == nullptr || n_partial < 1) return (int)hipErrorInvalidValue;
   const bool split = a.bf16 == 2;  // fp32 data everywhere; only the MFMA sites differ
   if (split) a.bf16 = 0;

@@ -81,11 +81,11 @@ __global__ void square_kernel(const float* __restrict__ m, float* __restrict__ o
 
 int mlp_backward_into(const nesvor_mlp_t& net, int group_sums, const float* xa, const float* xb, const float* dy,
                       float* const* saved, float* dxa, float* dxb, float* partial, float* grad_segment, int n_params,
-                      int64_t N, hipStream_t st) {
+                      int64_t N, hipStream_t st, float* dxb_absmax = nullptr) {
   nesvor_mlp_t d = net;
   d.dxa_group_sums = group_sums;
   float* no_scratch[NESVOR_MAX_MLP_LAYERS] = {nullptr, nullptr, nullptr, nullptr};  // fused dX + dW + db kernel: no dpre scratch
-  NESVOR_TRY(nesvor_mlp_backward(&d, xa, xb, dy, saved, no_scratch, dxa, dxb, partial, NESVOR_STEP_MLP_PARTIALS, N, st));
+  NESVOR_TRY(nesvor_mlp_backward_bounded(&d, xa, xb, dy, saved, no_scratch, dxa, dxb, partial, NESVOR_STEP_MLP_PARTIALS, N, dxb_absmax, st));
   // per-workgroup partial sums (columns W0,b0,W1,b1,...) -> the network's segment of the flat gradient
   return nesvor_sum_rows(partial, grad_segment, NESVOR_STEP_MLP_PARTIALS, n_params, n_params, st);
 }
@@ -133,6 +133,9 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   float* acc = d.small + 13 * n;                 // [dc (n) | dmat (n,12)], zero-filled by the prologue
   float* dc = acc;
   float* dmat = acc + n;
+  // max |dpe|, raised by the density network's backward and read by the hash-grid backward (which then skips its own pass
+  // over dpe); zero-filled with the accumulators.  With a bias field dpe is a sum of two networks' gradients: no bound.
+  float* dpe_bound = d.has_b ? nullptr : d.small + 26 * n;
   const int layout = NESVOR_LAYOUT_FEATURE_MAJOR;
 
   if (phase != 2) {
@@ -143,7 +146,7 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
       if (hipEventRecord(ctx->ev_pose, side) != hipSuccess) return (int)hipGetLastError();
     }
     // ---- forward
-    NESVOR_TRY(nesvor_step_prologue(d.has_c ? d.logit_coef : nullptr, c, d.axisangle, mat, acc, 13 * n, n, main));
+    NESVOR_TRY(nesvor_step_prologue(d.has_c ? d.logit_coef : nullptr, c, d.axisangle, mat, acc, 13 * n + 1, n, main));
     NESVOR_TRY(nesvor_psf_transform_forward_rng(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.x, d.u, B, S, main));
     NESVOR_TRY(nesvor_hashgrid_forward(&d.grid, d.u, d.table, d.pe, N, layout | (S >= 128 ? NESVOR_LAYOUT_CLUSTERED : 0), main));
     NESVOR_TRY(nesvor_mlp_forward(&d.density, nullptr, d.pe, d.z, d.saved_d, N, main));
@@ -177,7 +180,7 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
       NESVOR_TRY(mlp_backward_into(d.sigma, group_sums, d.se, d.z, d.dlv, d.saved_s, d.ks ? d.dxa : nullptr, d.dz + N, d.partial,
                                    d.g_sigma, d.n_sigma_params, N, main));
     NESVOR_TRY(mlp_backward_into(d.density, 0, nullptr, d.pe, d.dz, d.saved_d, nullptr, d.dpe, d.partial, d.g_density,
-                                 d.n_density_params, N, main));
+                                 d.n_density_params, N, main, dpe_bound));
     if (d.has_b) {
       NESVOR_TRY(mlp_backward_into(d.bias_net, group_sums, d.se, d.pe, d.dlb, d.saved_b, d.ks ? d.dxa_b : nullptr, d.dpe_b, d.partial,
                                    d.g_bias_net, d.n_bias_params, N, main));
@@ -188,8 +191,8 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   // ---- hash-grid backward (+ input gradient when the poses are optimised)
   float* du = d.opt_T ? d.du : nullptr;
   if (phase == 0) {
-    NESVOR_TRY(nesvor_hashgrid_backward_levels(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 1, 0, L,
-                                               d.queue_scale, main));
+    NESVOR_TRY(nesvor_hashgrid_backward_bounded(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 1, 0, L,
+                                                d.queue_scale, dpe_bound, main));
     if (d.overlap_owner) {
       // the owner pass only finishes grad_table: it runs under the sampler backward and the per-slice bookkeeping
       if (hipEventRecord(ctx->ev_agg, main) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_agg, 0) != hipSuccess) return (int)hipGetLastError();
@@ -202,11 +205,11 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
     }
   } else if (phase == 1) {
     // fine levels first (the end of the flat gradient): the host starts their all-reduce when this call returns
-    return nesvor_hashgrid_backward_levels(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 3, split_level, L,
-                                           d.queue_scale, main);
+    return nesvor_hashgrid_backward_bounded(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 3, split_level, L,
+                                            d.queue_scale, dpe_bound, main);
   } else {
-    NESVOR_TRY(nesvor_hashgrid_backward_levels(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 3 | 4 | 8, 0,
-                                               split_level, d.queue_scale, main));
+    NESVOR_TRY(nesvor_hashgrid_backward_bounded(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 3 | 4 | 8, 0,
+                                                split_level, d.queue_scale, dpe_bound, main));
   }
   if (d.opt_T)
     NESVOR_TRY(nesvor_psf_transform_backward_rng(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.dxl, du, d.dpix, B, S, main));

@@ -120,14 +120,16 @@ def _workspace(spec, N, device, sizer=None):
 
 
 def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True, layout=_lib.LAYOUT_ROW_MAJOR,
-                      method="owner", levels=None, grad_u=None, first=True, owner_stream=None):
+                      method="owner", levels=None, grad_u=None, first=True, owner_stream=None, dy_bound=None):
     """Accumulates into grad_table (allocated zero-filled if None); returns (grad_table, grad_u|None).
     method: "owner" (LDS aggregation + per-chunk owners, the MI355X path) or "atomic" (per-corner atomics).
     levels = (begin, end): only these levels ("owner" method) - a data-parallel step splits the backward in two so
     that the all-reduce of the first part overlaps the second; later parts pass the first part's ``grad_u`` and
     ``first=False`` (queue tails are not reset, the input gradient is added).
     owner_stream: launch the owner pass (which only finishes ``grad_table``) on this stream, behind the aggregation pass;
-    ``grad_u`` is complete on the current stream, the caller joins ``owner_stream`` before it reads ``grad_table``."""
+    ``grad_u`` is complete on the current stream, the caller joins ``owner_stream`` before it reads ``grad_table``.
+    dy_bound: 1-element device tensor >= max |dpe| ("owner" method): the aggregation pass then skips its own pass over dpe
+    (the training step gets the bound from the MLP backward that produced dpe, csrc/step.hip)."""
     _lib.require_device(u, table, dpe, dtype=torch.float32, name="hashgrid backward input")
     N = u.shape[0]
     if grad_table is None:
@@ -149,7 +151,8 @@ def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True
                     _lib.ptr(grad_u), N, layout, _lib.ptr(ws))
             l0, l1 = (0, spec.n_levels) if levels is None else levels
             extra = 0 if first else (4 | 8)  # keep the queue tails, add to grad_u
-            call = lambda stage: lib.nesvor_hashgrid_backward_levels(*args, stage | extra, l0, l1, sizer.scale, _lib.stream_ptr())
+            call = lambda stage: lib.nesvor_hashgrid_backward_bounded(*args, stage | extra, l0, l1, sizer.scale, _lib.ptr(dy_bound),
+                                                                      _lib.stream_ptr())
             if _lib.kernel_timer.enabled:  # bracket each of the two launches with its own events
                 with _lib.kernel_timer.span("hashgrid_bwd_aggregate"):
                     err = call(1)
@@ -160,7 +163,8 @@ def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True
                 err = call(1)
                 if err == 0:
                     owner_stream.wait_stream(torch.cuda.current_stream(u.device))
-                    err = lib.nesvor_hashgrid_backward_levels(*args, 2 | extra, l0, l1, sizer.scale, ctypes.c_void_p(owner_stream.cuda_stream))
+                    err = lib.nesvor_hashgrid_backward_bounded(*args, 2 | extra, l0, l1, sizer.scale, _lib.ptr(dy_bound),
+                                                               ctypes.c_void_p(owner_stream.cuda_stream))
             else:
                 err = call(3)
         else:

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "nesvor_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|int64_t)\s+(nesvor_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t|void\s*\*?)\s*(nesvor_\w+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
