@@ -552,11 +552,14 @@ __device__ __forceinline__ uint32_t spread3(uint32_t x) {  // 8 bits -> every th
 //    neighbouring cells / other waves) are summed by the chunk's owner in phase 2.
 // LDS: 2 x 64 counters, so occupancy is set by registers only.
 // float (|x| < 2^62, an integer after scaling by a power of two) <-> two's-complement 64-bit fixed point without the
-// compiler's generic f32<->i64 expansions: hi = floor(x / 2^32), lo = x - hi 2^32 (exact in fp32).
+// compiler's generic f32<->i64 expansions (see to_fixed).
 __device__ __forceinline__ unsigned long long to_fixed(float x) {
-  const float t = floorf(x * 0x1p-32f);
-  const float r = fmaf(-t, 0x1p32f, x);  // in [0, 2^32), exact
-  return ((unsigned long long)(uint32_t)(int32_t)t << 32) | (unsigned long long)(uint32_t)r;
+  // hi = round(x / 2^32), lo = x - hi 2^32 in [-2^31, 2^31]: exact in fp32 for every x (a floor-based split is not: for a
+  // small negative x it forms 2^32 + x, which needs 32 bits - harmless while the scale follows the workgroup's own maximum,
+  // 2^-15 relative once a caller-supplied bound sits 2^30 above a workgroup's gradients)
+  const float t = rintf(x * 0x1p-32f);
+  const int32_t lo = (int32_t)fmaf(-t, 0x1p32f, x);
+  return ((unsigned long long)(uint32_t)((int32_t)t + (lo >> 31)) << 32) | (unsigned long long)(uint32_t)lo;
 }
 __device__ __forceinline__ float from_fixed(unsigned long long q) {
   return fmaf((float)(int32_t)(q >> 32), 0x1p32f, (float)(uint32_t)q);

@@ -348,13 +348,15 @@ class DirectStep:
             else:
                 noise = torch.randn(B, S, 3, dtype=xyz.dtype, device=dev)
         # per-slice small tensors in one launch: c = n softmax(logit_coef), pose matrices, zeroed accumulators
-        small = torch.empty(n * (1 + 12 + 13), dtype=torch.float32, device=dev)
+        small = torch.empty(n * (1 + 12 + 13) + 1, dtype=torch.float32, device=dev)
+        # last element: max |dpe|, raised by the density network's backward for the hash-grid backward (zeroed by the prologue)
+        dpe_bound = None if self.has_b else small[26 * n :]
         c = small[:n] if self.has_c else None
         mat = small[n : 13 * n].view(n, 3, 4)
-        acc = small[13 * n :]  # [dc (n) | dmat (n,12)]
+        acc = small[13 * n : 26 * n]  # [dc (n) | dmat (n,12)]
         with torch.cuda.device(dev):
             err = lib.nesvor_step_prologue(_lib.ptr(m.logit_coef if self.has_c else None), _lib.ptr(c), _lib.ptr(m.axisangle),
-                                           _lib.ptr(mat), _lib.ptr(acc), 13 * n, n, _lib.stream_ptr())
+                                           _lib.ptr(mat), _lib.ptr(acc), 13 * n + 1, n, _lib.stream_ptr())
         _lib.check(err, "step prologue")
         x, u = sampler.forward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb, rng, S)
         pe = hashgrid_forward(enc.spec, u, enc.params, _lib.LAYOUT_FEATURE_MAJOR, clustered=S >= 128)  # (E, N)
@@ -404,7 +406,7 @@ class DirectStep:
                                                   dz[1 : 1 + a.n_features_z], se is not None, self.bf16)
             self.s_net.store_grads(partial_s)
         dpe = torch.empty_like(pe)
-        _, partial_d = mlp_mod.backward_raw(dW, dB, None, pe, dz, saved_d, 0, pe.shape[0], S, dpe, False, self.bf16)
+        _, partial_d = mlp_mod.backward_raw(dW, dB, None, pe, dz, saved_d, 0, pe.shape[0], S, dpe, False, self.bf16, dxb_absmax=dpe_bound)
         self.d_net.store_grads(partial_d)
         dxa_b = None
         if self.has_b:
@@ -421,16 +423,16 @@ class DirectStep:
 
             L = enc.spec.n_levels
             _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR,
-                                      levels=(self.split_level, L))
+                                      levels=(self.split_level, L), dy_bound=dpe_bound)
             lo, hi = self._early_range
             self._early = (ddp.allreduce_flat_(self.flat.grad[lo:hi]), lo, hi)  # async: RCCL's stream, behind the launch above
             _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR,
-                                      levels=(0, self.split_level), grad_u=du, first=False)
+                                      levels=(0, self.split_level), grad_u=du, first=False, dy_bound=dpe_bound)
         else:
             # (per-kernel event timing needs both launches on one stream; NESVOR_OWNER_OVERLAP=0: the same for a kernel trace)
             overlap_owner = not _lib.kernel_timer.enabled and self._overlap_owner
             _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR,
-                                      owner_stream=self.side if overlap_owner else None)
+                                      owner_stream=self.side if overlap_owner else None, dy_bound=dpe_bound)
             self._owner_pending = overlap_owner
         dpix = sampler.backward_raw(mat, slice_idx, xyz, m.psf_sigma, noise, bb, dxl, du, rng, S) if self.opt_T else None
 

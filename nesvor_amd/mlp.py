@@ -222,10 +222,11 @@ def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False)
     return y, saved
 
 
-def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_dxa, bf16=False):
+def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_dxa, bf16=False, dxb_absmax=None):
     """One backward pass, no autograd.  dxb: (k_b, N) contiguous tensor the input gradient is written to (or
     None); -> (dxa (N, k_a) per-sample or (N/16, k_a) per 16-sample group | None - sum it over each pixel's rows -,
-    partial (n_partial, n_params) to be summed over dim 0)."""
+    partial (n_partial, n_params) to be summed over dim 0).  dxb_absmax: zero-filled 1-element tensor raised to max |dxb|
+    (handed to the hash-grid backward as its ``dy_bound``)."""
     n_layers = len(weights)
     N = xb.shape[1]
     k_a = 0 if xa is None else xa.shape[1]
@@ -243,9 +244,9 @@ def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_d
     n_partial = N_PARTIAL_FUSED if fused else N_PARTIAL
     partial = torch.empty((n_partial, total), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), _lib.kernel_timer.span("mlp_bwd"):
-        err = _lib.load().nesvor_mlp_backward(
+        err = _lib.load().nesvor_mlp_backward_bounded(
             ctypes.byref(d), _lib.ptr(xa), _lib.ptr(xb), _lib.ptr(dy), _ptr_array(saved), _ptr_array(dpre),
-            _lib.ptr(dxa), _lib.ptr(dxb), _lib.ptr(partial), n_partial, N, _lib.stream_ptr())
+            _lib.ptr(dxa), _lib.ptr(dxb), _lib.ptr(partial), n_partial, N, _lib.ptr(dxb_absmax), _lib.stream_ptr())
     _lib.check(err, "mlp backward")
     return dxa, partial
 

@@ -551,6 +551,46 @@ def test_hashgrid_full_size_properties(device):
     assert abs(float(lhs - rhs)) < 1e-4 * abs(float(lhs)) + 1e-3
 
 
+@pytest.mark.parametrize("slack", [1.0, 1000.0])
+def test_hashgrid_backward_with_producer_bound(device, slack):
+    """``dy_bound`` (max |dy| handed over by the producer of dy - in the training step the density network's backward,
+    csrc/step.hip) replaces the aggregation pass's own pass over dy; it only sets the scale of the 64-bit fixed-point sums,
+    so the gradients must agree with the self-scaled launch to fp32 accuracy - also for a bound 1000x too large - and
+    per-workgroup gradients far below the global maximum must keep their relative accuracy."""
+    from nesvor_amd.encoding import hashgrid_backward
+    from nesvor_amd.grid import HashGridSpec
+    from nesvor_amd.mlp import backward_raw, forward_raw
+
+    spec = HashGridSpec(16, 2, 19, 9, 1.26)
+    N = 1 << 18
+    u = _psf_cloud(N // 256, 256, 5).to(device)
+    table = torch.randn(spec.n_params, device=device) * 0.1
+    dy = torch.randn(32, N, device=device)
+    dy[:, : N // 2] *= 1e-6  # half of the clouds carry gradients a million (a billion with slack) times below the bound
+    bound = (dy.abs().max() * slack).reshape(1)
+    g0, u0 = hashgrid_backward(spec, u, table, dy, None, True, 1)
+    g1, u1 = hashgrid_backward(spec, u, table, dy, None, True, 1, dy_bound=bound)
+    scale = float(g0.abs().max())
+    assert float((g1 - g0).abs().max()) <= 2e-6 * scale
+    torch.testing.assert_close(u1, u0, rtol=1e-5, atol=1e-6 * float(u0.abs().max()))
+    # the small half alone, against an fp64 scatter of the same weights via the atomic kernel's result
+    gs0, _ = hashgrid_backward(spec, u[: N // 2], table, dy[:, : N // 2].contiguous(), None, False, 1)
+    gs1, _ = hashgrid_backward(spec, u[: N // 2], table, dy[:, : N // 2].contiguous(), None, False, 1, dy_bound=bound)
+    assert float((gs1 - gs0).abs().max()) <= 2e-6 * float(gs0.abs().max())
+    # the producer side: the fused MLP backward raises the scalar to max |dxb| exactly
+    from nesvor_amd.models import build_network
+    from nesvor_amd.mlp import linear_layers
+
+    net = build_network(n_input_dims=32, n_output_dims=16, activation="ReLU", output_activation="None", n_neurons=64,
+                        n_hidden_layers=2, dtype=torch.float32).to(device)
+    W, Bs = [l.weight.detach() for l in linear_layers(net)], [l.bias.detach() for l in linear_layers(net)]
+    xb, dz = torch.randn(32, N, device=device), torch.randn(16, N, device=device)
+    _, saved = forward_raw(W, Bs, None, xb, 0, 32, 256, True)
+    dxb, mx = torch.empty(32, N, device=device), torch.zeros(1, device=device)
+    backward_raw(W, Bs, None, xb, dz, saved, 0, 32, 256, dxb, False, dxb_absmax=mx)
+    assert float(mx) == float(dxb.abs().max())
+
+
 def test_hashgrid_owner_equals_atomic_full_size_uniform(device):
     """Uniform points defeat the per-cloud aggregation and fill the chunk queues to (and past) their
     capacity: the queue-overflow fallback must keep the result exact."""
