@@ -558,7 +558,7 @@ __device__ __forceinline__ unsigned long long to_fixed(float x) {
   // small negative x it forms 2^32 + x, which needs 32 bits - harmless while the scale follows the workgroup's own maximum,
   // 2^-15 relative once a caller-supplied bound sits 2^30 above a workgroup's gradients)
   const float t = rintf(x * 0x1p-32f);
-  const int32_t lo = (int32_t)fmaf(-t, 0x1p32f, x);
+  const int32_t lo = __float2int_rn(fmaf(-t, 0x1p32f, x));  // (to nearest: a truncation bias would add up over the adds of a slot)
   return ((unsigned long long)(uint32_t)((int32_t)t + (lo >> 31)) << 32) | (unsigned long long)(uint32_t)lo;
 }
 __device__ __forceinline__ float from_fixed(unsigned long long q) {

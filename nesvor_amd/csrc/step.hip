@@ -208,8 +208,18 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
     return nesvor_hashgrid_backward_bounded(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 3, split_level, L,
                                             d.queue_scale, dpe_bound, main);
   } else {
-    NESVOR_TRY(nesvor_hashgrid_backward_bounded(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 3 | 4 | 8, 0,
+    // the coarse levels: aggregation on the main stream, their owner pass again under the rest of the step (the caller joins
+    // the side stream before it reduces / applies the rest of the gradient)
+    NESVOR_TRY(nesvor_hashgrid_backward_bounded(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 1 | 4 | 8, 0,
                                                 split_level, d.queue_scale, dpe_bound, main));
+    hipStream_t owner_stream = main;
+    if (d.overlap_owner) {
+      if (hipEventRecord(ctx->ev_agg, main) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_agg, 0) != hipSuccess) return (int)hipGetLastError();
+      owner_stream = side;
+    }
+    NESVOR_TRY(nesvor_hashgrid_backward_bounded(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 2 | 4 | 8, 0,
+                                                split_level, d.queue_scale, dpe_bound, owner_stream));
+    if (d.overlap_owner && hipEventRecord(ctx->ev_owner, side) != hipSuccess) return (int)hipGetLastError();
   }
   if (d.opt_T)
     NESVOR_TRY(nesvor_psf_transform_backward_rng(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.dxl, du, d.dpix, B, S, main));
@@ -229,7 +239,7 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
                                   d.opt_T ? d.trans_terms : nullptr, losses, n, B, img_scale, img_off, main));
   if (d.has_b) hipLaunchKernelGGL(square_kernel, dim3(1), dim3(1), 0, main, d.lb_mean, losses + 5);
   if (adam != nullptr) {
-    if (phase == 0 && d.overlap_owner && hipStreamWaitEvent(main, ctx->ev_owner, 0) != hipSuccess) return (int)hipGetLastError();
+    if (phase != 1 && d.overlap_owner && hipStreamWaitEvent(main, ctx->ev_owner, 0) != hipSuccess) return (int)hipGetLastError();
     NESVOR_TRY(nesvor_adamw_step(d.flat_param, d.flat_grad, d.flat_exp_avg, d.flat_exp_avg_sq, d.flat_numel, adam->lr, adam->beta1, adam->beta2,
                                  adam->eps, adam->weight_decay, adam->bias_correction1, adam->bias_correction2, adam->grad_scale, 1, main));
   }

@@ -272,7 +272,7 @@ class DirectStep:
                 lo, hi = self._early_range
                 self._early = (ddp.allreduce_flat_(self.flat.grad[lo:hi]), lo, hi)  # async: RCCL's stream, behind the launches above
                 _lib.check(lib.nesvor_step_run(*args, 2, self.split_level, None, stream), "training step (coarse levels)")
-                self._owner_pending = False
+                self._owner_pending = bool(d.overlap_owner)  # the coarse levels' owner pass runs on the side stream
             else:
                 _lib.check(lib.nesvor_step_run(*args, 0, 0, a_ptr, stream), "training step")
                 self._owner_pending = bool(d.overlap_owner) and adam is None  # with its own AdamW the step has joined the owner pass
