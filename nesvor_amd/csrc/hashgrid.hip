@@ -562,7 +562,10 @@ __device__ __forceinline__ unsigned long long to_fixed(float x) {
   return ((unsigned long long)(uint32_t)((int32_t)t + (lo >> 31)) << 32) | (unsigned long long)(uint32_t)lo;
 }
 __device__ __forceinline__ float from_fixed(unsigned long long q) {
-  return fmaf((float)(int32_t)(q >> 32), 0x1p32f, (float)(uint32_t)q);
+  // q = hi 2^32 + lo with lo taken as SIGNED (hi absorbs its sign bit): a small negative sum is then read as 0 2^32 - |q|,
+  // not as -1 2^32 + (2^32 - |q|), whose low word needs 32 bits
+  const uint32_t lo = (uint32_t)q;
+  return fmaf((float)((int32_t)(q >> 32) + (int32_t)(lo >> 31)), 0x1p32f, (float)(int32_t)lo);
 }
 
 // NESVOR_FIXED32 (build macro, F == 2 only): a merge-table slot holds both features as two 32-bit fixed-point fields of one

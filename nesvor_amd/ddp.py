@@ -123,35 +123,74 @@ class ShardedExchange:
     The two collectives are the two halves of a ring all-reduce (same bytes on the wire), but over the xGMI mesh every
     rank exchanges its 1/W slices with all W-1 peers concurrently, and the dense optimizer sweep - the per-iteration cost
     that does not shrink with W - drops to 1/W of the table per rank.  The flat buffers are padded to a multiple of 4 W
-    elements by the trainer.  On a backend without reduce-scatter (gloo, CPU tests) the gradient is all-reduced and the
-    slice taken from it - same result."""
+    elements by the trainer.
 
-    def __init__(self, numel: int, group=None) -> None:
+    ``split`` (a multiple of 4 W, or None) cuts the buffer into two independently sharded PARTS, [0, split) and
+    [split, numel): part 1 - the fine hash-grid levels, the end of the buffer, whose gradient an iteration finishes first -
+    is reduce-scattered EARLY (asynchronously, under the rest of the backward, ``reduce_scatter(.., part=1,
+    async_op=True)``), part 0 when the step's gradients are complete; every rank then owns one slice of each part.  This is
+    the sharded counterpart of the early all-reduce of ``nesvor_amd.direct``.
+
+    On a backend without reduce-scatter (gloo, CPU tests) the gradient is all-reduced and the slice taken from it - same
+    result."""
+
+    def __init__(self, numel: int, group=None, split: Optional[int] = None) -> None:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         if numel % (4 * self.world):
             raise ValueError("flat buffers must be padded to a multiple of 4 x world size")
-        self.shard = numel // self.world
-        self.lo, self.hi = self.rank * self.shard, (self.rank + 1) * self.shard
+        if split is not None and (split % (4 * self.world) or not 0 < split < numel):
+            raise ValueError("split must be a multiple of 4 x world size inside the buffer")
+        self.parts = [(0, numel)] if split is None else [(0, split), (split, numel)]
         self.native = _backend_has_reduce_scatter(group)
+        self._mine = [None] * len(self.parts)
+        # single-part compatibility attributes
+        self.shard = numel // self.world
+        self.lo, self.hi = self.owned(0) if split is None else (None, None)
 
-    def reduce_scatter(self, flat_grad: torch.Tensor) -> torch.Tensor:
-        """-> this rank's slice of the summed gradient (a buffer owned by the exchange)."""
-        if getattr(self, "_mine", None) is None or self._mine.device != flat_grad.device:
-            self._mine = torch.empty(self.shard, dtype=flat_grad.dtype, device=flat_grad.device)
+    def owned(self, part: int = 0):
+        """[lo, hi) of the flat buffers this rank owns inside ``part``."""
+        a, b = self.parts[part]
+        n = (b - a) // self.world
+        return a + self.rank * n, a + (self.rank + 1) * n
+
+    def reduce_scatter(self, flat_grad: torch.Tensor, part: int = 0, async_op: bool = False):
+        """-> this rank's slice of the summed gradient of ``part`` (a buffer owned by the exchange); with ``async_op``
+        -> (slice, work handle): the slice is valid after ``work.wait()``."""
+        a, b = self.parts[part]
+        lo, hi = self.owned(part)
+        mine = self._mine[part]
+        if mine is None or mine.device != flat_grad.device:
+            mine = self._mine[part] = torch.empty(hi - lo, dtype=flat_grad.dtype, device=flat_grad.device)
         if self.native:
-            dist.reduce_scatter_tensor(self._mine, flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            work = dist.reduce_scatter_tensor(mine, flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         else:
-            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-            self._mine.copy_(flat_grad[self.lo : self.hi])
-        return self._mine
+            work = dist.all_reduce(flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if async_op:
+                work = _ThenCopy(work, mine, flat_grad[lo:hi])
+            else:
+                mine.copy_(flat_grad[lo:hi])
+        return (mine, work) if async_op else mine
 
     def all_gather_(self, flat_param: torch.Tensor) -> None:
-        """Every rank's updated slice -> the full parameter buffer on every rank (in place)."""
-        if self.native:
-            dist.all_gather_into_tensor(flat_param, flat_param[self.lo : self.hi].clone(), group=self.group)
-        else:
-            parts = [torch.empty(self.shard, dtype=flat_param.dtype, device=flat_param.device) for _ in range(self.world)]
-            dist.all_gather(parts, flat_param[self.lo : self.hi].clone(), group=self.group)
-            flat_param.copy_(torch.cat(parts))
+        """Every rank's updated slices -> the full parameter buffer on every rank (in place)."""
+        for part, (a, b) in enumerate(self.parts):
+            lo, hi = self.owned(part)
+            if self.native:
+                dist.all_gather_into_tensor(flat_param[a:b], flat_param[lo:hi].clone(), group=self.group)
+            else:
+                pieces = [torch.empty(hi - lo, dtype=flat_param.dtype, device=flat_param.device) for _ in range(self.world)]
+                dist.all_gather(pieces, flat_param[lo:hi].clone(), group=self.group)
+                flat_param[a:b].copy_(torch.cat(pieces))
+
+
+class _ThenCopy:
+    """Work handle of the all-reduce-based fallback: wait, then take this rank's slice."""
+
+    def __init__(self, work, dst, src):
+        self.work, self.dst, self.src = work, dst, src
+
+    def wait(self):
+        self.work.wait()
+        self.dst.copy_(self.src)

@@ -124,11 +124,30 @@ class DirectStep:
                 self._split_candidate = min(range(1, spec.n_levels), key=lambda l: abs(spec.levels[l].offset - total / 2))
                 off, cnt = flat.offsets["inr.encoding.params"]
                 self._early_range = (off + spec.levels[self._split_candidate].offset * F, off + cnt)
+        self.early_exchange = None  # callable(lo, hi) -> handle for take_early_reduce(); default: all-reduce of flat.grad[lo:hi]
 
     def set_overlap(self, on: bool) -> None:
         """Split the hash-grid backward and start the fine levels' all-reduce early (FusedTrainer turns this on when a
         reduce hook is installed: the hook's owner then finishes the reduction in optimizer_step)."""
         self.split_level = self._split_candidate if on else 0
+
+    def early_range(self):
+        """[lo, hi) of the flat gradient that is complete after the fine levels' backward.  For the sharded exchange the range
+        must be cut into W equal, 16-byte aligned slices: lo is rounded UP to a multiple of 4 W (the few fine-level entries
+        below it travel with the late part) and hi is the padded end of the buffer."""
+        lo, hi = self._early_range
+        if self.early_exchange is not None:
+            q = 4 * self.world
+            lo, hi = -(-lo // q) * q, self.flat.numel
+        return lo, hi
+
+    def _start_early(self):
+        from . import ddp
+
+        lo, hi = self.early_range()
+        if self.early_exchange is not None:
+            return self.early_exchange(lo, hi)
+        return ddp.allreduce_flat_(self.flat.grad[lo:hi]), lo, hi
 
     def take_early_reduce(self):
         """(work handles, start, end) of the flat-gradient range whose all-reduce this step has already started, or None."""
@@ -269,8 +288,7 @@ class DirectStep:
                 from . import ddp
 
                 _lib.check(lib.nesvor_step_run(*args, 1, self.split_level, None, stream), "training step (fine levels)")
-                lo, hi = self._early_range
-                self._early = (ddp.allreduce_flat_(self.flat.grad[lo:hi]), lo, hi)  # async: RCCL's stream, behind the launches above
+                self._early = self._start_early()  # async: RCCL's stream, behind the launches above
                 _lib.check(lib.nesvor_step_run(*args, 2, self.split_level, None, stream), "training step (coarse levels)")
                 self._owner_pending = bool(d.overlap_owner)  # the coarse levels' owner pass runs on the side stream
             else:
@@ -424,8 +442,7 @@ class DirectStep:
             L = enc.spec.n_levels
             _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR,
                                       levels=(self.split_level, L), dy_bound=dpe_bound)
-            lo, hi = self._early_range
-            self._early = (ddp.allreduce_flat_(self.flat.grad[lo:hi]), lo, hi)  # async: RCCL's stream, behind the launch above
+            self._early = self._start_early()  # async: RCCL's stream, behind the launch above
             _, du = hashgrid_backward(enc.spec, u, enc.params, dpe, gt, self.opt_T, _lib.LAYOUT_FEATURE_MAJOR,
                                       levels=(0, self.split_level), grad_u=du, first=False, dy_bound=dpe_bound)
         else:

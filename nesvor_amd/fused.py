@@ -87,8 +87,29 @@ class FusedTrainer:
     @reduce_hook.setter
     def reduce_hook(self, hook) -> None:
         self._reduce_hook = hook
-        if self.direct is not None:  # the sharded exchange is one reduce-scatter after the step: no early all-reduce
-            self.direct.set_overlap(hook is not None and not self.sharded)
+        if self.direct is not None:
+            # the fine hash-grid levels' gradient is exchanged early, under the rest of the backward: an all-reduce of that
+            # range, or - with optimizer sharding - its reduce-scatter (ddp.ShardedExchange part 1)
+            self.direct.set_overlap(hook is not None)
+            if self.sharded and self.direct.split_level:
+                self.direct.early_exchange = self._early_reduce_scatter
+
+    def _sharded_exchange(self):
+        from . import ddp
+
+        if self._exchange is None:
+            split = None
+            if self.direct is not None and self.direct.split_level:
+                split = self.direct.early_range()[0]
+            self._exchange = ddp.ShardedExchange(self.flat.numel, split=split)
+        return self._exchange
+
+    def _early_reduce_scatter(self, lo: int, hi: int):
+        """Called by the step once the fine levels' gradient is complete: start part 1's reduce-scatter (asynchronous, on the
+        collective's stream) -> ((slice, work), lo, hi) for ``optimizer_step``."""
+        ex = self._sharded_exchange()
+        assert (lo, hi) == ex.parts[1]
+        return ex.reduce_scatter(self.flat.grad, 1, async_op=True), lo, hi
 
     def decay_lr(self, gamma: float) -> None:
         self.lr *= gamma
@@ -132,14 +153,20 @@ class FusedTrainer:
         if self.direct is not None:
             self.direct.join_owner()  # the table gradient is complete behind the owner pass on the side stream
         if self.sharded:
-            from . import ddp
-
-            if self._exchange is None:
-                self._exchange = ddp.ShardedExchange(self.flat.numel)
-            ex = self._exchange
-            mine = ex.reduce_scatter(self.flat.grad)
+            ex = self._sharded_exchange()
+            early = self.direct.take_early_reduce() if self.direct is not None else None
+            slices = {}
+            if early is not None:  # part 1 (the fine levels) is already being reduce-scattered (nesvor_amd.direct)
+                slices[1] = early[0][0]
+            for part in range(len(ex.parts)):
+                if part not in slices:
+                    slices[part] = ex.reduce_scatter(self.flat.grad, part)
+            if early is not None:
+                early[0][1].wait()
             self.t += 1
-            self._adamw(ex.lo, ex.hi, mine)
+            for part, mine in slices.items():
+                lo, hi = ex.owned(part)
+                self._adamw(lo, hi, mine)
             self.flat.grad.zero_()  # this rank's partial sums: the next step accumulates from zero
             ex.all_gather_(self.flat.param)
             return

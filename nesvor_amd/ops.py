@@ -449,6 +449,13 @@ def _loss_forward(z0, log_var, log_bias, x, v, slice_idx, c, log_var_slice, reg_
     _lib.require_device(slice_idx, dtype=torch.int64, name="slice_idx")
     B, S = x.shape[0], x.shape[1]
     lb_mean = log_bias.mean().reshape(1) if log_bias is not None else torch.zeros(1, dtype=torch.float32, device=x.device)
+    if log_bias is not None:
+        from . import ddp
+
+        if ddp.active():  # biasReg = (mean log_bias)^2 is not a mean of per-sample terms (models.py:322-323): take the GLOBAL
+            # mean, so that value and averaged gradients are those of the undivided batch (as nesvor_amd.direct does)
+            torch.distributed.all_reduce(lb_mean)
+            lb_mean /= torch.distributed.get_world_size()
     loss_pix = torch.empty((B, 3), dtype=torch.float32, device=x.device)
     a = _loss._fill(z0, log_var, log_bias, x, v, slice_idx, c, log_var_slice, lb_mean if log_bias is not None else None, reg_type, delta)
     a.loss_pix = loss_pix.data_ptr()

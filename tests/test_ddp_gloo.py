@@ -110,6 +110,29 @@ def _sharded_worker(rank, world, port, out):
         torch.save(param, out)
     with pytest.raises(ValueError):
         ddp.ShardedExchange(n + 1)
+    # two independently sharded parts, the second one exchanged early and asynchronously (the fine hash-grid levels)
+    split = 8 * world * 3
+    ex2 = ddp.ShardedExchange(n, split=split)
+    assert ex2.parts == [(0, split), (split, n)]
+    with pytest.raises(ValueError):
+        ddp.ShardedExchange(n, split=split + 4)
+    g2 = grads[rank].clone()
+    late_garbage = g2[:split].clone()
+    g2[:split] = float("nan")  # the late part is not complete yet when the early exchange starts: it must not be touched
+    mine1, work = ex2.reduce_scatter(g2, 1, async_op=True)
+    g2[:split] = late_garbage
+    mine0 = ex2.reduce_scatter(g2, 0)
+    work.wait()
+    total = sum(grads)
+    lo0, hi0 = ex2.owned(0)
+    lo1, hi1 = ex2.owned(1)
+    assert (hi0 - lo0, hi1 - lo1) == (split // world, (n - split) // world)
+    torch.testing.assert_close(mine0, total[lo0:hi0])
+    torch.testing.assert_close(mine1, total[lo1:hi1])
+    param2 = torch.zeros(n)
+    param2[lo0:hi0], param2[lo1:hi1] = -0.1 * mine0, -0.1 * mine1
+    ex2.all_gather_(param2)
+    torch.testing.assert_close(param2, -0.1 * total)
     dist.barrier()
     dist.destroy_process_group()
 

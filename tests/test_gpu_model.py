@@ -391,6 +391,13 @@ def test_train_data_parallel_sharded_optimizer_matches_allreduce(device, tmp_pat
     for k in ref:
         assert torch.equal(a[k], b[k]), k
         torch.testing.assert_close(a[k], ref[k], rtol=2e-3, atol=2e-5, msg=k)
+    # sharding composed with the early exchange: the fine levels' part is reduce-scattered under the coarse levels' backward
+    mp.spawn(_ddp_train_worker, args=(2, _free_port(), str(tmp_path), "1", "gloo", "1"), nprocs=2, join=True)
+    c = torch.load(tmp_path / "rank0_overlap1_sharded.pt")
+    d = torch.load(tmp_path / "rank1_overlap1_sharded.pt")
+    for k in ref:
+        assert torch.equal(c[k], d[k]), k
+        torch.testing.assert_close(c[k], ref[k], rtol=2e-3, atol=2e-5, msg=k)
 
 
 def test_train_data_parallel_rccl_single_rank(device, tmp_path):
