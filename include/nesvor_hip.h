@@ -205,8 +205,9 @@ int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* u, const fl
 
 /* The same backward restricted to levels [level_begin, level_end): a data-parallel step runs the fine levels first,
  * starts their all-reduce and overlaps it with the remaining levels.  Extra `stages` bits: 4 = do not reset the
- * queue tails (every launch of one backward after the first), 8 = add the input gradient of these levels to grad_u
- * instead of overwriting it.  The launches of one backward share `workspace`. */
+ * queue tails and re-use the sample order the first launch sorted (every launch of one backward after the first: same
+ * u, same N), 8 = add the input gradient of these levels to grad_u instead of overwriting it.  The launches of one
+ * backward share `workspace`. */
 int nesvor_hashgrid_backward_levels(const nesvor_grid_t* grid, const float* u, const float* table, const float* dpe,
                                     float* grad_table, float* grad_u, int64_t N, int layout, void* workspace, int stages,
                                     int level_begin, int level_end, const float* queue_scale, void* stream);

@@ -528,6 +528,8 @@ struct BwdPlan {
   int32_t level_begin, level_end;              // this launch handles levels [level_begin, level_end) (all by default)
   int32_t accumulate_u;                        // input gradient: add to grad_u instead of overwriting (later launches of a split backward)
   const float* dy_bound;                       // device scalar >= max |dy| over the whole batch, or null: the kernel reads all dy itself first
+  uint8_t* order;                              // one byte per sample: the Morton-sorted order of every workgroup's samples (end of the workspace)
+  int32_t order_mode;                          // 1: sort and write `order` (first launch of a backward), 2: read it (later launches of a split backward)
 };
 
 __device__ __forceinline__ uint32_t spread3(uint32_t x) {  // 8 bits -> every third bit
@@ -653,6 +655,10 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       code = spread3(c.gx) | (spread3(c.gy) << 1) | (spread3(c.gz) << 2);
     }
     sv = (code << 8) | (uint32_t)tid;
+    // a later launch of a split backward (data parallel: coarse levels after the fine ones) re-uses the order the first
+    // launch found - same samples, same key
+    if (plan.order_mode == 2) sv = (uint32_t)plan.order[base + tid];
+    else
 #pragma unroll 1
     for (int rep = 0; rep < (NESVOR_ABL(1) ? 2 : 1); ++rep)
 #pragma unroll 1
@@ -674,6 +680,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
       }
     }
   }
+  if (plan.order_mode == 1) plan.order[base + tid] = (uint8_t)(sv & 255u);
   const int64_t i = base + (sv & 255u);  // the sample this lane owns from now on
   const bool valid = i < N;
   const int64_t ii = valid ? i : N - 1;
@@ -1579,6 +1586,8 @@ int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table,
   uint32_t* tails = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + (par ? kTailBytes : 0));
   uint32_t* tails_next = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + (par ? 0 : kTailBytes));
   uint32_t* records = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + 2 * kTailBytes);
+  plan.order = reinterpret_cast<uint8_t*>(records) + n_rec * (1 + F) * sizeof(uint32_t);  // ceil(N / 256) * 256 bytes
+  plan.order_mode = (stages & 4) ? 2 : 1;
   dim3 grid((unsigned)((N + 255) / 256)), block(256);
   hipError_t e;
   if (!(stages & 1)) goto owner_stage;
@@ -1682,7 +1691,7 @@ extern "C" int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t*
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return -1;
   if (!make_plan(grid, N, &plan, &n_rec, queue_scale)) return -1;
   if (plan.n_buckets > kOverflowBase) return -1;
-  return (int64_t)(2 * kTailBytes + n_rec * (1 + grid->n_features) * sizeof(uint32_t));
+  return (int64_t)(2 * kTailBytes + n_rec * (1 + grid->n_features) * sizeof(uint32_t) + (uint64_t)((N + 255) / 256) * 256);
 }
 
 extern "C" int64_t nesvor_hashgrid_backward_workspace_zero_bytes(void) { return (int64_t)(2 * kTailBytes); }
