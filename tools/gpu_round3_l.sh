@@ -10,5 +10,5 @@ for f in ("gpurun_out/r03_bench_l_ddp.json",):
     d = json.loads([l for l in open(f).read().splitlines() if l.startswith('{"metric"')][-1])
     print(f, d["value"], d["ms_per_step"], d["roofline"]["kernels_ms_per_step"] if d.get("roofline") else None)
 PY
-bash tools/collect_profiles_r03.sh 07d2967+wip > gpurun_out/r03_collect.log 2>&1; echo "collect rc=$?"
+bash tools/collect_profiles_r03.sh c764866 > gpurun_out/r03_collect.log 2>&1; echo "collect rc=$?"
 tail -30 gpurun_out/r03_collect.log

@@ -94,5 +94,9 @@ else:
     # small gradients next to large ones: relative error of the entries below 1e-4 of the maximum
     small = (g2.abs() < 1e-4 * g2.abs().max()) & (g2 != 0)
     rel_small = float(((g1 - g2).abs()[small] / g2.abs()[small]).median()) if bool(small.any()) else 0.0
+    # uniform points (nothing merges: the record stream and the owner pass carry everything)
+    uu = torch.rand(N, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    t_uni = timeit(lambda: hashgrid_backward(spec, uu, table, dy, gt, True, 1, "owner"), 5)
+    print(f"uniform points: backward {t_uni:.3f} ms", end="  ")
     print(f"error against fp64: owner [{acc(g1)}]  atomic fp32 [{acc(g2)}]")
     print(f"aggregate {t_agg:.3f} ms (no input grad {t_agg_noin:.3f})  owner {t_own:.3f}  fwd {t_fwd:.3f}  | owner vs atomic: table {err:.1e} (median rel of small entries {rel_small:.1e}), grad_u {erru:.1e}")
