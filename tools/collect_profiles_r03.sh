@@ -46,6 +46,7 @@ python $ROOT/tools/step_traffic.py $OUT/step_FETCH_SIZE $OUT/step_WRITE_SIZE 20 
 # 6. micro-benchmarks
 python $ROOT/tools/bench_hashgrid.py > $OUT/hashgrid_microbench.log 2>&1
 python $ROOT/tools/bench_hg_levels.py > $OUT/hashgrid_per_level.log 2>&1
-python $ROOT/tools/mlp_variants.py r02:src=tools/scratch/mlp_r02.hip.txt r03: split0:-DNESVOR_SPLIT=0 split1:-DNESVOR_SPLIT=1 > $OUT/mlp_variants.log 2>&1
+python $ROOT/tools/mlp_variants.py r03: split0:-DNESVOR_SPLIT=0 split1:-DNESVOR_SPLIT=1 > $OUT/mlp_variants.log 2>&1
+python $ROOT/tools/hg_variants.py r03: fixed32:-DNESVOR_FIXED32=1 noinsert:-DNESVOR_ABLATE=4 nowrite:-DNESVOR_ABLATE=8 noscan:-DNESVOR_ABLATE=2 oldfixed:-DNESVOR_HG_OLDFIXED=1 > $OUT/hashgrid_ab.log 2>&1
 rm -rf $OUT/kstats $OUT/tl $OUT/tl512 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/mlp_sq1 $OUT/mlp_sq2 $OUT/mlp_sq3 $OUT/mlp_FETCH_SIZE $OUT/mlp_WRITE_SIZE $OUT/step_FETCH_SIZE $OUT/step_WRITE_SIZE
 ls -la $OUT
