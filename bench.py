@@ -397,7 +397,7 @@ def main():
             # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE per the microarch
             # guide); they cannot be collected inside this process, so the number carries the file and commit it was
             # measured at and is dropped when this run's launch shape differs
-            for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+            for fn in ("r03_pmc_traffic.json",):
                 try:
                     with open(os.path.join(ROOT, "profiles", fn)) as fh:
                         tj = json.load(fh)
@@ -455,16 +455,35 @@ def main():
                 fp32_mfma, bf16_mfma = 0, 6 * bp + 2 * 3 * (W // 16)
             busy = lambda n, cyc: n * cyc * groups / n_simd / (ms2 * 1e-3 * clock_hz)
             fl = 2 * n_points * sum(i * o for d in (dens, sig) for i, o in zip(d[:-1], d[1:]))  # one forward of both nets
-            roof_mlp = {"bound": "mfma", "kernel": "mlp_bwd_ws (density_net + sigma_net launches)", "launch_ms": ms2,
+            # Round 3 (DESIGN.md "What round 3 measured about the MLP kernels"): after the instruction-count work the four MLP
+            # launches of a step run at the rate the device streams their bytes - the saved hidden activations (2 x 256 B per
+            # point and network, written by the forward, read by the backward) are 74 % of them.  Algorithmic bytes per point:
+            #   forward  = input rows + 2 saved layers (512 B) + output rows;  backward = 2 saved layers + input rows + dY + dX
+            in_d, in_s = 4 * L * F, 4 * nz          # bytes of a point's network input that streams from HBM (the slice embedding is per pixel)
+            mlp_bytes_pt = (in_d + 512 + 4 * (1 + nz)) + (in_s + 512 + 4) + (512 + in_d + 4 * (1 + nz) + in_d) + (512 + in_s + 4 + in_s)
+            ms_all = ms2 + (ktimes["mlp_fwd"][0] * ktimes["mlp_fwd"][1] / k_steps if "mlp_fwd" in ktimes else 0.0)
+            mlp_gbps = mlp_bytes_pt * n_points / (ms_all * 1e-3) / 1e9
+            traffic_mlp = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_mlp.json")) as fh:
+                    traffic_mlp = json.load(fh)
+            except OSError:
+                pass
+            roof_mlp = {"bound": "hbm", "kernel": "mlp_fwd_pf x 2 + mlp_bwd_ws x 2 (density_net, sigma_net): the four MLP launches of a step",
+                        "achieved": mlp_gbps, "peak": 8000.0, "unit": "GB/s", "frac": mlp_gbps / 8000.0,
+                        "frac_of_copy_peak": None if not extras["copy_peak_GBps"] else mlp_gbps / extras["copy_peak_GBps"],
+                        "launch_ms": ms_all, "backward_ms": ms2, "algorithmic_bytes_per_point": mlp_bytes_pt,
+                        "algorithmic_bytes_per_step": mlp_bytes_pt * n_points,
+                        "traffic": traffic_mlp,
                         "fp32_pipe_busy_frac": busy(fp32_mfma, 32), "bf16_pipe_busy_frac": busy(bf16_mfma, 16),
-                        "matrix_pipe_busy_frac": busy(fp32_mfma, 32) + busy(bf16_mfma, 16),
-                        "mfma_per_16_sample_group": {"fp32_16x16x4": fp32_mfma, "bf16": bf16_mfma},
-                        "engine_clock_MHz": clock_hz / 1e6, "fp32_equivalent_TFLOPs": 2 * fl / (ms2 * 1e-3) / 1e12,
-                        "note": "busy fractions = MFMA issue cycles per SIMD / (launch time x engine clock): an upper-clock estimate "
-                                "(profiles/r02_pmc_sq_mlp_summary.txt: SQ_VALU_MFMA_BUSY_CYCLES = 33 % and VALU issue = 53 % of the "
-                                "kernel's SIMD time, 23 % of the MFMA time overlapped with VALU work); the kernel runs two waves per "
-                                "SIMD and is issue-bound on operand splitting (VALU) plus MFMAs, not on the activation streams "
-                                "(profiles/r02_mlp_ablation.log), see DESIGN.md"}
+                        "matrix_pipe_busy_frac_backward": busy(fp32_mfma, 32) + busy(bf16_mfma, 16),
+                        "mfma_per_16_sample_group_backward": {"fp32_16x16x4": fp32_mfma, "bf16": bf16_mfma},
+                        "engine_clock_MHz": clock_hz / 1e6, "fp32_equivalent_TFLOPs_backward": 2 * fl / (ms2 * 1e-3) / 1e12,
+                        "note": "bound = HBM: the kernels stream the saved activations at the device's copy rate (copy_peak_GBps in "
+                                "`roofline`); bf16 MFMAs and VALU instructions do not overlap on gfx950 (tools/mfma_bf16_overlap.hip), so "
+                                "the matrix pipe's busy fraction (MFMA issue cycles per SIMD / launch time at the maximum engine clock) "
+                                "stays near a third by construction of the 3-way operand split; SQ counters in "
+                                "profiles/r03_pmc_sq_mlp_summary.txt"}
         out = {
             "metric": "INR train iters/sec (2^20 samples, L=16 hash, 64-wide MLP)",
             "value": iters_per_s,

@@ -51,6 +51,11 @@ def run_smoke(device):
     scale = float(trainer.flat.grad.abs().max())
     assert float((trainer.flat.grad - g_direct).abs().max()) <= 1e-4 * scale
     trainer.optimizer_step()
+    # and the product's default issue path: the whole iteration + AdamW behind one C call (csrc/step.hip), PSF noise drawn in
+    # the kernels - same data one AdamW step later and another noise stream: the data term must stay within a factor of two
+    assert trainer.direct.native_ready()
+    l3 = trainer.step(d("xyz"), d("v"), d("idx"))
     torch.cuda.synchronize()
+    assert 0.5 * float(ref["MSE"]) <= float(l3["MSE"]) <= 2.0 * float(ref["MSE"]), (float(l3["MSE"]), float(ref["MSE"]))
     assert all(torch.isfinite(p).all() for p in model.parameters())
     print("smoke ok:", {k: float(v.detach()) for k, v in losses.items()})
