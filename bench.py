@@ -246,6 +246,9 @@ def main():
     if parallel:
         ddp.broadcast_params_(trainer.flat.param)
         trainer.reduce_hook = ddp.make_reduce_hook()
+    # as nesvor_amd.train.train: between iterations only the losses are read (every timed region ends with a device-wide
+    # synchronize, so the table update the last step left on its side stream is inside the region)
+    trainer.defer_table_join = os.environ.get("NESVOR_DEFER_TABLE_JOIN", "1") != "0"
     torch.manual_seed(1234 + rank)  # per-rank PSF noise stream; the permutation below is rank-independent
     perm_gen = torch.Generator(device=device).manual_seed(0)
 

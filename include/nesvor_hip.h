@@ -363,6 +363,23 @@ int nesvor_adamw_step(float* param, float* grad, float* exp_avg, float* exp_avg_
                       float bias_correction1, float bias_correction2, float grad_scale, int zero_grad,
                       void* stream);
 
+/* The same numbers as one struct (bias_correction{1,2} = 1 - beta{1,2}^t of the step being taken). */
+typedef struct {
+  float lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2, grad_scale;
+} nesvor_adamw_t;
+
+/* Hash-grid backward whose owner pass also takes the AdamW step on the table: the workgroup that completes a chunk's
+ * gradient updates table / exp_avg / exp_avg_sq of that chunk while the gradient is still in LDS, so the table gradient
+ * never travels through HBM.  Equals nesvor_hashgrid_backward_bounded(stages) over all levels followed by
+ * nesvor_adamw_step(table, grad_table, exp_avg, exp_avg_sq, <table numel>, ..., zero_grad = 1): grad_table is read (it may
+ * hold an earlier backward's gradient) and is all zero afterwards, but the gradient of THIS backward is never stored in it.
+ * stages: 1 = aggregation pass, 2 = owner pass + AdamW, 3 = both (as nesvor_hashgrid_backward; no level ranges).
+ * table, exp_avg, exp_avg_sq, grad_table: (sum of level sizes, F), the layout nesvor_hashgrid_forward reads. */
+int nesvor_hashgrid_backward_adamw(const nesvor_grid_t* grid, const float* u, float* table, const float* dpe,
+                                   float* grad_table, float* grad_u, int64_t N, int layout, void* workspace, int stages,
+                                   const float* queue_scale, const float* dy_bound, float* exp_avg, float* exp_avg_sq,
+                                   const nesvor_adamw_t* adam, void* stream);
+
 /* out[c] = sum_r in[r * ld + c], c < cols, for a row-major matrix of row pitch ld >= cols floats: reduces the
  * dw_partial of nesvor_mlp_backward (the `partial.sum(0)` of the host side) straight into a gradient segment; with
  * ld > cols, a column range of it (one layer's weights when the model keeps no biases, tinycudann.Network). */
@@ -397,7 +414,9 @@ typedef struct {
   int32_t opt_T, has_lv, has_c, has_lvs, has_b;
   int32_t n_features_z, ks, kb_bias;       /* ks: slice-embedding width fed to sigma_net / b_net (0: none); kb_bias: rows of pe b_net sees */
   int32_t reg_type;                        /* 0 edge, 1 TV, 2 L2 */
-  int32_t overlap_owner;                   /* owner pass of the hash-grid backward on side_stream */
+  int32_t overlap_owner;                   /* bit 0: owner pass of the hash-grid backward on side_stream; bit 1: a phase-0 run with
+                                              `adam` takes the table's AdamW step inside the owner pass (nesvor_hashgrid_backward_adamw;
+                                              the table must be the last segment of the flat buffers) */
   float delta, w_T;
   const float *axisangle, *axisangle_init, *psf_sigma, *bounding_box, *logit_coef, *log_var_slice, *slice_embedding, *table;
   float *g_axisangle, *g_logit_coef, *g_log_var_slice, *g_slice_embedding, *g_table, *g_density, *g_sigma, *g_bias_net;
@@ -415,15 +434,17 @@ typedef struct {
   void* side_stream;
 } nesvor_step_t;
 
-typedef struct {
-  float lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2, grad_scale;
-} nesvor_adamw_t;
-
 void* nesvor_step_create(const nesvor_step_t* desc);                 /* NULL on failure */
 int nesvor_step_update(void* step, const nesvor_step_t* desc);       /* pointers / sizes changed (e.g. a re-made workspace) */
 void nesvor_step_destroy(void* step);
 int nesvor_step_run(void* step, const float* xyz, const float* v, const int64_t* slice_idx, uint64_t seed, uint64_t offset,
                     float* losses, int phase, int split_level, const nesvor_adamw_t* adam, void* stream);
+/* OR-ed into `phase` (phase 0 with `adam` and overlap_owner bits 0 and 1): return without making `stream` wait for the table's
+ * update on side_stream.  The next nesvor_step_run joins it right before its hash-grid forward (its prologue and sampler
+ * then overlap the end of this update); anything else that touches the table, its moments or its gradient first calls
+ * nesvor_step_join.  Everything but the table (losses, the other parameters) is complete on `stream` as always. */
+#define NESVOR_STEP_DEFER_JOIN 8
+int nesvor_step_join(void* step, void* stream);
 
 /* ----------------------------------------------------------------------
  * Similarity sums of the stack registration.  Replaces, per optimisation step of `VVR`

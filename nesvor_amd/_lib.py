@@ -14,10 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NESVOR_HIP_LIB: load another build of the same ABI (tools/ablate_hashgrid.py times variants of one kernel this way)
 LIB_PATH = os.environ.get("NESVOR_HIP_LIB") or os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 25
+ABI_VERSION = 27
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
+STEP_DEFER_JOIN = 8  # nesvor_step_run: OR-ed into `phase` (NESVOR_STEP_DEFER_JOIN)
 LAYOUT_CLUSTERED = 4  # forward hint, OR-ed into the layout: 256 consecutive points are one spatial cluster
 
 
@@ -143,6 +144,7 @@ _SIGNATURES = {
     "nesvor_slice_grads": ([_P] * 9 + [c_int, c_int, c_int, _P], c_int),
     "nesvor_step_prologue": ([_P] * 5 + [c_int, c_int, _P], c_int),
     "nesvor_step_epilogue": ([_P] * 6 + [c_float, _P, _P, _P, _P, c_int, c_int, c_float, c_float, _P], c_int),
+    "nesvor_hashgrid_backward_adamw": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P, _P, _P, _P, POINTER(AdamwT), _P], c_int),
     "nesvor_adamw_step": (
         [_P, _P, _P, _P, c_int64] + [c_float] * 8 + [c_int, _P],
         c_int,
@@ -151,6 +153,7 @@ _SIGNATURES = {
     "nesvor_step_create": ([POINTER(StepT)], c_void_p),
     "nesvor_step_update": ([_P, POINTER(StepT)], c_int),
     "nesvor_step_destroy": ([_P], None),
+    "nesvor_step_join": ([_P, _P], c_int),
     "nesvor_step_run": ([_P, _P, _P, _P, c_uint64, c_uint64, _P, c_int, c_int, POINTER(AdamwT), _P], c_int),
     "nesvor_vvr_similarity": ([_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P], c_int),
 }

@@ -9,20 +9,9 @@
 #include <hip/hip_runtime.h>
 #include "common.h"
 
+#include "adam.h"
+
 namespace {
-
-struct AdamArgs {
-  float lr, beta1, beta2, eps, decay_mul, step_size, inv_sqrt_bc2, grad_scale;
-};
-
-__device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, const AdamArgs& a) {
-  const float gs = g * a.grad_scale;
-  p *= a.decay_mul;
-  m = fmaf(1.f - a.beta1, gs - m, m);
-  v = fmaf(1.f - a.beta2, gs * gs, a.beta2 * v);
-  const float denom = sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
-  p -= a.step_size * (m / denom);
-}
 
 template <bool ZERO>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
@@ -53,12 +42,7 @@ extern "C" int nesvor_adamw_step(float* param, float* grad, float* exp_avg, floa
                                  float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
                                  float bias_correction2, float grad_scale, int zero_grad, void* stream) {
   if (n <= 0) return 0;
-  AdamArgs a;
-  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
-  a.decay_mul = 1.f - lr * weight_decay;
-  a.step_size = lr / bias_correction1;
-  a.inv_sqrt_bc2 = 1.f / sqrtf(bias_correction2);
-  a.grad_scale = grad_scale;
+  const AdamArgs a = make_adam_args(lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2, grad_scale);
   int64_t blocks = ((n >> 2) + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 256 * 8) blocks = 256 * 8;
@@ -106,4 +90,4 @@ extern "C" int nesvor_sum_rows(const float* in, float* out, int rows, int cols, 
   return (int)hipGetLastError();
 }
 
-extern "C" int nesvor_hip_abi_version(void) { return 25; }
+extern "C" int nesvor_hip_abi_version(void) { return 27; }

@@ -43,7 +43,7 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
             os.path.getmtime(src),
-            os.path.getmtime(os.path.join(HERE, "common.h")),
+            max(os.path.getmtime(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".h")),
             os.path.getmtime(os.path.join(ROOT, "include", "nesvor_hip.h")),
             os.path.getmtime(os.path.abspath(__file__)),
         ):

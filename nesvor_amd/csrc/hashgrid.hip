@@ -45,6 +45,7 @@
 #include <type_traits>
 #include <unordered_map>
 #include "common.h"
+#include "adam.h"
 #include "../../include/nesvor_hip.h"
 
 // Timing ablations (tools/ablate_hashgrid.py): -DNESVOR_ABLATE=<bits> compiles pieces of the aggregation pass out.
@@ -1325,12 +1326,29 @@ constexpr uint32_t kOwnerSlice = 1u << 18;  // records per owner workgroup: a PS
 // grid.x = sum over buckets of ceil(cap / kOwnerSlice) slices; a slice past the queue tail exits at once.
 constexpr int kOwnerThreads = 512;   // 8 waves, four workgroups per CU (32 KiB of LDS each): measured 0.058 ms vs 0.077 (1024 threads) / 0.073 (256)
 
-template <int F, bool COALESCED>
+// ADAM: the owner pass also applies the optimiser to the table.  The workgroup that completes a chunk's gradient updates the
+// chunk's parameters and moments while the gradient is still in its LDS, so the table gradient is never written to (and read
+// back from, and zero-filled in) HBM; `grad_table` is read - it may hold a gradient from an earlier backward, or the
+// contributions of records that found their queue full - and what was non-zero in it is zero-filled.  The result equals this
+// pass without ADAM followed by nesvor_adamw_step(table, grad_table, ..., zero_grad = 1) (bit for bit where a chunk's
+// records fit one slice - every chunk of a PSF-cloud batch at the fine levels; in the order of the slices' atomic adds
+// otherwise, as without ADAM).  Chunks whose records span several slices: every slice adds its sums to grad_table and takes a
+// ticket (`done`, one counter per chunk, zero between launches); the slice that draws the last ticket does the update.
+struct OwnerAdam {
+  float* param;     // the table (entry 0 of level 0), updated in place
+  float* exp_avg;   // first / second moments, same indexing
+  float* exp_avg_sq;
+  uint32_t* done;   // tickets, one per bucket
+  AdamArgs a;
+};
+
+template <int F, bool COALESCED, bool ADAM = false>
 __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor_grid_t g, const BwdPlan plan,
                                                           const uint32_t* __restrict__ tails,
                                                           const uint32_t* __restrict__ records,
-                                                          float* __restrict__ grad_table) {
+                                                          float* __restrict__ grad_table, const OwnerAdam adam) {
   __shared__ __attribute__((aligned(16))) float acc[kOwnerLdsFloats];
+  __shared__ uint32_t ticket_s;
   const int tid = threadIdx.x;
   // decode (level, chunk, slice) from the flat workgroup id
   uint32_t wg = blockIdx.x;
@@ -1363,8 +1381,10 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
     return o;
   };
   const uint32_t r0 = slice * plan.slice[level];
-  if (r0 >= n) return;
-  const uint32_t r1 = min(n, r0 + plan.slice[level]);
+  // slices that hold records (ADAM: at least one, which also updates a chunk that received nothing - the moments decay)
+  const uint32_t n_part = ADAM ? max(1u, (n + plan.slice[level] - 1u) / plan.slice[level]) : 0u;
+  if (ADAM ? slice >= n_part : r0 >= n) return;
+  const uint32_t r1 = max(r0, min(n, r0 + plan.slice[level]));
   const bool sole_writer = n <= plan.slice[level];
   for (int t = tid; t < kOwnerLdsFloats / 4; t += kOwnerThreads) reinterpret_cast<float4*>(acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
@@ -1470,6 +1490,55 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
   const uint32_t e0 = chunk << plan.shift[level];
   const uint32_t ne = min((uint32_t)(1u << plan.shift[level]), g.size[level] - e0);
   float* out = grad_table + ((size_t)g.offset[level] + e0) * F;
+  if constexpr (ADAM) {
+    const size_t first = ((size_t)g.offset[level] + e0) * F;
+    float* P = adam.param + first;
+    float* M = adam.exp_avg + first;
+    float* V = adam.exp_avg_sq + first;
+    const uint32_t nf = ne * F;
+    if (!sole_writer) {
+      for (uint32_t t = tid; t < nf; t += kOwnerThreads) {
+        const float a = acc[t];
+        if (a != 0.f) atomicAdd(out + t, a);
+      }
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) ticket_s = atomicAdd(&adam.done[gb], 1u);
+      __syncthreads();
+      if (ticket_s != n_part - 1u) return;
+      if (tid == 0) adam.done[gb] = 0u;  // ready for the next launch
+      __threadfence();
+      for (uint32_t t = tid; t < nf; t += kOwnerThreads) {
+        const float gsum = __hip_atomic_load(out + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float p = P[t], m = M[t], v = V[t];
+        adam1(p, gsum, m, v, adam.a);
+        P[t] = p; M[t] = m; V[t] = v;
+        if (gsum != 0.f) out[t] = 0.f;
+      }
+      return;
+    }
+    if (nf % 4u == 0u) {  // (chunks and level offsets are multiples of 8 entries: aligned)
+      const float4* a4 = reinterpret_cast<const float4*>(acc);
+      float4* o4 = reinterpret_cast<float4*>(out);
+      for (uint32_t t = tid; t < nf / 4u; t += kOwnerThreads) {
+        float4 p = reinterpret_cast<float4*>(P)[t], m = reinterpret_cast<float4*>(M)[t], v = reinterpret_cast<float4*>(V)[t];
+        const float4 o = o4[t], a = a4[t];
+        adam1(p.x, a.x + o.x, m.x, v.x, adam.a); adam1(p.y, a.y + o.y, m.y, v.y, adam.a);
+        adam1(p.z, a.z + o.z, m.z, v.z, adam.a); adam1(p.w, a.w + o.w, m.w, v.w, adam.a);
+        reinterpret_cast<float4*>(P)[t] = p; reinterpret_cast<float4*>(M)[t] = m; reinterpret_cast<float4*>(V)[t] = v;
+        if (o.x != 0.f || o.y != 0.f || o.z != 0.f || o.w != 0.f) o4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      for (uint32_t t = tid; t < nf; t += kOwnerThreads) {
+        const float o = out[t];
+        float p = P[t], m = M[t], v = V[t];
+        adam1(p, acc[t] + o, m, v, adam.a);
+        P[t] = p; M[t] = m; V[t] = v;
+        if (o != 0.f) out[t] = 0.f;
+      }
+    }
+    return;
+  }
 #ifndef NESVOR_OWNER_F4
 #define NESVOR_OWNER_F4 1
 #endif
@@ -1575,6 +1644,8 @@ inline bool make_plan(const nesvor_grid_t* g, int64_t N, BwdPlan* plan, uint64_t
 }
 
 constexpr uint64_t kTailBytes = (uint64_t)kSubQueues * kTailStride * sizeof(uint32_t);  // one tails region; the workspace starts with two
+constexpr uint64_t kDoneBytes = (uint64_t)kTailStride * sizeof(uint32_t);  // then the owner pass's per-chunk tickets (OwnerAdam::done)
+constexpr uint64_t kHeadBytes = 2 * kTailBytes + kDoneBytes;               // zero-filled once by the caller; the records follow
 
 // Which of a workspace's two tail regions the current backward uses.  A fresh backward (not a later launch of a split
 // one) switches to the region the previous aggregation pass zero-filled; the caller zero-fills both once after
@@ -1591,7 +1662,7 @@ inline int tails_parity(void* workspace, bool advance) {
 template <int F, int LAYOUT>
 int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table, const float* dpe, float* gt,
                      float* gu, int64_t N, void* workspace, int stages, int level_begin, int level_end, const float* queue_scale,
-                     const float* dy_bound, hipStream_t st) {
+                     const float* dy_bound, const OwnerAdam* adam, hipStream_t st) {
   BwdPlan plan;
   uint64_t n_rec;
   if (!make_plan(g, N, &plan, &n_rec, queue_scale)) return (int)hipErrorInvalidValue;
@@ -1601,7 +1672,7 @@ int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table,
   const int par = tails_parity(workspace, (stages & 1) && !(stages & 4));
   uint32_t* tails = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + (par ? kTailBytes : 0));
   uint32_t* tails_next = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + (par ? 0 : kTailBytes));
-  uint32_t* records = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + 2 * kTailBytes);
+  uint32_t* records = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + kHeadBytes);
   uint8_t* order = reinterpret_cast<uint8_t*>(records) + n_rec * (1 + F) * sizeof(uint32_t);  // ceil(N / 256) * 256 bytes
   const int order_mode = (stages & 4) ? 2 : 1;
   dim3 grid((unsigned)((N + 255) / 256)), block(256);
@@ -1622,10 +1693,15 @@ int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table,
 owner_stage:
   if (stages & 2) {
     static const int coalesced = []() { const char* e = getenv("NESVOR_OWNER_COALESCED"); return e == nullptr ? 1 : atoi(e); }();
-    if (coalesced)
-      hipLaunchKernelGGL((hashgrid_bwd_owner<F, true>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt);
+    OwnerAdam oa{};
+    if (adam != nullptr) {
+      oa = *adam;
+      oa.done = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + 2 * kTailBytes);
+      hipLaunchKernelGGL((hashgrid_bwd_owner<F, true, true>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt, oa);
+    } else if (coalesced)
+      hipLaunchKernelGGL((hashgrid_bwd_owner<F, true>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt, oa);
     else
-      hipLaunchKernelGGL((hashgrid_bwd_owner<F, false>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt);
+      hipLaunchKernelGGL((hashgrid_bwd_owner<F, false>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt, oa);
   }
   return (int)hipGetLastError();
 }
@@ -1708,10 +1784,10 @@ extern "C" int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t*
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return -1;
   if (!make_plan(grid, N, &plan, &n_rec, queue_scale)) return -1;
   if (plan.n_buckets > kOverflowBase) return -1;
-  return (int64_t)(2 * kTailBytes + n_rec * (1 + grid->n_features) * sizeof(uint32_t) + (uint64_t)((N + 255) / 256) * 256);
+  return (int64_t)(kHeadBytes + n_rec * (1 + grid->n_features) * sizeof(uint32_t) + (uint64_t)((N + 255) / 256) * 256);
 }
 
-extern "C" int64_t nesvor_hashgrid_backward_workspace_zero_bytes(void) { return (int64_t)(2 * kTailBytes); }
+extern "C" int64_t nesvor_hashgrid_backward_workspace_zero_bytes(void) { return (int64_t)kHeadBytes; }
 
 extern "C" int64_t nesvor_hashgrid_backward_overflow_offset(void* workspace) {
   return (int64_t)(tails_parity(workspace, false) ? kTailBytes : 0) + (int64_t)kOverflowBase * (int64_t)sizeof(uint32_t);
@@ -1724,7 +1800,7 @@ extern "C" int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* 
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
   if (workspace == nullptr || (stages & 3) == 0) return (int)hipErrorInvalidValue;
   DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages & 3, 0, grid->n_levels,
-                    queue_scale, nullptr, (hipStream_t)stream);
+                    queue_scale, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int nesvor_hashgrid_backward_levels(const nesvor_grid_t* grid, const float* u, const float* table,
@@ -1736,7 +1812,7 @@ extern "C" int nesvor_hashgrid_backward_levels(const nesvor_grid_t* grid, const 
   if (workspace == nullptr || (stages & 3) == 0) return (int)hipErrorInvalidValue;
   if (level_begin < 0 || level_end > grid->n_levels || level_begin >= level_end) return (int)hipErrorInvalidValue;
   DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages, level_begin, level_end,
-                    queue_scale, nullptr, (hipStream_t)stream);
+                    queue_scale, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int nesvor_hashgrid_backward_bounded(const nesvor_grid_t* grid, const float* u, const float* table,
@@ -1748,5 +1824,20 @@ extern "C" int nesvor_hashgrid_backward_bounded(const nesvor_grid_t* grid, const
   if (workspace == nullptr || (stages & 3) == 0) return (int)hipErrorInvalidValue;
   if (level_begin < 0 || level_end > grid->n_levels || level_begin >= level_end) return (int)hipErrorInvalidValue;
   DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages, level_begin, level_end,
-                    queue_scale, dy_bound, (hipStream_t)stream);
+                    queue_scale, dy_bound, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int nesvor_hashgrid_backward_adamw(const nesvor_grid_t* grid, const float* u, float* table, const float* dpe,
+                                              float* grad_table, float* grad_u, int64_t N, int layout, void* workspace,
+                                              int stages, const float* queue_scale, const float* dy_bound, float* exp_avg,
+                                              float* exp_avg_sq, const nesvor_adamw_t* adam, void* stream) {
+  if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
+  if (N <= 0 || workspace == nullptr || (stages & ~3) != 0 || (stages & 3) == 0) return (int)hipErrorInvalidValue;
+  if (table == nullptr || grad_table == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr || adam == nullptr) return (int)hipErrorInvalidValue;
+  OwnerAdam oa;
+  oa.param = table; oa.exp_avg = exp_avg; oa.exp_avg_sq = exp_avg_sq; oa.done = nullptr;
+  oa.a = make_adam_args(adam->lr, adam->beta1, adam->beta2, adam->eps, adam->weight_decay, adam->bias_correction1,
+                        adam->bias_correction2, adam->grad_scale);
+  DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages, 0, grid->n_levels, queue_scale,
+                    dy_bound, &oa, (hipStream_t)stream);
 }

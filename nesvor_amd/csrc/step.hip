@@ -10,6 +10,8 @@
 //   side stream : pose regulariser (serial chain per slice)           ...            owner pass of the hash-grid backward
 //   main stream : prologue | sampler | hash grid | MLPs | loss | MLP backwards | aggregation pass | sampler backward
 //                 | per-slice gradients | epilogue | [AdamW]
+// (overlap_owner bit 1: the table's AdamW step is taken by the owner pass itself, chunk by chunk while a chunk's gradient is
+// in LDS - nesvor_hashgrid_backward_adamw - and the closing AdamW launch covers the small parameters only.)
 //
 // The configuration switches are those of the reference's args (no_transformation_optimization, no_pixel_variance,
 // no_slice_scale, no_slice_variance, n_levels_bias).  Data-parallel runs call the step in two phases so that the host
@@ -24,6 +26,7 @@ namespace {
 struct StepCtx {
   nesvor_step_t d;
   hipEvent_t ev_fork, ev_pose, ev_agg, ev_owner;
+  bool pending_join = false;  // a table update of the previous run is still on the side stream (NESVOR_STEP_DEFER_JOIN)
 };
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx,
@@ -126,6 +129,8 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   hipStream_t main = (hipStream_t)stream, side = (hipStream_t)d.side_stream;
   const int B = d.B, S = d.S, n = d.n_slices, L = d.grid.n_levels;
   const int64_t N = (int64_t)B * S;
+  const bool defer_join = (phase & NESVOR_STEP_DEFER_JOIN) != 0;
+  phase &= ~NESVOR_STEP_DEFER_JOIN;
   if (phase < 0 || phase > 2 || (phase != 0) != (split_level > 0 && split_level < L)) return (int)hipErrorInvalidValue;
   if (d.has_b && phase != 0) return (int)hipErrorInvalidValue;  // the bias field's global mean needs the host's all-reduce: Python path
   float* c = d.has_c ? d.small : nullptr;       // slice scale n softmax(logit_coef)
@@ -137,6 +142,12 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   // over dpe); zero-filled with the accumulators.  With a bias field dpe is a sum of two networks' gradients: no bound.
   float* dpe_bound = d.has_b ? nullptr : d.small + 26 * n;
   const int layout = NESVOR_LAYOUT_FEATURE_MAJOR;
+  const bool overlap_owner = (d.overlap_owner & 1) != 0;
+  // AdamW on the table inside the owner pass (single call covers gradient and update, nothing to exchange in between);
+  // the table is the LAST segment of the flat buffers
+  const int64_t table_off = d.table - d.flat_param;
+  const bool fuse_adamw = adam != nullptr && phase == 0 && (d.overlap_owner & 2) != 0 && d.table != nullptr && d.flat_param != nullptr &&
+                          d.g_table == d.flat_grad + table_off && table_off >= 0 && table_off < d.flat_numel;
 
   if (phase != 2) {
     // pose regulariser: a serial chain per slice, independent of the batch -> side stream, joined at the epilogue
@@ -148,6 +159,10 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
     // ---- forward
     NESVOR_TRY(nesvor_step_prologue(d.has_c ? d.logit_coef : nullptr, c, d.axisangle, mat, acc, 13 * n + 1, n, main));
     NESVOR_TRY(nesvor_psf_transform_forward_rng(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.x, d.u, B, S, main));
+    if (ctx->pending_join) {  // the previous run left its table update on the side stream
+      if (hipStreamWaitEvent(main, ctx->ev_owner, 0) != hipSuccess) return (int)hipGetLastError();
+      ctx->pending_join = false;
+    }
     NESVOR_TRY(nesvor_hashgrid_forward(&d.grid, d.u, d.table, d.pe, N, layout | (S >= 128 ? NESVOR_LAYOUT_CLUSTERED : 0), main));
     NESVOR_TRY(nesvor_mlp_forward(&d.density, nullptr, d.pe, d.z, d.saved_d, N, main));
     if (d.ks > 0) {
@@ -193,16 +208,21 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   if (phase == 0) {
     NESVOR_TRY(nesvor_hashgrid_backward_bounded(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 1, 0, L,
                                                 d.queue_scale, dpe_bound, main));
-    if (d.overlap_owner) {
-      // the owner pass only finishes grad_table: it runs under the sampler backward and the per-slice bookkeeping
+    // the owner pass only finishes grad_table (or, fused, takes the table's AdamW step): it runs under the sampler backward
+    // and the per-slice bookkeeping
+    hipStream_t owner_stream = main;
+    if (overlap_owner) {
       if (hipEventRecord(ctx->ev_agg, main) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_agg, 0) != hipSuccess) return (int)hipGetLastError();
-      NESVOR_TRY(nesvor_hashgrid_backward_levels(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 2, 0, L,
-                                                 d.queue_scale, side));
-      if (hipEventRecord(ctx->ev_owner, side) != hipSuccess) return (int)hipGetLastError();
-    } else {
-      NESVOR_TRY(nesvor_hashgrid_backward_levels(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 2, 0, L,
-                                                 d.queue_scale, main));
+      owner_stream = side;
     }
+    if (fuse_adamw)
+      NESVOR_TRY(nesvor_hashgrid_backward_adamw(&d.grid, d.u, d.flat_param + table_off, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 2,
+                                                d.queue_scale, dpe_bound, d.flat_exp_avg + table_off, d.flat_exp_avg_sq + table_off, adam,
+                                                owner_stream));
+    else
+      NESVOR_TRY(nesvor_hashgrid_backward_levels(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 2, 0, L,
+                                                 d.queue_scale, owner_stream));
+    if (overlap_owner && hipEventRecord(ctx->ev_owner, side) != hipSuccess) return (int)hipGetLastError();
   } else if (phase == 1) {
     // fine levels first (the end of the flat gradient): the host starts their all-reduce when this call returns
     return nesvor_hashgrid_backward_bounded(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 3, split_level, L,
@@ -213,13 +233,13 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
     NESVOR_TRY(nesvor_hashgrid_backward_bounded(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 1 | 4 | 8, 0,
                                                 split_level, d.queue_scale, dpe_bound, main));
     hipStream_t owner_stream = main;
-    if (d.overlap_owner) {
+    if (overlap_owner) {
       if (hipEventRecord(ctx->ev_agg, main) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_agg, 0) != hipSuccess) return (int)hipGetLastError();
       owner_stream = side;
     }
     NESVOR_TRY(nesvor_hashgrid_backward_bounded(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 2 | 4 | 8, 0,
                                                 split_level, d.queue_scale, dpe_bound, owner_stream));
-    if (d.overlap_owner && hipEventRecord(ctx->ev_owner, side) != hipSuccess) return (int)hipGetLastError();
+    if (overlap_owner && hipEventRecord(ctx->ev_owner, side) != hipSuccess) return (int)hipGetLastError();
   }
   if (d.opt_T)
     NESVOR_TRY(nesvor_psf_transform_backward_rng(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.dxl, du, d.dpix, B, S, main));
@@ -239,9 +259,31 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
                                   d.opt_T ? d.trans_terms : nullptr, losses, n, B, img_scale, img_off, main));
   if (d.has_b) hipLaunchKernelGGL(square_kernel, dim3(1), dim3(1), 0, main, d.lb_mean, losses + 5);
   if (adam != nullptr) {
-    if (phase != 1 && d.overlap_owner && hipStreamWaitEvent(main, ctx->ev_owner, 0) != hipSuccess) return (int)hipGetLastError();
-    NESVOR_TRY(nesvor_adamw_step(d.flat_param, d.flat_grad, d.flat_exp_avg, d.flat_exp_avg_sq, d.flat_numel, adam->lr, adam->beta1, adam->beta2,
-                                 adam->eps, adam->weight_decay, adam->bias_correction1, adam->bias_correction2, adam->grad_scale, 1, main));
+    if (fuse_adamw) {
+      // everything but the table; the table's update is the owner pass, which the next forward must wait for - here, or
+      // (NESVOR_STEP_DEFER_JOIN) in the next run right before its hash-grid forward, so that the next iteration's prologue and
+      // sampler run under the end of this one's table update
+      NESVOR_TRY(nesvor_adamw_step(d.flat_param, d.flat_grad, d.flat_exp_avg, d.flat_exp_avg_sq, table_off, adam->lr, adam->beta1, adam->beta2,
+                                   adam->eps, adam->weight_decay, adam->bias_correction1, adam->bias_correction2, adam->grad_scale, 1, main));
+      if (overlap_owner) {
+        if (defer_join) ctx->pending_join = true;
+        else if (hipStreamWaitEvent(main, ctx->ev_owner, 0) != hipSuccess) return (int)hipGetLastError();
+      }
+    } else {
+      if (phase != 1 && overlap_owner && hipStreamWaitEvent(main, ctx->ev_owner, 0) != hipSuccess) return (int)hipGetLastError();
+      NESVOR_TRY(nesvor_adamw_step(d.flat_param, d.flat_grad, d.flat_exp_avg, d.flat_exp_avg_sq, d.flat_numel, adam->lr, adam->beta1, adam->beta2,
+                                   adam->eps, adam->weight_decay, adam->bias_correction1, adam->bias_correction2, adam->grad_scale, 1, main));
+    }
   }
   return (int)hipGetLastError();
+}
+
+extern "C" int nesvor_step_join(void* handle, void* stream) {
+  if (handle == nullptr) return (int)hipErrorInvalidValue;
+  StepCtx* ctx = static_cast<StepCtx*>(handle);
+  if (ctx->pending_join) {
+    if (hipStreamWaitEvent((hipStream_t)stream, ctx->ev_owner, 0) != hipSuccess) return (int)hipGetLastError();
+    ctx->pending_join = false;
+  }
+  return 0;
 }

@@ -90,6 +90,9 @@ class DirectStep:
         # sampler backward and the per-slice bookkeeping
         self.side = torch.cuda.Stream(device=dev)
         self._overlap_owner = __import__("os").environ.get("NESVOR_OWNER_OVERLAP", "1") != "0"
+        # the table's AdamW step inside the owner pass (nesvor_hashgrid_backward_adamw) whenever one native call covers
+        # gradient and update (no data-parallel exchange in between): the table gradient then never goes through HBM
+        self._adamw_in_owner = __import__("os").environ.get("NESVOR_ADAMW_IN_OWNER", "1") != "0"
         # evaluation of the MLP matrix products (mlp.operand_mode): bf16-rounded operands for the half-precision model
         # structure and, opt-in, for the fp32 model (args.mlp_bf16); otherwise fp32 - the split-bf16 default, or the
         # plain fp32 MFMAs with args.mlp_fp32_mfma
@@ -170,7 +173,7 @@ class DirectStep:
         return not (self.has_b and self.parallel)
 
     def _native_state(self, B: int):
-        key = (B, mlp_mod.operand_mode(self.bf16), self._overlap_owner)  # (bench.py switches the evaluation mode of a live trainer)
+        key = (B, mlp_mod.operand_mode(self.bf16), self._overlap_owner, self._adamw_in_owner)  # (bench.py switches the evaluation mode of a live trainer)
         st = self._native.get(key)
         if st is not None:
             return st
@@ -206,7 +209,7 @@ class DirectStep:
         d.B, d.S, d.n_slices = B, S, n
         d.opt_T, d.has_lv, d.has_c, d.has_lvs, d.has_b = (int(x) for x in (self.opt_T, self.has_lv, self.has_c, self.has_lvs, self.has_b))
         d.n_features_z, d.ks, d.kb_bias, d.reg_type = a.n_features_z, self.ks, self.kb_bias, self.reg_type
-        d.overlap_owner = int(self._overlap_owner)
+        d.overlap_owner = int(self._overlap_owner) | (2 if self._adamw_in_owner else 0)
         d.delta, d.w_T = self.delta, self.w_T
         ptr = lambda t: None if t is None else t.data_ptr()
         d.axisangle, d.axisangle_init = ptr(m.axisangle), ptr(m.axisangle_init)
@@ -255,7 +258,7 @@ class DirectStep:
         st = self._native[key] = {"desc": d, "handle": ctypes.c_void_p(handle), "buf": buf, "ws": None}
         return st
 
-    def _run_native(self, xyz, v, slice_idx, adam=None) -> Dict[str, torch.Tensor]:
+    def _run_native(self, xyz, v, slice_idx, adam=None, defer_table_join=False) -> Dict[str, torch.Tensor]:
         from .encoding import _workspace, queue_sizer
 
         m = self.model
@@ -290,10 +293,14 @@ class DirectStep:
                 _lib.check(lib.nesvor_step_run(*args, 1, self.split_level, None, stream), "training step (fine levels)")
                 self._early = self._start_early()  # async: RCCL's stream, behind the launches above
                 _lib.check(lib.nesvor_step_run(*args, 2, self.split_level, None, stream), "training step (coarse levels)")
-                self._owner_pending = bool(d.overlap_owner)  # the coarse levels' owner pass runs on the side stream
+                self._owner_pending = bool(d.overlap_owner & 1)  # the coarse levels' owner pass runs on the side stream
             else:
-                _lib.check(lib.nesvor_step_run(*args, 0, 0, a_ptr, stream), "training step")
-                self._owner_pending = bool(d.overlap_owner) and adam is None  # with its own AdamW the step has joined the owner pass
+                # with its own AdamW the step has joined the owner pass - unless asked to leave the table's update (taken
+                # inside the owner pass) on the side stream: the next run joins it right before its hash-grid forward, anyone
+                # else through join_owner()
+                defer = bool(defer_table_join) and adam is not None and (d.overlap_owner & 3) == 3
+                _lib.check(lib.nesvor_step_run(*args, 0 | (_lib.STEP_DEFER_JOIN if defer else 0), 0, a_ptr, stream), "training step")
+                self._owner_pending = bool(d.overlap_owner & 1) and (adam is None or defer)
         sizer.snapshot(ws)
         losses = {D_LOSS: vals[0]}
         if self.has_var:
@@ -323,16 +330,20 @@ class DirectStep:
             self._owner_pending = False
 
     @torch.no_grad()
-    def run(self, xyz, v, slice_idx, noise=None, defer_owner_join: bool = False, adam=None) -> Dict[str, torch.Tensor]:
+    def run(self, xyz, v, slice_idx, noise=None, defer_owner_join: bool = False, adam=None, defer_table_join: bool = False) -> Dict[str, torch.Tensor]:
         """``adam`` (an ``_lib.AdamwT``): the one-call iteration also runs the optimizer (single process only); ignored - and
-        left to the caller - on the Python issue path.  Returns the loss dict; ``self.ran_optimizer`` says who owns the step."""
+        left to the caller - on the Python issue path.  Returns the loss dict; ``self.ran_optimizer`` says who owns the step.
+        ``defer_table_join`` (with ``adam``): the hash table's update may still be running on the side stream when this
+        returns (losses and all other parameters are complete on the current stream); the next ``run`` waits for it where
+        it first reads the table, any other reader of the table calls ``join_owner()`` first."""
         self.ran_optimizer = False
         if self.native_ready(noise):
-            losses = self._run_native(xyz, v, slice_idx, adam)
+            losses = self._run_native(xyz, v, slice_idx, adam, defer_table_join)
             self.ran_optimizer = adam is not None
-            if not defer_owner_join:
+            if not (defer_owner_join or (defer_table_join and adam is not None)):
                 self.join_owner()
             return losses
+        self.join_owner()  # (a table update a deferred native step left on the side stream)
         m, a = self.model, self.model.args
         lib = _lib.load()
         dev = xyz.device

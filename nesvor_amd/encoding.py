@@ -178,6 +178,32 @@ def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True
     return grad_table, grad_u
 
 
+def hashgrid_backward_adamw(spec, u, table, dpe, grad_table, exp_avg, exp_avg_sq, adam, need_input_grad=True,
+                            layout=_lib.LAYOUT_ROW_MAJOR, dy_bound=None):
+    """``hashgrid_backward`` (owner method, all levels) whose owner pass also takes the AdamW step on the table
+    (``nesvor_hashgrid_backward_adamw``): equals ``hashgrid_backward`` into ``grad_table`` followed by
+    ``nesvor_adamw_step(table, grad_table, exp_avg, exp_avg_sq, ..., zero_grad=1)`` - ``table`` and the moments are updated
+    in place, ``grad_table`` is zero afterwards - without the table gradient passing through HBM.  ``adam``: ``_lib.AdamwT``.
+    Returns grad_u (or None).  The training step (csrc/step.hip) makes the same call when one call covers gradient and
+    update."""
+    _lib.require_device(u, table, dpe, grad_table, exp_avg, exp_avg_sq, dtype=torch.float32, name="hashgrid backward + AdamW input")
+    N = u.shape[0]
+    grad_u = torch.empty_like(u) if need_input_grad else None
+    lib = _lib.load()
+    sizer = queue_sizer(spec, N, u.device)
+    sizer.poll()
+    ws = _workspace(spec, N, u.device, sizer)
+    if ws is None:
+        raise RuntimeError("the grid does not fit the owner method's plan")
+    with torch.cuda.device(u.device):
+        err = lib.nesvor_hashgrid_backward_adamw(ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(dpe), _lib.ptr(grad_table),
+                                                 _lib.ptr(grad_u), N, layout, _lib.ptr(ws), 3, sizer.scale, _lib.ptr(dy_bound),
+                                                 _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), ctypes.byref(adam), _lib.stream_ptr())
+    _lib.check(err, "hashgrid backward + AdamW")
+    sizer.snapshot(ws)
+    return grad_u
+
+
 def hashgrid_encode(u, table, spec, layout=_lib.LAYOUT_ROW_MAJOR, grad_accum=None):
     """pe = encode(u, table), differentiable in both: the dispatcher op ``torch.ops.nesvor.hashgrid_encode``
     (``nesvor_amd.ops``; row-major (N, L*F) output like tinycudann, or feature-major).  ``grad_accum``: a tensor the

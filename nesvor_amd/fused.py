@@ -72,6 +72,10 @@ class FusedTrainer:
         self.t = 0
         self.world_size = world_size
         self._reduce_hook = None  # set by ddp: callable(flat_grad) performing the all-reduce(sum)
+        # True (set by a training loop that touches nothing but the losses between steps): a single-process native step may
+        # return while the hash table's AdamW update is still running on the side stream; the next step waits for it where it
+        # reads the table (csrc/step.hip, NESVOR_STEP_DEFER_JOIN), everyone else calls join() first
+        self.defer_table_join = False
         self._late_join = os.environ.get("NESVOR_OWNER_JOIN_LATE", "1") != "0"  # 0: join the owner pass before the step's epilogue (A/B)
         # autograd-free evaluation of the iteration when the configuration allows it (nesvor_amd.direct)
         from . import direct
@@ -133,7 +137,8 @@ class FusedTrainer:
             t = self.t + 1
             adam = _lib.AdamwT(self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, 1 - self.betas[0] ** t,
                                1 - self.betas[1] ** t, 1.0 / self.world_size)
-            losses = self.direct.run(xyz, v, slice_idx, None, defer_owner_join=self._late_join, adam=adam)
+            losses = self.direct.run(xyz, v, slice_idx, None, defer_owner_join=self._late_join, adam=adam,
+                                     defer_table_join=self.defer_table_join)
             if self.direct.ran_optimizer:
                 self.t = t
                 return losses
@@ -185,5 +190,11 @@ class FusedTrainer:
         self.t += 1
         self._adamw(0, self.flat.numel)
 
+    def join(self) -> None:
+        """Make the current stream wait for a table update left on the side stream (``defer_table_join``)."""
+        if self.direct is not None:
+            self.direct.join_owner()
+
     def finish(self) -> None:
+        self.join()
         self.model.inr.encoding.grad_accum = None

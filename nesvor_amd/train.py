@@ -145,6 +145,8 @@ def train(slices: List[Slice], args: Namespace, on_iteration=None) -> Tuple[INR,
         if parallel:
             ddp.broadcast_params_(trainer.flat.param)
             trainer.reduce_hook = ddp.make_reduce_hook()
+        # nothing but the losses is read between iterations (a callback might read the model: then every step joins)
+        trainer.defer_table_join = on_iteration is None
     perm_gen = None
     if parallel:
         # identical batch permutations on every rank from a dedicated generator; the global stream (PSF

@@ -467,6 +467,50 @@ def test_direct_step_runs_without_autograd(device, golden):
     t.optimizer_step()
 
 
+def test_native_step_table_update_in_owner_pass_and_deferred_join(device, golden):
+    """Three arrangements of the single-process native step train alike: (a) AdamW as one launch over the flat buffer behind
+    the owner pass, (b) the table's AdamW step inside the owner pass (``nesvor_hashgrid_backward_adamw``: the table gradient
+    never reaches HBM, ``flat.grad`` stays zero), (c) as (b) with the join of the side stream deferred to the next step's
+    hash-grid forward (``FusedTrainer.defer_table_join``; ``join()`` before anyone else reads the table)."""
+    from nesvor_amd.fused import FusedTrainer
+    from nesvor_amd.models import NeSVoR
+    from nesvor_amd.transform import RigidTransform
+
+    args = small_args(device=device)
+    tf = RigidTransform(torch.tensor(golden["fw_sd::axisangle_init"]).to(device), trans_first=True)
+    res = torch.tensor(golden["ds_resolution"]).to(device)
+    bbox = torch.tensor(golden["fw_sd::inr.bounding_box"]).to(device)
+    torch.manual_seed(5)
+    models = [NeSVoR(tf, res, float(golden["ds_mean"]), bbox, args)]
+    with torch.no_grad():
+        for name, p in models[0].named_parameters():
+            if name == "inr.encoding.params":
+                p.mul_(1e3)
+    for _ in range(2):
+        models.append(NeSVoR(tf, res, float(golden["ds_mean"]), bbox, args))
+        models[-1].load_state_dict(models[0].state_dict())
+    ta, tb, tc = (FusedTrainer(m, args) for m in models)
+    ta.direct._adamw_in_owner = False
+    tc.defer_table_join = True
+    assert all(t.direct is not None and t.direct.native_ready() for t in (ta, tb, tc)) and tb.direct._adamw_in_owner
+    d = lambda k: torch.tensor(golden[f"fw_{k}"]).to(device)
+    for it in range(5):
+        ls = [t.step(d("xyz"), d("v"), d("idx")) for t in (ta, tb, tc)]
+        for k in ls[0]:
+            for l in ls[1:]:
+                assert abs(float(l[k]) - float(ls[0][k])) <= 1e-4 * abs(float(ls[0][k])) + 1e-7, (it, k)
+    assert tc.direct._owner_pending and not tb.direct._owner_pending
+    tc.join()
+    assert not tc.direct._owner_pending
+    for t in (tb, tc):
+        apart = ((t.flat.param - ta.flat.param).abs() > 1e-5 * (1 + ta.flat.param.abs())).float().mean()
+        assert float(apart) < 2e-3, float(apart)
+        for buf in ("exp_avg", "exp_avg_sq"):
+            a, b = getattr(ta.flat, buf), getattr(t.flat, buf)
+            assert float(((a - b).abs() > 1e-5 * float(a.abs().max())).float().mean()) < 2e-3, buf
+        assert float(t.flat.grad.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("over", [
     {}, {"depth": 2}, {"no_transformation_optimization": True}, {"no_pixel_variance": True},
     {"no_slice_scale": True, "no_slice_variance": True}, {"image_regularization": "TV"},

@@ -270,11 +270,11 @@ def test_edge_prior_gradient_is_the_derivative_of_the_charbonnier_penalty():
 
 
 def test_committed_bench_line_carries_the_contract_fields():
-    """The JSON line `bench.py` printed for the committed round profile (profiles/r02_bench_n1.json, produced by
-    tools/collect_profiles.sh on the GPU box): every field the measurement contract names, with consistent arithmetic."""
+    """The JSON line `bench.py` printed for the committed round profile (profiles/r03_bench_n1.json, produced by
+    tools/gpu_check.sh on the GPU box): every field the measurement contract names, with consistent arithmetic."""
     import json
 
-    path = os.path.join(ROOT, "profiles", "r02_bench_n1.json")
+    path = os.path.join(ROOT, "profiles", "r03_bench_n1.json")
     d = json.load(open(path))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
