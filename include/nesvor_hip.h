@@ -285,9 +285,21 @@ typedef struct {
                                     on the 16x faster bf16 matrix pipe.  Forward: all layers; backward: the dX chain of
                                     the wave-specialised kernel (the dW products and every other backward kernel use
                                     mode 0, which is always a valid evaluation of mode 2) */
+  int32_t compact_save;       /* 1: training keeps, per hidden unit and sample, ONE BIT (h > 0) of every hidden layer and the
+                                 values of the layers after the first only: saved_hidden[0] = one uint32 per (16-sample group,
+                                 lane) - 16 N bytes instead of 256 N - with bit 16 l + 4 b + r = [h_l > 0] for the unit the
+                                 lane holds in block b, element r of the fragment layout; saved_hidden[l >= 1] as before.  The
+                                 backward gates with the bits and recomputes the first hidden layer from the network input
+                                 (24 MFMAs per 16 samples, in exactly the operand layout the weight gradient needs) instead of
+                                 streaming it back: 268 MB less written and 268 MB less read per network at N = 2^20.
+                                 Needs what nesvor_mlp_compact_save_ok() checks (split operands, the pipelined forward and
+                                 the wave-specialised backward); forward and backward of one step must agree on it. */
   const float* weight[NESVOR_MAX_MLP_LAYERS];
   const float* bias[NESVOR_MAX_MLP_LAYERS];
 } nesvor_mlp_t;
+
+/* 1 if (net, N) can run with compact_save = 1 (the field itself is ignored by this query), else 0. */
+int nesvor_mlp_compact_save_ok(const nesvor_mlp_t* net, int64_t N);
 
 int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, const float* xb, float* y,
                        float* const* saved_hidden, int64_t N, void* stream);

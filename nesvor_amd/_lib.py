@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NESVOR_HIP_LIB: load another build of the same ABI (tools/ablate_hashgrid.py times variants of one kernel this way)
 LIB_PATH = os.environ.get("NESVOR_HIP_LIB") or os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -42,7 +42,7 @@ class MlpT(Structure):
     _fields_ = [
         ("width", c_int32), ("n_hidden", c_int32), ("out_dim", c_int32),
         ("k_a", c_int32), ("k_b", c_int32), ("b_row0", c_int32), ("samples_per_pixel", c_int32),
-        ("dxa_group_sums", c_int32), ("bf16_operands", c_int32),
+        ("dxa_group_sums", c_int32), ("bf16_operands", c_int32), ("compact_save", c_int32),
         ("weight", c_void_p * 4), ("bias", c_void_p * 4),
     ]
 
@@ -131,6 +131,7 @@ _SIGNATURES = {
     "nesvor_psf_transform_forward_rng": ([_P] * 4 + [c_uint64, c_uint64] + [_P] * 3 + [c_int, c_int, _P], c_int),
     "nesvor_psf_transform_backward_rng": ([_P] * 4 + [c_uint64, c_uint64] + [_P] * 4 + [c_int, c_int, _P], c_int),
     "nesvor_psf_noise": ([c_uint64, c_uint64, _P, c_int64, _P], c_int),
+    "nesvor_mlp_compact_save_ok": ([POINTER(MlpT), c_int64], c_int),
     "nesvor_mlp_forward": ([POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), c_int64, _P], c_int),
     "nesvor_mlp_backward": (
         [POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), POINTER(c_void_p), _P, _P, _P, c_int, c_int64, _P],

@@ -90,4 +90,4 @@ extern "C" int nesvor_sum_rows(const float* in, float* out, int rows, int cols, 
   return (int)hipGetLastError();
 }
 
-extern "C" int nesvor_hip_abi_version(void) { return 27; }
+extern "C" int nesvor_hip_abi_version(void) { return 28; }

@@ -76,6 +76,7 @@ struct MlpArgs {
   int dxa_group;                // dxa holds one row per 16-sample GROUP (sum over its samples) instead of one per sample
   int bf16;                     // 1: matrix operands rounded to bf16 (fp32 accumulation); 2: operands split into three bf16 (fp32-equivalent)
   int off32;                    // every row of xb / y starts below 2^32 bytes: lane offsets fit the 32-bit VGPR offset of scalar-base loads
+  uint32_t* Hm;                 // compact save (nesvor_mlp_t.compact_save): one word per (group, lane), bit 16 l + 4 b + r = [h_l > 0]
   float* dx_absmax;             // bwd, optional: device scalar raised (atomic max) to max |dxb| - the consumer of dxb (the hash-grid
                                 // backward) scales its fixed-point sums by it instead of reading dxb an extra time
 };
@@ -435,6 +436,57 @@ __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, co
   }
 }
 
+// The same layer product with the operand roles exchanged: D = X . W^T, rows = the 16 samples of the group, columns = the
+// output features of a block - lane (feature j, sample quad q) ends up with feature 16 ob + j of samples 4q .. 4q+3, which is
+// the B-operand layout of the weight-gradient products.  x: the group's input in the chain layout (lane (sample j, q):
+// features 16 kb + 4q + r), img: the FORWARD image of the layer (its fragments serve as B operands unchanged: both operand
+// layouts index the lane by the non-contracted dimension).  Same six terms in the same order as apply_layer.
+template <int KB, int OB>
+__device__ __forceinline__ void apply_layer_g1_T(const float* __restrict__ img, const f32x4 (&x)[KB], f32x4 (&y)[OB], int lane) {
+  const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
+  constexpr int plane = OB * KB * 256;
+  auto load_w = [&](int ob, int kb) __attribute__((always_inline)) {
+    const __bf16* pa = img16 + ((ob * KB + kb) * 64 + lane) * 4;
+    Split3 w;
+    w.hi = *reinterpret_cast<const s16x4*>(pa);
+    w.mid = *reinterpret_cast<const s16x4*>(pa + plane);
+    w.lo = *reinterpret_cast<const s16x4*>(pa + 2 * plane);
+    return w;
+  };
+#pragma unroll
+  for (int kb = 0; kb + 1 < KB; kb += 2) {
+    const Split3 p0 = split3(x[kb]), p1 = split3(x[kb + 1]);
+    const bf16x8 xh = join8(p0.hi, p1.hi), xm = join8(p0.mid, p1.mid), xl = join8(p0.lo, p1.lo);
+#pragma unroll
+    for (int ob = 0; ob < OB; ob += 2) {  // two independent accumulators at a time (a dependent MFMA issues later)
+      constexpr int kPair = OB >= 2 ? 2 : 1;
+      bf16x8 wh[kPair], wm[kPair], wl[kPair];
+#pragma unroll
+      for (int o = 0; o < kPair; ++o) {
+        const Split3 w0 = load_w(ob + o, kb), w1 = load_w(ob + o, kb + 1);
+        wh[o] = join8(w0.hi, w1.hi); wm[o] = join8(w0.mid, w1.mid); wl[o] = join8(w0.lo, w1.lo);
+      }
+#define NESVOR_TERM(XP, WP) _Pragma("unroll") for (int o = 0; o < kPair; ++o) y[ob + o] = mfma32_bf16(XP, WP[o], y[ob + o]);
+      NESVOR_TERM(xh, wl) NESVOR_TERM(xl, wh) NESVOR_TERM(xm, wm) NESVOR_TERM(xh, wm) NESVOR_TERM(xm, wh) NESVOR_TERM(xh, wh)
+#undef NESVOR_TERM
+    }
+  }
+  if constexpr (KB % 2 == 1) {
+    const Split3 px = split3(x[KB - 1]);
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) {
+      const Split3 w = load_w(ob, KB - 1);
+      f32x4 c = y[ob];
+      c = mfma16_bf16(px.hi, w.lo, c);
+      c = mfma16_bf16(px.lo, w.hi, c);
+      c = mfma16_bf16(px.mid, w.mid, c);
+      c = mfma16_bf16(px.hi, w.mid, c);
+      c = mfma16_bf16(px.mid, w.hi, c);
+      y[ob] = mfma16_bf16(px.hi, w.hi, c);
+    }
+  }
+}
+
 __device__ __forceinline__ float fetch_input(const MlpArgs& a, int kk, int64_t n) {
   if (kk < a.k_a) return a.xa[(size_t)(n / a.S) * a.k_a + kk];
   const int kb_ = kk - a.k_a;
@@ -561,7 +613,9 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 // held back to the end of the tile, and the prefetch is awaited right before them: the wait covers loads that are one
 // whole tile of MFMAs old, the stores drain under the next tile's MFMAs.
 // Requires the fast input path, whole tiles (n_groups % (4 kG) == 0) and NH = 1 or 2 hidden layers.
-template <int KB1, int NH, bool X6, bool SAVE>
+// COMPACT (with SAVE): one bit per hidden unit and sample for every layer, values only for the layers after the first
+// (nesvor_mlp_t.compact_save) - the launch then writes 0.47 GB instead of 0.74 GB at N = 2^20.
+template <int KB1, int NH, bool X6, bool SAVE, bool COMPACT = false>
 __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_pf_kernel(const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int k_in = a.k_a + a.k_b;
@@ -633,6 +687,9 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_pf_kern
     // the last tile of a workgroup re-requests a valid tile (no control flow between an issue and its settle)
     issue_x(min(tile + (int64_t)gridDim.x, n_tiles - 1), xr);
     f32x4 h[NH][kG][kHB];
+    uint32_t hmask[kG];
+#pragma unroll
+    for (int g = 0; g < kG; ++g) hmask[g] = 0u;
 #pragma unroll
     for (int l = 0; l < NH; ++l) {
 #pragma unroll
@@ -648,7 +705,11 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_pf_kern
 #pragma unroll
         for (int ob = 0; ob < kHB; ++ob)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[l][g][ob][r] = relu_f(h[l][g][ob][r]);
+          for (int r = 0; r < 4; ++r) {
+            h[l][g][ob][r] = relu_f(h[l][g][ob][r]);
+            // relu_f leaves +0 or a positive pattern: min(bits, 1) = [h > 0]; v_min_u32 + v_lshl_or_b32 per value
+            if constexpr (SAVE && COMPACT) hmask[g] |= min(__float_as_uint(h[l][g][ob][r]), 1u) << (16 * l + 4 * ob + r);
+          }
     }
     f32x4 o[kG][1];
     {
@@ -660,12 +721,16 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_pf_kern
     settle_x(xr);
     if constexpr (SAVE) {
 #pragma unroll
-      for (int l = 0; l < NH; ++l)
+      for (int l = COMPACT ? 1 : 0; l < NH; ++l)
 #pragma unroll
         for (int g = 0; g < kG; ++g)
 #pragma unroll
           for (int ob = 0; ob < kHB; ++ob)
             __builtin_nontemporal_store(h[l][g][ob], reinterpret_cast<f32x4*>(a.H[l] + (((size_t)hgroup(g0 + g) * kHB + ob) * 64 + lane) * 4));
+      if constexpr (COMPACT) {
+#pragma unroll
+        for (int g = 0; g < kG; ++g) __builtin_nontemporal_store(hmask[g], a.Hm + (size_t)hgroup(g0 + g) * 64 + lane);
+      }
     }
 #pragma unroll
     for (int g = 0; g < kG; ++g) {
@@ -1320,8 +1385,11 @@ __device__ __forceinline__ void accumulate_dw_split(const float* tiles, const f3
 #define NESVOR_MLP_SPLIT_DW 1
 #endif
 constexpr bool kSplitDw = NESVOR_MLP_SPLIT_DW != 0;  // 0: the dW products of the split mode stay on v_mfma_f32_16x16x4_f32 (A/B builds)
-template <int KB1, int NH, bool BF16 = false, bool X6 = false>
+// COMPACT (nesvor_mlp_t.compact_save): the chain waves gate with the saved sign bits (one word per lane and group instead of
+// NH x 4 fragments), the dW waves recompute the first hidden layer from the network input.
+template <int KB1, int NH, bool BF16 = false, bool X6 = false, bool COMPACT = false>
 __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
+  static_assert(!COMPACT || (X6 && !BF16), "compact save: split-operand mode only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int k_in = a.k_a + a.k_b;
   constexpr int kT = 1 + NH * kHB;                      // tiles per group: dY, then dpre of layers NH-1 .. 0
@@ -1329,10 +1397,16 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   float* imgo = lds;                                    // W_out^T : ib = 4, kb = 1
   float* imgh = imgo + kHB * 1 * kBlk;                  // W_l^T, l = 1..NH-1
   float* img1 = imgh + (NH - 1) * kHB * kHB * kBlk;     // W_1^T : ib = KB1, kb = 4
-  float* tiles = img1 + KB1 * kHB * kBlk;               // [pair][buffer][kT] tiles; reused as the flush buffer
+  float* imgf1 = img1 + KB1 * kHB * kBlk;               // COMPACT: forward image of W_1 (ob = 4, kb = KB1) and its bias
+  float* bias0 = imgf1 + (COMPACT ? kHB * KB1 * kBlk : 0);
+  float* tiles = bias0 + (COMPACT ? kWidth : 0);        // [pair][buffer][kT] tiles; reused as the flush buffer
   build_image_T<BF16, X6>(imgo, a.W[NH], a.out_dim, kWidth, kHB, 1);
   for (int l = 1; l < NH; ++l) build_image_T<BF16, X6>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, kHB, kHB);
   build_image_T<BF16, X6>(img1, a.W[0], kWidth, k_in, KB1, kHB);
+  if constexpr (COMPACT) {
+    build_image<false, X6>(imgf1, a.W[0], kWidth, k_in, kHB, KB1);
+    for (int e = threadIdx.x; e < kWidth; e += blockDim.x) bias0[e] = a.b[0][e];
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1389,51 +1463,63 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     uint32_t yoff[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) yoff[r] = (uint32_t)(((int64_t)min(4 * q + r, a.out_dim - 1) * a.N + j) * 4);
-    auto issue_group = [&](int64_t gi, float (&gy)[4], RawH (&hs)[NH][kHB]) __attribute__((always_inline)) {
+    auto issue_group = [&](int64_t gi, float (&gy)[4], RawH (&hs)[NH][kHB], float& mk) __attribute__((always_inline)) {
       // dY rows 4q .. 4q+3 of sample j: group base in SGPRs, the lane's part (row * N + j, below 2^30 floats: off32) in one VGPR each
       const char* ybase = reinterpret_cast<const char*>(a.y) + sgroup(gi) * 64;
 #pragma unroll
       for (int r = 0; r < 4; ++r) issue_load_b32_s<0>(gy[r], ybase, yoff[r]);
-      const uint32_t voff = (uint32_t)lane * (4u * kHBytes);
+      if constexpr (COMPACT) {
+        issue_load_b32_s<0>(mk, reinterpret_cast<const char*>(a.Hm) + hgroup(gi) * 256, (uint32_t)lane * 4u);
+      } else {
+        const uint32_t voff = (uint32_t)lane * (4u * kHBytes);
 #pragma unroll
-      for (int l = 0; l < NH; ++l) {
-        const char* base = reinterpret_cast<const char*>(a.H[l]) + hgroup(gi) * (int64_t)(kHB * 256 * kHBytes);  // wave-uniform
-        static_for<kHB>([&](auto IB) {
-          constexpr int ib = decltype(IB)::value;
-          if constexpr (BF16) issue_load_b64_s<ib * 256 * kHBytes>(hs[l][ib], base, voff);
-          else issue_load_b128_s<ib * 256 * kHBytes>(hs[l][ib], base, voff);
-        });
+        for (int l = 0; l < NH; ++l) {
+          const char* base = reinterpret_cast<const char*>(a.H[l]) + hgroup(gi) * (int64_t)(kHB * 256 * kHBytes);  // wave-uniform
+          static_for<kHB>([&](auto IB) {
+            constexpr int ib = decltype(IB)::value;
+            if constexpr (BF16) issue_load_b64_s<ib * 256 * kHBytes>(hs[l][ib], base, voff);
+            else issue_load_b128_s<ib * 256 * kHBytes>(hs[l][ib], base, voff);
+          });
+        }
       }
     };
-    auto settle_group = [&](float (&gy)[4], RawH (&hs)[NH][kHB]) __attribute__((always_inline)) {
+    auto settle_group = [&](float (&gy)[4], RawH (&hs)[NH][kHB], float& mk) __attribute__((always_inline)) {
       await_loads();
 #pragma unroll
       for (int r = 0; r < 4; ++r) pin(gy[r]);
+      if constexpr (COMPACT) {
+        pin(mk);
+      } else {
 #pragma unroll
-      for (int l = 0; l < NH; ++l)
+        for (int l = 0; l < NH; ++l)
 #pragma unroll
-        for (int ib = 0; ib < kHB; ++ib) pin(hs[l][ib]);
+          for (int ib = 0; ib < kHB; ++ib) pin(hs[l][ib]);
+      }
     };
     float dx_mx = 0.f;
     // one iteration: the group whose inputs sit in (gy_c, hs_c); the next group's inputs are requested into (gy_n, hs_n)
-    auto chain_iter = [&](int it, float (&gy_c)[4], RawH (&hs_c)[NH][kHB], float (&gy_n)[4], RawH (&hs_n)[NH][kHB]) __attribute__((always_inline)) {
+    auto chain_iter = [&](int it, float (&gy_c)[4], RawH (&hs_c)[NH][kHB], float& mk_c, float (&gy_n)[4], RawH (&hs_n)[NH][kHB],
+                          float& mk_n) __attribute__((always_inline)) {
       const int64_t gi = g_first + (int64_t)it * gstride;
       if (it < n_it && gi < n_groups) {
         f32x4 go;
 #pragma unroll
         for (int r = 0; r < 4; ++r) go[r] = 4 * q + r < a.out_dim ? gy_c[r] : 0.f;
         f32x4 hs[NH][kHB];
+        const uint32_t mbits = __float_as_uint(mk_c);  // COMPACT: bit 16 l + 4 ib + r = [h_l > 0] of this lane's fragment elements
+        if constexpr (!COMPACT) {
 #pragma unroll
-        for (int l = 0; l < NH; ++l)
+          for (int l = 0; l < NH; ++l)
 #pragma unroll
-          for (int ib = 0; ib < kHB; ++ib) {
-            if constexpr (BF16) hs[l][ib] = unpack_bf16(hs_c[l][ib]);
-            else hs[l][ib] = hs_c[l][ib];
-          }
+            for (int ib = 0; ib < kHB; ++ib) {
+              if constexpr (BF16) hs[l][ib] = unpack_bf16(hs_c[l][ib]);
+              else hs[l][ib] = hs_c[l][ib];
+            }
+        }
         // next group's inputs, one whole group of MFMAs ahead of their settle_group().  No control flow may merge
         // between an issue and its settle (a register copy at the merge would read the in-flight registers), so the
         // last iteration simply re-requests its own group
-        issue_group(min(gi + gstride, n_groups - 1), gy_n, hs_n);
+        issue_group(min(gi + gstride, n_groups - 1), gy_n, hs_n, mk_n);
         float* buf = my_tiles + (it & 1) * kT * kTileFloats;
         stage_tile(buf, go, j, q);
         dbc_o[0] += go;
@@ -1447,7 +1533,14 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
           for (int ib = 0; ib < kHB; ++ib) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d[ib][r] = hs[l][ib][r] > 0.f ? d[ib][r] : 0.f;
+            for (int r = 0; r < 4; ++r) {
+              if constexpr (COMPACT) {  // v_bfe_i32 (0 or all ones) + v_and_b32
+                const int32_t keep = (int32_t)(mbits << (31 - (16 * l + 4 * ib + r))) >> 31;
+                d[ib][r] = __uint_as_float(__float_as_uint(d[ib][r]) & (uint32_t)keep);
+              } else {
+                d[ib][r] = hs[l][ib][r] > 0.f ? d[ib][r] : 0.f;
+              }
+            }
             stage_tile(buf + (1 + (NH - 1 - l) * kHB + ib) * kTileFloats, d[ib], j, q);
             if (l > 0) dbc_h[l > 0 ? l - 1 : 0][ib] += d[ib];
             else dbc_1[ib] += d[ib];
@@ -1467,10 +1560,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             if (a.dx_absmax != nullptr) track_absmax<KB1>(a, dx, dx_mx);
             // drain the prefetch BEFORE the stores below: loads and stores share vmcnt, and the wait would otherwise
             // also cover the latency of these stores
-            settle_group(gy_n, hs_n);
+            settle_group(gy_n, hs_n, mk_n);
             store_dx_fast<KB1>(a, gi, j, q, dx);
           } else {
-            settle_group(gy_n, hs_n);
+            settle_group(gy_n, hs_n, mk_n);
           }
         }
       }
@@ -1485,10 +1578,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         if constexpr (BF16) { hs_a[l][ib] = f32x2{0.f, 0.f}; hs_b[l][ib] = f32x2{0.f, 0.f}; }
         else { hs_a[l][ib] = f32x4{0.f, 0.f, 0.f, 0.f}; hs_b[l][ib] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       }
-    if (g_first < n_groups) { issue_group(g_first, gy_a, hs_a); settle_group(gy_a, hs_a); }
+    float mk_a = 0.f, mk_b = 0.f;
+    if (g_first < n_groups) { issue_group(g_first, gy_a, hs_a, mk_a); settle_group(gy_a, hs_a, mk_a); }
     for (int it = 0; it <= n_it; it += 2) {
-      chain_iter(it, gy_a, hs_a, gy_b, hs_b);
-      if (it + 1 <= n_it) chain_iter(it + 1, gy_b, hs_b, gy_a, hs_a);
+      chain_iter(it, gy_a, hs_a, mk_a, gy_b, hs_b, mk_b);
+      if (it + 1 <= n_it) chain_iter(it + 1, gy_b, hs_b, mk_b, gy_a, hs_a, mk_a);
     }
     if (a.dx_absmax != nullptr) publish_absmax(a, dx_mx);
   } else {
@@ -1521,11 +1615,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     // awaited with vmcnt(activation loads) - loads retire in order, the younger ones may stay in flight.  (Issue and settle of
     // a register always sit in the same straight-line region: at a control-flow merge the compiler may copy registers, and a
     // copy of a register with a load in flight reads stale data.)
+    constexpr int kL0 = COMPACT ? 1 : 0;  // first hidden layer whose values are streamed from HBM (COMPACT: layer 0 is recomputed)
     auto issue_h = [&](int64_t gi, float (&hraw)[NH][kHB][4]) __attribute__((always_inline)) {
       // element (sample 4q + t, feature j of block ib) of the fragment layout [block][lane = (f >> 2) * 16 + sample][f & 3]
       const uint32_t voff = (uint32_t)((((j >> 2) * 16 + 4 * q) * 4 + (j & 3)) * kHBytes);
 #pragma unroll
-      for (int l = 0; l < NH; ++l) {
+      for (int l = kL0; l < NH; ++l) {
         const char* base = reinterpret_cast<const char*>(a.H[l]) + hgroup(gi) * (int64_t)(kHB * 256 * kHBytes);  // wave-uniform
         static_for<kHB>([&](auto IB) {
           static_for<4>([&](auto T) {
@@ -1536,7 +1631,33 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         });
       }
     };
-    constexpr int kHLoads = NH * kHB * 4;  // activation loads per group
+    constexpr int kHLoads = (NH - kL0) * kHB * 4;  // activation loads per group
+    // COMPACT: the group's input once more in the chain layout (lane (sample j, q): features 16 kb + 4q + r), the A operand of
+    // the recomputation of layer 0.  One dword per element as in the forward; base (pixel features / matrix rows) chosen by
+    // the block type in SGPRs, lane offsets precomputed.  ONE register set: an iteration first consumes the set (requested by
+    // the previous iteration and awaited at its end), then requests the next group's.
+    // lane offsets from ONE register per source (the kernel sits at the 256-register limit): pixel features at
+    // (16 kb + 4q + r) floats; matrix rows at ((b_row0 + 16 (kb - ka) + 4q + r) N + j) floats, the wave-uniform part added per
+    // load and the result clamped to the last valid row (a row beyond k_b reads something valid and is zeroed below)
+    const uint32_t xc_offa = (uint32_t)(4 * q * 4);
+    const uint32_t xc_offb = (uint32_t)(((int64_t)(a.b_row0 + 4 * q) * a.N + j) * 4);
+    const uint32_t xc_lim = (uint32_t)(((int64_t)(a.b_row0 + a.k_b - 1) * a.N + j) * 4);  // the lane's sample in the last valid row (offsets are relative to the group)
+    auto issue_xc = [&](int64_t gi, float (&xc)[KB1][4]) __attribute__((always_inline)) {
+      const int64_t pixel = a.spg_shift >= 0 ? (gi >> a.spg_shift) : gi / (a.S >> 4);
+      const char* abase = a.xa != nullptr ? reinterpret_cast<const char*>(a.xa) + pixel * (int64_t)(a.k_a * 4) : reinterpret_cast<const char*>(a.xb);
+      const char* bbase = reinterpret_cast<const char*>(a.xb) + sgroup(gi) * 64;
+      static_for<KB1>([&](auto KB) {
+        constexpr int kb = decltype(KB)::value;
+        const bool is_a = kb < ka_blocks;  // wave-uniform
+        const char* base = is_a ? abase : bbase;
+        static_for<4>([&](auto R) {
+          constexpr int r = decltype(R)::value;
+          const uint32_t ub = (uint32_t)((int64_t)(16 * (kb - ka_blocks) + r) * a.N * 4);  // scalar
+          const uint32_t off = is_a ? xc_offa + (uint32_t)((16 * kb + r) * 4) : min(xc_offb + ub, xc_lim);
+          issue_load_b32_s<0>(xc[kb][r], base, off);
+        });
+      });
+    };
     auto issue_x = [&](int64_t gi, f32x4 (&xraw)[KB1], float (&xsraw)[KB1]) __attribute__((always_inline)) {
       // both candidate sources of every input block are requested (no branch between issue and settle); the block
       // type picks one after the loads have landed
@@ -1553,7 +1674,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(pending)::value) : "memory");
 #pragma unroll
-      for (int l = 0; l < NH; ++l)
+      for (int l = kL0; l < NH; ++l)
 #pragma unroll
         for (int ib = 0; ib < kHB; ++ib)
 #pragma unroll
@@ -1567,19 +1688,41 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     };
     f32x4 xraw[KB1];
     float xsraw[KB1];
+    float xcr[KB1][4];
     // one iteration: the group (one behind the chain wave) whose saved activations sit in hraw_c; the next group's go into hraw_n
     auto dw_iter = [&](int it, float (&hraw_c)[NH][kHB][4], float (&hraw_n)[NH][kHB][4]) __attribute__((always_inline)) {
       const int64_t gi = g_first + (int64_t)(it - 1) * gstride;
       if (it > 0 && gi < n_groups) {
         f32x4 hb[NH][kHB];
 #pragma unroll
-        for (int l = 0; l < NH; ++l)
+        for (int l = kL0; l < NH; ++l)
 #pragma unroll
           for (int ib = 0; ib < kHB; ++ib)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
               hb[l][ib][t] = BF16 ? __uint_as_float(__float_as_uint(hraw_c[l][ib][t]) << 16) : hraw_c[l][ib][t];
         const int64_t gnext = min(gi + gstride, n_groups - 1);  // (the last iteration re-requests a valid group: no control flow between an issue and its settle)
+        if constexpr (COMPACT) {
+          // h_0 = relu(W_1 x + b_1) of this group, straight into the B-operand layout (apply_layer_g1_T); the input registers
+          // are free again afterwards and take the next group's request
+          f32x4 xc[KB1];
+#pragma unroll
+          for (int kb = 0; kb < KB1; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              xc[kb][r] = (kb < ka_blocks || 16 * (kb - ka_blocks) + 4 * q + r < a.k_b) ? xcr[kb][r] : 0.f;
+#pragma unroll
+          for (int ob = 0; ob < kHB; ++ob) {
+            const float b0 = bias0[16 * ob + j];
+            hb[0][ob] = f32x4{b0, b0, b0, b0};
+          }
+          apply_layer_g1_T<KB1, kHB>(imgf1, xc, hb[0], lane);
+#pragma unroll
+          for (int ob = 0; ob < kHB; ++ob)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) hb[0][ob][t] = relu_f(hb[0][ob][t]);
+          issue_xc(gnext, xcr);
+        }
         issue_x(gi, xraw, xsraw);
         issue_h(gnext, hraw_n);
         const float* buf = my_tiles + ((it - 1) & 1) * kT * kTileFloats;
@@ -1625,6 +1768,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           }
         }
         settle_h(hraw_n, std::integral_constant<int, 0>{});
+        if constexpr (COMPACT) {
+#pragma unroll
+          for (int kb = 0; kb < KB1; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pin(xcr[kb][r]);
+        }
       }
       pair_sync(it);
     };
@@ -1636,11 +1785,22 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) { hraw_a[l][ib][t] = 0.f; hraw_b[l][ib][t] = 0.f; }
 #pragma unroll
-    for (int kb = 0; kb < KB1; ++kb) { xraw[kb] = f32x4{0.f, 0.f, 0.f, 0.f}; xsraw[kb] = 0.f; }
+    for (int kb = 0; kb < KB1; ++kb) {
+      xraw[kb] = f32x4{0.f, 0.f, 0.f, 0.f}; xsraw[kb] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xcr[kb][r] = 0.f;
+    }
     // iteration it works on group it - 1: its activations must sit in the set that iteration reads (odd iterations read set b)
     if (g_first < n_groups) {
       issue_h(g_first, hraw_b);
+      if constexpr (COMPACT) issue_xc(g_first, xcr);
       settle_h(hraw_b, std::integral_constant<int, 0>{});
+      if constexpr (COMPACT) {
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pin(xcr[kb][r]);
+      }
     }
     for (int it = 0; it <= n_it; it += 2) {
       dw_iter(it, hraw_a, hraw_b);
@@ -1662,8 +1822,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   flush_dw_ws<1, kHB>(red, acc_o, dbc_o, out + poff, a.out_dim, kWidth, slot, chain);
 }
 
-size_t ws_bwd_lds_bytes(int n_hidden, int kb1, int blk = 256) {
+size_t ws_bwd_lds_bytes(int n_hidden, int kb1, int blk = 256, bool compact = false) {
   size_t img = (size_t)kHB * blk + (size_t)(n_hidden - 1) * kHB * kHB * blk + (size_t)kb1 * kHB * blk;
+  if (compact) img += (size_t)kb1 * kHB * blk + kWidth;  // forward image of the first layer + its bias
   size_t tiles = 4 * 2 * (size_t)(1 + n_hidden * kHB) * kTileFloats;
   if (tiles < 4 * (size_t)kHB * 256) tiles = 4 * (size_t)kHB * 256;
   return sizeof(float) * (img + tiles);
@@ -1738,7 +1899,24 @@ int fill_args(MlpArgs* a, const nesvor_mlp_t* d, int64_t N) {
   return 0;
 }
 
+// Which configurations can save compactly: those the pipelined forward AND the wave-specialised backward both take in the
+// split-operand mode, with at most two input blocks (the recomputation's registers).
+bool compact_ok(const MlpArgs& a, const nesvor_mlp_t* net, int64_t N) {
+  static const bool use_pf = []() { const char* e = getenv("NESVOR_MLP_FWD_PF"); return e == nullptr || atoi(e) != 0; }();
+  static const bool use_ws = []() { const char* e = getenv("NESVOR_MLP_BWD_WS"); return e == nullptr || atoi(e) != 0; }();
+  static const bool on = []() { const char* e = getenv("NESVOR_MLP_COMPACT"); return e == nullptr || atoi(e) != 0; }();
+  const int kb1 = (net->k_a + net->k_b + 15) / 16;
+  return on && use_pf && use_ws && a.bf16 == 2 && a.fast && a.off32 && net->n_hidden <= 2 && kb1 <= 2 && ((N >> 4) % (4 * kG)) == 0;
+}
+
 }  // namespace
+
+extern "C" int nesvor_mlp_compact_save_ok(const nesvor_mlp_t* net, int64_t N) {
+  if (net == nullptr || N <= 0) return 0;
+  MlpArgs a{};
+  if (fill_args(&a, net, N)) return 0;
+  return compact_ok(a, net, N) ? 1 : 0;
+}
 
 extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, const float* xb, float* y,
                                   float* const* saved_hidden, int64_t N, void* stream) {
@@ -1758,6 +1936,18 @@ extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, cons
   // software-pipelined kernel: fp32 data (both evaluation modes), fast inputs, whole tiles, one or two hidden layers
   static const bool use_pf = []() { const char* e = getenv("NESVOR_MLP_FWD_PF"); return e == nullptr || atoi(e) != 0; }();
   bool save_all = saved_hidden != nullptr, save_none = saved_hidden == nullptr;
+  const bool compact = net->compact_save != 0 && save_all;
+  if (compact) {
+    if (!compact_ok(a, net, N)) return (int)hipErrorInvalidValue;  // (the caller asks nesvor_mlp_compact_save_ok first)
+    a.Hm = reinterpret_cast<uint32_t*>(saved_hidden[0]);
+    a.H[0] = nullptr;
+    const size_t lds = fwd_lds_bytes(a.n_linear, kb1, 384);
+    if (net->n_hidden == 1)
+      return launch_kb(mlp_fwd_pf_kernel<1, 1, true, true, true>, mlp_fwd_pf_kernel<2, 1, true, true, true>, mlp_fwd_pf_kernel<2, 1, true, true, true>,
+                       mlp_fwd_pf_kernel<2, 1, true, true, true>, kb1, grid, lds, (hipStream_t)stream, a);
+    return launch_kb(mlp_fwd_pf_kernel<1, 2, true, true, true>, mlp_fwd_pf_kernel<2, 2, true, true, true>, mlp_fwd_pf_kernel<2, 2, true, true, true>,
+                     mlp_fwd_pf_kernel<2, 2, true, true, true>, kb1, grid, lds, (hipStream_t)stream, a);
+  }
   if (use_pf && a.bf16 != 1 && a.fast && net->n_hidden <= 2 && ((N >> 4) % (4 * kG)) == 0 && (save_all || save_none)) {
     const bool x6 = a.bf16 == 2;
     const size_t lds = fwd_lds_bytes(a.n_linear, kb1, x6 ? 384 : 256);
@@ -1797,6 +1987,8 @@ extern "C" int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float*
   a.dx_absmax = dxb != nullptr ? dxb_absmax : nullptr;
   if (saved_hidden == nullptr || dpre_scratch == nullptr || dw_partial == nullptr || n_partial < 1) return (int)hipErrorInvalidValue;
   const bool split = a.bf16 == 2;  // fp32 data everywhere; only the MFMA sites differ
+  const bool compact = net->compact_save != 0;
+  if (compact && (!compact_ok(a, net, N) || dpre_scratch[0] != nullptr)) return (int)hipErrorInvalidValue;
   if (split) a.bf16 = 0;
   a.xa = xa; a.xb = xb; a.y = const_cast<float*>(dy); a.dxa = dxa; a.dxb = dxb; a.dW_partial = dw_partial;
   for (int l = 0; l < kMaxLayers; ++l) {
@@ -1805,6 +1997,16 @@ extern "C" int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float*
   }
   const int kb1 = (net->k_a + net->k_b + 15) / 16;
   if (a.dxa_group && !(a.fast && net->n_hidden <= 2 && dpre_scratch[0] == nullptr)) return (int)hipErrorInvalidValue;
+  if (compact) {
+    a.Hm = reinterpret_cast<uint32_t*>(saved_hidden[0]);
+    a.H[0] = nullptr;
+    const size_t lds_c = ws_bwd_lds_bytes(net->n_hidden, kb1, 384, true);
+    if (net->n_hidden == 1)
+      return launch_kb(mlp_bwd_ws_kernel<1, 1, false, true, true>, mlp_bwd_ws_kernel<2, 1, false, true, true>, mlp_bwd_ws_kernel<2, 1, false, true, true>,
+                       mlp_bwd_ws_kernel<2, 1, false, true, true>, kb1, dim3((unsigned)n_partial), lds_c, (hipStream_t)stream, a, 512);
+    return launch_kb(mlp_bwd_ws_kernel<1, 2, false, true, true>, mlp_bwd_ws_kernel<2, 2, false, true, true>, mlp_bwd_ws_kernel<2, 2, false, true, true>,
+                     mlp_bwd_ws_kernel<2, 2, false, true, true>, kb1, dim3((unsigned)n_partial), lds_c, (hipStream_t)stream, a, 512);
+  }
   if (net->n_hidden <= 2 && dpre_scratch[0] == nullptr) {
     // fused dX + dW + db (the caller signals it by passing no dpre scratch); grid = n_partial workgroups
     static const bool use_ws = []() { const char* e = getenv("NESVOR_MLP_BWD_WS"); return e == nullptr || atoi(e) != 0; }();

@@ -230,22 +230,26 @@ class DirectStep:
         d.x, d.u, d.pe, d.z, d.dz, d.dpe = new("x", B, S, 3), new("u", N, 3), new("pe", E, N), new("z", zr, N), new("dz", zr, N), new("dpe", E, N)
         d.loss_pix, d.pix = new("loss_pix", B, 3), new("pix", 2, B)
         d.partial = new("partial", 256, largest)
-        for i in range(len(self.d_net.weights) - 1):
-            d.saved_d[i] = new(f"saved_d{i}", n_pad * 64)
+        def saved_buffers(net_desc, slots, tag, n_hidden):
+            # saved activations of one network; compact save where the kernels allow it (mlp.saved_sizes: sign bits in slot 0)
+            sizes = mlp_mod.saved_sizes(net_desc, N, n_hidden)
+            net_desc.compact_save = int(n_hidden > 0 and sizes[0] != n_pad * 64)
+            for i, n_el in enumerate(sizes):
+                slots[i] = new(f"{tag}{i}", n_el)
+
+        saved_buffers(d.density, d.saved_d, "saved_d", len(self.d_net.weights) - 1)
         if self.ks:
             d.se = new("se", B, self.ks)
         rows = N // 16 if (N % 16 == 0 and S % 16 == 0 and self.ks % 16 == 0) else N
         if self.has_lv:
             d.log_var, d.dlv = new("log_var", N), new("dlv", N)
-            for i in range(len(self.s_net.weights) - 1):
-                d.saved_s[i] = new(f"saved_s{i}", n_pad * 64)
+            saved_buffers(d.sigma, d.saved_s, "saved_s", len(self.s_net.weights) - 1)
             if self.ks:
                 d.dxa = new("dxa", rows, self.ks)
         if self.has_b:
             d.log_bias, d.dlb, d.dpe_b = new("log_bias", N), new("dlb", N), new("dpe_b", self.kb_bias, N)
             d.lb_mean, d.mean_scratch = new("lb_mean", 1), new("mean_scratch", 256)
-            for i in range(len(self.b_net.weights) - 1):
-                d.saved_b[i] = new(f"saved_b{i}", n_pad * 64)
+            saved_buffers(d.bias_net, d.saved_b, "saved_b", len(self.b_net.weights) - 1)
             if self.ks:
                 d.dxa_b = new("dxa_b", rows, self.ks)
         if self.opt_T:

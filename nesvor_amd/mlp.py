@@ -188,6 +188,31 @@ def _desc(weights, biases, k_a, k_b, b_row0, S, bf16=False):
     return d
 
 
+def compact_save(d, N: int) -> bool:
+    """Whether a training forward of descriptor ``d`` over N samples saves compactly (``nesvor_mlp_t.compact_save``): one
+    sign bit per hidden unit and sample (16 N bytes in ``saved[0]``) plus the values of the hidden layers after the first;
+    the backward recomputes the first hidden layer.  Host-side logic of the library (no device work)."""
+    return FUSED_BACKWARD and bool(_lib.load().nesvor_mlp_compact_save_ok(ctypes.byref(d), N))
+
+
+def dims_desc(n_hidden: int, out_dim: int, k_a: int, k_b: int, b_row0: int, S: int, bf16=False):
+    """A descriptor without parameter pointers (shape queries: ``saved_sizes``)."""
+    d = _lib.MlpT()
+    d.bf16_operands = operand_mode(bf16)
+    d.width, d.n_hidden, d.out_dim = 64, n_hidden, out_dim
+    d.k_a, d.k_b, d.b_row0, d.samples_per_pixel = k_a, k_b, b_row0, S
+    return d
+
+
+def saved_sizes(d, N: int, n_hidden: int):
+    """Element counts of the ``saved`` buffers of one training forward (fp32 elements; bf16 elements in the bf16 mode)."""
+    n_pad = (N + 15) // 16 * 16
+    sizes = [n_pad * 64] * n_hidden
+    if n_hidden and compact_save(d, N):
+        sizes[0] = n_pad * 4  # one uint32 per (16-sample group, lane)
+    return sizes
+
+
 def _ptr_array(tensors):
     arr = (ctypes.c_void_p * 4)()
     for i, t in enumerate(tensors):
@@ -209,10 +234,14 @@ def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False)
     if weights[0].shape[1] != k_a + k_b:
         raise RuntimeError("first layer width does not match k_a + k_b")
     d = _desc(weights, biases, k_a, k_b, b_row0, S, bf16)
-    n_pad = (N + 15) // 16 * 16
-    # saved hidden activations, MFMA fragment layout; bf16 mode stores them as bf16 (they are only used as bf16 operands)
+    # saved hidden activations, MFMA fragment layout; bf16 mode stores them as bf16 (they are only used as bf16 operands);
+    # compact save (split-operand mode, whole tiles): saved[0] holds sign bits only
     sdt = torch.bfloat16 if operand_mode(bf16) == BF16 else torch.float32
-    saved = [torch.empty(n_pad * 64, dtype=sdt, device=xb.device) for _ in range(len(weights) - 1)] if need_saved else []
+    saved = []
+    if need_saved:
+        sizes = saved_sizes(d, N, len(weights) - 1)
+        d.compact_save = int(sizes[0] != (N + 15) // 16 * 16 * 64)
+        saved = [torch.empty(n, dtype=sdt, device=xb.device) for n in sizes]
     y = torch.empty((d.out_dim, N), dtype=torch.float32, device=xb.device)
     with torch.cuda.device(xb.device), _lib.kernel_timer.span("mlp_fwd"):
         err = _lib.load().nesvor_mlp_forward(
@@ -231,6 +260,7 @@ def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_d
     N = xb.shape[1]
     k_a = 0 if xa is None else xa.shape[1]
     d = _desc(weights, biases, k_a, k_b, b_row0, S, bf16)
+    d.compact_save = int(saved[0].numel() == (N + 15) // 16 * 16 * 4)  # (the forward that wrote `saved` decided)
     dev = xb.device
     fused = (n_layers - 1) <= 2 and FUSED_BACKWARD
     # fused dX+dW+db kernel needs no dpre scratch (signalled by NULL entries); the two-kernel path does

@@ -398,7 +398,10 @@ def _mlp_fake(xa, xb, weights, biases, b_row0, k_b, S, operands, save):
     n = xb.shape[1]
     n_pad = (n + 15) // 16 * 16
     sdt = torch.bfloat16 if operands == _mlp.BF16 else torch.float32
-    saved = [xb.new_empty(n_pad * 64, dtype=sdt) for _ in range(len(weights) - 1)] if save else []
+    saved = []
+    if save:
+        d = _mlp.dims_desc(len(weights) - 1, weights[-1].shape[0], 0 if xa is None else xa.shape[1], k_b, b_row0, S, _operands(operands))
+        saved = [xb.new_empty(m, dtype=sdt) for m in _mlp.saved_sizes(d, n, len(weights) - 1)]
     return xb.new_empty((weights[-1].shape[0], n)), saved
 
 

@@ -1116,6 +1116,56 @@ def test_fused_mlp_split_operands_keep_fp32_accuracy(device, k_a, k_b, b_row0, r
             assert float((a_ + b_ - c_).norm() / c_.norm()) < 2e-6
 
 
+@pytest.mark.parametrize("k_a,k_b,b_row0,rows,depth,out_dim,S,N", [
+    (0, 32, 0, 32, 2, 16, 256, 1 << 16),   # density_net
+    (16, 15, 1, 16, 2, 1, 256, 1 << 16),   # sigma_net (pixel-feature block + ragged row block)
+    (16, 4, 0, 32, 1, 1, 256, 1 << 15),    # b_net, one hidden layer: nothing but sign bits is saved
+    (0, 16, 0, 16, 2, 16, 16, 1 << 14),    # one input block
+])
+def test_fused_mlp_compact_save(device, k_a, k_b, b_row0, rows, depth, out_dim, S, N, monkeypatch):
+    """``nesvor_mlp_t.compact_save`` (sign bits of the hidden layers + the values of the layers after the first; the backward
+    recomputes the first hidden layer in the dW waves) against the full save of the same kernels: outputs and input
+    gradients BIT FOR BIT (the dX chain sees the same gates), parameter gradients to fp32 rounding of the recomputed layer;
+    the saved buffers really are the small ones."""
+    from nesvor_amd import mlp
+    from nesvor_amd.models import build_network
+
+    torch.manual_seed(N + k_b)
+    net = build_network(n_input_dims=k_a + k_b, n_output_dims=out_dim, activation="ReLU", output_activation="None",
+                        n_neurons=64, n_hidden_layers=depth, dtype=torch.float32).to(device)
+    L = mlp.linear_layers(net)
+    W, Bs = [l.weight.detach() for l in L], [l.bias.detach() for l in L]
+    xa = torch.randn(N // S, k_a, device=device) if k_a else None
+    xb = torch.randn(rows, N, device=device)
+    xb[:, ::7] = 0.0  # exact zeros in the input (pre-activations that are exactly the bias)
+    dy = torch.randn(out_dim, N, device=device)
+    res = {}
+    for compact in (True, False):
+        if not compact:
+            monkeypatch.setattr(mlp, "compact_save", lambda d, n: False)
+        y, saved = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, True)
+        assert (saved[0].numel() == N * 4) == compact and all(t.numel() == N * 64 for t in saved[1:])
+        dxb = torch.empty(k_b, N, device=device)
+        dxa, partial = mlp.backward_raw(W, Bs, xa, xb, dy, saved, b_row0, k_b, S, dxb, xa is not None)
+        res[compact] = (y, dxb, dxa, partial.sum(0), saved)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    if xa is not None:
+        assert torch.equal(res[True][2], res[False][2])
+    gw_c, gw_f = res[True][3], res[False][3]
+    assert float((gw_c - gw_f).abs().max()) <= 2e-6 * float(gw_f.abs().max())
+    # the masks are the forward's: bit 16 l + 4 b + r of word (group, lane = 16 q + sample) = [h_l > 0] of unit 16 b + 4 q + r
+    words = res[True][4][0].view(torch.int32).view(N // 16, 4, 16)  # [group][q][sample]
+    saved_full = res[False][4]
+    if depth == 2:
+        assert torch.equal(res[True][4][1], saved_full[1])
+    for l in range(depth):
+        h = saved_full[l].view(N // 16, 4, 4, 16, 4)  # [group][block b][q][sample][r]
+        for b in range(4):
+            for r in range(4):
+                bit = (words >> (16 * l + 4 * b + r)) & 1
+                assert torch.equal(bit.bool(), h[:, b, :, :, r] > 0), (l, b, r)
+
+
 # -------------------------------------------------------------------- fused MLP
 @pytest.mark.parametrize("k_a,k_b,b_row0,rows,depth,out_dim,S,N", [
     (0, 32, 0, 32, 2, 16, 8, 1000),     # density_net (ragged N, not a multiple of 16)
