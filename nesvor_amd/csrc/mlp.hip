@@ -346,8 +346,11 @@ __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const
 }
 
 // single 16-sample group variant (used by the fused backward, where registers hold the dW accumulators)
-template <int KB, int OB, bool BF16 = false, bool X6 = false>
+// ZERO (split mode): y is an output, not an accumulator - the first term of every block product takes a literal zero as its C
+// operand instead of OB x 4 registers the caller would have to clear.
+template <int KB, int OB, bool BF16 = false, bool X6 = false, bool ZERO = false>
 __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, const f32x4 (&x)[KB], f32x4 (&y)[OB], int lane) {
+  static_assert(!ZERO || X6, "ZERO: split mode only");
   if constexpr (X6) {
     const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
     constexpr int plane = OB * KB * 256;
@@ -388,7 +391,13 @@ __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, co
         __builtin_amdgcn_sched_barrier(0x047F);
       }
 #define NESVOR_TERM(A, B) _Pragma("unroll") for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_bf16(A[ob], B, y[ob]);
-      NESVOR_TERM(al, bh) NESVOR_TERM(ah, bl) NESVOR_TERM(am, bm) NESVOR_TERM(am, bh) NESVOR_TERM(ah, bm) NESVOR_TERM(ah, bh)
+      if (ZERO && kb == 0) {
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_bf16(al[ob], bh, f32x4{0.f, 0.f, 0.f, 0.f});
+      } else {
+        NESVOR_TERM(al, bh)
+      }
+      NESVOR_TERM(ah, bl) NESVOR_TERM(am, bm) NESVOR_TERM(am, bh) NESVOR_TERM(ah, bm) NESVOR_TERM(ah, bh)
 #undef NESVOR_TERM
       if (more) {
         if (!NESVOR_MLP_APREFETCH) load_pair(kb + 2, nh, nm, nl);
@@ -399,7 +408,7 @@ __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, co
     if constexpr (KB % 2 == 1) {
       const Split3 pb = split3(x[KB - 1]);
 #pragma unroll
-      for (int ob = 0; ob < OB; ++ob) y[ob] = mfma_split(load_a(ob, KB - 1), pb, y[ob]);
+      for (int ob = 0; ob < OB; ++ob) y[ob] = mfma_split(load_a(ob, KB - 1), pb, (ZERO && KB == 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : y[ob]);
     }
     return;
   }
@@ -1525,18 +1534,21 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         dbc_o[0] += go;
         f32x4 gov[1] = {go};
         f32x4 d[kHB];
+        if constexpr (!X6) {
 #pragma unroll
-        for (int ib = 0; ib < kHB; ++ib) d[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-        apply_layer_g1<1, kHB, BF16, X6>(imgo, gov, d, lane);
+          for (int ib = 0; ib < kHB; ++ib) d[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        apply_layer_g1<1, kHB, BF16, X6, X6>(imgo, gov, d, lane);
 #pragma unroll
         for (int l = NH - 1; l >= 0; --l) {
 #pragma unroll
           for (int ib = 0; ib < kHB; ++ib) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              if constexpr (COMPACT) {  // v_bfe_i32 (0 or all ones) + v_and_b32
-                const int32_t keep = (int32_t)(mbits << (31 - (16 * l + 4 * ib + r))) >> 31;
-                d[ib][r] = __uint_as_float(__float_as_uint(d[ib][r]) & (uint32_t)keep);
+              if constexpr (COMPACT) {  // v_bfe_i32 (0 or all ones) + v_and_b32 (written out: the compiler's own form is and + compare + select)
+                uint32_t keep;
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(mbits), "n"(16 * l + 4 * ib + r));
+                d[ib][r] = __uint_as_float(__float_as_uint(d[ib][r]) & keep);
               } else {
                 d[ib][r] = hs[l][ib][r] > 0.f ? d[ib][r] : 0.f;
               }
@@ -1547,16 +1559,20 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           }
           if (l > 0) {
             f32x4 d2[kHB];
+            if constexpr (!X6) {
 #pragma unroll
-            for (int ib = 0; ib < kHB; ++ib) d2[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-            apply_layer_g1<kHB, kHB, BF16, X6>(imgh + (l - 1) * kHB * kHB * kBlk, d, d2, lane);
+              for (int ib = 0; ib < kHB; ++ib) d2[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            apply_layer_g1<kHB, kHB, BF16, X6, X6>(imgh + (l - 1) * kHB * kHB * kBlk, d, d2, lane);
 #pragma unroll
             for (int ib = 0; ib < kHB; ++ib) d[ib] = d2[ib];
           } else if (a.dxa != nullptr || a.dxb != nullptr) {
             f32x4 dx[KB1];
+            if constexpr (!X6) {
 #pragma unroll
-            for (int ib = 0; ib < KB1; ++ib) dx[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-            apply_layer_g1<kHB, KB1, BF16, X6>(img1, d, dx, lane);
+              for (int ib = 0; ib < KB1; ++ib) dx[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            apply_layer_g1<kHB, KB1, BF16, X6, X6>(img1, d, dx, lane);
             if (a.dx_absmax != nullptr) track_absmax<KB1>(a, dx, dx_mx);
             // drain the prefetch BEFORE the stores below: loads and stores share vmcnt, and the wait would otherwise
             // also cover the latency of these stores
