@@ -465,12 +465,16 @@ def main():
                 fp32_mfma, bf16_mfma = 0, 6 * bp + 2 * 3 * (W // 16)
             busy = lambda n, cyc: n * cyc * groups / n_simd / (ms2 * 1e-3 * clock_hz)
             fl = 2 * n_points * sum(i * o for d in (dens, sig) for i, o in zip(d[:-1], d[1:]))  # one forward of both nets
-            # Round 3 (DESIGN.md "What round 3 measured about the MLP kernels"): after the instruction-count work the four MLP
-            # launches of a step run at the rate the device streams their bytes - the saved hidden activations (2 x 256 B per
-            # point and network, written by the forward, read by the backward) are 74 % of them.  Algorithmic bytes per point:
-            #   forward  = input rows + 2 saved layers (512 B) + output rows;  backward = 2 saved layers + input rows + dY + dX
+            # Round 3 (DESIGN.md "What round 3 measured about the MLP kernels"): with the compact save (sign bits of the hidden layers
+            # + the values of the second one; the first is recomputed in the backward) the four MLP launches of a step stream
+            # 1788 B per point instead of 2748 and are bound by instruction issue: bf16 MFMAs (16 cycles) and VALU instructions
+            # (4 cycles) do not overlap on a gfx950 SIMD (tools/mfma_bf16_overlap.hip).  Algorithmic bytes per point:
+            #   forward  = input rows + saved (256 B second hidden layer + 16 B sign bits) + output rows
+            #   backward = saved + input rows + dY + dX
             in_d, in_s = 4 * L * F, 4 * nz          # bytes of a point's network input that streams from HBM (the slice embedding is per pixel)
-            mlp_bytes_pt = (in_d + 512 + 4 * (1 + nz)) + (in_s + 512 + 4) + (512 + in_d + 4 * (1 + nz) + in_d) + (512 + in_s + 4 + in_s)
+            compact = not (bf16_ops or opt.mlp_fp32_mfma) and os.environ.get("NESVOR_MLP_COMPACT", "1") != "0" and opt.depth == 2
+            saved_pt = (256 + 16) if compact else 512
+            mlp_bytes_pt = (in_d + saved_pt + 4 * (1 + nz)) + (in_s + saved_pt + 4) + (saved_pt + in_d + 4 * (1 + nz) + in_d) + (saved_pt + in_s + 4 + in_s)
             ms_all = ms2 + (ktimes["mlp_fwd"][0] * ktimes["mlp_fwd"][1] / k_steps if "mlp_fwd" in ktimes else 0.0)
             mlp_gbps = mlp_bytes_pt * n_points / (ms_all * 1e-3) / 1e9
             traffic_mlp = None
@@ -479,20 +483,27 @@ def main():
                     traffic_mlp = json.load(fh)
             except OSError:
                 pass
-            roof_mlp = {"bound": "hbm", "kernel": "mlp_fwd_pf x 2 + mlp_bwd_ws x 2 (density_net, sigma_net): the four MLP launches of a step",
+            # instructions per 16-sample group in the loop bodies of the compiled kernels (density-network instantiation, compact
+            # save; counted in the ISA: forward 84 MFMA + 280 VALU, backward chain wave 96 + 254, dW wave 108 + 440)
+            issue_cycles = 2 * ((84 * 16 + 280 * 4) + ((96 + 108) * 16 + (254 + 440) * 4)) * groups / n_simd if compact else None
+            roof_mlp = {"bound": "instruction issue (bf16 MFMA + VALU, not overlapped)" if compact else "hbm",
+                        "kernel": "mlp_fwd_pf x 2 + mlp_bwd_ws x 2 (density_net, sigma_net): the four MLP launches of a step",
                         "achieved": mlp_gbps, "peak": 8000.0, "unit": "GB/s", "frac": mlp_gbps / 8000.0,
                         "frac_of_copy_peak": None if not extras["copy_peak_GBps"] else mlp_gbps / extras["copy_peak_GBps"],
                         "launch_ms": ms_all, "backward_ms": ms2, "algorithmic_bytes_per_point": mlp_bytes_pt,
-                        "algorithmic_bytes_per_step": mlp_bytes_pt * n_points,
+                        "algorithmic_bytes_per_step": mlp_bytes_pt * n_points, "compact_save": compact,
                         "traffic": traffic_mlp,
-                        "fp32_pipe_busy_frac": busy(fp32_mfma, 32), "bf16_pipe_busy_frac": busy(bf16_mfma, 16),
-                        "matrix_pipe_busy_frac_backward": busy(fp32_mfma, 32) + busy(bf16_mfma, 16),
-                        "mfma_per_16_sample_group_backward": {"fp32_16x16x4": fp32_mfma, "bf16": bf16_mfma},
+                        "issue_floor_ms": None if issue_cycles is None else issue_cycles / clock_hz * 1e3,
+                        "issue_frac": None if issue_cycles is None else issue_cycles / clock_hz * 1e3 / ms_all,
+                        "fp32_pipe_busy_frac": busy(fp32_mfma, 32), "bf16_pipe_busy_frac": busy(bf16_mfma + (24 if compact else 0), 16),
+                        "matrix_pipe_busy_frac_backward": busy(fp32_mfma, 32) + busy(bf16_mfma + (24 if compact else 0), 16),
+                        "mfma_per_16_sample_group_backward": {"fp32_16x16x4": fp32_mfma, "bf16": bf16_mfma + (24 if compact else 0)},
                         "engine_clock_MHz": clock_hz / 1e6, "fp32_equivalent_TFLOPs_backward": 2 * fl / (ms2 * 1e-3) / 1e12,
-                        "note": "bound = HBM: the kernels stream the saved activations at the device's copy rate (copy_peak_GBps in "
-                                "`roofline`); bf16 MFMAs and VALU instructions do not overlap on gfx950 (tools/mfma_bf16_overlap.hip), so "
-                                "the matrix pipe's busy fraction (MFMA issue cycles per SIMD / launch time at the maximum engine clock) "
-                                "stays near a third by construction of the 3-way operand split; SQ counters in "
+                        "note": "HBM view: algorithmic bytes of the four launches / their time (the saved activations were 74 % of the bytes "
+                                "before the compact save; now the launches move 2.3 GB per step, PMC, and HBM is no longer what bounds them). "
+                                "Issue view: issue_frac = (16 cycles per bf16 MFMA + 4 per VALU instruction, per SIMD, at the maximum engine "
+                                "clock) / measured time - the two instruction classes do not overlap on gfx950 "
+                                "(tools/mfma_bf16_overlap.hip), the rest is dependency and LDS latency at two waves per SIMD; SQ counters in "
                                 "profiles/r03_pmc_sq_mlp_summary.txt"}
         out = {
             "metric": "INR train iters/sec (2^20 samples, L=16 hash, 64-wide MLP)",

@@ -38,6 +38,27 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/mlp_$c -- python $ROOT/tools/prof_mlp.py > /dev/null 2>&1
 done
 { for k in mlp_bwd_ws mlp_fwd_pf; do echo "== $k (KiB per launch; FETCH_SIZE counts 128-B requests at 64 B on gfx950: double it)"; python $ROOT/tools/pmc_summary.py $k $OUT/mlp_FETCH_SIZE $OUT/mlp_WRITE_SIZE; done; } > $OUT/pmc_traffic_mlp.txt
+python - "$OUT/pmc_traffic_mlp.txt" "$NESVOR_COMMIT" > $OUT/pmc_traffic_mlp.json <<'PY'
+import json, re, sys
+out = {"commit": sys.argv[2] + " (kernels as of the collection run, tools/collect_profiles_r03.sh)",
+       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python tools/prof_mlp.py ; density-network shape "
+                 "(32 -> 64 -> 64 -> 16), N = 2^20, split-bf16 evaluation, compact save",
+       "unit": "bytes per launch",
+       "note": "FETCH_SIZE, WRITE_SIZE are reported in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)"}
+kernel = None
+for line in open(sys.argv[1]):
+    m = re.match(r"== (\S+)", line)
+    if m:
+        kernel = m.group(1); out[kernel] = {}
+        continue
+    m = re.match(r"(FETCH_SIZE|WRITE_SIZE)\s+(\d+)", line)
+    if m and kernel:
+        out[kernel][m.group(1) + "_KiB"] = int(m.group(2))
+for k, v in out.items():
+    if isinstance(v, dict) and "FETCH_SIZE_KiB" in v and "WRITE_SIZE_KiB" in v:
+        v["traffic_bytes"] = (2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024
+print(json.dumps(out, indent=1))
+PY
 # 5. HBM bytes of a whole training step (all kernels of 10 steps, two passes)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/step_$c -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-extras --no-strict --small-batches "" > /dev/null 2>&1
@@ -46,7 +67,7 @@ python $ROOT/tools/step_traffic.py $OUT/step_FETCH_SIZE $OUT/step_WRITE_SIZE 20 
 # 6. micro-benchmarks
 python $ROOT/tools/bench_hashgrid.py > $OUT/hashgrid_microbench.log 2>&1
 python $ROOT/tools/bench_hg_levels.py > $OUT/hashgrid_per_level.log 2>&1
-python $ROOT/tools/mlp_variants.py r03: split0:-DNESVOR_SPLIT=0 split1:-DNESVOR_SPLIT=1 > $OUT/mlp_variants.log 2>&1
+python $ROOT/tools/mlp_variants.py r03: split0:-DNESVOR_SPLIT=0 split1:-DNESVOR_SPLIT=1 nosplit:-DNESVOR_MLP_ABLATE=4 all_in_cache:-DNESVOR_MLP_ABLATE=3 > $OUT/mlp_variants.log 2>&1
 python $ROOT/tools/hg_variants.py r03: fixed32:-DNESVOR_FIXED32=1 noinsert:-DNESVOR_ABLATE=4 nowrite:-DNESVOR_ABLATE=8 noscan:-DNESVOR_ABLATE=2 oldfixed:-DNESVOR_HG_OLDFIXED=1 > $OUT/hashgrid_ab.log 2>&1
 rm -rf $OUT/kstats $OUT/tl $OUT/tl512 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/mlp_sq1 $OUT/mlp_sq2 $OUT/mlp_sq3 $OUT/mlp_FETCH_SIZE $OUT/mlp_WRITE_SIZE $OUT/step_FETCH_SIZE $OUT/step_WRITE_SIZE
 ls -la $OUT
