@@ -80,7 +80,8 @@ def cpu_baseline(ds, args, seconds_budget=40.0):
         per = max(time.time() - t0, 1e-3)
         if per * n_iter <= seconds_budget or pixels == 64:
             break
-    n_iter = int(max(3, min(n_iter, seconds_budget / per)))
+    if pixels != 64:
+        n_iter = int(max(3, min(n_iter, seconds_budget / per)))  # (the 64-pixel sample always runs its 20 iterations)
     last = {}
     _, _, _, info = otl.train(mk(), cargs, n_iter=n_iter, log=lambda i, l: last.update(l), time_from_iter=1)
     rate = info["iters_per_s"]  # iterations 2..n_iter
@@ -483,9 +484,10 @@ def main():
                     traffic_mlp = json.load(fh)
             except OSError:
                 pass
-            # instructions per 16-sample group in the loop bodies of the compiled kernels (density-network instantiation, compact
-            # save; counted in the ISA: forward 84 MFMA + 280 VALU, backward chain wave 96 + 254, dW wave 108 + 440)
-            issue_cycles = 2 * ((84 * 16 + 280 * 4) + ((96 + 108) * 16 + (254 + 440) * 4)) * groups / n_simd if compact else None
+            # instructions per 16-sample group (SQ counters of the density-network launches, profiles/r03_pmc_sq_mlp_summary.txt:
+            # SQ_INSTS_MFMA and SQ_INSTS_VALU - which includes the MFMAs - over 65536 groups): forward 84 MFMA + 346 other VALU,
+            # backward 204 MFMA (chain wave 96, dW wave 108 of which 24 recompute the first hidden layer) + 792 other VALU
+            issue_cycles = 2 * ((84 * 16 + 346 * 4) + (204 * 16 + 792 * 4)) * groups / n_simd if compact else None
             roof_mlp = {"bound": "instruction issue (bf16 MFMA + VALU, not overlapped)" if compact else "hbm",
                         "kernel": "mlp_fwd_pf x 2 + mlp_bwd_ws x 2 (density_net, sigma_net): the four MLP launches of a step",
                         "achieved": mlp_gbps, "peak": 8000.0, "unit": "GB/s", "frac": mlp_gbps / 8000.0,
