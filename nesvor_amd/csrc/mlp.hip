@@ -346,70 +346,80 @@ __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const
 }
 
 // single 16-sample group variant (used by the fused backward, where registers hold the dW accumulators)
+// Split-mode layer product on operands that are already split (the chain waves of the wave-specialised backward split a
+// fragment once, for this product AND for the planes they hand to the dW waves).
+template <int KB, int OB, bool ZERO = false>
+__device__ __forceinline__ void apply_layer_g1_s(const float* __restrict__ img, const Split3 (&xs)[KB], f32x4 (&y)[OB], int lane) {
+  const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
+  constexpr int plane = OB * KB * 256;
+  auto load_a = [&](int ob, int kb) __attribute__((always_inline)) {
+    const __bf16* pa = img16 + ((ob * KB + kb) * 64 + lane) * 4;
+    Split3 a;
+    a.hi = *reinterpret_cast<const s16x4*>(pa);
+    a.mid = *reinterpret_cast<const s16x4*>(pa + plane);
+    a.lo = *reinterpret_cast<const s16x4*>(pa + 2 * plane);
+    return a;
+  };
+  // term-major over the OB independent accumulators (see apply_layer).  The weight planes of a k-block pair are read from
+  // LDS while the activations of that pair are being split (NESVOR_MLP_APREFETCH: and those of the NEXT pair before the
+  // products of the current one), not right in front of the first product that needs them.
+#ifndef NESVOR_MLP_APREFETCH
+#define NESVOR_MLP_APREFETCH 0  // measured (tools/mlp_variants.py, same box): 0.268 / 0.227 ms without, 0.275 / 0.233 ms with the read-ahead of the next pair
+#endif
+  auto load_pair = [&](int kb, bf16x8 (&ah)[OB], bf16x8 (&am)[OB], bf16x8 (&al)[OB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) {
+      const Split3 a0 = load_a(ob, kb), a1 = load_a(ob, kb + 1);
+      ah[ob] = join8(a0.hi, a1.hi); am[ob] = join8(a0.mid, a1.mid); al[ob] = join8(a0.lo, a1.lo);
+    }
+  };
+  bf16x8 ah[OB], am[OB], al[OB];
+  if constexpr (KB >= 2) {
+    load_pair(0, ah, am, al);
+    __builtin_amdgcn_sched_barrier(0x047F);  // LDS reads stay above, everything else may cross
+  }
+#pragma unroll
+  for (int kb = 0; kb + 1 < KB; kb += 2) {
+    const Split3 &p0 = xs[kb], &p1 = xs[kb + 1];
+    const bf16x8 bh = join8(p0.hi, p1.hi), bm = join8(p0.mid, p1.mid), bl = join8(p0.lo, p1.lo);
+    bf16x8 nh[OB], nm[OB], nl[OB];
+    const bool more = kb + 3 < KB;
+    if (NESVOR_MLP_APREFETCH && more) {
+      load_pair(kb + 2, nh, nm, nl);
+      __builtin_amdgcn_sched_barrier(0x047F);
+    }
+#define NESVOR_TERM(A, B) _Pragma("unroll") for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_bf16(A[ob], B, y[ob]);
+    if (ZERO && kb == 0) {
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_bf16(al[ob], bh, f32x4{0.f, 0.f, 0.f, 0.f});
+    } else {
+      NESVOR_TERM(al, bh)
+    }
+    NESVOR_TERM(ah, bl) NESVOR_TERM(am, bm) NESVOR_TERM(am, bh) NESVOR_TERM(ah, bm) NESVOR_TERM(ah, bh)
+#undef NESVOR_TERM
+    if (more) {
+      if (!NESVOR_MLP_APREFETCH) load_pair(kb + 2, nh, nm, nl);
+#pragma unroll
+      for (int ob = 0; ob < OB; ++ob) { ah[ob] = nh[ob]; am[ob] = nm[ob]; al[ob] = nl[ob]; }
+    }
+  }
+  if constexpr (KB % 2 == 1) {
+    const Split3& pb = xs[KB - 1];
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) y[ob] = mfma_split(load_a(ob, KB - 1), pb, (ZERO && KB == 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : y[ob]);
+  }
+}
+
 // ZERO (split mode): y is an output, not an accumulator - the first term of every block product takes a literal zero as its C
 // operand instead of OB x 4 registers the caller would have to clear.
 template <int KB, int OB, bool BF16 = false, bool X6 = false, bool ZERO = false>
 __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, const f32x4 (&x)[KB], f32x4 (&y)[OB], int lane) {
   static_assert(!ZERO || X6, "ZERO: split mode only");
   if constexpr (X6) {
-    const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
-    constexpr int plane = OB * KB * 256;
-    auto load_a = [&](int ob, int kb) __attribute__((always_inline)) {
-      const __bf16* pa = img16 + ((ob * KB + kb) * 64 + lane) * 4;
-      Split3 a;
-      a.hi = *reinterpret_cast<const s16x4*>(pa);
-      a.mid = *reinterpret_cast<const s16x4*>(pa + plane);
-      a.lo = *reinterpret_cast<const s16x4*>(pa + 2 * plane);
-      return a;
-    };
-    // term-major over the OB independent accumulators (see apply_layer).  The weight planes of a k-block pair are read from
-    // LDS while the activations of that pair are being split (NESVOR_MLP_APREFETCH: and those of the NEXT pair before the
-    // products of the current one), not right in front of the first product that needs them.
-#ifndef NESVOR_MLP_APREFETCH
-#define NESVOR_MLP_APREFETCH 0  // measured (tools/mlp_variants.py, same box): 0.268 / 0.227 ms without, 0.275 / 0.233 ms with the read-ahead of the next pair
-#endif
-    auto load_pair = [&](int kb, bf16x8 (&ah)[OB], bf16x8 (&am)[OB], bf16x8 (&al)[OB]) __attribute__((always_inline)) {
+    Split3 xs[KB];
 #pragma unroll
-      for (int ob = 0; ob < OB; ++ob) {
-        const Split3 a0 = load_a(ob, kb), a1 = load_a(ob, kb + 1);
-        ah[ob] = join8(a0.hi, a1.hi); am[ob] = join8(a0.mid, a1.mid); al[ob] = join8(a0.lo, a1.lo);
-      }
-    };
-    bf16x8 ah[OB], am[OB], al[OB];
-    if constexpr (KB >= 2) {
-      load_pair(0, ah, am, al);
-      __builtin_amdgcn_sched_barrier(0x047F);  // LDS reads stay above, everything else may cross
-    }
-#pragma unroll
-    for (int kb = 0; kb + 1 < KB; kb += 2) {
-      const Split3 p0 = split3(x[kb]), p1 = split3(x[kb + 1]);
-      const bf16x8 bh = join8(p0.hi, p1.hi), bm = join8(p0.mid, p1.mid), bl = join8(p0.lo, p1.lo);
-      bf16x8 nh[OB], nm[OB], nl[OB];
-      const bool more = kb + 3 < KB;
-      if (NESVOR_MLP_APREFETCH && more) {
-        load_pair(kb + 2, nh, nm, nl);
-        __builtin_amdgcn_sched_barrier(0x047F);
-      }
-#define NESVOR_TERM(A, B) _Pragma("unroll") for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_bf16(A[ob], B, y[ob]);
-      if (ZERO && kb == 0) {
-#pragma unroll
-        for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_bf16(al[ob], bh, f32x4{0.f, 0.f, 0.f, 0.f});
-      } else {
-        NESVOR_TERM(al, bh)
-      }
-      NESVOR_TERM(ah, bl) NESVOR_TERM(am, bm) NESVOR_TERM(am, bh) NESVOR_TERM(ah, bm) NESVOR_TERM(ah, bh)
-#undef NESVOR_TERM
-      if (more) {
-        if (!NESVOR_MLP_APREFETCH) load_pair(kb + 2, nh, nm, nl);
-#pragma unroll
-        for (int ob = 0; ob < OB; ++ob) { ah[ob] = nh[ob]; am[ob] = nm[ob]; al[ob] = nl[ob]; }
-      }
-    }
-    if constexpr (KB % 2 == 1) {
-      const Split3 pb = split3(x[KB - 1]);
-#pragma unroll
-      for (int ob = 0; ob < OB; ++ob) y[ob] = mfma_split(load_a(ob, KB - 1), pb, (ZERO && KB == 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : y[ob]);
-    }
+    for (int kb = 0; kb < KB; ++kb) xs[kb] = split3(x[kb]);
+    apply_layer_g1_s<KB, OB, ZERO>(img, xs, y, lane);
     return;
   }
   if constexpr (BF16) {
@@ -1060,6 +1070,51 @@ __device__ __forceinline__ void read_operand(const float* tile, int i, int q, fl
   for (int t = 0; t < 4; ++t) v[t] = tile[(4 * q + t) * kTileStride + i];  // feature i of samples 4q..4q+3
 }
 
+// Plane tiles (split mode of the wave-specialised backward): the chain wave hands a 16 x 16 dpre tile to its dW wave already
+// split - three bf16 planes of 512 bytes, TRANSPOSED ([feature row][sample]), so that the dW wave's A operand (feature i,
+// samples 4q..4q+3) is one 8-byte read per plane and needs no splitting of its own.  Feature f = 4q + r sits in row 4r + q:
+// the four rows a wave-store touches (r fixed, q = 0..3) are then adjacent and cover 32 distinct LDS banks.
+// NESVOR_MLP_PLANES (build macro, default 0).  Measured (density / sigma network backward): 0.279 / 0.243 ms per launch with
+// the planes (tools/mlp_variants.py) against 0.264 / 0.228 with fp32 tiles that BOTH waves of a pair split
+// (profiles/r03_mlp_variants.log), in the training step 2 x 0.231 against 2 x 0.216 ms - although the planes take 86 VALU
+// instructions per group off the dW wave (440 -> 354): the 96 two-byte LDS stores per group they cost the chain wave
+// outweigh the 8 x 14 split instructions they save.
+#ifndef NESVOR_MLP_PLANES
+#define NESVOR_MLP_PLANES 0
+#endif
+constexpr int kPlaneTileFloats = 3 * 16 * 16 / 2;  // three planes of 256 bf16
+constexpr int kTile0Stride = 16;                   // the dY tile stays fp32 (it is the one tile that must fit next to the planes: no padding)
+constexpr int kTile0Floats = 16 * kTile0Stride;
+__device__ __forceinline__ void stage_tile0(float* tile, const f32x4& frag, int j, int q) {
+  *reinterpret_cast<f32x4*>(tile + j * kTile0Stride + 4 * q) = frag;
+}
+__device__ __forceinline__ void read_operand0(const float* tile, int i, int q, float (&v)[4]) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) v[t] = tile[(4 * q + t) * kTile0Stride + i];
+}
+// (written as instructions: left to the compiler, the high halves are re-converted from the fp32 values - one extra
+// v_cvt_pk_bf16_f32 per stored element - instead of being stored with ds_write_b16_d16_hi)
+template <int OFF> __device__ __forceinline__ void lds_store_lo16(uint32_t addr, uint32_t v) {
+  asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void lds_store_hi16(uint32_t addr, uint32_t v) {
+  asm volatile("ds_write_b16_d16_hi %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void stage_planes(float* tile, const Split3& s, int j, int q) {
+  // lane (sample j, q) holds feature 4q + r -> row 4r + q (32 bytes per row), plane p at 512 p bytes
+  const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)tile + (uint32_t)((q * 16 + j) * 2);
+  const uint2 h = __builtin_bit_cast(uint2, s.hi), m = __builtin_bit_cast(uint2, s.mid), l = __builtin_bit_cast(uint2, s.lo);
+  lds_store_lo16<0>(addr, h.x);    lds_store_hi16<128>(addr, h.x);        lds_store_lo16<256>(addr, h.y);        lds_store_hi16<384>(addr, h.y);
+  lds_store_lo16<512>(addr, m.x);  lds_store_hi16<512 + 128>(addr, m.x);  lds_store_lo16<512 + 256>(addr, m.y);  lds_store_hi16<512 + 384>(addr, m.y);
+  lds_store_lo16<1024>(addr, l.x); lds_store_hi16<1024 + 128>(addr, l.x); lds_store_lo16<1024 + 256>(addr, l.y); lds_store_hi16<1024 + 384>(addr, l.y);
+}
+__device__ __forceinline__ void read_planes(const float* tile, int i, int q, Split3& a) {
+  const unsigned short* t16 = reinterpret_cast<const unsigned short*>(tile) + (4 * (i & 3) + (i >> 2)) * 16 + 4 * q;
+  a.hi = *reinterpret_cast<const s16x4*>(t16);
+  a.mid = *reinterpret_cast<const s16x4*>(t16 + 256);
+  a.lo = *reinterpret_cast<const s16x4*>(t16 + 512);
+}
+
 template <int OB, int IB>
 __device__ __forceinline__ void accumulate_dw(float* scratch, const f32x4 (&dy)[OB], const f32x4 (&x)[IB],
                                               f32x4 (&acc)[OB][IB], float (&db)[OB], int lane) {
@@ -1388,6 +1443,41 @@ __device__ __forceinline__ void accumulate_dw_split(const float* tiles, const f3
 }
 
 
+// The same products with the A operands arriving split (plane tiles, see stage_planes): `ap` holds the requested planes of
+// the first tile; the next one (of this layer, or `next_tile`) is requested before the current one is multiplied.
+template <int OB, int IB>
+__device__ __forceinline__ void accumulate_dw_planes(const float* tiles, const f32x4 (&bv)[IB], f32x4 (&acc)[OB][IB], int i, int q,
+                                                     Split3& ap, const float* next_tile) {
+  // B operands two input blocks at a time: their tuples (8 registers per block) are what peaks the register use of the
+  // kernel; the A planes are then read once per pair of input blocks (3 x 8-byte LDS reads per tile)
+  constexpr int CH = IB;  // (chunks of two input blocks were tried to lower the register peak: +32 VALU per group for re-joined A tuples)
+#pragma unroll
+  for (int ib0 = 0; ib0 < IB; ib0 += CH) {
+    bf16x8 b_hl[CH], b_mh[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const Split3 sb = split3(bv[ib0 + c]);
+      b_hl[c] = join8(sb.hi, sb.lo);
+      b_mh[c] = join8(sb.mid, sb.hi);
+    }
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob) {
+      Split3 an = ap;
+      const float* nt = ob + 1 < OB ? tiles + (ob + 1) * kPlaneTileFloats : (ib0 + CH < IB ? tiles : next_tile);
+      if (nt != nullptr) read_planes(nt, i, q, an);
+      __builtin_amdgcn_sched_barrier(0x047F);  // everything but LDS instructions may cross: the read above stays above
+      const bf16x8 a_lh = join8(ap.lo, ap.hi), a_mm = join8(ap.mid, ap.mid), a_hh = join8(ap.hi, ap.hi);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) acc[ob][ib0 + c] = mfma32_bf16(a_lh, b_hl[c], acc[ob][ib0 + c]);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) acc[ob][ib0 + c] = mfma32_bf16(a_mm, b_mh[c], acc[ob][ib0 + c]);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) acc[ob][ib0 + c] = mfma32_bf16(a_hh, b_mh[c], acc[ob][ib0 + c]);
+      ap = an;
+    }
+  }
+}
+
 // X6: the dX chain (contraction over features, 32 at a time) runs on split-bf16 operands - see split3(); the dW waves
 // contract over the 16 samples of a group, where the split would not pay, and keep the fp32 MFMAs.
 #ifndef NESVOR_MLP_SPLIT_DW
@@ -1442,7 +1532,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
       __syncthreads();
     }
   };
-  float* my_tiles = tiles + pair * 2 * kT * kTileFloats;
+  // split mode: tile 0 (dY) fp32 without padding, the NH x 4 dpre tiles as bf16 planes (see stage_planes)
+  constexpr bool PLANES = X6 && kSplitDw && (NESVOR_MLP_PLANES != 0);
+  constexpr int kBufFloats = PLANES ? kTile0Floats + NH * kHB * kPlaneTileFloats : kT * kTileFloats;
+  float* my_tiles = tiles + pair * 2 * kBufFloats;
   const int64_t n_groups = a.N >> 4;
   const int64_t gstride = (int64_t)gridDim.x * 4;
   const int64_t wg_first = (int64_t)blockIdx.x * 4;
@@ -1529,8 +1622,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         // between an issue and its settle (a register copy at the merge would read the in-flight registers), so the
         // last iteration simply re-requests its own group
         issue_group(min(gi + gstride, n_groups - 1), gy_n, hs_n, mk_n);
-        float* buf = my_tiles + (it & 1) * kT * kTileFloats;
-        stage_tile(buf, go, j, q);
+        float* buf = my_tiles + (it & 1) * kBufFloats;
+        if constexpr (PLANES) stage_tile0(buf, go, j, q);
+        else stage_tile(buf, go, j, q);
         dbc_o[0] += go;
         f32x4 gov[1] = {go};
         f32x4 d[kHB];
@@ -1541,6 +1635,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         apply_layer_g1<1, kHB, BF16, X6, X6>(imgo, gov, d, lane);
 #pragma unroll
         for (int l = NH - 1; l >= 0; --l) {
+          Split3 ds[kHB];  // (PLANES)
 #pragma unroll
           for (int ib = 0; ib < kHB; ++ib) {
 #pragma unroll
@@ -1553,7 +1648,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
                 d[ib][r] = hs[l][ib][r] > 0.f ? d[ib][r] : 0.f;
               }
             }
-            stage_tile(buf + (1 + (NH - 1 - l) * kHB + ib) * kTileFloats, d[ib], j, q);
+            if constexpr (PLANES) {
+              ds[ib] = split3(d[ib]);  // once: for the planes and for this wave's own product below
+              stage_planes(buf + kTile0Floats + ((NH - 1 - l) * kHB + ib) * kPlaneTileFloats, ds[ib], j, q);
+            } else {
+              stage_tile(buf + (1 + (NH - 1 - l) * kHB + ib) * kTileFloats, d[ib], j, q);
+            }
             if (l > 0) dbc_h[l > 0 ? l - 1 : 0][ib] += d[ib];
             else dbc_1[ib] += d[ib];
           }
@@ -1563,7 +1663,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
               for (int ib = 0; ib < kHB; ++ib) d2[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            apply_layer_g1<kHB, kHB, BF16, X6, X6>(imgh + (l - 1) * kHB * kHB * kBlk, d, d2, lane);
+            if constexpr (PLANES) apply_layer_g1_s<kHB, kHB, true>(imgh + (l - 1) * kHB * kHB * kBlk, ds, d2, lane);
+            else apply_layer_g1<kHB, kHB, BF16, X6, X6>(imgh + (l - 1) * kHB * kHB * kBlk, d, d2, lane);
 #pragma unroll
             for (int ib = 0; ib < kHB; ++ib) d[ib] = d2[ib];
           } else if (a.dxa != nullptr || a.dxb != nullptr) {
@@ -1572,7 +1673,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
               for (int ib = 0; ib < KB1; ++ib) dx[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            apply_layer_g1<kHB, KB1, BF16, X6, X6>(img1, d, dx, lane);
+            if constexpr (PLANES) apply_layer_g1_s<kHB, KB1, true>(img1, ds, dx, lane);
+            else apply_layer_g1<kHB, KB1, BF16, X6, X6>(img1, d, dx, lane);
             if (a.dx_absmax != nullptr) track_absmax<KB1>(a, dx, dx_mx);
             // drain the prefetch BEFORE the stores below: loads and stores share vmcnt, and the wait would otherwise
             // also cover the latency of these stores
@@ -1616,15 +1718,6 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     }
     // B operands (layer inputs) of one group: lane (feature j, sample quad q) holds feature j of samples 4q..4q+3
     const int ka_blocks = a.k_a >> 4;
-    // lane parts of the input addresses (32-bit byte offsets, see off32): pixel feature 16 kb + j / row (b_row0 + row), samples 4q..
-    uint32_t xsoff[KB1], xoff[KB1];
-#pragma unroll
-    for (int kb = 0; kb < KB1; ++kb) {
-      const bool is_a = kb < ka_blocks;
-      const int row = is_a ? 0 : min(16 * (kb - ka_blocks) + j, a.k_b - 1);
-      xsoff[kb] = is_a ? (uint32_t)((16 * kb + j) * 4) : 0u;
-      xoff[kb] = (uint32_t)(((int64_t)(a.b_row0 + row) * a.N + 4 * q) * 4);
-    }
     // The saved activations are prefetched a whole group ahead into a second register set (32 registers each, swapped every
     // iteration).  The network input - the operand an iteration uses LAST, two thirds of an iteration (~3 us) after its top -
     // has one register set: it is requested at the top of the iteration that uses it, BEFORE the next group's activations, and
@@ -1655,20 +1748,22 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     // lane offsets from ONE register per source (the kernel sits at the 256-register limit): pixel features at
     // (16 kb + 4q + r) floats; matrix rows at ((b_row0 + 16 (kb - ka) + 4q + r) N + j) floats, the wave-uniform part added per
     // load and the result clamped to the last valid row (a row beyond k_b reads something valid and is zeroed below)
-    const uint32_t xc_offa = (uint32_t)(4 * q * 4);
-    const uint32_t xc_offb = (uint32_t)(((int64_t)(a.b_row0 + 4 * q) * a.N + j) * 4);
-    const uint32_t xc_lim = (uint32_t)(((int64_t)(a.b_row0 + a.k_b - 1) * a.N + j) * 4);  // the lane's sample in the last valid row (offsets are relative to the group)
     auto issue_xc = [&](int64_t gi, float (&xc)[KB1][4]) __attribute__((always_inline)) {
       const int64_t pixel = a.spg_shift >= 0 ? (gi >> a.spg_shift) : gi / (a.S >> 4);
       const char* abase = a.xa != nullptr ? reinterpret_cast<const char*>(a.xa) + pixel * (int64_t)(a.k_a * 4) : reinterpret_cast<const char*>(a.xb);
       const char* bbase = reinterpret_cast<const char*>(a.xb) + sgroup(gi) * 64;
+      // (recomputed per group - three multiply-adds - rather than kept: the kernel sits at the 256-register limit)
+      const uint32_t n4 = (uint32_t)a.N * 4u;
+      const uint32_t xc_offa = (uint32_t)(4 * q * 4);
+      const uint32_t xc_offb = (uint32_t)(a.b_row0 + 4 * q) * n4 + (uint32_t)(j * 4);
+      const uint32_t xc_lim = (uint32_t)(a.b_row0 + a.k_b - 1) * n4 + (uint32_t)(j * 4);  // the lane's sample in the last valid row (offsets are relative to the group)
       static_for<KB1>([&](auto KB) {
         constexpr int kb = decltype(KB)::value;
         const bool is_a = kb < ka_blocks;  // wave-uniform
         const char* base = is_a ? abase : bbase;
         static_for<4>([&](auto R) {
           constexpr int r = decltype(R)::value;
-          const uint32_t ub = (uint32_t)((int64_t)(16 * (kb - ka_blocks) + r) * a.N * 4);  // scalar
+          const uint32_t ub = (uint32_t)(16 * (kb - ka_blocks) + r) * n4;  // scalar
           const uint32_t off = is_a ? xc_offa + (uint32_t)((16 * kb + r) * 4) : min(xc_offb + ub, xc_lim);
           issue_load_b32_s<0>(xc[kb][r], base, off);
         });
@@ -1680,10 +1775,15 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
       const int64_t pixel = a.spg_shift >= 0 ? (gi >> a.spg_shift) : gi / (a.S >> 4);
       const char* abase = a.xa != nullptr ? reinterpret_cast<const char*>(a.xa) + pixel * (int64_t)(a.k_a * 4) : reinterpret_cast<const char*>(a.xb);
       const char* bbase = reinterpret_cast<const char*>(a.xb) + sgroup(gi) * 64;
+      // lane parts of the addresses (32-bit byte offsets, see off32): pixel feature 16 kb + j / row (b_row0 + row), samples 4q..
+      // - formed here, per group, not kept in registers across the loop (the kernel sits at the 256-register limit)
+      const uint32_t n4 = (uint32_t)a.N * 4u;
       static_for<KB1>([&](auto KB) {
         constexpr int kb = decltype(KB)::value;
-        issue_load_b32_s<0>(xsraw[kb], abase, xsoff[kb]);
-        issue_load_b128_s<0>(xraw[kb], bbase, xoff[kb]);
+        const bool is_a = kb < ka_blocks;
+        const int row = is_a ? 0 : min(16 * (kb - ka_blocks) + j, a.k_b - 1);
+        issue_load_b32_s<0>(xsraw[kb], abase, is_a ? (uint32_t)((16 * kb + j) * 4) : 0u);
+        issue_load_b128_s<0>(xraw[kb], bbase, (uint32_t)(a.b_row0 + row) * n4 + (uint32_t)(16 * q));
       });
     };
     auto settle_h = [&](float (&hraw)[NH][kHB][4], auto pending) __attribute__((always_inline)) {  // `pending`: younger loads that may stay in flight
@@ -1740,8 +1840,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           issue_xc(gnext, xcr);
         }
         issue_x(gi, xraw, xsraw);
-        issue_h(gnext, hraw_n);
-        const float* buf = my_tiles + ((it - 1) & 1) * kT * kTileFloats;
+        // the next group's activations: a whole iteration ahead - or (COMPACT with plane tiles, where the recomputation's input set
+        // and the plane prefetch make the dW2 product the register peak of the kernel) right after that product
+        constexpr bool kHLate = COMPACT && PLANES;
+        if constexpr (!kHLate) issue_h(gnext, hraw_n);
+        const float* buf = my_tiles + ((it - 1) & 1) * kBufFloats;
         auto input_operands = [&](f32x4 (&xb_)[KB1]) __attribute__((always_inline)) {
           settle_x(xraw, xsraw, std::integral_constant<int, kHLoads>{});  // requested at the top, before the kHLoads that may fly on
 #pragma unroll
@@ -1756,6 +1859,25 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         };
         if constexpr (X6 && kSplitDw) {
           float av[4];
+          if constexpr (PLANES) {
+            // dY tile (fp32, split here) and the first plane tile are requested together; every later A operand one tile ahead
+            Split3 ap;
+            read_operand0(buf, j, q, av);
+            read_planes(buf + kTile0Floats, j, q, ap);
+            accumulate_dw_split<1, kHB>(buf, hb[NH - 1], acc_o, j, q, av, nullptr);
+#pragma unroll
+            for (int l = NH - 1; l >= 0; --l) {
+              const float* dt = buf + kTile0Floats + (NH - 1 - l) * kHB * kPlaneTileFloats;
+              if (l > 0) {
+                accumulate_dw_planes<kHB, kHB>(dt, hb[l - 1], acc_h[l - 1], j, q, ap, dt + kHB * kPlaneTileFloats);
+              } else {
+                if constexpr (kHLate) issue_h(gnext, hraw_n);
+                f32x4 xb_[KB1];
+                input_operands(xb_);
+                accumulate_dw_planes<kHB, KB1>(dt, xb_, acc_1, j, q, ap, nullptr);
+              }
+            }
+          } else {
           read_operand(buf, j, q, av);  // dY tile; every later A fragment is requested one fragment ahead (accumulate_dw_split)
           accumulate_dw_split<1, kHB>(buf, hb[NH - 1], acc_o, j, q, av, buf + kTileFloats);
 #pragma unroll
@@ -1768,6 +1890,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
               input_operands(xb_);
               accumulate_dw_split<kHB, KB1>(dt, xb_, acc_1, j, q, av, nullptr);
             }
+          }
           }
         } else {
           accumulate_dw_regs<1, kHB, BF16>(buf, hb[NH - 1], acc_o, j, q);
@@ -1841,7 +1964,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 size_t ws_bwd_lds_bytes(int n_hidden, int kb1, int blk = 256, bool compact = false) {
   size_t img = (size_t)kHB * blk + (size_t)(n_hidden - 1) * kHB * kHB * blk + (size_t)kb1 * kHB * blk;
   if (compact) img += (size_t)kb1 * kHB * blk + kWidth;  // forward image of the first layer + its bias
-  size_t tiles = 4 * 2 * (size_t)(1 + n_hidden * kHB) * kTileFloats;
+  const bool planes = blk == 384 && kSplitDw && (NESVOR_MLP_PLANES != 0);  // split mode: fp32 dY tile + plane tiles (mlp_bwd_ws_kernel::PLANES)
+  size_t tiles = 4 * 2 * (planes ? (size_t)kTile0Floats + (size_t)n_hidden * kHB * kPlaneTileFloats : (size_t)(1 + n_hidden * kHB) * kTileFloats);
   if (tiles < 4 * (size_t)kHB * 256) tiles = 4 * (size_t)kHB * 256;
   return sizeof(float) * (img + tiles);
 }
