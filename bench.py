@@ -487,7 +487,11 @@ def main():
             # instructions per 16-sample group (SQ counters of the density-network launches, profiles/r03_pmc_sq_mlp_summary.txt:
             # SQ_INSTS_MFMA and SQ_INSTS_VALU - which includes the MFMAs - over 65536 groups): forward 84 MFMA + 346 other VALU,
             # backward 204 MFMA (chain wave 96, dW wave 108 of which 24 recompute the first hidden layer) + 792 other VALU
-            issue_cycles = 2 * ((84 * 16 + 346 * 4) + (204 * 16 + 792 * 4)) * groups / n_simd if compact else None
+            # sigma_net (one output row: its output layer runs on the VALU, csrc/mlp.hip OUT1): 12 / 36 MFMAs and 37 / 112 VALU
+            # instructions fewer per group (forward / backward; counted in the ISA of the two instantiations)
+            out1 = os.environ.get("NESVOR_MLP_OUT1", "1") != "0"
+            sig_f, sig_b = ((72, 309), (168, 680)) if out1 else ((84, 346), (204, 792))
+            issue_cycles = ((84 * 16 + 346 * 4) + (204 * 16 + 792 * 4) + (sig_f[0] * 16 + sig_f[1] * 4) + (sig_b[0] * 16 + sig_b[1] * 4)) * groups / n_simd if compact else None
             roof_mlp = {"bound": "instruction issue (bf16 MFMA + VALU, not overlapped)" if compact else "hbm",
                         "kernel": "mlp_fwd_pf x 2 + mlp_bwd_ws x 2 (density_net, sigma_net): the four MLP launches of a step",
                         "achieved": mlp_gbps, "peak": 8000.0, "unit": "GB/s", "frac": mlp_gbps / 8000.0,

@@ -634,7 +634,10 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 // Requires the fast input path, whole tiles (n_groups % (4 kG) == 0) and NH = 1 or 2 hidden layers.
 // COMPACT (with SAVE): one bit per hidden unit and sample for every layer, values only for the layers after the first
 // (nesvor_mlp_t.compact_save) - the launch then writes 0.47 GB instead of 0.74 GB at N = 2^20.
-template <int KB1, int NH, bool X6, bool SAVE, bool COMPACT = false>
+// OUT1 (split mode, out_dim == 1: sigma_net, b_net): the output layer is a dot product per sample - 16 fp32 FMAs per lane and
+// a sum over the four feature quads - instead of twelve MFMAs on 15/16 padding plus the 3-way split of the last hidden layer
+// (4 fragments x 14 VALU), which nothing else needs.
+template <int KB1, int NH, bool X6, bool SAVE, bool COMPACT = false, bool OUT1 = false>
 __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_pf_kernel(const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int k_in = a.k_a + a.k_b;
@@ -643,9 +646,14 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_pf_kern
   float* imgh = img1 + kHB * KB1 * kBlk;
   float* imgo = imgh + (NH - 1) * kHB * kHB * kBlk;
   float* bias = imgo + 1 * kHB * kBlk;
+  float* wout = bias + (NH + 1) * kWidth;  // OUT1: the single output row in fp32
   build_image<false, X6>(img1, a.W[0], kWidth, k_in, kHB, KB1);
   for (int l = 1; l < NH; ++l) build_image<false, X6>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, kHB, kHB);
-  build_image<false, X6>(imgo, a.W[NH], a.out_dim, kWidth, 1, kHB);
+  if constexpr (OUT1) {
+    for (int e = threadIdx.x; e < kWidth; e += blockDim.x) wout[e] = a.W[NH][e];
+  } else {
+    build_image<false, X6>(imgo, a.W[NH], a.out_dim, kWidth, 1, kHB);
+  }
   for (int e = threadIdx.x; e < (NH + 1) * kWidth; e += blockDim.x) {
     const int l = e / kWidth, o = e % kWidth;
     bias[e] = (l < NH || o < a.out_dim) ? a.b[l][o] : 0.f;
@@ -731,12 +739,30 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_pf_kern
           }
     }
     f32x4 o[kG][1];
-    {
+    if constexpr (OUT1) {
+      float part[kG];
+#pragma unroll
+      for (int g = 0; g < kG; ++g) part[g] = 0.f;
+#pragma unroll
+      for (int ob = 0; ob < kHB; ++ob) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wout + 16 * ob + 4 * q);
+#pragma unroll
+        for (int g = 0; g < kG; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[g] = fmaf(w[r], h[NH - 1][g][ob][r], part[g]);
+      }
+#pragma unroll
+      for (int g = 0; g < kG; ++g) {
+        part[g] += __shfl_xor(part[g], 16, 64);
+        part[g] += __shfl_xor(part[g], 32, 64);
+        o[g][0] = f32x4{part[g] + bias[NH * kWidth], 0.f, 0.f, 0.f};  // (only lanes q == 0 store it)
+      }
+    } else {
       const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + NH * kWidth + 4 * q);
 #pragma unroll
       for (int g = 0; g < kG; ++g) o[g][0] = bq;
+      apply_layer<kHB, 1, false, X6>(imgo, h[NH - 1], o, lane);
     }
-    apply_layer<kHB, 1, false, X6>(imgo, h[NH - 1], o, lane);
     settle_x(xr);
     if constexpr (SAVE) {
 #pragma unroll
@@ -1486,9 +1512,13 @@ __device__ __forceinline__ void accumulate_dw_planes(const float* tiles, const f
 constexpr bool kSplitDw = NESVOR_MLP_SPLIT_DW != 0;  // 0: the dW products of the split mode stay on v_mfma_f32_16x16x4_f32 (A/B builds)
 // COMPACT (nesvor_mlp_t.compact_save): the chain waves gate with the saved sign bits (one word per lane and group instead of
 // NH x 4 fragments), the dW waves recompute the first hidden layer from the network input.
-template <int KB1, int NH, bool BF16 = false, bool X6 = false, bool COMPACT = false>
+// OUT1 (split mode, out_dim == 1): the output layer's two products are rank one - d h = w_out dy and dW_out = sum_s dy_s h_s -
+// and run as fp32 VALU work (16 multiplies per lane in the chain wave, 16 FMAs in the dW wave) instead of 24 + 12 MFMAs on
+// 15/16 padding and the splits of their operands.
+template <int KB1, int NH, bool BF16 = false, bool X6 = false, bool COMPACT = false, bool OUT1 = false>
 __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   static_assert(!COMPACT || (X6 && !BF16), "compact save: split-operand mode only");
+  static_assert(!OUT1 || (X6 && !BF16), "OUT1: split-operand mode only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int k_in = a.k_a + a.k_b;
   constexpr int kT = 1 + NH * kHB;                      // tiles per group: dY, then dpre of layers NH-1 .. 0
@@ -1498,8 +1528,13 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   float* img1 = imgh + (NH - 1) * kHB * kHB * kBlk;     // W_1^T : ib = KB1, kb = 4
   float* imgf1 = img1 + KB1 * kHB * kBlk;               // COMPACT: forward image of W_1 (ob = 4, kb = KB1) and its bias
   float* bias0 = imgf1 + (COMPACT ? kHB * KB1 * kBlk : 0);
-  float* tiles = bias0 + (COMPACT ? kWidth : 0);        // [pair][buffer][kT] tiles; reused as the flush buffer
-  build_image_T<BF16, X6>(imgo, a.W[NH], a.out_dim, kWidth, kHB, 1);
+  float* wout = bias0 + (COMPACT ? kWidth : 0);         // OUT1: the single output row in fp32
+  float* tiles = wout + (OUT1 ? kWidth : 0);            // [pair][buffer][kT] tiles; reused as the flush buffer
+  if constexpr (OUT1) {
+    for (int e = threadIdx.x; e < kWidth; e += blockDim.x) wout[e] = a.W[NH][e];
+  } else {
+    build_image_T<BF16, X6>(imgo, a.W[NH], a.out_dim, kWidth, kHB, 1);
+  }
   for (int l = 1; l < NH; ++l) build_image_T<BF16, X6>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, kHB, kHB);
   build_image_T<BF16, X6>(img1, a.W[0], kWidth, k_in, KB1, kHB);
   if constexpr (COMPACT) {
@@ -1543,6 +1578,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   const int64_t g_first = wg_first + pair;
 
   f32x4 acc_o[1][kHB];
+  float acc1[kHB] = {0.f, 0.f, 0.f, 0.f};  // OUT1: dW_out of feature j of block ib, partial over this lane's sample quads (dW waves)
   f32x4 acc_h[NH > 1 ? NH - 1 : 1][kHB][kHB];
   f32x4 acc_1[kHB][KB1];
   // bias-gradient sums, kept by the chain waves in their own layout: lane (sample j, q) adds dpre[features 4q..4q+3]
@@ -1632,7 +1668,17 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
           for (int ib = 0; ib < kHB; ++ib) d[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        apply_layer_g1<1, kHB, BF16, X6, X6>(imgo, gov, d, lane);
+        if constexpr (OUT1) {
+          const float dyj = __shfl(go[0], j, 64);  // dY of sample j sits in the q = 0 lane
+#pragma unroll
+          for (int ib = 0; ib < kHB; ++ib) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wout + 16 * ib + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[ib][r] = w[r] * dyj;
+          }
+        } else {
+          apply_layer_g1<1, kHB, BF16, X6, X6>(imgo, gov, d, lane);
+        }
 #pragma unroll
         for (int l = NH - 1; l >= 0; --l) {
           Split3 ds[kHB];  // (PLANES)
@@ -1878,8 +1924,19 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
               }
             }
           } else {
+          if constexpr (OUT1) {
+            float dy4[4];
+            read_operand(buf, 0, q, dy4);                       // row 0 of the dY tile: samples 4q..4q+3 (a broadcast read)
+            read_operand(buf + kTileFloats, j, q, av);          // first dpre tile, requested ahead as below
+            __builtin_amdgcn_sched_barrier(0x047F);
+#pragma unroll
+            for (int ib = 0; ib < kHB; ++ib)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) acc1[ib] = fmaf(dy4[t], hb[NH - 1][ib][t], acc1[ib]);
+          } else {
           read_operand(buf, j, q, av);  // dY tile; every later A fragment is requested one fragment ahead (accumulate_dw_split)
           accumulate_dw_split<1, kHB>(buf, hb[NH - 1], acc_o, j, q, av, buf + kTileFloats);
+          }
 #pragma unroll
           for (int l = NH - 1; l >= 0; --l) {
             const float* dt = buf + (1 + (NH - 1 - l) * kHB) * kTileFloats;
@@ -1946,6 +2003,18 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
       if (it + 1 <= n_it) dw_iter(it + 1, hraw_b, hraw_a);
     }
   }
+  if constexpr (OUT1) {
+    // the rank-one sums in the accumulator layout the flush expects: row 0 of the (1 x 64) gradient sits in the q = 0 lanes
+    if (role == 1) {
+#pragma unroll
+      for (int ib = 0; ib < kHB; ++ib) {
+        float t = acc1[ib];
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        acc_o[0][ib] = f32x4{q == 0 ? t : 0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
   // epilogue: per-workgroup partial sums in nn.Linear parameter order W0,b0,W1,b1,... (accumulators live in waves 4-7)
   const int slot = role == 1 ? pair : -1, chain = role == 0 ? pair : -1;
   float* out = a.dW_partial + (size_t)blockIdx.x * a.total_params;
@@ -1979,7 +2048,7 @@ size_t fused_bwd_lds_bytes(int n_hidden, int kb1) {
 
 size_t fwd_lds_bytes(int n_linear, int kb1, int blk = 256) {
   const int n_hidden = n_linear - 1;
-  return sizeof(float) * ((size_t)kHB * kb1 * blk + (size_t)(n_hidden - 1) * kHB * kHB * blk + kHB * blk + (size_t)n_linear * kWidth);
+  return sizeof(float) * ((size_t)kHB * kb1 * blk + (size_t)(n_hidden - 1) * kHB * kHB * blk + kHB * blk + (size_t)n_linear * kWidth + kWidth);
 }
 size_t bwd_lds_bytes(int n_linear, int kb1) {
   const int n_hidden = n_linear - 1;
@@ -2039,6 +2108,12 @@ int fill_args(MlpArgs* a, const nesvor_mlp_t* d, int64_t N) {
   return 0;
 }
 
+// NESVOR_MLP_OUT1=0: networks with one output row keep the MFMA output layer (A/B)
+bool out1_on() {
+  static const bool on = []() { const char* e = getenv("NESVOR_MLP_OUT1"); return e == nullptr || atoi(e) != 0; }();
+  return on;
+}
+
 // Which configurations can save compactly: those the pipelined forward AND the wave-specialised backward both take in the
 // split-operand mode, with at most two input blocks (the recomputation's registers).
 bool compact_ok(const MlpArgs& a, const nesvor_mlp_t* net, int64_t N) {
@@ -2082,6 +2157,15 @@ extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, cons
     a.Hm = reinterpret_cast<uint32_t*>(saved_hidden[0]);
     a.H[0] = nullptr;
     const size_t lds = fwd_lds_bytes(a.n_linear, kb1, 384);
+    if (net->out_dim == 1 && out1_on()) {  // single output row: VALU output layer
+      if (net->n_hidden == 1)
+        return launch_kb(mlp_fwd_pf_kernel<1, 1, true, true, true, true>, mlp_fwd_pf_kernel<2, 1, true, true, true, true>,
+                         mlp_fwd_pf_kernel<2, 1, true, true, true, true>, mlp_fwd_pf_kernel<2, 1, true, true, true, true>, kb1, grid, lds,
+                         (hipStream_t)stream, a);
+      return launch_kb(mlp_fwd_pf_kernel<1, 2, true, true, true, true>, mlp_fwd_pf_kernel<2, 2, true, true, true, true>,
+                       mlp_fwd_pf_kernel<2, 2, true, true, true, true>, mlp_fwd_pf_kernel<2, 2, true, true, true, true>, kb1, grid, lds,
+                       (hipStream_t)stream, a);
+    }
     if (net->n_hidden == 1)
       return launch_kb(mlp_fwd_pf_kernel<1, 1, true, true, true>, mlp_fwd_pf_kernel<2, 1, true, true, true>, mlp_fwd_pf_kernel<2, 1, true, true, true>,
                        mlp_fwd_pf_kernel<2, 1, true, true, true>, kb1, grid, lds, (hipStream_t)stream, a);
@@ -2140,6 +2224,16 @@ extern "C" int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float*
   if (compact) {
     a.Hm = reinterpret_cast<uint32_t*>(saved_hidden[0]);
     a.H[0] = nullptr;
+    if (net->out_dim == 1 && out1_on()) {  // single output row: VALU output layer
+      const size_t lds_o = ws_bwd_lds_bytes(net->n_hidden, kb1, 384, true) + sizeof(float) * kWidth;
+      if (net->n_hidden == 1)
+        return launch_kb(mlp_bwd_ws_kernel<1, 1, false, true, true, true>, mlp_bwd_ws_kernel<2, 1, false, true, true, true>,
+                         mlp_bwd_ws_kernel<2, 1, false, true, true, true>, mlp_bwd_ws_kernel<2, 1, false, true, true, true>, kb1,
+                         dim3((unsigned)n_partial), lds_o, (hipStream_t)stream, a, 512);
+      return launch_kb(mlp_bwd_ws_kernel<1, 2, false, true, true, true>, mlp_bwd_ws_kernel<2, 2, false, true, true, true>,
+                       mlp_bwd_ws_kernel<2, 2, false, true, true, true>, mlp_bwd_ws_kernel<2, 2, false, true, true, true>, kb1,
+                       dim3((unsigned)n_partial), lds_o, (hipStream_t)stream, a, 512);
+    }
     const size_t lds_c = ws_bwd_lds_bytes(net->n_hidden, kb1, 384, true);
     if (net->n_hidden == 1)
       return launch_kb(mlp_bwd_ws_kernel<1, 1, false, true, true>, mlp_bwd_ws_kernel<2, 1, false, true, true>, mlp_bwd_ws_kernel<2, 1, false, true, true>,
