@@ -637,8 +637,11 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 // OUT1 (split mode, out_dim == 1: sigma_net, b_net): the output layer is a dot product per sample - 16 fp32 FMAs per lane and
 // a sum over the four feature quads - instead of twelve MFMAs on 15/16 padding plus the 3-way split of the last hidden layer
 // (4 fragments x 14 VALU), which nothing else needs.
+#ifndef NESVOR_FWD_MINBLOCKS
+#define NESVOR_FWD_MINBLOCKS 2
+#endif
 template <int KB1, int NH, bool X6, bool SAVE, bool COMPACT = false, bool OUT1 = false>
-__global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_pf_kernel(const MlpArgs a) {
+__global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) void mlp_fwd_pf_kernel(const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int k_in = a.k_a + a.k_b;
   constexpr int kBlk = X6 ? 384 : 256;
