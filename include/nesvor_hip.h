@@ -245,6 +245,11 @@ int nesvor_psf_transform_backward(const float* mat, const int64_t* slice_idx, co
 int nesvor_psf_transform_forward_rng(const float* mat, const int64_t* slice_idx, const float* xyz, const float* sigma,
                                      uint64_t seed, uint64_t offset, const float* bb, float* x, float* u, int B, int S,
                                      void* stream);
+/* The same launch also gathers se[b, :] = embedding[slice_idx[b], :] ((B, ks); ks = 0: nothing) - the per-pixel input of
+ * sigma_net / b_net of the training step (the `slice_embedding(slice_idx)` lookup of nesvor/nesvor/models.py:281). */
+int nesvor_psf_transform_forward_rng_gather(const float* mat, const int64_t* slice_idx, const float* xyz, const float* sigma,
+                                            uint64_t seed, uint64_t offset, const float* bb, float* x, float* u, int B, int S,
+                                            const float* embedding, float* se, int ks, void* stream);
 int nesvor_psf_transform_backward_rng(const float* mat, const int64_t* slice_idx, const float* xyz, const float* sigma,
                                       uint64_t seed, uint64_t offset, const float* bb, const float* dx, const float* du,
                                       float* dmat, int B, int S, void* stream);
@@ -396,6 +401,9 @@ int nesvor_hashgrid_backward_adamw(const nesvor_grid_t* grid, const float* u, fl
  * dw_partial of nesvor_mlp_backward (the `partial.sum(0)` of the host side) straight into a gradient segment; with
  * ld > cols, a column range of it (one layer's weights when the model keeps no biases, tinycudann.Network). */
 int nesvor_sum_rows(const float* in, float* out, int rows, int cols, int ld, void* stream);
+/* n_jobs <= 4 of those sums (same number of rows) in one launch; in / out / cols / ld: host arrays of n_jobs entries. */
+int nesvor_sum_rows_multi(const float* const* in, float* const* out, const int* cols, const int* ld, int n_jobs, int rows,
+                          void* stream);
 
 /* ------------------------------------------------------------------------
  * One training iteration behind one entry point (csrc/step.hip).  Replaces the loop body of the reference's train()
@@ -406,8 +414,9 @@ int nesvor_sum_rows(const float* in, float* out, int rows, int cols, int ld, voi
  *   switches   : opt_T = !no_transformation_optimization, has_lv = !no_pixel_variance, has_c = !no_slice_scale,
  *                has_lvs = !no_slice_variance, has_b = n_levels_bias > 0 (cli/main.py:61,86-110)
  *   small      : n (1 + 12 + 13) + 1 floats: slice scale c | pose matrices | zeroed accumulators [dc | dmat] | max |dpe|
- *   saved_*    : per hidden layer N_pad16 * 64 floats (nesvor_mlp_forward);  partial: NESVOR_STEP_MLP_PARTIALS x (largest
- *                network's parameter count) floats;  losses (run argument): 6 floats {MSE, logVar, MSE+logVar, transReg,
+ *   saved_*    : per hidden layer N_pad16 * 64 floats (nesvor_mlp_forward; slot 0 of a network with compact_save: 4 N_pad16
+ *                floats);  partial: 3 x NESVOR_STEP_MLP_PARTIALS x (largest network's parameter count) floats - one third per
+ *                network, summed by one nesvor_sum_rows_multi launch;  losses (run argument): 6 floats {MSE, logVar, MSE+logVar, transReg,
  *                imageReg, biasReg} (models.py:14-19)
  *   queue_scale: HOST array (nesvor_hashgrid_backward);  side_stream: a second stream of the same device (pose regulariser,
  *                owner pass of the hash-grid backward); with overlap_owner the table gradient is complete only behind the

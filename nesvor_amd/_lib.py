@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NESVOR_HIP_LIB: load another build of the same ABI (tools/ablate_hashgrid.py times variants of one kernel this way)
 LIB_PATH = os.environ.get("NESVOR_HIP_LIB") or os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 28
+ABI_VERSION = 30
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -128,6 +128,7 @@ _SIGNATURES = {
     "nesvor_hashgrid_backward_atomic": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P], c_int),
     "nesvor_psf_transform_forward": ([_P] * 8 + [c_int, c_int, _P], c_int),
     "nesvor_psf_transform_backward": ([_P] * 9 + [c_int, c_int, _P], c_int),
+    "nesvor_psf_transform_forward_rng_gather": ([_P] * 4 + [c_uint64, c_uint64] + [_P] * 3 + [c_int, c_int, _P, _P, c_int, _P], c_int),
     "nesvor_psf_transform_forward_rng": ([_P] * 4 + [c_uint64, c_uint64] + [_P] * 3 + [c_int, c_int, _P], c_int),
     "nesvor_psf_transform_backward_rng": ([_P] * 4 + [c_uint64, c_uint64] + [_P] * 4 + [c_int, c_int, _P], c_int),
     "nesvor_psf_noise": ([c_uint64, c_uint64, _P, c_int64, _P], c_int),
@@ -150,6 +151,7 @@ _SIGNATURES = {
         [_P, _P, _P, _P, c_int64] + [c_float] * 8 + [c_int, _P],
         c_int,
     ),
+    "nesvor_sum_rows_multi": ([_P, _P, _P, _P, c_int, c_int, _P], c_int),
     "nesvor_sum_rows": ([_P, _P, c_int, c_int, c_int, _P], c_int),
     "nesvor_step_create": ([POINTER(StepT)], c_void_p),
     "nesvor_step_update": ([_P, POINTER(StepT)], c_int),

@@ -90,4 +90,59 @@ extern "C" int nesvor_sum_rows(const float* in, float* out, int rows, int cols, 
   return (int)hipGetLastError();
 }
 
-extern "C" int nesvor_hip_abi_version(void) { return 28; }
+// Up to four of those sums in ONE launch (the partial gradients of the step's networks, summed after the last backward).
+namespace {
+struct SumJobs {
+  const float* in[4];
+  float* out[4];
+  int cols[4], ld[4], first_block[5];
+  int rows;
+};
+__global__ __launch_bounds__(64 * kSumRowGroups) void sum_rows_multi_kernel(const SumJobs jobs) {
+  __shared__ float red[kSumRowGroups][64];
+  int job = 0;
+  while (job < 3 && (int)blockIdx.x >= jobs.first_block[job + 1]) ++job;
+  const float* __restrict__ in = jobs.in[job];
+  const int cols = jobs.cols[job], ld = jobs.ld[job], rows = jobs.rows;
+  const int lane = threadIdx.x & 63, col = ((int)blockIdx.x - jobs.first_block[job]) * 64 + lane, rg = threadIdx.x >> 6;
+  float a0 = 0.f, a1 = 0.f;
+  if (col < cols) {
+    int r = rg;
+    for (; r + kSumRowGroups < rows; r += 2 * kSumRowGroups) {
+      a0 += in[(size_t)r * ld + col]; a1 += in[(size_t)(r + kSumRowGroups) * ld + col];
+    }
+    for (; r < rows; r += kSumRowGroups) a0 += in[(size_t)r * ld + col];
+  }
+  red[rg][lane] = a0 + a1;
+  __syncthreads();
+  if (rg == 0 && col < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < kSumRowGroups; ++g) s += red[g][lane];
+    jobs.out[job][col] = s;
+  }
+}
+}  // namespace
+
+extern "C" int nesvor_sum_rows_multi(const float* const* in, float* const* out, const int* cols, const int* ld, int n_jobs, int rows,
+                                     void* stream) {
+  if (n_jobs <= 0 || rows <= 0) return 0;
+  if (n_jobs > 4) return (int)hipErrorInvalidValue;
+  SumJobs j{};
+  int blocks = 0;
+  for (int k = 0; k < 4; ++k) {
+    j.first_block[k] = blocks;
+    if (k < n_jobs) {
+      if (cols[k] <= 0 || ld[k] < cols[k]) return (int)hipErrorInvalidValue;
+      j.in[k] = in[k]; j.out[k] = out[k]; j.cols[k] = cols[k]; j.ld[k] = ld[k];
+      blocks += (cols[k] + 63) / 64;
+    }
+  }
+  j.first_block[4] = blocks;
+  for (int k = n_jobs; k < 4; ++k) j.first_block[k] = blocks;  // (unused jobs own no block)
+  j.rows = rows;
+  hipLaunchKernelGGL(sum_rows_multi_kernel, dim3((unsigned)blocks), dim3(64 * kSumRowGroups), 0, (hipStream_t)stream, j);
+  return (int)hipGetLastError();
+}
+
+extern "C" int nesvor_hip_abi_version(void) { return 30; }

@@ -59,11 +59,16 @@ __global__ __launch_bounds__(256) void psf_noise_kernel(NoiseSource src, float* 
 __global__ __launch_bounds__(256) void psf_transform_fwd(const float* __restrict__ mat, const int64_t* __restrict__ slice_idx,
                                                          const float* __restrict__ xyz, const float* __restrict__ sigma,
                                                          const NoiseSource noise, const float* __restrict__ bb,
-                                                         float* __restrict__ x, float* __restrict__ u, int B, int S) {
+                                                         float* __restrict__ x, float* __restrict__ u, int B, int S,
+                                                         const float* __restrict__ emb = nullptr, float* __restrict__ se = nullptr, int ks = 0) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const int64_t k = slice_idx[b];
+  // optional: the pixel's row of the slice embedding (the per-pixel input of sigma_net / b_net), gathered by the wave that
+  // looks the slice up anyway - one launch less per training iteration
+  if (se != nullptr)
+    for (int c = lane; c < ks; c += 64) se[(size_t)b * ks + c] = emb[(size_t)k * ks + c];
   const float* m = mat + k * 12;
   const float r00 = m[0], r01 = m[1], r02 = m[2], t0 = m[3];
   const float r10 = m[4], r11 = m[5], r12 = m[6], t1 = m[7];
@@ -158,6 +163,18 @@ extern "C" int nesvor_psf_transform_forward_rng(const float* mat, const int64_t*
   if (B <= 0 || S <= 0) return 0;
   hipLaunchKernelGGL(psf_transform_fwd, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, mat, slice_idx, xyz, sigma,
                      NoiseSource{nullptr, seed, offset}, bb, x, u, B, S);
+  return (int)hipGetLastError();
+}
+
+// nesvor_psf_transform_forward_rng that also gathers se[b, :] = embedding[slice_idx[b], :] (B, ks)
+extern "C" int nesvor_psf_transform_forward_rng_gather(const float* mat, const int64_t* slice_idx, const float* xyz,
+                                                       const float* sigma, uint64_t seed, uint64_t offset, const float* bb,
+                                                       float* x, float* u, int B, int S, const float* embedding, float* se, int ks,
+                                                       void* stream) {
+  if (B <= 0 || S <= 0) return 0;
+  if (ks > 0 && (embedding == nullptr || se == nullptr)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(psf_transform_fwd, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, mat, slice_idx, xyz, sigma,
+                     NoiseSource{nullptr, seed, offset}, bb, x, u, B, S, embedding, ks > 0 ? se : nullptr, ks);
   return (int)hipGetLastError();
 }
 

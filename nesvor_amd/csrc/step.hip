@@ -29,14 +29,6 @@ struct StepCtx {
   bool pending_join = false;  // a table update of the previous run is still on the side stream (NESVOR_STEP_DEFER_JOIN)
 };
 
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx,
-                                                          float* __restrict__ out, int B, int k) {
-  const int i = blockIdx.x * 256 + threadIdx.x;  // one float per thread
-  if (i >= B * k) return;
-  const int b = i / k, c = i - b * k;
-  out[i] = table[(size_t)idx[b] * k + c];
-}
-
 // out[0] = mean(x[0..n)) in two launches (deterministic order): partial sums of 256 workgroups, then one wave
 __global__ __launch_bounds__(256) void mean_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
   __shared__ float red[256];
@@ -88,9 +80,10 @@ int mlp_backward_into(const nesvor_mlp_t& net, int group_sums, const float* xa, 
   nesvor_mlp_t d = net;
   d.dxa_group_sums = group_sums;
   float* no_scratch[NESVOR_MAX_MLP_LAYERS] = {nullptr, nullptr, nullptr, nullptr};  // fused dX + dW + db kernel: no dpre scratch
-  NESVOR_TRY(nesvor_mlp_backward_bounded(&d, xa, xb, dy, saved, no_scratch, dxa, dxb, partial, NESVOR_STEP_MLP_PARTIALS, N, dxb_absmax, st));
-  // per-workgroup partial sums (columns W0,b0,W1,b1,...) -> the network's segment of the flat gradient
-  return nesvor_sum_rows(partial, grad_segment, NESVOR_STEP_MLP_PARTIALS, n_params, n_params, st);
+  // per-workgroup partial sums (columns W0,b0,W1,b1,...); the caller sums them into the network's segment of the flat gradient
+  // (ONE launch for all networks of the step, after the last backward: nesvor_sum_rows_multi)
+  (void)grad_segment; (void)n_params;
+  return nesvor_mlp_backward_bounded(&d, xa, xb, dy, saved, no_scratch, dxa, dxb, partial, NESVOR_STEP_MLP_PARTIALS, N, dxb_absmax, st);
 }
 
 }  // namespace
@@ -158,16 +151,14 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
     }
     // ---- forward
     NESVOR_TRY(nesvor_step_prologue(d.has_c ? d.logit_coef : nullptr, c, d.axisangle, mat, acc, 13 * n + 1, n, main));
-    NESVOR_TRY(nesvor_psf_transform_forward_rng(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.x, d.u, B, S, main));
+    NESVOR_TRY(nesvor_psf_transform_forward_rng_gather(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.x, d.u, B, S,
+                                                       d.ks > 0 ? d.slice_embedding : nullptr, d.ks > 0 ? d.se : nullptr, d.ks, main));
     if (ctx->pending_join) {  // the previous run left its table update on the side stream
       if (hipStreamWaitEvent(main, ctx->ev_owner, 0) != hipSuccess) return (int)hipGetLastError();
       ctx->pending_join = false;
     }
     NESVOR_TRY(nesvor_hashgrid_forward(&d.grid, d.u, d.table, d.pe, N, layout | (S >= 128 ? NESVOR_LAYOUT_CLUSTERED : 0), main));
     NESVOR_TRY(nesvor_mlp_forward(&d.density, nullptr, d.pe, d.z, d.saved_d, N, main));
-    if (d.ks > 0) {
-      hipLaunchKernelGGL(gather_rows_kernel, dim3((B * d.ks + 255) / 256), dim3(256), 0, main, d.slice_embedding, slice_idx, d.se, B, d.ks);
-    }
     if (d.has_b) {
       NESVOR_TRY(nesvor_mlp_forward(&d.bias_net, d.se, d.pe, d.log_bias, d.saved_b, N, main));
       hipLaunchKernelGGL(mean_partial_kernel, dim3(256), dim3(256), 0, main, d.log_bias, N, d.mean_scratch);
@@ -191,16 +182,31 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
     NESVOR_TRY(nesvor_imaging_loss(&la, main));
     // ---- backward through the networks
     const int group_sums = (N % 16 == 0 && S % 16 == 0 && d.ks % 16 == 0) ? 1 : 0;
+    // every network writes its per-workgroup partial parameter gradients into its own third of `partial` (the host allocates
+    // 3 x NESVOR_STEP_MLP_PARTIALS rows of the widest network)
+    int widest = d.n_density_params;
+    if (d.has_lv && d.n_sigma_params > widest) widest = d.n_sigma_params;
+    if (d.has_b && d.n_bias_params > widest) widest = d.n_bias_params;
+    float* part_d = d.partial;
+    float* part_s = d.partial + (size_t)NESVOR_STEP_MLP_PARTIALS * widest;
+    float* part_b = d.partial + 2 * (size_t)NESVOR_STEP_MLP_PARTIALS * widest;
     if (d.has_lv)
-      NESVOR_TRY(mlp_backward_into(d.sigma, group_sums, d.se, d.z, d.dlv, d.saved_s, d.ks ? d.dxa : nullptr, d.dz + N, d.partial,
+      NESVOR_TRY(mlp_backward_into(d.sigma, group_sums, d.se, d.z, d.dlv, d.saved_s, d.ks ? d.dxa : nullptr, d.dz + N, part_s,
                                    d.g_sigma, d.n_sigma_params, N, main));
-    NESVOR_TRY(mlp_backward_into(d.density, 0, nullptr, d.pe, d.dz, d.saved_d, nullptr, d.dpe, d.partial, d.g_density,
+    NESVOR_TRY(mlp_backward_into(d.density, 0, nullptr, d.pe, d.dz, d.saved_d, nullptr, d.dpe, part_d, d.g_density,
                                  d.n_density_params, N, main, dpe_bound));
     if (d.has_b) {
-      NESVOR_TRY(mlp_backward_into(d.bias_net, group_sums, d.se, d.pe, d.dlb, d.saved_b, d.ks ? d.dxa_b : nullptr, d.dpe_b, d.partial,
+      NESVOR_TRY(mlp_backward_into(d.bias_net, group_sums, d.se, d.pe, d.dlb, d.saved_b, d.ks ? d.dxa_b : nullptr, d.dpe_b, part_b,
                                    d.g_bias_net, d.n_bias_params, N, main));
       const int64_t nb = (int64_t)d.kb_bias * N;
       hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((nb / 4 + 255) / 256 + 1)), dim3(256), 0, main, d.dpe, d.dpe_b, nb);
+    }
+    {
+      const float* in[3]; float* out[3]; int cols[3], n_jobs = 0;
+      in[n_jobs] = part_d; out[n_jobs] = d.g_density; cols[n_jobs++] = d.n_density_params;
+      if (d.has_lv) { in[n_jobs] = part_s; out[n_jobs] = d.g_sigma; cols[n_jobs++] = d.n_sigma_params; }
+      if (d.has_b) { in[n_jobs] = part_b; out[n_jobs] = d.g_bias_net; cols[n_jobs++] = d.n_bias_params; }
+      NESVOR_TRY(nesvor_sum_rows_multi(in, out, cols, cols, n_jobs, NESVOR_STEP_MLP_PARTIALS, main));
     }
   }
   // ---- hash-grid backward (+ input gradient when the poses are optimised)

@@ -229,7 +229,7 @@ class DirectStep:
         d.small = new("small", n * 26 + 1)
         d.x, d.u, d.pe, d.z, d.dz, d.dpe = new("x", B, S, 3), new("u", N, 3), new("pe", E, N), new("z", zr, N), new("dz", zr, N), new("dpe", E, N)
         d.loss_pix, d.pix = new("loss_pix", B, 3), new("pix", 2, B)
-        d.partial = new("partial", 256, largest)
+        d.partial = new("partial", 3 * 256, largest)  # per-workgroup partial parameter gradients: one third per network
         def saved_buffers(net_desc, slots, tag, n_hidden):
             # saved activations of one network; compact save where the kernels allow it (mlp.saved_sizes: sign bits in slot 0)
             sizes = mlp_mod.saved_sizes(net_desc, N, n_hidden)

@@ -490,9 +490,11 @@ def test_native_step_table_update_in_owner_pass_and_deferred_join(device, golden
         models.append(NeSVoR(tf, res, float(golden["ds_mean"]), bbox, args))
         models[-1].load_state_dict(models[0].state_dict())
     ta, tb, tc = (FusedTrainer(m, args) for m in models)
+    if not all(t.direct is not None and t.direct.native_ready() for t in (ta, tb, tc)):
+        pytest.skip("the one-call step is switched off (NESVOR_STEP_NATIVE=0)")
     ta.direct._adamw_in_owner = False
+    tb.direct._adamw_in_owner = tc.direct._adamw_in_owner = True  # (whatever NESVOR_ADAMW_IN_OWNER says)
     tc.defer_table_join = True
-    assert all(t.direct is not None and t.direct.native_ready() for t in (ta, tb, tc)) and tb.direct._adamw_in_owner
     d = lambda k: torch.tensor(golden[f"fw_{k}"]).to(device)
     for it in range(5):
         ls = [t.step(d("xyz"), d("v"), d("idx")) for t in (ta, tb, tc)]
@@ -545,7 +547,9 @@ def test_one_call_step_equals_python_issued_step(device, golden, over):
     t1, t2 = FusedTrainer(m1, args), FusedTrainer(m2, args)
     assert t1.direct is not None and t2.direct is not None
     t2.direct._native_on = False
-    assert t1.direct.native_ready() and not t2.direct.native_ready()
+    if not t1.direct.native_ready():
+        pytest.skip("the one-call step is switched off (NESVOR_STEP_NATIVE=0)")
+    assert not t2.direct.native_ready()
     d = lambda k: torch.tensor(golden[f"fw_{k}"]).to(device)
     # (1) gradients of one iteration, no optimizer: the owner pass of the hash-grid backward sums records in arrival order,
     # so even two runs of ONE path differ in the last bits of the table gradient - 1e-5 of the largest entry
