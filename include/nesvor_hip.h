@@ -365,6 +365,12 @@ int nesvor_step_epilogue(const float* dc, const float* c, float* dlogit, const f
 int nesvor_slice_grads(const int64_t* slice_idx, const float* dc_pix, const float* dlvs_pix, const float* dxa,
                        const float* dpix, float* dc, float* dlvs, float* dse, float* dmat, int B, int S, int ks,
                        void* stream);
+/* The same sums without atomics: one workgroup per slice lists the batch's pixels of its slice (in batch order: reproducible
+ * sums) and adds their totals to the outputs it alone owns.  Needs B <= 4096 and 256 % ks == 0 (or dxa == NULL); returns
+ * hipErrorInvalidValue (= 1) otherwise, and the caller falls back to nesvor_slice_grads. */
+int nesvor_slice_grads_by_slice(const int64_t* slice_idx, const float* dc_pix, const float* dlvs_pix, const float* dxa,
+                                const float* dpix, float* dc, float* dlvs, float* dse, float* dmat, int B, int S, int ks,
+                                int n_slices, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused AdamW over a flat fp32 parameter buffer.  Replaces the

@@ -318,6 +318,87 @@ __global__ __launch_bounds__(256) void slice_grads_kernel(const int64_t* __restr
 
 }  // namespace
 
+// The same sums with ONE workgroup per slice and no global atomics: the workgroup scans the batch's slice indices (B x 8
+// bytes, from L2), lists the pixels of its slice in LDS - in batch order, by ballots and prefix counts, so that the sums are
+// reproducible - and sums their contributions: the 14 scalars of a pixel by one thread each, the slice-embedding gradient
+// by feature and row group; then it ADDS the totals to the outputs it alone owns.  B x 30 fp32 atomics on a few hundred
+// addresses (23 us at B = 4096, twice that next to the owner pass of the hash-grid backward) become a few microseconds of reads.
+// Needs B <= kSliceListMax and 256 % ks == 0 (or no dxa); nesvor_slice_grads_by_slice returns hipErrorInvalidValue otherwise and
+// the caller uses the atomic kernel.
+namespace {
+constexpr int kSliceListMax = 4096;
+__global__ __launch_bounds__(256) void slice_grads_by_slice_kernel(const int64_t* __restrict__ slice_idx, const float* __restrict__ dc_pix,
+                                                                   const float* __restrict__ dlvs_pix, const float* __restrict__ dxa,
+                                                                   const float* __restrict__ dpix, float* dc, float* dlvs, float* dse,
+                                                                   float* dmat, int B, int S, int ks) {
+  __shared__ int list[kSliceListMax];
+  __shared__ int wcount[4];
+  __shared__ float red[256];
+  const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int M = 0;  // pixels of slice k found so far (uniform)
+  for (int base = 0; base < B; base += 256) {
+    const int b = base + tid;
+    const bool hit = b < B && slice_idx[b] == (int64_t)k;
+    const unsigned long long bal = __ballot(hit);
+    if (lane == 0) wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int off = M;
+    for (int w = 0; w < wave; ++w) off += wcount[w];
+    if (hit) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = b;
+    M += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    __syncthreads();
+  }
+  if (M == 0) return;
+  {
+    // the 14 scalars of a pixel (dc, dlvs, dmat[12]): thread (component c, pixel lane p) sums every 16th listed pixel, the 16
+    // partial sums of a component are then added in a fixed order
+    const int c = tid >> 4, p = tid & 15;
+    float a = 0.f;
+    if (c < 14) {
+      const float* src = c == 0 ? dc_pix : (c == 1 ? dlvs_pix : dpix);
+      if (src != nullptr) {
+#pragma unroll 4
+        for (int m = p; m < M; m += 16) a += c < 2 ? src[list[m]] : src[(size_t)list[m] * 12 + (c - 2)];
+      }
+    }
+    red[tid] = a;
+    __syncthreads();
+    if (tid < 14) {
+      float t = 0.f;
+      for (int q = 0; q < 16; ++q) t += red[tid * 16 + q];
+      if (tid == 0) { if (dc_pix != nullptr) dc[k] += t; }
+      else if (tid == 1) { if (dlvs_pix != nullptr) dlvs[k] += t; }
+      else if (dpix != nullptr) dmat[(size_t)k * 12 + (tid - 2)] += t;
+    }
+    __syncthreads();
+  }
+  if (dxa == nullptr || ks <= 0) return;
+  const int f = tid % ks, rg = tid / ks, nrg = 256 / ks;
+  float a = 0.f;
+  for (int r = rg; r < S; r += nrg) {
+#pragma unroll 8
+    for (int m = 0; m < M; ++m) a += dxa[((size_t)list[m] * S + r) * ks + f];  // independent loads: many in flight
+  }
+  red[tid] = a;
+  __syncthreads();
+  if (tid < ks) {
+    float t = 0.f;
+    for (int g = 0; g < nrg; ++g) t += red[g * ks + tid];
+    dse[(size_t)k * ks + tid] += t;
+  }
+}
+}  // namespace
+
+extern "C" int nesvor_slice_grads_by_slice(const int64_t* slice_idx, const float* dc_pix, const float* dlvs_pix, const float* dxa,
+                                           const float* dpix, float* dc, float* dlvs, float* dse, float* dmat, int B, int S, int ks,
+                                           int n_slices, void* stream) {
+  if (B <= 0 || n_slices <= 0) return 0;
+  if (B > kSliceListMax || (dxa != nullptr && ks > 0 && (ks > 256 || 256 % ks != 0))) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(slice_grads_by_slice_kernel, dim3((unsigned)n_slices), dim3(256), 0, (hipStream_t)stream, slice_idx, dc_pix, dlvs_pix,
+                     dxa, dpix, dc, dlvs, dse, dmat, B, S, ks);
+  return (int)hipGetLastError();
+}
+
 extern "C" int nesvor_slice_grads(const int64_t* slice_idx, const float* dc_pix, const float* dlvs_pix, const float* dxa,
                                   const float* dpix, float* dc, float* dlvs, float* dse, float* dmat, int B, int S, int ks,
                                   void* stream) {

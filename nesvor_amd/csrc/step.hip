@@ -17,6 +17,7 @@
 // no_slice_scale, no_slice_variance, n_levels_bias).  Data-parallel runs call the step in two phases so that the host
 // can start the all-reduce of the fine levels' gradient in between (nesvor_amd/ddp.py).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include "../../include/nesvor_hip.h"
@@ -253,11 +254,22 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   const int group_sums = (N % 16 == 0 && S % 16 == 0 && d.ks % 16 == 0) ? 1 : 0;
   const int rows_per_pixel = group_sums ? S / 16 : S;
   const float* dxa_first = (d.has_lv && d.ks) ? d.dxa : ((d.has_b && d.ks) ? d.dxa_b : nullptr);
-  NESVOR_TRY(nesvor_slice_grads(slice_idx, d.has_c ? d.pix : nullptr, d.has_lvs ? d.pix + B : nullptr, dxa_first, d.opt_T ? d.dpix : nullptr, dc,
-                                d.has_lvs ? d.g_log_var_slice : nullptr, d.ks ? d.g_slice_embedding : nullptr, dmat, B, rows_per_pixel, d.ks, main));
+  // NESVOR_SLICE_GRADS=by_slice: one workgroup per slice, no atomics, reproducible sums (where the batch fits its pixel list).
+  // Default: the per-pixel atomic kernel - measured 1.136-1.140 ms per iteration against 1.152-1.160: a few hundred workgroups
+  // with serial sums start behind the owner pass's workgroups and finish later (61 us) than 4096 x 30 contended atomics (46 us)
+  auto slice_grads = [&](const float* dc_pix, const float* dlvs_pix, const float* dxa, const float* dpix, float* dc_, float* dlvs_,
+                         float* dse_, float* dmat_) -> int {
+    static const bool by_slice = []() { const char* e = getenv("NESVOR_SLICE_GRADS"); return e != nullptr && strcmp(e, "by_slice") == 0; }();
+    if (by_slice) {
+      const int e = nesvor_slice_grads_by_slice(slice_idx, dc_pix, dlvs_pix, dxa, dpix, dc_, dlvs_, dse_, dmat_, B, rows_per_pixel, d.ks, n, main);
+      if (e != (int)hipErrorInvalidValue) return e;
+    }
+    return nesvor_slice_grads(slice_idx, dc_pix, dlvs_pix, dxa, dpix, dc_, dlvs_, dse_, dmat_, B, rows_per_pixel, d.ks, main);
+  };
+  NESVOR_TRY(slice_grads(d.has_c ? d.pix : nullptr, d.has_lvs ? d.pix + B : nullptr, dxa_first, d.opt_T ? d.dpix : nullptr, dc,
+                         d.has_lvs ? d.g_log_var_slice : nullptr, d.ks ? d.g_slice_embedding : nullptr, dmat));
   if (d.has_lv && d.has_b && d.ks)  // second consumer of the slice embedding
-    NESVOR_TRY(nesvor_slice_grads(slice_idx, nullptr, nullptr, d.dxa_b, nullptr, nullptr, nullptr, d.g_slice_embedding, nullptr, B, rows_per_pixel,
-                                  d.ks, main));
+    NESVOR_TRY(slice_grads(nullptr, nullptr, d.dxa_b, nullptr, nullptr, nullptr, d.g_slice_embedding, nullptr));
   if (d.opt_T && hipStreamWaitEvent(main, ctx->ev_pose, 0) != hipSuccess) return (int)hipGetLastError();
   const float img_scale = (d.reg_type == 0 ? d.delta : 1.f) / (float)N, img_off = d.reg_type == 0 ? -d.delta : 0.f;
   NESVOR_TRY(nesvor_step_epilogue(d.has_c ? dc : nullptr, c, d.has_c ? d.g_logit_coef : nullptr, d.opt_T ? dmat : nullptr, d.axisangle,

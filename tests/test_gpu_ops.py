@@ -1272,6 +1272,31 @@ def test_step_bookkeeping_kernels(device):
     torch.testing.assert_close(dmat, torch.zeros(n, 3, 4, device=device).index_add_(0, idx, dpix), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(dse, torch.zeros(n, ks, device=device).index_add_(0, idx, dxa.view(B, -1, ks).sum(1)), rtol=1e-4, atol=1e-4)
 
+    # the atomic-free variant (one workgroup per slice, pixel list in batch order): same sums, twice the same bits; ADDS to
+    # what the outputs hold; also with one slice owning every pixel, with missing parts, and with a batch larger than one
+    # 256-pixel scan chunk; refuses what it cannot list
+    for trial, (idx2, Bt) in enumerate(((idx, B), (torch.full((B,), 5, device=device), B), (torch.randint(0, n, (1000,), device=device), 1000))):
+        dcp, dlp = torch.randn(Bt, device=device), torch.randn(Bt, device=device)
+        dx2, dp2 = torch.randn(Bt * S // 16, ks, device=device), torch.randn(Bt, 3, 4, device=device)
+        outs = []
+        for rep in range(2):
+            o = [torch.ones(n, device=device), torch.ones(n, device=device), torch.ones(n, ks, device=device), torch.ones(n, 3, 4, device=device)]
+            assert lib.nesvor_slice_grads_by_slice(_lib.ptr(idx2), _lib.ptr(dcp), _lib.ptr(dlp), _lib.ptr(dx2), _lib.ptr(dp2), _lib.ptr(o[0]),
+                                                   _lib.ptr(o[1]), _lib.ptr(o[2]), _lib.ptr(o[3]), Bt, S // 16, ks, n, st) == 0
+            outs.append(o)
+        for a_, b_ in zip(outs[0], outs[1]):
+            assert torch.equal(a_, b_)
+        o = outs[0]
+        torch.testing.assert_close(o[0], torch.ones(n, device=device).index_add_(0, idx2, dcp), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(o[1], torch.ones(n, device=device).index_add_(0, idx2, dlp), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(o[3], torch.ones(n, 3, 4, device=device).index_add_(0, idx2, dp2), rtol=1e-5, atol=2e-5)
+        torch.testing.assert_close(o[2], torch.ones(n, ks, device=device).index_add_(0, idx2, dx2.view(Bt, -1, ks).sum(1)), rtol=1e-4, atol=2e-4)
+    only_se = torch.zeros(n, ks, device=device)
+    assert lib.nesvor_slice_grads_by_slice(_lib.ptr(idx), None, None, _lib.ptr(dxa), None, None, None, _lib.ptr(only_se), None, B, S // 16, ks, n, st) == 0
+    torch.testing.assert_close(only_se, torch.zeros(n, ks, device=device).index_add_(0, idx, dxa.view(B, -1, ks).sum(1)), rtol=1e-4, atol=1e-4)
+    assert lib.nesvor_slice_grads_by_slice(_lib.ptr(idx), None, None, _lib.ptr(dxa), None, None, None, _lib.ptr(only_se), None, 5000, 1, ks, n, st) == 1
+    assert lib.nesvor_slice_grads_by_slice(_lib.ptr(idx), None, None, _lib.ptr(dxa), None, None, None, _lib.ptr(only_se), None, B, 1, 24, n, st) == 1
+
     logit = torch.randn(n, device=device)
     ax = torch.randn(n, 6, device=device) * torch.tensor([0.5, 0.5, 0.5, 3, 3, 3], device=device)
     c, mat, zb = torch.empty(n, device=device), torch.empty(n, 3, 4, device=device), torch.ones(50, device=device)
