@@ -279,6 +279,16 @@ __global__ __launch_bounds__(1024) void step_prologue_kernel(const float* __rest
                                                             const float* __restrict__ axisangle, float* __restrict__ mat,
                                                             float* __restrict__ zero_buf, int n_zero, int n) {
   __shared__ float red[16];
+  // (grid = 3: softmax | pose matrices | zero-fill, one workgroup each)
+  if (blockIdx.x == 1) {
+    if (axisangle != nullptr)
+      for (int i = threadIdx.x; i < n; i += blockDim.x) ax2mat_fwd_one(axisangle + (size_t)i * 6, mat + (size_t)i * 12);
+    return;
+  }
+  if (blockIdx.x == 2) {
+    for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_buf[i] = 0.f;
+    return;
+  }
   if (logit_coef != nullptr) {
     float mx = -INFINITY;
     for (int i = threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, logit_coef[i]);
@@ -294,9 +304,6 @@ __global__ __launch_bounds__(1024) void step_prologue_kernel(const float* __rest
     const float scale = (float)n / se;
     for (int i = threadIdx.x; i < n; i += blockDim.x) c[i] = expf(logit_coef[i] - mx) * scale;
   }
-  if (axisangle != nullptr)
-    for (int i = threadIdx.x; i < n; i += blockDim.x) ax2mat_fwd_one(axisangle + (size_t)i * 6, mat + (size_t)i * 12);
-  for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_buf[i] = 0.f;
 }
 
 __global__ __launch_bounds__(1024) void step_epilogue_kernel(const float* __restrict__ dc, const float* __restrict__ c,
@@ -306,30 +313,37 @@ __global__ __launch_bounds__(1024) void step_epilogue_kernel(const float* __rest
                                                             const float* __restrict__ loss_pix, const float* __restrict__ trans_terms,
                                                             float* __restrict__ losses, int n, int B, float inv_B, float img_scale,
                                                             float img_offset) {
+  // three independent pieces, one workgroup each (grid = 3): five block reductions in a row were 10-13 us on the branch that
+  // decides when the next iteration can start
   __shared__ float red[16];
-  if (dc != nullptr) {  // c = n softmax(l):  dl = c (dc - <dc, c> / n)
-    float dot = 0.f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dot += dc[i] * c[i];
-    dot = block_sum_1024(dot, red) / (float)n;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dlogit[i] = c[i] * (dc[i] - dot);
-  }
-  float tr = 0.f;
-  if (dmat != nullptr) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      float g[6];
-      ax2mat_bwd_one(dmat + (size_t)i * 12, axisangle + (size_t)i * 6, g);
-#pragma unroll
-      for (int d = 0; d < 6; ++d) daxisangle[(size_t)i * 6 + d] = g[d] + w_trans * dtrans[(size_t)i * 6 + d];
-      tr += trans_terms[i];
+  if (blockIdx.x == 0) {
+    if (dc != nullptr) {  // c = n softmax(l):  dl = c (dc - <dc, c> / n)
+      float dot = 0.f;
+      for (int i = threadIdx.x; i < n; i += blockDim.x) dot += dc[i] * c[i];
+      dot = block_sum_1024(dot, red) / (float)n;
+      for (int i = threadIdx.x; i < n; i += blockDim.x) dlogit[i] = c[i] * (dc[i] - dot);
     }
-    tr = block_sum_1024(tr, red);
-  }
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int i = threadIdx.x; i < B; i += blockDim.x) { s0 += loss_pix[3 * i]; s1 += loss_pix[3 * i + 1]; s2 += loss_pix[3 * i + 2]; }
-  s0 = block_sum_1024(s0, red); s1 = block_sum_1024(s1, red); s2 = block_sum_1024(s2, red);
-  if (threadIdx.x == 0) {
-    losses[0] = s0 * inv_B; losses[1] = s1 * inv_B; losses[2] = (s0 + s1) * inv_B;
-    losses[3] = tr; losses[4] = s2 * img_scale + img_offset;
+  } else if (blockIdx.x == 1) {
+    float tr = 0.f;
+    if (dmat != nullptr) {
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float g[6];
+        ax2mat_bwd_one(dmat + (size_t)i * 12, axisangle + (size_t)i * 6, g);
+#pragma unroll
+        for (int d = 0; d < 6; ++d) daxisangle[(size_t)i * 6 + d] = g[d] + w_trans * dtrans[(size_t)i * 6 + d];
+        tr += trans_terms[i];
+      }
+      tr = block_sum_1024(tr, red);
+    }
+    if (threadIdx.x == 0) losses[3] = tr;
+  } else {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) { s0 += loss_pix[3 * i]; s1 += loss_pix[3 * i + 1]; s2 += loss_pix[3 * i + 2]; }
+    s0 = block_sum_1024(s0, red); s1 = block_sum_1024(s1, red); s2 = block_sum_1024(s2, red);
+    if (threadIdx.x == 0) {
+      losses[0] = s0 * inv_B; losses[1] = s1 * inv_B; losses[2] = (s0 + s1) * inv_B;
+      losses[4] = s2 * img_scale + img_offset;
+    }
   }
 }
 
@@ -346,7 +360,7 @@ int launch1d(K kernel, int n, void* stream, Args... args) {
 extern "C" int nesvor_step_prologue(const float* logit_coef, float* c, const float* axisangle, float* mat, float* zero_buf,
                                     int n_zero, int n, void* stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(step_prologue_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logit_coef, c, axisangle, mat, zero_buf,
+  hipLaunchKernelGGL(step_prologue_kernel, dim3(3), dim3(1024), 0, (hipStream_t)stream, logit_coef, c, axisangle, mat, zero_buf,
                      n_zero, n);
   return (int)hipGetLastError();
 }
@@ -356,7 +370,7 @@ extern "C" int nesvor_step_epilogue(const float* dc, const float* c, float* dlog
                                     const float* trans_terms, float* losses, int n, int B, float img_scale, float img_offset,
                                     void* stream) {
   if (n <= 0 || B <= 0) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(step_epilogue_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dc, c, dlogit, dmat, axisangle, dtrans,
+  hipLaunchKernelGGL(step_epilogue_kernel, dim3(3), dim3(1024), 0, (hipStream_t)stream, dc, c, dlogit, dmat, axisangle, dtrans,
                      w_trans, daxisangle, loss_pix, trans_terms, losses, n, B, 1.f / (float)B, img_scale, img_offset);
   return (int)hipGetLastError();
 }
