@@ -208,6 +208,12 @@ def main():
                     help="pixel batch sizes of the small_batch block (strong-scaling regime on one GPU); empty string: skip")
     ap.add_argument("--no-strict", action="store_true", help="skip the second pass with the MLP products on fp32 MFMAs (kernel timelines)")
     opt = ap.parse_args()
+    # stdout carries ONE line, the JSON result.  Libraries write there too (RCCL prints a version banner through C stdio, which
+    # lands AFTER a flushed Python print when stdout is a pipe or a file): file descriptor 1 is pointed at stderr for the run and
+    # the result goes to the saved descriptor.
+    result_fd = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
 
     import __graft_entry__ as ge
 
@@ -550,7 +556,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ds, args)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if parallel:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
