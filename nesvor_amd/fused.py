@@ -76,6 +76,7 @@ class FusedTrainer:
         # return while the hash table's AdamW update is still running on the side stream; the next step waits for it where it
         # reads the table (csrc/step.hip, NESVOR_STEP_DEFER_JOIN), everyone else calls join() first
         self.defer_table_join = False
+        self._opt_stream = None  # data parallel: AdamW of the early-exchanged part of the gradient (optimizer_step)
         self._late_join = os.environ.get("NESVOR_OWNER_JOIN_LATE", "1") != "0"  # 0: join the owner pass before the step's epilogue (A/B)
         # autograd-free evaluation of the iteration when the configuration allows it (nesvor_amd.direct)
         from . import direct
@@ -179,14 +180,26 @@ class FusedTrainer:
             early = self.direct.take_early_reduce() if self.direct is not None else None
             if early is not None:  # [start, end) of the flat gradient is already being all-reduced (nesvor_amd.direct)
                 works, start, end = early
+                self.t += 1
+                # the early part - the fine levels, two thirds of the table - takes its AdamW step on a stream of its own as soon
+                # as its all-reduce is done, under whatever the main stream still runs of this iteration (the coarse levels'
+                # backward, the rest of the exchange); nothing there touches that range of the flat buffers
+                main = torch.cuda.current_stream(self.flat.param.device)
+                if self._opt_stream is None:
+                    self._opt_stream = torch.cuda.Stream(device=self.flat.param.device)
+                with torch.cuda.stream(self._opt_stream):
+                    for w in works:
+                        w.wait()
+                    self._adamw(start, end)
                 if start > 0:
                     self.reduce_hook(self.flat.grad[:start])
+                    self._adamw(0, start)
                 if end < self.flat.numel:
                     self.reduce_hook(self.flat.grad[end:])
-                for w in works:
-                    w.wait()
-            else:
-                self.reduce_hook(self.flat.grad)
+                    self._adamw(end, self.flat.numel)
+                main.wait_stream(self._opt_stream)
+                return
+            self.reduce_hook(self.flat.grad)
         self.t += 1
         self._adamw(0, self.flat.numel)
 
