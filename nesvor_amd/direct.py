@@ -128,6 +128,10 @@ class DirectStep:
                 off, cnt = flat.offsets["inr.encoding.params"]
                 self._early_range = (off + spec.levels[self._split_candidate].offset * F, off + cnt)
         self.early_exchange = None  # callable(lo, hi) -> handle for take_early_reduce(); default: all-reduce of flat.grad[lo:hi]
+        # callable(works, lo, hi) run on the side stream right behind the early all-reduce (FusedTrainer: the AdamW step of that
+        # range, under the coarse levels' backward; the side stream is idle there and maps to a hardware queue of its own -
+        # a fresh stream shared the main stream's queue and its kernel ran after the whole iteration)
+        self.early_update = None
 
     def set_overlap(self, on: bool) -> None:
         """Split the hash-grid backward and start the fine levels' all-reduce early (FusedTrainer turns this on when a
@@ -296,6 +300,9 @@ class DirectStep:
 
                 _lib.check(lib.nesvor_step_run(*args, 1, self.split_level, None, stream), "training step (fine levels)")
                 self._early = self._start_early()  # async: RCCL's stream, behind the launches above
+                if self.early_update is not None and self.early_exchange is None and self._early is not None:
+                    with torch.cuda.stream(self.side):
+                        self.early_update(*self._early)
                 _lib.check(lib.nesvor_step_run(*args, 2, self.split_level, None, stream), "training step (coarse levels)")
                 self._owner_pending = bool(d.overlap_owner & 1)  # the coarse levels' owner pass runs on the side stream
             else:

@@ -10,6 +10,8 @@ buffer with matching flat gradient and Adam-moment buffers, so that
 from argparse import Namespace
 from typing import Dict, Optional
 
+import os
+
 import torch
 
 from . import ops as _ops  # noqa: F401  (registers torch.ops.nesvor)
@@ -58,7 +60,6 @@ class FusedTrainer:
             raise RuntimeError("FusedTrainer needs the model on a HIP device (no CPU path)")
         self.model, self.args = model, args
         # optimizer-state sharding over the ranks (ddp.ShardedExchange): opt-in, args.ddp_sharded_optimizer / NESVOR_DDP_SHARDED=1
-        import os
 
         distributed = world_size > 1 if distributed is None else distributed
         self.sharded = distributed and bool(getattr(args, "ddp_sharded_optimizer", os.environ.get("NESVOR_DDP_SHARDED") == "1"))
@@ -77,6 +78,7 @@ class FusedTrainer:
         # reads the table (csrc/step.hip, NESVOR_STEP_DEFER_JOIN), everyone else calls join() first
         self.defer_table_join = False
         self._opt_stream = None  # data parallel: AdamW of the early-exchanged part of the gradient (optimizer_step)
+        self._early_updated = False
         self._late_join = os.environ.get("NESVOR_OWNER_JOIN_LATE", "1") != "0"  # 0: join the owner pass before the step's epilogue (A/B)
         # autograd-free evaluation of the iteration when the configuration allows it (nesvor_amd.direct)
         from . import direct
@@ -98,6 +100,8 @@ class FusedTrainer:
             self.direct.set_overlap(hook is not None)
             if self.sharded and self.direct.split_level:
                 self.direct.early_exchange = self._early_reduce_scatter
+            elif hook is not None and self.direct.split_level and os.environ.get("NESVOR_DDP_EARLY_ADAMW", "1") != "0":
+                self.direct.early_update = self._early_adamw
 
     def _sharded_exchange(self):
         from . import ddp
@@ -108,6 +112,15 @@ class FusedTrainer:
                 split = self.direct.early_range()[0]
             self._exchange = ddp.ShardedExchange(self.flat.numel, split=split)
         return self._exchange
+
+    def _early_adamw(self, works, lo: int, hi: int) -> None:
+        """DirectStep.early_update: on the side stream, behind the all-reduce of flat.grad[lo:hi] (the fine levels of the table),
+        while the main stream runs the coarse levels' backward - AdamW of that range with this step's t."""
+        for w in works:
+            w.wait()
+        self.t += 1
+        self._adamw(lo, hi)
+        self._early_updated = True
 
     def _early_reduce_scatter(self, lo: int, hi: int):
         """Called by the step once the fine levels' gradient is complete: start part 1's reduce-scatter (asynchronous, on the
@@ -180,24 +193,28 @@ class FusedTrainer:
             early = self.direct.take_early_reduce() if self.direct is not None else None
             if early is not None:  # [start, end) of the flat gradient is already being all-reduced (nesvor_amd.direct)
                 works, start, end = early
-                self.t += 1
-                # the early part - the fine levels, two thirds of the table - takes its AdamW step on a stream of its own as soon
-                # as its all-reduce is done, under whatever the main stream still runs of this iteration (the coarse levels'
-                # backward, the rest of the exchange); nothing there touches that range of the flat buffers
-                main = torch.cuda.current_stream(self.flat.param.device)
-                if self._opt_stream is None:
-                    self._opt_stream = torch.cuda.Stream(device=self.flat.param.device)
-                with torch.cuda.stream(self._opt_stream):
-                    for w in works:
-                        w.wait()
-                    self._adamw(start, end)
+                if self._early_updated:
+                    # the early part took its AdamW step on the side stream, right behind its all-reduce (_early_adamw): joined
+                    # by join_owner() above; t is already this step's
+                    self._early_updated = False
+                else:
+                    self.t += 1
+                    # (Python-issued step) the early part - the fine levels, two thirds of the table - takes its AdamW step on a
+                    # stream of its own as soon as its all-reduce is done; nothing else touches that range of the flat buffers
+                    main = torch.cuda.current_stream(self.flat.param.device)
+                    if self._opt_stream is None:
+                        self._opt_stream = torch.cuda.Stream(device=self.flat.param.device)
+                    with torch.cuda.stream(self._opt_stream):
+                        for w in works:
+                            w.wait()
+                        self._adamw(start, end)
+                    main.wait_stream(self._opt_stream)
                 if start > 0:
                     self.reduce_hook(self.flat.grad[:start])
                     self._adamw(0, start)
                 if end < self.flat.numel:
                     self.reduce_hook(self.flat.grad[end:])
                     self._adamw(end, self.flat.numel)
-                main.wait_stream(self._opt_stream)
                 return
             self.reduce_hook(self.flat.grad)
         self.t += 1
