@@ -2119,6 +2119,8 @@ bool out1_on() {
 
 // Which configurations can save compactly: those the pipelined forward AND the wave-specialised backward both take in the
 // split-operand mode, with at most two input blocks (the recomputation's registers).
+// Depends on SHAPE fields only (a.fast / a.off32 are functions of N, S, k_a, k_b, b_row0, out_dim): the fake kernel of the
+// custom op (nesvor_amd/ops.py::_mlp_fake) sizes the saved buffers from a descriptor without pointers.
 bool compact_ok(const MlpArgs& a, const nesvor_mlp_t* net, int64_t N) {
   static const bool use_pf = []() { const char* e = getenv("NESVOR_MLP_FWD_PF"); return e == nullptr || atoi(e) != 0; }();
   static const bool use_ws = []() { const char* e = getenv("NESVOR_MLP_BWD_WS"); return e == nullptr || atoi(e) != 0; }();

@@ -283,6 +283,13 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
       // sampler run under the end of this one's table update
       NESVOR_TRY(nesvor_adamw_step(d.flat_param, d.flat_grad, d.flat_exp_avg, d.flat_exp_avg_sq, table_off, adam->lr, adam->beta1, adam->beta2,
                                    adam->eps, adam->weight_decay, adam->bias_correction1, adam->bias_correction2, adam->grad_scale, 1, main));
+      // ... and whatever the caller laid out BEHIND the table (FlatParams puts the table last; a parameter tied with it for
+      // the largest size would follow it): segments are 16-byte aligned, the owner pass covered exactly the table's entries
+      const int64_t table_end = (table_off + (int64_t)(d.grid.offset[L - 1] + d.grid.size[L - 1]) * d.grid.n_features + 3) / 4 * 4;
+      if (table_end < d.flat_numel)
+        NESVOR_TRY(nesvor_adamw_step(d.flat_param + table_end, d.flat_grad + table_end, d.flat_exp_avg + table_end, d.flat_exp_avg_sq + table_end,
+                                     d.flat_numel - table_end, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->weight_decay,
+                                     adam->bias_correction1, adam->bias_correction2, adam->grad_scale, 1, main));
       if (overlap_owner) {
         if (defer_join) ctx->pending_join = true;
         else if (hipStreamWaitEvent(main, ctx->ev_owner, 0) != hipSuccess) return (int)hipGetLastError();

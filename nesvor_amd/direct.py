@@ -113,6 +113,7 @@ class DirectStep:
         # (NESVOR_DDP_OVERLAP=0: one launch, one all-reduce after the step)
         self._early = None
         self._owner_pending = False  # an owner pass of the hash-grid backward is running on the side stream
+        self._pending_state = None   # ... left there by this native context (its next run joins it by itself)
         self._kernel_noise = os.environ.get("NESVOR_PSF_NOISE", "kernel") != "tensor"
         self._noise_stream, self._noise_calls = 0x5851F42D4C957F2D, 0  # stream id of the training draws, calls so far
         self._native = {}  # batch size -> (StepT, handle, buffers) of the one-call iteration (csrc/step.hip)
@@ -274,6 +275,12 @@ class DirectStep:
         dev = xyz.device
         B = xyz.shape[0]
         st = self._native_state(B)
+        if self._owner_pending and self._pending_state is not None and self._pending_state is not st:
+            # a table update the PREVIOUS step left on the side stream belongs to another context (other batch size or
+            # operand mode): only that context's next run would wait for it - join here, before this one reads the table
+            # and reuses the backward's workspace
+            self.join_owner()
+            _lib.check(lib.nesvor_step_join(self._pending_state["handle"], _lib.stream_ptr()), "step join")
         d = st["desc"]
         spec = m.inr.encoding.spec
         N = B * d.S
@@ -304,7 +311,8 @@ class DirectStep:
                     with torch.cuda.stream(self.side):
                         self.early_update(*self._early)
                 _lib.check(lib.nesvor_step_run(*args, 2, self.split_level, None, stream), "training step (coarse levels)")
-                self._owner_pending = bool(d.overlap_owner & 1)  # the coarse levels' owner pass runs on the side stream
+                # the coarse levels' owner pass runs on the side stream - and so did the early range's AdamW (early_update)
+                self._owner_pending = bool(d.overlap_owner & 1) or (self.early_update is not None and self.early_exchange is None)
             else:
                 # with its own AdamW the step has joined the owner pass - unless asked to leave the table's update (taken
                 # inside the owner pass) on the side stream: the next run joins it right before its hash-grid forward, anyone
@@ -312,6 +320,7 @@ class DirectStep:
                 defer = bool(defer_table_join) and adam is not None and (d.overlap_owner & 3) == 3
                 _lib.check(lib.nesvor_step_run(*args, 0 | (_lib.STEP_DEFER_JOIN if defer else 0), 0, a_ptr, stream), "training step")
                 self._owner_pending = bool(d.overlap_owner & 1) and (adam is None or defer)
+        self._pending_state = st if self._owner_pending else None
         sizer.snapshot(ws)
         losses = {D_LOSS: vals[0]}
         if self.has_var:

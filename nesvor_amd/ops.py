@@ -395,6 +395,9 @@ def _mlp_backward_formula(ctx, dy, d_saved):
 
 
 def _mlp_fake(xa, xb, weights, biases, b_row0, k_b, S, operands, save):
+    # the saved buffers' sizes follow from SHAPE fields alone (csrc/mlp.hip::compact_ok reads n_hidden, k_a, k_b, b_row0,
+    # out_dim, samples_per_pixel, the operand mode and N through fill_args - no pointer of the descriptor), so this
+    # pointer-less descriptor and forward_raw's real one always agree (tests/test_cabi.py::test_mlp_fake_sizes_match_forward)
     n = xb.shape[1]
     n_pad = (n + 15) // 16 * 16
     sdt = torch.bfloat16 if operands == _mlp.BF16 else torch.float32

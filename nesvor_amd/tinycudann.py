@@ -52,6 +52,21 @@ class Encoding(nn.Module):
         return out.to(self.dtype)
 
 
+# tinycudann's activation names (network_config["activation"] / ["output_activation"]) on the library-GEMM fallback
+_ACTIVATIONS = {
+    "None": lambda t: t, "ReLU": torch.relu, "LeakyReLU": lambda t: torch.nn.functional.leaky_relu(t, 0.01),
+    "Exponential": torch.exp, "Sigmoid": torch.sigmoid, "Tanh": torch.tanh, "Softplus": torch.nn.functional.softplus,
+    "Squareplus": lambda t: 0.5 * (t + torch.sqrt(t * t + 4.0)), "Sine": torch.sin,
+}
+
+
+def _activation(name: str):
+    try:
+        return _ACTIVATIONS[name]
+    except KeyError:
+        raise NotImplementedError(f"tinycudann activation {name!r} is not implemented (known: {sorted(_ACTIVATIONS)})") from None
+
+
 class Network(nn.Module):
     """Bias-free MLP with flat params; output width padded to a multiple of 16 as tinycudann does."""
 
@@ -63,6 +78,7 @@ class Network(nn.Module):
         depth = int(network_config["n_hidden_layers"])
         self.activation = network_config.get("activation", "ReLU")
         self.output_activation = network_config.get("output_activation", "None")
+        _activation(self.activation), _activation(self.output_activation)  # unknown names fail at construction
         pad_out = (n_output_dims + 15) // 16 * 16
         dims = [n_input_dims] + [width] * depth + [pad_out]
         self.shapes = [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]
@@ -86,13 +102,13 @@ class Network(nn.Module):
             import logging
 
             logging.warning("tinycudann.Network %s is outside the fused HIP kernels: evaluated on library GEMMs", self.shapes)
-        act = {"ReLU": torch.relu, "None": lambda t: t}[self.activation]
+        act, out_act = _activation(self.activation), _activation(self.output_activation)
         off, h = 0, x.to(self.params.dtype)
         for li, (o, i) in enumerate(self.shapes):
             h = h @ self.params[off : off + o * i].view(o, i).t()
             off += o * i
             if li < len(self.shapes) - 1:
                 h = act(h)
-        return h[..., : self.n_output_dims]
+        return out_act(h[..., : self.n_output_dims])
 
     _warned = False

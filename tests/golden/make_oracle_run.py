@@ -1,0 +1,148 @@
+"""Generate tests/golden/oracle_run_c1.npz: BASELINE config C1 run by the CPU ORACLE.
+
+Run in the build container (CPU only; needs neither /root/reference nor a GPU):
+
+    python tests/golden/make_oracle_run.py            # 200 iterations, ~1 h on 8 cores
+    python tests/golden/make_oracle_run.py --n-iter 3 --out /tmp/x.npz   # a quick check of the plumbing
+
+What it is: the 3-stack phantom3d(128) data of every BASELINE configuration (77 slices of 151 x 151 per stack, PSF
+(9, 5, 5); BASELINE.md "CPU-baseline plan"), synthesised by the oracle's restatement of the slice-acquisition kernel,
+then ``oracle.train_loop.train`` - the restatement of the reference's loop, nesvor/nesvor/train.py:123-232 and
+models.py:260-327 - on the HEADLINE model (``bench.make_args``: L = 16 levels at scale 1.26, T = 2^19, F = 2, two hidden
+layers of 64, poses optimised, edge regulariser) at BASELINE.md's reduced C1 batch (1024 pixels x 64 samples) for 200
+iterations from ``torch.manual_seed(0)``.
+
+What it stores (data only): the six losses of every iteration, the wall time of every iteration on this machine, the
+final PSNR against the phantom (whole object, and interior only = object without the bright skull shell), a coarse
+sampled volume (every 4th voxel centre of the 128^3 lattice), a few dataset checksums so that the GPU test can tell
+that it rebuilt the same data.  tests/test_gpu_fullsize.py::test_c1_oracle_run_replayed_by_hip replays the same random
+stream through the HIP ``train()`` and holds it to this file: losses of the first 10 iterations at rtol 1e-4, PSNR
+within 0.1 dB at iteration 200 (north_star's parity statement at the stated phantom, with the oracle standing in for
+the CUDA reference: SURVEY 8c).
+"""
+import argparse
+import math
+import os
+import sys
+import time
+from argparse import Namespace
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+N = 128
+SKULL = 0.5  # phantom intensities above this are the skull shell (1.0); the interior is 0 < truth <= SKULL
+
+
+def register_oracle_cpu_kernels():
+    """The product has no CPU path; for this script the oracle is registered as the CPU kernel of the rigid-transform
+    dispatcher ops (as tests/conftest.py::oracle_backend does) so that the host-side classes (RigidTransform, Slice,
+    Dataset) run on CPU tensors."""
+    from oracle import transform_convert as o
+
+    import nesvor_amd.ops  # noqa: F401
+
+    lib = torch.library.Library("nesvor", "IMPL")
+    lib.impl("axisangle2mat_forward", o.axisangle2mat_forward, "CPU")
+    lib.impl("axisangle2mat_backward", o.axisangle2mat_backward, "CPU")
+    lib.impl("mat2axisangle_forward", o.mat2axisangle_forward, "CPU")
+    lib.impl("mat2axisangle_backward", o.mat2axisangle_backward, "CPU")
+    return lib
+
+
+def cpu_stacks(n_stacks=3):
+    """nesvor_amd.phantom.simulate_stacks on CPU, its slice-acquisition call answered by the oracle."""
+    from nesvor_amd import phantom as ph
+    from oracle import slice_acq as osa
+
+    def sa(mat, vol, vol_mask, slices_mask, psf, slice_shape, res_slice, need_weight, interp_psf):
+        out = osa.slice_acquisition_forward(mat, vol, vol_mask, slices_mask, psf, slice_shape, res_slice, need_weight, interp_psf)
+        return out[0] if isinstance(out, (list, tuple)) else out
+
+    ph.slice_acquisition = sa
+    vol = torch.tensor(ph.phantom3d(n=N), dtype=torch.float32)
+    slices, _ = ph.simulate_stacks(vol, n_stacks=n_stacks)
+    return vol, slices
+
+
+def phantom_points(stride=1):
+    g = torch.arange(0, N, stride, dtype=torch.float32) - (N - 1) / 2
+    zz, yy, xx = torch.meshgrid(g, g, g, indexing="ij")
+    return torch.stack([xx, yy, zz], -1).reshape(-1, 3)
+
+
+def fit_psnr(rec, truth, sel, peak):
+    s = float((rec[sel] * truth[sel]).sum() / (rec[sel] ** 2).sum())
+    return 10 * math.log10(peak**2 / float(((rec[sel] * s - truth[sel]) ** 2).mean())), s
+
+
+def dataset_checksums(ds):
+    return np.array([ds.v.shape[0], float(ds.v.double().sum()), float(ds.xyz.double().abs().sum()), float(ds.slice_idx.double().sum()),
+                     ds.mean], dtype=np.float64)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n-iter", type=int, default=200)
+    ap.add_argument("--batch-size", type=int, default=1024)
+    ap.add_argument("--n-samples", type=int, default=64)
+    ap.add_argument("--out", default=os.path.join(HERE, "oracle_run_c1.npz"))
+    opt = ap.parse_args()
+
+    from bench import make_args
+    from nesvor_amd.train import Dataset
+    from oracle import nesvor_model as nm
+    from oracle import train_loop as otl
+
+    keep = register_oracle_cpu_kernels()  # the registration lives as long as this object
+    t0 = time.time()
+    vol, slices = cpu_stacks(3)
+    print(f"data: {len(slices)} slices in {time.time() - t0:.1f} s", flush=True)
+    args = make_args(torch.device("cpu"), opt.batch_size, opt.n_samples, 2, opt.n_iter)
+    ds = Dataset(slices, args)
+    sums = dataset_checksums(ds)
+    cds = otl.ArrayDataset(ds.xyz, ds.v, ds.slice_idx, ds.transformation.matrix(), ds.resolution)
+    stamps = [time.time()]
+
+    def log(i, losses):
+        stamps.append(time.time())
+        if i <= 10 or i % 10 == 0:
+            print(i, f"{stamps[-1] - stamps[-2]:.2f} s", {k: round(v, 6) for k, v in losses.items()}, flush=True)
+
+    torch.manual_seed(0)
+    P, levels, bb, info = otl.train(cds, Namespace(**vars(args)), log=log)
+    keys = list(info["history"][0].keys())
+    hist = np.array([[h[k] for k in keys] for h in info["history"]], dtype=np.float64)
+    secs = np.diff(np.array(stamps))
+    truth = vol.reshape(-1)
+    pts = phantom_points()
+    rec = torch.empty(pts.shape[0])
+    with torch.no_grad():
+        for i in range(0, pts.shape[0], 1 << 18):
+            rec[i : i + (1 << 18)] = nm.sample_points(P, levels, args, bb, pts[i : i + (1 << 18)], None, 0.0)
+    peak = float(truth.max())
+    whole, interior = truth > 0, (truth > 0) & (truth <= SKULL)
+    p_whole, s_whole = fit_psnr(rec, truth, whole, peak)
+    p_int, s_int = fit_psnr(rec, truth, interior, peak)
+    coarse = rec.reshape(N, N, N)[::4, ::4, ::4].contiguous().numpy().astype(np.float32)
+    t_from = 20 if opt.n_iter > 40 else 1
+    rate = (opt.n_iter - t_from) / float(secs[t_from:].sum())
+    print(f"PSNR whole object {p_whole:.3f} dB (scale {s_whole:.4f}), interior {p_int:.3f} dB (scale {s_int:.4f}); "
+          f"{rate:.4f} it/s over iterations {t_from + 1}..{opt.n_iter} on {torch.get_num_threads()} threads")
+    np.savez_compressed(
+        opt.out, loss_keys=np.array(keys), loss_history=hist, seconds_per_iteration=secs.astype(np.float32),
+        psnr_whole_db=np.float64(p_whole), psnr_interior_db=np.float64(p_int), scale_whole=np.float64(s_whole),
+        scale_interior=np.float64(s_int), coarse_volume_stride4=coarse, dataset_checksums=sums,
+        config=np.array([opt.n_iter, opt.batch_size, opt.n_samples, N, 3, len(levels), torch.get_num_threads(), os.cpu_count()]),
+        iters_per_s=np.float64(rate), bounding_box=bb.numpy(), skull_threshold=np.float64(SKULL))
+    print("wrote", opt.out)
+    del keep
+
+
+if __name__ == "__main__":
+    main()

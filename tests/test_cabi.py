@@ -82,6 +82,27 @@ def test_custom_ops_are_registered_with_schemas_and_meta_kernels():
     assert y.shape == (16, 160) and len(saved) == 2
 
 
+def test_mlp_fake_sizes_match_forward():
+    """The fake kernel of ``nesvor::fused_mlp`` sizes the saved-activation buffers from a descriptor WITHOUT pointers; the
+    real forward decides the compact save on its full descriptor.  Both must agree for every shape (the predicate,
+    csrc/mlp.hip::compact_ok, reads shape fields only) - host logic of the library, no device work."""
+    from nesvor_amd import mlp
+
+    for n_hidden, out_dim, k_a, k_b, b_row0, S, N in [(2, 16, 0, 32, 0, 256, 1 << 20), (2, 1, 16, 15, 1, 256, 1 << 20),
+                                                       (1, 16, 0, 32, 0, 64, 1 << 16), (2, 16, 0, 32, 0, 24, 24 * 100),
+                                                       (2, 1, 16, 8, 0, 256, 1 << 18), (3, 16, 0, 32, 0, 256, 1 << 18),
+                                                       (2, 16, 0, 48, 0, 256, 1 << 18), (2, 16, 0, 32, 0, 256, (1 << 18) + 16)]:
+        dims = [k_a + k_b] + [64] * n_hidden + [out_dim]
+        ws = [torch.zeros(o, i) for i, o in zip(dims[:-1], dims[1:])]
+        bs = [torch.zeros(o) for o in dims[1:]]
+        for mode in (False, True, mlp.MFMA_FP32):
+            real = mlp._desc(ws, bs, k_a, k_b, b_row0, S, mode)
+            bare = mlp.dims_desc(n_hidden, out_dim, k_a, k_b, b_row0, S, mode)
+            assert mlp.saved_sizes(real, N, n_hidden) == mlp.saved_sizes(bare, N, n_hidden), (n_hidden, out_dim, k_a, k_b, S, N, mode)
+    # the headline networks do save compactly (the default evaluation of the fp32 products)
+    assert mlp.saved_sizes(mlp.dims_desc(2, 16, 0, 32, 0, 256), 1 << 20, 2)[0] == (1 << 20) * 4
+
+
 def test_product_does_not_import_oracle():
     """The oracle is test infrastructure: nothing under nesvor_amd/ may reference it."""
     pkg = os.path.join(ROOT, "nesvor_amd")
