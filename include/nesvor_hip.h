@@ -272,7 +272,16 @@ int nesvor_psf_noise(uint64_t seed, uint64_t offset, float* out, int64_t n_sampl
  * order W0,b0,W1,b1,.. that the caller sums over dim 0 (no atomics anywhere).
  * ---------------------------------------------------------------------- */
 typedef struct {
-  int32_t width;              /* hidden width; 64 */
+  int32_t width;              /* hidden width; 64.  LIMIT: the fused kernels are built around one 64-column tile per layer (four
+                                 16-feature blocks, weights resident in LDS as MFMA operand images).  The reference takes any
+                                 --width / --depth (nesvor/cli/main.py:68-73, build_network models.py:42-67): widths below 64
+                                 run zero-padded on these kernels (exactly the same function; nesvor_amd/mlp.py::kernel_params),
+                                 depth up to NESVOR_MAX_MLP_LAYERS - 1 hidden layers is native, and anything wider or deeper is
+                                 REFUSED here (hipErrorInvalidValue) - the host side (nesvor_amd/mlp.py::library_mlp) then keeps
+                                 sampler, hash grid and loss on the HIP kernels and evaluates those matrix products with
+                                 rocBLAS under autograd (tests/test_gpu_parity.py::test_other_widths_and_depths_match_oracle_losses:
+                                 128 x 1, 64 x 4, 96 x 5 against the oracle) - a stated fallback off BASELINE's configuration,
+                                 not a hand-written path */
   int32_t n_hidden;           /* hidden layers, 1..NESVOR_MAX_MLP_LAYERS-1 */
   int32_t out_dim;            /* 1..16 */
   int32_t k_a, k_b, b_row0;

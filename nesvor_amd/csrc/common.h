@@ -68,6 +68,41 @@ __device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t v) {
   return max(max(r0, r1), max(r2, r3));
 }
 
+// Full-wave max of floats on the VALU only (same DPP pattern); wave-uniform result.
+__device__ __forceinline__ float wave_max_f32_dpp(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false)));
+  const int iv = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// The value lane (l ^ J) holds, J a power of two below 64, without a trip through the LDS crossbar (ds_bpermute: ~100
+// cycles of latency per exchange): quad permutes, row rotates / shifts with bank masks, and gfx950's lane-swap
+// instructions across 16- and 32-lane halves.
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v, int lane) {
+  static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "power of two below the wave size");
+  const int iv = (int)v;
+  if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xf, 0xf, false);       // quad_perm [1,0,3,2]
+  else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+  else if constexpr (J == 4) {
+    int t = __builtin_amdgcn_update_dpp(iv, iv, 0x104, 0xf, 0x5, false);  // row_shl:4 into banks 0 and 2 (lanes 0-3, 8-11 of a row)
+    t = __builtin_amdgcn_update_dpp(t, iv, 0x114, 0xf, 0xA, false);       // row_shr:4 into banks 1 and 3
+    return (uint32_t)t;
+  } else if constexpr (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(iv, iv, 0x128, 0xf, 0xf, false);  // row_ror:8
+  else if constexpr (J == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // r[0] = rows [0,0,2,2], r[1] = rows [1,1,3,3]
+    return (lane & 16) ? r[0] : r[1];
+  } else {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // r[0] = halves [lo,lo], r[1] = [hi,hi]
+    return (lane & 32) ? r[0] : r[1];
+  }
+}
+
 // fp32 add into LDS through an integer compare-and-swap loop.  On gfx950 ds_add_f32 retires ~1 lane
 // per 3 cycles (192+ cycles per wave-instruction, measured, independent of conflicts) while
 // ds_cmpst_rtn_b32 runs at ~7 cycles per conflict-free wave-instruction, so the CAS loop wins

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
   {
     float lo[3] = {ux, uy, uz}, hi[3] = {ux, uy, uz};
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { lo[d] = -wave_max(-lo[d]); hi[d] = wave_max(hi[d]); }
+    for (int d = 0; d < 3; ++d) { lo[d] = -wave_max_f32_dpp(-lo[d]); hi[d] = wave_max_f32_dpp(hi[d]); }
     if (lane == 0) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) { ubox[tid >> 6][d] = lo[d]; ubox[tid >> 6][3 + d] = hi[d]; }
@@ -533,6 +533,31 @@ struct BwdPlan {
 //  compiler's per-level reads of it - plan.shift[level], plan.cap[level] ... - from scalar loads to per-lane global loads,
 //  which cost the uniform-points case a factor of three)
 
+// Bitonic sort of one 32-bit key per thread over SPAN consecutive threads of a 256-thread workgroup (ascending).  The 26
+// exchanges at distance 1..8 are DPP moves, the 7 at distance 16 / 32 lane swaps (common.h::lane_xor_u32); only the 3
+// exchanges across waves go through LDS.  (Rounds 1-3 used __shfl_xor = ds_bpermute for all 33 in-wave exchanges: one
+// sort cost 0.03 ms of the pass, profiles/r01_ablate_hashgrid.log.)
+template <int K, int J>
+__device__ __forceinline__ void bitonic_merge(uint32_t& sv, int tid, uint32_t* sortbuf) {
+  uint32_t other;
+  if constexpr (J < 64) {
+    other = lane_xor_u32<J>(sv, tid & 63);
+  } else {
+    __syncthreads();
+    sortbuf[tid] = sv;
+    __syncthreads();
+    other = sortbuf[tid ^ J];
+  }
+  const bool keep_min = ((tid & K) == 0) == ((tid & J) == 0);
+  sv = keep_min ? min(sv, other) : max(sv, other);
+  if constexpr (J > 1) bitonic_merge<K, J / 2>(sv, tid, sortbuf);
+}
+template <int K>
+__device__ __forceinline__ void bitonic_sort(uint32_t& sv, int tid, uint32_t* sortbuf) {
+  if constexpr (K > 2) bitonic_sort<K / 2>(sv, tid, sortbuf);
+  bitonic_merge<K, K / 2>(sv, tid, sortbuf);
+}
+
 __device__ __forceinline__ uint32_t spread3(uint32_t x) {  // 8 bits -> every third bit
   x &= 0xffu;
   x = (x ^ (x << 8)) & 0x0300f00fu;
@@ -677,6 +702,14 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
     // launch found - same samples, same key
     if (order_mode == 2) sv = (uint32_t)order[base + tid];
     else
+#ifndef NESVOR_SORT_BPERMUTE
+#pragma unroll 1
+    for (int rep = 0; rep < (NESVOR_ABL(1) ? 2 : 1); ++rep) {
+      if (rep) sv ^= 0x80000000u;  // (ablation: something to sort the second time)
+      bitonic_sort<NESVOR_SORT_SPAN>(sv, tid, sortbuf);
+      if (rep) sv ^= 0x80000000u;
+    }
+#else
 #pragma unroll 1
     for (int rep = 0; rep < (NESVOR_ABL(1) ? 2 : 1); ++rep)
 #pragma unroll 1
@@ -697,6 +730,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         sv = (lower == up) ? mn : mx;
       }
     }
+#endif
   }
   if (order_mode == 1) order[base + tid] = (uint8_t)(sv & 255u);
   const int64_t i = base + (sv & 255u);  // the sample this lane owns from now on
@@ -722,8 +756,8 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
     float lo[3] = {ux, uy, uz}, hi[3] = {ux, uy, uz};
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      lo[d] = -wave_max(-lo[d]);
-      hi[d] = wave_max(hi[d]);
+      lo[d] = -wave_max_f32_dpp(-lo[d]);
+      hi[d] = wave_max_f32_dpp(hi[d]);
     }
     // ONE fixed-point scale for the whole launch of this workgroup: max |dy| over its samples and all levels (eight
     // levels' loads in flight at a time).  The adds of one slot sum to at most 256 max|dy| (corner weights of a sample
@@ -750,7 +784,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
 #pragma unroll
         for (int f = 0; f < F; ++f) m = fmaxf(m, fabsf(d[q][f]));
     }
-    m = wave_max(m);
+    m = wave_max_f32_dpp(m);
     if (lane == 0) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) { ubox[tid >> 6][d] = lo[d]; ubox[tid >> 6][3 + d] = hi[d]; }
