@@ -633,6 +633,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
   // no launch of its own is needed for it
   for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < (uint32_t)kSubQueues * kTailStride; t += gridDim.x * 256u) tails_next[t] = 0u;
   constexpr bool kPack = (F == 2) && (NESVOR_FIXED32 != 0);
+  constexpr bool kPerLevel = kPack && (NESVOR_FIXED32 >= 2);  // packed fields scaled by the workgroup's max |dy| of EACH level
   constexpr int kWords = kPack ? 1 : F;  // 64-bit words per slot
   __shared__ uint32_t bcount[kMaxChunks];
   // per bucket of the current round: box rounds hold uint4 (reserved position, first record of the sub-queue, capacity,
@@ -655,6 +656,8 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
   // box rounds: the table entries of the round's lattice boxes ([slot][F]); the input gradient reads its 8 corners here
   __shared__ __attribute__((aligned(16))) float tcache[INPUT_GRAD && MERGE ? kSlots * F : 1];
   __shared__ float gmax[4];           // per wave max |dy| over all levels of this launch
+  __shared__ uint32_t lmax_bits[NESVOR_MAX_LEVELS + 1];  // kPerLevel: max |dy| of the workgroup's samples per level (float bits)
+  __shared__ float lscale[NESVOR_MAX_LEVELS + 1][2];     // kPerLevel: fixed-point scale of a level and its inverse
   __shared__ uint32_t merge_stat[2];  // records inserted / drained at the current level (hashed table)
   __shared__ uint32_t slots_log2;     // slots of the hashed table used at the current level: 256 .. kSlots, ~4x the
                                       // previous level's distinct vertices (they grow ~1.3-1.5x per level), so that
@@ -686,6 +689,9 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
   for (int t = tid; t < kSlots * kWords; t += 256) tvals[t] = 0ull;
   if (tid < 2) merge_stat[tid] = 0;
   if (tid == 0) { merge_off = MERGE ? 0u : 1u; slots_log2 = __builtin_ctz(kSlots); }
+  if constexpr (kPerLevel) {
+    if (tid <= NESVOR_MAX_LEVELS) lmax_bits[tid] = 0u;
+  }
 
   // ---- sort the workgroup's samples by Morton code of the finest-level cell
   uint32_t sv;
@@ -767,8 +773,13 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
     // over dy - 134 MB at N = 2^20, read a second time level by level below - is skipped: 64-bit words leave room for a
     // bound that is orders of magnitude above this workgroup's own maximum.
     float m = 0.f;
-    if constexpr (BOUND) m = *dy_bound;
-    else
+    if constexpr (kPerLevel) __syncthreads();  // lmax_bits zero-filled (no barrier before this point when the sort is skipped)
+    if constexpr (BOUND) {
+      m = *dy_bound;
+      if constexpr (kPerLevel) {  // (a global bound: every level gets the same scale)
+        if (tid < NESVOR_MAX_LEVELS) lmax_bits[tid] = __float_as_uint(m);
+      }
+    } else
     for (int l0 = plan.level_begin; l0 < level_end; l0 += 8) {
       float d[8][F];
 #pragma unroll
@@ -780,9 +791,16 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         }
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
+      for (int q = 0; q < 8; ++q) {
+        float ml = 0.f;
 #pragma unroll
-        for (int f = 0; f < F; ++f) m = fmaxf(m, fabsf(d[q][f]));
+        for (int f = 0; f < F; ++f) ml = fmaxf(ml, fabsf(d[q][f]));
+        m = fmaxf(m, ml);
+        if constexpr (kPerLevel) {
+          ml = wave_max_f32_dpp(ml);
+          if (lane == 0 && l0 + q < level_end) atomicMax(&lmax_bits[l0 + q], __float_as_uint(ml));
+        }
+      }
     }
     m = wave_max_f32_dpp(m);
     if (lane == 0) {
@@ -828,6 +846,14 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
         lpar[tid][0] = p.res; lpar[tid][1] = p.size; lpar[tid][2] = p.offset; lpar[tid][3] = p.hashed;
         lpar[tid][4] = plan.cap[tid]; lpar[tid][5] = plan.bucket_base[tid]; lpar[tid][6] = (uint32_t)plan.rec_off[tid];
         lpar[tid][7] = plan.shift[tid];
+        if constexpr (kPerLevel) {
+          // a slot sums at most 256 values of at most max |dy| each: mapped below 2^30
+          const float mxl = 256.f * __uint_as_float(lmax_bits[tid]);
+          int se = 29 - ((int)((__float_as_uint(mxl) >> 23) & 0xFFu) - 127);
+          se = se > 100 ? 100 : (se < -100 ? -100 : se);
+          lscale[tid][0] = __uint_as_float((uint32_t)(se + 127) << 23);
+          lscale[tid][1] = __uint_as_float((uint32_t)(127 - se) << 23);
+        }
       }
       if (tid <= g.n_levels) {
 #pragma unroll
@@ -970,7 +996,9 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
   };
 
   // one corner's F values -> the slot's fixed-point words
-  auto slot_add = [&](uint32_t slot, const float (&v)[F]) __attribute__((always_inline)) {
+  auto scale_of = [&](uint32_t lv) __attribute__((always_inline)) { return kPerLevel ? lscale[lv][0] : fscale; };
+  auto inv_of = [&](uint32_t lv) __attribute__((always_inline)) { return kPerLevel ? lscale[lv][1] : finv; };
+  auto slot_add = [&](uint32_t slot, const float (&v)[F], float fscale) __attribute__((always_inline)) {
     if constexpr (kPack) {
       const int32_t q0 = __float2int_rn(v[0] * fscale), q1 = __float2int_rn(v[1] * fscale);
       // ((int64)q1 << 32) + (int64)q0: the low field's sign borrows from the high field; undone when the slot is read
@@ -981,7 +1009,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
     }
   };
   // read + clear one slot; false: nothing was added (or everything cancelled exactly)
-  auto slot_take = [&](uint32_t slot, float (&v)[F]) __attribute__((always_inline)) -> bool {
+  auto slot_take = [&](uint32_t slot, float (&v)[F], float finv) __attribute__((always_inline)) -> bool {
     bool any = false;
     if constexpr (kPack) {
       const unsigned long long w = tvals[slot];
@@ -1071,9 +1099,10 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
 #pragma unroll
         for (int f = 0; f < F; ++f) dy_a[f] = dy_b[f];
         if (lv + 2 < level_end) load_dy(lv + 2, dy_b);
+        const float fs_lv = scale_of((uint32_t)lv);
         if (!NESVOR_ABL(4) && tail) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) slot_add(s0 + (k & 1) + ((k >> 1) & 1) * nx + (k >> 2) * nxy, val[k]);
+          for (int k = 0; k < 8; ++k) slot_add(s0 + (k & 1) + ((k >> 1) & 1) * nx + (k >> 2) * nxy, val[k], fs_lv);
         }
       }
     };
@@ -1133,7 +1162,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
 #pragma unroll
           for (int f = 0; f < F; ++f) rval[j][f] = 0.f;
           const uint32_t slot = (uint32_t)j * 256u + (uint32_t)tid;
-          if (slot < n_slots && slot_take(slot, rval[j])) {
+          if (slot < n_slots && slot_take(slot, rval[j], inv_of(lk[j] >> 27))) {
             const uint32_t lv = lk[j] >> 27;
             rkey[j] = lk[j] & kKeyMask;
             const uint32_t bucket = bkt_off[lv] + (rkey[j] >> lpar[lv][7]);
@@ -1306,7 +1335,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
 #pragma unroll
               for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + idx[k]) * F + f, val[k][f]);
             } else {
-              slot_add(h[k], val[k]);
+              slot_add(h[k], val[k], scale_of((uint32_t)level));
             }
           }
         }
@@ -1327,7 +1356,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
           if (key != kEmpty) {
             tkeys[slot] = kEmpty;
             rmask |= 1u << j; rkey[j] = key;
-            slot_take(slot, rval[j]);
+            slot_take(slot, rval[j], inv_of((uint32_t)level));
             rank[j] = atomicAdd(&bcount[key >> plan.shift[level]], 1u);
             ++mine;
           }
