@@ -301,7 +301,8 @@ typedef struct {
                                     mode 0, which is always a valid evaluation of mode 2) */
   int32_t compact_save;       /* 1: training keeps, per hidden unit and sample, ONE BIT (h > 0) of every hidden layer and the
                                  values of the layers after the first only: saved_hidden[0] = one uint32 per (16-sample group,
-                                 lane) - 16 N bytes instead of 256 N - with bit 16 l + 4 b + r = [h_l > 0] for the unit the
+                                 lane) - 16 N bytes instead of 256 N - with bit 16 l + 4 b + r = [pre-activation sign bit clear] (= [h_l > 0] for every
+                                 value but an exact +0, which only zero-padded units produce) for the unit the
                                  lane holds in block b, element r of the fragment layout; saved_hidden[l >= 1] as before.  The
                                  backward gates with the bits and recomputes the first hidden layer from the network input
                                  (24 MFMAs per 16 samples, in exactly the operand layout the weight gradient needs) instead of

@@ -648,7 +648,8 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 // a sum over the four feature quads - instead of twelve MFMAs on 15/16 padding plus the 3-way split of the last hidden layer
 // (4 fragments x 14 VALU), which nothing else needs.
 #ifndef NESVOR_FWD_MINBLOCKS
-#define NESVOR_FWD_MINBLOCKS 3  // round 4: with the scalar-base input addressing the split-mode instantiations need 144-156 VGPRs
+#define NESVOR_FWD_MINBLOCKS 2  // (round 4: with the scalar-base input addressing the split-mode instantiations need 144-156 VGPRs - three
+                                // workgroups would fit a CU; launch_kb explains why two are launched)
 #endif
 template <int KB1, int NH, bool X6, bool SAVE, bool COMPACT = false, bool OUT1 = false>
 __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) void mlp_fwd_pf_kernel(const MlpArgs a) {
@@ -753,16 +754,28 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) v
       }
       if (l == 0) apply_layer<KB1, kHB, false, X6>(img1, x, h[0], lane);
       else apply_layer<kHB, kHB, false, X6>(imgh + (l - 1) * kHB * kHB * kBlk, h[l - 1], h[l], lane);
+      if constexpr (SAVE && COMPACT) {
+        // The gate bits of a layer from the SIGN bits of the pre-activations: v_alignbit_b32 sg, sg, x, 31 = (sg << 1) | (x >> 31)
+        // shifts one sign in per instruction (rounds 1-3: v_min_u32 + v_lshl_or_b32 on the ReLU output, two per value).
+        // Inserted from the highest bit index down, complemented once per layer: bit 4 ob + r = [x >= +0], which is [h > 0]
+        // for every pre-activation but an exact +0 (there the gate lets a gradient through that ReLU'(0) = 0 drops; an
+        // exact zero pre-activation only occurs for zero-padded units, whose incoming gradient is zero either way).
+#pragma unroll
+        for (int g = 0; g < kG; ++g) {
+          uint32_t sg = 0u;
+#pragma unroll
+          for (int ob = kHB - 1; ob >= 0; --ob)
+#pragma unroll
+            for (int r = 3; r >= 0; --r) sg = __builtin_amdgcn_alignbit(sg, __float_as_uint(h[l][g][ob][r]), 31);
+          hmask[g] = l == 0 ? (~sg & 0xFFFFu) : ((~sg << 16) | hmask[g]);
+        }
+      }
 #pragma unroll
       for (int g = 0; g < kG; ++g)
 #pragma unroll
         for (int ob = 0; ob < kHB; ++ob)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            h[l][g][ob][r] = relu_f(h[l][g][ob][r]);
-            // relu_f leaves +0 or a positive pattern: min(bits, 1) = [h > 0]; v_min_u32 + v_lshl_or_b32 per value
-            if constexpr (SAVE && COMPACT) hmask[g] |= min(__float_as_uint(h[l][g][ob][r]), 1u) << (16 * l + 4 * ob + r);
-          }
+          for (int r = 0; r < 4; ++r) h[l][g][ob][r] = relu_f(h[l][g][ob][r]);
     }
     f32x4 o[kG][1];
     if constexpr (OUT1) {
@@ -2082,10 +2095,17 @@ size_t bwd_lds_bytes(int n_linear, int kb1) {
   return sizeof(float) * ((size_t)kHB * 256 + (size_t)(n_hidden - 1) * kHB * kHB * 256 + (size_t)kb1 * kHB * 256);
 }
 
-// persistent_tiles > 0: the kernel walks `persistent_tiles` tiles with a grid-stride loop and wants exactly as many workgroups
-// as the device holds at once - CUs x the occupancy of THIS instantiation at this LDS size (queried once per kernel: the
-// pipelined forward needs 152-156 VGPRs in the split mode = three workgroups per CU since round 4, 172+ = two in the
-// fp32-MFMA mode); `grid` is then ignored.
+// persistent_tiles > 0: the kernel walks `persistent_tiles` tiles with a grid-stride loop and wants as many workgroups as the
+// device holds at once - CUs x min(occupancy of THIS instantiation at this LDS size, NESVOR_FWD_WGS_PER_CU); `grid` is then
+// ignored.  Since round 4 the pipelined forward needs 144-156 VGPRs in the split mode and THREE workgroups fit a CU.  Alone,
+// the launch is fastest that way (density / sigma network 0.116 / 0.086 ms against 0.125 / 0.095 with two).  Inside the
+// training step it is a loss on most boxes: the step runs at 1.21-1.26 kW of socket power, the engine clock floats at
+// 2.30-2.39 GHz under it, and the denser forward is paid for by the kernels behind it (in-job A/B, gpurun_out/r04i: forward
+// -0.002 ms, the two backward launches +0.017, step 1.135 -> 1.170 ms; on a box with more headroom 1.10 vs 1.12 the other
+// way).  Two per CU is the default; -DNESVOR_FWD_WGS_PER_CU=3 / NESVOR_FWD_GRID=768 for a box that has the headroom.
+#ifndef NESVOR_FWD_WGS_PER_CU
+#define NESVOR_FWD_WGS_PER_CU 2
+#endif
 template <typename K>
 int launch_kb(K k1, K k2, K k3, K k4, int kb1, dim3 grid, size_t lds, hipStream_t st, const MlpArgs& a, int threads = 256,
               int64_t persistent_tiles = 0) {
@@ -2115,6 +2135,7 @@ int launch_kb(K k1, K k2, K k3, K k4, int kb1, dim3 grid, size_t lds, hipStream_
         int dev = 0, cus = 256, per_cu = 2;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, threads, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (per_cu > NESVOR_FWD_WGS_PER_CU) per_cu = NESVOR_FWD_WGS_PER_CU;
         it = resident.emplace(std::make_pair(fn, lds), cus * per_cu).first;
       }
       n_wg = it->second;
