@@ -42,6 +42,16 @@ def init_distributed(backend: Optional[str] = None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if (world > 1 or forced()) and not dist.is_initialized():
+        hwq = os.environ.get("GPU_MAX_HW_QUEUES")
+        if hwq is not None and hwq.isdigit() and int(hwq) > 4:
+            # measured (tools/ddp_queue_probe.sh, profiles/r04_ddp_queue_probe.log): with 8 hardware queues and RCCL's queues
+            # live EVERY kernel of the step starts ~40 us late (prologue 5 -> 48 us, loss 17 -> 56 us in a kernel trace; step
+            # 1.24 -> 1.86 ms) whatever the stream layout or stream priorities - the command processor's queue switching, not
+            # an ordering problem of this code.  ROCm's default (4) does not show it.
+            import logging
+
+            logging.warning("GPU_MAX_HW_QUEUES=%s: the data-parallel step runs ~50 %% slower above 4 hardware queues on MI355X "
+                            "(see nesvor_amd/ddp.py); unset it or use 4", hwq)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:

@@ -88,7 +88,9 @@ class DirectStep:
         # side stream: the pose regulariser (a serial chain per slice) at the start of the step; at its end the owner pass of
         # the hash-grid backward (latency-bound, finishes the table gradient only) while the main stream runs the
         # sampler backward and the per-slice bookkeeping
-        self.side = torch.cuda.Stream(device=dev)
+        # NESVOR_SIDE_STREAM_PRIORITY (A/B switch): HIP stream priority of the side stream (lower number = higher priority)
+        _prio = __import__("os").environ.get("NESVOR_SIDE_STREAM_PRIORITY")
+        self.side = torch.cuda.Stream(device=dev) if _prio is None else torch.cuda.Stream(device=dev, priority=int(_prio))
         self._overlap_owner = __import__("os").environ.get("NESVOR_OWNER_OVERLAP", "1") != "0"
         # the table's AdamW step inside the owner pass (nesvor_hashgrid_backward_adamw) whenever one native call covers
         # gradient and update (no data-parallel exchange in between): the table gradient then never goes through HBM
