@@ -346,7 +346,7 @@ def main():
         step()
         torch.cuda.synchronize(device)
     # per-kernel HIP-event timing runs over its own K steps before the timed region (same process, data, kernels)
-    ktimes = {}
+    ktimes, bracket_ms = {}, 0.0
     if not opt.no_kernel_timing:
         for _ in range(2):
             step()
@@ -357,6 +357,18 @@ def main():
         torch.cuda.synchronize(device)
         ktimes = _lib.kernel_timer.summary()
         _lib.kernel_timer.reset(enabled=False)
+        # what an event bracket adds to the launch it brackets: the same two events around a one-element fill (a ~1.5 us kernel).
+        # A kernel trace (rocprofv3, profiles/r04_bench_n1_kernel_stats.csv) times the kernel alone and reads 4-7 us less per
+        # launch than these brackets - three launches make up the hash-grid roofline, so its event-based fraction sits ~0.03
+        # below the trace-based one.  `frac` stays the event-based number; this field says how much of it is the bracket.
+        tiny = torch.zeros(1, device=device)
+        pairs = []
+        for _ in range(50):
+            s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_ev.record(); tiny.zero_(); e_ev.record()
+            pairs.append((s_ev, e_ev))
+        torch.cuda.synchronize(device)
+        bracket_ms = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
     for _ in range(opt.warmup):
         step()
     elapsed, losses = timed(opt.steps)
@@ -484,6 +496,9 @@ def main():
                     "forward_only": (gbps(fwd_B, t_f) / 8000.0) if t_f > 0 else None,
                 },
                 "timing": f"HIP events on the launch stream over {k_steps} steps of this run, before the timed region",
+                "event_bracket_ms_around_a_one_element_fill": bracket_ms,
+                "frac_if_each_of_the_three_brackets_cost_that_much": None if strict_bw is None else
+                    (fwd_B + bwd_B) * n_points / (max(t_f + t_b - 3 * max(bracket_ms - 0.0015, 0.0), 1e-6) * 1e-3) / 1e9 / 8000.0,
                 "timing_path": "the same kernels on the same data as the timed region, issued from Python (nesvor_amd/direct.py::run) so that "
                                "every launch can be bracketed by events: all launches on ONE stream, and the owner pass WITHOUT the hash "
                                "table's AdamW step (the 2328 B/point do not contain optimizer bytes).  The timed region runs the one-call "
@@ -541,13 +556,15 @@ def main():
             except OSError:
                 pass
             # instructions per 16-sample group (SQ counters of the density-network launches, profiles/r03_pmc_sq_mlp_summary.txt:
-            # SQ_INSTS_MFMA and SQ_INSTS_VALU - which includes the MFMAs - over 65536 groups): forward 84 MFMA + 346 other VALU,
+            # SQ_INSTS_MFMA and SQ_INSTS_VALU - which includes the MFMAs - over 65536 groups): forward 84 MFMA + 346 other VALU (round 3),
             # backward 204 MFMA (chain wave 96, dW wave 108 of which 24 recompute the first hidden layer) + 792 other VALU
             # sigma_net (one output row: its output layer runs on the VALU, csrc/mlp.hip OUT1): 12 / 36 MFMAs and 37 / 112 VALU
             # instructions fewer per group (forward / backward; counted in the ISA of the two instantiations)
             out1 = os.environ.get("NESVOR_MLP_OUT1", "1") != "0"
-            sig_f, sig_b = ((72, 309), (168, 680)) if out1 else ((84, 346), (204, 792))
-            issue_cycles = ((84 * 16 + 346 * 4) + (204 * 16 + 792 * 4) + (sig_f[0] * 16 + sig_f[1] * 4) + (sig_b[0] * 16 + sig_b[1] * 4)) * groups / n_simd if compact else None
+            # round 4 (profiles/r04_pmc_sq_mlp_summary.txt): the forward's address arithmetic was hoisted out of its tile loop and the
+            # gate bits come from one v_alignbit per value: 84 MFMA + 258 other VALU per group (round 3: 346); backward unchanged
+            sig_f, sig_b = ((72, 221), (168, 680)) if out1 else ((84, 258), (204, 792))
+            issue_cycles = ((84 * 16 + 258 * 4) + (204 * 16 + 792 * 4) + (sig_f[0] * 16 + sig_f[1] * 4) + (sig_b[0] * 16 + sig_b[1] * 4)) * groups / n_simd if compact else None
             roof_mlp = {"bound": "instruction issue (bf16 MFMA + VALU, not overlapped)" if compact else "hbm",
                         "kernel": "mlp_fwd_pf x 2 + mlp_bwd_ws x 2 (density_net, sigma_net): the four MLP launches of a step",
                         "achieved": mlp_gbps, "peak": 8000.0, "unit": "GB/s", "frac": mlp_gbps / 8000.0,
@@ -566,7 +583,7 @@ def main():
                                 "Issue view: issue_frac = (16 cycles per bf16 MFMA + 4 per VALU instruction, per SIMD, at the maximum engine "
                                 "clock) / measured time - the two instruction classes do not overlap on gfx950 "
                                 "(tools/mfma_bf16_overlap.hip), the rest is dependency and LDS latency at two waves per SIMD; SQ counters in "
-                                "profiles/r03_pmc_sq_mlp_summary.txt"}
+                                "profiles/r04_pmc_sq_mlp_summary.txt; the engine clock under this load floats at 2.30-2.39 GHz (profiles/r04_power_probe.log)"}
         out = {
             "metric": "INR train iters/sec (2^20 samples, L=16 hash, 64-wide MLP)",
             "value": iters_per_s,

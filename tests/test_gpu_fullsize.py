@@ -192,7 +192,7 @@ def test_slice_acq_full_size_stack_vs_oracle(device, phantom, angle_index):
 def test_config_c3_data_six_stacks_one_gpu(device, phantom):
     """BASELINE C3's data and iteration size on the one GPU a test box has: 6 stacks (462 slices) of the 128^3 phantom,
     4096 pixels x 256 samples = 2^20 samples per iteration, the headline model, 2000 iterations.  The reconstruction
-    must be at least as good as the 3-stack one of C2 (floor 15 dB; measured value printed)."""
+    must be at least as good as the 3-stack one of C2 (measured 16.75 dB; floor = measured - 0.5 dB)."""
     from bench import make_args
     from nesvor_amd.phantom import simulate_stacks
     from nesvor_amd.train import train
@@ -205,7 +205,7 @@ def test_config_c3_data_six_stacks_one_gpu(device, phantom):
     assert all(torch.isfinite(p).all() for p in inr.parameters())
     p = _psnr_vs_phantom(inr, phantom)
     print(f"C3 data (6 stacks, 2^20 samples/iter, 2000 iterations): PSNR {p:.2f} dB")
-    assert p >= 15.0
+    assert p >= 16.25  # measured 16.75 (rounds 3 and 4); the C1 fixtures pin the PSNR against the oracle to 0.1 dB
 
 
 def _pose_errors(est, true):
@@ -217,9 +217,9 @@ def test_config_c4_motion_at_128(device, phantom):
     """BASELINE C4 at its stated size: the 128^3 phantom, every slice acquired at a perturbed pose (rotvec ~ N(0, (2
     deg)^2), t ~ N(0, (1 mm)^2), seed 0), training starts from the nominal poses and optimises poses and INR jointly
     (models.py:193-210, 357-363); headline model, 4096 x 256 samples, 2000 iterations.
-    * the mean pose error against the true poses shrinks, in rotation and in translation;
-    * pose optimisation pays for itself: PSNR >= the run with the poses frozen at their nominal values;
-    * the reconstruction stays within 1 dB of the motion-free one and above 16 dB (tools/recon_phantom.py: 16.9 dB)."""
+    * the mean pose error against the true poses shrinks to below 0.75 x (rotation) / 0.9 x (translation) of its start;
+    * pose optimisation pays for itself: PSNR >= 3 dB above the run with the poses frozen at their nominal values;
+    * the reconstruction stays within 0.85 dB of the motion-free one and above 16.4 dB (floors = measured values - 0.5 dB)."""
     from bench import make_args
     from nesvor_amd.phantom import simulate_stacks
     from nesvor_amd.train import train
@@ -239,11 +239,12 @@ def test_config_c4_motion_at_128(device, phantom):
     print("C4 at 128^3:", {k: round(v["psnr"], 2) for k, v in results.items()},
           "rot deg %.3f -> %.3f, trans mm %.3f -> %.3f" % (m["before"][0].mean(), m["after"][0].mean(),
                                                            m["before"][1].mean(), m["after"][1].mean()))
-    assert float(m["after"][0].mean()) < float(m["before"][0].mean())
-    assert float(m["after"][1].mean()) < float(m["before"][1].mean())
-    assert m["psnr"] >= results["motion_frozen"]["psnr"] - 0.1
-    assert m["psnr"] >= results["still"]["psnr"] - 1.0
-    assert m["psnr"] >= 16.0
+    # measured (rounds 3 and 4): rotation 3.15 -> 2.01 deg, translation 3.20 -> 2.53 mm; still 17.25 / motion 16.91 / frozen 12.52 dB
+    assert float(m["after"][0].mean()) < 0.75 * float(m["before"][0].mean())
+    assert float(m["after"][1].mean()) < 0.9 * float(m["before"][1].mean())
+    assert m["psnr"] >= results["motion_frozen"]["psnr"] + 3.0
+    assert m["psnr"] >= results["still"]["psnr"] - 0.85
+    assert m["psnr"] >= 16.4 and results["still"]["psnr"] >= 16.75
 
 
 def test_config_c5_shape_at_128(device, phantom):
@@ -254,7 +255,7 @@ def test_config_c5_shape_at_128(device, phantom):
       coarsest levels, 16-8 mm cells) is free to take over smooth intensity structure - the product bias x density is what
       the data term sees, biasReg only pins the MEAN log bias - and ``sample_volume`` returns the density alone, exactly
       as the reference does (sample.py:17-33 evaluates ``INR.forward``).  Measured: 15.1 dB against 16.9 dB without the
-      field (at 64^3 / 600 iterations the two agree to 0.5 dB); asserted: within 2.5 dB and above 14 dB;
+      field (at 64^3 / 600 iterations the two agree to 0.5 dB); asserted: within 2.35 dB and above 14.5 dB (measured - 0.5 dB);
     * the sampled volume lives on the mask's 0.5 mm lattice, is zero outside the mask, and compared voxel by voxel with
       the phantom interpolated to that lattice reaches the PSNR of the voxel-centre evaluation within 1 dB."""
     import torch.nn.functional as F
@@ -293,4 +294,4 @@ def test_config_c5_shape_at_128(device, phantom):
             print(f"C5 sample_volume at 0.5 mm: {tuple(out.image.shape)} voxels, {int(out.mask.sum())} in the mask, PSNR {p_vol:.2f} dB")
             assert p_vol >= psnr[nb] - 1.0
     print(f"C5 shape at 128^3, 6 stacks, 5000 iterations: PSNR without bias field {psnr[0]:.2f} dB, with n_levels_bias=4 {psnr[4]:.2f} dB")
-    assert psnr[4] >= psnr[0] - 2.5 and psnr[4] >= 14.0
+    assert psnr[4] >= psnr[0] - 2.35 and psnr[4] >= 14.5 and psnr[0] >= 16.4  # measured 16.88 / 15.03 dB
