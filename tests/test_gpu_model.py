@@ -75,6 +75,46 @@ def test_fused_trainer_step_equals_autograd_plus_adamw(device, golden):
         torch.testing.assert_close(p2.detach(), p1.detach(), rtol=5e-3, atol=2e-5, msg=n1)
 
 
+def test_deferred_table_join_survives_a_change_of_batch_size(device, golden):
+    """Round-3 advisor finding: a table update left on the side stream (``defer_table_join``) was only ever joined by the
+    native context that left it there - one context per (batch size, operand mode) - so a step with ANOTHER batch size read
+    the table, and reused the backward's workspace, under the running update.  ``DirectStep._run_native`` now joins when the
+    context changes.  Two trainers from the same state, one joining every step, one deferring, batch size alternating
+    between two values every step: losses and parameters must agree as in the fixed-size test above."""
+    from nesvor_amd.fused import FusedTrainer
+    from nesvor_amd.models import NeSVoR
+    from nesvor_amd.transform import RigidTransform
+
+    args = small_args(device=device)
+    tf = RigidTransform(torch.tensor(golden["fw_sd::axisangle_init"]).to(device), trans_first=True)
+    res = torch.tensor(golden["ds_resolution"]).to(device)
+    bbox = torch.tensor(golden["fw_sd::inr.bounding_box"]).to(device)
+    torch.manual_seed(5)
+    ma = NeSVoR(tf, res, float(golden["ds_mean"]), bbox, args)
+    with torch.no_grad():
+        ma.inr.encoding.params.mul_(1e3)
+    mb = NeSVoR(tf, res, float(golden["ds_mean"]), bbox, args)
+    mb.load_state_dict(ma.state_dict())
+    ta, tb = FusedTrainer(ma, args), FusedTrainer(mb, args)
+    if not all(t.direct is not None and t.direct.native_ready() for t in (ta, tb)):
+        pytest.skip("the one-call step is switched off (NESVOR_STEP_NATIVE=0)")
+    ta.direct._adamw_in_owner = tb.direct._adamw_in_owner = True
+    tb.defer_table_join = True
+    d = lambda k: torch.tensor(golden[f"fw_{k}"]).to(device)
+    xyz, v, idx = d("xyz"), d("v"), d("idx")
+    n = xyz.shape[0]
+    sizes = [n, n // 2, n, n // 2 + 4, n, n // 2]
+    for it, b in enumerate(sizes):
+        la, lb = (t.step(xyz[:b].contiguous(), v[:b].contiguous(), idx[:b].contiguous()) for t in (ta, tb))
+        for k in la:
+            assert abs(float(lb[k]) - float(la[k])) <= 1e-4 * abs(float(la[k])) + 1e-7, (it, b, k)
+    assert len(tb.direct._native) >= 2  # more than one native context was in play
+    tb.join()
+    apart = ((tb.flat.param - ta.flat.param).abs() > 1e-5 * (1 + ta.flat.param.abs())).float().mean()
+    assert float(apart) < 2e-3, float(apart)
+    assert float(tb.flat.grad.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("over", [
     {}, {"depth": 2}, {"no_transformation_optimization": True}, {"no_pixel_variance": True},
     {"no_slice_scale": True, "no_slice_variance": True}, {"image_regularization": "TV"},
