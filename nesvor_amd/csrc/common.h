@@ -103,6 +103,23 @@ __device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v, int lane) {
   }
 }
 
+// Global loads / stores in the scalar-base form: address = SGPR pair (wave-uniform base) + zero-extended 32-bit VGPR byte
+// offset.  The compiler only selects this form when it can prove the offset fits 32 bits; written out, a gather or a
+// feature-major row store needs no 64-bit vector address arithmetic (v_lshl_add_u64 / v_add_co pairs per access).  The loads
+// are invisible to the compiler's wait-count insertion: every consumer must sit behind gwait_loads().
+typedef float nesvor_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gload_b64_sbase(nesvor_f32x2& dst, const void* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void gstore_b32_sbase(const void* sbase, uint32_t voff, float v) {
+  asm volatile("global_store_dword %0, %1, %2" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void gwait_loads() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void gpin(nesvor_f32x2& x) { asm volatile("" : "+v"(x)); }
+
 // fp32 add into LDS through an integer compare-and-swap loop.  On gfx950 ds_add_f32 retires ~1 lane
 // per 3 cycles (192+ cycles per wave-instruction, measured, independent of conflicts) while
 // ds_cmpst_rtn_b32 runs at ~7 cycles per conflict-free wave-instruction, so the CAS loop wins

@@ -223,6 +223,15 @@ __global__ __launch_bounds__(256) void hashgrid_fwd(const nesvor_grid_t g, const
 // LDS copy (512 slots) together share a round (levels 0-6, 7-8, 9-10, 11 for the bench's clouds), and the next round's table
 // entries are in flight while the current round interpolates (two copies, one barrier per round).  Levels whose box
 // does not fit (the finest one or two of a cloud; almost all for unclustered points) gather from global memory.
+// A/B switches of the per-cloud forward (round 4): packed fp32 blend, scalar-base row stores (11 % fewer VALU instructions per
+// wave; the launch takes 0.075 ms with or without them - it is latency-bound at full occupancy, profiles/r04_pmc_sq_hashgrid_fwd_cloud_summary.txt -
+// and gathers issued as scalar-base inline asm with an explicit vmcnt(0) cost 0.003 ms: the wait also drains the row stores)
+#ifndef NESVOR_FWD_PK
+#define NESVOR_FWD_PK 1
+#endif
+#ifndef NESVOR_FWD_SSTORE
+#define NESVOR_FWD_SSTORE 1
+#endif
 template <int F, int LAYOUT>
 __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g, const float* __restrict__ u,
                                                           const float* __restrict__ table, float* __restrict__ pe, int64_t N) {
@@ -300,6 +309,9 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
   __syncthreads();
   const int box_end = __builtin_amdgcn_readfirstlane(box_end_s);
   auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+  // feature-major rows: scalar row base + the lane's 32-bit byte offset (4 i < 2^32) - no vector address arithmetic per store
+  const bool off32 = NESVOR_FWD_SSTORE && N < ((int64_t)1 << 30);
+  const uint32_t i4 = (uint32_t)i * 4u;
   auto store_pe = [&](int level, const float (&acc)[F]) __attribute__((always_inline)) {
     if (!valid) return;
     if constexpr (LAYOUT == NESVOR_LAYOUT_ROW_MAJOR) {
@@ -307,11 +319,33 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
 #pragma unroll
       for (int f = 0; f < F; ++f) o[f] = acc[f];
     } else {
+      if (off32) {
 #pragma unroll
-      for (int f = 0; f < F; ++f) pe[(size_t)(level * F + f) * N + i] = acc[f];
+        for (int f = 0; f < F; ++f) gstore_b32_sbase(pe + (size_t)(level * F + f) * N, i4, acc[f]);
+      } else {
+#pragma unroll
+        for (int f = 0; f < F; ++f) pe[(size_t)(level * F + f) * N + i] = acc[f];
+      }
     }
   };
   auto blend = [&](const CellPos& c, const float (&v)[8][F], float (&acc)[F]) __attribute__((always_inline)) {
+    if constexpr (F == 2 && NESVOR_FWD_PK) {
+      // packed fp32 (v_pk_mul_f32 / v_pk_fma_f32: two lanes of fp32 per instruction): the x-pair of every weight and the two
+      // features of every corner go through one instruction each - the same products and fused multiply-adds in the same
+      // order as the scalar form below (bit-identical), 18 instead of 31 VALU instructions per level
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const f32x2 wx2 = {1.f - c.wx, c.wx};
+      const float ay[2] = {1.f - c.wy, c.wy}, az[2] = {1.f - c.wz, c.wz};
+      f32x2 a = {0.f, 0.f};
+#pragma unroll
+      for (int zy = 0; zy < 4; ++zy) {  // corners k = 2 zy, 2 zy + 1: weights (ax ay) az
+        const f32x2 w2 = (wx2 * ay[zy & 1]) * az[zy >> 1];
+        a = __builtin_elementwise_fma(f32x2{w2.x, w2.x}, f32x2{v[2 * zy][0], v[2 * zy][1]}, a);
+        a = __builtin_elementwise_fma(f32x2{w2.y, w2.y}, f32x2{v[2 * zy + 1][0], v[2 * zy + 1][1]}, a);
+      }
+      acc[0] = a.x; acc[1] = a.y;
+      return;
+    }
 #pragma unroll
     for (int f = 0; f < F; ++f) acc[f] = 0.f;
 #pragma unroll
@@ -400,11 +434,13 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
     const float* tab0 = table + (size_t)p0.offset * F;
     const float* tab1 = table + (size_t)p1.offset * F;
     float v0[8][F], v1[8][F], acc[F];
+    {
 #pragma unroll
     for (int k = 0; k < 8; ++k) load_feat<F>(tab0 + (size_t)corner_index(p0, c0.gx + (k & 1), c0.gy + ((k >> 1) & 1), c0.gz + (k >> 2)) * F, v0[k]);
     if (two) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) load_feat<F>(tab1 + (size_t)corner_index(p1, c1.gx + (k & 1), c1.gy + ((k >> 1) & 1), c1.gz + (k >> 2)) * F, v1[k]);
+    }
     }
     blend(c0, v0, acc);
     store_pe(lv, acc);

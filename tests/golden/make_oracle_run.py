@@ -92,7 +92,11 @@ def main():
     ap.add_argument("--batch-size", type=int, default=1024)
     ap.add_argument("--n-samples", type=int, default=64)
     ap.add_argument("--out", default=os.path.join(HERE, "oracle_run_c1.npz"))
+    ap.add_argument("--threads", type=int, default=0, help="torch.set_num_threads (0: PyTorch's default); the GPU boxes' 128-thread hosts "
+                                                            "run this loop 5-7x faster on 32 threads (bench.py cpu_baseline)")
     opt = ap.parse_args()
+    if opt.threads > 0:
+        torch.set_num_threads(opt.threads)
 
     from bench import make_args
     from nesvor_amd.train import Dataset

@@ -21,6 +21,6 @@ table = ((torch.rand(spec.n_params, generator=torch.Generator().manual_seed(1337
 dy = torch.randn(32, N, device=dev)
 gt = torch.zeros_like(table)
 for _ in range(3):
-    hashgrid_forward(spec, u, table, 1)
+    hashgrid_forward(spec, u, table, 1, clustered=(dist != "U"))  # the kernel the training step launches: per-cloud for PSF clouds
     hashgrid_backward(spec, u, table, dy, gt, True, 1, "owner")
 torch.cuda.synchronize()
