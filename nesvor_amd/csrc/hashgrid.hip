@@ -653,8 +653,15 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) {
 // BOUND: max |dy| comes from the caller (`dy_bound`) and the pass over dy that determines it is compiled out.  A template
 // parameter, not a run-time branch: with the branch in place the compiler restructured the pass it guards, and the kernel
 // WITHOUT a bound ran 3x slower on uniform points (4.9 vs 1.6 ms) and 4 % slower on PSF clouds (tools/hg_variants.py).
+#ifndef NESVOR_HG_SLOTS
+#define NESVOR_HG_SLOTS 1024      // merge-table slots at F <= 2.  A/B (gpurun_out/s2j2): 2048 slots at two workgroups per CU (66 KB of LDS) let levels
+                                  // 12-13 take the box path, and the pass goes from 0.346 to 0.505 ms: it lives on its four waves per SIMD
+#endif
+#ifndef NESVOR_HG_MINBLOCKS
+#define NESVOR_HG_MINBLOCKS 4
+#endif
 template <int F, int LAYOUT, bool INPUT_GRAD, bool MERGE, bool BOUND = false>
-__global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_bwd_aggregate(const nesvor_grid_t g, const BwdPlan plan,
+__global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2)) void hashgrid_bwd_aggregate(const nesvor_grid_t g, const BwdPlan plan,
                                                               const float* __restrict__ u,
                                                               const float* __restrict__ table,
                                                               const float* __restrict__ dpe,
@@ -680,7 +687,7 @@ __global__ __launch_bounds__(256, F <= 2 ? 4 : (F == 4 ? 3 : 2)) void hashgrid_b
   __shared__ uint32_t sortbuf[256];
   // workgroup-wide merge table: slots addressed by position in the lattice box (box rounds; tkeys then holds
   // level << 27 | entry index of every slot) or by open addressing keyed by the level-local entry index
-  constexpr int kSlots = F <= 2 ? 1024 : (F == 4 ? 512 : 256);
+  constexpr int kSlots = F <= 2 ? NESVOR_HG_SLOTS : (F == 4 ? 512 : 256);
   constexpr uint32_t kEmpty = 0xFFFFFFFFu;
   constexpr uint32_t kKeyMask = (1u << 27) - 1u;
   constexpr int kMaxGroup = 8;  // levels per box round

@@ -1137,18 +1137,36 @@ __device__ __forceinline__ void read_operand(const float* tile, int i, int q, fl
 }
 
 // Plane tiles (split mode of the wave-specialised backward): the chain wave hands a 16 x 16 dpre tile to its dW wave already
-// split - three bf16 planes of 512 bytes, TRANSPOSED ([feature row][sample]), so that the dW wave's A operand (feature i,
-// samples 4q..4q+3) is one 8-byte read per plane and needs no splitting of its own.  Feature f = 4q + r sits in row 4r + q:
-// the four rows a wave-store touches (r fixed, q = 0..3) are then adjacent and cover 32 distinct LDS banks.
-// NESVOR_MLP_PLANES (build macro, default 0).  Measured (density / sigma network backward): 0.279 / 0.243 ms per launch with
-// the planes (tools/mlp_variants.py) against 0.264 / 0.228 with fp32 tiles that BOTH waves of a pair split
-// (profiles/r03_mlp_variants.log), in the training step 2 x 0.231 against 2 x 0.216 ms - although the planes take 86 VALU
-// instructions per group off the dW wave (440 -> 354): the 96 two-byte LDS stores per group they cost the chain wave
-// outweigh the 8 x 14 split instructions they save.
+// split - three bf16 planes of 512 bytes - so that the dW wave's A operand (feature i, samples 4q..4q+3) is one 8-byte read
+// per plane and needs no splitting of its own (112 VALU instructions per group off the dW wave).
+// NESVOR_MLP_PLANES (build macro): 0 = fp32 tiles that BOTH waves of a pair split (rounds 1-3 and the start of round 4);
+// 1 = planes stored TRANSPOSED ([feature row][sample]; feature f = 4q + r in row 4r + q) with 96 two-byte LDS stores per
+//     group, which cost the chain wave more than the split they save (round 3: 0.279 / 0.243 ms per launch against 0.264 / 0.228);
+// 2 = the default since round 4: planes stored as the chain wave holds them, transposed by the READ (below).  Same box, same job
+//     (gpurun_out/s2j2): density / sigma backward 0.277 / 0.220 ms (0) -> 0.262 / 0.205 (2), in the step 0.425 -> 0.400 ms for the
+//     two launches.  Bit-identical results: the planes are those the dW wave would have formed.
 #ifndef NESVOR_MLP_PLANES
-#define NESVOR_MLP_PLANES 0
+#define NESVOR_MLP_PLANES 2
 #endif
-constexpr int kPlaneTileFloats = 3 * 16 * 16 / 2;  // three planes of 256 bf16
+// NESVOR_MLP_PLANES=2 (round 4): the chain wave stores each plane of its fragment UNtransposed - one ds_write_b64 per plane, the
+// lane's four bf16 (features 4q..4q+3 of sample j) at 8-byte chunk j + kPlaneQ q - and the dW wave reads it with gfx950's
+// transposing LDS read: ds_read_b64_tr_b16 hands lane i of a 16-lane group the element (i & 3) of the chunks whose addresses
+// the group's lanes 4t + (i >> 2), t = 0..3, supply.  Lane (feature i, sample quad q') therefore supplies the address of chunk
+// (sample 4q' + (i >> 2), feature quad i & 3) and receives feature i of samples 4q'..4q'+3: the A operand, already split.
+// 24 eight-byte stores per group instead of 96 two-byte ones.  With kPlaneQ = 16 the feature quads q and q + 2 of one read
+// fall on the same banks (64 dwords); the chunk index of a sample is therefore XOR-ed with 4 for q >= 2 (a permutation
+// inside each quad's 16 chunks: the store stays one dense 512-byte row per plane).  A padded stride (kPlaneQ = 18 / 20) does
+// the same without the swizzle but does not fit the 160 KiB of LDS next to the operand images.
+#ifndef NESVOR_MLP_PLANE_Q
+#define NESVOR_MLP_PLANE_Q 16
+#endif
+#ifndef NESVOR_MLP_PLANE_SWZ
+#define NESVOR_MLP_PLANE_SWZ 1
+#endif
+constexpr bool kPlanesTr = NESVOR_MLP_PLANES == 2;
+constexpr int kPlaneQ = NESVOR_MLP_PLANE_Q;
+constexpr int kPlaneBytes = kPlanesTr ? ((8 * (3 * kPlaneQ + 16) + 15) / 16) * 16 : 512;
+constexpr int kPlaneTileFloats = 3 * kPlaneBytes / 4;  // three planes of 256 bf16
 constexpr int kTile0Stride = 16;                   // the dY tile stays fp32 (it is the one tile that must fit next to the planes: no padding)
 constexpr int kTile0Floats = 16 * kTile0Stride;
 __device__ __forceinline__ void stage_tile0(float* tile, const f32x4& frag, int j, int q) {
@@ -1166,7 +1184,15 @@ template <int OFF> __device__ __forceinline__ void lds_store_lo16(uint32_t addr,
 template <int OFF> __device__ __forceinline__ void lds_store_hi16(uint32_t addr, uint32_t v) {
   asm volatile("ds_write_b16_d16_hi %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 __device__ __forceinline__ void stage_planes(float* tile, const Split3& s, int j, int q) {
+  if constexpr (kPlanesTr) {
+    char* p = reinterpret_cast<char*>(tile) + 8 * ((NESVOR_MLP_PLANE_SWZ ? (j ^ ((q >> 1) << 2)) : j) + kPlaneQ * q);
+    *reinterpret_cast<s16x4*>(p) = s.hi;
+    *reinterpret_cast<s16x4*>(p + kPlaneBytes) = s.mid;
+    *reinterpret_cast<s16x4*>(p + 2 * kPlaneBytes) = s.lo;
+    return;
+  }
   // lane (sample j, q) holds feature 4q + r -> row 4r + q (32 bytes per row), plane p at 512 p bytes
   const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)tile + (uint32_t)((q * 16 + j) * 2);
   const uint2 h = __builtin_bit_cast(uint2, s.hi), m = __builtin_bit_cast(uint2, s.mid), l = __builtin_bit_cast(uint2, s.lo);
@@ -1175,6 +1201,14 @@ __device__ __forceinline__ void stage_planes(float* tile, const Split3& s, int j
   lds_store_lo16<1024>(addr, l.x); lds_store_hi16<1024 + 128>(addr, l.x); lds_store_lo16<1024 + 256>(addr, l.y); lds_store_hi16<1024 + 384>(addr, l.y);
 }
 __device__ __forceinline__ void read_planes(const float* tile, int i, int q, Split3& a) {
+  if constexpr (kPlanesTr) {
+    const int js = 4 * q + (i >> 2);  // the sample whose chunk this lane addresses; its feature quad is i & 3
+    const char* p = reinterpret_cast<const char*>(tile) + 8 * ((NESVOR_MLP_PLANE_SWZ ? (js ^ ((i & 2) << 1)) : js) + kPlaneQ * (i & 3));
+    a.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    a.mid = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + kPlaneBytes));
+    a.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 2 * kPlaneBytes));
+    return;
+  }
   const unsigned short* t16 = reinterpret_cast<const unsigned short*>(tile) + (4 * (i & 3) + (i >> 2)) * 16 + 4 * q;
   a.hi = *reinterpret_cast<const s16x4*>(t16);
   a.mid = *reinterpret_cast<const s16x4*>(t16 + 256);
@@ -1928,7 +1962,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         issue_x(gi, xraw, xsraw);
         // the next group's activations: a whole iteration ahead - or (COMPACT with plane tiles, where the recomputation's input set
         // and the plane prefetch make the dW2 product the register peak of the kernel) right after that product
-        constexpr bool kHLate = COMPACT && PLANES;
+#ifndef NESVOR_MLP_HLATE
+#define NESVOR_MLP_HLATE 0  // (1 was needed by the two-byte-store planes at the register limit; with the transposing read the early request fits: 248 VGPRs, 0.267 -> 0.262 ms)
+#endif
+        constexpr bool kHLate = COMPACT && PLANES && (NESVOR_MLP_HLATE != 0);
         if constexpr (!kHLate) issue_h(gnext, hraw_n);
         const float* buf = my_tiles + ((it - 1) & 1) * kBufFloats;
         auto input_operands = [&](f32x4 (&xb_)[KB1]) __attribute__((always_inline)) {
@@ -1948,9 +1985,20 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           if constexpr (PLANES) {
             // dY tile (fp32, split here) and the first plane tile are requested together; every later A operand one tile ahead
             Split3 ap;
-            read_operand0(buf, j, q, av);
-            read_planes(buf + kTile0Floats, j, q, ap);
-            accumulate_dw_split<1, kHB>(buf, hb[NH - 1], acc_o, j, q, av, nullptr);
+            if constexpr (OUT1) {
+              float dy4[4];
+              read_operand0(buf, 0, q, dy4);                    // row 0 of the dY tile: samples 4q..4q+3 (a broadcast read)
+              read_planes(buf + kTile0Floats, j, q, ap);
+              __builtin_amdgcn_sched_barrier(0x047F);
+#pragma unroll
+              for (int ib = 0; ib < kHB; ++ib)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc1[ib] = fmaf(dy4[t], hb[NH - 1][ib][t], acc1[ib]);
+            } else {
+              read_operand0(buf, j, q, av);
+              read_planes(buf + kTile0Floats, j, q, ap);
+              accumulate_dw_split<1, kHB>(buf, hb[NH - 1], acc_o, j, q, av, nullptr);
+            }
 #pragma unroll
             for (int l = NH - 1; l >= 0; --l) {
               const float* dt = buf + kTile0Floats + (NH - 1 - l) * kHB * kPlaneTileFloats;

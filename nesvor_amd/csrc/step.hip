@@ -26,7 +26,8 @@ namespace {
 
 struct StepCtx {
   nesvor_step_t d;
-  hipEvent_t ev_fork, ev_pose, ev_agg, ev_owner;
+  hipEvent_t ev_fork, ev_pose, ev_agg, ev_owner, ev_bwd, ev_sums;
+  bool sums_on_side = false;  // the networks' parameter-gradient sums of the current iteration were left on the side stream
   bool pending_join = false;  // a table update of the previous run is still on the side stream (NESVOR_STEP_DEFER_JOIN)
 };
 
@@ -94,7 +95,7 @@ extern "C" void* nesvor_step_create(const nesvor_step_t* desc) {
   StepCtx* c = new (std::nothrow) StepCtx;
   if (c == nullptr) return nullptr;
   c->d = *desc;
-  hipEvent_t* evs[4] = {&c->ev_fork, &c->ev_pose, &c->ev_agg, &c->ev_owner};
+  hipEvent_t* evs[6] = {&c->ev_fork, &c->ev_pose, &c->ev_agg, &c->ev_owner, &c->ev_bwd, &c->ev_sums};
   for (hipEvent_t* e : evs) {
     if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
   }
@@ -111,6 +112,7 @@ extern "C" void nesvor_step_destroy(void* handle) {
   if (handle == nullptr) return;
   StepCtx* c = static_cast<StepCtx*>(handle);
   (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_pose); (void)hipEventDestroy(c->ev_agg); (void)hipEventDestroy(c->ev_owner);
+  (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_sums);
   delete c;
 }
 
@@ -207,7 +209,23 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
       in[n_jobs] = part_d; out[n_jobs] = d.g_density; cols[n_jobs++] = d.n_density_params;
       if (d.has_lv) { in[n_jobs] = part_s; out[n_jobs] = d.g_sigma; cols[n_jobs++] = d.n_sigma_params; }
       if (d.has_b) { in[n_jobs] = part_b; out[n_jobs] = d.g_bias_net; cols[n_jobs++] = d.n_bias_params; }
-      NESVOR_TRY(nesvor_sum_rows_multi(in, out, cols, cols, n_jobs, NESVOR_STEP_MLP_PARTIALS, main));
+      // Only the closing AdamW (or the caller's optimizer / gradient exchange, which joins the side stream) reads these sums.
+      // NESVOR_STEP_SUMS_SIDE=1 runs them on the side stream, under the aggregation pass, instead of in front of it (9 us of
+      // the critical path) - measured in one job, alternating (gpurun_out/s2j2): 895 / 900 it/s on the main stream, 893 / 896
+      // on the side stream: the aggregation pass starts later behind the cross-stream hand-over than it gains.  Off.
+      hipStream_t sums_stream = main;
+      ctx->sums_on_side = false;
+      static const bool sums_side = []() { const char* e = getenv("NESVOR_STEP_SUMS_SIDE"); return e != nullptr && strcmp(e, "1") == 0; }();  // A/B switch
+      const bool on_side = overlap_owner && sums_side;
+      if (on_side) {
+        if (hipEventRecord(ctx->ev_bwd, main) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_bwd, 0) != hipSuccess) return (int)hipGetLastError();
+        sums_stream = side;
+      }
+      NESVOR_TRY(nesvor_sum_rows_multi(in, out, cols, cols, n_jobs, NESVOR_STEP_MLP_PARTIALS, sums_stream));
+      if (on_side) {
+        if (hipEventRecord(ctx->ev_sums, side) != hipSuccess) return (int)hipGetLastError();
+        ctx->sums_on_side = true;
+      }
     }
   }
   // ---- hash-grid backward (+ input gradient when the poses are optimised)
@@ -277,6 +295,10 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
                                   d.opt_T ? d.trans_terms : nullptr, losses, n, B, img_scale, img_off, main));
   if (d.has_b) hipLaunchKernelGGL(square_kernel, dim3(1), dim3(1), 0, main, d.lb_mean, losses + 5);
   if (adam != nullptr) {
+    if (ctx->sums_on_side) {
+      if (hipStreamWaitEvent(main, ctx->ev_sums, 0) != hipSuccess) return (int)hipGetLastError();
+      ctx->sums_on_side = false;
+    }
     if (fuse_adamw) {
       // everything but the table; the table's update is the owner pass, which the next forward must wait for - here, or
       // (NESVOR_STEP_DEFER_JOIN) in the next run right before its hash-grid forward, so that the next iteration's prologue and
