@@ -114,8 +114,12 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x4 pack_bf16(const f32x4& v) {
-  return __builtin_bit_cast(s16x4, __builtin_convertvector(v, bf16x4));
+  // two v_cvt_pk_bf16_f32 (converting the four-vector at once is scalarised where a half of the result is used on its own:
+  // four conversions with an undefined second source plus two v_perm_b32)
+  const bf16x2_t a = __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2_t), b = __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2_t);
+  return __builtin_bit_cast(s16x4, __builtin_shufflevector(a, b, 0, 1, 2, 3));
 }
 __device__ __forceinline__ f32x4 mfma16_bf16(s16x4 a, s16x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
@@ -1215,6 +1219,31 @@ __device__ __forceinline__ void read_planes(const float* tile, int i, int q, Spl
   a.lo = *reinterpret_cast<const s16x4*>(t16 + 512);
 }
 
+// The three A tuples of a dW block product - (lo | hi), (mid | mid), (hi | hi): the hi plane is needed in three register pairs,
+// the mid plane in two.  With the transposing read every pair is READ into place (six LDS reads per tile instead of three reads
+// and six register moves: the LDS pipe has room, the VALU does not).  `dup[0..1]` are two opaque zeros (VGPRs written by an empty
+// asm): added to the address they keep the compiler from merging the repeated reads back into one read plus moves.
+struct PlanesA { bf16x8 lh, mm, hh; };
+__device__ __forceinline__ void read_planes3(const float* tile, int i, int q, const uint32_t (&dup)[2], PlanesA& a) {
+  if constexpr (kPlanesTr) {
+    const int js = 4 * q + (i >> 2);
+    const char* p = reinterpret_cast<const char*>(tile) + 8 * ((NESVOR_MLP_PLANE_SWZ ? (js ^ ((i & 2) << 1)) : js) + kPlaneQ * (i & 3));
+    const char* p1 = p + dup[0];
+    const char* p2 = p + dup[1];
+    const s16x4 l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 2 * kPlaneBytes));
+    const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    const s16x4 m0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + kPlaneBytes));
+    const s16x4 m1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1 + kPlaneBytes));
+    const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+    const s16x4 h2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p2));
+    a.lh = join8(l, h0); a.mm = join8(m0, m1); a.hh = join8(h1, h2);
+    return;
+  }
+  Split3 s;
+  read_planes(tile, i, q, s);
+  a.lh = join8(s.lo, s.hi); a.mm = join8(s.mid, s.mid); a.hh = join8(s.hi, s.hi);
+}
+
 template <int OB, int IB>
 __device__ __forceinline__ void accumulate_dw(float* scratch, const f32x4 (&dy)[OB], const f32x4 (&x)[IB],
                                               f32x4 (&acc)[OB][IB], float (&db)[OB], int lane) {
@@ -1547,34 +1576,27 @@ __device__ __forceinline__ void accumulate_dw_split(const float* tiles, const f3
 // the first tile; the next one (of this layer, or `next_tile`) is requested before the current one is multiplied.
 template <int OB, int IB>
 __device__ __forceinline__ void accumulate_dw_planes(const float* tiles, const f32x4 (&bv)[IB], f32x4 (&acc)[OB][IB], int i, int q,
-                                                     Split3& ap, const float* next_tile) {
-  // B operands two input blocks at a time: their tuples (8 registers per block) are what peaks the register use of the
-  // kernel; the A planes are then read once per pair of input blocks (3 x 8-byte LDS reads per tile)
-  constexpr int CH = IB;  // (chunks of two input blocks were tried to lower the register peak: +32 VALU per group for re-joined A tuples)
+                                                     PlanesA& ap, const float* next_tile, const uint32_t (&dup)[2]) {
+  bf16x8 b_hl[IB], b_mh[IB];
 #pragma unroll
-  for (int ib0 = 0; ib0 < IB; ib0 += CH) {
-    bf16x8 b_hl[CH], b_mh[CH];
+  for (int c = 0; c < IB; ++c) {
+    const Split3 sb = split3(bv[c]);
+    b_hl[c] = join8(sb.hi, sb.lo);
+    b_mh[c] = join8(sb.mid, sb.hi);
+  }
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const Split3 sb = split3(bv[ib0 + c]);
-      b_hl[c] = join8(sb.hi, sb.lo);
-      b_mh[c] = join8(sb.mid, sb.hi);
-    }
+  for (int ob = 0; ob < OB; ++ob) {
+    PlanesA an = ap;
+    const float* nt = ob + 1 < OB ? tiles + (ob + 1) * kPlaneTileFloats : next_tile;
+    if (nt != nullptr) read_planes3(nt, i, q, dup, an);
+    __builtin_amdgcn_sched_barrier(0x047F);  // everything but LDS instructions may cross: the read above stays above
 #pragma unroll
-    for (int ob = 0; ob < OB; ++ob) {
-      Split3 an = ap;
-      const float* nt = ob + 1 < OB ? tiles + (ob + 1) * kPlaneTileFloats : (ib0 + CH < IB ? tiles : next_tile);
-      if (nt != nullptr) read_planes(nt, i, q, an);
-      __builtin_amdgcn_sched_barrier(0x047F);  // everything but LDS instructions may cross: the read above stays above
-      const bf16x8 a_lh = join8(ap.lo, ap.hi), a_mm = join8(ap.mid, ap.mid), a_hh = join8(ap.hi, ap.hi);
+    for (int c = 0; c < IB; ++c) acc[ob][c] = mfma32_bf16(ap.lh, b_hl[c], acc[ob][c]);
 #pragma unroll
-      for (int c = 0; c < CH; ++c) acc[ob][ib0 + c] = mfma32_bf16(a_lh, b_hl[c], acc[ob][ib0 + c]);
+    for (int c = 0; c < IB; ++c) acc[ob][c] = mfma32_bf16(ap.mm, b_mh[c], acc[ob][c]);
 #pragma unroll
-      for (int c = 0; c < CH; ++c) acc[ob][ib0 + c] = mfma32_bf16(a_mm, b_mh[c], acc[ob][ib0 + c]);
-#pragma unroll
-      for (int c = 0; c < CH; ++c) acc[ob][ib0 + c] = mfma32_bf16(a_hh, b_mh[c], acc[ob][ib0 + c]);
-      ap = an;
-    }
+    for (int c = 0; c < IB; ++c) acc[ob][c] = mfma32_bf16(ap.hh, b_mh[c], acc[ob][c]);
+    ap = an;
   }
 }
 
@@ -1736,6 +1758,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         if constexpr (PLANES) stage_tile0(buf, go, j, q);
         else stage_tile(buf, go, j, q);
         dbc_o[0] += go;
+        pin(dbc_o[0]);  // (the sum stays HERE: sunk to the end of the iteration it keeps `go` alive past its in-place split)
         f32x4 gov[1] = {go};
         f32x4 d[kHB];
         if constexpr (!X6) {
@@ -1768,14 +1791,17 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
                 d[ib][r] = hs[l][ib][r] > 0.f ? d[ib][r] : 0.f;
               }
             }
+            // (the bias-gradient sums take d BEFORE the split: the split's residuals are formed in place - v_dot2c accumulates
+            // into its destination - and a d that is still needed afterwards costs one register move per value)
+            if (l > 0) { dbc_h[l > 0 ? l - 1 : 0][ib] += d[ib]; pin(dbc_h[l > 0 ? l - 1 : 0][ib]); }
+            else { dbc_1[ib] += d[ib]; pin(dbc_1[ib]); }
             if constexpr (PLANES) {
+              __builtin_amdgcn_sched_barrier(0x07FC);  // VALU instructions stay on their side: the adds above, the split below
               ds[ib] = split3(d[ib]);  // once: for the planes and for this wave's own product below
               stage_planes(buf + kTile0Floats + ((NH - 1 - l) * kHB + ib) * kPlaneTileFloats, ds[ib], j, q);
             } else {
               stage_tile(buf + (1 + (NH - 1 - l) * kHB + ib) * kTileFloats, d[ib], j, q);
             }
-            if (l > 0) dbc_h[l > 0 ? l - 1 : 0][ib] += d[ib];
-            else dbc_1[ib] += d[ib];
           }
           if (l > 0) {
             f32x4 d2[kHB];
@@ -1925,6 +1951,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     f32x4 xraw[KB1];
     float xsraw[KB1];
     float xcr[KB1][4];
+    uint32_t dup[2] = {0u, 0u};  // opaque zeros (read_planes3)
+    asm volatile("" : "+v"(dup[0]));
+    asm volatile("" : "+v"(dup[1]));
     // one iteration: the group (one behind the chain wave) whose saved activations sit in hraw_c; the next group's go into hraw_n
     auto dw_iter = [&](int it, float (&hraw_c)[NH][kHB][4], float (&hraw_n)[NH][kHB][4]) __attribute__((always_inline)) {
       const int64_t gi = g_first + (int64_t)(it - 1) * gstride;
@@ -1946,7 +1975,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           for (int kb = 0; kb < KB1; ++kb)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              xc[kb][r] = (kb < ka_blocks || 16 * (kb - ka_blocks) + 4 * q + r < a.k_b) ? xcr[kb][r] : 0.f;
+              xc[kb][r] = xcr[kb][r];  // (rows beyond k_b hold a valid - clamped - row's values and meet zero weight columns of the image: no masking)
 #pragma unroll
           for (int ob = 0; ob < kHB; ++ob) {
             const float b0 = bias0[16 * ob + j];
@@ -1976,7 +2005,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
               const float v = xsraw[kb];
               xb_[kb] = f32x4{v, v, v, v};
             } else {
-              xb_[kb] = (16 * (kb - ka_blocks) + j) < a.k_b ? xraw[kb] : f32x4{0.f, 0.f, 0.f, 0.f};
+              xb_[kb] = xraw[kb];  // (rows beyond k_b: a clamped row's finite values; their dW columns are never written out, flush_dw_ws)
             }
           }
         };
@@ -1984,11 +2013,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           float av[4];
           if constexpr (PLANES) {
             // dY tile (fp32, split here) and the first plane tile are requested together; every later A operand one tile ahead
-            Split3 ap;
+            PlanesA ap;
             if constexpr (OUT1) {
               float dy4[4];
               read_operand0(buf, 0, q, dy4);                    // row 0 of the dY tile: samples 4q..4q+3 (a broadcast read)
-              read_planes(buf + kTile0Floats, j, q, ap);
+              read_planes3(buf + kTile0Floats, j, q, dup, ap);
               __builtin_amdgcn_sched_barrier(0x047F);
 #pragma unroll
               for (int ib = 0; ib < kHB; ++ib)
@@ -1996,19 +2025,19 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
                 for (int t = 0; t < 4; ++t) acc1[ib] = fmaf(dy4[t], hb[NH - 1][ib][t], acc1[ib]);
             } else {
               read_operand0(buf, j, q, av);
-              read_planes(buf + kTile0Floats, j, q, ap);
+              read_planes3(buf + kTile0Floats, j, q, dup, ap);
               accumulate_dw_split<1, kHB>(buf, hb[NH - 1], acc_o, j, q, av, nullptr);
             }
 #pragma unroll
             for (int l = NH - 1; l >= 0; --l) {
               const float* dt = buf + kTile0Floats + (NH - 1 - l) * kHB * kPlaneTileFloats;
               if (l > 0) {
-                accumulate_dw_planes<kHB, kHB>(dt, hb[l - 1], acc_h[l - 1], j, q, ap, dt + kHB * kPlaneTileFloats);
+                accumulate_dw_planes<kHB, kHB>(dt, hb[l - 1], acc_h[l - 1], j, q, ap, dt + kHB * kPlaneTileFloats, dup);
               } else {
                 if constexpr (kHLate) issue_h(gnext, hraw_n);
                 f32x4 xb_[KB1];
                 input_operands(xb_);
-                accumulate_dw_planes<kHB, KB1>(dt, xb_, acc_1, j, q, ap, nullptr);
+                accumulate_dw_planes<kHB, KB1>(dt, xb_, acc_1, j, q, ap, nullptr, dup);
               }
             }
           } else {
@@ -2057,6 +2086,17 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           for (int kb = 0; kb < KB1; ++kb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) pin(xcr[kb][r]);
+        }
+        // The consumed set is dead, but its next definition (the request two iterations on) sits under that iteration's
+        // condition, so to the compiler the registers stay live around the loop - and the in-place splits of the activations
+        // copied every value first (one v_mov per value).  An empty asm that "defines" the set ends the old values here.
+        if constexpr (X6 && !BF16) {
+#pragma unroll
+          for (int l = kL0; l < NH; ++l)
+#pragma unroll
+            for (int ib = 0; ib < kHB; ++ib)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) asm volatile("" : "=v"(hraw_c[l][ib][t]));
         }
       }
       pair_sync(it);
