@@ -47,7 +47,8 @@ constexpr int kMaxLayers = NESVOR_MAX_MLP_LAYERS;  // linear layers incl. the ou
 
 // Timing experiments only (tools/mlp_variants.py; results are wrong by construction): NESVOR_MLP_ABLATE bit 1 wraps every
 // access to the saved hidden activations into the first 4096 groups (a 16 MiB window per layer that stays in L2 / MALL),
-// bit 2 does the same to the sample index of the input / output / gradient streams, bit 4 removes the VALU work of split3().
+// bit 2 does the same to the sample index of the input / output / gradient streams, bit 4 removes the VALU work of split3(),
+// bit 8 skips the construction of the weight images in LDS.
 #ifndef NESVOR_MLP_ABLATE
 #define NESVOR_MLP_ABLATE 0
 #endif
@@ -213,6 +214,7 @@ __device__ __forceinline__ f32x4 mfma_split(const Split3& a, const Split3& b, f3
 // (X6: three bf16 planes hi | mid | lo of `total` elements each, i.e. 1.5x the fp32 carve)
 template <bool BF16 = false, bool X6 = false>
 __device__ void build_image(float* img, const float* __restrict__ W, int out_dim, int in_dim, int ob_n, int kb_n) {
+  if (NESVOR_MLP_ABLATE & 8) return;  // timing experiment: what the image build costs a launch
   const int total = ob_n * kb_n * 256;
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
     const int r = e & 3, lane = (e >> 2) & 63, blk = e >> 8;
@@ -232,6 +234,7 @@ __device__ void build_image(float* img, const float* __restrict__ W, int out_dim
 // transposed image: rows i = input features (ib blocks), k = output features (kb blocks)
 template <bool BF16 = false, bool X6 = false>
 __device__ void build_image_T(float* img, const float* __restrict__ W, int out_dim, int in_dim, int ib_n, int kb_n) {
+  if (NESVOR_MLP_ABLATE & 8) return;
   const int total = ib_n * kb_n * 256;
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
     const int r = e & 3, lane = (e >> 2) & 63, blk = e >> 8;
@@ -246,6 +249,45 @@ __device__ void build_image_T(float* img, const float* __restrict__ W, int out_d
       p[e] = hi; p[total + e] = mid; p[2 * total + e] = (__bf16)(r1 - (float)mid);
     } else if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w;
     else img[e] = w;
+  }
+}
+
+// The same two images with compile-time shapes (no run-time division per element) and the global loads of eight elements
+// per thread in flight at once: the generic builders above walk one dependent load per iteration - 27 to 42 L2 round trips per
+// thread before the first tile, 6-11 us of every launch of the pipelined forward (tools/mlp_variants.py, -DNESVOR_MLP_ABLATE=8).
+// T: transposed image (build_image_T); A_N / B_N = (ob_n, kb_n) or (ib_n, kb_n) of the generic versions.
+template <bool BF16, bool X6, bool T, int A_N, int B_N, int THREADS>
+__device__ __forceinline__ void build_image_ct(float* img, const float* __restrict__ W, int out_dim, int in_dim) {
+  if (NESVOR_MLP_ABLATE & 8) return;
+  constexpr int total = A_N * B_N * 256;
+  constexpr int U = 8;
+  for (int e0 = threadIdx.x; e0 < total; e0 += THREADS * U) {
+    float w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * THREADS;
+      const int r = e & 3, lane = (e >> 2) & 63, blk = e >> 8;
+      const int kb = blk % B_N, ab = blk / B_N;
+      const int row = 16 * ab + (lane & 15), col = 16 * kb + 4 * (lane >> 4) + r;  // T: row = input feature, col = output feature
+      const int o = T ? col : row, k = T ? row : col;
+      const bool ok = e < total && o < out_dim && k < in_dim;
+      w[u] = W[ok ? (size_t)o * in_dim + k : 0];  // (every load issued, no branch: zero-filled below)
+      w[u] = ok ? w[u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * THREADS;
+      if (e < total) {
+        if constexpr (X6) {
+          __bf16* p = reinterpret_cast<__bf16*>(img);
+          const __bf16 hi = (__bf16)w[u];
+          const float r1 = w[u] - (float)hi;
+          const __bf16 mid = (__bf16)r1;
+          p[e] = hi; p[total + e] = mid; p[2 * total + e] = (__bf16)(r1 - (float)mid);
+        } else if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w[u];
+        else img[e] = w[u];
+      }
+    }
   }
 }
 
@@ -665,12 +707,12 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) v
   float* imgo = imgh + (NH - 1) * kHB * kHB * kBlk;
   float* bias = imgo + 1 * kHB * kBlk;
   float* wout = bias + (NH + 1) * kWidth;  // OUT1: the single output row in fp32
-  build_image<false, X6>(img1, a.W[0], kWidth, k_in, kHB, KB1);
-  for (int l = 1; l < NH; ++l) build_image<false, X6>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, kHB, kHB);
+  build_image_ct<false, X6, false, kHB, KB1, 256>(img1, a.W[0], kWidth, k_in);
+  for (int l = 1; l < NH; ++l) build_image_ct<false, X6, false, kHB, kHB, 256>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth);
   if constexpr (OUT1) {
     for (int e = threadIdx.x; e < kWidth; e += blockDim.x) wout[e] = a.W[NH][e];
   } else {
-    build_image<false, X6>(imgo, a.W[NH], a.out_dim, kWidth, 1, kHB);
+    build_image_ct<false, X6, false, 1, kHB, 256>(imgo, a.W[NH], a.out_dim, kWidth);
   }
   for (int e = threadIdx.x; e < (NH + 1) * kWidth; e += blockDim.x) {
     const int l = e / kWidth, o = e % kWidth;
@@ -741,6 +783,10 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) v
       for (int kb = 0; kb < KB1; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
+          // (a select, not an alias: x must be a COPY of the prefetch set.  The next tile's loads are requested into xr right
+          //  below, while x is still in use; with x = xr the compiler gives the new xr other registers and moves them back
+          //  for the loop - a register move that can read a register whose load has not landed.  Tried in round 4: whole
+          //  16-sample groups of wrong outputs, at random, tools/diag_mlp.py.)
           x[g][kb][r] = (kb < ka_blocks || 16 * (kb - ka_blocks) + 4 * q + r < a.k_b) ? xr[g][kb][r] : 0.f;
     // the last tile of a workgroup re-requests a valid tile (no control flow between an issue and its settle)
     issue_x(min(tile + (int64_t)gridDim.x, n_tiles - 1), xr);
@@ -1462,40 +1508,43 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const MlpArgs a) {
 // is covered by the other.  One workgroup barrier per group; both roles stay under 256 registers.
 // Requires the fast input path (a.fast).
 template <int OB, int IB>
-__device__ void flush_dw_ws(float* red /* 4 x kHB*256 floats */, const f32x4 (&acc)[OB][IB], const f32x4 (&dbc)[OB],
+__device__ void flush_dw_ws(float* red /* 4 x OB x IB x 256 + 4 x kWidth floats */, const f32x4 (&acc)[OB][IB], const f32x4 (&dbc)[OB],
                             float* out, int out_dim, int in_dim, int slot /* 0..3: accumulator (dW) wave, -1: none */,
                             int chain /* 0..3: chain wave (owns the bias-gradient sums), -1: none */) {
+  // One staging round per LAYER (two workgroup barriers) - rounds 1-3 staged one output block at a time, 24 barriers per launch,
+  // a fixed cost that weighs on small batches.  The region holds the four dW waves' accumulators of the layer side by side,
+  // then the four chain waves' bias sums.
   const int lane = threadIdx.x & 63;
+  constexpr int kAcc = OB * IB * 256;
+  float* redb = red + 4 * kAcc;
+  __syncthreads();
+  if (slot >= 0) {
 #pragma unroll
-  for (int ob = 0; ob < OB; ++ob) {
-    __syncthreads();
-    if (slot >= 0) {
+    for (int ob = 0; ob < OB; ++ob)
 #pragma unroll
-      for (int ib = 0; ib < IB; ++ib) *reinterpret_cast<f32x4*>(&red[slot * kHB * 256 + (ib * 64 + lane) * 4]) = acc[ob][ib];
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < IB * 256; e += blockDim.x) {
-      const float s = (red[e] + red[kHB * 256 + e]) + (red[2 * kHB * 256 + e] + red[3 * kHB * 256 + e]);
-      const int r = e & 3, ln = (e >> 2) & 63, ib = e >> 8;
-      const int o = 16 * ob + 4 * (ln >> 4) + r, in = 16 * ib + (ln & 15);
-      if (o < out_dim && in < in_dim) out[o * in_dim + in] = s;
-    }
+      for (int ib = 0; ib < IB; ++ib) *reinterpret_cast<f32x4*>(&red[slot * kAcc + ((ob * IB + ib) * 64 + lane) * 4]) = acc[ob][ib];
   }
   // bias gradient: the chain waves summed dpre per lane (sample j, features 4q..4q+3 of block ob) over their groups;
-  // sum the 16 sample lanes of a row, then the four pairs
-  __syncthreads();
+  // sum the 16 sample lanes of a row here, the four waves below
   if (chain >= 0) {
 #pragma unroll
     for (int ob = 0; ob < OB; ++ob) {
       f32x4 t;
 #pragma unroll
       for (int r = 0; r < 4; ++r) t[r] = row_sum_dpp(dbc[ob][r]);
-      if ((lane & 15) == 0) *reinterpret_cast<f32x4*>(&red[chain * kWidth + 16 * ob + 4 * (lane >> 4)]) = t;
+      if ((lane & 15) == 0) *reinterpret_cast<f32x4*>(&redb[chain * kWidth + 16 * ob + 4 * (lane >> 4)]) = t;
     }
   }
   __syncthreads();
+  for (int e = threadIdx.x; e < kAcc; e += blockDim.x) {
+    const float s = (red[e] + red[kAcc + e]) + (red[2 * kAcc + e] + red[3 * kAcc + e]);
+    const int r = e & 3, ln = (e >> 2) & 63, blk = e >> 8;
+    const int ib = blk % IB, ob = blk / IB;
+    const int o = 16 * ob + 4 * (ln >> 4) + r, in = 16 * ib + (ln & 15);
+    if (o < out_dim && in < in_dim) out[o * in_dim + in] = s;
+  }
   for (int e = threadIdx.x; e < OB * 16; e += blockDim.x) {
-    const float s = (red[e] + red[kWidth + e]) + (red[2 * kWidth + e] + red[3 * kWidth + e]);
+    const float s = (redb[e] + redb[kWidth + e]) + (redb[2 * kWidth + e] + redb[3 * kWidth + e]);
     if (e < out_dim) out[out_dim * in_dim + e] = s;
   }
 }
@@ -1629,12 +1678,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   if constexpr (OUT1) {
     for (int e = threadIdx.x; e < kWidth; e += blockDim.x) wout[e] = a.W[NH][e];
   } else {
-    build_image_T<BF16, X6>(imgo, a.W[NH], a.out_dim, kWidth, kHB, 1);
+    build_image_ct<BF16, X6, true, kHB, 1, 512>(imgo, a.W[NH], a.out_dim, kWidth);
   }
-  for (int l = 1; l < NH; ++l) build_image_T<BF16, X6>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, kHB, kHB);
-  build_image_T<BF16, X6>(img1, a.W[0], kWidth, k_in, KB1, kHB);
+  for (int l = 1; l < NH; ++l) build_image_ct<BF16, X6, true, kHB, kHB, 512>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth);
+  build_image_ct<BF16, X6, true, KB1, kHB, 512>(img1, a.W[0], kWidth, k_in);
   if constexpr (COMPACT) {
-    build_image<false, X6>(imgf1, a.W[0], kWidth, k_in, kHB, KB1);
+    build_image_ct<false, X6, false, kHB, KB1, 512>(imgf1, a.W[0], kWidth, k_in);
     for (int e = threadIdx.x; e < kWidth; e += blockDim.x) bias0[e] = a.b[0][e];
   }
   __syncthreads();
@@ -1975,7 +2024,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           for (int kb = 0; kb < KB1; ++kb)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              xc[kb][r] = xcr[kb][r];  // (rows beyond k_b hold a valid - clamped - row's values and meet zero weight columns of the image: no masking)
+              // (a select, i.e. a COPY of the prefetch set, as in the forward: the set is re-requested below while the compiler is
+              //  free to schedule uses of xc behind that request)
+              xc[kb][r] = (kb < ka_blocks || 16 * (kb - ka_blocks) + 4 * q + r < a.k_b) ? xcr[kb][r] : 0.f;
 #pragma unroll
           for (int ob = 0; ob < kHB; ++ob) {
             const float b0 = bias0[16 * ob + j];
@@ -2163,7 +2214,10 @@ size_t ws_bwd_lds_bytes(int n_hidden, int kb1, int blk = 256, bool compact = fal
   if (compact) img += (size_t)kb1 * kHB * blk + kWidth;  // forward image of the first layer + its bias
   const bool planes = blk == 384 && kSplitDw && (NESVOR_MLP_PLANES != 0);  // split mode: fp32 dY tile + plane tiles (mlp_bwd_ws_kernel::PLANES)
   size_t tiles = 4 * 2 * (planes ? (size_t)kTile0Floats + (size_t)n_hidden * kHB * kPlaneTileFloats : (size_t)(1 + n_hidden * kHB) * kTileFloats);
-  if (tiles < 4 * (size_t)kHB * 256) tiles = 4 * (size_t)kHB * 256;
+  // the epilogue stages one layer's accumulators of the four dW waves at once (flush_dw_ws)
+  const size_t widest = (size_t)kHB * (size_t)((n_hidden > 1 && kHB > kb1) ? kHB : kb1);
+  const size_t flush = 4 * widest * 256 + 4 * kWidth;
+  if (tiles < flush) tiles = flush;
   return sizeof(float) * (img + tiles);
 }
 

@@ -1116,6 +1116,39 @@ def test_fused_mlp_split_operands_keep_fp32_accuracy(device, k_a, k_b, b_row0, r
             assert float((a_ + b_ - c_).norm() / c_.norm()) < 2e-6
 
 
+@pytest.mark.parametrize("k_a,k_b,b_row0,rows,out_dim", [(0, 32, 0, 32, 16), (16, 15, 1, 16, 1)])
+def test_fused_mlp_is_reproducible_at_full_size(device, k_a, k_b, b_row0, rows, out_dim):
+    """The pipelined forward and the wave-specialised backward keep loads in flight in registers the compiler knows nothing
+    about (inline-asm requests awaited a tile / a group later).  A register move the compiler places between a request
+    and its wait reads a register whose load has not landed: whole 16-sample groups of wrong values, at random (seen in
+    round 4 when the forward's copy of its prefetch set was turned into an alias).  Such a fault is not reproducible, so:
+    five runs at the bench's size must agree bit for bit - outputs, saved state, input gradient (the parameter gradient
+    is a sum of per-workgroup partials in a fixed order: bit-identical too)."""
+    from nesvor_amd import mlp
+    from nesvor_amd.models import build_network
+
+    torch.manual_seed(3)
+    N, S = 1 << 20, 256
+    net = build_network(n_input_dims=k_a + k_b, n_output_dims=out_dim, activation="ReLU", output_activation="None",
+                        n_neurons=64, n_hidden_layers=2, dtype=torch.float32).to(device)
+    L = mlp.linear_layers(net)
+    W, Bs = [l.weight.detach() for l in L], [l.bias.detach() for l in L]
+    xa = torch.randn(N // S, k_a, device=device) if k_a else None
+    xb = torch.randn(rows, N, device=device)
+    dy = torch.randn(out_dim, N, device=device)
+    ref = None
+    for _ in range(5):
+        y, saved = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, True, mlp.SPLIT)
+        dxb = torch.empty(k_b, N, device=device)
+        _, partial = mlp.backward_raw(W, Bs, xa, xb, dy, saved, b_row0, k_b, S, dxb, xa is not None, mlp.SPLIT)
+        cur = (y.clone(), dxb.clone(), partial.sum(0))
+        if ref is None:
+            ref = cur
+        else:
+            for a_, b_ in zip(ref, cur):
+                assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("k_a,k_b,b_row0,rows,depth,out_dim,S,N", [
     (0, 32, 0, 32, 2, 16, 256, 1 << 16),   # density_net
     (16, 15, 1, 16, 2, 1, 256, 1 << 16),   # sigma_net (pixel-feature block + ragged row block)
