@@ -643,6 +643,26 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) {
 }
 #endif
 
+// NESVOR_HG_PK_FIXED=1 (A/B build, off): two values at once (F = 2: the two features of a corner) - the scaling, the residual
+// and the corner weights as packed fp32 instructions (v_pk_mul_f32, v_pk_fma_f32): 326 instead of 361 VALU instructions per
+// level and wave in the box rounds, same arithmetic, bit-identical words - and the pass is SLOWER (round 4, one job, alternating:
+// 0.3010 -> 0.3083 ms in the step, 0.342 -> 0.348 isolated; profiles/r04_hashgrid_ab_packed_f32.log): a packed fp32
+// instruction is not a cheaper issue slot than the two it replaces on gfx950 (the forward's packed blend had shown the same:
+// 11 % fewer instructions, same time).
+#ifndef NESVOR_HG_PK_FIXED
+#define NESVOR_HG_PK_FIXED 0
+#endif
+typedef float hg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void to_fixed2(hg_f32x2 x, unsigned long long (&q)[2]) {
+  const hg_f32x2 t = __builtin_elementwise_rint(x * 0x1p-32f);
+  const hg_f32x2 r = __builtin_elementwise_fma(-t, hg_f32x2{0x1p32f, 0x1p32f}, x);
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int32_t lo = __float2int_rn(r[f]);
+    q[f] = ((unsigned long long)(uint32_t)((int32_t)t[f] + (lo >> 31)) << 32) | (unsigned long long)(uint32_t)lo;
+  }
+}
+
 // NESVOR_FIXED32 (build macro, F == 2 only): a merge-table slot holds both features as two 32-bit fixed-point fields of one
 // 64-bit word (one ds_add_u64 per corner, 3 VALU instructions per value) instead of one 64-bit fixed-point word per
 // feature.  Resolution: 2^-22 of 256 max|dy| of the workgroup and level (the 64-bit form resolves 2^-52).  Off by default.
@@ -985,11 +1005,22 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
     }
     {
       const float ax[2] = {1.f - c.wx, c.wx}, ay[2] = {1.f - c.wy, c.wy}, az[2] = {1.f - c.wz, c.wz};
+      if constexpr (F == 2 && NESVOR_HG_PK_FIXED) {
+        // the same products (ax ay) az and w dy as packed fp32 multiplies: 14 instructions instead of 28
+        const hg_f32x2 ax2 = {ax[0], ax[1]}, dy2 = {dy[0], dy[1]};
+#pragma unroll
+        for (int zy = 0; zy < 4; ++zy) {
+          const hg_f32x2 w2 = (ax2 * ay[zy & 1]) * az[zy >> 1];  // corners k = 2 zy, 2 zy + 1
+          const hg_f32x2 v0 = hg_f32x2{w2[0], w2[0]} * dy2, v1 = hg_f32x2{w2[1], w2[1]} * dy2;
+          val[2 * zy][0] = v0[0]; val[2 * zy][1] = v0[1]; val[2 * zy + 1][0] = v1[0]; val[2 * zy + 1][1] = v1[1];
+        }
+      } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float w = ax[k & 1] * ay[(k >> 1) & 1] * az[k >> 2];
 #pragma unroll
         for (int f = 0; f < F; ++f) val[k][f] = w * dy[f];
+      }
       }
     }
     // Segmented inclusive scan (a run = consecutive lanes of a 16-lane row in the same cell), on the VALU:
@@ -1047,8 +1078,15 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
       // ((int64)q1 << 32) + (int64)q0: the low field's sign borrows from the high field; undone when the slot is read
       atomicAdd(&tvals[slot], ((unsigned long long)(uint32_t)(q1 + (q0 >> 31)) << 32) | (unsigned long long)(uint32_t)q0);
     } else {
+      if constexpr (F == 2 && NESVOR_HG_PK_FIXED) {
+        unsigned long long q[2];
+        to_fixed2(hg_f32x2{v[0], v[1]} * fscale, q);
+        atomicAdd(&tvals[slot], q[0]);
+        atomicAdd(&tvals[kSlots + slot], q[1]);
+      } else {
 #pragma unroll
-      for (int f = 0; f < F; ++f) atomicAdd(&tvals[f * kSlots + slot], to_fixed(v[f] * fscale));
+        for (int f = 0; f < F; ++f) atomicAdd(&tvals[f * kSlots + slot], to_fixed(v[f] * fscale));
+      }
     }
   };
   // read + clear one slot; false: nothing was added (or everything cancelled exactly)
