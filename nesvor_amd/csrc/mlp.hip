@@ -1705,8 +1705,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     if (NESVOR_MLP_PAIR_SYNC) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) __hip_atomic_store(&arrive[role][pair], it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifndef NESVOR_MLP_SPIN_SLEEP
+#define NESVOR_MLP_SPIN_SLEEP 1
+#endif
       while (__hip_atomic_load(&arrive[1 - role][pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < it + 1)
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(NESVOR_MLP_SPIN_SLEEP);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     } else {
       __syncthreads();
