@@ -1509,11 +1509,39 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
   const uint32_t gb = plan.bucket_base[level] + chunk;
   // the bucket's records = the concatenation of its sub-queues; record r of that virtual queue sits at
   // r + sum over the sub-queues that end at or before r of their unused tail
+  // Latencies taken out of the workgroup's serial chain (round 4; NESVOR_OWNER_EARLY=0 restores the old order): the queue tails
+  // are requested first and the LDS accumulator is zero-filled while they fly (it used to wait behind the early-exit test on
+  // them); with ADAM the first float4 of the chunk's parameters / moments / old gradient per thread - which depend on nothing
+  // the record phase produces - is requested here as well and lands under the record phase.
+#ifndef NESVOR_OWNER_EARLY
+#define NESVOR_OWNER_EARLY 1
+#endif
+  uint32_t traw[kSubQueues];
+#pragma unroll
+  for (int x = 0; x < kSubQueues; ++x) traw[x] = (uint32_t)x < plan.n_sub ? tails[x * kTailStride + gb] : 0u;
+  const uint32_t e0 = chunk << plan.shift[level];
+  const uint32_t ne = min((uint32_t)(1u << plan.shift[level]), g.size[level] - e0);
+  float4 pf_p = make_float4(0.f, 0.f, 0.f, 0.f), pf_m = pf_p, pf_v = pf_p, pf_o = pf_p;
+  bool prefetched = false;
+  if constexpr (ADAM && NESVOR_OWNER_EARLY) {
+    const uint32_t nf = ne * F;
+    if (nf % 4u == 0u && (uint32_t)tid < nf / 4u) {
+      const size_t first = ((size_t)g.offset[level] + e0) * F;
+      pf_p = reinterpret_cast<const float4*>(adam.param + first)[tid];
+      pf_m = reinterpret_cast<const float4*>(adam.exp_avg + first)[tid];
+      pf_v = reinterpret_cast<const float4*>(adam.exp_avg_sq + first)[tid];
+      pf_o = reinterpret_cast<const float4*>(grad_table + first)[tid];
+      prefetched = true;
+    }
+  }
+  if (NESVOR_OWNER_EARLY) {
+    for (int t = tid; t < kOwnerLdsFloats / 4; t += kOwnerThreads) reinterpret_cast<float4*>(acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   uint32_t n = 0;
   uint32_t pre[kSubQueues], gap[kSubQueues];  // pre[x]: first virtual index of sub-queue x; gap[x]: hole before it
 #pragma unroll
   for (int x = 0; x < kSubQueues; ++x) {
-    const uint32_t nx = (uint32_t)x < plan.n_sub ? min(tails[x * kTailStride + gb], plan.cap[level]) : 0u;
+    const uint32_t nx = min(traw[x], plan.cap[level]);
     pre[x] = n;
     gap[x] = x ? plan.cap[level] - (n - pre[x - 1]) : 0u;
     n += nx;
@@ -1530,7 +1558,9 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
   if (ADAM ? slice >= n_part : r0 >= n) return;
   const uint32_t r1 = max(r0, min(n, r0 + plan.slice[level]));
   const bool sole_writer = n <= plan.slice[level];
-  for (int t = tid; t < kOwnerLdsFloats / 4; t += kOwnerThreads) reinterpret_cast<float4*>(acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!NESVOR_OWNER_EARLY) {
+    for (int t = tid; t < kOwnerLdsFloats / 4; t += kOwnerThreads) reinterpret_cast<float4*>(acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   __syncthreads();
   const uint32_t mask = (1u << plan.shift[level]) - 1u;
   const uint32_t* rec = records + (plan.rec_off[level] + (uint64_t)chunk * plan.n_sub * plan.cap[level]) * (1 + F);
@@ -1631,8 +1661,6 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
   }
   }
   __syncthreads();
-  const uint32_t e0 = chunk << plan.shift[level];
-  const uint32_t ne = min((uint32_t)(1u << plan.shift[level]), g.size[level] - e0);
   float* out = grad_table + ((size_t)g.offset[level] + e0) * F;
   if constexpr (ADAM) {
     const size_t first = ((size_t)g.offset[level] + e0) * F;
@@ -1665,8 +1693,10 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
       const float4* a4 = reinterpret_cast<const float4*>(acc);
       float4* o4 = reinterpret_cast<float4*>(out);
       for (uint32_t t = tid; t < nf / 4u; t += kOwnerThreads) {
-        float4 p = reinterpret_cast<float4*>(P)[t], m = reinterpret_cast<float4*>(M)[t], v = reinterpret_cast<float4*>(V)[t];
-        const float4 o = o4[t], a = a4[t];
+        const bool first_it = prefetched && t == (uint32_t)tid;  // (this thread's first float4 arrived during the record phase)
+        float4 p = first_it ? pf_p : reinterpret_cast<float4*>(P)[t], m = first_it ? pf_m : reinterpret_cast<float4*>(M)[t],
+               v = first_it ? pf_v : reinterpret_cast<float4*>(V)[t];
+        const float4 o = first_it ? pf_o : o4[t], a = a4[t];
         adam1(p.x, a.x + o.x, m.x, v.x, adam.a); adam1(p.y, a.y + o.y, m.y, v.y, adam.a);
         adam1(p.z, a.z + o.z, m.z, v.z, adam.a); adam1(p.w, a.w + o.w, m.w, v.w, adam.a);
         reinterpret_cast<float4*>(P)[t] = p; reinterpret_cast<float4*>(M)[t] = m; reinterpret_cast<float4*>(V)[t] = v;
