@@ -738,6 +738,13 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
   // through scratch memory): res, size, offset, hashed, queue capacity, first bucket, first record, chunks
   __shared__ uint32_t lpar[NESVOR_MAX_LEVELS + 1][8];
   __shared__ int32_t box_end_s;       // levels [level_begin, box_end) address the table by box slot
+#ifndef NESVOR_HG_TRANSPOSE
+#define NESVOR_HG_TRANSPOSE 16      // lane-transposed inserts for waves with at most this many run tails at a box level (0: off)
+#endif
+  constexpr bool kTranspose = (F == 2) && !kPack && (NESVOR_HG_TRANSPOSE > 0);
+  constexpr int kTransMax = NESVOR_HG_TRANSPOSE;
+  constexpr int kStripStride = 20;    // floats per parked tail: 16 values, the first slot, padding (16-byte rows)
+  __shared__ __attribute__((aligned(16))) float tstage[4][kTranspose ? 4 * kStripStride : 1];
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t base = (int64_t)blockIdx.x * 256;
   const int E = g.n_levels * F;
@@ -1181,7 +1188,35 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
         for (int f = 0; f < F; ++f) dy_a[f] = dy_b[f];
         if (lv + 2 < level_end) load_dy(lv + 2, dy_b);
         const float fs_lv = scale_of((uint32_t)lv);
-        if (!NESVOR_ABL(4) && tail) {
+        // Few run tails in the wave (the coarse levels: 8-20 of 64 lanes, profiles/r04_tails_per_wave.log): the direct form
+        // below still issues its 16 LDS adds and ~130 fixed-point VALU instructions for the whole wave.  Lane-transposed
+        // form: four tails at a time park their 16 values (and first slot) in a per-wave LDS strip, then lane 16 t + 2 k + f
+        // converts and adds value (corner k, feature f) of tail t - one conversion and one add per FOUR tails.  The adds are
+        // integer adds of the same fixed-point words: bit-identical sums.  (LDS operations of a wave execute in order: the
+        // strip needs no barrier.)
+        const unsigned long long tmask = __ballot(tail);
+        const int n_tails = __builtin_popcountll(tmask);
+        if (kTranspose && !NESVOR_ABL(4) && n_tails <= kTransMax) {
+          const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
+          float* const strip = tstage[tid >> 6];
+          const int tl = lane >> 4, kf = lane & 15, kc = kf >> 1;
+          const uint32_t koff = (uint32_t)(kc & 1) + (uint32_t)((kc >> 1) & 1) * nx + (uint32_t)(kc >> 2) * nxy;
+#pragma unroll 1
+          for (int b0 = 0; b0 < n_tails; b0 += 4) {
+            if (tail && (uint32_t)(rank - b0) < 4u) {
+              float* d = strip + (rank - b0) * kStripStride;
+#pragma unroll
+              for (int k2 = 0; k2 < 4; ++k2)
+                *reinterpret_cast<float4*>(d + 4 * k2) = make_float4(val[2 * k2][0], val[2 * k2][1], val[2 * k2 + 1][0], val[2 * k2 + 1][1]);
+              d[16] = __uint_as_float(s0);
+            }
+            if (b0 + tl < n_tails) {
+              const float v = strip[tl * kStripStride + kf];
+              const uint32_t slot = __float_as_uint(strip[tl * kStripStride + 16]) + koff;
+              atomicAdd(&tvals[(kf & 1) * kSlots + slot], to_fixed(v * fs_lv));
+            }
+          }
+        } else if (!NESVOR_ABL(4) && tail) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) slot_add(s0 + (k & 1) + ((k >> 1) & 1) * nx + (k >> 2) * nxy, val[k], fs_lv);
         }
