@@ -739,7 +739,11 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
   __shared__ uint32_t lpar[NESVOR_MAX_LEVELS + 1][8];
   __shared__ int32_t box_end_s;       // levels [level_begin, box_end) address the table by box slot
 #ifndef NESVOR_HG_TRANSPOSE
-#define NESVOR_HG_TRANSPOSE 16      // lane-transposed inserts for waves with at most this many run tails at a box level (0: off)
+#define NESVOR_HG_TRANSPOSE 0       // A/B build option: lane-transposed inserts for waves with at most this many run tails at a box level.
+                                    // Measured (round 4, one job, profiles/r04_hashgrid_ab_transposed_inserts.log): 8 / 16 / 24 -> pass 0.342 /
+                                    // 0.344 / 0.356 ms against 0.349 isolated, 0.304 / 0.313 against 0.302 in the step, per-level times unchanged:
+                                    // a coarse level's ~10 us is its latency chain (table copy reads -> scan -> adds, one level at a time at four
+                                    // waves per SIMD), not the 130 conversion instructions the transposed form removes.  Off.
 #endif
   constexpr bool kTranspose = (F == 2) && !kPack && (NESVOR_HG_TRANSPOSE > 0);
   constexpr int kTransMax = NESVOR_HG_TRANSPOSE;
