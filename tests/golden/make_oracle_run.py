@@ -1,9 +1,19 @@
-"""Generate tests/golden/oracle_run_c1.npz: BASELINE config C1 run by the CPU ORACLE.
+"""Generate tests/golden/oracle_run_*.npz: the BASELINE configurations run by the CPU ORACLE.
 
 Run in the build container (CPU only; needs neither /root/reference nor a GPU):
 
-    python tests/golden/make_oracle_run.py            # 200 iterations, ~1 h on 8 cores
+    python tests/golden/make_oracle_run.py            # C1: 200 iterations at the reduced batch
     python tests/golden/make_oracle_run.py --n-iter 3 --out /tmp/x.npz   # a quick check of the plumbing
+    python tests/golden/make_oracle_run.py --preset c2   # round 5: C2 (2^18 points per iteration)
+    python tests/golden/make_oracle_run.py --preset c4   #          C4 (per-slice motion, poses optimised; stores the final axisangle)
+    python tests/golden/make_oracle_run.py --preset c5   #          C5's shape (6 stacks, bias field on 4 levels, 0.5 mm output lattice)
+    python tests/golden/make_oracle_run.py --preset c5_nobias   #   its twin without the bias field
+    python tests/golden/make_oracle_run.py --preset c5_long [--preset c5_nobias_long]   # the pair at 2000 iterations (bias-field cost)
+
+Round 5 (verdict item 1): ``--stacks``, ``--motion-deg/--motion-mm/--seed``, ``--n-levels-bias``, ``--output-resolution`` and the
+presets above; besides what the C1 file holds, every file now stores the final pose parameters ``axisangle`` (n, 6) next to their
+initial and (under motion) true values, and the oracle's ``sample_points`` (sample.py:17-33: isotropic output PSF, host noise
+from ``torch.manual_seed(5)``) on a strided lattice of the ``output_resolution`` grid.
 
 What it is: the 3-stack phantom3d(128) data of every BASELINE configuration (77 slices of 151 x 151 per stack, PSF
 (9, 5, 5); BASELINE.md "CPU-baseline plan"), synthesised by the oracle's restatement of the slice-acquisition kernel,
@@ -55,7 +65,7 @@ def register_oracle_cpu_kernels():
     return lib
 
 
-def cpu_stacks(n_stacks=3):
+def cpu_stacks(n_stacks=3, motion_deg=0.0, motion_mm=0.0, seed=0):
     """nesvor_amd.phantom.simulate_stacks on CPU, its slice-acquisition call answered by the oracle."""
     from nesvor_amd import phantom as ph
     from oracle import slice_acq as osa
@@ -66,8 +76,8 @@ def cpu_stacks(n_stacks=3):
 
     ph.slice_acquisition = sa
     vol = torch.tensor(ph.phantom3d(n=N), dtype=torch.float32)
-    slices, _ = ph.simulate_stacks(vol, n_stacks=n_stacks)
-    return vol, slices
+    slices, true_tf = ph.simulate_stacks(vol, n_stacks=n_stacks, motion_deg=motion_deg, motion_mm=motion_mm, seed=seed)
+    return vol, slices, true_tf
 
 
 def phantom_points(stride=1):
@@ -86,15 +96,52 @@ def dataset_checksums(ds):
                      ds.mean], dtype=np.float64)
 
 
+PRESETS = {
+    # name: (file suffix, option overrides) - BASELINE.json's configs at what the 8-core build container can run
+    "c1": ("c1", {}),
+    "c2": ("c2", dict(batch_size=1024, n_samples=256)),  # C2: 2^18 points per iteration, the headline model
+    "c4": ("c4", dict(motion_deg=2.0, motion_mm=1.0, seed=0)),  # C4: per-slice motion, joint pose + INR optimisation
+    "c5": ("c5", dict(stacks=6, n_levels_bias=4, output_resolution=0.5)),  # C5's shape
+    "c5_nobias": ("c5_nobias", dict(stacks=6, n_levels_bias=0, output_resolution=0.5)),
+    "c5_long": ("c5_long", dict(stacks=6, n_levels_bias=4, output_resolution=0.5, n_iter=2000)),
+    "c5_nobias_long": ("c5_nobias_long", dict(stacks=6, n_levels_bias=0, output_resolution=0.5, n_iter=2000)),
+}
+
+
+def sample_lattice(output_resolution, stride):
+    """Every ``stride``-th node per axis of the ``output_resolution`` lattice over the phantom's cube (centred; the nodes are
+    those of ``Volume.resample``'s lattice up to its mask-dependent origin - what matters here is the spacing the output
+    PSF is sized for)."""
+    n = int(round(N / output_resolution))
+    g = (torch.arange(0, n, stride, dtype=torch.float32) - (n - 1) / 2) * output_resolution
+    zz, yy, xx = torch.meshgrid(g, g, g, indexing="ij")
+    return torch.stack([xx, yy, zz], -1).reshape(-1, 3)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--preset", choices=sorted(PRESETS), default=None)
     ap.add_argument("--n-iter", type=int, default=200)
     ap.add_argument("--batch-size", type=int, default=1024)
     ap.add_argument("--n-samples", type=int, default=64)
-    ap.add_argument("--out", default=os.path.join(HERE, "oracle_run_c1.npz"))
+    ap.add_argument("--stacks", type=int, default=3)
+    ap.add_argument("--motion-deg", type=float, default=0.0, help="per-slice rotation-vector noise at synthesis, degrees (C4: 2)")
+    ap.add_argument("--motion-mm", type=float, default=0.0, help="per-slice translation noise at synthesis, mm (C4: 1)")
+    ap.add_argument("--seed", type=int, default=0, help="seed of the motion draw (phantom.simulate_stacks)")
+    ap.add_argument("--n-levels-bias", type=int, default=0)
+    ap.add_argument("--output-resolution", type=float, default=0.8)
+    ap.add_argument("--sample-stride", type=int, default=8, help="the stored sample_points lattice takes every k-th node per axis")
+    ap.add_argument("--out", default=None)
     ap.add_argument("--threads", type=int, default=0, help="torch.set_num_threads (0: PyTorch's default); the GPU boxes' 128-thread hosts "
                                                             "run this loop 5-7x faster on 32 threads (bench.py cpu_baseline)")
     opt = ap.parse_args()
+    suffix = "c1"
+    if opt.preset:
+        suffix, over = PRESETS[opt.preset]
+        for k, v in over.items():
+            setattr(opt, k, v)
+    if opt.out is None:
+        opt.out = os.path.join(HERE, f"oracle_run_{suffix}.npz")
     if opt.threads > 0:
         torch.set_num_threads(opt.threads)
 
@@ -105,9 +152,10 @@ def main():
 
     keep = register_oracle_cpu_kernels()  # the registration lives as long as this object
     t0 = time.time()
-    vol, slices = cpu_stacks(3)
+    vol, slices, true_tf = cpu_stacks(opt.stacks, opt.motion_deg, opt.motion_mm, opt.seed)
     print(f"data: {len(slices)} slices in {time.time() - t0:.1f} s", flush=True)
     args = make_args(torch.device("cpu"), opt.batch_size, opt.n_samples, 2, opt.n_iter)
+    args.n_levels_bias, args.output_resolution = opt.n_levels_bias, opt.output_resolution
     ds = Dataset(slices, args)
     sums = dataset_checksums(ds)
     cds = otl.ArrayDataset(ds.xyz, ds.v, ds.slice_idx, ds.transformation.matrix(), ds.resolution)
@@ -134,17 +182,31 @@ def main():
     p_whole, s_whole = fit_psnr(rec, truth, whole, peak)
     p_int, s_int = fit_psnr(rec, truth, interior, peak)
     coarse = rec.reshape(N, N, N)[::4, ::4, ::4].contiguous().numpy().astype(np.float32)
+    # sample.py:17-33 on a strided lattice of the output grid: isotropic output PSF, n_inference_samples draws per point from
+    # the host generator, chunks of inference_batch_size - the HIP sample_points replays it under args.host_rng
+    lattice = sample_lattice(opt.output_resolution, opt.sample_stride)
+    torch.manual_seed(5)
+    sampled = otl.sample_points(P, levels, args, bb, lattice).numpy().astype(np.float32)
     t_from = 20 if opt.n_iter > 40 else 1
     rate = (opt.n_iter - t_from) / float(secs[t_from:].sum())
     print(f"PSNR whole object {p_whole:.3f} dB (scale {s_whole:.4f}), interior {p_int:.3f} dB (scale {s_int:.4f}); "
           f"{rate:.4f} it/s over iterations {t_from + 1}..{opt.n_iter} on {torch.get_num_threads()} threads")
+    ax_true = true_tf.axisangle(True).numpy()
+    d0 = info["axisangle_init"].numpy() - ax_true
+    d1 = P["axisangle"].numpy() - ax_true
+    print("pose parameters vs truth, mean |.| rotation / translation: start %.4f rad / %.4f mm, end %.4f rad / %.4f mm" %
+          (np.abs(d0[:, :3]).mean(), np.abs(d0[:, 3:]).mean(), np.abs(d1[:, :3]).mean(), np.abs(d1[:, 3:]).mean()))
     np.savez_compressed(
         opt.out, loss_keys=np.array(keys), loss_history=hist, seconds_per_iteration=secs.astype(np.float32),
         psnr_whole_db=np.float64(p_whole), psnr_interior_db=np.float64(p_int), scale_whole=np.float64(s_whole),
         scale_interior=np.float64(s_int), coarse_volume_stride4=coarse, dataset_checksums=sums,
-        config=np.array([opt.n_iter, opt.batch_size, opt.n_samples, N, 3, len(levels), torch.get_num_threads(), os.cpu_count()]),
+        config=np.array([opt.n_iter, opt.batch_size, opt.n_samples, N, opt.stacks, len(levels), torch.get_num_threads(), os.cpu_count()]),
+        config_ext=np.array([opt.motion_deg, opt.motion_mm, opt.seed, opt.n_levels_bias, opt.output_resolution, opt.sample_stride],
+                            dtype=np.float64),
         iters_per_s=np.float64(rate), iters_per_s_median=np.float64(1.0 / np.median(secs[t_from:])), bounding_box=bb.numpy(),
-        skull_threshold=np.float64(SKULL))
+        skull_threshold=np.float64(SKULL), axisangle_final=P["axisangle"].numpy().astype(np.float32),
+        axisangle_init=info["axisangle_init"].numpy().astype(np.float32), axisangle_true=ax_true.astype(np.float32),
+        sampled_points=sampled, sampled_seed=np.int64(5))
     # (iters_per_s = mean over iterations 21..n as BASELINE.md asks; the median-based rate ignores iterations that shared
     #  the build container's 8 cores with a compiler run - the full-batch fixture was generated next to other work)
     print("wrote", opt.out)
