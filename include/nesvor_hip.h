@@ -179,6 +179,10 @@ typedef struct {
 /* u (N,3) in [0,1]; table flat fp32; pe out. */
 int nesvor_hashgrid_forward(const nesvor_grid_t* grid, const float* u, const float* table, float* pe,
                             int64_t N, int layout, void* stream);
+/* The same forward; additionally raises the slotted bound pe_absmax (NESVOR_ABSMAX_FLOATS floats, zero-filled by the caller; may
+ * be NULL) to max |pe| - the input bound of the network that consumes pe (nesvor_mlp_t.prep + NESVOR_MLP_PREP_XB). */
+int nesvor_hashgrid_forward_bounded(const nesvor_grid_t* grid, const float* u, const float* table, float* pe,
+                                    int64_t N, int layout, float* pe_absmax, void* stream);
 /* grad_table is ACCUMULATED into (caller zero-fills when needed);
  * grad_u (N,3) is OVERWRITTEN, or NULL to skip the input gradient.
  * Owner-computes scatter (LDS aggregation per 256 samples -> per-chunk queues ->
@@ -294,11 +298,15 @@ typedef struct {
                                     mixed-precision mode, not the reference's fp32 semantics; the saved activations
                                     are bf16.  Backward: wave-specialised kernel only (N, S, k_a multiples of 16, at
                                     most two hidden layers, k_a + k_b <= 32 for two hidden layers);
-                                 2: every fp32 operand split into the exact sum of three bf16 numbers, six bf16 MFMAs
-                                    per product: fp32-equivalent accuracy (error against fp64 as the fp32 FMA chain's)
-                                    on the 16x faster bf16 matrix pipe.  Forward: all layers; backward: the dX chain of
-                                    the wave-specialised kernel (the dW products and every other backward kernel use
-                                    mode 0, which is always a valid evaluation of mode 2) */
+                                 2: every fp32 operand x written as two fp16 numbers of a scaled copy (x s = hi + lo, both
+                                    roundings to nearest, s a power of two per operand tensor and launch derived from the
+                                    bounds in `prep`), three fp16 MFMAs per product, fp32 accumulation: fp32-equivalent accuracy
+                                    (error against fp64 at or below the fp32 FMA chain's: tools/f16_split_probe.hip,
+                                    tests/test_gpu_ops.py::test_fused_mlp_split_operands_keep_fp32_accuracy) on the 16x
+                                    faster 16-bit matrix pipe.  Pipelined forward and wave-specialised backward (dX chain and dW
+                                    products); every other kernel evaluates this mode as mode 0, which is always a valid
+                                    evaluation of it.  (Rounds 2-4: three bf16 terms per operand, six MFMAs per product.)
+                                    REQUIRES `prep` */
   int32_t compact_save;       /* 1: training keeps, per hidden unit and sample, ONE BIT (h > 0) of every hidden layer and the
                                  values of the layers after the first only: saved_hidden[0] = one uint32 per (16-sample group,
                                  lane) - 16 N bytes instead of 256 N - with bit 16 l + 4 b + r = [pre-activation sign bit clear] (= [h_l > 0] for every
@@ -311,7 +319,41 @@ typedef struct {
                                  the wave-specialised backward); forward and backward of one step must agree on it. */
   const float* weight[NESVOR_MAX_MLP_LAYERS];
   const float* bias[NESVOR_MAX_MLP_LAYERS];
+  const float* prep;          /* mode 2: NESVOR_MLP_PREP_FLOATS device floats, valid bounds for THIS launch (a bound may be loose -
+                                 it costs resolution below 2^-17 of it - but never too small: fp16 overflows at 65504 s).
+                                 Operand bounds are SLOTTED: NESVOR_ABSMAX_FLOATS floats each, the bound is the maximum of every
+                                 NESVOR_ABSMAX_STRIDE-th of them
+                                 (publishing kernels spread their atomic maxima over the slots by workgroup):
+                                   [NESVOR_MLP_PREP_XA ..] >= max |xa|, [NESVOR_MLP_PREP_XB ..] >= max |xb rows b_row0 .. b_row0 + k_b|,
+                                   [NESVOR_MLP_PREP_DY ..] >= max |dy| (backward),
+                                   [NESVOR_MLP_PREP_LAYER0 + 4 l + {0,1,2,3}] = max |W_l|, max_o sum_k |W_l[o][k]|,
+                                   max_k sum_o |W_l[o][k]|, max |b_l|.
+                                 nesvor_mlp_prepare() fills any part of it; inside the training step the producing kernels publish
+                                 the operand bounds (hash-grid forward: max |pe|; the networks' y_absmax / dxb_absmax; the loss
+                                 kernel: max |d z|, max |d log_var|) and one launch per step takes the weight norms.  Forward
+                                 and backward of one step must see the same [0], [1] and weights. */
+  float* y_absmax;            /* forward, optional: a slotted bound (NESVOR_ABSMAX_FLOATS zero-filled device floats) raised to max |y| */
 } nesvor_mlp_t;
+#define NESVOR_ABSMAX_SLOTS 16      /* a slotted bound: this many floats, NESVOR_ABSMAX_STRIDE floats (one 256-byte line) apart - */
+#define NESVOR_ABSMAX_STRIDE 64     /* atomics on one cache line serialise at the memory side, publishers spread by workgroup */
+#define NESVOR_ABSMAX_FLOATS (NESVOR_ABSMAX_SLOTS * NESVOR_ABSMAX_STRIDE)
+#define NESVOR_MLP_PREP_XA 0
+#define NESVOR_MLP_PREP_XB (1 * NESVOR_ABSMAX_FLOATS)
+#define NESVOR_MLP_PREP_DY (2 * NESVOR_ABSMAX_FLOATS)
+#define NESVOR_MLP_PREP_LAYER0 (3 * NESVOR_ABSMAX_FLOATS)
+#define NESVOR_MLP_PREP_FLOATS (NESVOR_MLP_PREP_LAYER0 + 4 * NESVOR_MAX_MLP_LAYERS)
+#define NESVOR_MLP_WHAT_INPUT 1   /* `what` of nesvor_mlp_prepare: the xa and xb bounds */
+#define NESVOR_MLP_WHAT_DY 2      /* the dy bound */
+#define NESVOR_MLP_WHAT_WEIGHTS 4 /* the per-layer norms from net->weight / net->bias */
+/* Fill (parts of) `prep` for `net` on `stream`: absolute maxima by a grid-wide reduction (the selected entries are zero-filled
+ * first), weight norms by one workgroup per layer.  xa / xb / dy may be NULL when their bit is not set. */
+int nesvor_mlp_prepare(const nesvor_mlp_t* net, const float* xa, const float* xb, const float* dy, int64_t N, float* prep,
+                       int what, void* stream);
+/* The weight norms of up to three networks in ONE launch (the training step: once per iteration, on its side stream);
+ * optionally also max |x[0..n_x)| into the slotted bound `x_slots` (the slice embedding table: the pixel features of
+ * sigma_net / b_net are rows of it).  preps[i] as nesvor_mlp_t.prep of nets[i]; nothing is zero-filled. */
+int nesvor_mlp_prepare_weights(const nesvor_mlp_t* const* nets, float* const* preps, int n_nets, const float* x, int64_t n_x,
+                               float* x_slots, void* stream);
 
 /* 1 if (net, N) can run with compact_save = 1 (the field itself is ignored by this query), else 0. */
 int nesvor_mlp_compact_save_ok(const nesvor_mlp_t* net, int64_t N);
@@ -349,6 +391,10 @@ typedef struct {
   float* loss_pix; float* dz0; float* dlog_var; float* dlog_bias; float* dx; float* dc_pix; float* dlvs_pix;
   int32_t B, S, reg_type;
   float delta;
+  /* optional (backward launch): slotted bounds (NESVOR_ABSMAX_FLOATS floats each, zero-filled by the caller) raised to max |dz0|,
+     max |dlog_var|, max |dlog_bias| - the upstream-gradient bounds of the networks that consume them
+     (nesvor_mlp_t.prep + NESVOR_MLP_PREP_DY) */
+  float* dz0_absmax; float* dlog_var_absmax; float* dlog_bias_absmax;
 } nesvor_loss_t;
 
 int nesvor_imaging_loss(const nesvor_loss_t* args, void* stream);
@@ -429,7 +475,9 @@ int nesvor_sum_rows_multi(const float* const* in, float* const* out, const int* 
  * pointers unless stated; gradients go straight into the caller's (flat) gradient buffer, which the AdamW step zero-fills.
  *   switches   : opt_T = !no_transformation_optimization, has_lv = !no_pixel_variance, has_c = !no_slice_scale,
  *                has_lvs = !no_slice_variance, has_b = n_levels_bias > 0 (cli/main.py:61,86-110)
- *   small      : n (1 + 12 + 13) + 1 floats: slice scale c | pose matrices | zeroed accumulators [dc | dmat] | max |dpe|
+ *   small      : n (1 + 12 + 13) + 1 + 3 NESVOR_MLP_PREP_FLOATS floats: slice scale c | pose matrices | zeroed accumulators
+ *                [dc | dmat] | max |dpe| | the three networks' operand bounds and weight norms (nesvor_mlp_t.prep; the step
+ *                points density / sigma / bias_net at them itself)
  *   saved_*    : per hidden layer N_pad16 * 64 floats (nesvor_mlp_forward; slot 0 of a network with compact_save: 4 N_pad16
  *                floats);  partial: 3 x NESVOR_STEP_MLP_PARTIALS x (largest network's parameter count) floats - one third per
  *                network, summed by one nesvor_sum_rows_multi launch;  losses (run argument): 6 floats {MSE, logVar, MSE+logVar, transReg,

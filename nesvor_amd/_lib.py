@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NESVOR_HIP_LIB: load another build of the same ABI (tools/ablate_hashgrid.py times variants of one kernel this way)
 LIB_PATH = os.environ.get("NESVOR_HIP_LIB") or os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -44,6 +44,7 @@ class MlpT(Structure):
         ("k_a", c_int32), ("k_b", c_int32), ("b_row0", c_int32), ("samples_per_pixel", c_int32),
         ("dxa_group_sums", c_int32), ("bf16_operands", c_int32), ("compact_save", c_int32),
         ("weight", c_void_p * 4), ("bias", c_void_p * 4),
+        ("prep", c_void_p), ("y_absmax", c_void_p),
     ]
 
 
@@ -53,7 +54,8 @@ class LossT(Structure):
     _fields_ = [(n, c_void_p) for n in (
         "z0", "log_var", "log_bias", "x", "v", "slice_idx", "c", "log_var_slice", "log_bias_mean", "gw",
         "loss_pix", "dz0", "dlog_var", "dlog_bias", "dx", "dc_pix", "dlvs_pix")] + [
-        ("B", c_int32), ("S", c_int32), ("reg_type", c_int32), ("delta", c_float)]
+        ("B", c_int32), ("S", c_int32), ("reg_type", c_int32), ("delta", c_float),
+        ("dz0_absmax", c_void_p), ("dlog_var_absmax", c_void_p), ("dlog_bias_absmax", c_void_p)]
 
 
 class StepT(Structure):
@@ -119,6 +121,7 @@ _SIGNATURES = {
     "nesvor_slice_acq_backward_interp_f64": ([_P] * 8 + [c_int] * 9 + [c_double, _P], c_int),
     "nesvor_slice_acq_adjoint_backward_interp_f64": ([_P] * 10 + [c_int] * 9 + [c_double, c_int, _P], c_int),
     "nesvor_hashgrid_forward": ([POINTER(GridT), _P, _P, _P, c_int64, c_int, _P], c_int),
+    "nesvor_hashgrid_forward_bounded": ([POINTER(GridT), _P, _P, _P, c_int64, c_int, _P, _P], c_int),
     "nesvor_hashgrid_backward_workspace_bytes": ([POINTER(GridT), c_int64, _P], c_int64),
     "nesvor_hashgrid_backward_workspace_zero_bytes": ([], c_int64),
     "nesvor_hashgrid_backward_overflow_offset": ([_P], c_int64),
@@ -133,6 +136,8 @@ _SIGNATURES = {
     "nesvor_psf_transform_backward_rng": ([_P] * 4 + [c_uint64, c_uint64] + [_P] * 4 + [c_int, c_int, _P], c_int),
     "nesvor_psf_noise": ([c_uint64, c_uint64, _P, c_int64, _P], c_int),
     "nesvor_mlp_compact_save_ok": ([POINTER(MlpT), c_int64], c_int),
+    "nesvor_mlp_prepare": ([POINTER(MlpT), _P, _P, _P, c_int64, _P, c_int, _P], c_int),
+    "nesvor_mlp_prepare_weights": ([_P, _P, c_int, _P, c_int64, _P, _P], c_int),
     "nesvor_mlp_forward": ([POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), c_int64, _P], c_int),
     "nesvor_mlp_backward": (
         [POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), POINTER(c_void_p), _P, _P, _P, c_int, c_int64, _P],

@@ -80,6 +80,41 @@ __device__ __forceinline__ float wave_max_f32_dpp(float v) {
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+// Publish the maximum of the non-negative `m` into a SLOTTED bound: NESVOR_ABSMAX_SLOTS device floats, NESVOR_ABSMAX_STRIDE floats
+// (one 256-byte line) apart, whose maximum is the bound (non-negative floats order like their bit patterns: integer atomic max).
+// Thousands of waves finish together, and atomics on one cache line serialise at the memory side at ~5.5 ns each (measured,
+// round 5: 8 K publishes into one scalar stretched the 18 us loss kernel to 63 us; into 64 adjacent floats - two lines - still
+// to 29 us, and the hash-grid forward from 70 to 99 us).  Spread over 16 lines by workgroup, and reduced over the workgroup
+// first where every thread reaches the call (publish_absmax_wg), they cost nothing measurable.  Consumers take the maximum
+// over the slots (absmax_slots); the caller zero-fills them.
+#ifndef NESVOR_ABSMAX_SLOTS
+#define NESVOR_ABSMAX_SLOTS 16
+#define NESVOR_ABSMAX_STRIDE 64
+#endif
+__device__ __forceinline__ void publish_absmax_f32(float* slots, float m) {  // one atomic per wave (waves may have left the kernel)
+  m = wave_max_f32_dpp(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f)
+    atomicMax(reinterpret_cast<unsigned int*>(slots) + (blockIdx.x & (NESVOR_ABSMAX_SLOTS - 1)) * NESVOR_ABSMAX_STRIDE, __float_as_uint(m));
+}
+__device__ __forceinline__ void publish_absmax_wg(float* slots, float m) {  // one atomic per workgroup: EVERY thread must call (barrier)
+  __shared__ float wg_max[16];
+  m = wave_max_f32_dpp(m);
+  if ((threadIdx.x & 63) == 0) wg_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = wg_max[0];
+    for (int w = 1; w < (int)((blockDim.x + 63) >> 6); ++w) t = fmaxf(t, wg_max[w]);
+    if (t > 0.f) atomicMax(reinterpret_cast<unsigned int*>(slots) + (blockIdx.x & (NESVOR_ABSMAX_SLOTS - 1)) * NESVOR_ABSMAX_STRIDE, __float_as_uint(t));
+  }
+}
+__device__ __forceinline__ float absmax_slots(const float* __restrict__ slots) {  // (uniform address: scalar loads, s_max_u32)
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(slots);
+  uint32_t m = 0u;
+#pragma unroll
+  for (int i = 0; i < NESVOR_ABSMAX_SLOTS; ++i) m = max(m, s[i * NESVOR_ABSMAX_STRIDE]);
+  return __uint_as_float(m);
+}
+
 // The value lane (l ^ J) holds, J a power of two below 64, without a trip through the LDS crossbar (ds_bpermute: ~100
 // cycles of latency per exchange): quad permutes, row rotates / shifts with bank masks, and gfx950's lane-swap
 // instructions across 16- and 32-lane halves.

@@ -130,7 +130,7 @@ __device__ __forceinline__ void load_feat(const float* __restrict__ p, float (&v
 template <int F, int LAYOUT>
 __global__ __launch_bounds__(256) void hashgrid_fwd(const nesvor_grid_t g, const float* __restrict__ u,
                                                     const float* __restrict__ table, float* __restrict__ pe,
-                                                    int64_t N, int box_cache) {
+                                                    int64_t N, int box_cache, float* __restrict__ pe_absmax) {
   constexpr int kFwdSlots = F <= 2 ? 1024 : (F == 4 ? 512 : 256);  // 8 KB of LDS (2048 slots: no faster)
   __shared__ uint32_t wbox[4][6];
   __shared__ __attribute__((aligned(16))) float cache[kFwdSlots * F];
@@ -195,24 +195,31 @@ __global__ __launch_bounds__(256) void hashgrid_fwd(const nesvor_grid_t g, const
       load_feat<F>(tab + (size_t)idx * F, v[k]);
     }
   }
-  if (!valid) return;
   float acc[F];
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.f;
+  if (valid) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float w = ((k & 1) ? c.wx : 1.f - c.wx) * (((k >> 1) & 1) ? c.wy : 1.f - c.wy) * ((k >> 2) ? c.wz : 1.f - c.wz);
+    for (int k = 0; k < 8; ++k) {
+      const float w = ((k & 1) ? c.wx : 1.f - c.wx) * (((k >> 1) & 1) ? c.wy : 1.f - c.wy) * ((k >> 2) ? c.wz : 1.f - c.wz);
 #pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] = fmaf(w, v[k][f], acc[f]);
+      for (int f = 0; f < F; ++f) acc[f] = fmaf(w, v[k][f], acc[f]);
+    }
+    const int E = g.n_levels * F;
+    if constexpr (LAYOUT == NESVOR_LAYOUT_ROW_MAJOR) {
+      float* o = pe + (size_t)i * E + level * F;
+#pragma unroll
+      for (int f = 0; f < F; ++f) o[f] = acc[f];
+    } else {
+#pragma unroll
+      for (int f = 0; f < F; ++f) pe[(size_t)(level * F + f) * N + i] = acc[f];
+    }
   }
-  const int E = g.n_levels * F;
-  if constexpr (LAYOUT == NESVOR_LAYOUT_ROW_MAJOR) {
-    float* o = pe + (size_t)i * E + level * F;
+  if (pe_absmax != nullptr) {  // (all lanes arrive here: the wave-wide maximum)
+    float m = 0.f;
 #pragma unroll
-    for (int f = 0; f < F; ++f) o[f] = acc[f];
-  } else {
-#pragma unroll
-    for (int f = 0; f < F; ++f) pe[(size_t)(level * F + f) * N + i] = acc[f];
+    for (int f = 0; f < F; ++f) m = fmaxf(m, fabsf(acc[f]));
+    publish_absmax_wg(pe_absmax, m);
   }
 }
 
@@ -234,7 +241,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd(const nesvor_grid_t g, const
 #endif
 template <int F, int LAYOUT>
 __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g, const float* __restrict__ u,
-                                                          const float* __restrict__ table, float* __restrict__ pe, int64_t N) {
+                                                          const float* __restrict__ table, float* __restrict__ pe, int64_t N,
+                                                          float* __restrict__ pe_absmax) {  // optional: raised to max |pe| (the density network's input bound)
 #ifndef NESVOR_FWD_CLOUD_SLOTS
 #define NESVOR_FWD_CLOUD_SLOTS 512
 #endif
@@ -312,8 +320,11 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
   // feature-major rows: scalar row base + the lane's 32-bit byte offset (4 i < 2^32) - no vector address arithmetic per store
   const bool off32 = NESVOR_FWD_SSTORE && N < ((int64_t)1 << 30);
   const uint32_t i4 = (uint32_t)i * 4u;
+  float pe_mx = 0.f;
   auto store_pe = [&](int level, const float (&acc)[F]) __attribute__((always_inline)) {
     if (!valid) return;
+#pragma unroll
+    for (int f = 0; f < F; ++f) pe_mx = fmaxf(pe_mx, fabsf(acc[f]));
     if constexpr (LAYOUT == NESVOR_LAYOUT_ROW_MAJOR) {
       float* o = pe + (size_t)i * E + level * F;
 #pragma unroll
@@ -449,6 +460,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
       store_pe(lv + 1, acc);
     }
   }
+  if (pe_absmax != nullptr) publish_absmax_wg(pe_absmax, pe_mx);
 }
 
 // ----------------------------------------------------------------- backward
@@ -1920,7 +1932,7 @@ owner_stage:
 }
 
 template <int F, int LAYOUT>
-int launch_fwd(const nesvor_grid_t* g, const float* u, const float* table, float* pe, int64_t N, int clustered, hipStream_t st) {
+int launch_fwd(const nesvor_grid_t* g, const float* u, const float* table, float* pe, int64_t N, int clustered, float* pe_absmax, hipStream_t st) {
   // Two kernels, identical results: "cloud" (one workgroup per 256 samples, all levels: the fastest on spatially
   // clustered batches - PSF clouds - and 1.4x slower than the other on unclustered points) is taken when the caller
   // says its batch is clustered (NESVOR_LAYOUT_CLUSTERED); "level" (one block per 256 samples and level) otherwise.
@@ -1932,11 +1944,11 @@ int launch_fwd(const nesvor_grid_t* g, const float* u, const float* table, float
   }();
   const int mode = forced >= 0 ? forced : (clustered ? 0 : 1);
   if (mode == 0) {
-    hipLaunchKernelGGL((hashgrid_fwd_cloud<F, LAYOUT>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, *g, u, table, pe, N);
+    hipLaunchKernelGGL((hashgrid_fwd_cloud<F, LAYOUT>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, *g, u, table, pe, N, pe_absmax);
     return (int)hipGetLastError();
   }
   dim3 grid((unsigned)((N + 255) / 256), g->n_levels), block(256);
-  hipLaunchKernelGGL((hashgrid_fwd<F, LAYOUT>), grid, block, 0, st, *g, u, table, pe, N, mode == 1 ? 1 : 0);
+  hipLaunchKernelGGL((hashgrid_fwd<F, LAYOUT>), grid, block, 0, st, *g, u, table, pe, N, mode == 1 ? 1 : 0, pe_absmax);
   return (int)hipGetLastError();
 }
 
@@ -1973,13 +1985,18 @@ int launch_bwd(const nesvor_grid_t* g, const float* u, const float* table, const
     return (int)hipErrorInvalidValue;                                                           \
   } while (0)
 
-extern "C" int nesvor_hashgrid_forward(const nesvor_grid_t* grid, const float* u, const float* table, float* pe,
-                                       int64_t N, int layout, void* stream) {
+extern "C" int nesvor_hashgrid_forward_bounded(const nesvor_grid_t* grid, const float* u, const float* table, float* pe,
+                                               int64_t N, int layout, float* pe_absmax, void* stream) {
   if (N <= 0) return 0;
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
   const int clustered = (layout & NESVOR_LAYOUT_CLUSTERED) ? 1 : 0;
   layout &= ~NESVOR_LAYOUT_CLUSTERED;
-  DISPATCH_F_LAYOUT(launch_fwd, grid, u, table, pe, N, clustered, (hipStream_t)stream);
+  DISPATCH_F_LAYOUT(launch_fwd, grid, u, table, pe, N, clustered, pe_absmax, (hipStream_t)stream);
+}
+
+extern "C" int nesvor_hashgrid_forward(const nesvor_grid_t* grid, const float* u, const float* table, float* pe,
+                                       int64_t N, int layout, void* stream) {
+  return nesvor_hashgrid_forward_bounded(grid, u, table, pe, N, layout, nullptr, stream);
 }
 
 extern "C" int nesvor_hashgrid_backward_atomic(const nesvor_grid_t* grid, const float* u, const float* table,

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void imaging_loss_kernel(const nesvor_loss_t a
   }
   const float reg_scale = (REG == 0 ? a.delta : 1.f) * gw_img / ((float)a.B * S);
   const float g_lb_reg = has_lb ? gw_bias * 2.f * a.log_bias_mean[0] / ((float)a.B * S) : 0.f;
+  float mx_dz = 0.f, mx_lv = 0.f, mx_lb = 0.f;  // published for the consumers of these gradients (nesvor_mlp_t.prep[2])
   for (int s = lane; s < S; s += 64) {
     const float z = a.z0[base + s];
     const float dens = softplus_f(z);
@@ -107,15 +108,20 @@ __global__ __launch_bounds__(256) void imaging_loss_kernel(const nesvor_loss_t a
       g_dx2 = -dd * dd / (dx2 * dx2);
     }
     g_dens += 2.f * reg_scale * g_dd;
-    a.dz0[base + s] = g_dens * sigmoid_f(z);
+    const float o_dz = g_dens * sigmoid_f(z);
+    a.dz0[base + s] = o_dz;
+    mx_dz = fmaxf(mx_dz, fabsf(o_dz));
     if (a.dx != nullptr) {
       const float gx = 2.f * reg_scale * g_dx2 * 2.f;
       float* o = a.dx + (base + s) * 3;
       o[0] = gx * ex; o[1] = gx * ey; o[2] = gx * ez;
     }
-    if (has_lv) a.dlog_var[base + s] = g_m2 * bias * expf(a.log_var[base + s]) / S;  // bias detached
-    if (has_lb) a.dlog_bias[base + s] = g_vout * c * dens * bias / S + g_lb_reg;
+    if (has_lv) { const float o_lv = g_m2 * bias * expf(a.log_var[base + s]) / S; a.dlog_var[base + s] = o_lv; mx_lv = fmaxf(mx_lv, fabsf(o_lv)); }  // bias detached
+    if (has_lb) { const float o_lb = g_vout * c * dens * bias / S + g_lb_reg; a.dlog_bias[base + s] = o_lb; mx_lb = fmaxf(mx_lb, fabsf(o_lb)); }
   }
+  if (a.dz0_absmax != nullptr) publish_absmax_f32(a.dz0_absmax, mx_dz);
+  if (has_lv && a.dlog_var_absmax != nullptr) publish_absmax_f32(a.dlog_var_absmax, mx_lv);
+  if (has_lb && a.dlog_bias_absmax != nullptr) publish_absmax_f32(a.dlog_bias_absmax, mx_lb);
 }
 
 
@@ -192,6 +198,7 @@ __global__ __launch_bounds__(256) void imaging_loss_cached_kernel(const nesvor_l
   }
   const float reg_scale = (REG == 0 ? a.delta : 1.f) * gw_img / ((float)a.B * S);
   const float g_lb_reg = has_lb ? gw_bias * 2.f * a.log_bias_mean[0] / ((float)a.B * S) : 0.f;
+  float mx_dz = 0.f, mx_lv = 0.f, mx_lb = 0.f;
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     const size_t s = base + lane + 64 * i;
@@ -210,15 +217,20 @@ __global__ __launch_bounds__(256) void imaging_loss_cached_kernel(const nesvor_l
       g_dx2 = -dd[i] * dd[i] / (dx2[i] * dx2[i]);
     }
     g_dens += 2.f * reg_scale * g_dd;
-    a.dz0[s] = g_dens * sigmoid_f(z[i]);
+    const float o_dz = g_dens * sigmoid_f(z[i]);
+    a.dz0[s] = o_dz;
+    mx_dz = fmaxf(mx_dz, fabsf(o_dz));
     if (a.dx != nullptr) {
       const float gx = 2.f * reg_scale * g_dx2 * 2.f;
       float* o = a.dx + s * 3;
       o[0] = gx * ex[i][0]; o[1] = gx * ex[i][1]; o[2] = gx * ex[i][2];
     }
-    if (has_lv) a.dlog_var[s] = g_m2 * bias[i] * elv[i] / S;
-    if (has_lb) a.dlog_bias[s] = g_vout * c * dens[i] * bias[i] / S + g_lb_reg;
+    if (has_lv) { const float o_lv = g_m2 * bias[i] * elv[i] / S; a.dlog_var[s] = o_lv; mx_lv = fmaxf(mx_lv, fabsf(o_lv)); }
+    if (has_lb) { const float o_lb = g_vout * c * dens[i] * bias[i] / S + g_lb_reg; a.dlog_bias[s] = o_lb; mx_lb = fmaxf(mx_lb, fabsf(o_lb)); }
   }
+  if (a.dz0_absmax != nullptr) publish_absmax_f32(a.dz0_absmax, mx_dz);
+  if (has_lv && a.dlog_var_absmax != nullptr) publish_absmax_f32(a.dlog_var_absmax, mx_lv);
+  if (has_lb && a.dlog_bias_absmax != nullptr) publish_absmax_f32(a.dlog_bias_absmax, mx_lb);
 }
 
 }  // namespace

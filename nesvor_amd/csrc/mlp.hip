@@ -80,6 +80,8 @@ struct MlpArgs {
   uint32_t* Hm;                 // compact save (nesvor_mlp_t.compact_save): one word per (group, lane), bit 16 l + 4 b + r = [h_l > 0]
   float* dx_absmax;             // bwd, optional: device scalar raised (atomic max) to max |dxb| - the consumer of dxb (the hash-grid
                                 // backward) scales its fixed-point sums by it instead of reading dxb an extra time
+  const float* prep;            // split mode: operand bounds and weight norms of this launch (nesvor_mlp_t.prep; see MlpScales)
+  float* y_absmax;              // fwd, optional: slotted bound raised to max |y| (the next network's input bound)
 };
 
 // max |dx| over the xb blocks of a lane's dX fragments, folded into `mx`
@@ -126,58 +128,50 @@ __device__ __forceinline__ f32x4 mfma16_bf16(s16x4 a, s16x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
 
-// Split mode (nesvor_mlp_t.bf16_operands == 2): every fp32 operand is written as the exact sum of three bf16 numbers
-// (8 + 8 + 8 mantissa bits: hi = rn(x), mid = rn(x - hi), lo = rn(x - hi - mid)) and a product a.b is evaluated as
-// the six bf16 MFMAs  a_hi b_hi + a_hi b_mid + a_mid b_hi + a_mid b_mid + a_hi b_lo + a_lo b_hi  with fp32
-// accumulation.  The three dropped terms are below 2^-23 |a||b|: the result carries the accuracy of an fp32 FMA chain,
-// while six bf16 16x16x16 MFMAs (8 cycles each) replace four fp32 16x16x4 MFMAs (36 cycles each).
-struct Split3 { s16x4 hi, mid, lo; };
-__device__ __forceinline__ f32x4 widen_bf16(const s16x4& v) {  // four bf16 -> fp32 (exact)
-  const uint2 u = __builtin_bit_cast(uint2, v);
-  return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
-               __uint_as_float(u.y & 0xFFFF0000u)};
+// Split mode (nesvor_mlp_t.bf16_operands == 2), round 5: every fp32 operand x is written as TWO fp16 numbers of a scaled copy,
+//     x s = hi + lo,   hi = rn_f16(x s),   lo = rn_f16(x s - hi)       (both round-to-nearest: |x s - hi - lo| <= 2^-24 |x s|)
+// with s a power of two chosen PER LAUNCH and per operand tensor such that a bound on the tensor maps into [2^13, 2^14) - fp16
+// then resolves every value above 2^-17 of the bound to 22-24 bits and the rest to an absolute 2^-38 of the bound - and a product
+// a b is evaluated as the three fp16 MFMAs  a_lo b_hi + a_hi b_lo + a_hi b_hi  with fp32 accumulation (the dropped a_lo b_lo is
+// below 2^-23 |a||b|).  Measured on the device (tools/f16_split_probe.hip, profiles/r05_f16_split_probe.log): the error of a
+// 64-term product against fp64 is BELOW that of the fp32 MFMA chain on all three operand families tried (2.1e-7 against 3.6e-7
+// of the largest result for N(0,1) operands; 3.4e-7 against 4.2e-7 with a dynamic range of e^3 per row), the f16 shape issues at
+// the bf16 shape's rate, fp16 subnormals are honoured by the matrix pipe, and a block of 24 MFMAs + 12 splits takes 1.33 us
+// where rounds 2-4's three-way bf16 split (six terms) took 2.15 us for the same products.
+// The bounds come from the caller (nesvor_mlp_t.prep: max |input|, max |dY| and per layer max |W|, the largest row / column L1
+// norms of W and max |b|, all device scalars - nesvor_mlp_prepare computes them, the training step lets the producing kernels
+// publish them) and propagate through the layers as |W x + b| <= ||W||_inf max|x| + max|b|: every scale is a wave-uniform
+// constant of the launch, the bias enters pre-scaled as the accumulators' initial value, ReLU and the gate bits do not care
+// about a positive scale, and the scale of a layer's output folds into the multiplier of the next split - no per-value work
+// besides the split itself (8 VALU per four values, v_fma_mixlo/hi_f16: the scale rides in the conversion) and one multiply
+// per OUTPUT value.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+struct Split2 { s16x4 hi, lo; };
+// (plain asm, not volatile: a pure function of its inputs - the scheduler may move and merge it; `m` is wave-uniform)
+__device__ __forceinline__ Split2 split2(const f32x4& v, float m) {
+  uint32_t h0, h1, l0, l1;
+  if (NESVOR_MLP_ABLATE & 4) {  // timing experiment: the split's VALU work removed
+    Split2 r;
+    r.hi = __builtin_bit_cast(s16x4, f32x2{v[0], v[1]});
+    r.lo = r.hi;
+    return r;
+  }
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(v[0]), "s"(m));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(v[1]), "s"(m));
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1) : "v"(v[2]), "s"(m));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(v[3]), "s"(m));
+  // x m - hi is exact in fp32 (hi is within 2^-11 of x m): ONE rounding, to fp16
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(v[0]), "s"(m), "v"(h0));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(v[1]), "s"(m), "v"(h0));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(v[2]), "s"(m), "v"(h1));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(v[3]), "s"(m), "v"(h1));
+  Split2 r;
+  r.hi = __builtin_bit_cast(s16x4, uint2{h0, h1});
+  r.lo = __builtin_bit_cast(s16x4, uint2{l0, l1});
+  return r;
 }
-// How the residuals x - widen(hi) are formed (NESVOR_SPLIT; planes are bit-identical in all variants, tools/split_probe.hip):
-//   0: v_lshlrev / v_and widen + v_sub_f32                                            22 VALU instructions per 4 values
-//   1: the same widening, two residuals per v_pk_add_f32 (neg modifiers)               18
-//   2: v_dot2c_f32_bf16: x += <(hi_even, hi_odd), (-1, 0) or (0, -1)> - widening and subtraction in one instruction; the
-//      selector must not be a compile-time constant (the inline constant -1.0 would address the HIGH half)   14
-#ifndef NESVOR_SPLIT
-#define NESVOR_SPLIT 2
-#endif
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
-  f32x2 d;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t opaque_sgpr(uint32_t v) { asm("" : "+s"(v)); return v; }  // (not volatile: hoisted out of the loops)
-__device__ __forceinline__ f32x4 residual(const f32x4& x, const s16x4& planes) {
-#if NESVOR_SPLIT == 2
-  const uint2 p = __builtin_bit_cast(uint2, planes);
-  const bf16x2 even = __builtin_bit_cast(bf16x2, opaque_sgpr(0x0000BF80u)), odd = __builtin_bit_cast(bf16x2, opaque_sgpr(0xBF800000u));
-  return f32x4{__builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p.x), even, x[0], false),
-               __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p.x), odd, x[1], false),
-               __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p.y), even, x[2], false),
-               __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p.y), odd, x[3], false)};
-#elif NESVOR_SPLIT == 1
-  const f32x4 w = widen_bf16(planes);
-  const f32x2 a = pk_sub(f32x2{x[0], x[1]}, f32x2{w[0], w[1]}), b = pk_sub(f32x2{x[2], x[3]}, f32x2{w[2], w[3]});
-  return f32x4{a[0], a[1], b[0], b[1]};
-#else
-  return x - widen_bf16(planes);
-#endif
-}
-__device__ __forceinline__ Split3 split3(const f32x4& v) {
-  Split3 s;
-  s.hi = pack_bf16(v);
-  if (NESVOR_MLP_ABLATE & 4) { s.mid = s.hi; s.lo = s.hi; return s; }  // timing experiment: the split's VALU work removed
-  const f32x4 r1 = residual(v, s.hi);
-  s.mid = pack_bf16(r1);
-  s.lo = pack_bf16(residual(r1, s.mid));
-  return s;
-}
-// gfx950's full-rate bf16 shape contracts 32 k-values per instruction: lane (j, q) supplies k-slots (q, 0..7).  The
+// gfx950's full-rate 16-bit shapes contract 32 k-values per instruction: lane (j, q) supplies k-slots (q, 0..7).  The
 // k index may be numbered freely as long as A and B agree, so slots 0..3 take the lane's four values of one 16-feature
 // block and slots 4..7 those of the next block: two of the kernels' fragments side by side, no data movement.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -188,31 +182,73 @@ __device__ __forceinline__ bf16x8 join8(const s16x4& a, const s16x4& b) {
 __device__ __forceinline__ f32x4 mfma32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
-// two k-blocks at once (a0/b0: block kb, a1/b1: block kb + 1)
-__device__ __forceinline__ f32x4 mfma_split2(const Split3& a0, const Split3& a1, const Split3& b0, const Split3& b1, f32x4 c) {
-  const bf16x8 ah = join8(a0.hi, a1.hi), am = join8(a0.mid, a1.mid), al = join8(a0.lo, a1.lo);
-  const bf16x8 bh = join8(b0.hi, b1.hi), bm = join8(b0.mid, b1.mid), bl = join8(b0.lo, b1.lo);
-  c = mfma32_bf16(al, bh, c);
-  c = mfma32_bf16(ah, bl, c);
-  c = mfma32_bf16(am, bm, c);
-  c = mfma32_bf16(am, bh, c);
-  c = mfma32_bf16(ah, bm, c);
-  return mfma32_bf16(ah, bh, c);
+__device__ __forceinline__ f16x8 join8h(const s16x4& a, const s16x4& b) {
+  return __builtin_bit_cast(f16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
-__device__ __forceinline__ f32x4 mfma_split(const Split3& a, const Split3& b, f32x4 c) {
-  c = mfma16_bf16(a.lo, b.hi, c);
-  c = mfma16_bf16(a.hi, b.lo, c);
-  c = mfma16_bf16(a.mid, b.mid, c);
-  c = mfma16_bf16(a.mid, b.hi, c);
-  c = mfma16_bf16(a.hi, b.mid, c);
-  return mfma16_bf16(a.hi, b.hi, c);
+__device__ __forceinline__ f32x4 mfma32_f16(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16_f16(s16x4 a, s16x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+}
+// one 16-k block (an odd last block): the three terms, smallest first
+__device__ __forceinline__ f32x4 mfma_split(const Split2& a, const Split2& b, f32x4 c) {
+  c = mfma16_f16(a.lo, b.hi, c);
+  c = mfma16_f16(a.hi, b.lo, c);
+  return mfma16_f16(a.hi, b.hi, c);
+}
+
+// Scales of one launch in the split mode (all powers of two, wave-uniform; `prep` as nesvor_mlp_t.prep):
+//   sx[l]  input of linear layer l (l = 0: the network input, l >= 1: the post-ReLU activations of hidden layer l - 1)
+//   sw[l]  W_l (both the forward and the transposed images)
+//   sd[l]  backward: d pre-activation of hidden layer l (l < n_hidden); sd[n_hidden] = the upstream gradient dY
+// Accumulator units: forward layer l: sw[l] sx[l];  backward product W_{l+1}^T d_{l+1}: sw[l+1] sd[l+1];  dW_l: sd[l] sx[l].
+struct MlpScales {
+  float sx[kMaxLayers + 1], sw[kMaxLayers], sd[kMaxLayers + 1];
+};
+__device__ __forceinline__ float uniform_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+// the power of two s with bound * s in [2^14, 2^15) (fp16 overflows at 65504), clamped to [2^-40, 2^40] (products and ratios of two scales stay finite)
+__device__ __forceinline__ float pow2_scale(float bound) {
+  const int e = (int)((__float_as_uint(bound) >> 23) & 0xFFu) - 126;  // bound = m 2^e, m in [0.5, 1); zero / subnormal: e = -126
+  const int se = min(max(15 - e, -40), 40);
+  return uniform_f(__uint_as_float((uint32_t)(se + 127) << 23));
+}
+__device__ __forceinline__ float pow2_inv(float p) {  // 1 / p for a power of two p in the clamped range: exact
+  return uniform_f(__uint_as_float((254u << 23) - __float_as_uint(p)));
+}
+__device__ __forceinline__ MlpScales mlp_scales(const float* __restrict__ prep, int n_hidden, bool has_a, bool backward) {
+  MlpScales s;
+  float bound = absmax_slots(prep + NESVOR_MLP_PREP_XB);
+  if (has_a) bound = fmaxf(bound, absmax_slots(prep + NESVOR_MLP_PREP_XA));
+#pragma unroll
+  for (int l = 0; l < kMaxLayers; ++l) {
+    s.sx[l] = 1.f; s.sw[l] = 1.f; s.sd[l] = 1.f;
+    if (l <= n_hidden) {
+      const float* nl = prep + NESVOR_MLP_PREP_LAYER0 + 4 * l;
+      s.sx[l] = pow2_scale(bound);
+      s.sw[l] = pow2_scale(nl[0]);
+      bound = fmaf(nl[1], bound, nl[3]) * 1.0001f;  // |W x + b| <= ||W||_inf max |x| + max |b|
+    }
+  }
+  s.sx[kMaxLayers] = 1.f; s.sd[kMaxLayers] = 1.f;
+  if (backward) {
+    float g = absmax_slots(prep + NESVOR_MLP_PREP_DY);
+#pragma unroll
+    for (int l = kMaxLayers - 1; l >= 0; --l) {
+      if (l == n_hidden) s.sd[l] = pow2_scale(g);
+      if (l < n_hidden) {
+        g = prep[NESVOR_MLP_PREP_LAYER0 + 4 * (l + 1) + 2] * g * 1.0001f;  // |W^T d| <= max column L1 norm of W times max |d|
+        s.sd[l] = pow2_scale(g);
+      }
+    }
+  }
+  return s;
 }
 
 // ---------------------------------------------------------------- LDS images
 // forward image of a layer with `ob_n` output blocks and `kb_n` input blocks
 // (BF16: the image holds bf16 elements at the same element indices, i.e. it uses the first half of the fp32 carve)
-// (X6: three bf16 planes hi | mid | lo of `total` elements each, i.e. 1.5x the fp32 carve)
-template <bool BF16 = false, bool X6 = false>
+template <bool BF16 = false>
 __device__ void build_image(float* img, const float* __restrict__ W, int out_dim, int in_dim, int ob_n, int kb_n) {
   if (NESVOR_MLP_ABLATE & 8) return;  // timing experiment: what the image build costs a launch
   const int total = ob_n * kb_n * 256;
@@ -221,18 +257,12 @@ __device__ void build_image(float* img, const float* __restrict__ W, int out_dim
     const int kb = blk % kb_n, ob = blk / kb_n;
     const int o = 16 * ob + (lane & 15), k = 16 * kb + 4 * (lane >> 4) + r;
     const float w = (o < out_dim && k < in_dim) ? W[(size_t)o * in_dim + k] : 0.f;
-    if constexpr (X6) {
-      __bf16* p = reinterpret_cast<__bf16*>(img);
-      const __bf16 hi = (__bf16)w;
-      const float r1 = w - (float)hi;
-      const __bf16 mid = (__bf16)r1;
-      p[e] = hi; p[total + e] = mid; p[2 * total + e] = (__bf16)(r1 - (float)mid);
-    } else if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w;
+    if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w;
     else img[e] = w;
   }
 }
 // transposed image: rows i = input features (ib blocks), k = output features (kb blocks)
-template <bool BF16 = false, bool X6 = false>
+template <bool BF16 = false>
 __device__ void build_image_T(float* img, const float* __restrict__ W, int out_dim, int in_dim, int ib_n, int kb_n) {
   if (NESVOR_MLP_ABLATE & 8) return;
   const int total = ib_n * kb_n * 256;
@@ -241,13 +271,7 @@ __device__ void build_image_T(float* img, const float* __restrict__ W, int out_d
     const int kb = blk % kb_n, ib = blk / kb_n;
     const int in = 16 * ib + (lane & 15), o = 16 * kb + 4 * (lane >> 4) + r;
     const float w = (o < out_dim && in < in_dim) ? W[(size_t)o * in_dim + in] : 0.f;
-    if constexpr (X6) {
-      __bf16* p = reinterpret_cast<__bf16*>(img);
-      const __bf16 hi = (__bf16)w;
-      const float r1 = w - (float)hi;
-      const __bf16 mid = (__bf16)r1;
-      p[e] = hi; p[total + e] = mid; p[2 * total + e] = (__bf16)(r1 - (float)mid);
-    } else if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w;
+    if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w;
     else img[e] = w;
   }
 }
@@ -256,8 +280,9 @@ __device__ void build_image_T(float* img, const float* __restrict__ W, int out_d
 // per thread in flight at once: the generic builders above walk one dependent load per iteration - 27 to 42 L2 round trips per
 // thread before the first tile, 6-11 us of every launch of the pipelined forward (tools/mlp_variants.py, -DNESVOR_MLP_ABLATE=8).
 // T: transposed image (build_image_T); A_N / B_N = (ob_n, kb_n) or (ib_n, kb_n) of the generic versions.
-template <bool BF16, bool X6, bool T, int A_N, int B_N, int THREADS>
-__device__ __forceinline__ void build_image_ct(float* img, const float* __restrict__ W, int out_dim, int in_dim) {
+// SPL: two fp16 planes hi | lo of `total` elements each of W * scale (split2's arithmetic) - the size of the fp32 carve.
+template <bool BF16, bool SPL, bool T, int A_N, int B_N, int THREADS>
+__device__ __forceinline__ void build_image_ct(float* img, const float* __restrict__ W, int out_dim, int in_dim, float scale = 1.f) {
   if (NESVOR_MLP_ABLATE & 8) return;
   constexpr int total = A_N * B_N * 256;
   constexpr int U = 8;
@@ -278,12 +303,11 @@ __device__ __forceinline__ void build_image_ct(float* img, const float* __restri
     for (int u = 0; u < U; ++u) {
       const int e = e0 + u * THREADS;
       if (e < total) {
-        if constexpr (X6) {
-          __bf16* p = reinterpret_cast<__bf16*>(img);
-          const __bf16 hi = (__bf16)w[u];
-          const float r1 = w[u] - (float)hi;
-          const __bf16 mid = (__bf16)r1;
-          p[e] = hi; p[total + e] = mid; p[2 * total + e] = (__bf16)(r1 - (float)mid);
+        if constexpr (SPL) {
+          _Float16* p = reinterpret_cast<_Float16*>(img);
+          const float ws = w[u] * scale;
+          const _Float16 hi = (_Float16)ws;
+          p[e] = hi; p[total + e] = (_Float16)(ws - (float)hi);
         } else if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w[u];
         else img[e] = w[u];
       }
@@ -292,56 +316,56 @@ __device__ __forceinline__ void build_image_ct(float* img, const float* __restri
 }
 
 // y[g][ob] (+)= img . x   for G groups at once; KB input blocks, OB output blocks
-template <int KB, int OB, bool BF16 = false, bool X6 = false>
+// SPL: `mult` = (scale of this layer's B operand) / (units x arrives in); y accumulates in units sw sx (MlpScales)
+template <int KB, int OB, bool BF16 = false, bool SPL = false>
 __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const f32x4 (&x)[kG][KB], f32x4 (&y)[kG][OB],
-                                            int lane) {
-  if constexpr (X6) {
-    const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
+                                            int lane, float mult = 1.f) {
+  if constexpr (SPL) {
+    const _Float16* img16 = reinterpret_cast<const _Float16*>(img);
     constexpr int plane = OB * KB * 256;
     auto load_a = [&](int ob, int kb) __attribute__((always_inline)) {
-      const __bf16* pa = img16 + ((ob * KB + kb) * 64 + lane) * 4;
-      Split3 a;
+      const _Float16* pa = img16 + ((ob * KB + kb) * 64 + lane) * 4;
+      Split2 a;
       a.hi = *reinterpret_cast<const s16x4*>(pa);
-      a.mid = *reinterpret_cast<const s16x4*>(pa + plane);
-      a.lo = *reinterpret_cast<const s16x4*>(pa + 2 * plane);
+      a.lo = *reinterpret_cast<const s16x4*>(pa + plane);
       return a;
     };
-    // Six MFMAs accumulate into one fragment; issued back to back they wait for one another (a dependent bf16 MFMA
+    // Three MFMAs accumulate into one fragment; issued back to back they wait for one another (a dependent MFMA
     // issues ~1.5-2x later than an independent one).  The terms are therefore walked in the outer loop and the
     // independent accumulators (two output blocks x kG groups) in the inner one; every accumulator still receives
-    // its six terms in the same order.
+    // its terms in the same order, smallest first.
 #pragma unroll
     for (int kb = 0; kb + 1 < KB; kb += 2) {
-      bf16x8 bh[kG], bm[kG], bl[kG];
+      f16x8 bh[kG], bl[kG];
 #pragma unroll
       for (int g = 0; g < kG; ++g) {
-        const Split3 p0 = split3(x[g][kb]), p1 = split3(x[g][kb + 1]);
-        bh[g] = join8(p0.hi, p1.hi); bm[g] = join8(p0.mid, p1.mid); bl[g] = join8(p0.lo, p1.lo);
+        const Split2 p0 = split2(x[g][kb], mult), p1 = split2(x[g][kb + 1], mult);
+        bh[g] = join8h(p0.hi, p1.hi); bl[g] = join8h(p0.lo, p1.lo);
       }
 #pragma unroll
       for (int ob = 0; ob < OB; ob += 2) {
         constexpr int kPair = OB >= 2 ? 2 : 1;
-        bf16x8 ah[kPair], am[kPair], al[kPair];
+        f16x8 ah[kPair], al[kPair];
 #pragma unroll
         for (int o = 0; o < kPair; ++o) {
-          const Split3 a0 = load_a(ob + o, kb), a1 = load_a(ob + o, kb + 1);
-          ah[o] = join8(a0.hi, a1.hi); am[o] = join8(a0.mid, a1.mid); al[o] = join8(a0.lo, a1.lo);
+          const Split2 a0 = load_a(ob + o, kb), a1 = load_a(ob + o, kb + 1);
+          ah[o] = join8h(a0.hi, a1.hi); al[o] = join8h(a0.lo, a1.lo);
         }
 #define NESVOR_TERM(A, B)                                                                       \
   _Pragma("unroll") for (int o = 0; o < kPair; ++o)                                             \
-    _Pragma("unroll") for (int g = 0; g < kG; ++g) y[g][ob + o] = mfma32_bf16(A[o], B[g], y[g][ob + o]);
-        NESVOR_TERM(al, bh) NESVOR_TERM(ah, bl) NESVOR_TERM(am, bm) NESVOR_TERM(am, bh) NESVOR_TERM(ah, bm) NESVOR_TERM(ah, bh)
+    _Pragma("unroll") for (int g = 0; g < kG; ++g) y[g][ob + o] = mfma32_f16(A[o], B[g], y[g][ob + o]);
+        NESVOR_TERM(al, bh) NESVOR_TERM(ah, bl) NESVOR_TERM(ah, bh)
 #undef NESVOR_TERM
       }
     }
     if constexpr (KB % 2 == 1) {
       constexpr int kb = KB - 1;
-      Split3 pb[kG];
+      Split2 pb[kG];
 #pragma unroll
-      for (int g = 0; g < kG; ++g) pb[g] = split3(x[g][kb]);
+      for (int g = 0; g < kG; ++g) pb[g] = split2(x[g][kb], mult);
 #pragma unroll
       for (int ob = 0; ob < OB; ++ob) {
-        const Split3 a = load_a(ob, kb);
+        const Split2 a = load_a(ob, kb);
 #pragma unroll
         for (int g = 0; g < kG; ++g) y[g][ob] = mfma_split(a, pb[g], y[g][ob]);
       }
@@ -395,62 +419,53 @@ __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const
 // Split-mode layer product on operands that are already split (the chain waves of the wave-specialised backward split a
 // fragment once, for this product AND for the planes they hand to the dW waves).
 template <int KB, int OB, bool ZERO = false>
-__device__ __forceinline__ void apply_layer_g1_s(const float* __restrict__ img, const Split3 (&xs)[KB], f32x4 (&y)[OB], int lane) {
-  const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
+__device__ __forceinline__ void apply_layer_g1_s(const float* __restrict__ img, const Split2 (&xs)[KB], f32x4 (&y)[OB], int lane) {
+  const _Float16* img16 = reinterpret_cast<const _Float16*>(img);
   constexpr int plane = OB * KB * 256;
   auto load_a = [&](int ob, int kb) __attribute__((always_inline)) {
-    const __bf16* pa = img16 + ((ob * KB + kb) * 64 + lane) * 4;
-    Split3 a;
+    const _Float16* pa = img16 + ((ob * KB + kb) * 64 + lane) * 4;
+    Split2 a;
     a.hi = *reinterpret_cast<const s16x4*>(pa);
-    a.mid = *reinterpret_cast<const s16x4*>(pa + plane);
-    a.lo = *reinterpret_cast<const s16x4*>(pa + 2 * plane);
+    a.lo = *reinterpret_cast<const s16x4*>(pa + plane);
     return a;
   };
   // term-major over the OB independent accumulators (see apply_layer).  The weight planes of a k-block pair are read from
-  // LDS while the activations of that pair are being split (NESVOR_MLP_APREFETCH: and those of the NEXT pair before the
-  // products of the current one), not right in front of the first product that needs them.
-#ifndef NESVOR_MLP_APREFETCH
-#define NESVOR_MLP_APREFETCH 0  // measured (tools/mlp_variants.py, same box): 0.268 / 0.227 ms without, 0.275 / 0.233 ms with the read-ahead of the next pair
-#endif
-  auto load_pair = [&](int kb, bf16x8 (&ah)[OB], bf16x8 (&am)[OB], bf16x8 (&al)[OB]) __attribute__((always_inline)) {
+  // LDS while the activations of that pair are being split, not right in front of the first product that needs them.
+  auto load_pair = [&](int kb, f16x8 (&ah)[OB], f16x8 (&al)[OB]) __attribute__((always_inline)) {
 #pragma unroll
     for (int ob = 0; ob < OB; ++ob) {
-      const Split3 a0 = load_a(ob, kb), a1 = load_a(ob, kb + 1);
-      ah[ob] = join8(a0.hi, a1.hi); am[ob] = join8(a0.mid, a1.mid); al[ob] = join8(a0.lo, a1.lo);
+      const Split2 a0 = load_a(ob, kb), a1 = load_a(ob, kb + 1);
+      ah[ob] = join8h(a0.hi, a1.hi); al[ob] = join8h(a0.lo, a1.lo);
     }
   };
-  bf16x8 ah[OB], am[OB], al[OB];
+  f16x8 ah[OB], al[OB];
   if constexpr (KB >= 2) {
-    load_pair(0, ah, am, al);
+    load_pair(0, ah, al);
     __builtin_amdgcn_sched_barrier(0x047F);  // LDS reads stay above, everything else may cross
   }
 #pragma unroll
   for (int kb = 0; kb + 1 < KB; kb += 2) {
-    const Split3 &p0 = xs[kb], &p1 = xs[kb + 1];
-    const bf16x8 bh = join8(p0.hi, p1.hi), bm = join8(p0.mid, p1.mid), bl = join8(p0.lo, p1.lo);
-    bf16x8 nh[OB], nm[OB], nl[OB];
+    const Split2 &p0 = xs[kb], &p1 = xs[kb + 1];
+    const f16x8 bh = join8h(p0.hi, p1.hi), bl = join8h(p0.lo, p1.lo);
+    f16x8 nh[OB], nl[OB];
     const bool more = kb + 3 < KB;
-    if (NESVOR_MLP_APREFETCH && more) {
-      load_pair(kb + 2, nh, nm, nl);
-      __builtin_amdgcn_sched_barrier(0x047F);
-    }
-#define NESVOR_TERM(A, B) _Pragma("unroll") for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_bf16(A[ob], B, y[ob]);
+#define NESVOR_TERM(A, B) _Pragma("unroll") for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_f16(A[ob], B, y[ob]);
     if (ZERO && kb == 0) {
 #pragma unroll
-      for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_bf16(al[ob], bh, f32x4{0.f, 0.f, 0.f, 0.f});
+      for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_f16(al[ob], bh, f32x4{0.f, 0.f, 0.f, 0.f});
     } else {
       NESVOR_TERM(al, bh)
     }
-    NESVOR_TERM(ah, bl) NESVOR_TERM(am, bm) NESVOR_TERM(am, bh) NESVOR_TERM(ah, bm) NESVOR_TERM(ah, bh)
+    NESVOR_TERM(ah, bl) NESVOR_TERM(ah, bh)
 #undef NESVOR_TERM
     if (more) {
-      if (!NESVOR_MLP_APREFETCH) load_pair(kb + 2, nh, nm, nl);
+      load_pair(kb + 2, nh, nl);
 #pragma unroll
-      for (int ob = 0; ob < OB; ++ob) { ah[ob] = nh[ob]; am[ob] = nm[ob]; al[ob] = nl[ob]; }
+      for (int ob = 0; ob < OB; ++ob) { ah[ob] = nh[ob]; al[ob] = nl[ob]; }
     }
   }
   if constexpr (KB % 2 == 1) {
-    const Split3& pb = xs[KB - 1];
+    const Split2& pb = xs[KB - 1];
 #pragma unroll
     for (int ob = 0; ob < OB; ++ob) y[ob] = mfma_split(load_a(ob, KB - 1), pb, (ZERO && KB == 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : y[ob]);
   }
@@ -458,13 +473,13 @@ __device__ __forceinline__ void apply_layer_g1_s(const float* __restrict__ img, 
 
 // ZERO (split mode): y is an output, not an accumulator - the first term of every block product takes a literal zero as its C
 // operand instead of OB x 4 registers the caller would have to clear.
-template <int KB, int OB, bool BF16 = false, bool X6 = false, bool ZERO = false>
-__device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, const f32x4 (&x)[KB], f32x4 (&y)[OB], int lane) {
-  static_assert(!ZERO || X6, "ZERO: split mode only");
-  if constexpr (X6) {
-    Split3 xs[KB];
+template <int KB, int OB, bool BF16 = false, bool SPL = false, bool ZERO = false>
+__device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, const f32x4 (&x)[KB], f32x4 (&y)[OB], int lane, float mult = 1.f) {
+  static_assert(!ZERO || SPL, "ZERO: split mode only");
+  if constexpr (SPL) {
+    Split2 xs[KB];
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) xs[kb] = split3(x[kb]);
+    for (int kb = 0; kb < KB; ++kb) xs[kb] = split2(x[kb], mult);
     apply_layer_g1_s<KB, OB, ZERO>(img, xs, y, lane);
     return;
   }
@@ -488,16 +503,13 @@ __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, co
   }
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
+    f32x4 a[OB];
 #pragma unroll
-    for (int r4 = 0; r4 < 1; ++r4) {
-      f32x4 a[OB];
+    for (int ob = 0; ob < OB; ++ob) a[ob] = *reinterpret_cast<const f32x4*>(img + ((ob * KB + kb) * 64 + lane) * 4);
 #pragma unroll
-      for (int ob = 0; ob < OB; ++ob) a[ob] = *reinterpret_cast<const f32x4*>(img + ((ob * KB + kb) * 64 + lane) * 4);
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int ob = 0; ob < OB; ++ob) y[ob] = mfma4(a[ob][r], x[kb][r], y[ob]);
-    }
+      for (int ob = 0; ob < OB; ++ob) y[ob] = mfma4(a[ob][r], x[kb][r], y[ob]);
   }
 }
 
@@ -505,49 +517,45 @@ __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, co
 // output features of a block - lane (feature j, sample quad q) ends up with feature 16 ob + j of samples 4q .. 4q+3, which is
 // the B-operand layout of the weight-gradient products.  x: the group's input in the chain layout (lane (sample j, q):
 // features 16 kb + 4q + r), img: the FORWARD image of the layer (its fragments serve as B operands unchanged: both operand
-// layouts index the lane by the non-contracted dimension).  Same six terms in the same order as apply_layer.
+// layouts index the lane by the non-contracted dimension).  Same terms in the same order as apply_layer; `mult` as there.
 template <int KB, int OB>
-__device__ __forceinline__ void apply_layer_g1_T(const float* __restrict__ img, const f32x4 (&x)[KB], f32x4 (&y)[OB], int lane) {
-  const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
+__device__ __forceinline__ void apply_layer_g1_T(const float* __restrict__ img, const f32x4 (&x)[KB], f32x4 (&y)[OB], int lane, float mult) {
+  const _Float16* img16 = reinterpret_cast<const _Float16*>(img);
   constexpr int plane = OB * KB * 256;
   auto load_w = [&](int ob, int kb) __attribute__((always_inline)) {
-    const __bf16* pa = img16 + ((ob * KB + kb) * 64 + lane) * 4;
-    Split3 w;
+    const _Float16* pa = img16 + ((ob * KB + kb) * 64 + lane) * 4;
+    Split2 w;
     w.hi = *reinterpret_cast<const s16x4*>(pa);
-    w.mid = *reinterpret_cast<const s16x4*>(pa + plane);
-    w.lo = *reinterpret_cast<const s16x4*>(pa + 2 * plane);
+    w.lo = *reinterpret_cast<const s16x4*>(pa + plane);
     return w;
   };
 #pragma unroll
   for (int kb = 0; kb + 1 < KB; kb += 2) {
-    const Split3 p0 = split3(x[kb]), p1 = split3(x[kb + 1]);
-    const bf16x8 xh = join8(p0.hi, p1.hi), xm = join8(p0.mid, p1.mid), xl = join8(p0.lo, p1.lo);
+    const Split2 p0 = split2(x[kb], mult), p1 = split2(x[kb + 1], mult);
+    const f16x8 xh = join8h(p0.hi, p1.hi), xl = join8h(p0.lo, p1.lo);
 #pragma unroll
     for (int ob = 0; ob < OB; ob += 2) {  // two independent accumulators at a time (a dependent MFMA issues later)
       constexpr int kPair = OB >= 2 ? 2 : 1;
-      bf16x8 wh[kPair], wm[kPair], wl[kPair];
+      f16x8 wh[kPair], wl[kPair];
 #pragma unroll
       for (int o = 0; o < kPair; ++o) {
-        const Split3 w0 = load_w(ob + o, kb), w1 = load_w(ob + o, kb + 1);
-        wh[o] = join8(w0.hi, w1.hi); wm[o] = join8(w0.mid, w1.mid); wl[o] = join8(w0.lo, w1.lo);
+        const Split2 w0 = load_w(ob + o, kb), w1 = load_w(ob + o, kb + 1);
+        wh[o] = join8h(w0.hi, w1.hi); wl[o] = join8h(w0.lo, w1.lo);
       }
-#define NESVOR_TERM(XP, WP) _Pragma("unroll") for (int o = 0; o < kPair; ++o) y[ob + o] = mfma32_bf16(XP, WP[o], y[ob + o]);
-      NESVOR_TERM(xh, wl) NESVOR_TERM(xl, wh) NESVOR_TERM(xm, wm) NESVOR_TERM(xh, wm) NESVOR_TERM(xm, wh) NESVOR_TERM(xh, wh)
+#define NESVOR_TERM(XP, WP) _Pragma("unroll") for (int o = 0; o < kPair; ++o) y[ob + o] = mfma32_f16(XP, WP[o], y[ob + o]);
+      NESVOR_TERM(xh, wl) NESVOR_TERM(xl, wh) NESVOR_TERM(xh, wh)
 #undef NESVOR_TERM
     }
   }
   if constexpr (KB % 2 == 1) {
-    const Split3 px = split3(x[KB - 1]);
+    const Split2 px = split2(x[KB - 1], mult);
 #pragma unroll
     for (int ob = 0; ob < OB; ++ob) {
-      const Split3 w = load_w(ob, KB - 1);
+      const Split2 w = load_w(ob, KB - 1);
       f32x4 c = y[ob];
-      c = mfma16_bf16(px.hi, w.lo, c);
-      c = mfma16_bf16(px.lo, w.hi, c);
-      c = mfma16_bf16(px.mid, w.mid, c);
-      c = mfma16_bf16(px.hi, w.mid, c);
-      c = mfma16_bf16(px.mid, w.hi, c);
-      y[ob] = mfma16_bf16(px.hi, w.hi, c);
+      c = mfma16_f16(px.hi, w.lo, c);
+      c = mfma16_f16(px.lo, w.hi, c);
+      y[ob] = mfma16_f16(px.hi, w.hi, c);
     }
   }
 }
@@ -670,8 +678,11 @@ template <int IMM> __device__ __forceinline__ void store_b32_s(const void* sbase
 template <int IMM> __device__ __forceinline__ void store_b32_s_nt(const void* sbase, uint32_t voff, uint32_t v) {
   asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" : : "v"(voff), "v"(v), "s"(sbase), "i"(IMM) : "memory");
 }
+// (s_nop: a VMEM store of more than 64 bits reads its data registers after issue - a VALU write of those registers needs wait
+//  states behind it, which the hazard recogniser only inserts for instructions it can see.  The stored value may be a temporary
+//  whose registers are rewritten at once: round 5's scaled copies of the saved activations came out as the NEXT block's values.)
 template <int IMM> __device__ __forceinline__ void store_b128_s_nt(const void* sbase, uint32_t voff, const f32x4& v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt" : : "v"(voff), "v"(v), "s"(sbase), "i"(IMM) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase), "i"(IMM) : "memory");
 }
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., so that loop indices can be asm immediates
 template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -697,26 +708,47 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 #define NESVOR_FWD_MINBLOCKS 2  // (round 4: with the scalar-base input addressing the split-mode instantiations need 144-156 VGPRs - three
                                 // workgroups would fit a CU; launch_kb explains why two are launched)
 #endif
-template <int KB1, int NH, bool X6, bool SAVE, bool COMPACT = false, bool OUT1 = false>
-__global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) void mlp_fwd_pf_kernel(const MlpArgs a) {
+template <int KB1, int NH, bool SPL, bool SAVE, bool COMPACT = false, bool OUT1 = false>
+__global__ __launch_bounds__(256, (SPL && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) void mlp_fwd_pf_kernel(const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int k_in = a.k_a + a.k_b;
-  constexpr int kBlk = X6 ? 384 : 256;
+  constexpr int kBlk = 256;  // floats per image block (split mode: two fp16 planes)
   float* img1 = lds;
   float* imgh = img1 + kHB * KB1 * kBlk;
   float* imgo = imgh + (NH - 1) * kHB * kHB * kBlk;
   float* bias = imgo + 1 * kHB * kBlk;
   float* wout = bias + (NH + 1) * kWidth;  // OUT1: the single output row in fp32
-  build_image_ct<false, X6, false, kHB, KB1, 256>(img1, a.W[0], kWidth, k_in);
-  for (int l = 1; l < NH; ++l) build_image_ct<false, X6, false, kHB, kHB, 256>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth);
-  if constexpr (OUT1) {
-    for (int e = threadIdx.x; e < kWidth; e += blockDim.x) wout[e] = a.W[NH][e];
+  // split mode: the launch's scales (MlpScales).  unit[l] = units of layer l's accumulators, mult[l] = multiplier of the split
+  // that feeds layer l (its input arrives in the previous layer's units; the network input in true units)
+  float unit[NH + 1], inv_unit[NH + 1], mult[NH + 1];
+#pragma unroll
+  for (int l = 0; l <= NH; ++l) { unit[l] = 1.f; inv_unit[l] = 1.f; mult[l] = 1.f; }
+  if constexpr (SPL) {
+    const MlpScales sc = mlp_scales(a.prep, NH, a.k_a > 0, false);
+#pragma unroll
+    for (int l = 0; l <= NH; ++l) {
+      unit[l] = uniform_f(sc.sw[l] * sc.sx[l]);
+      inv_unit[l] = pow2_inv(unit[l]);
+      mult[l] = l == 0 ? sc.sx[0] : uniform_f(sc.sx[l] * inv_unit[l - 1]);
+    }
+    build_image_ct<false, SPL, false, kHB, KB1, 256>(img1, a.W[0], kWidth, k_in, sc.sw[0]);
+#pragma unroll
+    for (int l = 1; l < NH; ++l) build_image_ct<false, SPL, false, kHB, kHB, 256>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, sc.sw[l]);
+    if constexpr (!OUT1) build_image_ct<false, SPL, false, 1, kHB, 256>(imgo, a.W[NH], a.out_dim, kWidth, sc.sw[NH]);
   } else {
-    build_image_ct<false, X6, false, 1, kHB, 256>(imgo, a.W[NH], a.out_dim, kWidth);
+    build_image_ct<false, SPL, false, kHB, KB1, 256>(img1, a.W[0], kWidth, k_in);
+    for (int l = 1; l < NH; ++l) build_image_ct<false, SPL, false, kHB, kHB, 256>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth);
+    if constexpr (!OUT1) build_image_ct<false, SPL, false, 1, kHB, 256>(imgo, a.W[NH], a.out_dim, kWidth);
+  }
+  if constexpr (OUT1) {  // the VALU output layer consumes the last hidden layer in ITS units
+    for (int e = threadIdx.x; e < kWidth; e += blockDim.x) wout[e] = a.W[NH][e] * inv_unit[NH - 1];
   }
   for (int e = threadIdx.x; e < (NH + 1) * kWidth; e += blockDim.x) {
     const int l = e / kWidth, o = e % kWidth;
-    bias[e] = (l < NH || o < a.out_dim) ? a.b[l][o] : 0.f;
+    float us = 1.f;  // biases enter as the accumulators' initial values: in the layer's units (the OUT1 output stays fp32)
+#pragma unroll
+    for (int t = 0; t <= NH; ++t) us = (t == l && !(OUT1 && t == NH)) ? unit[t] : us;
+    bias[e] = (l < NH || o < a.out_dim) ? a.b[l][o] * us : 0.f;
   }
   __syncthreads();
 
@@ -773,6 +805,7 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) v
     for (int kb = 0; kb < KB1; ++kb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) xr[g][kb][r] = 0.f;
+  float y_mx = 0.f;
   if ((int64_t)blockIdx.x < n_tiles) { issue_x(blockIdx.x, xr); settle_x(xr); }
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t g0 = (tile * 4 + wave) * kG;
@@ -802,8 +835,8 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) v
 #pragma unroll
         for (int g = 0; g < kG; ++g) h[l][g][ob] = bq;
       }
-      if (l == 0) apply_layer<KB1, kHB, false, X6>(img1, x, h[0], lane);
-      else apply_layer<kHB, kHB, false, X6>(imgh + (l - 1) * kHB * kHB * kBlk, h[l - 1], h[l], lane);
+      if (l == 0) apply_layer<KB1, kHB, false, SPL>(img1, x, h[0], lane, mult[0]);
+      else apply_layer<kHB, kHB, false, SPL>(imgh + (l - 1) * kHB * kHB * kBlk, h[l - 1], h[l], lane, mult[l]);
       if constexpr (SAVE && COMPACT) {
         // The gate bits of a layer from the SIGN bits of the pre-activations: v_alignbit_b32 sg, sg, x, 31 = (sg << 1) | (x >> 31)
         // shifts one sign in per instruction (rounds 1-3: v_min_u32 + v_lshl_or_b32 on the ReLU output, two per value).
@@ -850,7 +883,17 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) v
       const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + NH * kWidth + 4 * q);
 #pragma unroll
       for (int g = 0; g < kG; ++g) o[g][0] = bq;
-      apply_layer<kHB, 1, false, X6>(imgo, h[NH - 1], o, lane);
+      apply_layer<kHB, 1, false, SPL>(imgo, h[NH - 1], o, lane, mult[NH]);
+      if constexpr (SPL) {
+#pragma unroll
+        for (int g = 0; g < kG; ++g) o[g][0] *= inv_unit[NH];
+      }
+    }
+    if (a.y_absmax != nullptr) {
+#pragma unroll
+      for (int g = 0; g < kG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y_mx = fmaxf(y_mx, fabsf(o[g][0][r]));  // (rows beyond out_dim: zero weights and bias)
     }
     settle_x(xr);
     if constexpr (SAVE) {
@@ -859,7 +902,12 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) v
 #pragma unroll
         for (int g = 0; g < kG; ++g) {
           const char* hbase = reinterpret_cast<const char*>(a.H[l]) + hgroup(g0 + g) * (int64_t)(kHB * 64 * 16);
-          static_for<kHB>([&](auto ob) { store_b128_s_nt<decltype(ob)::value * 64 * 16>(hbase, (uint32_t)lane * 16u, h[l][g][decltype(ob)::value]); });
+          // (split mode: the layer's values leave in true units - an exact multiplication by a power of two)
+          static_for<kHB>([&](auto ob) {
+            f32x4 hv = h[l][g][decltype(ob)::value];
+            if constexpr (SPL) hv *= inv_unit[l];
+            store_b128_s_nt<decltype(ob)::value * 64 * 16>(hbase, (uint32_t)lane * 16u, hv);
+          });
         }
       if constexpr (COMPACT) {
 #pragma unroll
@@ -875,23 +923,27 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) v
         if (4 * q + r < a.out_dim) store_b32_s<0>(ybase, yoff[r], o[g][0][r]);
     }
   }
+  if (a.y_absmax != nullptr) publish_absmax_wg(a.y_absmax, y_mx);
 }
 
 // ------------------------------------------------------------------- forward
-template <int KB1, bool BF16 = false, bool X6 = false>
-__global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_kernel(const MlpArgs a) {  // split mode: keep two workgroups per CU (the grid is sized for that)
+// (the general kernel: any N, any input composition, up to three hidden layers; fp32 MFMAs or bf16-rounded operands - the
+//  split mode lives in the pipelined kernel above, and shapes it does not take are evaluated here on the fp32 pipe, which is
+//  always a valid evaluation of the split mode)
+template <int KB1, bool BF16 = false>
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n_hidden = a.n_linear - 1;
   const int k_in = a.k_a + a.k_b;
-  // LDS carve: [img1 | img hidden 2..n_hidden | img out | biases]   (an image block = 256 floats; 384 in split mode)
-  constexpr int kBlk = X6 ? 384 : 256;
+  // LDS carve: [img1 | img hidden 2..n_hidden | img out | biases]   (an image block = 256 floats)
+  constexpr int kBlk = 256;
   float* img1 = lds;
   float* imgh = img1 + kHB * KB1 * kBlk;
   float* imgo = imgh + (n_hidden - 1) * kHB * kHB * kBlk;
   float* bias = imgo + 1 * kHB * kBlk;
-  build_image<BF16, X6>(img1, a.W[0], kWidth, k_in, kHB, KB1);
-  for (int l = 1; l < n_hidden; ++l) build_image<BF16, X6>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, kHB, kHB);
-  build_image<BF16, X6>(imgo, a.W[n_hidden], a.out_dim, kWidth, 1, kHB);
+  build_image<BF16>(img1, a.W[0], kWidth, k_in, kHB, KB1);
+  for (int l = 1; l < n_hidden; ++l) build_image<BF16>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, kHB, kHB);
+  build_image<BF16>(imgo, a.W[n_hidden], a.out_dim, kWidth, 1, kHB);
   for (int e = threadIdx.x; e < a.n_linear * kWidth; e += blockDim.x) {
     const int l = e / kWidth, o = e % kWidth;
     bias[e] = (l < n_hidden || o < a.out_dim) ? a.b[l][o] : 0.f;
@@ -902,6 +954,7 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_kernel(
   const int j = lane & 15, q = lane >> 4;
   const int64_t n_groups = (a.N + 15) / 16;
   const int64_t n_tiles = (n_groups + 4 * kG - 1) / (4 * kG);
+  float y_mx = 0.f;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t g0 = (tile * 4 + wave) * kG;
     f32x4 x[kG][KB1];
@@ -924,7 +977,7 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_kernel(
 #pragma unroll
       for (int g = 0; g < kG; ++g) h[g][ob] = bq;
     }
-    apply_layer<KB1, kHB, BF16, X6>(img1, x, h, lane);
+    apply_layer<KB1, kHB, BF16>(img1, x, h, lane);
     for (int l = 0;; ++l) {
       // ReLU + save fragments of hidden layer l
 #pragma unroll
@@ -948,7 +1001,7 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_kernel(
 #pragma unroll
         for (int g = 0; g < kG; ++g) h2[g][ob] = bq;
       }
-      apply_layer<kHB, kHB, BF16, X6>(imgh + l * kHB * kHB * kBlk, h, h2, lane);
+      apply_layer<kHB, kHB, BF16>(imgh + l * kHB * kHB * kBlk, h, h2, lane);
 #pragma unroll
       for (int g = 0; g < kG; ++g)
 #pragma unroll
@@ -960,17 +1013,18 @@ __global__ __launch_bounds__(256, (X6 && KB1 <= 2) ? 2 : 1) void mlp_fwd_kernel(
 #pragma unroll
       for (int g = 0; g < kG; ++g) o[g][0] = bq;
     }
-    apply_layer<kHB, 1, BF16, X6>(imgo, h, o, lane);
+    apply_layer<kHB, 1, BF16>(imgo, h, o, lane);
 #pragma unroll
     for (int g = 0; g < kG; ++g) {
       const int64_t n = (g0 + g) * 16 + j;
       if (n < a.N) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (4 * q + r < a.out_dim) a.y[(size_t)(4 * q + r) * a.N + n] = o[g][0][r];
+          if (4 * q + r < a.out_dim) { a.y[(size_t)(4 * q + r) * a.N + n] = o[g][0][r]; y_mx = fmaxf(y_mx, fabsf(o[g][0][r])); }
       }
     }
   }
+  if (a.y_absmax != nullptr) publish_absmax_wg(a.y_absmax, y_mx);
 }
 
 // -------------------------------------------------------------- backward: dX
@@ -1187,37 +1241,21 @@ __device__ __forceinline__ void read_operand(const float* tile, int i, int q, fl
 }
 
 // Plane tiles (split mode of the wave-specialised backward): the chain wave hands a 16 x 16 dpre tile to its dW wave already
-// split - three bf16 planes of 512 bytes - so that the dW wave's A operand (feature i, samples 4q..4q+3) is one 8-byte read
-// per plane and needs no splitting of its own (112 VALU instructions per group off the dW wave).
-// NESVOR_MLP_PLANES (build macro): 0 = fp32 tiles that BOTH waves of a pair split (rounds 1-3 and the start of round 4);
-// 1 = planes stored TRANSPOSED ([feature row][sample]; feature f = 4q + r in row 4r + q) with 96 two-byte LDS stores per
-//     group, which cost the chain wave more than the split they save (round 3: 0.279 / 0.243 ms per launch against 0.264 / 0.228);
-// 2 = the default since round 4: planes stored as the chain wave holds them, transposed by the READ (below).  Same box, same job
-//     (gpurun_out/s2j2): density / sigma backward 0.277 / 0.220 ms (0) -> 0.262 / 0.205 (2), in the step 0.425 -> 0.400 ms for the
-//     two launches.  Bit-identical results: the planes are those the dW wave would have formed.
-#ifndef NESVOR_MLP_PLANES
-#define NESVOR_MLP_PLANES 2
-#endif
-// NESVOR_MLP_PLANES=2 (round 4): the chain wave stores each plane of its fragment UNtransposed - one ds_write_b64 per plane, the
-// lane's four bf16 (features 4q..4q+3 of sample j) at 8-byte chunk j + kPlaneQ q - and the dW wave reads it with gfx950's
-// transposing LDS read: ds_read_b64_tr_b16 hands lane i of a 16-lane group the element (i & 3) of the chunks whose addresses
-// the group's lanes 4t + (i >> 2), t = 0..3, supply.  Lane (feature i, sample quad q') therefore supplies the address of chunk
-// (sample 4q' + (i >> 2), feature quad i & 3) and receives feature i of samples 4q'..4q'+3: the A operand, already split.
-// 24 eight-byte stores per group instead of 96 two-byte ones.  With kPlaneQ = 16 the feature quads q and q + 2 of one read
-// fall on the same banks (64 dwords); the chunk index of a sample is therefore XOR-ed with 4 for q >= 2 (a permutation
-// inside each quad's 16 chunks: the store stays one dense 512-byte row per plane).  A padded stride (kPlaneQ = 18 / 20) does
-// the same without the swizzle but does not fit the 160 KiB of LDS next to the operand images.
-#ifndef NESVOR_MLP_PLANE_Q
-#define NESVOR_MLP_PLANE_Q 16
-#endif
-#ifndef NESVOR_MLP_PLANE_SWZ
-#define NESVOR_MLP_PLANE_SWZ 1
-#endif
-constexpr bool kPlanesTr = NESVOR_MLP_PLANES == 2;
-constexpr int kPlaneQ = NESVOR_MLP_PLANE_Q;
-constexpr int kPlaneBytes = kPlanesTr ? ((8 * (3 * kPlaneQ + 16) + 15) / 16) * 16 : 512;
-constexpr int kPlaneTileFloats = 3 * kPlaneBytes / 4;  // three planes of 256 bf16
-constexpr int kTile0Stride = 16;                   // the dY tile stays fp32 (it is the one tile that must fit next to the planes: no padding)
+// split - two fp16 planes of 512 bytes - so that the dW wave's A operand (feature i, samples 4q..4q+3) is one 8-byte read
+// per plane and needs no splitting of its own.  The chain wave stores each plane of its fragment as it holds it - one
+// ds_write_b64 per plane, the lane's four halves (features 4q..4q+3 of sample j) at 8-byte chunk j + kPlaneQ q - and the dW
+// wave reads it with gfx950's transposing LDS read: ds_read_b64_tr_b16 hands lane i of a 16-lane group the element (i & 3) of
+// the chunks whose addresses the group's lanes 4t + (i >> 2), t = 0..3, supply.  Lane (feature i, sample quad q') therefore
+// supplies the address of chunk (sample 4q' + (i >> 2), feature quad i & 3) and receives feature i of samples 4q'..4q'+3:
+// the A operand, already split (tools/tr16_probe.hip prints the instruction's lane map).  With kPlaneQ = 16 the feature quads
+// q and q + 2 of one read fall on the same banks (64 dwords); the chunk index of a sample is therefore XOR-ed with 4 for
+// q >= 2 (a permutation inside each quad's 16 chunks: the store stays one dense 512-byte row per plane).
+// (Rounds 1-3 staged fp32 tiles that both waves split; round 4 introduced the planes - then three bf16 planes per tile;
+//  DESIGN_LOG.md keeps the measurements of the variants.)
+constexpr int kPlaneQ = 16;
+constexpr int kPlaneBytes = 512;
+constexpr int kPlaneTileFloats = 2 * kPlaneBytes / 4;  // two planes of 256 fp16
+constexpr int kTile0Stride = 16;                   // the dY tile stays fp32 (no padding)
 constexpr int kTile0Floats = 16 * kTile0Stride;
 __device__ __forceinline__ void stage_tile0(float* tile, const f32x4& frag, int j, int q) {
   *reinterpret_cast<f32x4*>(tile + j * kTile0Stride + 4 * q) = frag;
@@ -1226,68 +1264,26 @@ __device__ __forceinline__ void read_operand0(const float* tile, int i, int q, f
 #pragma unroll
   for (int t = 0; t < 4; ++t) v[t] = tile[(4 * q + t) * kTile0Stride + i];
 }
-// (written as instructions: left to the compiler, the high halves are re-converted from the fp32 values - one extra
-// v_cvt_pk_bf16_f32 per stored element - instead of being stored with ds_write_b16_d16_hi)
-template <int OFF> __device__ __forceinline__ void lds_store_lo16(uint32_t addr, uint32_t v) {
-  asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
-}
-template <int OFF> __device__ __forceinline__ void lds_store_hi16(uint32_t addr, uint32_t v) {
-  asm volatile("ds_write_b16_d16_hi %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
-}
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-__device__ __forceinline__ void stage_planes(float* tile, const Split3& s, int j, int q) {
-  if constexpr (kPlanesTr) {
-    char* p = reinterpret_cast<char*>(tile) + 8 * ((NESVOR_MLP_PLANE_SWZ ? (j ^ ((q >> 1) << 2)) : j) + kPlaneQ * q);
-    *reinterpret_cast<s16x4*>(p) = s.hi;
-    *reinterpret_cast<s16x4*>(p + kPlaneBytes) = s.mid;
-    *reinterpret_cast<s16x4*>(p + 2 * kPlaneBytes) = s.lo;
-    return;
-  }
-  // lane (sample j, q) holds feature 4q + r -> row 4r + q (32 bytes per row), plane p at 512 p bytes
-  const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)tile + (uint32_t)((q * 16 + j) * 2);
-  const uint2 h = __builtin_bit_cast(uint2, s.hi), m = __builtin_bit_cast(uint2, s.mid), l = __builtin_bit_cast(uint2, s.lo);
-  lds_store_lo16<0>(addr, h.x);    lds_store_hi16<128>(addr, h.x);        lds_store_lo16<256>(addr, h.y);        lds_store_hi16<384>(addr, h.y);
-  lds_store_lo16<512>(addr, m.x);  lds_store_hi16<512 + 128>(addr, m.x);  lds_store_lo16<512 + 256>(addr, m.y);  lds_store_hi16<512 + 384>(addr, m.y);
-  lds_store_lo16<1024>(addr, l.x); lds_store_hi16<1024 + 128>(addr, l.x); lds_store_lo16<1024 + 256>(addr, l.y); lds_store_hi16<1024 + 384>(addr, l.y);
+__device__ __forceinline__ void stage_planes(float* tile, const Split2& s, int j, int q) {
+  char* p = reinterpret_cast<char*>(tile) + 8 * ((j ^ ((q >> 1) << 2)) + kPlaneQ * q);
+  *reinterpret_cast<s16x4*>(p) = s.hi;
+  *reinterpret_cast<s16x4*>(p + kPlaneBytes) = s.lo;
 }
-__device__ __forceinline__ void read_planes(const float* tile, int i, int q, Split3& a) {
-  if constexpr (kPlanesTr) {
-    const int js = 4 * q + (i >> 2);  // the sample whose chunk this lane addresses; its feature quad is i & 3
-    const char* p = reinterpret_cast<const char*>(tile) + 8 * ((NESVOR_MLP_PLANE_SWZ ? (js ^ ((i & 2) << 1)) : js) + kPlaneQ * (i & 3));
-    a.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-    a.mid = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + kPlaneBytes));
-    a.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 2 * kPlaneBytes));
-    return;
-  }
-  const unsigned short* t16 = reinterpret_cast<const unsigned short*>(tile) + (4 * (i & 3) + (i >> 2)) * 16 + 4 * q;
-  a.hi = *reinterpret_cast<const s16x4*>(t16);
-  a.mid = *reinterpret_cast<const s16x4*>(t16 + 256);
-  a.lo = *reinterpret_cast<const s16x4*>(t16 + 512);
-}
-
-// The three A tuples of a dW block product - (lo | hi), (mid | mid), (hi | hi): the hi plane is needed in three register pairs,
-// the mid plane in two.  With the transposing read every pair is READ into place (six LDS reads per tile instead of three reads
-// and six register moves: the LDS pipe has room, the VALU does not).  `dup[0..1]` are two opaque zeros (VGPRs written by an empty
-// asm): added to the address they keep the compiler from merging the repeated reads back into one read plus moves.
-struct PlanesA { bf16x8 lh, mm, hh; };
-__device__ __forceinline__ void read_planes3(const float* tile, int i, int q, const uint32_t (&dup)[2], PlanesA& a) {
-  if constexpr (kPlanesTr) {
-    const int js = 4 * q + (i >> 2);
-    const char* p = reinterpret_cast<const char*>(tile) + 8 * ((NESVOR_MLP_PLANE_SWZ ? (js ^ ((i & 2) << 1)) : js) + kPlaneQ * (i & 3));
-    const char* p1 = p + dup[0];
-    const char* p2 = p + dup[1];
-    const s16x4 l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 2 * kPlaneBytes));
-    const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-    const s16x4 m0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + kPlaneBytes));
-    const s16x4 m1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1 + kPlaneBytes));
-    const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
-    const s16x4 h2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p2));
-    a.lh = join8(l, h0); a.mm = join8(m0, m1); a.hh = join8(h1, h2);
-    return;
-  }
-  Split3 s;
-  read_planes(tile, i, q, s);
-  a.lh = join8(s.lo, s.hi); a.mm = join8(s.mid, s.mid); a.hh = join8(s.hi, s.hi);
+// The two A tuples of a dW block product - (lo | hi) and (hi | lo): each plane is needed in both halves of a register
+// quadruple.  Every tuple is READ into place (four transposing reads per tile instead of two reads and four register
+// moves: the LDS pipe has room, the VALU does not).  `dup` is an opaque zero (a VGPR written by an empty asm): added to the
+// address it keeps the compiler from merging the repeated reads back into one read plus moves.
+struct PlanesA { f16x8 lh, hl; };
+__device__ __forceinline__ void read_planes2(const float* tile, int i, int q, uint32_t dup, PlanesA& a) {
+  const int js = 4 * q + (i >> 2);  // the sample whose chunk this lane addresses; its feature quad is i & 3
+  const char* p = reinterpret_cast<const char*>(tile) + 8 * ((js ^ ((i & 2) << 1)) + kPlaneQ * (i & 3));
+  const char* p1 = p + dup;
+  const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + kPlaneBytes));
+  const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+  const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1 + kPlaneBytes));
+  a.lh = join8h(l0, h0); a.hl = join8h(h1, l1);
 }
 
 template <int OB, int IB>
@@ -1510,7 +1506,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const MlpArgs a) {
 template <int OB, int IB>
 __device__ void flush_dw_ws(float* red /* 4 x OB x IB x 256 + 4 x kWidth floats */, const f32x4 (&acc)[OB][IB], const f32x4 (&dbc)[OB],
                             float* out, int out_dim, int in_dim, int slot /* 0..3: accumulator (dW) wave, -1: none */,
-                            int chain /* 0..3: chain wave (owns the bias-gradient sums), -1: none */) {
+                            int chain /* 0..3: chain wave (owns the bias-gradient sums), -1: none */,
+                            float w_scale = 1.f, float b_scale = 1.f /* split mode: 1 / units of the accumulators / of the sums */) {
   // One staging round per LAYER (two workgroup barriers) - rounds 1-3 staged one output block at a time, 24 barriers per launch,
   // a fixed cost that weighs on small batches.  The region holds the four dW waves' accumulators of the layer side by side,
   // then the four chain waves' bias sums.
@@ -1541,11 +1538,11 @@ __device__ void flush_dw_ws(float* red /* 4 x OB x IB x 256 + 4 x kWidth floats 
     const int r = e & 3, ln = (e >> 2) & 63, blk = e >> 8;
     const int ib = blk % IB, ob = blk / IB;
     const int o = 16 * ob + 4 * (ln >> 4) + r, in = 16 * ib + (ln & 15);
-    if (o < out_dim && in < in_dim) out[o * in_dim + in] = s;
+    if (o < out_dim && in < in_dim) out[o * in_dim + in] = s * w_scale;
   }
   for (int e = threadIdx.x; e < OB * 16; e += blockDim.x) {
     const float s = (redb[e] + redb[kWidth + e]) + (redb[2 * kWidth + e] + redb[3 * kWidth + e]);
-    if (e < out_dim) out[out_dim * in_dim + e] = s;
+    if (e < out_dim) out[out_dim * in_dim + e] = s * b_scale;
   }
 }
 
@@ -1575,99 +1572,74 @@ __device__ __forceinline__ void accumulate_dw_regs(const float* tiles, const f32
       for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma4(av[ob][t], bv[ib][t], acc[ob][ib]);
 }
 
-// dW accumulation on the bf16 pipe at fp32 accuracy (split mode).  The contraction runs over the 16 samples of ONE
-// group, half of what v_mfma_f32_16x16x32_bf16 contracts - but the split product is a sum of six 16-sample products,
+// dW accumulation on the fp16 pipe at fp32 accuracy (split mode).  The contraction runs over the 16 samples of ONE
+// group, half of what v_mfma_f32_16x16x32_f16 contracts - but the split product is a sum of 16-sample products,
 // and the k index of the instruction may be numbered freely: k-slots 0..3 of a lane carry one term's operands and
 // slots 4..7 another's, so one instruction evaluates TWO terms,
 //     (a_lo | a_hi) . (b_hi | b_lo)  =  a_lo b_hi + a_hi b_lo
-//     (a_mid| a_mid). (b_mid| b_hi)  =  a_mid b_mid + a_mid b_hi
-//     (a_hi | a_hi) . (b_mid| b_hi)  =  a_hi b_mid + a_hi b_hi
-// three instructions (48 matrix-pipe cycles) per 16x16x16 block product instead of four v_mfma_f32_16x16x4_f32 (128
-// cycles during which the SIMD issues no VALU work at all), smallest terms first.  The operands are split here: the A
-// tiles come out of LDS as fp32, the B operands are the prefetched fp32 registers.  (The bias gradients - sums of the A
-// operands over the samples - are accumulated by the chain waves, which hold the same values and have registers to spare.)
-// The A operand of an output block comes out of the staging tiles (LDS, four ds_read_b32 per lane) and is needed a few
-// instructions later by its split: left to the scheduler the read sits right in front of its use and every one of the nine
-// operand fragments of a group pays the LDS latency in full (this wave has ONE partner on its SIMD).  The reads are therefore
-// issued one fragment ahead - `av` arrives requested, the next fragment (of this layer, or `next_tile` = the first of the
-// next layer) is requested before the current one is multiplied - and a scheduling barrier keeps LDS reads from sinking.
-template <int OB, int IB>
-__device__ __forceinline__ void accumulate_dw_split(const float* tiles, const f32x4 (&bv)[IB], f32x4 (&acc)[OB][IB], int i, int q,
-                                                    float (&av)[4], const float* next_tile) {
-  bf16x8 b_hl[IB], b_mh[IB];
+//     (a_hi | a_lo) . (b_hi | b_lo)  =  a_hi b_hi + a_lo b_lo        (the fourth term comes for free here)
+// two instructions (32 matrix-pipe cycles) per 16x16x16 block product instead of four v_mfma_f32_16x16x4_f32 (128
+// cycles during which the SIMD issues no VALU work at all), smallest terms first; ONE B tuple serves both.
+// This variant splits its A operand here (the dY tile comes out of LDS as fp32: `av`, requested by the caller); `ma` / `mb`:
+// split multipliers of the A / B operands.
+template <int IB>
+__device__ __forceinline__ void accumulate_dw_split(const f32x4 (&bv)[IB], f32x4 (&acc)[1][IB], const float (&av)[4], float ma, float mb) {
+  f16x8 b_hl[IB];
 #pragma unroll
   for (int ib = 0; ib < IB; ++ib) {
-    const Split3 sb = split3(bv[ib]);
-    b_hl[ib] = join8(sb.hi, sb.lo);
-    b_mh[ib] = join8(sb.mid, sb.hi);
+    const Split2 sb = split2(bv[ib], mb);
+    b_hl[ib] = join8h(sb.hi, sb.lo);
   }
+  const Split2 sa = split2(f32x4{av[0], av[1], av[2], av[3]}, ma);
+  const f16x8 a_lh = join8h(sa.lo, sa.hi), a_hl = join8h(sa.hi, sa.lo);
 #pragma unroll
-  for (int ob = 0; ob < OB; ++ob) {
-    float an[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* nt = ob + 1 < OB ? tiles + (ob + 1) * kTileFloats : next_tile;
-    if (nt != nullptr) read_operand(nt, i, q, an);
-    __builtin_amdgcn_sched_barrier(0x047F);  // everything but LDS instructions may cross: the read above stays above
-    const Split3 sa = split3(f32x4{av[0], av[1], av[2], av[3]});
-    const bf16x8 a_lh = join8(sa.lo, sa.hi), a_mm = join8(sa.mid, sa.mid), a_hh = join8(sa.hi, sa.hi);
+  for (int ib = 0; ib < IB; ++ib) acc[0][ib] = mfma32_f16(a_lh, b_hl[ib], acc[0][ib]);
 #pragma unroll
-    for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma32_bf16(a_lh, b_hl[ib], acc[ob][ib]);
-#pragma unroll
-    for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma32_bf16(a_mm, b_mh[ib], acc[ob][ib]);
-#pragma unroll
-    for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma32_bf16(a_hh, b_mh[ib], acc[ob][ib]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) av[t] = an[t];
-  }
+  for (int ib = 0; ib < IB; ++ib) acc[0][ib] = mfma32_f16(a_hl, b_hl[ib], acc[0][ib]);
 }
 
-
 // The same products with the A operands arriving split (plane tiles, see stage_planes): `ap` holds the requested planes of
-// the first tile; the next one (of this layer, or `next_tile`) is requested before the current one is multiplied.
+// the first tile; the next one (of this layer, or `next_tile`) is requested before the current one is multiplied - left to
+// the scheduler every read sits right in front of its use and pays the LDS latency in full (this wave has ONE partner on its
+// SIMD); a scheduling barrier keeps LDS reads from sinking.
 template <int OB, int IB>
 __device__ __forceinline__ void accumulate_dw_planes(const float* tiles, const f32x4 (&bv)[IB], f32x4 (&acc)[OB][IB], int i, int q,
-                                                     PlanesA& ap, const float* next_tile, const uint32_t (&dup)[2]) {
-  bf16x8 b_hl[IB], b_mh[IB];
+                                                     PlanesA& ap, const float* next_tile, uint32_t dup, float mb) {
+  f16x8 b_hl[IB];
 #pragma unroll
   for (int c = 0; c < IB; ++c) {
-    const Split3 sb = split3(bv[c]);
-    b_hl[c] = join8(sb.hi, sb.lo);
-    b_mh[c] = join8(sb.mid, sb.hi);
+    const Split2 sb = split2(bv[c], mb);
+    b_hl[c] = join8h(sb.hi, sb.lo);
   }
 #pragma unroll
   for (int ob = 0; ob < OB; ++ob) {
     PlanesA an = ap;
     const float* nt = ob + 1 < OB ? tiles + (ob + 1) * kPlaneTileFloats : next_tile;
-    if (nt != nullptr) read_planes3(nt, i, q, dup, an);
+    if (nt != nullptr) read_planes2(nt, i, q, dup, an);
     __builtin_amdgcn_sched_barrier(0x047F);  // everything but LDS instructions may cross: the read above stays above
 #pragma unroll
-    for (int c = 0; c < IB; ++c) acc[ob][c] = mfma32_bf16(ap.lh, b_hl[c], acc[ob][c]);
+    for (int c = 0; c < IB; ++c) acc[ob][c] = mfma32_f16(ap.lh, b_hl[c], acc[ob][c]);
 #pragma unroll
-    for (int c = 0; c < IB; ++c) acc[ob][c] = mfma32_bf16(ap.mm, b_mh[c], acc[ob][c]);
-#pragma unroll
-    for (int c = 0; c < IB; ++c) acc[ob][c] = mfma32_bf16(ap.hh, b_mh[c], acc[ob][c]);
+    for (int c = 0; c < IB; ++c) acc[ob][c] = mfma32_f16(ap.hl, b_hl[c], acc[ob][c]);
     ap = an;
   }
 }
 
-// X6: the dX chain (contraction over features, 32 at a time) runs on split-bf16 operands - see split3(); the dW waves
-// contract over the 16 samples of a group, where the split would not pay, and keep the fp32 MFMAs.
-#ifndef NESVOR_MLP_SPLIT_DW
-#define NESVOR_MLP_SPLIT_DW 1
-#endif
-constexpr bool kSplitDw = NESVOR_MLP_SPLIT_DW != 0;  // 0: the dW products of the split mode stay on v_mfma_f32_16x16x4_f32 (A/B builds)
+// SPL: the dX chain (contraction over features, 32 at a time) AND the dW products (contraction over the 16 samples of a group,
+// two terms per instruction: accumulate_dw_planes) run on split-fp16 operands - see split2() and MlpScales for the units.
 // COMPACT (nesvor_mlp_t.compact_save): the chain waves gate with the saved sign bits (one word per lane and group instead of
 // NH x 4 fragments), the dW waves recompute the first hidden layer from the network input.
 // OUT1 (split mode, out_dim == 1): the output layer's two products are rank one - d h = w_out dy and dW_out = sum_s dy_s h_s -
 // and run as fp32 VALU work (16 multiplies per lane in the chain wave, 16 FMAs in the dW wave) instead of 24 + 12 MFMAs on
 // 15/16 padding and the splits of their operands.
-template <int KB1, int NH, bool BF16 = false, bool X6 = false, bool COMPACT = false, bool OUT1 = false>
+template <int KB1, int NH, bool BF16 = false, bool SPL = false, bool COMPACT = false, bool OUT1 = false>
 __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
-  static_assert(!COMPACT || (X6 && !BF16), "compact save: split-operand mode only");
-  static_assert(!OUT1 || (X6 && !BF16), "OUT1: split-operand mode only");
+  static_assert(!COMPACT || (SPL && !BF16), "compact save: split-operand mode only");
+  static_assert(!OUT1 || (SPL && !BF16), "OUT1: split-operand mode only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int k_in = a.k_a + a.k_b;
   constexpr int kT = 1 + NH * kHB;                      // tiles per group: dY, then dpre of layers NH-1 .. 0
-  constexpr int kBlk = X6 ? 384 : 256;                  // floats per image block (three bf16 planes in split mode)
+  constexpr int kBlk = 256;                             // floats per image block (split mode: two fp16 planes)
   float* imgo = lds;                                    // W_out^T : ib = 4, kb = 1
   float* imgh = imgo + kHB * 1 * kBlk;                  // W_l^T, l = 1..NH-1
   float* img1 = imgh + (NH - 1) * kHB * kHB * kBlk;     // W_1^T : ib = KB1, kb = 4
@@ -1675,16 +1647,38 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   float* bias0 = imgf1 + (COMPACT ? kHB * KB1 * kBlk : 0);
   float* wout = bias0 + (COMPACT ? kWidth : 0);         // OUT1: the single output row in fp32
   float* tiles = wout + (OUT1 ? kWidth : 0);            // [pair][buffer][kT] tiles; reused as the flush buffer
+  // split mode: the launch's scales (MlpScales).  Chain: dY is split with sd[NH]; the product W_{l+1}^T d_{l+1} leaves d_l in
+  // units sw[l+1] sd[l+1], the split that feeds the next product (and the planes) takes it to sd[l]; dX leaves in sw[0] sd[0].
+  // dW waves: B operands h_l are split with sx[l+1] (true units from HBM; the recomputed first layer arrives in sw[0] sx[0]),
+  // the network input with sx[0]; accumulators of dW_l in sd[l] sx[l].
+  MlpScales sc;
+#pragma unroll
+  for (int l = 0; l <= kMaxLayers; ++l) { sc.sx[l] = 1.f; sc.sd[l] = 1.f; if (l < kMaxLayers) sc.sw[l] = 1.f; }
+  if constexpr (SPL) sc = mlp_scales(a.prep, NH, a.k_a > 0, true);
+  float m_d[NH + 1];      // chain: multiplier of the split of d_l (l = NH: dY, true units)
+  float inv_d[NH + 1];    // 1 / units d_l arrives in before its split (bias-gradient sums); inv_d[NH] = 1
+  float inv_w[NH + 1];    // 1 / units of the dW_l accumulators
+#pragma unroll
+  for (int l = NH; l >= 0; --l) {
+    const float units = l == NH ? 1.f : ((OUT1 && l == NH - 1) ? 1.f : uniform_f(sc.sw[l + 1] * sc.sd[l + 1]));  // (OUT1: d_{NH-1} = w dy in fp32)
+    inv_d[l] = pow2_inv(units);
+    m_d[l] = uniform_f(sc.sd[l] * inv_d[l]);
+    inv_w[l] = pow2_inv(uniform_f(sc.sd[l] * sc.sx[l]));
+  }
+  const float inv_dx = pow2_inv(uniform_f(sc.sw[0] * sc.sd[0]));
+  const float unit0 = uniform_f(sc.sw[0] * sc.sx[0]);               // units of the recomputed first hidden layer (COMPACT)
+  const float m_h0 = uniform_f(sc.sx[1] * pow2_inv(unit0));         // ... and the multiplier of its split
   if constexpr (OUT1) {
     for (int e = threadIdx.x; e < kWidth; e += blockDim.x) wout[e] = a.W[NH][e];
   } else {
-    build_image_ct<BF16, X6, true, kHB, 1, 512>(imgo, a.W[NH], a.out_dim, kWidth);
+    build_image_ct<BF16, SPL, true, kHB, 1, 512>(imgo, a.W[NH], a.out_dim, kWidth, sc.sw[NH]);
   }
-  for (int l = 1; l < NH; ++l) build_image_ct<BF16, X6, true, kHB, kHB, 512>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth);
-  build_image_ct<BF16, X6, true, KB1, kHB, 512>(img1, a.W[0], kWidth, k_in);
+#pragma unroll
+  for (int l = 1; l < NH; ++l) build_image_ct<BF16, SPL, true, kHB, kHB, 512>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, sc.sw[l]);
+  build_image_ct<BF16, SPL, true, KB1, kHB, 512>(img1, a.W[0], kWidth, k_in, sc.sw[0]);
   if constexpr (COMPACT) {
-    build_image_ct<false, X6, false, kHB, KB1, 512>(imgf1, a.W[0], kWidth, k_in);
-    for (int e = threadIdx.x; e < kWidth; e += blockDim.x) bias0[e] = a.b[0][e];
+    build_image_ct<false, SPL, false, kHB, KB1, 512>(imgf1, a.W[0], kWidth, k_in, sc.sw[0]);
+    for (int e = threadIdx.x; e < kWidth; e += blockDim.x) bias0[e] = a.b[0][e] * unit0;
   }
   __syncthreads();
 
@@ -1715,8 +1709,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
       __syncthreads();
     }
   };
-  // split mode: tile 0 (dY) fp32 without padding, the NH x 4 dpre tiles as bf16 planes (see stage_planes)
-  constexpr bool PLANES = X6 && kSplitDw && (NESVOR_MLP_PLANES != 0);
+  // split mode: tile 0 (dY) fp32 without padding, the NH x 4 dpre tiles as fp16 planes (see stage_planes)
+  constexpr bool PLANES = SPL;
   constexpr int kBufFloats = PLANES ? kTile0Floats + NH * kHB * kPlaneTileFloats : kT * kTileFloats;
   float* my_tiles = tiles + pair * 2 * kBufFloats;
   const int64_t n_groups = a.N >> 4;
@@ -1813,7 +1807,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         pin(dbc_o[0]);  // (the sum stays HERE: sunk to the end of the iteration it keeps `go` alive past its in-place split)
         f32x4 gov[1] = {go};
         f32x4 d[kHB];
-        if constexpr (!X6) {
+        if constexpr (!SPL) {
 #pragma unroll
           for (int ib = 0; ib < kHB; ++ib) d[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -1826,11 +1820,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             for (int r = 0; r < 4; ++r) d[ib][r] = w[r] * dyj;
           }
         } else {
-          apply_layer_g1<1, kHB, BF16, X6, X6>(imgo, gov, d, lane);
+          apply_layer_g1<1, kHB, BF16, SPL, SPL>(imgo, gov, d, lane, m_d[NH]);
         }
 #pragma unroll
         for (int l = NH - 1; l >= 0; --l) {
-          Split3 ds[kHB];  // (PLANES)
+          Split2 ds[kHB];  // (PLANES)
 #pragma unroll
           for (int ib = 0; ib < kHB; ++ib) {
 #pragma unroll
@@ -1843,13 +1837,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
                 d[ib][r] = hs[l][ib][r] > 0.f ? d[ib][r] : 0.f;
               }
             }
-            // (the bias-gradient sums take d BEFORE the split: the split's residuals are formed in place - v_dot2c accumulates
-            // into its destination - and a d that is still needed afterwards costs one register move per value)
+            // (the bias-gradient sums take d BEFORE the split, in the units d arrives in: flush_dw_ws scales them back)
             if (l > 0) { dbc_h[l > 0 ? l - 1 : 0][ib] += d[ib]; pin(dbc_h[l > 0 ? l - 1 : 0][ib]); }
             else { dbc_1[ib] += d[ib]; pin(dbc_1[ib]); }
             if constexpr (PLANES) {
               __builtin_amdgcn_sched_barrier(0x07FC);  // VALU instructions stay on their side: the adds above, the split below
-              ds[ib] = split3(d[ib]);  // once: for the planes and for this wave's own product below
+              ds[ib] = split2(d[ib], m_d[l]);  // once: for the planes and for this wave's own product below
               stage_planes(buf + kTile0Floats + ((NH - 1 - l) * kHB + ib) * kPlaneTileFloats, ds[ib], j, q);
             } else {
               stage_tile(buf + (1 + (NH - 1 - l) * kHB + ib) * kTileFloats, d[ib], j, q);
@@ -1857,22 +1850,26 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           }
           if (l > 0) {
             f32x4 d2[kHB];
-            if constexpr (!X6) {
+            if constexpr (!SPL) {
 #pragma unroll
               for (int ib = 0; ib < kHB; ++ib) d2[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if constexpr (PLANES) apply_layer_g1_s<kHB, kHB, true>(imgh + (l - 1) * kHB * kHB * kBlk, ds, d2, lane);
-            else apply_layer_g1<kHB, kHB, BF16, X6, X6>(imgh + (l - 1) * kHB * kHB * kBlk, d, d2, lane);
+            else apply_layer_g1<kHB, kHB, BF16, SPL, SPL>(imgh + (l - 1) * kHB * kHB * kBlk, d, d2, lane);
 #pragma unroll
             for (int ib = 0; ib < kHB; ++ib) d[ib] = d2[ib];
           } else if (a.dxa != nullptr || a.dxb != nullptr) {
             f32x4 dx[KB1];
-            if constexpr (!X6) {
+            if constexpr (!SPL) {
 #pragma unroll
               for (int ib = 0; ib < KB1; ++ib) dx[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if constexpr (PLANES) apply_layer_g1_s<kHB, KB1, true>(img1, ds, dx, lane);
-            else apply_layer_g1<kHB, KB1, BF16, X6, X6>(img1, d, dx, lane);
+            else apply_layer_g1<kHB, KB1, BF16, SPL, SPL>(img1, d, dx, lane);
+            if constexpr (SPL) {
+#pragma unroll
+              for (int kb = 0; kb < KB1; ++kb) dx[kb] *= inv_dx;
+            }
             if (a.dx_absmax != nullptr) track_absmax<KB1>(a, dx, dx_mx);
             // drain the prefetch BEFORE the stores below: loads and stores share vmcnt, and the wait would otherwise
             // also cover the latency of these stores
@@ -2003,9 +2000,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     f32x4 xraw[KB1];
     float xsraw[KB1];
     float xcr[KB1][4];
-    uint32_t dup[2] = {0u, 0u};  // opaque zeros (read_planes3)
-    asm volatile("" : "+v"(dup[0]));
-    asm volatile("" : "+v"(dup[1]));
+    uint32_t dup = 0u;  // an opaque zero (read_planes2)
+    asm volatile("" : "+v"(dup));
     // one iteration: the group (one behind the chain wave) whose saved activations sit in hraw_c; the next group's go into hraw_n
     auto dw_iter = [&](int it, float (&hraw_c)[NH][kHB][4], float (&hraw_n)[NH][kHB][4]) __attribute__((always_inline)) {
       const int64_t gi = g_first + (int64_t)(it - 1) * gstride;
@@ -2035,7 +2031,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             const float b0 = bias0[16 * ob + j];
             hb[0][ob] = f32x4{b0, b0, b0, b0};
           }
-          apply_layer_g1_T<KB1, kHB>(imgf1, xc, hb[0], lane);
+          apply_layer_g1_T<KB1, kHB>(imgf1, xc, hb[0], lane, sc.sx[0]);
 #pragma unroll
           for (int ob = 0; ob < kHB; ++ob)
 #pragma unroll
@@ -2063,62 +2059,38 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             }
           }
         };
-        if constexpr (X6 && kSplitDw) {
-          float av[4];
-          if constexpr (PLANES) {
-            // dY tile (fp32, split here) and the first plane tile are requested together; every later A operand one tile ahead
-            PlanesA ap;
-            if constexpr (OUT1) {
-              float dy4[4];
-              read_operand0(buf, 0, q, dy4);                    // row 0 of the dY tile: samples 4q..4q+3 (a broadcast read)
-              read_planes3(buf + kTile0Floats, j, q, dup, ap);
-              __builtin_amdgcn_sched_barrier(0x047F);
-#pragma unroll
-              for (int ib = 0; ib < kHB; ++ib)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc1[ib] = fmaf(dy4[t], hb[NH - 1][ib][t], acc1[ib]);
-            } else {
-              read_operand0(buf, j, q, av);
-              read_planes3(buf + kTile0Floats, j, q, dup, ap);
-              accumulate_dw_split<1, kHB>(buf, hb[NH - 1], acc_o, j, q, av, nullptr);
-            }
-#pragma unroll
-            for (int l = NH - 1; l >= 0; --l) {
-              const float* dt = buf + kTile0Floats + (NH - 1 - l) * kHB * kPlaneTileFloats;
-              if (l > 0) {
-                accumulate_dw_planes<kHB, kHB>(dt, hb[l - 1], acc_h[l - 1], j, q, ap, dt + kHB * kPlaneTileFloats, dup);
-              } else {
-                if constexpr (kHLate) issue_h(gnext, hraw_n);
-                f32x4 xb_[KB1];
-                input_operands(xb_);
-                accumulate_dw_planes<kHB, KB1>(dt, xb_, acc_1, j, q, ap, nullptr, dup);
-              }
-            }
-          } else {
+        if constexpr (SPL) {
+          // dY tile (fp32, split here) and the first plane tile are requested together; every later A operand one tile ahead
+          PlanesA ap;
           if constexpr (OUT1) {
             float dy4[4];
-            read_operand(buf, 0, q, dy4);                       // row 0 of the dY tile: samples 4q..4q+3 (a broadcast read)
-            read_operand(buf + kTileFloats, j, q, av);          // first dpre tile, requested ahead as below
+            read_operand0(buf, 0, q, dy4);                    // row 0 of the dY tile: samples 4q..4q+3 (a broadcast read)
+            read_planes2(buf + kTile0Floats, j, q, dup, ap);
             __builtin_amdgcn_sched_barrier(0x047F);
 #pragma unroll
             for (int ib = 0; ib < kHB; ++ib)
 #pragma unroll
               for (int t = 0; t < 4; ++t) acc1[ib] = fmaf(dy4[t], hb[NH - 1][ib][t], acc1[ib]);
           } else {
-          read_operand(buf, j, q, av);  // dY tile; every later A fragment is requested one fragment ahead (accumulate_dw_split)
-          accumulate_dw_split<1, kHB>(buf, hb[NH - 1], acc_o, j, q, av, buf + kTileFloats);
+            float av[4];
+            read_operand0(buf, j, q, av);
+            read_planes2(buf + kTile0Floats, j, q, dup, ap);
+            __builtin_amdgcn_sched_barrier(0x047F);
+            accumulate_dw_split<kHB>(hb[NH - 1], acc_o, av, m_d[NH], (COMPACT && NH == 1) ? m_h0 : sc.sx[NH]);
           }
 #pragma unroll
           for (int l = NH - 1; l >= 0; --l) {
-            const float* dt = buf + (1 + (NH - 1 - l) * kHB) * kTileFloats;
+            const float* dt = buf + kTile0Floats + (NH - 1 - l) * kHB * kPlaneTileFloats;
             if (l > 0) {
-              accumulate_dw_split<kHB, kHB>(dt, hb[l - 1], acc_h[l - 1], j, q, av, dt + kHB * kTileFloats);
+              // B operand: the activations of hidden layer l - 1 - from HBM in true units, or (COMPACT, l - 1 = 0) recomputed above
+              accumulate_dw_planes<kHB, kHB>(dt, hb[l - 1], acc_h[l - 1], j, q, ap, dt + kHB * kPlaneTileFloats, dup,
+                                             (COMPACT && l == 1) ? m_h0 : sc.sx[l]);
             } else {
+              if constexpr (kHLate) issue_h(gnext, hraw_n);
               f32x4 xb_[KB1];
               input_operands(xb_);
-              accumulate_dw_split<kHB, KB1>(dt, xb_, acc_1, j, q, av, nullptr);
+              accumulate_dw_planes<kHB, KB1>(dt, xb_, acc_1, j, q, ap, nullptr, dup, sc.sx[0]);
             }
-          }
           }
         } else {
           accumulate_dw_regs<1, kHB, BF16>(buf, hb[NH - 1], acc_o, j, q);
@@ -2144,7 +2116,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         // The consumed set is dead, but its next definition (the request two iterations on) sits under that iteration's
         // condition, so to the compiler the registers stay live around the loop - and the in-place splits of the activations
         // copied every value first (one v_mov per value).  An empty asm that "defines" the set ends the old values here.
-        if constexpr (X6 && !BF16) {
+        if constexpr (SPL && !BF16) {
 #pragma unroll
           for (int l = kL0; l < NH; ++l)
 #pragma unroll
@@ -2202,20 +2174,101 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   float* out = a.dW_partial + (size_t)blockIdx.x * a.total_params;
   float* red = tiles;
   int poff = 0;
-  flush_dw_ws<kHB, KB1>(red, acc_1, dbc_1, out + poff, kWidth, k_in, slot, chain);
+  flush_dw_ws<kHB, KB1>(red, acc_1, dbc_1, out + poff, kWidth, k_in, slot, chain, inv_w[0], inv_d[0]);
   poff += kWidth * k_in + kWidth;
 #pragma unroll
   for (int l = 1; l < NH; ++l) {
-    flush_dw_ws<kHB, kHB>(red, acc_h[l - 1], dbc_h[l - 1], out + poff, kWidth, kWidth, slot, chain);
+    flush_dw_ws<kHB, kHB>(red, acc_h[l - 1], dbc_h[l - 1], out + poff, kWidth, kWidth, slot, chain, inv_w[l], inv_d[l]);
     poff += kWidth * kWidth + kWidth;
   }
-  flush_dw_ws<1, kHB>(red, acc_o, dbc_o, out + poff, a.out_dim, kWidth, slot, chain);
+  flush_dw_ws<1, kHB>(red, acc_o, dbc_o, out + poff, a.out_dim, kWidth, slot, chain,
+                      OUT1 ? ((COMPACT && NH == 1) ? pow2_inv(unit0) : 1.f) : inv_w[NH], 1.f);  // (OUT1: fp32 sums of dy h; a recomputed h arrives in unit0)
 }
 
-size_t ws_bwd_lds_bytes(int n_hidden, int kb1, int blk = 256, bool compact = false) {
+// ------------------------------------------------------------ nesvor_mlp_prepare
+// absolute maximum of `rows` rows of `n` floats each (row r at x + r * ld) -> slotted bound `out` (publish_absmax_f32)
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restrict__ x, int rows, int64_t n, int64_t ld, float* __restrict__ out) {
+  float m = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int r = 0; r < rows; ++r) {
+    const float* row = x + (size_t)r * ld;
+    if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+      const float4* r4 = reinterpret_cast<const float4*>(row);
+      for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = r4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+      for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(row[i]));
+    } else {
+      for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(row[i]));
+    }
+  }
+  publish_absmax_wg(out, m);
+}
+// One workgroup per linear layer: max |W|, largest row L1 norm, largest column L1 norm, max |b| (the matrix - at most 64 x 64 -
+// goes through LDS: sixteen independent coalesced loads per thread, then row sums by 64 x 4 threads and column sums by 64 x 4).
+// Workgroups past the layers (at most one): max |x[0..n_x)| into slot 0 of x_slots (the slice embedding table).
+constexpr int kNormJobs = 3 * kMaxLayers;
+struct NormJobs {
+  const float* W[kNormJobs]; const float* b[kNormJobs]; float* dst[kNormJobs];  // dst: prep + NESVOR_MLP_PREP_LAYER0 + 4 l of the layer's network
+  int out[kNormJobs], in[kNormJobs];
+  int n_jobs;
+  const float* x; int64_t n_x; float* x_slots;
+};
+__global__ __launch_bounds__(256) void weight_norms_kernel(const NormJobs jobs) {
+  __shared__ float w[64 * 65];
+  __shared__ float red[4][4];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= jobs.n_jobs) {
+    float m = 0.f;
+    for (int64_t i = tid; i < jobs.n_x; i += 256) m = fmaxf(m, fabsf(jobs.x[i]));
+    m = wave_max_f32_dpp(m);
+    if ((tid & 63) == 0) red[tid >> 6][0] = m;
+    __syncthreads();
+    if (tid == 0) jobs.x_slots[0] = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+    return;
+  }
+  const int l = blockIdx.x, out_dim = jobs.out[l], in_dim = jobs.in[l];
+  const float* W = jobs.W[l];
+  const int total = out_dim * in_dim;  // <= 4096
+  float v[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) { const int e = tid + 256 * u; v[u] = W[e < total ? e : 0]; }
+  float wmax = 0.f;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = tid + 256 * u;
+    if (e < total) { const float a = fabsf(v[u]); wmax = fmaxf(wmax, a); w[(e / in_dim) * 65 + e % in_dim] = a; }
+  }
+  __syncthreads();
+  // rows: thread (o = tid >> 2, part = tid & 3) sums columns part, part + 4, ...; columns likewise
+  float rown = 0.f, coln = 0.f, bmax = 0.f;
+  {
+    const int o = tid >> 2, part = tid & 3;
+    float sr = 0.f, sc = 0.f;
+    if (o < out_dim) for (int k = part; k < in_dim; k += 4) sr += w[o * 65 + k];
+    if (o < in_dim) for (int r = part; r < out_dim; r += 4) sc += w[r * 65 + o];
+    // the four parts sit in neighbouring lanes
+    sr += __shfl_xor(sr, 1, 64); sr += __shfl_xor(sr, 2, 64);
+    sc += __shfl_xor(sc, 1, 64); sc += __shfl_xor(sc, 2, 64);
+    rown = sr; coln = sc;
+    if (tid < out_dim) bmax = fabsf(jobs.b[l][tid]);
+  }
+  float r4[4] = {wmax, rown, coln, bmax};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    r4[t] = wave_max_f32_dpp(r4[t]);
+    if ((tid & 63) == 0) red[tid >> 6][t] = r4[t];
+  }
+  __syncthreads();
+  if (tid < 4) jobs.dst[l][tid] = fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid]));
+}
+
+size_t ws_bwd_lds_bytes(int n_hidden, int kb1, bool split = false, bool compact = false) {
+  constexpr size_t blk = 256;
   size_t img = (size_t)kHB * blk + (size_t)(n_hidden - 1) * kHB * kHB * blk + (size_t)kb1 * kHB * blk;
   if (compact) img += (size_t)kb1 * kHB * blk + kWidth;  // forward image of the first layer + its bias
-  const bool planes = blk == 384 && kSplitDw && (NESVOR_MLP_PLANES != 0);  // split mode: fp32 dY tile + plane tiles (mlp_bwd_ws_kernel::PLANES)
+  const bool planes = split;  // split mode: fp32 dY tile + plane tiles (mlp_bwd_ws_kernel::PLANES)
   size_t tiles = 4 * 2 * (planes ? (size_t)kTile0Floats + (size_t)n_hidden * kHB * kPlaneTileFloats : (size_t)(1 + n_hidden * kHB) * kTileFloats);
   // the epilogue stages one layer's accumulators of the four dW waves at once (flush_dw_ws)
   const size_t widest = (size_t)kHB * (size_t)((n_hidden > 1 && kHB > kb1) ? kHB : kb1);
@@ -2231,8 +2284,9 @@ size_t fused_bwd_lds_bytes(int n_hidden, int kb1) {
   return sizeof(float) * (img + scratch);
 }
 
-size_t fwd_lds_bytes(int n_linear, int kb1, int blk = 256) {
+size_t fwd_lds_bytes(int n_linear, int kb1) {
   const int n_hidden = n_linear - 1;
+  constexpr size_t blk = 256;
   return sizeof(float) * ((size_t)kHB * kb1 * blk + (size_t)(n_hidden - 1) * kHB * kHB * blk + kHB * blk + (size_t)n_linear * kWidth + kWidth);
 }
 size_t bwd_lds_bytes(int n_linear, int kb1) {
@@ -2311,6 +2365,8 @@ int fill_args(MlpArgs* a, const nesvor_mlp_t* d, int64_t N) {
   a->dxa_group = d->dxa_group_sums ? 1 : 0;
   a->bf16 = d->bf16_operands;  // 0: fp32 MFMA, 1: bf16-rounded operands, 2: split (fp32-equivalent) operands
   if (a->bf16 < 0 || a->bf16 > 2) return (int)hipErrorInvalidValue;
+  a->prep = d->prep;
+  a->y_absmax = d->y_absmax;
   {
     const int64_t rows = (int64_t)(d->b_row0 + d->k_b > d->out_dim ? d->b_row0 + d->k_b : d->out_dim);
     a->off32 = rows * N * 4 + 64 < ((int64_t)1 << 32) ? 1 : 0;
@@ -2343,6 +2399,58 @@ bool compact_ok(const MlpArgs& a, const nesvor_mlp_t* net, int64_t N) {
 
 }  // namespace
 
+extern "C" int nesvor_mlp_prepare_weights(const nesvor_mlp_t* const* nets, float* const* preps, int n_nets, const float* x, int64_t n_x,
+                                          float* x_slots, void* stream) {
+  if (n_nets < 0 || n_nets > 3 || (n_nets > 0 && (nets == nullptr || preps == nullptr))) return (int)hipErrorInvalidValue;
+  NormJobs jobs{};
+  int nj = 0;
+  for (int i = 0; i < n_nets; ++i) {
+    const nesvor_mlp_t* net = nets[i];
+    if (net == nullptr || preps[i] == nullptr || net->n_hidden < 1 || net->n_hidden + 1 > kMaxLayers || net->width != kWidth ||
+        net->k_a + net->k_b > 64 || net->out_dim > 64)
+      return (int)hipErrorInvalidValue;
+    for (int l = 0; l <= net->n_hidden; ++l, ++nj) {
+      jobs.W[nj] = net->weight[l]; jobs.b[nj] = net->bias[l];
+      jobs.in[nj] = l == 0 ? net->k_a + net->k_b : net->width;
+      jobs.out[nj] = l == net->n_hidden ? net->out_dim : net->width;
+      jobs.dst[nj] = preps[i] + NESVOR_MLP_PREP_LAYER0 + 4 * l;
+      if (jobs.W[nj] == nullptr || jobs.b[nj] == nullptr) return (int)hipErrorInvalidValue;
+    }
+  }
+  jobs.n_jobs = nj;
+  const bool with_x = x != nullptr && x_slots != nullptr && n_x > 0;
+  jobs.x = x; jobs.n_x = with_x ? n_x : 0; jobs.x_slots = x_slots;
+  if (nj + (with_x ? 1 : 0) == 0) return 0;
+  hipLaunchKernelGGL(weight_norms_kernel, dim3((unsigned)(nj + (with_x ? 1 : 0))), dim3(256), 0, (hipStream_t)stream, jobs);
+  return (int)hipGetLastError();
+}
+
+extern "C" int nesvor_mlp_prepare(const nesvor_mlp_t* net, const float* xa, const float* xb, const float* dy, int64_t N, float* prep,
+                                  int what, void* stream) {
+  if (net == nullptr || prep == nullptr || N <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const int S = net->samples_per_pixel > 0 ? net->samples_per_pixel : 1;
+  auto absmax = [&](const float* x, int rows, int64_t n, int64_t ld, float* out) -> int {
+    if (hipMemsetAsync(out, 0, sizeof(float) * NESVOR_ABSMAX_FLOATS, st) != hipSuccess) return (int)hipGetLastError();
+    if (x == nullptr || rows <= 0 || n <= 0) return 0;
+    const int64_t work = ((int64_t)rows * n + 1023) / 1024;
+    hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)(work < 2048 ? (work < 1 ? 1 : work) : 2048)), dim3(256), 0, st, x, rows, n, ld, out);
+    return (int)hipGetLastError();
+  };
+  if (what & NESVOR_MLP_WHAT_INPUT) {
+    int e = absmax(net->k_a > 0 ? xa : nullptr, 1, (N / S) * (int64_t)net->k_a, 0, prep + NESVOR_MLP_PREP_XA);
+    if (e) return e;
+    e = absmax(xb != nullptr ? xb + (size_t)net->b_row0 * N : nullptr, net->k_b, N, N, prep + NESVOR_MLP_PREP_XB);
+    if (e) return e;
+  }
+  if (what & NESVOR_MLP_WHAT_DY) {
+    const int e = absmax(dy, net->out_dim, N, N, prep + NESVOR_MLP_PREP_DY);
+    if (e) return e;
+  }
+  if (what & NESVOR_MLP_WHAT_WEIGHTS) return nesvor_mlp_prepare_weights(&net, &prep, 1, nullptr, 0, nullptr, stream);
+  return (int)hipGetLastError();
+}
+
 extern "C" int nesvor_mlp_compact_save_ok(const nesvor_mlp_t* net, int64_t N) {
   if (net == nullptr || N <= 0) return 0;
   MlpArgs a{};
@@ -2367,11 +2475,12 @@ extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, cons
   static const bool use_pf = []() { const char* e = getenv("NESVOR_MLP_FWD_PF"); return e == nullptr || atoi(e) != 0; }();
   bool save_all = saved_hidden != nullptr, save_none = saved_hidden == nullptr;
   const bool compact = net->compact_save != 0 && save_all;
+  if (a.bf16 == 2 && a.prep == nullptr) return (int)hipErrorInvalidValue;  // the split mode needs its operand bounds (nesvor_mlp_prepare)
   if (compact) {
     if (!compact_ok(a, net, N)) return (int)hipErrorInvalidValue;  // (the caller asks nesvor_mlp_compact_save_ok first)
     a.Hm = reinterpret_cast<uint32_t*>(saved_hidden[0]);
     a.H[0] = nullptr;
-    const size_t lds = fwd_lds_bytes(a.n_linear, kb1, 384);
+    const size_t lds = fwd_lds_bytes(a.n_linear, kb1);
     if (net->out_dim == 1 && out1_on()) {  // single output row: VALU output layer
       if (net->n_hidden == 1)
         return launch_kb(mlp_fwd_pf_kernel<1, 1, true, true, true, true>, mlp_fwd_pf_kernel<2, 1, true, true, true, true>,
@@ -2389,9 +2498,9 @@ extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, cons
   }
   if (use_pf && a.bf16 != 1 && a.fast && a.off32 && net->n_hidden <= 2 && ((N >> 4) % (4 * kG)) == 0 && (save_all || save_none)) {
     const bool x6 = a.bf16 == 2;
-    const size_t lds = fwd_lds_bytes(a.n_linear, kb1, x6 ? 384 : 256);
-#define NESVOR_PF(NH, X6, SAVE) launch_kb(mlp_fwd_pf_kernel<1, NH, X6, SAVE>, mlp_fwd_pf_kernel<2, NH, X6, SAVE>, \
-      mlp_fwd_pf_kernel<3, NH, X6, SAVE>, mlp_fwd_pf_kernel<4, NH, X6, SAVE>, kb1, grid, lds, (hipStream_t)stream, a, 256, n_tiles)
+    const size_t lds = fwd_lds_bytes(a.n_linear, kb1);
+#define NESVOR_PF(NH, SPL, SAVE) launch_kb(mlp_fwd_pf_kernel<1, NH, SPL, SAVE>, mlp_fwd_pf_kernel<2, NH, SPL, SAVE>, \
+      mlp_fwd_pf_kernel<3, NH, SPL, SAVE>, mlp_fwd_pf_kernel<4, NH, SPL, SAVE>, kb1, grid, lds, (hipStream_t)stream, a, 256, n_tiles)
     if (net->n_hidden == 1) {
       if (x6) return save_all ? NESVOR_PF(1, true, true) : NESVOR_PF(1, true, false);
       return save_all ? NESVOR_PF(1, false, true) : NESVOR_PF(1, false, false);
@@ -2400,10 +2509,8 @@ extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, cons
     return save_all ? NESVOR_PF(2, false, true) : NESVOR_PF(2, false, false);
 #undef NESVOR_PF
   }
-  if (a.bf16 == 2)
-    return launch_kb(mlp_fwd_kernel<1, false, true>, mlp_fwd_kernel<2, false, true>, mlp_fwd_kernel<3, false, true>,
-                     mlp_fwd_kernel<4, false, true>, kb1, grid, fwd_lds_bytes(a.n_linear, kb1, 384), (hipStream_t)stream, a);
-  if (a.bf16)
+  // (the split mode of a shape the pipelined kernel does not take: the plain fp32 MFMAs - always a valid evaluation of it)
+  if (a.bf16 == 1)
     return launch_kb(mlp_fwd_kernel<1, true>, mlp_fwd_kernel<2, true>, mlp_fwd_kernel<3, true>, mlp_fwd_kernel<4, true>, kb1,
                      grid, fwd_lds_bytes(a.n_linear, kb1), (hipStream_t)stream, a);
   return launch_kb(mlp_fwd_kernel<1>, mlp_fwd_kernel<2>, mlp_fwd_kernel<3>, mlp_fwd_kernel<4>, kb1, grid,
@@ -2427,6 +2534,7 @@ extern "C" int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float*
   if (saved_hidden == nullptr || dpre_scratch == nullptr || dw_partial == nullptr || n_partial < 1) return (int)hipErrorInvalidValue;
   const bool split = a.bf16 == 2;  // fp32 data everywhere; only the MFMA sites differ
   const bool compact = net->compact_save != 0;
+  if (split && a.prep == nullptr) return (int)hipErrorInvalidValue;  // the split mode needs its operand bounds (nesvor_mlp_prepare)
   if (compact && (!compact_ok(a, net, N) || dpre_scratch[0] != nullptr)) return (int)hipErrorInvalidValue;
   if (split) a.bf16 = 0;
   a.xa = xa; a.xb = xb; a.y = const_cast<float*>(dy); a.dxa = dxa; a.dxb = dxb; a.dW_partial = dw_partial;
@@ -2440,7 +2548,7 @@ extern "C" int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float*
     a.Hm = reinterpret_cast<uint32_t*>(saved_hidden[0]);
     a.H[0] = nullptr;
     if (net->out_dim == 1 && out1_on()) {  // single output row: VALU output layer
-      const size_t lds_o = ws_bwd_lds_bytes(net->n_hidden, kb1, 384, true) + sizeof(float) * kWidth;
+      const size_t lds_o = ws_bwd_lds_bytes(net->n_hidden, kb1, true, true) + sizeof(float) * kWidth;
       if (net->n_hidden == 1)
         return launch_kb(mlp_bwd_ws_kernel<1, 1, false, true, true, true>, mlp_bwd_ws_kernel<2, 1, false, true, true, true>,
                          mlp_bwd_ws_kernel<2, 1, false, true, true, true>, mlp_bwd_ws_kernel<2, 1, false, true, true, true>, kb1,
@@ -2449,7 +2557,7 @@ extern "C" int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float*
                        mlp_bwd_ws_kernel<2, 2, false, true, true, true>, mlp_bwd_ws_kernel<2, 2, false, true, true, true>, kb1,
                        dim3((unsigned)n_partial), lds_o, (hipStream_t)stream, a, 512);
     }
-    const size_t lds_c = ws_bwd_lds_bytes(net->n_hidden, kb1, 384, true);
+    const size_t lds_c = ws_bwd_lds_bytes(net->n_hidden, kb1, true, true);
     if (net->n_hidden == 1)
       return launch_kb(mlp_bwd_ws_kernel<1, 1, false, true, true>, mlp_bwd_ws_kernel<2, 1, false, true, true>, mlp_bwd_ws_kernel<2, 1, false, true, true>,
                        mlp_bwd_ws_kernel<2, 1, false, true, true>, kb1, dim3((unsigned)n_partial), lds_c, (hipStream_t)stream, a, 512);
@@ -2469,7 +2577,7 @@ extern "C" int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float*
                          mlp_bwd_ws_kernel<4, 2, true>, kb1, dim3((unsigned)n_partial), lds_ws, (hipStream_t)stream, a, 512);
       }
       if (split) {
-        const size_t lds_x6 = ws_bwd_lds_bytes(net->n_hidden, kb1, 384);
+        const size_t lds_x6 = ws_bwd_lds_bytes(net->n_hidden, kb1, true);
         if (net->n_hidden == 1)
           return launch_kb(mlp_bwd_ws_kernel<1, 1, false, true>, mlp_bwd_ws_kernel<2, 1, false, true>, mlp_bwd_ws_kernel<3, 1, false, true>,
                            mlp_bwd_ws_kernel<4, 1, false, true>, kb1, dim3((unsigned)n_partial), lds_x6, (hipStream_t)stream, a, 512);

@@ -26,7 +26,7 @@ namespace {
 
 struct StepCtx {
   nesvor_step_t d;
-  hipEvent_t ev_fork, ev_pose, ev_agg, ev_owner, ev_bwd, ev_sums;
+  hipEvent_t ev_fork, ev_pose, ev_agg, ev_owner, ev_bwd, ev_sums, ev_norms;
   bool sums_on_side = false;  // the networks' parameter-gradient sums of the current iteration were left on the side stream
   bool pending_join = false;  // a table update of the previous run is still on the side stream (NESVOR_STEP_DEFER_JOIN)
 };
@@ -95,7 +95,7 @@ extern "C" void* nesvor_step_create(const nesvor_step_t* desc) {
   StepCtx* c = new (std::nothrow) StepCtx;
   if (c == nullptr) return nullptr;
   c->d = *desc;
-  hipEvent_t* evs[6] = {&c->ev_fork, &c->ev_pose, &c->ev_agg, &c->ev_owner, &c->ev_bwd, &c->ev_sums};
+  hipEvent_t* evs[7] = {&c->ev_fork, &c->ev_pose, &c->ev_agg, &c->ev_owner, &c->ev_bwd, &c->ev_sums, &c->ev_norms};
   for (hipEvent_t* e : evs) {
     if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
   }
@@ -112,7 +112,7 @@ extern "C" void nesvor_step_destroy(void* handle) {
   if (handle == nullptr) return;
   StepCtx* c = static_cast<StepCtx*>(handle);
   (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_pose); (void)hipEventDestroy(c->ev_agg); (void)hipEventDestroy(c->ev_owner);
-  (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_sums);
+  (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_sums); (void)hipEventDestroy(c->ev_norms);
   delete c;
 }
 
@@ -137,6 +137,18 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   // max |dpe|, raised by the density network's backward and read by the hash-grid backward (which then skips its own pass
   // over dpe); zero-filled with the accumulators.  With a bias field dpe is a sum of two networks' gradients: no bound.
   float* dpe_bound = d.has_b ? nullptr : d.small + 26 * n;
+  // Operand bounds and weight norms of the three networks (nesvor_mlp_t.prep, split-operand mode): 3 x NESVOR_MLP_PREP_FLOATS floats
+  // behind the accumulators, zero-filled with them by the prologue.  Nobody passes over an operand to find its bound: the
+  // producing kernels publish them - the hash-grid forward max |pe|, the density network max |z|, the loss kernel max |d z_0|,
+  // max |d log_var|, max |d log_bias|, sigma_net's backward max |d z_1..| - and one launch per network takes the weight norms on
+  // the side stream, under the sampler and the hash-grid forward.
+  float* prep_d = d.small + 26 * n + 1;
+  float* prep_s = prep_d + NESVOR_MLP_PREP_FLOATS;
+  float* prep_b = prep_s + NESVOR_MLP_PREP_FLOATS;
+  nesvor_mlp_t net_d = d.density, net_s = d.sigma, net_b = d.bias_net;
+  net_d.prep = prep_d; net_s.prep = prep_s; net_b.prep = prep_b;
+  net_d.y_absmax = d.has_lv ? prep_s + NESVOR_MLP_PREP_XB : nullptr;  // z rows 1.. are sigma_net's matrix input
+  const bool split_d = net_d.bf16_operands == 2, split_s = d.has_lv && net_s.bf16_operands == 2, split_b = d.has_b && net_b.bf16_operands == 2;
   const int layout = NESVOR_LAYOUT_FEATURE_MAJOR;
   const bool overlap_owner = (d.overlap_owner & 1) != 0;
   // AdamW on the table inside the owner pass (single call covers gradient and update, nothing to exchange in between);
@@ -146,28 +158,48 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
                           d.g_table == d.flat_grad + table_off && table_off >= 0 && table_off < d.flat_numel;
 
   if (phase != 2) {
-    // pose regulariser: a serial chain per slice, independent of the batch -> side stream, joined at the epilogue
-    if (d.opt_T) {
-      if (hipEventRecord(ctx->ev_fork, main) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_fork, 0) != hipSuccess) return (int)hipGetLastError();
-      NESVOR_TRY(nesvor_trans_loss(d.axisangle, d.axisangle_init, d.trans_terms, d.g_trans, n, side));
-      if (hipEventRecord(ctx->ev_pose, side) != hipSuccess) return (int)hipGetLastError();
-    }
     // ---- forward
-    NESVOR_TRY(nesvor_step_prologue(d.has_c ? d.logit_coef : nullptr, c, d.axisangle, mat, acc, 13 * n + 1, n, main));
+    NESVOR_TRY(nesvor_step_prologue(d.has_c ? d.logit_coef : nullptr, c, d.axisangle, mat, acc, 13 * n + 1 + 3 * NESVOR_MLP_PREP_FLOATS, n, main));
+    // side stream, behind the prologue's zero-fill: the networks' weight norms and the slice embedding's bound (functions of the
+    // parameters alone), then the pose regulariser (a serial chain per slice, independent of the batch; joined at the epilogue)
+    const bool any_split = split_d || split_s || split_b;
+    if (d.opt_T || any_split) {
+      if (hipEventRecord(ctx->ev_fork, main) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_fork, 0) != hipSuccess) return (int)hipGetLastError();
+      if (any_split) {
+        const nesvor_mlp_t* nets[3]; float* preps[3]; int nn = 0;
+        if (split_d) { nets[nn] = &net_d; preps[nn++] = prep_d; }
+        if (split_s) { nets[nn] = &net_s; preps[nn++] = prep_s; }
+        if (split_b) { nets[nn] = &net_b; preps[nn++] = prep_b; }
+        // ONE launch: the weight norms of all networks and - the pixel features of sigma_net are rows of the slice embedding -
+        // the table's maximum as their bound
+        const bool se_bound = split_s && d.ks > 0;
+        NESVOR_TRY(nesvor_mlp_prepare_weights(nets, preps, nn, se_bound ? d.slice_embedding : nullptr, (int64_t)n * d.ks,
+                                              se_bound ? prep_s + NESVOR_MLP_PREP_XA : nullptr, side));
+        if (hipEventRecord(ctx->ev_norms, side) != hipSuccess) return (int)hipGetLastError();
+      }
+      if (d.opt_T) {
+        NESVOR_TRY(nesvor_trans_loss(d.axisangle, d.axisangle_init, d.trans_terms, d.g_trans, n, side));
+        if (hipEventRecord(ctx->ev_pose, side) != hipSuccess) return (int)hipGetLastError();
+      }
+    }
     NESVOR_TRY(nesvor_psf_transform_forward_rng_gather(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.x, d.u, B, S,
                                                        d.ks > 0 ? d.slice_embedding : nullptr, d.ks > 0 ? d.se : nullptr, d.ks, main));
     if (ctx->pending_join) {  // the previous run left its table update on the side stream
       if (hipStreamWaitEvent(main, ctx->ev_owner, 0) != hipSuccess) return (int)hipGetLastError();
       ctx->pending_join = false;
     }
-    NESVOR_TRY(nesvor_hashgrid_forward(&d.grid, d.u, d.table, d.pe, N, layout | (S >= 128 ? NESVOR_LAYOUT_CLUSTERED : 0), main));
-    NESVOR_TRY(nesvor_mlp_forward(&d.density, nullptr, d.pe, d.z, d.saved_d, N, main));
+    NESVOR_TRY(nesvor_hashgrid_forward_bounded(&d.grid, d.u, d.table, d.pe, N, layout | (S >= 128 ? NESVOR_LAYOUT_CLUSTERED : 0),
+                                               split_d ? prep_d + NESVOR_MLP_PREP_XB : nullptr, main));
+    if (any_split && hipStreamWaitEvent(main, ctx->ev_norms, 0) != hipSuccess) return (int)hipGetLastError();
+    NESVOR_TRY(nesvor_mlp_forward(&net_d, nullptr, d.pe, d.z, d.saved_d, N, main));
     if (d.has_b) {
-      NESVOR_TRY(nesvor_mlp_forward(&d.bias_net, d.se, d.pe, d.log_bias, d.saved_b, N, main));
+      // (the bias field is off BASELINE's headline configuration: its input bounds by a pass of their own)
+      if (split_b) NESVOR_TRY(nesvor_mlp_prepare(&net_b, d.se, d.pe, nullptr, N, prep_b, NESVOR_MLP_WHAT_INPUT, main));
+      NESVOR_TRY(nesvor_mlp_forward(&net_b, d.se, d.pe, d.log_bias, d.saved_b, N, main));
       hipLaunchKernelGGL(mean_partial_kernel, dim3(256), dim3(256), 0, main, d.log_bias, N, d.mean_scratch);
       hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(256), 0, main, d.mean_scratch, 256, 1.f / (float)N, d.lb_mean);
     }
-    if (d.has_lv) NESVOR_TRY(nesvor_mlp_forward(&d.sigma, d.se, d.z, d.log_var, d.saved_s, N, main));
+    if (d.has_lv) NESVOR_TRY(nesvor_mlp_forward(&net_s, d.se, d.z, d.log_var, d.saved_s, N, main));
     // ---- losses: values and gradients in one launch
     const int z_rows = 1 + d.n_features_z, written = 1 + (d.has_lv ? d.n_features_z : 0);
     if (written < z_rows) {
@@ -182,6 +214,7 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
     la.dlog_bias = d.has_b ? d.dlb : nullptr; la.dx = d.opt_T ? d.dxl : nullptr;
     la.dc_pix = d.has_c ? d.pix : nullptr; la.dlvs_pix = d.has_lvs ? d.pix + B : nullptr;
     la.B = B; la.S = S; la.reg_type = d.reg_type; la.delta = d.delta;
+    la.dz0_absmax = prep_d + NESVOR_MLP_PREP_DY; la.dlog_var_absmax = prep_s + NESVOR_MLP_PREP_DY; la.dlog_bias_absmax = prep_b + NESVOR_MLP_PREP_DY;
     NESVOR_TRY(nesvor_imaging_loss(&la, main));
     // ---- backward through the networks
     const int group_sums = (N % 16 == 0 && S % 16 == 0 && d.ks % 16 == 0) ? 1 : 0;
@@ -193,13 +226,13 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
     float* part_d = d.partial;
     float* part_s = d.partial + (size_t)NESVOR_STEP_MLP_PARTIALS * widest;
     float* part_b = d.partial + 2 * (size_t)NESVOR_STEP_MLP_PARTIALS * widest;
-    if (d.has_lv)
-      NESVOR_TRY(mlp_backward_into(d.sigma, group_sums, d.se, d.z, d.dlv, d.saved_s, d.ks ? d.dxa : nullptr, d.dz + N, part_s,
-                                   d.g_sigma, d.n_sigma_params, N, main));
-    NESVOR_TRY(mlp_backward_into(d.density, 0, nullptr, d.pe, d.dz, d.saved_d, nullptr, d.dpe, part_d, d.g_density,
+    if (d.has_lv)  // (its input gradient = rows 1.. of dz: raises the density network's upstream bound next to the loss kernel's row 0)
+      NESVOR_TRY(mlp_backward_into(net_s, group_sums, d.se, d.z, d.dlv, d.saved_s, d.ks ? d.dxa : nullptr, d.dz + N, part_s,
+                                   d.g_sigma, d.n_sigma_params, N, main, prep_d + NESVOR_MLP_PREP_DY));  // (a scalar publish: slot 0)
+    NESVOR_TRY(mlp_backward_into(net_d, 0, nullptr, d.pe, d.dz, d.saved_d, nullptr, d.dpe, part_d, d.g_density,
                                  d.n_density_params, N, main, dpe_bound));
     if (d.has_b) {
-      NESVOR_TRY(mlp_backward_into(d.bias_net, group_sums, d.se, d.pe, d.dlb, d.saved_b, d.ks ? d.dxa_b : nullptr, d.dpe_b, part_b,
+      NESVOR_TRY(mlp_backward_into(net_b, group_sums, d.se, d.pe, d.dlb, d.saved_b, d.ks ? d.dxa_b : nullptr, d.dpe_b, part_b,
                                    d.g_bias_net, d.n_bias_params, N, main));
       const int64_t nb = (int64_t)d.kb_bias * N;
       hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((nb / 4 + 255) / 256 + 1)), dim3(256), 0, main, d.dpe, d.dpe_b, nb);

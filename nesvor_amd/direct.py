@@ -233,7 +233,7 @@ class DirectStep:
         d.gw = self.gw.data_ptr()
         d.flat_param, d.flat_grad, d.flat_exp_avg, d.flat_exp_avg_sq = (t.data_ptr() for t in (f.param, f.grad, f.exp_avg, f.exp_avg_sq))
         d.flat_numel = f.numel
-        d.small = new("small", n * 26 + 1)
+        d.small = new("small", n * 26 + 1 + 3 * mlp_mod.PREP_FLOATS)  # ... | max |dpe| | the networks' operand bounds and weight norms
         d.x, d.u, d.pe, d.z, d.dz, d.dpe = new("x", B, S, 3), new("u", N, 3), new("pe", E, N), new("z", zr, N), new("dz", zr, N), new("dpe", E, N)
         d.loss_pix, d.pix = new("loss_pix", B, 3), new("pix", 2, B)
         d.partial = new("partial", 3 * 256, largest)  # per-workgroup partial parameter gradients: one third per network

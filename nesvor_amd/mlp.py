@@ -21,9 +21,10 @@ FUSED_BACKWARD = True  # False: separate dX and dW kernels (kept as cross-check 
 # How an fp32 matrix product is evaluated (nesvor_mlp_t.bf16_operands):
 #   MFMA_FP32 (0): v_mfma_f32_16x16x4_f32 - an fp32 FMA chain;
 #   BF16 (1): operands rounded to bf16 - mixed precision, opt-in (args.mlp_bf16) / the half-precision model structure;
-#   SPLIT (2): every fp32 operand written as the exact sum of three bf16 numbers, six bf16 MFMAs per product, fp32
-#     accumulation: the accuracy of the fp32 FMA chain (tools/bench_mlp_split.py: max error against fp64 2.4e-7 vs
-#     3.3e-7) at 1.25-1.6x the speed, because the fp32 matrix pipe of gfx950 is 16x slower than the bf16 one.
+#   SPLIT (2): every fp32 operand written as two fp16 numbers of a scaled copy (x s = hi + lo, s a power of two per operand
+#     tensor and launch from the bounds in ``prep``), three fp16 MFMAs per product, fp32 accumulation: error against fp64 at
+#     or below the fp32 FMA chain's (profiles/r05_f16_split_probe.log: 2.1e-7 vs 3.6e-7 of the largest result), because the
+#     fp32 matrix pipe of gfx950 is 16x slower than the 16-bit one.  (Rounds 2-4: three bf16 terms per operand, six MFMAs.)
 # SPLIT is what "fp32" means by default; NESVOR_MLP_FP32=mfma (or FP32_OPERANDS = MFMA_FP32) selects the plain path.
 MFMA_FP32, BF16, SPLIT = 0, 1, 2
 FP32_OPERANDS = MFMA_FP32 if os.environ.get("NESVOR_MLP_FP32", "split").lower() == "mfma" else SPLIT
@@ -178,14 +179,35 @@ class NetParams:
                 off += p.numel()
 
 
-def _desc(weights, biases, k_a, k_b, b_row0, S, bf16=False):
+ABSMAX_FLOATS = 16 * 64  # NESVOR_ABSMAX_FLOATS: an operand bound is the maximum over 16 slots, one 256-byte line apart
+PREP_FLOATS = 3 * ABSMAX_FLOATS + 4 * 4  # NESVOR_MLP_PREP_FLOATS
+PREP_INPUT, PREP_DY, PREP_WEIGHTS = 1, 2, 4  # `what` of nesvor_mlp_prepare
+
+
+def _desc(weights, biases, k_a, k_b, b_row0, S, bf16=False, prep=None):
     d = _lib.MlpT()
     d.bf16_operands = operand_mode(bf16)
     d.width, d.n_hidden, d.out_dim = 64, len(weights) - 1, weights[-1].shape[0]
     d.k_a, d.k_b, d.b_row0, d.samples_per_pixel = k_a, k_b, b_row0, S
     for i, (w, b) in enumerate(zip(weights, biases)):
         d.weight[i], d.bias[i] = w.data_ptr(), b.data_ptr()
+    if prep is not None:
+        d.prep = prep.data_ptr()
     return d
+
+
+def prepare(d, xa, xb, dy, N, what, prep=None):
+    """The split mode's operand bounds and weight norms (``nesvor_mlp_t.prep``) by ``nesvor_mlp_prepare``: a reduction over the
+    operands named by ``what``.  The training step does not come here - its producing kernels publish the bounds
+    (nesvor_amd/direct.py) - this is for standalone calls of the op."""
+    if prep is None:
+        prep = torch.zeros(PREP_FLOATS, dtype=torch.float32, device=xb.device)
+    with torch.cuda.device(xb.device):
+        err = _lib.load().nesvor_mlp_prepare(ctypes.byref(d), _lib.ptr(xa), _lib.ptr(xb), _lib.ptr(dy), N, _lib.ptr(prep), what,
+                                             _lib.stream_ptr())
+    _lib.check(err, "mlp prepare")
+    d.prep = prep.data_ptr()
+    return prep
 
 
 def compact_save(d, N: int) -> bool:
@@ -220,10 +242,12 @@ def _ptr_array(tensors):
     return arr
 
 
-def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False):
+def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False, prep=None, y_absmax=None):
     """One forward launch, no autograd: -> (y (out_dim, N), saved hidden activations [] when not need_saved).
-    bf16: False = fp32 (FP32_OPERANDS picks split-bf16 or fp32-MFMA evaluation of the products), True = matrix operands
-    rounded to bf16 with fp32 accumulation (opt-in mixed precision); an int selects a mode constant directly."""
+    bf16: False = fp32 (FP32_OPERANDS picks split-fp16 or fp32-MFMA evaluation of the products), True = matrix operands
+    rounded to bf16 with fp32 accumulation (opt-in mixed precision); an int selects a mode constant directly.
+    prep: the split mode's bounds (``nesvor_mlp_t.prep``; None: computed here by a pass over the inputs and the weights);
+    y_absmax: zero-filled tensor of ABSMAX_FLOATS floats whose maximum is raised to max |y|."""
     _lib.require_device(xb, *weights, *biases, dtype=torch.float32, name="fused MLP input/params")
     N = xb.shape[1]
     k_a = 0 if xa is None else xa.shape[1]
@@ -233,7 +257,11 @@ def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False)
             raise RuntimeError("pixel features: P * samples_per_pixel must equal N")
     if weights[0].shape[1] != k_a + k_b:
         raise RuntimeError("first layer width does not match k_a + k_b")
-    d = _desc(weights, biases, k_a, k_b, b_row0, S, bf16)
+    d = _desc(weights, biases, k_a, k_b, b_row0, S, bf16, prep)
+    if d.bf16_operands == SPLIT and prep is None:
+        prep = prepare(d, xa, xb, None, N, PREP_INPUT | PREP_WEIGHTS)
+    if y_absmax is not None:
+        d.y_absmax = y_absmax.data_ptr()
     # saved hidden activations, MFMA fragment layout; bf16 mode stores them as bf16 (they are only used as bf16 operands);
     # compact save (split-operand mode, whole tiles): saved[0] holds sign bits only
     sdt = torch.bfloat16 if operand_mode(bf16) == BF16 else torch.float32
@@ -251,7 +279,7 @@ def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False)
     return y, saved
 
 
-def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_dxa, bf16=False, dxb_absmax=None):
+def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_dxa, bf16=False, dxb_absmax=None, prep=None):
     """One backward pass, no autograd.  dxb: (k_b, N) contiguous tensor the input gradient is written to (or
     None); -> (dxa (N, k_a) per-sample or (N/16, k_a) per 16-sample group | None - sum it over each pixel's rows -,
     partial (n_partial, n_params) to be summed over dim 0).  dxb_absmax: zero-filled 1-element tensor raised to max |dxb|
@@ -259,7 +287,9 @@ def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_d
     n_layers = len(weights)
     N = xb.shape[1]
     k_a = 0 if xa is None else xa.shape[1]
-    d = _desc(weights, biases, k_a, k_b, b_row0, S, bf16)
+    d = _desc(weights, biases, k_a, k_b, b_row0, S, bf16, prep)
+    if d.bf16_operands == SPLIT and prep is None:  # (the same input bounds and weight norms as the forward's: same data)
+        prep = prepare(d, xa, xb, dy, N, PREP_INPUT | PREP_DY | PREP_WEIGHTS)
     d.compact_save = int(saved[0].numel() == (N + 15) // 16 * 16 * 4)  # (the forward that wrote `saved` decided)
     dev = xb.device
     fused = (n_layers - 1) <= 2 and FUSED_BACKWARD

