@@ -251,6 +251,12 @@ def main():
     ap.add_argument("--small-batches", default="2048,1024,512",
                     help="pixel batch sizes of the small_batch block (strong-scaling regime on one GPU); empty string: skip")
     ap.add_argument("--no-strict", action="store_true", help="skip the second pass with the MLP products on fp32 MFMAs (kernel timelines)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="how often the timed region of --steps steps is repeated (the median region is reported; every region is in "
+                         "`timed_regions_ms_per_step`); 0 = automatic: 5 when --steps < 100 - a 20-step region is a 20 ms sample -, else 1")
+    ap.add_argument("--roctx-region", action="store_true",
+                    help="under `rocprofv3 --selected-regions`: resume the profiler behind the settle iterations and pause it after the timed "
+                         "region, so that the trace's kernel averages are those of settled launches (tools/collect_profiles_r05.sh)")
     opt = ap.parse_args()
     # stdout carries ONE line, the JSON result.  Libraries write there too (RCCL prints a version banner through C stdio, which
     # lands AFTER a flushed Python print when stdout is a pipe or a file): file descriptor 1 is pointed at stderr for the run and
@@ -345,18 +351,44 @@ def main():
     for _ in range(8):
         step()
         torch.cuda.synchronize(device)
-    # per-kernel HIP-event timing runs over its own K steps before the timed region (same process, data, kernels)
-    ktimes, bracket_ms = {}, 0.0
+    roctx = None
+    if opt.roctx_region:
+        import ctypes
+
+        roctx = ctypes.CDLL("librocprofiler-sdk-roctx.so")
+        roctx.roctxProfilerResume(ctypes.c_uint64(0))
+    # per-kernel HIP-event timing runs over its own K steps before the timed region (same process, data, kernels).  Round 5: the
+    # PRODUCT launches are timed - the one-call step brackets its own launches with events on the stream each goes to
+    # (nesvor_step_timing: the owner pass with its fused AdamW on the side stream); the Python-issued variant of rounds 1-4 (all
+    # launches on one stream, owner pass without the optimizer) remains for configurations the one-call step does not take
+    ktimes, bracket_ms, product_timing, k_spans = {}, 0.0, False, {}
     if not opt.no_kernel_timing:
         for _ in range(2):
             step()
-        _lib.kernel_timer.reset(enabled=True)
         k_steps = min(opt.steps, 50)
-        for _ in range(k_steps):
-            step()
-        torch.cuda.synchronize(device)
-        ktimes = _lib.kernel_timer.summary()
-        _lib.kernel_timer.reset(enabled=False)
+        direct = trainer.direct
+        if direct is not None and not parallel and direct.native_ready():
+            product_timing = True
+            direct.set_native_timing(True)
+            for _ in range(k_steps):
+                step()
+                for name, ms_ in direct.read_native_timing().items():
+                    k_spans.setdefault(name, []).append(ms_)
+            direct.set_native_timing(False)
+            for _ in range(2):  # (a step whose table update the next one joins late again)
+                step()
+            torch.cuda.synchronize(device)
+            mean = lambda name: sum(k_spans[name]) / len(k_spans[name]) if name in k_spans else 0.0
+            ktimes = {name: (k_steps, mean(name)) for name in k_spans}
+            ktimes["mlp_fwd"] = (k_steps, mean("mlp_fwd_density") + mean("mlp_fwd_sigma"))
+            ktimes["mlp_bwd"] = (k_steps, mean("mlp_bwd_density") + mean("mlp_bwd_sigma"))
+        else:
+            _lib.kernel_timer.reset(enabled=True)
+            for _ in range(k_steps):
+                step()
+            torch.cuda.synchronize(device)
+            ktimes = _lib.kernel_timer.summary()
+            _lib.kernel_timer.reset(enabled=False)
         # what an event bracket adds to the launch it brackets: the same two events around a one-element fill (a ~1.5 us kernel).
         # A kernel trace (rocprofv3, profiles/r04_bench_n1_kernel_stats.csv) times the kernel alone and reads 4-7 us less per
         # launch than these brackets - three launches make up the hash-grid roofline, so its event-based fraction sits ~0.03
@@ -371,7 +403,17 @@ def main():
         bracket_ms = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
     for _ in range(opt.warmup):
         step()
-    elapsed, losses = timed(opt.steps)
+    # the timed region: EXACTLY --steps steps between barrier + synchronize.  A short region (the driver's 20 steps = 20 ms) is a
+    # noisy sample of a GPU whose clock floats with its power draw: it is repeated and the MEDIAN region is the one reported
+    n_rep = opt.repeats if opt.repeats > 0 else (5 if opt.steps < 100 else 1)
+    regions = []
+    for _ in range(n_rep):
+        e_, losses = timed(opt.steps)
+        regions.append(e_)
+    elapsed = sorted(regions)[len(regions) // 2]
+    if roctx is not None:
+        torch.cuda.synchronize(device)
+        roctx.roctxProfilerPause(ctypes.c_uint64(0))
     final_loss = {k: float(val.detach()) for k, val in losses.items()}
 
     # the same K steps with the MLP products evaluated by fp32 MFMAs (the default evaluates the same fp32 products as
@@ -451,6 +493,7 @@ def main():
         }
         roof = None
         dominant = None
+        n_table = int(model.inr.encoding.spec.n_params)
         if ktimes:
             # per step: under torch.distributed the backward is split by levels into two aggregation + two owner launches
             # (the all-reduce of the first part overlaps the second), so sum the launches of one step
@@ -458,19 +501,27 @@ def main():
             kt = {k: per_step(k) for k in ktimes}
             kt["hashgrid_bwd"] = kt.get("hashgrid_bwd_aggregate", 0.0) + kt.get("hashgrid_bwd_owner", 0.0)
             # which native operation costs the step most (all spans compared, the two launches of an operation together)
-            ops_ms = {k: v for k, v in kt.items() if k not in ("hashgrid_bwd_aggregate", "hashgrid_bwd_owner")}
+            parts = ("hashgrid_bwd_aggregate", "hashgrid_bwd_owner", "mlp_fwd_density", "mlp_fwd_sigma", "mlp_bwd_density", "mlp_bwd_sigma")
+            ops_ms = {k: v for k, v in kt.items() if k not in parts}
             dominant = max(ops_ms, key=lambda k: ops_ms[k])
-            # the operation the north-star prices: hash-grid forward + backward as launched INSIDE the training step
-            # (PSF-cloud points, input gradient on: poses are optimised).  Three accountings, SURVEY 8d's first:
-            t_f, t_b = kt.get("hashgrid_fwd", 0.0), kt["hashgrid_bwd"]
+            # The operation the north-star prices: hash-grid forward + backward as launched INSIDE the training step (PSF-cloud
+            # points, input gradient on: poses are optimised).  Bytes: SURVEY 8d's 2328 B/point; the owner launch of the product
+            # step also takes the table's AdamW step (SURVEY 8d "other per-iter algorithmic traffic": 28 B per table parameter),
+            # so both accountings of THOSE launches are first-class fields.
+            t_f, t_agg, t_own = kt.get("hashgrid_fwd", 0.0), kt.get("hashgrid_bwd_aggregate", 0.0), kt.get("hashgrid_bwd_owner", 0.0)
+            t_b = t_agg + t_own
             fwd_B, bwd_B, bwd_in_B = (12 + 32 * F * L + 4 * F * L), (12 + 4 * F * L + 32 * F * L), (32 * F * L + 12)
-            gbps = lambda nbytes, ms: nbytes * n_points / (ms * 1e-3) / 1e9 if ms > 0 else None
-            strict_bw = gbps(fwd_B + bwd_B, t_f + t_b)
+            adamw_bytes = 28 * n_table if product_timing else 0  # (the Python-issued owner pass carries no optimizer)
+            frac_of = lambda nbytes, ms: (nbytes / (ms * 1e-3) / 1e9 / 8000.0) if ms > 0 else None
+            bytes_8d = (fwd_B + bwd_B) * n_points
+            strict_frac = frac_of(bytes_8d, t_f + t_b)
+            with_adamw = frac_of(bytes_8d + adamw_bytes, t_f + t_b)
+            brk = max(bracket_ms - 0.0015, 0.0)
             traffic, traffic_src = None, None
             # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE per the microarch
             # guide); they cannot be collected inside this process, so the number carries the file and commit it was
             # measured at and is dropped when this run's launch shape differs
-            for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+            for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", fn)) as fh:
                         tj = json.load(fh)
@@ -480,119 +531,140 @@ def main():
                     traffic = tj["hashgrid_bwd"].get("traffic_bytes", 0) + tj.get("hashgrid_fwd", {}).get("traffic_bytes", 0)
                     traffic_src = f"profiles/{fn} (hashgrid_fwd + hashgrid_bwd launches, kernels at commit {tj.get('commit')})"
                 break
+            # what actually bounds the backward (PMC traffic is ~0.55x the algorithmic bytes: not HBM): issue rates measured by the
+            # probes under tools/ on this architecture - conflict-free ds_add_u64 6.4 cycles per wave instruction
+            # (tools/lds_atomic_probe*.hip), 16 inserts of F = 2 words per wave and level; the merge-table's measured conflict
+            # rate (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.41, profiles/r04_pmc_sq_hashgrid_aggregate_summary.txt) on top
+            props = torch.cuda.get_device_properties(device)
+            n_cu = props.multi_processor_count
+            clock_hz_ = float(getattr(props, "clock_rate", 2.4e6)) * 1e3
+            waves = n_points / 64.0
+            lds_atomic_floor_ms = waves * L * 16 * 6.4 / n_cu / clock_hz_ * 1e3
             roof = {
                 "bound": "hbm",
                 "kernel": "hashgrid_fwd + hashgrid_bwd (aggregate + owner launches) inside the training step, PSF-cloud points, input gradient on",
-                "achieved": strict_bw, "peak": 8000.0, "unit": "GB/s", "frac": None if strict_bw is None else strict_bw / 8000.0,
-                "definition": "SURVEY 8d: forward + parameter-gradient bytes (12+72L)+(12+72L) = 2328 B/point at L=16, divided by the time "
-                              "of ALL hash-grid launches of the step (the backward also produces the input gradient)",
+                "achieved": None if strict_frac is None else (with_adamw if product_timing else strict_frac) * 8000.0,
+                "peak": 8000.0, "unit": "GB/s",
+                "frac": with_adamw if product_timing else strict_frac,
+                "definition": ("algorithmic bytes of the three launches timed, over their time: SURVEY 8d's forward + parameter-gradient bytes "
+                               "(12+72L)+(12+72L) = 2328 B/point at L=16" + (", plus the 28 B per table parameter of the AdamW step that the "
+                               "PRODUCT owner launch takes while a chunk's gradient sits in LDS (nesvor_hashgrid_backward_adamw; SURVEY 8d "
+                               "'other per-iter algorithmic traffic')" if product_timing else "") + "; the backward also produces the "
+                               "input gradient (1036 B/point, not counted).  frac_8d_bytes_only prices the same time with the 2328 B/point alone"),
+                "frac_8d_bytes_only": strict_frac,
+                "frac_with_adamw_bytes": with_adamw if product_timing else None,
+                "frac_forward": frac_of(fwd_B * n_points, t_f),
+                "frac_backward": frac_of(bwd_B * n_points + adamw_bytes, t_b),
+                "frac_backward_8d_bytes_only": frac_of(bwd_B * n_points, t_b),
+                "frac_backward_aggregate_launch_alone": frac_of(bwd_B * n_points, t_agg),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "launch_ms": t_f + t_b, "forward_ms": t_f, "backward_ms": t_b,
-                "algorithmic_bytes_per_launch": (fwd_B + bwd_B) * n_points,
+                "launch_ms": t_f + t_b, "forward_ms": t_f, "backward_ms": t_b, "backward_aggregate_ms": t_agg, "backward_owner_ms": t_own,
+                "algorithmic_bytes_per_launch": bytes_8d + adamw_bytes, "algorithmic_bytes_8d": bytes_8d, "adamw_bytes_in_owner_launch": adamw_bytes,
                 "accountings": {
-                    "strict_8d_bytes_over_all_time": None if strict_bw is None else strict_bw / 8000.0,
-                    "all_bytes_incl_input_grad_over_all_time": gbps(fwd_B + bwd_B + bwd_in_B, t_f + t_b) / 8000.0,
-                    "backward_only_incl_input_grad": gbps(bwd_B + bwd_in_B, t_b) / 8000.0,  # rounds 1-2 reported this one as frac
-                    "forward_only": (gbps(fwd_B, t_f) / 8000.0) if t_f > 0 else None,
+                    "all_bytes_incl_input_grad_over_all_time": frac_of((fwd_B + bwd_B + bwd_in_B) * n_points + adamw_bytes, t_f + t_b),
+                    "frac_8d_minus_brackets": None if strict_frac is None else frac_of(bytes_8d, max(t_f + t_b - 3 * brk, 1e-6)),
+                    "frac_with_adamw_minus_brackets": None if with_adamw is None else frac_of(bytes_8d + adamw_bytes, max(t_f + t_b - 3 * brk, 1e-6)),
                 },
-                "timing": f"HIP events on the launch stream over {k_steps} steps of this run, before the timed region",
+                "secondary_bounds": {
+                    "note": "HBM is not what bounds the backward: its PMC traffic is ~0.55x the algorithmic bytes (the table is cache-resident, "
+                            "the scatter is aggregated on chip).  The aggregation launch is a per-level latency chain at 4 waves per SIMD "
+                            "(SQ_WAIT_ANY 49 %, profiles/r04_pmc_sq_hashgrid_aggregate_summary.txt); the issue-rate floors below are what "
+                            "the same work costs the LDS pipe alone",
+                    "lds_atomic_issue_floor_ms": lds_atomic_floor_ms,
+                    "lds_atomic_issue_floor_with_measured_conflicts_ms": lds_atomic_floor_ms * 1.41,
+                    "source": "ds_add_u64: 6.4 cycles per conflict-free wave instruction (tools/lds_atomic_probe*.hip); 16 inserts x L levels "
+                              "per wave; conflicts 0.41 of LDS-active cycles (SQ counters)",
+                },
+                "timing": (f"HIP events around the PRODUCT launches of the one-call step (csrc/step.hip: nesvor_step_timing), each pair on the "
+                           f"stream its launch goes to - the owner pass with the table's fused AdamW on the side stream -, {k_steps} steps of "
+                           f"this run before the timed region" if product_timing else
+                           f"HIP events on the launch stream over {k_steps} steps of this run (Python-issued launches: one stream, owner pass "
+                           f"without the optimizer), before the timed region"),
                 "event_bracket_ms_around_a_one_element_fill": bracket_ms,
-                "frac_if_each_of_the_three_brackets_cost_that_much": None if strict_bw is None else
-                    (fwd_B + bwd_B) * n_points / (max(t_f + t_b - 3 * max(bracket_ms - 0.0015, 0.0), 1e-6) * 1e-3) / 1e9 / 8000.0,
-                "timing_path": "the same kernels on the same data as the timed region, issued from Python (nesvor_amd/direct.py::run) so that "
-                               "every launch can be bracketed by events: all launches on ONE stream, and the owner pass WITHOUT the hash "
-                               "table's AdamW step (the 2328 B/point do not contain optimizer bytes).  The timed region runs the one-call "
-                               "step (csrc/step.hip): owner pass + table AdamW in one launch on the side stream - per-kernel durations of "
-                               "that step: profiles/r04_step_timeline.txt; medians of both owner variants: "
-                               "profiles/r04_bench_n1_kernel_stats.csv, whose last lines recompute this fraction from the trace alone",
                 "copy_peak_GBps": extras["copy_peak_GBps"], "fill_peak_GBps": extras["fill_peak_GBps"],
                 "dominant_operation_of_the_step": {"name": dominant, "ms_per_step": ops_ms[dominant],
-                                                   "note": "largest per-step time among the timed native operations; roofline_mlp prices the MLP backward"},
+                                                   "note": "largest per-step time among the timed native operations; roofline_mlp prices the MLP launches"},
                 "kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(kt.items())},
+                "kernels_ms_median": {k: round(sorted(v)[len(v) // 2], 4) for k, v in sorted(k_spans.items())} if k_spans else None,
             }
         roof_mlp = None
         if ktimes and "mlp_bwd" in ktimes and not args.n_levels_bias and not args.no_pixel_variance:
-            # second-largest consumer: the two fused MLP backward launches (dX chain + dW + db).  Two matrix pipes are in
-            # play, so one flops / peak ratio fits neither: the busy fraction of each pipe is stated instead, from the
-            # kernels' MFMA counts per 16-sample group (block products of the layer shapes), the issue cost of each MFMA
-            # (v_mfma_f32_16x16x4_f32: 32 cycles, v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16: 16; tools/mfma_valu_overlap.hip
-            # and the SQ_VALU_MFMA_BUSY_CYCLES counters under profiles/) and the device's engine clock
+            # The four MLP launches (density_net / sigma_net forward, wave-specialised backward: dX chain + dW + db).  Round 5: the
+            # fp32 products are two-way fp16 splits (three fp16 MFMAs per product; rounds 2-4: six bf16 MFMAs) and the compact save
+            # keeps gate bits only (the backward recomputes both hidden layers).  MFMA counts per 16-sample group follow from the
+            # layer shapes: a product of OB x KB 16-blocks costs 3 MFMAs per (output block, PAIR of k-blocks) in the chains -
+            # 16x16x32 shape, two k-blocks per instruction - and 2 per block product in the dW waves (two terms per instruction).
             nz, ns, W = args.n_features_z, args.n_features_slice, args.width
-            blocks = lambda dims: sum(-(-o // 16) * -(-i // 16) for i, o in zip(dims[:-1], dims[1:]))
-            dens = [L * F] + [W] * opt.depth + [1 + nz]
-            sig = [ns + nz] + [W] * opt.depth + [1]
-            bp = blocks(dens) + blocks(sig)              # 16x16x16 block products of one forward of both networks
-            groups = n_points / 16
+            HB = W // 16
+            kb_d, kb_s = -(-(L * F) // 16), -(-(ns + nz) // 16)
+            pairs = lambda kb: (kb + 1) // 2
             props = torch.cuda.get_device_properties(device)
             clock_hz = float(getattr(props, "clock_rate", 2.4e6)) * 1e3  # kHz; MI355X maximum engine clock 2400 MHz (MI355X_MICROARCH.md)
             n_simd = props.multi_processor_count * 4
+            groups = n_points / 16
+            split = not (opt.mlp_bf16 or opt.half_precision_model or opt.mlp_fp32_mfma)
+            compact = split and os.environ.get("NESVOR_MLP_COMPACT", "1") != "0" and opt.depth == 2
+            out1 = os.environ.get("NESVOR_MLP_OUT1", "1") != "0"
+            def fwd_mfma(kb1, out_rows_on_mfma):
+                return 3 * (HB * pairs(kb1) + (opt.depth - 1) * HB * pairs(HB) + (pairs(HB) if out_rows_on_mfma else 0))
+            def bwd_mfma(kb1, out_rows_on_mfma):
+                chain = 3 * ((HB if out_rows_on_mfma else 0) + (opt.depth - 1) * HB * pairs(HB) + kb1 * pairs(HB))
+                dw = 2 * (HB * kb1 + (opt.depth - 1) * HB * HB + (HB if out_rows_on_mfma else 0))
+                recompute = 3 * (HB * pairs(kb1) + (opt.depth - 1) * HB * pairs(HB)) if compact else 0
+                return chain + dw + recompute
+            mf = {"fwd_density": fwd_mfma(kb_d, True), "fwd_sigma": fwd_mfma(kb_s, not out1),
+                  "bwd_density": bwd_mfma(kb_d, True), "bwd_sigma": bwd_mfma(kb_s, not out1)} if split else None
             ms2 = ktimes["mlp_bwd"][0] * ktimes["mlp_bwd"][1] / k_steps
-            bf16_ops = opt.mlp_bf16 or opt.half_precision_model
-            if bf16_ops:      # dX chain and dW on the bf16 pipe: one 16-k MFMA per block product and role
-                fp32_mfma, bf16_mfma = 0, 2 * bp
-            elif opt.mlp_fp32_mfma:  # four 4-k fp32 MFMAs per block product and role
-                fp32_mfma, bf16_mfma = 8 * bp, 0
-            else:             # default (split): three 32-k bf16 MFMAs per block product for dW (two split terms per instruction) and
-                              # per block product of the dX chain (six per pair), six 16-k ones for the chain's unpaired output-layer blocks
-                fp32_mfma, bf16_mfma = 0, 6 * bp + 2 * 3 * (W // 16)
-            busy = lambda n, cyc: n * cyc * groups / n_simd / (ms2 * 1e-3 * clock_hz)
-            fl = 2 * n_points * sum(i * o for d in (dens, sig) for i, o in zip(d[:-1], d[1:]))  # one forward of both nets
-            # Round 3 (DESIGN.md "What round 3 measured about the MLP kernels"): with the compact save (sign bits of the hidden layers
-            # + the values of the second one; the first is recomputed in the backward) the four MLP launches of a step stream
-            # 1788 B per point instead of 2748 and are bound by instruction issue: bf16 MFMAs (16 cycles) and VALU instructions
-            # (4 cycles) do not overlap on a gfx950 SIMD (tools/mfma_bf16_overlap.hip).  Algorithmic bytes per point:
-            #   forward  = input rows + saved (256 B second hidden layer + 16 B sign bits) + output rows
-            #   backward = saved + input rows + dY + dX
-            in_d, in_s = 4 * L * F, 4 * nz          # bytes of a point's network input that streams from HBM (the slice embedding is per pixel)
-            compact = not (bf16_ops or opt.mlp_fp32_mfma) and os.environ.get("NESVOR_MLP_COMPACT", "1") != "0" and opt.depth == 2
-            saved_pt = (256 + 16) if compact else 512
+            ms1 = ktimes["mlp_fwd"][0] * ktimes["mlp_fwd"][1] / k_steps if "mlp_fwd" in ktimes else 0.0
+            ms_all = ms1 + ms2
+            # algorithmic bytes per point: forward = input rows + saved state + output rows; backward = saved state + input rows +
+            # dY + dX (compact save: 16 B of gate bits per point and network; full save: 256 B per hidden layer)
+            in_d, in_s = 4 * L * F, 4 * nz          # a point's network input that streams from HBM (the slice embedding is per pixel)
+            saved_pt = 16 if compact else 256 * opt.depth
             mlp_bytes_pt = (in_d + saved_pt + 4 * (1 + nz)) + (in_s + saved_pt + 4) + (saved_pt + in_d + 4 * (1 + nz) + in_d) + (saved_pt + in_s + 4 + in_s)
-            ms_all = ms2 + (ktimes["mlp_fwd"][0] * ktimes["mlp_fwd"][1] / k_steps if "mlp_fwd" in ktimes else 0.0)
             mlp_gbps = mlp_bytes_pt * n_points / (ms_all * 1e-3) / 1e9
             traffic_mlp = None
-            try:
-                with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_mlp.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_traffic_mlp.json")) else "r03_pmc_traffic_mlp.json")) as fh:
-                    traffic_mlp = json.load(fh)
-            except OSError:
-                pass
-            # instructions per 16-sample group (SQ counters of the density-network launches, profiles/r03_pmc_sq_mlp_summary.txt:
-            # SQ_INSTS_MFMA and SQ_INSTS_VALU - which includes the MFMAs - over 65536 groups): forward 84 MFMA + 346 other VALU (round 3),
-            # backward 204 MFMA (chain wave 96, dW wave 108 of which 24 recompute the first hidden layer) + 792 other VALU
-            # sigma_net (one output row: its output layer runs on the VALU, csrc/mlp.hip OUT1): 12 / 36 MFMAs and 37 / 112 VALU
-            # instructions fewer per group (forward / backward; counted in the ISA of the two instantiations)
-            out1 = os.environ.get("NESVOR_MLP_OUT1", "1") != "0"
-            # round 4 (profiles/r04_pmc_sq_mlp_summary.txt): the forward's address arithmetic was hoisted out of its tile loop and the
-            # gate bits come from one v_alignbit per value: 84 MFMA + 258 other VALU per group (round 3: 346); backward unchanged
-            sig_f, sig_b = ((72, 221), (168, 680)) if out1 else ((84, 258), (204, 792))
-            issue_cycles = ((84 * 16 + 258 * 4) + (204 * 16 + 792 * 4) + (sig_f[0] * 16 + sig_f[1] * 4) + (sig_b[0] * 16 + sig_b[1] * 4)) * groups / n_simd if compact else None
-            roof_mlp = {"bound": "instruction issue (bf16 MFMA + VALU, not overlapped)" if compact else "hbm",
+            for fn in ("r05_pmc_traffic_mlp.json", "r04_pmc_traffic_mlp.json"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", fn)) as fh:
+                        traffic_mlp = json.load(fh)
+                        traffic_mlp["source"] = f"profiles/{fn}"
+                    break
+                except OSError:
+                    pass
+            busy = lambda n_mfma, ms: n_mfma * 16 * groups / n_simd / (ms * 1e-3 * clock_hz) if ms > 0 else None
+            fl = 2 * n_points * sum(i * o for dims in ([L * F] + [W] * opt.depth + [1 + nz], [ns + nz] + [W] * opt.depth + [1])
+                                    for i, o in zip(dims[:-1], dims[1:]))  # one forward of both nets
+            roof_mlp = {"bound": "hbm",
                         "kernel": "mlp_fwd_pf x 2 + mlp_bwd_ws x 2 (density_net, sigma_net): the four MLP launches of a step",
                         "achieved": mlp_gbps, "peak": 8000.0, "unit": "GB/s", "frac": mlp_gbps / 8000.0,
                         "frac_of_copy_peak": None if not extras["copy_peak_GBps"] else mlp_gbps / extras["copy_peak_GBps"],
-                        "launch_ms": ms_all, "backward_ms": ms2, "algorithmic_bytes_per_point": mlp_bytes_pt,
+                        "launch_ms": ms_all, "forward_ms": ms1, "backward_ms": ms2, "algorithmic_bytes_per_point": mlp_bytes_pt,
                         "algorithmic_bytes_per_step": mlp_bytes_pt * n_points, "compact_save": compact,
                         "traffic": traffic_mlp,
-                        "issue_floor_ms": None if issue_cycles is None else issue_cycles / clock_hz * 1e3,
-                        "issue_frac": None if issue_cycles is None else issue_cycles / clock_hz * 1e3 / ms_all,
-                        "fp32_pipe_busy_frac": busy(fp32_mfma, 32), "bf16_pipe_busy_frac": busy(bf16_mfma + (24 if compact else 0), 16),
-                        "matrix_pipe_busy_frac_backward": busy(fp32_mfma, 32) + busy(bf16_mfma + (24 if compact else 0), 16),
-                        "mfma_per_16_sample_group_backward": {"fp32_16x16x4": fp32_mfma, "bf16": bf16_mfma + (24 if compact else 0)},
-                        "engine_clock_MHz": clock_hz / 1e6, "fp32_equivalent_TFLOPs_backward": 2 * fl / (ms2 * 1e-3) / 1e12,
-                        "note": "HBM view: algorithmic bytes of the four launches / their time (the saved activations were 74 % of the bytes "
-                                "before the compact save; now the launches move 2.3 GB per step, PMC, and HBM is no longer what bounds them). "
-                                "Issue view: issue_frac = (16 cycles per bf16 MFMA + 4 per VALU instruction, per SIMD, at the maximum engine "
-                                "clock) / measured time - the two instruction classes do not overlap on gfx950 "
-                                "(tools/mfma_bf16_overlap.hip), the rest is dependency and LDS latency at two waves per SIMD; SQ counters in "
-                                "profiles/r04_pmc_sq_mlp_summary.txt; the engine clock under this load floats at 2.30-2.39 GHz (profiles/r04_power_probe.log)"}
+                        "mfma_per_16_sample_group": mf,
+                        "matrix_pipe_busy_frac_forward": busy(mf["fwd_density"] + mf["fwd_sigma"], ms1) if mf else None,
+                        "matrix_pipe_busy_frac_backward": busy(mf["bwd_density"] + mf["bwd_sigma"], ms2) if mf else None,
+                        "engine_clock_MHz": clock_hz / 1e6, "fp32_equivalent_TFLOPs": 3 * fl / (ms_all * 1e-3) / 1e12,
+                        "note": "HBM view: algorithmic bytes of the four launches over their time (with the bits-only save the launches "
+                                "stream inputs, outputs and 16 B of gate bits per point and network; rounds 3-4 also streamed one hidden "
+                                "layer's values, 536 MB written + 536 MB read per step).  Matrix-pipe view: 16 cycles per 16x16x32 fp16 MFMA "
+                                "at the maximum engine clock; MFMA and VALU issue do not overlap on a gfx950 SIMD "
+                                "(tools/mfma_bf16_overlap.hip), and the engine clock floats at 2.30-2.39 GHz under this step "
+                                "(profiles/r04_power_probe.log).  SQ instruction counters: profiles/r05_pmc_sq_mlp_summary.txt"}
         out = {
             "metric": "INR train iters/sec (2^20 samples, L=16 hash, 64-wide MLP)",
             "value": iters_per_s,
             "unit": "iters/s (2^20-sample iterations, whole job)",
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
             "ms_per_step": elapsed / opt.steps * 1e3,
+            "timed_regions": n_rep, "timed_regions_ms_per_step": [round(r / opt.steps * 1e3, 5) for r in regions],
+            "timed_region_note": "EXACTLY `steps` steps between barrier + synchronize, repeated `timed_regions` times; value and "
+                                 "ms_per_step are those of the MEDIAN region",
             "higher_is_better": True, "scaling": opt.scaling, "vs_baseline": None,
-            "dtype": (("f32" if opt.mlp_fp32_mfma else "f32 (MLP products evaluated on 3-way bf16 splits of the fp32 operands, fp32 accumulation: "
-                       "fp32-equivalent error; the all-fp32-MFMA rate of the same run is in strict_fp32_mfma)")
+            "dtype": (("f32" if opt.mlp_fp32_mfma else "f32 (MLP products evaluated on 2-way fp16 splits of the power-of-two-scaled fp32 operands, "
+                       "fp32 accumulation: error against fp64 at or below the fp32 MFMA chain's; the all-fp32-MFMA rate of the same run is in "
+                       "strict_fp32_mfma)")
                       if not (opt.mlp_bf16 or opt.half_precision_model) else
                       "f32 (MLP matrix operands rounded to bf16, fp32 accumulation)" + (", bias-free half-precision model structure" if opt.half_precision_model else "")),
             "data": "synthetic",
@@ -605,10 +677,10 @@ def main():
             },
             "mlp_products": ("fp32 MFMA (v_mfma_f32_16x16x4_f32)" if opt.mlp_fp32_mfma else
                              "bf16-rounded operands" if (opt.mlp_bf16 or opt.half_precision_model) else
-                             "fp32 operands split into three bf16 terms, six bf16 MFMAs per product, fp32 accumulation: error "
-                             "against fp64 equal to the fp32 MFMA chain's (tests/test_gpu_ops.py::"
-                             "test_fused_mlp_split_operands_keep_fp32_accuracy); forward, dX chain and dW all run on the bf16 "
-                             "matrix pipe (roofline_mlp.fp32_pipe_busy_frac = 0)"),
+                             "fp32 operands scaled by a per-launch power of two and split into two fp16 terms (round to nearest), "
+                             "three fp16 MFMAs per product (four in the dW products), fp32 accumulation: error against fp64 at or "
+                             "below the fp32 MFMA chain's (tests/test_gpu_ops.py::test_fused_mlp_split_operands_keep_fp32_accuracy, "
+                             "profiles/r05_f16_split_probe.log); forward, dX chain and dW all run on the 16-bit matrix pipe"),
             "strict_fp32_mfma": strict,
             "strong_scaling": strong,
             "small_batch": small,

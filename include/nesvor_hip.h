@@ -307,14 +307,16 @@ typedef struct {
                                     products); every other kernel evaluates this mode as mode 0, which is always a valid
                                     evaluation of it.  (Rounds 2-4: three bf16 terms per operand, six MFMAs per product.)
                                     REQUIRES `prep` */
-  int32_t compact_save;       /* 1: training keeps, per hidden unit and sample, ONE BIT (h > 0) of every hidden layer and the
-                                 values of the layers after the first only: saved_hidden[0] = one uint32 per (16-sample group,
-                                 lane) - 16 N bytes instead of 256 N - with bit 16 l + 4 b + r = [pre-activation sign bit clear] (= [h_l > 0] for every
-                                 value but an exact +0, which only zero-padded units produce) for the unit the
-                                 lane holds in block b, element r of the fragment layout; saved_hidden[l >= 1] as before.  The
-                                 backward gates with the bits and recomputes the first hidden layer from the network input
-                                 (24 MFMAs per 16 samples, in exactly the operand layout the weight gradient needs) instead of
-                                 streaming it back: 268 MB less written and 268 MB less read per network at N = 2^20.
+  int32_t compact_save;       /* 1: training keeps, per hidden unit and sample, ONE BIT (h > 0) of every hidden layer and nothing
+                                 else: saved_hidden[0] = one uint32 per (16-sample group, lane) - 16 N bytes instead of 256 N
+                                 per hidden layer - with bit 16 l + 4 b + r = [pre-activation sign bit clear] (= [h_l > 0] for every
+                                 value but an exact +0: the gate then passes a gradient the reference's ReLU'(0) = 0 drops - the
+                                 convention of this mode, see tests/test_gpu_ops.py::test_fused_mlp_compact_save) for the unit the
+                                 lane holds in block b, element r of the fragment layout; saved_hidden[l >= 1] are not
+                                 touched (any non-NULL pointer).  The backward gates with the bits and RECOMPUTES every hidden
+                                 layer from the network input (the forward's own products, 12 + 24 MFMAs per 16 samples at two
+                                 hidden layers) instead of streaming it back: 536 MB less written and 670 MB less read per
+                                 network and step at N = 2^20.  (Rounds 3-4 kept the values of the layers after the first.)
                                  Needs what nesvor_mlp_compact_save_ok() checks (split operands, the pipelined forward and
                                  the wave-specialised backward); forward and backward of one step must agree on it. */
   const float* weight[NESVOR_MAX_MLP_LAYERS];
@@ -492,6 +494,18 @@ int nesvor_sum_rows_multi(const float* const* in, float* const* out, const int* 
  * The PSF noise is drawn inside the sampler kernels from (seed, offset) as in nesvor_psf_transform_forward_rng.
  * ---------------------------------------------------------------------- */
 #define NESVOR_STEP_MLP_PARTIALS 256
+/* nesvor_step_timing: spans of a phase-0 run that are bracketed by HIP events on the stream their launch goes to */
+#define NESVOR_STEP_SPAN_PSF_FWD 0
+#define NESVOR_STEP_SPAN_HASHGRID_FWD 1
+#define NESVOR_STEP_SPAN_MLP_FWD_DENSITY 2
+#define NESVOR_STEP_SPAN_MLP_FWD_SIGMA 3
+#define NESVOR_STEP_SPAN_LOSS 4
+#define NESVOR_STEP_SPAN_MLP_BWD_SIGMA 5
+#define NESVOR_STEP_SPAN_MLP_BWD_DENSITY 6
+#define NESVOR_STEP_SPAN_HASHGRID_BWD_AGGREGATE 7
+#define NESVOR_STEP_SPAN_HASHGRID_BWD_OWNER 8   /* the owner pass; with the fused optimizer: owner pass + the table's AdamW step */
+#define NESVOR_STEP_SPAN_PSF_BWD 9
+#define NESVOR_STEP_TIMED_SPANS 10
 typedef struct {
   nesvor_grid_t grid;
   nesvor_mlp_t density, sigma, bias_net;   /* weights / biases: the model's parameters; bf16_operands: evaluation mode */
@@ -530,6 +544,11 @@ int nesvor_step_run(void* step, const float* xyz, const float* v, const int64_t*
  * nesvor_step_join.  Everything but the table (losses, the other parameters) is complete on `stream` as always. */
 #define NESVOR_STEP_DEFER_JOIN 8
 int nesvor_step_join(void* step, void* stream);
+/* Per-launch timing of the product step (the roofline leg of bench.py): nesvor_step_timing(handle, 1) makes every following
+ * nesvor_step_run bracket the launches listed above with HIP events on the stream each goes to; nesvor_step_timing_read waits
+ * for the last run and returns NESVOR_STEP_TIMED_SPANS durations in ms (-1: the span did not occur in that run). */
+int nesvor_step_timing(void* handle, int on);
+int nesvor_step_timing_read(void* handle, float* ms);
 
 /* ----------------------------------------------------------------------
  * Similarity sums of the stack registration.  Replaces, per optimisation step of `VVR`

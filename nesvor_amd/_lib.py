@@ -163,6 +163,8 @@ _SIGNATURES = {
     "nesvor_step_update": ([_P, POINTER(StepT)], c_int),
     "nesvor_step_destroy": ([_P], None),
     "nesvor_step_join": ([_P, _P], c_int),
+    "nesvor_step_timing": ([_P, c_int], c_int),
+    "nesvor_step_timing_read": ([_P, _P], c_int),
     "nesvor_step_run": ([_P, _P, _P, _P, c_uint64, c_uint64, _P, c_int, c_int, POINTER(AdamwT), _P], c_int),
     "nesvor_vvr_similarity": ([_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int, _P, _P, _P], c_int),
 }

@@ -699,8 +699,9 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 // held back to the end of the tile, and the prefetch is awaited right before them: the wait covers loads that are one
 // whole tile of MFMAs old, the stores drain under the next tile's MFMAs.
 // Requires the fast input path, whole tiles (n_groups % (4 kG) == 0) and NH = 1 or 2 hidden layers.
-// COMPACT (with SAVE): one bit per hidden unit and sample for every layer, values only for the layers after the first
-// (nesvor_mlp_t.compact_save) - the launch then writes 0.47 GB instead of 0.74 GB at N = 2^20.
+// COMPACT (with SAVE): one bit per hidden unit and sample for every layer and nothing else (nesvor_mlp_t.compact_save; round 5 -
+// rounds 3-4 also stored the values of the layers after the first): the density network's launch writes 0.08 GB instead of
+// 0.74 GB (full save) / 0.35 GB (rounds 3-4) at N = 2^20 next to the 0.13 GB it reads.
 // OUT1 (split mode, out_dim == 1: sigma_net, b_net): the output layer is a dot product per sample - 16 fp32 FMAs per lane and
 // a sum over the four feature quads - instead of twelve MFMAs on 15/16 padding plus the 3-way split of the last hidden layer
 // (4 fragments x 14 VALU), which nothing else needs.
@@ -896,9 +897,9 @@ __global__ __launch_bounds__(256, (SPL && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) 
         for (int r = 0; r < 4; ++r) y_mx = fmaxf(y_mx, fabsf(o[g][0][r]));  // (rows beyond out_dim: zero weights and bias)
     }
     settle_x(xr);
-    if constexpr (SAVE) {
+    if constexpr (SAVE && !COMPACT) {  // (COMPACT: the gate bits below are all the backward needs - it recomputes the activations)
 #pragma unroll
-      for (int l = COMPACT ? 1 : 0; l < NH; ++l)
+      for (int l = 0; l < NH; ++l)
 #pragma unroll
         for (int g = 0; g < kG; ++g) {
           const char* hbase = reinterpret_cast<const char*>(a.H[l]) + hgroup(g0 + g) * (int64_t)(kHB * 64 * 16);
@@ -909,11 +910,11 @@ __global__ __launch_bounds__(256, (SPL && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) 
             store_b128_s_nt<decltype(ob)::value * 64 * 16>(hbase, (uint32_t)lane * 16u, hv);
           });
         }
-      if constexpr (COMPACT) {
+    }
+    if constexpr (SAVE && COMPACT) {
 #pragma unroll
-        for (int g = 0; g < kG; ++g)
-          store_b32_s_nt<0>(reinterpret_cast<const char*>(a.Hm) + hgroup(g0 + g) * 256, (uint32_t)lane * 4u, hmask[g]);
-      }
+      for (int g = 0; g < kG; ++g)
+        store_b32_s_nt<0>(reinterpret_cast<const char*>(a.Hm) + hgroup(g0 + g) * 256, (uint32_t)lane * 4u, hmask[g]);
     }
 #pragma unroll
     for (int g = 0; g < kG; ++g) {
@@ -1571,6 +1572,14 @@ __device__ __forceinline__ void accumulate_dw_regs(const float* tiles, const f32
 #pragma unroll
       for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma4(av[ob][t], bv[ib][t], acc[ob][ib]);
 }
+// the B tuple (hi | lo) of a plane tile: feature i of samples 4q..4q+3 from both planes
+__device__ __forceinline__ f16x8 read_planes_b(const float* tile, int i, int q) {
+  const int js = 4 * q + (i >> 2);
+  const char* p = reinterpret_cast<const char*>(tile) + 8 * ((js ^ ((i & 2) << 1)) + kPlaneQ * (i & 3));
+  const s16x4 h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const s16x4 l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + kPlaneBytes));
+  return join8h(h, l);
+}
 
 // dW accumulation on the fp16 pipe at fp32 accuracy (split mode).  The contraction runs over the 16 samples of ONE
 // group, half of what v_mfma_f32_16x16x32_f16 contracts - but the split product is a sum of 16-sample products,
@@ -1603,6 +1612,9 @@ __device__ __forceinline__ void accumulate_dw_split(const f32x4 (&bv)[IB], f32x4
 // the scheduler every read sits right in front of its use and pays the LDS latency in full (this wave has ONE partner on its
 // SIMD); a scheduling barrier keeps LDS reads from sinking.
 template <int OB, int IB>
+__device__ __forceinline__ void accumulate_dw_tuples(const float* tiles, const f16x8 (&b_hl)[IB], f32x4 (&acc)[OB][IB], int i, int q,
+                                                     PlanesA& ap, const float* next_tile, uint32_t dup);
+template <int OB, int IB>
 __device__ __forceinline__ void accumulate_dw_planes(const float* tiles, const f32x4 (&bv)[IB], f32x4 (&acc)[OB][IB], int i, int q,
                                                      PlanesA& ap, const float* next_tile, uint32_t dup, float mb) {
   f16x8 b_hl[IB];
@@ -1611,6 +1623,12 @@ __device__ __forceinline__ void accumulate_dw_planes(const float* tiles, const f
     const Split2 sb = split2(bv[c], mb);
     b_hl[c] = join8h(sb.hi, sb.lo);
   }
+  accumulate_dw_tuples<OB, IB>(tiles, b_hl, acc, i, q, ap, next_tile, dup);
+}
+// ... with the B tuples (hi | lo) given (COMPACT: read from the dW wave's own plane tiles, see mlp_bwd_ws_kernel)
+template <int OB, int IB>
+__device__ __forceinline__ void accumulate_dw_tuples(const float* tiles, const f16x8 (&b_hl)[IB], f32x4 (&acc)[OB][IB], int i, int q,
+                                                     PlanesA& ap, const float* next_tile, uint32_t dup) {
 #pragma unroll
   for (int ob = 0; ob < OB; ++ob) {
     PlanesA an = ap;
@@ -1643,9 +1661,13 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   float* imgo = lds;                                    // W_out^T : ib = 4, kb = 1
   float* imgh = imgo + kHB * 1 * kBlk;                  // W_l^T, l = 1..NH-1
   float* img1 = imgh + (NH - 1) * kHB * kHB * kBlk;     // W_1^T : ib = KB1, kb = 4
-  float* imgf1 = img1 + KB1 * kHB * kBlk;               // COMPACT: forward image of W_1 (ob = 4, kb = KB1) and its bias
-  float* bias0 = imgf1 + (COMPACT ? kHB * KB1 * kBlk : 0);
-  float* wout = bias0 + (COMPACT ? kWidth : 0);         // OUT1: the single output row in fp32
+  // COMPACT: the forward images of every hidden layer (W_1: ob = 4, kb = KB1; W_l: 4 x 4) and their biases - the dW waves
+  // recompute the hidden activations - and one set of kHB plane tiles per dW wave for the recomputed B operands
+  float* imgf1 = img1 + KB1 * kHB * kBlk;
+  float* imgf2 = imgf1 + (COMPACT ? kHB * KB1 * kBlk : 0);
+  float* bias0 = imgf2 + (COMPACT ? (NH - 1) * kHB * kHB * kBlk : 0);   // [NH][kWidth], layer l in units sw[l] sx[l]
+  float* bplanes = bias0 + (COMPACT ? NH * kWidth : 0);
+  float* wout = bplanes + (COMPACT ? 4 * kHB * kPlaneTileFloats : 0);  // OUT1: the single output row in fp32
   float* tiles = wout + (OUT1 ? kWidth : 0);            // [pair][buffer][kT] tiles; reused as the flush buffer
   // split mode: the launch's scales (MlpScales).  Chain: dY is split with sd[NH]; the product W_{l+1}^T d_{l+1} leaves d_l in
   // units sw[l+1] sd[l+1], the split that feeds the next product (and the planes) takes it to sd[l]; dX leaves in sw[0] sd[0].
@@ -1666,8 +1688,13 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     inv_w[l] = pow2_inv(uniform_f(sc.sd[l] * sc.sx[l]));
   }
   const float inv_dx = pow2_inv(uniform_f(sc.sw[0] * sc.sd[0]));
-  const float unit0 = uniform_f(sc.sw[0] * sc.sx[0]);               // units of the recomputed first hidden layer (COMPACT)
-  const float m_h0 = uniform_f(sc.sx[1] * pow2_inv(unit0));         // ... and the multiplier of its split
+  // COMPACT: units of the recomputed hidden layers and the multipliers of their splits (into the next layer's input scale)
+  float unit_h[NH], m_h[NH];
+#pragma unroll
+  for (int l = 0; l < NH; ++l) {
+    unit_h[l] = uniform_f(sc.sw[l] * sc.sx[l]);
+    m_h[l] = uniform_f(sc.sx[l + 1] * pow2_inv(unit_h[l]));
+  }
   if constexpr (OUT1) {
     for (int e = threadIdx.x; e < kWidth; e += blockDim.x) wout[e] = a.W[NH][e];
   } else {
@@ -1678,7 +1705,14 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   build_image_ct<BF16, SPL, true, KB1, kHB, 512>(img1, a.W[0], kWidth, k_in, sc.sw[0]);
   if constexpr (COMPACT) {
     build_image_ct<false, SPL, false, kHB, KB1, 512>(imgf1, a.W[0], kWidth, k_in, sc.sw[0]);
-    for (int e = threadIdx.x; e < kWidth; e += blockDim.x) bias0[e] = a.b[0][e] * unit0;
+#pragma unroll
+    for (int l = 1; l < NH; ++l) build_image_ct<false, SPL, false, kHB, kHB, 512>(imgf2 + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, sc.sw[l]);
+    for (int e = threadIdx.x; e < NH * kWidth; e += blockDim.x) {
+      float us = unit_h[0];
+#pragma unroll
+      for (int l = 1; l < NH; ++l) us = e >= l * kWidth ? unit_h[l] : us;
+      bias0[e] = a.b[e / kWidth][e % kWidth] * us;
+    }
   }
   __syncthreads();
 
@@ -1721,6 +1755,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 
   f32x4 acc_o[1][kHB];
   float acc1[kHB] = {0.f, 0.f, 0.f, 0.f};  // OUT1: dW_out of feature j of block ib, partial over this lane's sample quads (dW waves)
+  f32x4 acc1c[kHB];                         // OUT1 + COMPACT: the same sums in the chain layout (lane (sample j, q): features 4q..4q+3 of block ib)
+#pragma unroll
+  for (int x = 0; x < kHB; ++x) acc1c[x] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 acc_h[NH > 1 ? NH - 1 : 1][kHB][kHB];
   f32x4 acc_1[kHB][KB1];
   // bias-gradient sums, kept by the chain waves in their own layout: lane (sample j, q) adds dpre[features 4q..4q+3]
@@ -1911,6 +1948,143 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         for (int y = 0; y < kHB; ++y) acc_h[l][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
+    if constexpr (COMPACT) {
+      // ---- bits-only save (round 5): this wave recomputes EVERY hidden layer of its group from the network input, in the chain
+      // layout (H^T = W X^T, exactly the forward's products on the forward images), and turns each layer's activations into
+      // the B operand of its weight-gradient product through LDS: split once (for the next layer's product AND the planes),
+      // store the two fp16 planes as held, read them back with the transposing read (read_planes_b).  Nothing but the input and
+      // the gate bits comes from HBM: the forward writes 16 bytes per sample and network instead of 272, this kernel reads the
+      // input once instead of twice and no activations at all (0.75 -> 0.35 GB for the density network's launch at N = 2^20).
+      // Order: dW_0 (input planes), then h_0 -> dW_1, ..., last the output layer - so that ONE set of kHB plane tiles per wave is
+      // reused layer after layer (LDS operations of a wave execute in order: a layer's planes are read before the next are stored).
+      const int ka_blocks = a.k_a >> 4;
+      float* my_b = bplanes + pair * kHB * kPlaneTileFloats;
+      auto issue_xc = [&](int64_t gi, float (&xc)[KB1][4]) __attribute__((always_inline)) {
+        const int64_t pixel = a.spg_shift >= 0 ? (gi >> a.spg_shift) : gi / (a.S >> 4);
+        const char* abase = a.xa != nullptr ? reinterpret_cast<const char*>(a.xa) + pixel * (int64_t)(a.k_a * 4) : reinterpret_cast<const char*>(a.xb);
+        const char* bbase = reinterpret_cast<const char*>(a.xb) + sgroup(gi) * 64;
+        const uint32_t n4 = (uint32_t)a.N * 4u;
+        const uint32_t xc_offa = (uint32_t)(4 * q * 4);
+        const uint32_t xc_offb = (uint32_t)(a.b_row0 + 4 * q) * n4 + (uint32_t)(j * 4);
+        const uint32_t xc_lim = (uint32_t)(a.b_row0 + a.k_b - 1) * n4 + (uint32_t)(j * 4);  // the lane's sample in the last valid row
+        static_for<KB1>([&](auto KB) {
+          constexpr int kb = decltype(KB)::value;
+          const bool is_a = kb < ka_blocks;  // wave-uniform
+          const char* base = is_a ? abase : bbase;
+          static_for<4>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            const uint32_t ub = (uint32_t)(16 * (kb - ka_blocks) + r) * n4;  // scalar
+            const uint32_t off = is_a ? xc_offa + (uint32_t)((16 * kb + r) * 4) : min(xc_offb + ub, xc_lim);
+            issue_load_b32_s<0>(xc[kb][r], base, off);
+          });
+        });
+      };
+      float xcr[KB1][4];
+      uint32_t dup = 0u;  // an opaque zero (read_planes2)
+      asm volatile("" : "+v"(dup));
+      auto settle_xc = [&]() __attribute__((always_inline)) {
+        await_loads();
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pin(xcr[kb][r]);
+      };
+      auto dw_iter = [&](int it) __attribute__((always_inline)) {
+        const int64_t gi = g_first + (int64_t)(it - 1) * gstride;
+        if (it > 0 && gi < n_groups) {
+          const int64_t gnext = min(gi + gstride, n_groups - 1);  // (the last iteration re-requests a valid group: no control flow between an issue and its settle)
+          const float* buf = my_tiles + ((it - 1) & 1) * kBufFloats;
+          const float* dt0 = buf + kTile0Floats + (NH - 1) * kHB * kPlaneTileFloats;  // planes of d pre-activation 0 (staged last by the chain wave)
+          f32x4 xc[KB1];
+#pragma unroll
+          for (int kb = 0; kb < KB1; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              // (a select, i.e. a COPY of the prefetch set, as in the forward: the set is re-requested below while the compiler is
+              //  free to schedule uses of xc behind that request)
+              xc[kb][r] = (kb < ka_blocks || 16 * (kb - ka_blocks) + 4 * q + r < a.k_b) ? xcr[kb][r] : 0.f;
+          issue_xc(gnext, xcr);
+          PlanesA ap;
+          read_planes2(dt0, j, q, dup, ap);
+          // the input: split once - the B operand of the first layer's product here and, through the planes, of dW_0
+          Split2 xs[KB1];
+#pragma unroll
+          for (int kb = 0; kb < KB1; ++kb) {
+            xs[kb] = split2(xc[kb], sc.sx[0]);
+            stage_planes(my_b + kb * kPlaneTileFloats, xs[kb], j, q);
+          }
+          f32x4 h[kHB];
+#pragma unroll
+          for (int ob = 0; ob < kHB; ++ob) h[ob] = *reinterpret_cast<const f32x4*>(bias0 + 16 * ob + 4 * q);
+          apply_layer_g1_s<KB1, kHB>(imgf1, xs, h, lane);
+#pragma unroll
+          for (int ob = 0; ob < kHB; ++ob)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[ob][r] = relu_f(h[ob][r]);
+          {
+            f16x8 bx[KB1];
+#pragma unroll
+            for (int kb = 0; kb < KB1; ++kb) bx[kb] = read_planes_b(my_b + kb * kPlaneTileFloats, j, q);
+            accumulate_dw_tuples<kHB, KB1>(dt0, bx, acc_1, j, q, ap, NH > 1 ? dt0 - kHB * kPlaneTileFloats : nullptr, dup);
+          }
+          // hidden layers 1 .. NH-1: h = activations of layer l - 1 (units unit_h[l - 1]) on entry
+#pragma unroll
+          for (int l = 1; l < NH; ++l) {
+            const float* dtl = buf + kTile0Floats + (NH - 1 - l) * kHB * kPlaneTileFloats;  // planes of d pre-activation l
+            Split2 hs[kHB];
+#pragma unroll
+            for (int ib = 0; ib < kHB; ++ib) {
+              hs[ib] = split2(h[ib], m_h[l - 1]);
+              stage_planes(my_b + ib * kPlaneTileFloats, hs[ib], j, q);
+            }
+#pragma unroll
+            for (int ob = 0; ob < kHB; ++ob) h[ob] = *reinterpret_cast<const f32x4*>(bias0 + l * kWidth + 16 * ob + 4 * q);
+            apply_layer_g1_s<kHB, kHB>(imgf2 + (l - 1) * kHB * kHB * kBlk, hs, h, lane);
+#pragma unroll
+            for (int ob = 0; ob < kHB; ++ob)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) h[ob][r] = relu_f(h[ob][r]);
+            f16x8 bh[kHB];
+#pragma unroll
+            for (int ib = 0; ib < kHB; ++ib) bh[ib] = read_planes_b(my_b + ib * kPlaneTileFloats, j, q);
+            accumulate_dw_tuples<kHB, kHB>(dtl, bh, acc_h[l - 1], j, q, ap, l + 1 < NH ? dtl - kHB * kPlaneTileFloats : nullptr, dup);
+          }
+          // output layer: h = activations of the last hidden layer (units unit_h[NH - 1])
+          if constexpr (OUT1) {
+            const float dyj = buf[j * kTile0Stride];  // dY of sample j (row 0 of the fp32 tile)
+#pragma unroll
+            for (int ib = 0; ib < kHB; ++ib)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc1c[ib][r] = fmaf(dyj, h[ib][r], acc1c[ib][r]);
+          } else {
+            float av[4];
+            read_operand0(buf, j, q, av);
+            f16x8 bh[kHB];
+#pragma unroll
+            for (int ib = 0; ib < kHB; ++ib) {
+              const Split2 hs = split2(h[ib], m_h[NH - 1]);
+              stage_planes(my_b + ib * kPlaneTileFloats, hs, j, q);
+            }
+#pragma unroll
+            for (int ib = 0; ib < kHB; ++ib) bh[ib] = read_planes_b(my_b + ib * kPlaneTileFloats, j, q);
+            const Split2 sa = split2(f32x4{av[0], av[1], av[2], av[3]}, m_d[NH]);
+            const f16x8 a_lh = join8h(sa.lo, sa.hi), a_hl = join8h(sa.hi, sa.lo);
+#pragma unroll
+            for (int ib = 0; ib < kHB; ++ib) acc_o[0][ib] = mfma32_f16(a_lh, bh[ib], acc_o[0][ib]);
+#pragma unroll
+            for (int ib = 0; ib < kHB; ++ib) acc_o[0][ib] = mfma32_f16(a_hl, bh[ib], acc_o[0][ib]);
+          }
+          settle_xc();
+        }
+        pair_sync(it);
+      };
+#pragma unroll
+      for (int kb = 0; kb < KB1; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xcr[kb][r] = 0.f;
+      if (g_first < n_groups) { issue_xc(g_first, xcr); settle_xc(); }
+      for (int it = 0; it <= n_it; ++it) dw_iter(it);
+    } else {
     // B operands (layer inputs) of one group: lane (feature j, sample quad q) holds feature j of samples 4q..4q+3
     const int ka_blocks = a.k_a >> 4;
     // The saved activations are prefetched a whole group ahead into a second register set (32 registers each, swapped every
@@ -1919,7 +2093,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     // awaited with vmcnt(activation loads) - loads retire in order, the younger ones may stay in flight.  (Issue and settle of
     // a register always sit in the same straight-line region: at a control-flow merge the compiler may copy registers, and a
     // copy of a register with a load in flight reads stale data.)
-    constexpr int kL0 = COMPACT ? 1 : 0;  // first hidden layer whose values are streamed from HBM (COMPACT: layer 0 is recomputed)
+    constexpr int kL0 = 0;  // (every hidden layer's values are streamed from HBM on this path)
     auto issue_h = [&](int64_t gi, float (&hraw)[NH][kHB][4]) __attribute__((always_inline)) {
       // element (sample 4q + t, feature j of block ib) of the fragment layout [block][lane = (f >> 2) * 16 + sample][f & 3]
       const uint32_t voff = (uint32_t)((((j >> 2) * 16 + 4 * q) * 4 + (j & 3)) * kHBytes);
@@ -1936,34 +2110,6 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
       }
     };
     constexpr int kHLoads = (NH - kL0) * kHB * 4;  // activation loads per group
-    // COMPACT: the group's input once more in the chain layout (lane (sample j, q): features 16 kb + 4q + r), the A operand of
-    // the recomputation of layer 0.  One dword per element as in the forward; base (pixel features / matrix rows) chosen by
-    // the block type in SGPRs, lane offsets precomputed.  ONE register set: an iteration first consumes the set (requested by
-    // the previous iteration and awaited at its end), then requests the next group's.
-    // lane offsets from ONE register per source (the kernel sits at the 256-register limit): pixel features at
-    // (16 kb + 4q + r) floats; matrix rows at ((b_row0 + 16 (kb - ka) + 4q + r) N + j) floats, the wave-uniform part added per
-    // load and the result clamped to the last valid row (a row beyond k_b reads something valid and is zeroed below)
-    auto issue_xc = [&](int64_t gi, float (&xc)[KB1][4]) __attribute__((always_inline)) {
-      const int64_t pixel = a.spg_shift >= 0 ? (gi >> a.spg_shift) : gi / (a.S >> 4);
-      const char* abase = a.xa != nullptr ? reinterpret_cast<const char*>(a.xa) + pixel * (int64_t)(a.k_a * 4) : reinterpret_cast<const char*>(a.xb);
-      const char* bbase = reinterpret_cast<const char*>(a.xb) + sgroup(gi) * 64;
-      // (recomputed per group - three multiply-adds - rather than kept: the kernel sits at the 256-register limit)
-      const uint32_t n4 = (uint32_t)a.N * 4u;
-      const uint32_t xc_offa = (uint32_t)(4 * q * 4);
-      const uint32_t xc_offb = (uint32_t)(a.b_row0 + 4 * q) * n4 + (uint32_t)(j * 4);
-      const uint32_t xc_lim = (uint32_t)(a.b_row0 + a.k_b - 1) * n4 + (uint32_t)(j * 4);  // the lane's sample in the last valid row (offsets are relative to the group)
-      static_for<KB1>([&](auto KB) {
-        constexpr int kb = decltype(KB)::value;
-        const bool is_a = kb < ka_blocks;  // wave-uniform
-        const char* base = is_a ? abase : bbase;
-        static_for<4>([&](auto R) {
-          constexpr int r = decltype(R)::value;
-          const uint32_t ub = (uint32_t)(16 * (kb - ka_blocks) + r) * n4;  // scalar
-          const uint32_t off = is_a ? xc_offa + (uint32_t)((16 * kb + r) * 4) : min(xc_offb + ub, xc_lim);
-          issue_load_b32_s<0>(xc[kb][r], base, off);
-        });
-      });
-    };
     auto issue_x = [&](int64_t gi, f32x4 (&xraw)[KB1], float (&xsraw)[KB1]) __attribute__((always_inline)) {
       // both candidate sources of every input block are requested (no branch between issue and settle); the block
       // type picks one after the loads have landed
@@ -1999,7 +2145,6 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     };
     f32x4 xraw[KB1];
     float xsraw[KB1];
-    float xcr[KB1][4];
     uint32_t dup = 0u;  // an opaque zero (read_planes2)
     asm volatile("" : "+v"(dup));
     // one iteration: the group (one behind the chain wave) whose saved activations sit in hraw_c; the next group's go into hraw_n
@@ -2015,37 +2160,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             for (int t = 0; t < 4; ++t)
               hb[l][ib][t] = BF16 ? __uint_as_float(__float_as_uint(hraw_c[l][ib][t]) << 16) : hraw_c[l][ib][t];
         const int64_t gnext = min(gi + gstride, n_groups - 1);  // (the last iteration re-requests a valid group: no control flow between an issue and its settle)
-        if constexpr (COMPACT) {
-          // h_0 = relu(W_1 x + b_1) of this group, straight into the B-operand layout (apply_layer_g1_T); the input registers
-          // are free again afterwards and take the next group's request
-          f32x4 xc[KB1];
-#pragma unroll
-          for (int kb = 0; kb < KB1; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              // (a select, i.e. a COPY of the prefetch set, as in the forward: the set is re-requested below while the compiler is
-              //  free to schedule uses of xc behind that request)
-              xc[kb][r] = (kb < ka_blocks || 16 * (kb - ka_blocks) + 4 * q + r < a.k_b) ? xcr[kb][r] : 0.f;
-#pragma unroll
-          for (int ob = 0; ob < kHB; ++ob) {
-            const float b0 = bias0[16 * ob + j];
-            hb[0][ob] = f32x4{b0, b0, b0, b0};
-          }
-          apply_layer_g1_T<KB1, kHB>(imgf1, xc, hb[0], lane, sc.sx[0]);
-#pragma unroll
-          for (int ob = 0; ob < kHB; ++ob)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) hb[0][ob][t] = relu_f(hb[0][ob][t]);
-          issue_xc(gnext, xcr);
-        }
         issue_x(gi, xraw, xsraw);
-        // the next group's activations: a whole iteration ahead - or (COMPACT with plane tiles, where the recomputation's input set
-        // and the plane prefetch make the dW2 product the register peak of the kernel) right after that product
-#ifndef NESVOR_MLP_HLATE
-#define NESVOR_MLP_HLATE 0  // (1 was needed by the two-byte-store planes at the register limit; with the transposing read the early request fits: 248 VGPRs, 0.267 -> 0.262 ms)
-#endif
-        constexpr bool kHLate = COMPACT && PLANES && (NESVOR_MLP_HLATE != 0);
-        if constexpr (!kHLate) issue_h(gnext, hraw_n);
+        // the next group's activations: a whole iteration ahead
+        issue_h(gnext, hraw_n);
         const float* buf = my_tiles + ((it - 1) & 1) * kBufFloats;
         auto input_operands = [&](f32x4 (&xb_)[KB1]) __attribute__((always_inline)) {
           settle_x(xraw, xsraw, std::integral_constant<int, kHLoads>{});  // requested at the top, before the kHLoads that may fly on
@@ -2076,7 +2193,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             read_operand0(buf, j, q, av);
             read_planes2(buf + kTile0Floats, j, q, dup, ap);
             __builtin_amdgcn_sched_barrier(0x047F);
-            accumulate_dw_split<kHB>(hb[NH - 1], acc_o, av, m_d[NH], (COMPACT && NH == 1) ? m_h0 : sc.sx[NH]);
+            accumulate_dw_split<kHB>(hb[NH - 1], acc_o, av, m_d[NH], sc.sx[NH]);
           }
 #pragma unroll
           for (int l = NH - 1; l >= 0; --l) {
@@ -2084,9 +2201,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             if (l > 0) {
               // B operand: the activations of hidden layer l - 1 - from HBM in true units, or (COMPACT, l - 1 = 0) recomputed above
               accumulate_dw_planes<kHB, kHB>(dt, hb[l - 1], acc_h[l - 1], j, q, ap, dt + kHB * kPlaneTileFloats, dup,
-                                             (COMPACT && l == 1) ? m_h0 : sc.sx[l]);
+                                             sc.sx[l]);
             } else {
-              if constexpr (kHLate) issue_h(gnext, hraw_n);
               f32x4 xb_[KB1];
               input_operands(xb_);
               accumulate_dw_planes<kHB, KB1>(dt, xb_, acc_1, j, q, ap, nullptr, dup, sc.sx[0]);
@@ -2107,12 +2223,6 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           }
         }
         settle_h(hraw_n, std::integral_constant<int, 0>{});
-        if constexpr (COMPACT) {
-#pragma unroll
-          for (int kb = 0; kb < KB1; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pin(xcr[kb][r]);
-        }
         // The consumed set is dead, but its next definition (the request two iterations on) sits under that iteration's
         // condition, so to the compiler the registers stay live around the loop - and the in-place splits of the activations
         // copied every value first (one v_mov per value).  An empty asm that "defines" the set ends the old values here.
@@ -2137,25 +2247,17 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
     for (int kb = 0; kb < KB1; ++kb) {
       xraw[kb] = f32x4{0.f, 0.f, 0.f, 0.f}; xsraw[kb] = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xcr[kb][r] = 0.f;
     }
     // iteration it works on group it - 1: its activations must sit in the set that iteration reads (odd iterations read set b)
     if (g_first < n_groups) {
       issue_h(g_first, hraw_b);
-      if constexpr (COMPACT) issue_xc(g_first, xcr);
       settle_h(hraw_b, std::integral_constant<int, 0>{});
-      if constexpr (COMPACT) {
-#pragma unroll
-        for (int kb = 0; kb < KB1; ++kb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pin(xcr[kb][r]);
-      }
     }
     for (int it = 0; it <= n_it; it += 2) {
       dw_iter(it, hraw_a, hraw_b);
       if (it + 1 <= n_it) dw_iter(it + 1, hraw_b, hraw_a);
     }
+    }  // (!COMPACT)
   }
   if constexpr (OUT1) {
     // the rank-one sums in the accumulator layout the flush expects: row 0 of the (1 x 64) gradient sits in the q = 0 lanes
@@ -2163,8 +2265,17 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
       for (int ib = 0; ib < kHB; ++ib) {
         float t = acc1[ib];
-        t += __shfl_xor(t, 16, 64);
-        t += __shfl_xor(t, 32, 64);
+        if constexpr (COMPACT) {
+          // chain layout (lane (sample j, q'): features 4q' + r of the block, summed over this lane's groups) -> feature j: sum the
+          // 16 sample lanes of a row, then lane j takes element j & 3 of row j >> 2
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = __shfl(row_sum_dpp(acc1c[ib][r]), 16 * (j >> 2), 64);
+          t = (j & 3) == 0 ? v[0] : ((j & 3) == 1 ? v[1] : ((j & 3) == 2 ? v[2] : v[3]));
+        } else {
+          t += __shfl_xor(t, 16, 64);
+          t += __shfl_xor(t, 32, 64);
+        }
         acc_o[0][ib] = f32x4{q == 0 ? t : 0.f, 0.f, 0.f, 0.f};
       }
     }
@@ -2182,7 +2293,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     poff += kWidth * kWidth + kWidth;
   }
   flush_dw_ws<1, kHB>(red, acc_o, dbc_o, out + poff, a.out_dim, kWidth, slot, chain,
-                      OUT1 ? ((COMPACT && NH == 1) ? pow2_inv(unit0) : 1.f) : inv_w[NH], 1.f);  // (OUT1: fp32 sums of dy h; a recomputed h arrives in unit0)
+                      OUT1 ? (COMPACT ? pow2_inv(unit_h[NH - 1]) : 1.f) : inv_w[NH], 1.f);  // (OUT1: fp32 sums of dy h; a recomputed h arrives in its layer's units)
 }
 
 // ------------------------------------------------------------ nesvor_mlp_prepare
@@ -2267,7 +2378,8 @@ __global__ __launch_bounds__(256) void weight_norms_kernel(const NormJobs jobs) 
 size_t ws_bwd_lds_bytes(int n_hidden, int kb1, bool split = false, bool compact = false) {
   constexpr size_t blk = 256;
   size_t img = (size_t)kHB * blk + (size_t)(n_hidden - 1) * kHB * kHB * blk + (size_t)kb1 * kHB * blk;
-  if (compact) img += (size_t)kb1 * kHB * blk + kWidth;  // forward image of the first layer + its bias
+  // compact: forward images and biases of every hidden layer + one set of kHB plane tiles per dW wave (mlp_bwd_ws_kernel)
+  if (compact) img += (size_t)kb1 * kHB * blk + (size_t)(n_hidden - 1) * kHB * kHB * blk + (size_t)n_hidden * kWidth + 4 * (size_t)kHB * kPlaneTileFloats;
   const bool planes = split;  // split mode: fp32 dY tile + plane tiles (mlp_bwd_ws_kernel::PLANES)
   size_t tiles = 4 * 2 * (planes ? (size_t)kTile0Floats + (size_t)n_hidden * kHB * kPlaneTileFloats : (size_t)(1 + n_hidden * kHB) * kTileFloats);
   // the epilogue stages one layer's accumulators of the four dW waves at once (flush_dw_ws)

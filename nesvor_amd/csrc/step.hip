@@ -29,6 +29,17 @@ struct StepCtx {
   hipEvent_t ev_fork, ev_pose, ev_agg, ev_owner, ev_bwd, ev_sums, ev_norms;
   bool sums_on_side = false;  // the networks' parameter-gradient sums of the current iteration were left on the side stream
   bool pending_join = false;  // a table update of the previous run is still on the side stream (NESVOR_STEP_DEFER_JOIN)
+  // nesvor_step_timing: HIP-event brackets around the PRODUCT launches of a run, each pair on the stream its launch goes to
+  bool timing = false, timed_run = false;
+  hipEvent_t t0[NESVOR_STEP_TIMED_SPANS], t1[NESVOR_STEP_TIMED_SPANS];
+  bool span_used[NESVOR_STEP_TIMED_SPANS];
+};
+struct Span {  // records t0 now and t1 when it goes out of scope (timing on), on the stream of the launch it brackets
+  StepCtx* c; int k; hipStream_t st;
+  Span(StepCtx* c_, int k_, hipStream_t st_) : c(c_->timing ? c_ : nullptr), k(k_), st(st_) {
+    if (c != nullptr) { (void)hipEventRecord(c->t0[k], st); c->span_used[k] = true; }
+  }
+  ~Span() { if (c != nullptr) (void)hipEventRecord(c->t1[k], st); }
 };
 
 // out[0] = mean(x[0..n)) in two launches (deterministic order): partial sums of 256 workgroups, then one wave
@@ -99,7 +110,35 @@ extern "C" void* nesvor_step_create(const nesvor_step_t* desc) {
   for (hipEvent_t* e : evs) {
     if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
   }
+  for (int k = 0; k < NESVOR_STEP_TIMED_SPANS; ++k) { c->t0[k] = nullptr; c->t1[k] = nullptr; c->span_used[k] = false; }
   return c;
+}
+
+// Per-launch HIP-event timing of the product step (bench.py's roofline leg): on = 1 creates the event pairs and makes every
+// following nesvor_step_run bracket its launches - on the stream each goes to, so the owner pass (+ the table's AdamW) is timed
+// where it runs, on the side stream; nesvor_step_timing_read waits for the last run and returns the NESVOR_STEP_TIMED_SPANS
+// durations in ms (-1: the span did not occur).  An event bracket reads a few microseconds more than the kernel it brackets.
+extern "C" int nesvor_step_timing(void* handle, int on) {
+  if (handle == nullptr) return (int)hipErrorInvalidValue;
+  StepCtx* c = static_cast<StepCtx*>(handle);
+  if (on && c->t0[0] == nullptr) {
+    for (int k = 0; k < NESVOR_STEP_TIMED_SPANS; ++k)
+      if (hipEventCreate(&c->t0[k]) != hipSuccess || hipEventCreate(&c->t1[k]) != hipSuccess) return (int)hipGetLastError();
+  }
+  c->timing = on != 0;
+  c->timed_run = false;
+  return 0;
+}
+extern "C" int nesvor_step_timing_read(void* handle, float* ms) {
+  if (handle == nullptr || ms == nullptr) return (int)hipErrorInvalidValue;
+  StepCtx* c = static_cast<StepCtx*>(handle);
+  for (int k = 0; k < NESVOR_STEP_TIMED_SPANS; ++k) ms[k] = -1.f;
+  if (!c->timed_run) return 0;
+  for (int k = 0; k < NESVOR_STEP_TIMED_SPANS; ++k) {
+    if (!c->span_used[k]) continue;
+    if (hipEventSynchronize(c->t1[k]) != hipSuccess || hipEventElapsedTime(&ms[k], c->t0[k], c->t1[k]) != hipSuccess) return (int)hipGetLastError();
+  }
+  return 0;
 }
 
 extern "C" int nesvor_step_update(void* handle, const nesvor_step_t* desc) {
@@ -113,6 +152,10 @@ extern "C" void nesvor_step_destroy(void* handle) {
   StepCtx* c = static_cast<StepCtx*>(handle);
   (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_pose); (void)hipEventDestroy(c->ev_agg); (void)hipEventDestroy(c->ev_owner);
   (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_sums); (void)hipEventDestroy(c->ev_norms);
+  for (int k = 0; k < NESVOR_STEP_TIMED_SPANS; ++k) {
+    if (c->t0[k] != nullptr) (void)hipEventDestroy(c->t0[k]);
+    if (c->t1[k] != nullptr) (void)hipEventDestroy(c->t1[k]);
+  }
   delete c;
 }
 
@@ -157,6 +200,7 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   const bool fuse_adamw = adam != nullptr && phase == 0 && (d.overlap_owner & 2) != 0 && d.table != nullptr && d.flat_param != nullptr &&
                           d.g_table == d.flat_grad + table_off && table_off >= 0 && table_off < d.flat_numel;
 
+  if (ctx->timing) { for (int k = 0; k < NESVOR_STEP_TIMED_SPANS; ++k) ctx->span_used[k] = false; ctx->timed_run = true; }
   if (phase != 2) {
     // ---- forward
     NESVOR_TRY(nesvor_step_prologue(d.has_c ? d.logit_coef : nullptr, c, d.axisangle, mat, acc, 13 * n + 1 + 3 * NESVOR_MLP_PREP_FLOATS, n, main));
@@ -182,16 +226,25 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
         if (hipEventRecord(ctx->ev_pose, side) != hipSuccess) return (int)hipGetLastError();
       }
     }
-    NESVOR_TRY(nesvor_psf_transform_forward_rng_gather(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.x, d.u, B, S,
-                                                       d.ks > 0 ? d.slice_embedding : nullptr, d.ks > 0 ? d.se : nullptr, d.ks, main));
+    {
+      Span t(ctx, NESVOR_STEP_SPAN_PSF_FWD, main);
+      NESVOR_TRY(nesvor_psf_transform_forward_rng_gather(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.x, d.u, B, S,
+                                                         d.ks > 0 ? d.slice_embedding : nullptr, d.ks > 0 ? d.se : nullptr, d.ks, main));
+    }
     if (ctx->pending_join) {  // the previous run left its table update on the side stream
       if (hipStreamWaitEvent(main, ctx->ev_owner, 0) != hipSuccess) return (int)hipGetLastError();
       ctx->pending_join = false;
     }
-    NESVOR_TRY(nesvor_hashgrid_forward_bounded(&d.grid, d.u, d.table, d.pe, N, layout | (S >= 128 ? NESVOR_LAYOUT_CLUSTERED : 0),
-                                               split_d ? prep_d + NESVOR_MLP_PREP_XB : nullptr, main));
+    {
+      Span t(ctx, NESVOR_STEP_SPAN_HASHGRID_FWD, main);
+      NESVOR_TRY(nesvor_hashgrid_forward_bounded(&d.grid, d.u, d.table, d.pe, N, layout | (S >= 128 ? NESVOR_LAYOUT_CLUSTERED : 0),
+                                                 split_d ? prep_d + NESVOR_MLP_PREP_XB : nullptr, main));
+    }
     if (any_split && hipStreamWaitEvent(main, ctx->ev_norms, 0) != hipSuccess) return (int)hipGetLastError();
-    NESVOR_TRY(nesvor_mlp_forward(&net_d, nullptr, d.pe, d.z, d.saved_d, N, main));
+    {
+      Span t(ctx, NESVOR_STEP_SPAN_MLP_FWD_DENSITY, main);
+      NESVOR_TRY(nesvor_mlp_forward(&net_d, nullptr, d.pe, d.z, d.saved_d, N, main));
+    }
     if (d.has_b) {
       // (the bias field is off BASELINE's headline configuration: its input bounds by a pass of their own)
       if (split_b) NESVOR_TRY(nesvor_mlp_prepare(&net_b, d.se, d.pe, nullptr, N, prep_b, NESVOR_MLP_WHAT_INPUT, main));
@@ -199,7 +252,10 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
       hipLaunchKernelGGL(mean_partial_kernel, dim3(256), dim3(256), 0, main, d.log_bias, N, d.mean_scratch);
       hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(256), 0, main, d.mean_scratch, 256, 1.f / (float)N, d.lb_mean);
     }
-    if (d.has_lv) NESVOR_TRY(nesvor_mlp_forward(&net_s, d.se, d.z, d.log_var, d.saved_s, N, main));
+    if (d.has_lv) {
+      Span t(ctx, NESVOR_STEP_SPAN_MLP_FWD_SIGMA, main);
+      NESVOR_TRY(nesvor_mlp_forward(&net_s, d.se, d.z, d.log_var, d.saved_s, N, main));
+    }
     // ---- losses: values and gradients in one launch
     const int z_rows = 1 + d.n_features_z, written = 1 + (d.has_lv ? d.n_features_z : 0);
     if (written < z_rows) {
@@ -215,7 +271,10 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
     la.dc_pix = d.has_c ? d.pix : nullptr; la.dlvs_pix = d.has_lvs ? d.pix + B : nullptr;
     la.B = B; la.S = S; la.reg_type = d.reg_type; la.delta = d.delta;
     la.dz0_absmax = prep_d + NESVOR_MLP_PREP_DY; la.dlog_var_absmax = prep_s + NESVOR_MLP_PREP_DY; la.dlog_bias_absmax = prep_b + NESVOR_MLP_PREP_DY;
-    NESVOR_TRY(nesvor_imaging_loss(&la, main));
+    {
+      Span t(ctx, NESVOR_STEP_SPAN_LOSS, main);
+      NESVOR_TRY(nesvor_imaging_loss(&la, main));
+    }
     // ---- backward through the networks
     const int group_sums = (N % 16 == 0 && S % 16 == 0 && d.ks % 16 == 0) ? 1 : 0;
     // every network writes its per-workgroup partial parameter gradients into its own third of `partial` (the host allocates
@@ -226,11 +285,16 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
     float* part_d = d.partial;
     float* part_s = d.partial + (size_t)NESVOR_STEP_MLP_PARTIALS * widest;
     float* part_b = d.partial + 2 * (size_t)NESVOR_STEP_MLP_PARTIALS * widest;
-    if (d.has_lv)  // (its input gradient = rows 1.. of dz: raises the density network's upstream bound next to the loss kernel's row 0)
+    if (d.has_lv) {  // (its input gradient = rows 1.. of dz: raises the density network's upstream bound next to the loss kernel's row 0)
+      Span t(ctx, NESVOR_STEP_SPAN_MLP_BWD_SIGMA, main);
       NESVOR_TRY(mlp_backward_into(net_s, group_sums, d.se, d.z, d.dlv, d.saved_s, d.ks ? d.dxa : nullptr, d.dz + N, part_s,
                                    d.g_sigma, d.n_sigma_params, N, main, prep_d + NESVOR_MLP_PREP_DY));  // (a scalar publish: slot 0)
-    NESVOR_TRY(mlp_backward_into(net_d, 0, nullptr, d.pe, d.dz, d.saved_d, nullptr, d.dpe, part_d, d.g_density,
-                                 d.n_density_params, N, main, dpe_bound));
+    }
+    {
+      Span t(ctx, NESVOR_STEP_SPAN_MLP_BWD_DENSITY, main);
+      NESVOR_TRY(mlp_backward_into(net_d, 0, nullptr, d.pe, d.dz, d.saved_d, nullptr, d.dpe, part_d, d.g_density,
+                                   d.n_density_params, N, main, dpe_bound));
+    }
     if (d.has_b) {
       NESVOR_TRY(mlp_backward_into(net_b, group_sums, d.se, d.pe, d.dlb, d.saved_b, d.ks ? d.dxa_b : nullptr, d.dpe_b, part_b,
                                    d.g_bias_net, d.n_bias_params, N, main));
@@ -264,8 +328,11 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   // ---- hash-grid backward (+ input gradient when the poses are optimised)
   float* du = d.opt_T ? d.du : nullptr;
   if (phase == 0) {
-    NESVOR_TRY(nesvor_hashgrid_backward_bounded(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 1, 0, L,
-                                                d.queue_scale, dpe_bound, main));
+    {
+      Span t(ctx, NESVOR_STEP_SPAN_HASHGRID_BWD_AGGREGATE, main);
+      NESVOR_TRY(nesvor_hashgrid_backward_bounded(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 1, 0, L,
+                                                  d.queue_scale, dpe_bound, main));
+    }
     // the owner pass only finishes grad_table (or, fused, takes the table's AdamW step): it runs under the sampler backward
     // and the per-slice bookkeeping
     hipStream_t owner_stream = main;
@@ -273,13 +340,16 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
       if (hipEventRecord(ctx->ev_agg, main) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_agg, 0) != hipSuccess) return (int)hipGetLastError();
       owner_stream = side;
     }
-    if (fuse_adamw)
-      NESVOR_TRY(nesvor_hashgrid_backward_adamw(&d.grid, d.u, d.flat_param + table_off, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 2,
-                                                d.queue_scale, dpe_bound, d.flat_exp_avg + table_off, d.flat_exp_avg_sq + table_off, adam,
-                                                owner_stream));
-    else
-      NESVOR_TRY(nesvor_hashgrid_backward_levels(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 2, 0, L,
-                                                 d.queue_scale, owner_stream));
+    {
+      Span t(ctx, NESVOR_STEP_SPAN_HASHGRID_BWD_OWNER, owner_stream);  // (with fuse_adamw: the owner pass AND the table's AdamW step)
+      if (fuse_adamw)
+        NESVOR_TRY(nesvor_hashgrid_backward_adamw(&d.grid, d.u, d.flat_param + table_off, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 2,
+                                                  d.queue_scale, dpe_bound, d.flat_exp_avg + table_off, d.flat_exp_avg_sq + table_off, adam,
+                                                  owner_stream));
+      else
+        NESVOR_TRY(nesvor_hashgrid_backward_levels(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 2, 0, L,
+                                                   d.queue_scale, owner_stream));
+    }
     if (overlap_owner && hipEventRecord(ctx->ev_owner, side) != hipSuccess) return (int)hipGetLastError();
   } else if (phase == 1) {
     // fine levels first (the end of the flat gradient): the host starts their all-reduce when this call returns
@@ -299,8 +369,10 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
                                                 split_level, d.queue_scale, dpe_bound, owner_stream));
     if (overlap_owner && hipEventRecord(ctx->ev_owner, side) != hipSuccess) return (int)hipGetLastError();
   }
-  if (d.opt_T)
+  if (d.opt_T) {
+    Span t(ctx, NESVOR_STEP_SPAN_PSF_BWD, main);
     NESVOR_TRY(nesvor_psf_transform_backward_rng(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.dxl, du, d.dpix, B, S, main));
+  }
   // ---- per-slice parameters
   const int group_sums = (N % 16 == 0 && S % 16 == 0 && d.ks % 16 == 0) ? 1 : 0;
   const int rows_per_pixel = group_sums ? S / 16 : S;

@@ -35,6 +35,29 @@ def active(group=None) -> bool:
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or forced())
 
 
+def cap_hw_queues(limit: int = 4) -> Optional[str]:
+    """``GPU_MAX_HW_QUEUES`` above ``limit`` is lowered to it - BEFORE the HIP runtime reads it (its first call in this process).
+    Measured (tools/ddp_queue_probe.sh, profiles/r04_ddp_queue_probe*.log): with 8 hardware queues and RCCL's queues live EVERY
+    kernel of the data-parallel step starts ~40 us late (prologue 5 -> 48 us, loss 17 -> 56 us in a kernel trace; step 1.20 ->
+    1.86 ms) whatever the stream layout or stream priorities - the command processor's queue switching, not an ordering problem
+    this code could fix.  ROCm's default (4) and 2 do not show it.  Round 4 only warned; a launcher or a harness that exports the
+    variable would have made the first scaling curve ever measured read 50 % low, so it is overridden (and logged).  Returns what
+    happened ("lowered" / "too late: HIP already initialised" / None)."""
+    hwq = os.environ.get("GPU_MAX_HW_QUEUES")
+    if hwq is None or not hwq.strip().isdigit() or int(hwq) <= limit:
+        return None
+    import logging
+
+    if torch.cuda.is_initialized():
+        logging.warning("GPU_MAX_HW_QUEUES=%s and the HIP runtime is already initialised: the data-parallel step runs ~50 %% slower "
+                        "above %d hardware queues on MI355X (nesvor_amd/ddp.py); export GPU_MAX_HW_QUEUES=%d before launching", hwq, limit, limit)
+        return "too late: HIP already initialised"
+    os.environ["GPU_MAX_HW_QUEUES"] = str(limit)
+    logging.warning("GPU_MAX_HW_QUEUES=%s lowered to %d for this process (above %d every kernel of the data-parallel step starts ~40 us "
+                    "late on MI355X: nesvor_amd/ddp.py)", hwq, limit, limit)
+    return "lowered"
+
+
 def init_distributed(backend: Optional[str] = None):
     """Initialise from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
     Returns (rank, local_rank, world_size).  No-op single-process fallback when WORLD_SIZE is unset."""
@@ -42,16 +65,7 @@ def init_distributed(backend: Optional[str] = None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if (world > 1 or forced()) and not dist.is_initialized():
-        hwq = os.environ.get("GPU_MAX_HW_QUEUES")
-        if hwq is not None and hwq.isdigit() and int(hwq) > 4:
-            # measured (tools/ddp_queue_probe.sh, profiles/r04_ddp_queue_probe.log): with 8 hardware queues and RCCL's queues
-            # live EVERY kernel of the step starts ~40 us late (prologue 5 -> 48 us, loss 17 -> 56 us in a kernel trace; step
-            # 1.24 -> 1.86 ms) whatever the stream layout or stream priorities - the command processor's queue switching, not
-            # an ordering problem of this code.  ROCm's default (4) does not show it.
-            import logging
-
-            logging.warning("GPU_MAX_HW_QUEUES=%s: the data-parallel step runs ~50 %% slower above 4 hardware queues on MI355X "
-                            "(see nesvor_amd/ddp.py); unset it or use 4", hwq)
+        cap_hw_queues()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:

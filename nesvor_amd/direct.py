@@ -119,6 +119,7 @@ class DirectStep:
         self._kernel_noise = os.environ.get("NESVOR_PSF_NOISE", "kernel") != "tensor"
         self._noise_stream, self._noise_calls = 0x5851F42D4C957F2D, 0  # stream id of the training draws, calls so far
         self._native = {}  # batch size -> (StepT, handle, buffers) of the one-call iteration (csrc/step.hip)
+        self._native_timing, self._last_state = False, None
         self._native_on = os.environ.get("NESVOR_STEP_NATIVE", "1") != "0"
         self.split_level = 0  # 0 = one launch; set by set_overlap() once a gradient all-reduce is installed
         self._split_candidate = 0
@@ -267,7 +268,29 @@ class DirectStep:
         if not handle:
             raise RuntimeError("nesvor_step_create failed")
         st = self._native[key] = {"desc": d, "handle": ctypes.c_void_p(handle), "buf": buf, "ws": None}
+        if self._native_timing:
+            _lib.check(_lib.load().nesvor_step_timing(st["handle"], 1), "step timing")
         return st
+
+    # names of the spans nesvor_step_timing_read returns (NESVOR_STEP_SPAN_*), in order
+    TIMED_SPANS = ("psf_transform_fwd", "hashgrid_fwd", "mlp_fwd_density", "mlp_fwd_sigma", "imaging_loss_bwd", "mlp_bwd_sigma",
+                   "mlp_bwd_density", "hashgrid_bwd_aggregate", "hashgrid_bwd_owner", "psf_transform_bwd")
+
+    def set_native_timing(self, on: bool) -> None:
+        """HIP-event brackets around the launches of the one-call step, each on the stream its launch goes to (``nesvor_step_timing``:
+        the product launches themselves are timed - the owner pass with its fused AdamW on the side stream)."""
+        self._native_timing = bool(on)
+        for st in self._native.values():
+            _lib.check(_lib.load().nesvor_step_timing(st["handle"], int(on)), "step timing")
+
+    def read_native_timing(self):
+        """{span name: ms} of the LAST one-call step (waits for it); spans that did not occur are left out."""
+        st = self._last_state
+        if st is None:
+            return {}
+        out = (ctypes.c_float * len(self.TIMED_SPANS))()
+        _lib.check(_lib.load().nesvor_step_timing_read(st["handle"], out), "step timing read")
+        return {k: float(v) for k, v in zip(self.TIMED_SPANS, out) if v >= 0}
 
     def _run_native(self, xyz, v, slice_idx, adam=None, defer_table_join=False) -> Dict[str, torch.Tensor]:
         from .encoding import _workspace, queue_sizer
@@ -323,6 +346,7 @@ class DirectStep:
                 _lib.check(lib.nesvor_step_run(*args, 0 | (_lib.STEP_DEFER_JOIN if defer else 0), 0, a_ptr, stream), "training step")
                 self._owner_pending = bool(d.overlap_owner & 1) and (adam is None or defer)
         self._pending_state = st if self._owner_pending else None
+        self._last_state = st
         sizer.snapshot(ws)
         losses = {D_LOSS: vals[0]}
         if self.has_var:

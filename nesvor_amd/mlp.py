@@ -212,8 +212,8 @@ def prepare(d, xa, xb, dy, N, what, prep=None):
 
 def compact_save(d, N: int) -> bool:
     """Whether a training forward of descriptor ``d`` over N samples saves compactly (``nesvor_mlp_t.compact_save``): one
-    sign bit per hidden unit and sample (16 N bytes in ``saved[0]``) plus the values of the hidden layers after the first;
-    the backward recomputes the first hidden layer.  Host-side logic of the library (no device work)."""
+    sign bit per hidden unit and sample (16 N bytes in ``saved[0]``) and nothing else; the backward recomputes the hidden
+    layers.  Host-side logic of the library (no device work)."""
     return FUSED_BACKWARD and bool(_lib.load().nesvor_mlp_compact_save_ok(ctypes.byref(d), N))
 
 
@@ -231,7 +231,9 @@ def saved_sizes(d, N: int, n_hidden: int):
     n_pad = (N + 15) // 16 * 16
     sizes = [n_pad * 64] * n_hidden
     if n_hidden and compact_save(d, N):
-        sizes[0] = n_pad * 4  # one uint32 per (16-sample group, lane)
+        # one uint32 per (16-sample group, lane): the gate bits of every hidden layer; the backward recomputes the values
+        # (the other slots are placeholders: the kernels do not touch them)
+        sizes = [n_pad * 4] + [16] * (n_hidden - 1)
     return sizes
 
 

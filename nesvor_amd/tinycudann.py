@@ -52,11 +52,14 @@ class Encoding(nn.Module):
         return out.to(self.dtype)
 
 
-# tinycudann's activation names (network_config["activation"] / ["output_activation"]) on the library-GEMM fallback
+# tinycudann's activation names (network_config["activation"] / ["output_activation"]) on the library-GEMM fallback.  Only the
+# names whose definitions need no recollection of tiny-cuda-nn's source are offered (the package is absent from /root/reference
+# and from this image: SURVEY 8c): its Softplus / Squareplus are, as far as recalled, scaled variants (K_ACT = 10) - a config
+# that names them is REFUSED rather than silently evaluated as another function (advisor, round 4).  NeSVoR itself uses ReLU
+# and None only (models.py:30-41).
 _ACTIVATIONS = {
     "None": lambda t: t, "ReLU": torch.relu, "LeakyReLU": lambda t: torch.nn.functional.leaky_relu(t, 0.01),
-    "Exponential": torch.exp, "Sigmoid": torch.sigmoid, "Tanh": torch.tanh, "Softplus": torch.nn.functional.softplus,
-    "Squareplus": lambda t: 0.5 * (t + torch.sqrt(t * t + 4.0)), "Sine": torch.sin,
+    "Exponential": torch.exp, "Sigmoid": torch.sigmoid, "Tanh": torch.tanh, "Sine": torch.sin,
 }
 
 

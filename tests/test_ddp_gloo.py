@@ -146,3 +146,20 @@ def test_sharded_exchange_equals_allreduce_then_full_update(tmp_path):
     g = torch.Generator().manual_seed(7)
     grads = [torch.randn(80, generator=g) for _ in range(2)]
     torch.testing.assert_close(torch.load(out), -0.1 * sum(grads))
+
+
+def test_cap_hw_queues_overrides_before_hip_initialises(monkeypatch):
+    """``GPU_MAX_HW_QUEUES`` above 4 makes every kernel of the data-parallel step start ~40 us late on MI355X
+    (profiles/r04_ddp_queue_probe*.log): ``ddp.init_distributed`` lowers it before the HIP runtime reads it (round 4 only warned)."""
+    import torch
+
+    from nesvor_amd import ddp
+
+    if torch.cuda.is_initialized():
+        pytest.skip("the HIP runtime is already up in this process")
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    assert ddp.cap_hw_queues() == "lowered" and os.environ["GPU_MAX_HW_QUEUES"] == "4"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
+    assert ddp.cap_hw_queues() is None and os.environ["GPU_MAX_HW_QUEUES"] == "2"
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    assert ddp.cap_hw_queues() is None and "GPU_MAX_HW_QUEUES" not in os.environ

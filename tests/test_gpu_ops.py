@@ -1149,6 +1149,61 @@ def test_fused_mlp_is_reproducible_at_full_size(device, k_a, k_b, b_row0, rows, 
                 assert torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize("mode", ["fp32_mfma", "split"])
+@pytest.mark.parametrize("depth", [1, 2])
+@pytest.mark.parametrize("k_in", [16, 32, 48, 64])
+def test_fused_mlp_every_pipelined_instantiation_is_reproducible_and_right(device, k_in, depth, mode):
+    """The advisor's round-4 finding on the loads the pipelined kernels keep in flight in registers the compiler knows nothing
+    about: one bit-reproducibility test of ONE instantiation does not notice the hazard coming back in another (a register
+    move between a request and its wait; seen in round 4 as random wrong 16-sample groups).  Every instantiation the launchers
+    take - 1 and 2 hidden layers, fp32 MFMAs and the split mode, 1..4 input blocks - at N = 2^18: three runs of forward +
+    backward agree BIT FOR BIT, and outputs, input gradient and parameter gradients agree with an fp64 evaluation (a stale
+    register gives whole groups of O(1) errors; fp32 rounding is 1e-6)."""
+    from nesvor_amd import mlp
+    from nesvor_amd.models import build_network
+
+    torch.manual_seed(k_in + depth)
+    N, S, out_dim = 1 << 18, 256, 16
+    net = build_network(n_input_dims=k_in, n_output_dims=out_dim, activation="ReLU", output_activation="None",
+                        n_neurons=64, n_hidden_layers=depth, dtype=torch.float32).to(device)
+    L = mlp.linear_layers(net)
+    W, Bs = [l.weight.detach() for l in L], [l.bias.detach() for l in L]
+    xb = torch.randn(k_in, N, device=device)
+    dy = torch.randn(out_dim, N, device=device)
+    m = mlp.MFMA_FP32 if mode == "fp32_mfma" else mlp.SPLIT
+    runs = []
+    for _ in range(3):
+        y, saved = mlp.forward_raw(W, Bs, None, xb, 0, k_in, S, True, m)
+        dxb = torch.empty(k_in, N, device=device)
+        _, partial = mlp.backward_raw(W, Bs, None, xb, dy, saved, 0, k_in, S, dxb, False, m)
+        runs.append((y.clone(), dxb.clone(), partial.sum(0)))
+    for other in runs[1:]:
+        for a_, b_ in zip(runs[0], other):
+            assert torch.equal(a_, b_)
+    Wd, Bd = [w.double() for w in W], [b.double() for b in Bs]
+    acts, pre = [xb.t().double()], []
+    for i in range(depth):
+        pre.append(acts[-1] @ Wd[i].t() + Bd[i])
+        acts.append(pre[-1].relu())
+    y_ref = (acts[-1] @ Wd[depth].t() + Bd[depth]).t()
+    d = dy.t().double()
+    grads = {}
+    for i in range(depth, -1, -1):
+        grads[i] = torch.cat([(d.t() @ acts[i]).reshape(-1), d.sum(0)])
+        if i > 0:
+            d = (d @ Wd[i]) * (pre[i - 1] > 0)
+    dx_ref = (d @ Wd[0]).t()
+    gw_ref = torch.cat([grads[i] for i in range(depth + 1)])
+    y, dxb, gw = runs[0]
+    rel = lambda a_, b_: float((a_.double() - b_).abs().max() / b_.abs().max())
+    # (a quarter of a million samples: a few pre-activations within rounding of zero flip their gate against fp64 - those
+    #  samples' input gradients are off by O(1); everything else is fp32 rounding)
+    bad = (dxb.double() - dx_ref).abs().amax(0) > 1e-5 * dx_ref.abs().max()
+    assert rel(y, y_ref) < 2e-6 and int(bad.sum()) <= 16
+    assert float((dxb.double() - dx_ref)[:, ~bad].abs().max() / dx_ref.abs().max()) < 2e-6
+    assert float((gw.double() - gw_ref).norm() / gw_ref.norm()) < 1e-3
+
+
 @pytest.mark.parametrize("k_a,k_b,b_row0,rows,depth,out_dim,S,N", [
     (0, 32, 0, 32, 2, 16, 256, 1 << 16),   # density_net
     (16, 15, 1, 16, 2, 1, 256, 1 << 16),   # sigma_net (pixel-feature block + ragged row block)
@@ -1156,11 +1211,11 @@ def test_fused_mlp_is_reproducible_at_full_size(device, k_a, k_b, b_row0, rows, 
     (0, 16, 0, 16, 2, 16, 16, 1 << 14),    # one input block
 ])
 def test_fused_mlp_compact_save(device, k_a, k_b, b_row0, rows, depth, out_dim, S, N, monkeypatch):
-    """``nesvor_mlp_t.compact_save`` (sign bits of the hidden layers + the values of the layers after the first; the backward
-    recomputes the first hidden layer in the dW waves) against the full save of the same kernels: outputs and input
-    gradients BIT FOR BIT (the dX chain sees the same gates; to fp32 rounding for networks with one output row, whose output
-    layer the compact kernels evaluate on the VALU), parameter gradients to fp32 rounding of the recomputed layer;
-    the saved buffers really are the small ones."""
+    """``nesvor_mlp_t.compact_save`` (round 5: the sign bits of the hidden layers and nothing else; the backward recomputes
+    every hidden layer in its dW waves) against the full save of the same kernels: outputs and input gradients BIT FOR BIT
+    (the dX chain sees the same gates; to fp32 rounding for networks with one output row, whose output layer the compact
+    kernels evaluate on the VALU), parameter gradients to fp32 rounding of the recomputed layers; the saved buffers really
+    are the small ones."""
     from nesvor_amd import mlp
     from nesvor_amd.models import build_network
 
@@ -1178,7 +1233,7 @@ def test_fused_mlp_compact_save(device, k_a, k_b, b_row0, rows, depth, out_dim, 
         if not compact:
             monkeypatch.setattr(mlp, "compact_save", lambda d, n: False)
         y, saved = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, True)
-        assert (saved[0].numel() == N * 4) == compact and all(t.numel() == N * 64 for t in saved[1:])
+        assert (saved[0].numel() == N * 4) == compact and all(t.numel() == (16 if compact else N * 64) for t in saved[1:])
         dxb = torch.empty(k_b, N, device=device)
         dxa, partial = mlp.backward_raw(W, Bs, xa, xb, dy, saved, b_row0, k_b, S, dxb, xa is not None)
         res[compact] = (y, dxb, dxa, partial.sum(0), saved)
@@ -1196,8 +1251,6 @@ def test_fused_mlp_compact_save(device, k_a, k_b, b_row0, rows, depth, out_dim, 
     # the masks are the forward's: bit 16 l + 4 b + r of word (group, lane = 16 q + sample) = [h_l > 0] of unit 16 b + 4 q + r
     words = res[True][4][0].view(torch.int32).view(N // 16, 4, 16)  # [group][q][sample]
     saved_full = res[False][4]
-    if depth == 2:
-        assert torch.equal(res[True][4][1], saved_full[1])
     for l in range(depth):
         h = saved_full[l].view(N // 16, 4, 4, 16, 4)  # [group][block b][q][sample][r]
         for b in range(4):
