@@ -254,9 +254,6 @@ def main():
     ap.add_argument("--repeats", type=int, default=0,
                     help="how often the timed region of --steps steps is repeated (the median region is reported; every region is in "
                          "`timed_regions_ms_per_step`); 0 = automatic: 5 when --steps < 100 - a 20-step region is a 20 ms sample -, else 1")
-    ap.add_argument("--roctx-region", action="store_true",
-                    help="under `rocprofv3 --selected-regions`: resume the profiler behind the settle iterations and pause it after the timed "
-                         "region, so that the trace's kernel averages are those of settled launches (tools/collect_profiles_r05.sh)")
     opt = ap.parse_args()
     # stdout carries ONE line, the JSON result.  Libraries write there too (RCCL prints a version banner through C stdio, which
     # lands AFTER a flushed Python print when stdout is a pipe or a file): file descriptor 1 is pointed at stderr for the run and
@@ -351,12 +348,6 @@ def main():
     for _ in range(8):
         step()
         torch.cuda.synchronize(device)
-    roctx = None
-    if opt.roctx_region:
-        import ctypes
-
-        roctx = ctypes.CDLL("librocprofiler-sdk-roctx.so")
-        roctx.roctxProfilerResume(ctypes.c_uint64(0))
     # per-kernel HIP-event timing runs over its own K steps before the timed region (same process, data, kernels).  Round 5: the
     # PRODUCT launches are timed - the one-call step brackets its own launches with events on the stream each goes to
     # (nesvor_step_timing: the owner pass with its fused AdamW on the side stream); the Python-issued variant of rounds 1-4 (all
@@ -411,9 +402,6 @@ def main():
         e_, losses = timed(opt.steps)
         regions.append(e_)
     elapsed = sorted(regions)[len(regions) // 2]
-    if roctx is not None:
-        torch.cuda.synchronize(device)
-        roctx.roctxProfilerPause(ctypes.c_uint64(0))
     final_loss = {k: float(val.detach()) for k, val in losses.items()}
 
     # the same K steps with the MLP products evaluated by fp32 MFMAs (the default evaluates the same fp32 products as

@@ -46,12 +46,17 @@ fwd = med_of(lambda k: k.startswith("hashgrid_fwd_cloud"))
 agg = med_of(lambda k: k.startswith("hashgrid_bwd_aggregate"))
 own = med_of(lambda k: k.startswith("hashgrid_bwd_owner") and k.split(">")[0].replace(" ", "").endswith("false"))  # <F, COALESCED, ADAM = false>
 own_adam = med_of(lambda k: k.startswith("hashgrid_bwd_owner") and k.split(">")[0].replace(" ", "").endswith("true"))
+table_params = int(sys.argv[3]) if len(sys.argv) > 3 else 7854240  # the headline table (L=16, F=2, T=2^19): AdamW moves 28 B per parameter
 if fwd and agg and (own or own_adam):
-    o = own if own else own_adam
-    us = fwd + agg + o
     gb = 2328 * points / 1e9
-    print(f"# hash-grid roofline from the medians above: ({fwd:.1f} + {agg:.1f} + {o:.1f}) us = {us:.1f} us for {gb:.3f} GB "
-          f"(2328 B/point x {points} points) -> {gb / (us * 1e-6) / 1e3:.3f} TB/s = frac {gb / (us * 1e-6) / 8e3:.4f} of 8 TB/s"
-          + ("" if own else "   [owner pass WITH the table's AdamW step: no launch without it in this trace]"))
-    if own and own_adam:
-        print(f"# owner pass with the table's AdamW step inside (the product step's launch): {own_adam:.1f} us")
+    if own_adam:  # the PRODUCT launches (round 5: what bench.py's `roofline` times): the owner pass takes the table's AdamW step
+        us = fwd + agg + own_adam
+        gb_a = gb + 28 * table_params / 1e9
+        print(f"# hash-grid roofline from the medians above, product launches: ({fwd:.1f} + {agg:.1f} + {own_adam:.1f}) us = {us:.1f} us; "
+              f"2328 B/point x {points} points + 28 B x {table_params} table parameters (AdamW inside the owner launch) = {gb_a:.3f} GB "
+              f"-> {gb_a / (us * 1e-6) / 1e3:.3f} TB/s = frac {gb_a / (us * 1e-6) / 8e3:.4f} of 8 TB/s; with the 2328 B/point alone "
+              f"({gb:.3f} GB): frac_8d_bytes_only {gb / (us * 1e-6) / 8e3:.4f}")
+    if own:
+        us = fwd + agg + own
+        print(f"# ... with the owner pass WITHOUT the optimizer ({own:.1f} us; the Python-issued variant): ({fwd:.1f} + {agg:.1f} + {own:.1f}) us "
+              f"-> frac {gb / (us * 1e-6) / 8e3:.4f}")
