@@ -345,3 +345,28 @@ def test_slice_acq_interp_psf_restatement_is_self_consistent():
         # a tap that crosses a rounding or support boundary inside +-eps makes F jump: compare slice by slice, allow one outlier
         err = (fd - gt[:, k, 3]).abs() / (gt[:, k, 3].abs() + 1e-3)
         assert int((err > 1e-4).sum()) <= 1, (k, fd, gt[:, k, 3])
+
+
+def test_bias_field_cost_in_the_oracle_pair():
+    """Round-4 verdict, weak item 2: on HIP the bias field (n_levels_bias = 4) cost the DENSITY's PSNR 1.85 dB at 128^3 (6 stacks,
+    5000 iterations of 4096 x 256) and nothing showed that the reference-equivalent path does the same.  Two committed oracle
+    runs (tests/golden/make_oracle_run.py --preset c5_long / c5_nobias_long: 6 stacks, 2000 iterations of 1024 x 64, same seeds)
+    settle it on the CPU side: WITH the field the whole-object PSNR of the density is lower (15.29 vs 15.70 dB) while the
+    interior - soft tissue without the skull shell - is BETTER (24.44 vs 23.29 dB): b_net takes over smooth intensity structure,
+    sample_volume returns the density alone (sample.py:17-33), and the thin bright shell pays.  The HIP runs replay both
+    fixtures within 0.1 dB (tests/test_gpu_fullsize.py::test_baseline_configs_oracle_runs_replayed_by_hip): the cost is a
+    property of the model, not a defect of the kernels."""
+    import os
+
+    import numpy as np
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    on, off = np.load(os.path.join(here, "oracle_run_c5_long.npz")), np.load(os.path.join(here, "oracle_run_c5_nobias_long.npz"))
+    assert list(on["config"][:6]) == list(off["config"][:6]) and int(on["config"][0]) == 2000 and int(on["config"][4]) == 6
+    assert float(on["config_ext"][3]) == 4 and float(off["config_ext"][3]) == 0
+    cost = float(off["psnr_whole_db"]) - float(on["psnr_whole_db"])
+    gain_interior = float(on["psnr_interior_db"]) - float(off["psnr_interior_db"])
+    print(f"oracle pair: whole object {float(off['psnr_whole_db']):.3f} -> {float(on['psnr_whole_db']):.3f} dB with the bias field (cost {cost:.3f}), "
+          f"interior {float(off['psnr_interior_db']):.3f} -> {float(on['psnr_interior_db']):.3f} dB (gain {gain_interior:.3f})")
+    assert 0.2 <= cost <= 1.0 and 0.5 <= gain_interior <= 2.0
+    assert "biasReg" in [str(k) for k in on["loss_keys"]] and "biasReg" not in [str(k) for k in off["loss_keys"]]
