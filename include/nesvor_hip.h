@@ -257,6 +257,12 @@ int nesvor_psf_transform_forward_rng_gather(const float* mat, const int64_t* sli
 int nesvor_psf_transform_backward_rng(const float* mat, const int64_t* slice_idx, const float* xyz, const float* sigma,
                                       uint64_t seed, uint64_t offset, const float* bb, const float* dx, const float* du,
                                       float* dmat, int B, int S, void* stream);
+/* The same backward; every pixel's gradient is also (dpix non-NULL) or only (dpix NULL) ADDED to row slice_idx[b] of dmat_slice
+ * (n,3,4) - the caller zero-fills it -, i.e. the index_add over slice_idx the reference's autograd performs, without a second
+ * launch over dpix. */
+int nesvor_psf_transform_backward_rng_slices(const float* mat, const int64_t* slice_idx, const float* xyz, const float* sigma,
+                                             uint64_t seed, uint64_t offset, const float* bounding_box, const float* dx,
+                                             const float* du, float* dpix, float* dmat_slice, int B, int S, void* stream);
 int nesvor_psf_noise(uint64_t seed, uint64_t offset, float* out, int64_t n_samples, void* stream);
 
 /* ------------------------------------------------------------------------

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void psf_transform_bwd(const float* __restrict
                                                          const float* __restrict__ xyz, const float* __restrict__ sigma,
                                                          const NoiseSource noise, const float* __restrict__ bb,
                                                          const float* __restrict__ dx, const float* __restrict__ du,
-                                                         float* __restrict__ dmat, int B, int S) {
+                                                         float* __restrict__ dmat, int B, int S,
+                                                         float* __restrict__ dmat_slice = nullptr) {  // optional (n,3,4): the pixel's gradient ADDED to its slice's
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -130,7 +131,8 @@ __global__ __launch_bounds__(256) void psf_transform_bwd(const float* __restrict
     float v = g[0];
 #pragma unroll
     for (int i = 1; i < 12; ++i) v = lane == i ? g[i] : v;
-    dmat[(size_t)b * 12 + lane] = v;
+    if (dmat != nullptr) dmat[(size_t)b * 12 + lane] = v;
+    if (dmat_slice != nullptr) atomicAdd(dmat_slice + k * 12 + lane, v);
   }
 }
 
@@ -184,6 +186,17 @@ extern "C" int nesvor_psf_transform_backward_rng(const float* mat, const int64_t
   if (B <= 0 || S <= 0) return 0;
   hipLaunchKernelGGL(psf_transform_bwd, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, mat, slice_idx, xyz, sigma,
                      NoiseSource{nullptr, seed, offset}, bb, dx, du, dmat, B, S);
+  return (int)hipGetLastError();
+}
+
+// ... that ALSO (or only: dpix may be NULL) adds every pixel's gradient to its slice's row of dmat_slice (n,3,4) - the index_add of
+// the reference's autograd (transform.py:274-280 through slice_idx), without a second launch over dpix
+extern "C" int nesvor_psf_transform_backward_rng_slices(const float* mat, const int64_t* slice_idx, const float* xyz, const float* sigma,
+                                                        uint64_t seed, uint64_t offset, const float* bb, const float* dx, const float* du,
+                                                        float* dpix, float* dmat_slice, int B, int S, void* stream) {
+  if (B <= 0 || S <= 0) return 0;
+  hipLaunchKernelGGL(psf_transform_bwd, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, mat, slice_idx, xyz, sigma,
+                     NoiseSource{nullptr, seed, offset}, bb, dx, du, dpix, B, S, dmat_slice);
   return (int)hipGetLastError();
 }
 

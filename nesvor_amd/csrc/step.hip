@@ -26,7 +26,7 @@ namespace {
 
 struct StepCtx {
   nesvor_step_t d;
-  hipEvent_t ev_fork, ev_pose, ev_agg, ev_owner, ev_bwd, ev_sums, ev_norms;
+  hipEvent_t ev_fork, ev_pose, ev_agg, ev_owner, ev_bwd, ev_sums, ev_norms, ev_sg0, ev_sg1;
   bool sums_on_side = false;  // the networks' parameter-gradient sums of the current iteration were left on the side stream
   bool pending_join = false;  // a table update of the previous run is still on the side stream (NESVOR_STEP_DEFER_JOIN)
   // nesvor_step_timing: HIP-event brackets around the PRODUCT launches of a run, each pair on the stream its launch goes to
@@ -106,7 +106,7 @@ extern "C" void* nesvor_step_create(const nesvor_step_t* desc) {
   StepCtx* c = new (std::nothrow) StepCtx;
   if (c == nullptr) return nullptr;
   c->d = *desc;
-  hipEvent_t* evs[7] = {&c->ev_fork, &c->ev_pose, &c->ev_agg, &c->ev_owner, &c->ev_bwd, &c->ev_sums, &c->ev_norms};
+  hipEvent_t* evs[9] = {&c->ev_fork, &c->ev_pose, &c->ev_agg, &c->ev_owner, &c->ev_bwd, &c->ev_sums, &c->ev_norms, &c->ev_sg0, &c->ev_sg1};
   for (hipEvent_t* e : evs) {
     if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
   }
@@ -152,6 +152,7 @@ extern "C" void nesvor_step_destroy(void* handle) {
   StepCtx* c = static_cast<StepCtx*>(handle);
   (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_pose); (void)hipEventDestroy(c->ev_agg); (void)hipEventDestroy(c->ev_owner);
   (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_sums); (void)hipEventDestroy(c->ev_norms);
+  (void)hipEventDestroy(c->ev_sg0); (void)hipEventDestroy(c->ev_sg1);
   for (int k = 0; k < NESVOR_STEP_TIMED_SPANS; ++k) {
     if (c->t0[k] != nullptr) (void)hipEventDestroy(c->t0[k]);
     if (c->t1[k] != nullptr) (void)hipEventDestroy(c->t1[k]);
@@ -200,6 +201,23 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   const bool fuse_adamw = adam != nullptr && phase == 0 && (d.overlap_owner & 2) != 0 && d.table != nullptr && d.flat_param != nullptr &&
                           d.g_table == d.flat_grad + table_off && table_off >= 0 && table_off < d.flat_numel;
 
+  const int group_sums_sg = (N % 16 == 0 && S % 16 == 0 && d.ks % 16 == 0) ? 1 : 0;
+  const int rows_per_pixel = group_sums_sg ? S / 16 : S;
+  const float* dxa_first = (d.has_lv && d.ks) ? d.dxa : ((d.has_b && d.ks) ? d.dxa_b : nullptr);
+  // NESVOR_SLICE_GRADS=by_slice: one workgroup per slice, no atomics, reproducible sums (where the batch fits its pixel list).
+  // Default: the per-pixel atomic kernel - measured 1.136-1.140 ms per iteration against 1.152-1.160: a few hundred workgroups
+  // with serial sums start behind the owner pass's workgroups and finish later (61 us) than 4096 x 30 contended atomics (46 us)
+  auto slice_grads = [&](const float* dc_pix, const float* dlvs_pix, const float* dxa, const float* dpix, float* dc_, float* dlvs_,
+                         float* dse_, float* dmat_, hipStream_t st_) -> int {
+    static const bool by_slice = []() { const char* e = getenv("NESVOR_SLICE_GRADS"); return e != nullptr && strcmp(e, "by_slice") == 0; }();
+    if (by_slice) {
+      const int e = nesvor_slice_grads_by_slice(slice_idx, dc_pix, dlvs_pix, dxa, dpix, dc_, dlvs_, dse_, dmat_, B, rows_per_pixel, d.ks, n, st_);
+      if (e != (int)hipErrorInvalidValue) return e;
+    }
+    return nesvor_slice_grads(slice_idx, dc_pix, dlvs_pix, dxa, dpix, dc_, dlvs_, dse_, dmat_, B, rows_per_pixel, d.ks, st_);
+  };
+  // (the bias field's second consumer of the slice embedding keeps round 4's single launch behind the sampler backward)
+  const bool early_sg = overlap_owner && !d.has_b;
   if (ctx->timing) { for (int k = 0; k < NESVOR_STEP_TIMED_SPANS; ++k) ctx->span_used[k] = false; ctx->timed_run = true; }
   if (phase != 2) {
     // ---- forward
@@ -290,6 +308,16 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
       NESVOR_TRY(mlp_backward_into(net_s, group_sums, d.se, d.z, d.dlv, d.saved_s, d.ks ? d.dxa : nullptr, d.dz + N, part_s,
                                    d.g_sigma, d.n_sigma_params, N, main, prep_d + NESVOR_MLP_PREP_DY));  // (a scalar publish: slot 0)
     }
+    // Per-slice sums that do not depend on the hash-grid backward - d slice scale, d slice variance and the slice embedding's
+    // gradient (sigma_net's input gradient) - go to the side stream NOW, under the density network's backward and the aggregation
+    // pass; the pose matrices' share is added by the sampler backward itself (nesvor_psf_transform_backward_rng_slices).  Round 4
+    // ran one slice_grads launch behind the sampler backward: 46 us of the step's serial tail next to the owner pass.
+    if (early_sg) {
+      if (hipEventRecord(ctx->ev_sg0, main) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_sg0, 0) != hipSuccess) return (int)hipGetLastError();
+      NESVOR_TRY(slice_grads(d.has_c ? d.pix : nullptr, d.has_lvs ? d.pix + B : nullptr, (d.has_lv && d.ks) ? d.dxa : nullptr, nullptr, dc,
+                             d.has_lvs ? d.g_log_var_slice : nullptr, d.ks ? d.g_slice_embedding : nullptr, nullptr, side));
+      if (hipEventRecord(ctx->ev_sg1, side) != hipSuccess) return (int)hipGetLastError();
+    }
     {
       Span t(ctx, NESVOR_STEP_SPAN_MLP_BWD_DENSITY, main);
       NESVOR_TRY(mlp_backward_into(net_d, 0, nullptr, d.pe, d.dz, d.saved_d, nullptr, d.dpe, part_d, d.g_density,
@@ -371,28 +399,19 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   }
   if (d.opt_T) {
     Span t(ctx, NESVOR_STEP_SPAN_PSF_BWD, main);
-    NESVOR_TRY(nesvor_psf_transform_backward_rng(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.dxl, du, d.dpix, B, S, main));
+    if (early_sg)  // the pixels' pose gradients straight into their slices' rows
+      NESVOR_TRY(nesvor_psf_transform_backward_rng_slices(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.dxl, du, nullptr, dmat, B, S, main));
+    else
+      NESVOR_TRY(nesvor_psf_transform_backward_rng(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.dxl, du, d.dpix, B, S, main));
   }
-  // ---- per-slice parameters
-  const int group_sums = (N % 16 == 0 && S % 16 == 0 && d.ks % 16 == 0) ? 1 : 0;
-  const int rows_per_pixel = group_sums ? S / 16 : S;
-  const float* dxa_first = (d.has_lv && d.ks) ? d.dxa : ((d.has_b && d.ks) ? d.dxa_b : nullptr);
-  // NESVOR_SLICE_GRADS=by_slice: one workgroup per slice, no atomics, reproducible sums (where the batch fits its pixel list).
-  // Default: the per-pixel atomic kernel - measured 1.136-1.140 ms per iteration against 1.152-1.160: a few hundred workgroups
-  // with serial sums start behind the owner pass's workgroups and finish later (61 us) than 4096 x 30 contended atomics (46 us)
-  auto slice_grads = [&](const float* dc_pix, const float* dlvs_pix, const float* dxa, const float* dpix, float* dc_, float* dlvs_,
-                         float* dse_, float* dmat_) -> int {
-    static const bool by_slice = []() { const char* e = getenv("NESVOR_SLICE_GRADS"); return e != nullptr && strcmp(e, "by_slice") == 0; }();
-    if (by_slice) {
-      const int e = nesvor_slice_grads_by_slice(slice_idx, dc_pix, dlvs_pix, dxa, dpix, dc_, dlvs_, dse_, dmat_, B, rows_per_pixel, d.ks, n, main);
-      if (e != (int)hipErrorInvalidValue) return e;
-    }
-    return nesvor_slice_grads(slice_idx, dc_pix, dlvs_pix, dxa, dpix, dc_, dlvs_, dse_, dmat_, B, rows_per_pixel, d.ks, main);
-  };
-  NESVOR_TRY(slice_grads(d.has_c ? d.pix : nullptr, d.has_lvs ? d.pix + B : nullptr, dxa_first, d.opt_T ? d.dpix : nullptr, dc,
-                         d.has_lvs ? d.g_log_var_slice : nullptr, d.ks ? d.g_slice_embedding : nullptr, dmat));
-  if (d.has_lv && d.has_b && d.ks)  // second consumer of the slice embedding
-    NESVOR_TRY(slice_grads(nullptr, nullptr, d.dxa_b, nullptr, nullptr, nullptr, d.g_slice_embedding, nullptr));
+  if (early_sg) {
+    if (hipStreamWaitEvent(main, ctx->ev_sg1, 0) != hipSuccess) return (int)hipGetLastError();
+  } else {
+    NESVOR_TRY(slice_grads(d.has_c ? d.pix : nullptr, d.has_lvs ? d.pix + B : nullptr, dxa_first, d.opt_T ? d.dpix : nullptr, dc,
+                           d.has_lvs ? d.g_log_var_slice : nullptr, d.ks ? d.g_slice_embedding : nullptr, dmat, main));
+    if (d.has_lv && d.has_b && d.ks)  // second consumer of the slice embedding
+      NESVOR_TRY(slice_grads(nullptr, nullptr, d.dxa_b, nullptr, nullptr, nullptr, d.g_slice_embedding, nullptr, main));
+  }
   if (d.opt_T && hipStreamWaitEvent(main, ctx->ev_pose, 0) != hipSuccess) return (int)hipGetLastError();
   const float img_scale = (d.reg_type == 0 ? d.delta : 1.f) / (float)N, img_off = d.reg_type == 0 ? -d.delta : 0.f;
   NESVOR_TRY(nesvor_step_epilogue(d.has_c ? dc : nullptr, c, d.has_c ? d.g_logit_coef : nullptr, d.opt_T ? dmat : nullptr, d.axisangle,
