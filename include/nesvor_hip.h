@@ -368,6 +368,10 @@ int nesvor_mlp_compact_save_ok(const nesvor_mlp_t* net, int64_t N);
 
 int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, const float* xb, float* y,
                        float* const* saved_hidden, int64_t N, void* stream);
+/* 1 if (net, N) is a shape the fused backward takes - dX, dW and db in ONE wave-specialised launch, no dpre scratch (pass NULL
+ * entries): N, samples_per_pixel and k_a multiples of 16, at most two hidden layers, at most two 16-row input blocks at two
+ * hidden layers.  0: pass dpre_scratch[l] (N_pad16 * 64 floats each) and the backward runs as a dX launch + a dW launch. */
+int nesvor_mlp_backward_fused_ok(const nesvor_mlp_t* net, int64_t N);
 int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, const float* xb, const float* dy,
                         float* const* saved_hidden, float* const* dpre_scratch, float* dxa, float* dxb,
                         float* dw_partial, int n_partial, int64_t N, void* stream);

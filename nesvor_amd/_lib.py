@@ -137,6 +137,7 @@ _SIGNATURES = {
     "nesvor_psf_transform_backward_rng_slices": ([_P] * 4 + [c_uint64, c_uint64] + [_P] * 5 + [c_int, c_int, _P], c_int),
     "nesvor_psf_noise": ([c_uint64, c_uint64, _P, c_int64, _P], c_int),
     "nesvor_mlp_compact_save_ok": ([POINTER(MlpT), c_int64], c_int),
+    "nesvor_mlp_backward_fused_ok": ([POINTER(MlpT), c_int64], c_int),
     "nesvor_mlp_prepare": ([POINTER(MlpT), _P, _P, _P, c_int64, _P, c_int, _P], c_int),
     "nesvor_mlp_prepare_weights": ([_P, _P, c_int, _P, c_int64, _P, _P], c_int),
     "nesvor_mlp_forward": ([POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), c_int64, _P], c_int),

@@ -629,16 +629,6 @@ __device__ __forceinline__ uint32_t spread3(uint32_t x) {  // 8 bits -> every th
 // LDS: 2 x 64 counters, so occupancy is set by registers only.
 // float (|x| < 2^62, an integer after scaling by a power of two) <-> two's-complement 64-bit fixed point without the
 // compiler's generic f32<->i64 expansions (see to_fixed).
-#ifdef NESVOR_HG_OLDFIXED  // A/B: the floor-based split of rounds 1-2 (inexact for small negative values)
-__device__ __forceinline__ unsigned long long to_fixed(float x) {
-  const float t = floorf(x * 0x1p-32f);
-  const float r = fmaf(-t, 0x1p32f, x);
-  return ((unsigned long long)(uint32_t)(int32_t)t << 32) | (unsigned long long)(uint32_t)r;
-}
-__device__ __forceinline__ float from_fixed(unsigned long long q) {
-  return fmaf((float)(int32_t)(q >> 32), 0x1p32f, (float)(uint32_t)q);
-}
-#else
 __device__ __forceinline__ unsigned long long to_fixed(float x) {
   // hi = round(x / 2^32), lo = x - hi 2^32 in [-2^31, 2^31]: exact in fp32 for every x (a floor-based split is not: for a
   // small negative x it forms 2^32 + x, which needs 32 bits - harmless while the scale follows the workgroup's own maximum,
@@ -653,27 +643,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) {
   const uint32_t lo = (uint32_t)q;
   return fmaf((float)((int32_t)(q >> 32) + (int32_t)(lo >> 31)), 0x1p32f, (float)(int32_t)lo);
 }
-#endif
 
-// NESVOR_HG_PK_FIXED=1 (A/B build, off): two values at once (F = 2: the two features of a corner) - the scaling, the residual
-// and the corner weights as packed fp32 instructions (v_pk_mul_f32, v_pk_fma_f32): 326 instead of 361 VALU instructions per
-// level and wave in the box rounds, same arithmetic, bit-identical words - and the pass is SLOWER (round 4, one job, alternating:
-// 0.3010 -> 0.3083 ms in the step, 0.342 -> 0.348 isolated; profiles/r04_hashgrid_ab_packed_f32.log): a packed fp32
-// instruction is not a cheaper issue slot than the two it replaces on gfx950 (the forward's packed blend had shown the same:
-// 11 % fewer instructions, same time).
-#ifndef NESVOR_HG_PK_FIXED
-#define NESVOR_HG_PK_FIXED 0
-#endif
-typedef float hg_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void to_fixed2(hg_f32x2 x, unsigned long long (&q)[2]) {
-  const hg_f32x2 t = __builtin_elementwise_rint(x * 0x1p-32f);
-  const hg_f32x2 r = __builtin_elementwise_fma(-t, hg_f32x2{0x1p32f, 0x1p32f}, x);
-#pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const int32_t lo = __float2int_rn(r[f]);
-    q[f] = ((unsigned long long)(uint32_t)((int32_t)t[f] + (lo >> 31)) << 32) | (unsigned long long)(uint32_t)lo;
-  }
-}
 
 // NESVOR_FIXED32 (build macro, F == 2 only): a merge-table slot holds both features as two 32-bit fixed-point fields of one
 // 64-bit word (one ds_add_u64 per corner, 3 VALU instructions per value) instead of one 64-bit fixed-point word per
@@ -750,17 +720,6 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
   // through scratch memory): res, size, offset, hashed, queue capacity, first bucket, first record, chunks
   __shared__ uint32_t lpar[NESVOR_MAX_LEVELS + 1][8];
   __shared__ int32_t box_end_s;       // levels [level_begin, box_end) address the table by box slot
-#ifndef NESVOR_HG_TRANSPOSE
-#define NESVOR_HG_TRANSPOSE 0       // A/B build option: lane-transposed inserts for waves with at most this many run tails at a box level.
-                                    // Measured (round 4, one job, profiles/r04_hashgrid_ab_transposed_inserts.log): 8 / 16 / 24 -> pass 0.342 /
-                                    // 0.344 / 0.356 ms against 0.349 isolated, 0.304 / 0.313 against 0.302 in the step, per-level times unchanged:
-                                    // a coarse level's ~10 us is its latency chain (table copy reads -> scan -> adds, one level at a time at four
-                                    // waves per SIMD), not the 130 conversion instructions the transposed form removes.  Off.
-#endif
-  constexpr bool kTranspose = (F == 2) && !kPack && (NESVOR_HG_TRANSPOSE > 0);
-  constexpr int kTransMax = NESVOR_HG_TRANSPOSE;
-  constexpr int kStripStride = 20;    // floats per parked tail: 16 values, the first slot, padding (16-byte rows)
-  __shared__ __attribute__((aligned(16))) float tstage[4][kTranspose ? 4 * kStripStride : 1];
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t base = (int64_t)blockIdx.x * 256;
   const int E = g.n_levels * F;
@@ -794,35 +753,12 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
     // launch found - same samples, same key
     if (order_mode == 2) sv = (uint32_t)order[base + tid];
     else
-#ifndef NESVOR_SORT_BPERMUTE
 #pragma unroll 1
     for (int rep = 0; rep < (NESVOR_ABL(1) ? 2 : 1); ++rep) {
       if (rep) sv ^= 0x80000000u;  // (ablation: something to sort the second time)
       bitonic_sort<NESVOR_SORT_SPAN>(sv, tid, sortbuf);
       if (rep) sv ^= 0x80000000u;
     }
-#else
-#pragma unroll 1
-    for (int rep = 0; rep < (NESVOR_ABL(1) ? 2 : 1); ++rep)
-#pragma unroll 1
-    for (int k = 2; k <= NESVOR_SORT_SPAN; k <<= 1) {
-#pragma unroll 1
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        uint32_t other;
-        if (j < 64) {
-          other = __shfl_xor(sv, j, 64);
-        } else {
-          __syncthreads();
-          sortbuf[tid] = sv;
-          __syncthreads();
-          other = sortbuf[tid ^ j];
-        }
-        const bool up = (tid & k) == 0, lower = (tid & j) == 0;
-        const uint32_t mn = min(sv, other), mx = max(sv, other);
-        sv = (lower == up) ? mn : mx;
-      }
-    }
-#endif
   }
   if (order_mode == 1) order[base + tid] = (uint8_t)(sv & 255u);
   const int64_t i = base + (sv & 255u);  // the sample this lane owns from now on
@@ -1028,22 +964,11 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
     }
     {
       const float ax[2] = {1.f - c.wx, c.wx}, ay[2] = {1.f - c.wy, c.wy}, az[2] = {1.f - c.wz, c.wz};
-      if constexpr (F == 2 && NESVOR_HG_PK_FIXED) {
-        // the same products (ax ay) az and w dy as packed fp32 multiplies: 14 instructions instead of 28
-        const hg_f32x2 ax2 = {ax[0], ax[1]}, dy2 = {dy[0], dy[1]};
-#pragma unroll
-        for (int zy = 0; zy < 4; ++zy) {
-          const hg_f32x2 w2 = (ax2 * ay[zy & 1]) * az[zy >> 1];  // corners k = 2 zy, 2 zy + 1
-          const hg_f32x2 v0 = hg_f32x2{w2[0], w2[0]} * dy2, v1 = hg_f32x2{w2[1], w2[1]} * dy2;
-          val[2 * zy][0] = v0[0]; val[2 * zy][1] = v0[1]; val[2 * zy + 1][0] = v1[0]; val[2 * zy + 1][1] = v1[1];
-        }
-      } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float w = ax[k & 1] * ay[(k >> 1) & 1] * az[k >> 2];
 #pragma unroll
         for (int f = 0; f < F; ++f) val[k][f] = w * dy[f];
-      }
       }
     }
     // Segmented inclusive scan (a run = consecutive lanes of a 16-lane row in the same cell), on the VALU:
@@ -1101,15 +1026,8 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
       // ((int64)q1 << 32) + (int64)q0: the low field's sign borrows from the high field; undone when the slot is read
       atomicAdd(&tvals[slot], ((unsigned long long)(uint32_t)(q1 + (q0 >> 31)) << 32) | (unsigned long long)(uint32_t)q0);
     } else {
-      if constexpr (F == 2 && NESVOR_HG_PK_FIXED) {
-        unsigned long long q[2];
-        to_fixed2(hg_f32x2{v[0], v[1]} * fscale, q);
-        atomicAdd(&tvals[slot], q[0]);
-        atomicAdd(&tvals[kSlots + slot], q[1]);
-      } else {
 #pragma unroll
-        for (int f = 0; f < F; ++f) atomicAdd(&tvals[f * kSlots + slot], to_fixed(v[f] * fscale));
-      }
+      for (int f = 0; f < F; ++f) atomicAdd(&tvals[f * kSlots + slot], to_fixed(v[f] * fscale));
     }
   };
   // read + clear one slot; false: nothing was added (or everything cancelled exactly)
@@ -1204,35 +1122,10 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
         for (int f = 0; f < F; ++f) dy_a[f] = dy_b[f];
         if (lv + 2 < level_end) load_dy(lv + 2, dy_b);
         const float fs_lv = scale_of((uint32_t)lv);
-        // Few run tails in the wave (the coarse levels: 8-20 of 64 lanes, profiles/r04_tails_per_wave.log): the direct form
-        // below still issues its 16 LDS adds and ~130 fixed-point VALU instructions for the whole wave.  Lane-transposed
-        // form: four tails at a time park their 16 values (and first slot) in a per-wave LDS strip, then lane 16 t + 2 k + f
-        // converts and adds value (corner k, feature f) of tail t - one conversion and one add per FOUR tails.  The adds are
-        // integer adds of the same fixed-point words: bit-identical sums.  (LDS operations of a wave execute in order: the
-        // strip needs no barrier.)
-        const unsigned long long tmask = __ballot(tail);
-        const int n_tails = __builtin_popcountll(tmask);
-        if (kTranspose && !NESVOR_ABL(4) && n_tails <= kTransMax) {
-          const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tmask, 0u));
-          float* const strip = tstage[tid >> 6];
-          const int tl = lane >> 4, kf = lane & 15, kc = kf >> 1;
-          const uint32_t koff = (uint32_t)(kc & 1) + (uint32_t)((kc >> 1) & 1) * nx + (uint32_t)(kc >> 2) * nxy;
-#pragma unroll 1
-          for (int b0 = 0; b0 < n_tails; b0 += 4) {
-            if (tail && (uint32_t)(rank - b0) < 4u) {
-              float* d = strip + (rank - b0) * kStripStride;
-#pragma unroll
-              for (int k2 = 0; k2 < 4; ++k2)
-                *reinterpret_cast<float4*>(d + 4 * k2) = make_float4(val[2 * k2][0], val[2 * k2][1], val[2 * k2 + 1][0], val[2 * k2 + 1][1]);
-              d[16] = __uint_as_float(s0);
-            }
-            if (b0 + tl < n_tails) {
-              const float v = strip[tl * kStripStride + kf];
-              const uint32_t slot = __float_as_uint(strip[tl * kStripStride + 16]) + koff;
-              atomicAdd(&tvals[(kf & 1) * kSlots + slot], to_fixed(v * fs_lv));
-            }
-          }
-        } else if (!NESVOR_ABL(4) && tail) {
+        // (Lane-transposed inserts for waves with few run tails - four tails park their values in an LDS strip, 64 lanes convert and
+        //  add one value each - were measured in round 4 and bought nothing: a coarse level's time is its latency chain, not the
+        //  130 conversion instructions.  DESIGN_LOG.md / profiles/r04_hashgrid_ab_transposed_inserts.log.)
+        if (!NESVOR_ABL(4) && tail) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) slot_add(s0 + (k & 1) + ((k >> 1) & 1) * nx + (k >> 2) * nxy, val[k], fs_lv);
         }

@@ -1223,15 +1223,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_dw_kernel(const MlpArgs a) {
 }
 
 // ------------------------------------------------- backward, fused dX + dW + db
-// One pass over the samples: the dX chain of mlp_bwd_dx_kernel, and at every layer the freshly formed
-// dpre fragment and the layer input fragment are transposed through a wave-private LDS tile
-// (written as b128 rows T[sample][feature], stride 20 floats; read back conflict-free as
-// A[i = feature][k = sample]) and contracted over the 16 samples into per-wave dW accumulators that stay
-// in registers for the whole launch.  Compared with the two-kernel path this removes the dpre store, the
-// dpre reload and the second read of the saved activations (1.6 GB per network at N = 2^20).
+// Staging tiles of the wave-specialised backward (fp32 / bf16-operand modes): 16 x 16 fp32, padded rows.
 constexpr int kTileStride = 20;                    // floats per sample row of a staging tile (16 + pad, 16-B aligned)
 constexpr int kTileFloats = 16 * kTileStride;      // one 16 x 16 tile
-constexpr int kTilesPerWave = 8;                   // 4 dY blocks + 4 X blocks
 
 __device__ __forceinline__ void stage_tile(float* tile, const f32x4& frag, int j, int q) {
   *reinterpret_cast<f32x4*>(tile + j * kTileStride + 4 * q) = frag;  // lane (j,q): features 4q..4q+3 of sample j
@@ -1287,210 +1281,6 @@ __device__ __forceinline__ void read_planes2(const float* tile, int i, int q, ui
   a.lh = join8h(l0, h0); a.hl = join8h(h1, l1);
 }
 
-template <int OB, int IB>
-__device__ __forceinline__ void accumulate_dw(float* scratch, const f32x4 (&dy)[OB], const f32x4 (&x)[IB],
-                                              f32x4 (&acc)[OB][IB], float (&db)[OB], int lane) {
-  const int j = lane & 15, q = lane >> 4;
-#pragma unroll
-  for (int ob = 0; ob < OB; ++ob) stage_tile(scratch + ob * kTileFloats, dy[ob], j, q);
-#pragma unroll
-  for (int ib = 0; ib < IB; ++ib) stage_tile(scratch + (4 + ib) * kTileFloats, x[ib], j, q);
-  float av[OB][4], bv[IB][4];
-#pragma unroll
-  for (int ob = 0; ob < OB; ++ob) {
-    read_operand(scratch + ob * kTileFloats, j, q, av[ob]);
-    db[ob] += (av[ob][0] + av[ob][1]) + (av[ob][2] + av[ob][3]);
-  }
-#pragma unroll
-  for (int ib = 0; ib < IB; ++ib) read_operand(scratch + (4 + ib) * kTileFloats, j, q, bv[ib]);
-  // keep the operand reads together and ahead of the MFMAs: left alone the scheduler sinks each ds_read next to
-  // its MFMA (register pressure), and with one wave per SIMD every read's latency is then paid in full
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int ob = 0; ob < OB; ++ob)
-#pragma unroll
-      for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma4(av[ob][t], bv[ib][t], acc[ob][ib]);
-}
-
-// write one layer's per-workgroup partial (sum of the 4 waves) in nn.Linear order W (out,in) then b (out)
-template <int OB, int IB>
-__device__ void flush_dw(float* red /* 4 x kHB*256 floats */, const f32x4 (&acc)[OB][IB], const float (&db)[OB],
-                         float* out, int out_dim, int in_dim) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int ob = 0; ob < OB; ++ob) {
-    __syncthreads();
-#pragma unroll
-    for (int ib = 0; ib < IB; ++ib) *reinterpret_cast<f32x4*>(&red[wave * kHB * 256 + (ib * 64 + lane) * 4]) = acc[ob][ib];
-    __syncthreads();
-    for (int e = threadIdx.x; e < IB * 256; e += blockDim.x) {
-      const float s = (red[e] + red[kHB * 256 + e]) + (red[2 * kHB * 256 + e] + red[3 * kHB * 256 + e]);
-      const int r = e & 3, ln = (e >> 2) & 63, ib = e >> 8;
-      const int o = 16 * ob + 4 * (ln >> 4) + r, in = 16 * ib + (ln & 15);
-      if (o < out_dim && in < in_dim) out[o * in_dim + in] = s;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int ob = 0; ob < OB; ++ob) red[wave * kHB * 256 + ob * 64 + lane] = db[ob];
-  __syncthreads();
-  for (int e = threadIdx.x; e < OB * 16; e += blockDim.x) {
-    const int ob = e >> 4, ii = e & 15;
-    float s = 0.f;
-    for (int w = 0; w < 4; ++w)
-      for (int qq = 0; qq < 4; ++qq) s += red[w * kHB * 256 + ob * 64 + qq * 16 + ii];
-    if (16 * ob + ii < out_dim) out[out_dim * in_dim + 16 * ob + ii] = s;
-  }
-}
-
-template <int KB1, int NH>
-__global__ __launch_bounds__(256) void mlp_bwd_fused_kernel(const MlpArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int k_in = a.k_a + a.k_b;
-  float* imgo = lds;                                    // W_out^T : ib = 4, kb = 1
-  float* imgh = imgo + kHB * 1 * 256;                   // W_l^T, l = 1..NH-1
-  float* img1 = imgh + (NH - 1) * kHB * kHB * 256;      // W_1^T : ib = KB1, kb = 4
-  float* scratch_all = img1 + KB1 * kHB * 256;          // 4 waves x 8 tiles; reused as the flush buffer
-  build_image_T(imgo, a.W[NH], a.out_dim, kWidth, kHB, 1);
-  for (int l = 1; l < NH; ++l) build_image_T(imgh + (l - 1) * kHB * kHB * 256, a.W[l], kWidth, kWidth, kHB, kHB);
-  build_image_T(img1, a.W[0], kWidth, k_in, KB1, kHB);
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = lane & 15, q = lane >> 4;
-  float* scratch = scratch_all + wave * kTilesPerWave * kTileFloats;
-  const int64_t n_groups = (a.N + 15) / 16;
-
-  f32x4 acc_o[1][kHB];
-  f32x4 acc_h[NH > 1 ? NH - 1 : 1][kHB][kHB];
-  f32x4 acc_1[kHB][KB1];
-  float db_o[1] = {0.f}, db_h[NH > 1 ? NH - 1 : 1][kHB], db_1[kHB];
-#pragma unroll
-  for (int x = 0; x < kHB; ++x) {
-    acc_o[0][x] = f32x4{0.f, 0.f, 0.f, 0.f};
-    db_1[x] = 0.f;
-#pragma unroll
-    for (int y = 0; y < KB1; ++y) acc_1[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int l = 0; l < (NH > 1 ? NH - 1 : 1); ++l) {
-      db_h[l][x] = 0.f;
-#pragma unroll
-      for (int y = 0; y < kHB; ++y) acc_h[l][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
-
-  // All global inputs of a group (dY, the saved activations of every hidden layer, the network input)
-  // are fetched one group AHEAD: this kernel runs one wave per SIMD (the dW accumulators fill the register
-  // file), so nothing else hides the HBM latency.
-  auto load_group = [&](int64_t gi, f32x4 (&go)[1], f32x4 (&hs)[NH][kHB], f32x4 (&x)[KB1]) {
-    const int64_t n = gi * 16 + j;
-    const bool nv = n < a.N;
-    const int64_t nc = nv ? n : a.N - 1;
-    if (a.fast) {
-      go[0] = load_dy_fast(a, gi, j, q);
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) go[0][r] = (nv && 4 * q + r < a.out_dim) ? a.y[(size_t)(4 * q + r) * a.N + n] : 0.f;
-    }
-#pragma unroll
-    for (int l = 0; l < NH; ++l)
-#pragma unroll
-      for (int ib = 0; ib < kHB; ++ib)
-        hs[l][ib] = *reinterpret_cast<const f32x4*>(a.H[l] + (((size_t)gi * kHB + ib) * 64 + lane) * 4);
-    if (a.fast) {
-      load_x_fast<KB1>(a, gi, j, q, x);
-    } else {
-#pragma unroll
-      for (int kb = 0; kb < KB1; ++kb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[kb][r] = nv ? fetch_input(a, 16 * kb + 4 * q + r, nc) : 0.f;
-    }
-  };
-  const int64_t gstride = (int64_t)gridDim.x * 4;
-  f32x4 go[1], go_n[1], hs[NH][kHB], hs_n[NH][kHB], x[KB1], x_n[KB1];
-  float dx_mx = 0.f;
-  int64_t gi = (int64_t)blockIdx.x * 4 + wave;
-  if (gi < n_groups) load_group(gi, go, hs, x);
-  for (; gi < n_groups; gi += gstride) {
-    const int64_t n = gi * 16 + j;
-    const bool nv = n < a.N;
-    if (gi + gstride < n_groups) load_group(gi + gstride, go_n, hs_n, x_n);
-    accumulate_dw<1, kHB>(scratch, go, hs[NH - 1], acc_o, db_o, lane);
-    f32x4 d[kHB];
-#pragma unroll
-    for (int ib = 0; ib < kHB; ++ib) d[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-    apply_layer_g1<1, kHB>(imgo, go, d, lane);
-#pragma unroll
-    for (int l = NH - 1; l >= 0; --l) {
-      // d = dL/dH_l; mask with the saved post-ReLU activations -> dpre_l
-#pragma unroll
-      for (int ib = 0; ib < kHB; ++ib)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d[ib][r] = hs[l][ib][r] > 0.f ? d[ib][r] : 0.f;
-      if (l > 0) {
-        accumulate_dw<kHB, kHB>(scratch, d, hs[l - 1], acc_h[l - 1], db_h[l - 1], lane);
-        f32x4 d2[kHB];
-#pragma unroll
-        for (int ib = 0; ib < kHB; ++ib) d2[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-        apply_layer_g1<kHB, kHB>(imgh + (l - 1) * kHB * kHB * 256, d, d2, lane);
-#pragma unroll
-        for (int ib = 0; ib < kHB; ++ib) d[ib] = d2[ib];
-      } else {
-        accumulate_dw<kHB, KB1>(scratch, d, x, acc_1, db_1, lane);
-        if (a.dxa != nullptr || a.dxb != nullptr) {
-          f32x4 dx[KB1];
-#pragma unroll
-          for (int ib = 0; ib < KB1; ++ib) dx[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-          apply_layer_g1<kHB, KB1>(img1, d, dx, lane);
-          if (a.dx_absmax != nullptr && nv) track_absmax<KB1>(a, dx, dx_mx);
-          // gfx9 counts loads and stores in one vmcnt and the compiler waits for vmcnt(0) once both kinds are
-          // pending: drain the prefetch loads (issued a whole group of MFMAs ago) HERE, before the stores below,
-          // so that the next iteration does not stall on the latency of these stores when it first touches the
-          // prefetched registers
-          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
-          if (a.fast) {
-            store_dx_fast<KB1>(a, gi, j, q, dx);
-          } else if (nv) {
-#pragma unroll
-            for (int ib = 0; ib < KB1; ++ib)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int kk = 16 * ib + 4 * q + r;
-                if (kk < a.k_a) {
-                  if (a.dxa != nullptr) a.dxa[(size_t)n * a.k_a + kk] = dx[ib][r];
-                } else if (kk - a.k_a < a.k_b) {
-                  if (a.dxb != nullptr) a.dxb[(size_t)(kk - a.k_a) * a.N + n] = dx[ib][r];
-                }
-              }
-          }
-        }
-      }
-    }
-    // rotate the prefetched group in
-    go[0] = go_n[0];
-#pragma unroll
-    for (int l = 0; l < NH; ++l)
-#pragma unroll
-      for (int ib = 0; ib < kHB; ++ib) hs[l][ib] = hs_n[l][ib];
-#pragma unroll
-    for (int kb = 0; kb < KB1; ++kb) x[kb] = x_n[kb];
-  }
-  if (a.dx_absmax != nullptr) publish_absmax(a, dx_mx);
-  // epilogue: per-workgroup partial sums in nn.Linear parameter order W0,b0,W1,b1,...
-  float* out = a.dW_partial + (size_t)blockIdx.x * a.total_params;
-  float* red = scratch_all;
-  int poff = 0;
-  flush_dw<kHB, KB1>(red, acc_1, db_1, out + poff, kWidth, k_in);
-  poff += kWidth * k_in + kWidth;
-#pragma unroll
-  for (int l = 1; l < NH; ++l) {
-    flush_dw<kHB, kHB>(red, acc_h[l - 1], db_h[l - 1], out + poff, kWidth, kWidth);
-    poff += kWidth * kWidth + kWidth;
-  }
-  flush_dw<1, kHB>(red, acc_o, db_o, out + poff, a.out_dim, kWidth);
-}
 
 // ------------------------------------------------- backward, wave-specialised (dX chain | dW)
 // The fused kernel above runs ONE wave per SIMD (its dW accumulators fill the register file), so every LDS
@@ -2389,13 +2179,6 @@ size_t ws_bwd_lds_bytes(int n_hidden, int kb1, bool split = false, bool compact 
   return sizeof(float) * (img + tiles);
 }
 
-size_t fused_bwd_lds_bytes(int n_hidden, int kb1) {
-  size_t img = (size_t)kHB * 256 + (size_t)(n_hidden - 1) * kHB * kHB * 256 + (size_t)kb1 * kHB * 256;
-  size_t scratch = 4 * (size_t)kTilesPerWave * kTileFloats;
-  if (scratch < 4 * (size_t)kHB * 256) scratch = 4 * (size_t)kHB * 256;
-  return sizeof(float) * (img + scratch);
-}
-
 size_t fwd_lds_bytes(int n_linear, int kb1) {
   const int n_hidden = n_linear - 1;
   constexpr size_t blk = 256;
@@ -2509,7 +2292,21 @@ bool compact_ok(const MlpArgs& a, const nesvor_mlp_t* net, int64_t N) {
   return on && use_pf && use_ws && a.bf16 == 2 && a.fast && a.off32 && net->n_hidden <= 2 && kb1 <= 2 && ((N >> 4) % (4 * kG)) == 0;
 }
 
+// shapes the wave-specialised fused backward (dX + dW + db in one launch, no dpre scratch) takes
+bool ws_ok(const MlpArgs& a, const nesvor_mlp_t* net) {
+  static const bool use_ws = []() { const char* e = getenv("NESVOR_MLP_BWD_WS"); return e == nullptr || atoi(e) != 0; }();
+  const int kb1 = (net->k_a + net->k_b + 15) / 16;
+  return use_ws && a.fast && a.off32 && net->n_hidden <= 2 && (kb1 <= 2 || net->n_hidden == 1);  // (wider inputs at two hidden layers would spill)
+}
+
 }  // namespace
+
+extern "C" int nesvor_mlp_backward_fused_ok(const nesvor_mlp_t* net, int64_t N) {
+  if (net == nullptr || N <= 0) return 0;
+  MlpArgs a{};
+  if (fill_args(&a, net, N)) return 0;
+  return ws_ok(a, net) ? 1 : 0;
+}
 
 extern "C" int nesvor_mlp_prepare_weights(const nesvor_mlp_t* const* nets, float* const* preps, int n_nets, const float* x, int64_t n_x,
                                           float* x_slots, void* stream) {
@@ -2678,8 +2475,7 @@ extern "C" int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float*
   }
   if (net->n_hidden <= 2 && dpre_scratch[0] == nullptr) {
     // fused dX + dW + db (the caller signals it by passing no dpre scratch); grid = n_partial workgroups
-    static const bool use_ws = []() { const char* e = getenv("NESVOR_MLP_BWD_WS"); return e == nullptr || atoi(e) != 0; }();
-    if (use_ws && a.fast && a.off32 && (kb1 <= 2 || net->n_hidden == 1)) {  // wave-specialised: 8 waves per workgroup (wider inputs would spill)
+    if (ws_ok(a, net)) {  // wave-specialised: 8 waves per workgroup
       const size_t lds_ws = ws_bwd_lds_bytes(net->n_hidden, kb1);
       if (a.bf16) {
         if (net->n_hidden == 1)
@@ -2702,13 +2498,10 @@ extern "C" int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float*
       return launch_kb(mlp_bwd_ws_kernel<1, 2>, mlp_bwd_ws_kernel<2, 2>, mlp_bwd_ws_kernel<3, 2>, mlp_bwd_ws_kernel<4, 2>,
                        kb1, dim3((unsigned)n_partial), lds_ws, (hipStream_t)stream, a, 512);
     }
-    if (a.bf16) return (int)hipErrorInvalidValue;  // the bf16 mode exists in the wave-specialised backward only
-    const size_t lds = fused_bwd_lds_bytes(net->n_hidden, kb1);
-    if (net->n_hidden == 1)
-      return launch_kb(mlp_bwd_fused_kernel<1, 1>, mlp_bwd_fused_kernel<2, 1>, mlp_bwd_fused_kernel<3, 1>,
-                       mlp_bwd_fused_kernel<4, 1>, kb1, dim3((unsigned)n_partial), lds, (hipStream_t)stream, a);
-    return launch_kb(mlp_bwd_fused_kernel<1, 2>, mlp_bwd_fused_kernel<2, 2>, mlp_bwd_fused_kernel<3, 2>,
-                     mlp_bwd_fused_kernel<4, 2>, kb1, dim3((unsigned)n_partial), lds, (hipStream_t)stream, a);
+    // no scratch and a shape the wave-specialised kernel does not take (ragged N, S or k_a not multiples of 16, three input
+    // blocks at two hidden layers): the caller asks nesvor_mlp_backward_fused_ok first and passes dpre scratch for the
+    // two-kernel path below.  (Rounds 1-4 carried a single-role fused kernel for these shapes.)
+    return (int)hipErrorInvalidValue;
   }
   if (a.bf16) return (int)hipErrorInvalidValue;
   const int64_t n_tiles = ((N + 15) / 16 + 4 * kG - 1) / (4 * kG);

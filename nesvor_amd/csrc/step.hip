@@ -357,6 +357,10 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   float* du = d.opt_T ? d.du : nullptr;
   if (phase == 0) {
     {
+      // (Two workgroups per cloud for batches that do not fill the chip - levels [0, 12) on the main stream, [12, 16) concurrently
+      //  on the side stream, each with its own input-gradient buffer - were tried in round 5: the sibling launch repeats sort and
+      //  set-up, 36 + 50 us side by side against 63 us, and the cross-stream hand-overs ate the rest: 0.285 -> 0.294 ms at 2^17
+      //  points.  Not kept.)
       Span t(ctx, NESVOR_STEP_SPAN_HASHGRID_BWD_AGGREGATE, main);
       NESVOR_TRY(nesvor_hashgrid_backward_bounded(&d.grid, d.u, d.table, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 1, 0, L,
                                                   d.queue_scale, dpe_bound, main));

