@@ -62,7 +62,8 @@ def _cpu_model():
 def cpu_baseline(ds, args, seconds_budget=100.0):
     """The CPU oracle (kind "port": oracle/train_loop.py restates the reference's train loop, nesvor/nesvor/train.py:123-232)
     timed on the STATED workload: same data, same model/config, the full batch of 4096 pixels x 256 samples = 2^20 points per
-    iteration - two iterations, the faster one is the value (the first carries the allocator's first touches) - after a
+    iteration - three iterations, the faster of the last two is the value (the first carries the data set's construction and the
+    allocator's first touches) - after a
     cross-check at 256 pixels (2^16 points, one warm-up + two timed iterations).  Rounds 1-3 timed a 2^14 / 2^16-point sample
     and scaled it proportionally to 2^20 points; that understates the CPU several times over, because its time per iteration
     grows far slower than the batch (measured on a GPU box's 128 threads: 2.5 / 4.7 / 8.7 s at 2^14 / 2^16 / 2^18 points, i.e.
@@ -107,10 +108,10 @@ def cpu_baseline(ds, args, seconds_budget=100.0):
             torch.set_num_threads(default_threads)
             runs.pop()
     left = lambda: seconds_budget - (time.time() - t0)
-    forecast = lambda px: 2 * t_small * (px / float(small_px)) ** 0.6  # two iterations; exponent on the safe side of the measured 0.45
+    forecast = lambda px: 3 * t_small * (px / float(small_px)) ** 0.6  # three iterations; exponent on the safe side of the measured 0.45
     extrapolated, alpha = False, None
     if full_px > small_px and forecast(full_px) <= left():
-        run(full_px, 2)
+        run(full_px, 3)  # (the first iteration carries the data set's construction and the allocator's first touches: the faster of the other two)
         t_full = runs[-1]["s_per_iter"]
     elif full_px > small_px:
         other = 1024 if (full_px > 1024 and forecast(1024) <= left()) else 64
@@ -137,7 +138,7 @@ def cpu_baseline(ds, args, seconds_budget=100.0):
         "points_per_s": pts / t_full,
         "final_losses": {k: float(v) for k, v in last.items()},
         "sample": "CPU oracle train loop, same data and model/config as the GPU run: "
-                  + (f"{full_px} px x {S} samples = {pts} points per iteration, the faster of two iterations ({t_full:.1f} s)" if not extrapolated else
+                  + (f"{full_px} px x {S} samples = {pts} points per iteration, the faster of the last two of three iterations ({t_full:.1f} s)" if not extrapolated else
                      f"time ~ points^{alpha:.2f} through the measured sizes ({', '.join(str(r['pixels']) + ' px: ' + format(r['s_per_iter'], '.2f') + ' s' for r in runs)}), "
                      f"evaluated at {full_px} px x {S} samples ({t_full:.1f} s; the full batch does not fit the {seconds_budget:.0f} s budget on this host)")
                   + f"; cross-check at {runs[0]['pixels']} px: {runs[0]['s_per_iter']:.2f} s per iteration; {time.time() - t0:.0f} s wall in total",
