@@ -685,6 +685,12 @@ def main():
         else:
             out["cpu_baseline"] = None
         os.write(result_fd, (json.dumps(out) + "\n").encode())
+        if os.environ.get("NESVOR_HASHGRID_QUEUE_SAVE"):
+            # the record-queue capacities this run settled on, for a profiled re-run without the settling launches
+            # (NESVOR_HASHGRID_QUEUE=load:<file>, tools/collect_profiles_r05.sh)
+            from nesvor_amd.encoding import save_queue_scales
+
+            save_queue_scales(os.environ["NESVOR_HASHGRID_QUEUE_SAVE"])
     if parallel:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -637,6 +637,26 @@ __device__ __forceinline__ unsigned long long to_fixed(float x) {
   const int32_t lo = __float2int_rn(fmaf(-t, 0x1p32f, x));  // (to nearest: a truncation bias would add up over the adds of a slot)
   return ((unsigned long long)(uint32_t)((int32_t)t + (lo >> 31)) << 32) | (unsigned long long)(uint32_t)lo;
 }
+// NESVOR_HG_F64FIX=1 (build flag, off): the conversion through the fp64 pipe.  x s + 1.5 2^52 (one v_cvt_f64_f32, one v_fma_f64
+// rounding to nearest) has the exponent of 2^52 for every |x s| < 2^50, so its bit pattern is M + q with M = 0x4338000000000000
+// and q = rint(x s) as a two's-complement integer: 2 instructions per value where to_fixed takes 7 and the scaling an eighth.
+// The 64-bit LDS adds sum N M + sum q; the low 51 bits of M are zero, so the low 51 bits of a slot are sum q mod 2^51 - read
+// back sign-extended from bit 50 (from_fixed51), exact while |sum q| < 2^50.  A slot that received anything is never zero
+// (N M = 0 mod 2^64 needs N = 0 mod 2^13; a workgroup has 2^11 contributions).  Measured (gpurun_out/r05p, two alternating
+// builds): 6 % fewer VALU instructions, aggregation pass 0.341 -> 0.333 ms isolated, 0.299 -> 0.293 ms in the step - and 11 bits
+// less room under a caller-supplied bound (resolution bound 2^-41 instead of 2^-52: a cloud whose gradients lie 2^-30 below the
+// bound keeps 2^-11 relative accuracy, test_hashgrid_backward_with_producer_bound[1000.0] fails).  Not worth that: off.
+#ifndef NESVOR_HG_F64FIX
+#define NESVOR_HG_F64FIX 0
+#endif
+__device__ __forceinline__ unsigned long long to_fixed51(float x, double scale) {
+  return (unsigned long long)__double_as_longlong(fma((double)x, scale, 0x1.8p52));
+}
+__device__ __forceinline__ float from_fixed51(unsigned long long q) {
+  const uint32_t lo = (uint32_t)q;
+  const int32_t hi = ((int32_t)(uint32_t)(q >> 32) << 13) >> 13;  // bits 32..50, sign-extended (v_bfe_i32)
+  return fmaf((float)(hi + (int32_t)(lo >> 31)), 0x1p32f, (float)(int32_t)lo);
+}
 __device__ __forceinline__ float from_fixed(unsigned long long q) {
   // q = hi 2^32 + lo with lo taken as SIGNED (hi absorbs its sign bit): a small negative sum is then read as 0 2^32 - |q|,
   // not as -1 2^32 + (2^32 - |q|), whose low word needs 32 bits
@@ -661,6 +681,16 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) {
 #endif
 #ifndef NESVOR_HG_MINBLOCKS
 #define NESVOR_HG_MINBLOCKS 4
+#endif
+// NESVOR_HG_SPATIAL (default): the hashed merge table of the fine levels (boxes that do not fit the table) is addressed by the
+// low bits of the vertex's lattice coordinates - slot = x mod 2^a | (y mod 2^b) << a | (z mod 2^c) << (a + b), a + b + c =
+// log2(slots), the bits dealt to the axes by the extent of the workgroup's box - instead of a multiplicative hash of the entry
+// index.  Two vertices of a cloud then share a first slot only if they lie a whole window apart: replaying 200 PSF clouds
+// (tools/sim_spatial_hash.py) 0.6 / 11 / 59 vertices per cloud miss their first slot at levels 13 / 14 / 15 against 41 / 89 / 176
+// with the multiplicative hash (313 / 462 / 672 vertices in 1024 slots), and every miss is a serial LDS round trip per probe.
+// Misses walk on by double hashing as before.  0: multiplicative hash, table size following the previous level's count.
+#ifndef NESVOR_HG_SPATIAL
+#define NESVOR_HG_SPATIAL 1
 #endif
 template <int F, int LAYOUT, bool INPUT_GRAD, bool MERGE, bool BOUND = false>
 __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2)) void hashgrid_bwd_aggregate(const nesvor_grid_t g, const BwdPlan plan,
@@ -712,6 +742,7 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
   // per level: first cell (x,y,z), cells spanned - 1 (x,y,z), vertices of the lattice box (0: the box does not fit the
   // table), largest slot a sample's first corner may take
   __shared__ uint32_t lbox[NESVOR_MAX_LEVELS + 1][8];
+  __shared__ uint32_t lwin[NESVOR_MAX_LEVELS + 1];  // NESVOR_HG_SPATIAL: address bits of x | y << 8 | z << 16 in the hashed merge table
   // box rounds (groups of consecutive levels whose boxes share the table): per level the first slot of its box, the
   // first (round-local) bucket of its chunks, and the end of its round
   __shared__ uint32_t slot_off[NESVOR_MAX_LEVELS + 1], bkt_off[NESVOR_MAX_LEVELS + 1], grp_end[NESVOR_MAX_LEVELS + 1];
@@ -845,7 +876,8 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
     {
       float mx = 256.f * fmaxf(fmaxf(gmax[0], gmax[1]), fmaxf(gmax[2], gmax[3]));
       mx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mx)));
-      int sexp = (kPack ? 29 : 60) - ((int)((__float_as_uint(mx) >> 23) & 0xFFu) - 127);
+      // (slot sums stay below 2^30 in the packed fields, 2^49 in the 51-bit words, 2^61 in the 64-bit ones)
+      int sexp = (kPack ? 29 : (NESVOR_HG_F64FIX ? 48 : 60)) - ((int)((__float_as_uint(mx) >> 23) & 0xFFu) - 127);
       sexp = sexp > 100 ? 100 : (sexp < -100 ? -100 : sexp);
       fscale = __uint_as_float((uint32_t)(sexp + 127) << 23);
       finv = __uint_as_float((uint32_t)(127 - sexp) << 23);
@@ -864,6 +896,18 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
         const uint32_t nx = ex + 2u, nxy = nx * (ey + 2u), vol = fits ? nxy * (ez + 2u) : 0u;
         b[0] = blo.gx; b[1] = blo.gy; b[2] = blo.gz; b[3] = ex; b[4] = ey; b[5] = ez; b[6] = vol;
         b[7] = fits ? vol - 2u - nx - nxy : 0u;  // = slot (inside the box) of the first corner of the box's last cell
+        {
+          // address bits of the spatially addressed table: one at a time to the axis whose box extent per slot is the largest
+          const uint32_t vx = min(ex, 1023u) + 2u, vy = min(ey, 1023u) + 2u, vz = min(ez, 1023u) + 2u;
+          uint32_t ba = 0, bb = 0, bc = 0;
+          for (int n = 0; n < __builtin_ctz(kSlots); ++n) {
+            const uint32_t rx = (vx << 12) >> ba, ry = (vy << 12) >> bb, rz = (vz << 12) >> bc;
+            if (rz >= rx && rz >= ry) ++bc;
+            else if (ry >= rx) ++bb;
+            else ++ba;
+          }
+          lwin[tid] = ba | (bb << 8) | (bc << 16);
+        }
         nch = plan.n_chunks[tid];
         lpar[tid][0] = p.res; lpar[tid][1] = p.size; lpar[tid][2] = p.offset; lpar[tid][3] = p.hashed;
         lpar[tid][4] = plan.cap[tid]; lpar[tid][5] = plan.bucket_base[tid]; lpar[tid][6] = (uint32_t)plan.rec_off[tid];
@@ -929,6 +973,7 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) idx[k] = corner_index(p, c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + (k >> 2));
+      s0 = (c.gx & 1023u) | ((c.gy & 1023u) << 10) | ((c.gz & 1023u) << 20);  // (what the spatially addressed merge table needs of the cell)
     }
     if constexpr (INPUT_GRAD) {
       float v[8][F];
@@ -1027,7 +1072,10 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
       atomicAdd(&tvals[slot], ((unsigned long long)(uint32_t)(q1 + (q0 >> 31)) << 32) | (unsigned long long)(uint32_t)q0);
     } else {
 #pragma unroll
-      for (int f = 0; f < F; ++f) atomicAdd(&tvals[f * kSlots + slot], to_fixed(v[f] * fscale));
+      for (int f = 0; f < F; ++f) {
+        if constexpr (NESVOR_HG_F64FIX != 0) atomicAdd(&tvals[f * kSlots + slot], to_fixed51(v[f], (double)fscale));
+        else atomicAdd(&tvals[f * kSlots + slot], to_fixed(v[f] * fscale));
+      }
     }
   };
   // read + clear one slot; false: nothing was added (or everything cancelled exactly)
@@ -1048,7 +1096,10 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
       for (int f = 0; f < F; ++f) { w[f] = tvals[f * kSlots + slot]; any = any || w[f] != 0ull; }
       if (any) {
 #pragma unroll
-        for (int f = 0; f < F; ++f) { v[f] = from_fixed(w[f]) * finv; tvals[f * kSlots + slot] = 0ull; }
+        for (int f = 0; f < F; ++f) {
+          v[f] = (NESVOR_HG_F64FIX != 0 ? from_fixed51(w[f]) : from_fixed(w[f])) * finv;
+          tvals[f * kSlots + slot] = 0ull;
+        }
       }
     }
     return any;
@@ -1325,13 +1376,25 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
         constexpr int NR = kSlots / 256;
         uint32_t rkey[NR], rank[NR], rmask = 0;
         float rval[NR][F];
-        const uint32_t slog = slots_log2, smask = (1u << slog) - 1u;
+        const uint32_t slog = NESVOR_HG_SPATIAL ? (uint32_t)__builtin_ctz(kSlots) : slots_log2, smask = (1u << slog) - 1u;
         if (!NESVOR_ABL(4) && tail) {
           uint32_t h[8];
           uint32_t pending = 0;
           // claim / find the 8 slots: first probes issued together, collisions walked one by one
+          if constexpr (NESVOR_HG_SPATIAL != 0) {
+            const uint32_t wb = sgpr(lwin[level]);
+            const uint32_t ba = wb & 255u, bb = (wb >> 8) & 255u, bc = wb >> 16;
+            const uint32_t mx = (1u << ba) - 1u, my = (1u << bb) - 1u, mz = (1u << bc) - 1u;
+            const uint32_t x0 = su & 1023u, y0 = (su >> 10) & 1023u, z0 = su >> 20;
+            const uint32_t hx[2] = {x0 & mx, (x0 + 1u) & mx};
+            const uint32_t hy[2] = {(y0 & my) << ba, ((y0 + 1u) & my) << ba};
+            const uint32_t hz[2] = {(z0 & mz) << (ba + bb), ((z0 + 1u) & mz) << (ba + bb)};
 #pragma unroll
-          for (int k = 0; k < 8; ++k) h[k] = (idx[k] * 2654435761u) >> (32 - slog);
+            for (int k = 0; k < 8; ++k) h[k] = hx[k & 1] | hy[(k >> 1) & 1] | hz[k >> 2];
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) h[k] = (idx[k] * 2654435761u) >> (32 - slog);
+          }
           uint32_t prev[8];
 #pragma unroll
           for (int k = 0; k < 8; ++k) prev[k] = atomicCAS(&tkeys[h[k]], kEmpty, idx[k]);

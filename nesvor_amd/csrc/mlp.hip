@@ -29,6 +29,7 @@
 #include <map>
 #include <type_traits>
 #include <utility>
+#include <tuple>
 #include <mutex>
 #include "common.h"
 #include "../../include/nesvor_hip.h"
@@ -2219,18 +2220,22 @@ int launch_kb(K k1, K k2, K k3, K k4, int kb1, dim3 grid, size_t lds, hipStream_
     }
   }
   if (persistent_tiles > 0) {
-    static std::map<std::pair<const void*, size_t>, int> resident;  // workgroups the device holds at once
-    static const int fixed = []() { const char* e = getenv("NESVOR_FWD_GRID"); return e ? atoi(e) : 0; }();  // A/B override
+    // workgroups the CURRENT device holds at once, per (device, kernel, LDS size): a process that drives several devices - other CU
+    // counts, other partition modes - sizes every device's persistent grid for itself (advisor, round 4)
+    static std::map<std::tuple<int, const void*, size_t>, int> resident;
+    static const int fixed = []() { const char* e = getenv("NESVOR_FWD_GRID"); return e ? atoi(e) : 0; }();  // A/B override (run-time)
     int n_wg = fixed;
     if (n_wg <= 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess) dev = 0;
       std::lock_guard<std::mutex> lock(mu);
-      auto it = resident.find({fn, lds});
+      auto it = resident.find(std::make_tuple(dev, fn, lds));
       if (it == resident.end()) {
-        int dev = 0, cus = 256, per_cu = 2;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        int cus = 256, per_cu = 2;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, threads, lds) != hipSuccess || per_cu < 1) per_cu = 2;
         if (per_cu > NESVOR_FWD_WGS_PER_CU) per_cu = NESVOR_FWD_WGS_PER_CU;
-        it = resident.emplace(std::make_pair(fn, lds), cus * per_cu).first;
+        it = resident.emplace(std::make_tuple(dev, fn, lds), cus * per_cu).first;
       }
       n_wg = it->second;
     }

@@ -39,14 +39,25 @@ class QueueSizer:
     memory after a backward, looked at before a later one (every call for the first 64 calls, every 4th afterwards, so
     that a change of the point distribution is noticed within a few calls).
 
-    ``NESVOR_HASHGRID_QUEUE=worst`` (or ``QueueSizer.policy = "worst"``) allocates the worst case once and never looks."""
+    ``NESVOR_HASHGRID_QUEUE=worst`` (or ``QueueSizer.policy = "worst"``) allocates the worst case once and never looks.
+    ``NESVOR_HASHGRID_QUEUE=load:<file>`` starts from the capacities an earlier process settled on and wrote with
+    ``save_queue_scales(<file>)`` (a resumed run, or a profiled run that must not contain the settling launches: bench.py
+    writes the file when ``NESVOR_HASHGRID_QUEUE_SAVE`` names one); growth continues from there as in the adaptive policy."""
 
     START = 1.0 / 16
     policy = __import__("os").environ.get("NESVOR_HASHGRID_QUEUE", "adaptive")
 
-    def __init__(self, n_levels: int) -> None:
+    def __init__(self, n_levels: int, key=None) -> None:
         start = 1.0 if QueueSizer.policy == "worst" else QueueSizer.START
         self.scale = (ctypes.c_float * _lib.MAX_LEVELS)(*([start] * _lib.MAX_LEVELS))
+        if QueueSizer.policy.startswith("load:") and key is not None:
+            import json, os
+
+            path = QueueSizer.policy[5:]
+            saved = json.load(open(path)).get(_key_name(key)) if os.path.exists(path) else None
+            if saved is not None:
+                for l, v in enumerate(saved[: _lib.MAX_LEVELS]):
+                    self.scale[l] = min(1.0, max(QueueSizer.START, float(v)))
         self.n_levels = n_levels
         self.calls = 0
         self.pending = None  # event of the counter copy in flight
@@ -88,11 +99,23 @@ class QueueSizer:
 _SIZERS = {}
 
 
+def _key_name(key) -> str:
+    return "/".join(str(k) for k in key[1:])  # (without the device: the capacities follow from the points, not the card)
+
+
+def save_queue_scales(path: str) -> None:
+    """Write the capacities every sizer of this process has settled on (``NESVOR_HASHGRID_QUEUE=load:<path>`` reads them)."""
+    import json
+
+    with open(path, "w") as f:
+        json.dump({_key_name(k): [float(v) for v in sz.scale] for k, sz in _SIZERS.items()}, f)
+
+
 def queue_sizer(spec, N, device) -> QueueSizer:
     key = (device, N, spec.n_levels, spec.n_features, spec.log2_hashmap_size, spec.base_resolution, spec.per_level_scale)
     sz = _SIZERS.get(key)
     if sz is None:
-        sz = _SIZERS[key] = QueueSizer(spec.n_levels)
+        sz = _SIZERS[key] = QueueSizer(spec.n_levels, key)
     return sz
 
 

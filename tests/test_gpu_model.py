@@ -2,6 +2,8 @@
 fixtures captured from the reference's Python and against the CPU oracle."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -85,7 +87,7 @@ def test_deferred_table_join_survives_a_change_of_batch_size(device, golden):
     from nesvor_amd.models import NeSVoR
     from nesvor_amd.transform import RigidTransform
 
-    args = small_args(device=device)
+    args = small_args(device=device, n_samples=16)  # (the one-call step needs samples per pixel in multiples of 16)
     tf = RigidTransform(torch.tensor(golden["fw_sd::axisangle_init"]).to(device), trans_first=True)
     res = torch.tensor(golden["ds_resolution"]).to(device)
     bbox = torch.tensor(golden["fw_sd::inr.bounding_box"]).to(device)
@@ -96,8 +98,9 @@ def test_deferred_table_join_survives_a_change_of_batch_size(device, golden):
     mb = NeSVoR(tf, res, float(golden["ds_mean"]), bbox, args)
     mb.load_state_dict(ma.state_dict())
     ta, tb = FusedTrainer(ma, args), FusedTrainer(mb, args)
-    if not all(t.direct is not None and t.direct.native_ready() for t in (ta, tb)):
+    if os.environ.get("NESVOR_STEP_NATIVE", "1") == "0":
         pytest.skip("the one-call step is switched off (NESVOR_STEP_NATIVE=0)")
+    assert all(t.direct is not None and t.direct.native_ready() for t in (ta, tb))
     ta.direct._adamw_in_owner = tb.direct._adamw_in_owner = True
     tb.defer_table_join = True
     d = lambda k: torch.tensor(golden[f"fw_{k}"]).to(device)
@@ -516,7 +519,7 @@ def test_native_step_table_update_in_owner_pass_and_deferred_join(device, golden
     from nesvor_amd.models import NeSVoR
     from nesvor_amd.transform import RigidTransform
 
-    args = small_args(device=device)
+    args = small_args(device=device, n_samples=16)  # (the one-call step needs samples per pixel in multiples of 16)
     tf = RigidTransform(torch.tensor(golden["fw_sd::axisangle_init"]).to(device), trans_first=True)
     res = torch.tensor(golden["ds_resolution"]).to(device)
     bbox = torch.tensor(golden["fw_sd::inr.bounding_box"]).to(device)
@@ -530,8 +533,9 @@ def test_native_step_table_update_in_owner_pass_and_deferred_join(device, golden
         models.append(NeSVoR(tf, res, float(golden["ds_mean"]), bbox, args))
         models[-1].load_state_dict(models[0].state_dict())
     ta, tb, tc = (FusedTrainer(m, args) for m in models)
-    if not all(t.direct is not None and t.direct.native_ready() for t in (ta, tb, tc)):
+    if os.environ.get("NESVOR_STEP_NATIVE", "1") == "0":
         pytest.skip("the one-call step is switched off (NESVOR_STEP_NATIVE=0)")
+    assert all(t.direct is not None and t.direct.native_ready() for t in (ta, tb, tc))
     ta.direct._adamw_in_owner = False
     tb.direct._adamw_in_owner = tc.direct._adamw_in_owner = True  # (whatever NESVOR_ADAMW_IN_OWNER says)
     tc.defer_table_join = True
@@ -554,9 +558,10 @@ def test_native_step_table_update_in_owner_pass_and_deferred_join(device, golden
 
 
 @pytest.mark.parametrize("over", [
-    {}, {"depth": 2}, {"no_transformation_optimization": True}, {"no_pixel_variance": True},
-    {"no_slice_scale": True, "no_slice_variance": True}, {"image_regularization": "TV"},
-    {"n_levels_bias": 2, "depth": 2}, {"n_levels_bias": 2, "no_pixel_variance": True}, {"n_samples": 24}, {"mlp_bf16": True, "n_samples": 16},
+    {"n_samples": 16}, {"depth": 2, "n_samples": 16}, {"no_transformation_optimization": True, "n_samples": 16},
+    {"no_pixel_variance": True, "n_samples": 16}, {"no_slice_scale": True, "no_slice_variance": True, "n_samples": 16},
+    {"image_regularization": "TV", "n_samples": 16}, {"n_levels_bias": 2, "depth": 2, "n_samples": 16},
+    {"n_levels_bias": 2, "no_pixel_variance": True, "n_samples": 32}, {"n_samples": 24}, {"mlp_bf16": True, "n_samples": 16},
 ])
 def test_one_call_step_equals_python_issued_step(device, golden, over):
     """``nesvor_step_run`` (csrc/step.hip: the whole iteration + AdamW enqueued by one C call into buffers allocated once)
@@ -587,8 +592,14 @@ def test_one_call_step_equals_python_issued_step(device, golden, over):
     t1, t2 = FusedTrainer(m1, args), FusedTrainer(m2, args)
     assert t1.direct is not None and t2.direct is not None
     t2.direct._native_on = False
-    if not t1.direct.native_ready():
+    if os.environ.get("NESVOR_STEP_NATIVE", "1") == "0":
         pytest.skip("the one-call step is switched off (NESVOR_STEP_NATIVE=0)")
+    if args.n_samples % 16:
+        # the one-call step launches every network's backward without dpre scratch (nesvor_mlp_backward_fused_ok): other sample
+        # counts run as Python-issued launches - checked here, and that they train, by the model tests above
+        assert not t1.direct.native_ready()
+        return
+    assert t1.direct.native_ready()
     assert not t2.direct.native_ready()
     d = lambda k: torch.tensor(golden[f"fw_{k}"]).to(device)
     # (1) gradients of one iteration, no optimizer: the owner pass of the hash-grid backward sums records in arrival order,

@@ -293,3 +293,32 @@ def test_committed_bench_line_carries_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_queue_capacities_saved_by_one_process_are_loaded_by_the_next(tmp_path, monkeypatch):
+    """``save_queue_scales`` / ``NESVOR_HASHGRID_QUEUE=load:<file>`` (encoding.QueueSizer): a sizer made under the load policy
+    starts from the capacities written for its key (clamped to [START, 1]), any other key from START; no GPU involved."""
+    import torch
+
+    from nesvor_amd import encoding
+    from nesvor_amd.encoding import QueueSizer
+    from nesvor_amd.grid import HashGridSpec
+
+    spec = HashGridSpec(16, 2, 19, 9, 1.26)
+    dev = torch.device("cpu")
+    monkeypatch.setattr(encoding, "_SIZERS", {})
+    monkeypatch.setattr(QueueSizer, "policy", "adaptive")
+    sz = encoding.queue_sizer(spec, 1 << 20, dev)
+    assert all(abs(sz.scale[l] - QueueSizer.START) < 1e-9 for l in range(16))
+    sz.scale[3], sz.scale[15] = 0.25, 1.0
+    path = str(tmp_path / "scales.json")
+    encoding.save_queue_scales(path)
+    monkeypatch.setattr(encoding, "_SIZERS", {})
+    monkeypatch.setattr(QueueSizer, "policy", "load:" + path)
+    again = encoding.queue_sizer(spec, 1 << 20, dev)
+    assert [round(float(again.scale[l]), 4) for l in (0, 3, 15)] == [round(QueueSizer.START, 4), 0.25, 1.0]
+    other = encoding.queue_sizer(spec, 1 << 17, dev)  # another batch size: nothing saved for it
+    assert all(abs(other.scale[l] - QueueSizer.START) < 1e-9 for l in range(16))
+    monkeypatch.setattr(QueueSizer, "policy", "load:" + str(tmp_path / "missing.json"))
+    monkeypatch.setattr(encoding, "_SIZERS", {})
+    assert abs(encoding.queue_sizer(spec, 1 << 20, dev).scale[3] - QueueSizer.START) < 1e-9

@@ -1,11 +1,13 @@
 #!/bin/bash
 # Round-5 profiles on the GPU box (run from the repo root through gpurun): everything lands in gpurun_out/r05prof/ and is
 # copied into profiles/ afterwards.   bash tools/collect_profiles_r05.sh <commit>
-# New against round 4 (verdict item 3d): the kernel trace of the bench runs with NESVOR_HASHGRID_QUEUE=worst - the record queues of
-# the hash-grid backward start at their worst-case size, so no launch of the trace takes the overflow fallback that the adaptive
-# sizing goes through in its first iterations (one 10 ms aggregation launch among 300-us ones bent round 4's rocprofv3 AVERAGE to
-# 0.60 where medians and events said 0.74) - and the launches traced are the PRODUCT's (default streams, fused AdamW).
-# (`rocprofv3 --selected-regions` with roctxProfilerResume / Pause from bench.py was tried first: the trace came out empty.)
+# New against round 4 (verdict item 3d): the kernel trace of the bench runs with the record queues of the hash-grid backward at the
+# capacities the untraced run before it settled on (NESVOR_HASHGRID_QUEUE_SAVE / NESVOR_HASHGRID_QUEUE=load:<file>), so no launch
+# of the trace takes the overflow fallback that the adaptive sizing goes through in its first iterations (one 10 ms aggregation
+# launch among 300-us ones bent round 4's rocprofv3 AVERAGE to 0.60 where medians and events said 0.74) - and the launches
+# traced are the PRODUCT's (default streams, fused AdamW, default queue capacities).
+# (Tried first: `rocprofv3 --selected-regions` with roctxProfilerResume / Pause from bench.py - the trace came out empty; worst-case
+#  queues (NESVOR_HASHGRID_QUEUE=worst) - no settling launches, but the owner pass walks more slices: 113 us against 82.)
 TAG=r05
 export NESVOR_COMMIT=${1:-unknown}
 ROOT=$(pwd)
@@ -14,8 +16,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench line (driver's invocation: 20 steps) and the 200-step default + kernel stats of the same command under rocprofv3
 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench_n1_driver_invocation.json 2> $OUT/bench_n1.err
-python $ROOT/bench.py > $OUT/bench_n1.json 2>> $OUT/bench_n1.err
-NESVOR_HASHGRID_QUEUE=worst rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats -- python $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-strict --small-batches "" > $OUT/bench_under_rocprof.json 2>/dev/null
+NESVOR_HASHGRID_QUEUE_SAVE=/tmp/nesvor_queue_scales.json python $ROOT/bench.py > $OUT/bench_n1.json 2>> $OUT/bench_n1.err
+NESVOR_HASHGRID_QUEUE=load:/tmp/nesvor_queue_scales.json rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats -- python $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-strict --small-batches "" > $OUT/bench_under_rocprof.json 2>/dev/null
 python $ROOT/tools/kernel_stats_settled.py $OUT/kstats > $OUT/bench_n1_kernel_stats.csv
 cp $(ls $OUT/kstats/*/*kernel_stats.csv | head -1) $OUT/bench_n1_kernel_stats_rocprof_avg.csv
 # 2. kernel timeline of one training step (default streams: owner pass on the side stream) and at 512 pixels (2^17 points)
