@@ -187,15 +187,16 @@ def measure_extras(model, args, device, opt):
     gt = torch.zeros_like(table)
     res = {}
     for name, u in (("uniform", u_uniform), ("psf_cloud", u_cloud)):
-        tf = _events_ms(lambda: hashgrid_forward(spec, u, table, _lib.LAYOUT_FEATURE_MAJOR, clustered=name == "psf_cloud"))
+        cl = name == "psf_cloud"  # the hint the caller of either distribution gives (unclustered: the backward orders the points by cell first)
+        tf = _events_ms(lambda: hashgrid_forward(spec, u, table, _lib.LAYOUT_FEATURE_MAJOR, clustered=cl))
         for _ in range(12):  # synchronised warm-up: lets the queue sizer grow the levels this distribution fills
-            hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR)
+            hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR, clustered=cl)
             torch.cuda.synchronize()
-        tb = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR))
-        tb0 = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, False, _lib.LAYOUT_FEATURE_MAJOR))  # parameter gradient only
+        tb = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR, clustered=cl))
+        tb0 = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, False, _lib.LAYOUT_FEATURE_MAJOR, clustered=cl))  # parameter gradient only
         # as inside the training step: the producer of dy (the MLP backward) hands over max |dy|, the pass over dy is skipped
         bound = dy.abs().max().reshape(1)
-        tbb = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR, dy_bound=bound))
+        tbb = _events_ms(lambda: hashgrid_backward(spec, u, table, dy, gt, True, _lib.LAYOUT_FEATURE_MAJOR, dy_bound=bound, clustered=cl))
         res[name] = (tf, tb, tb0, tbb)
     tf, tb, _, _ = res["uniform"]
     out["roofline_uniform"] = {

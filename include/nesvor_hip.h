@@ -175,6 +175,19 @@ typedef struct {
 #define NESVOR_LAYOUT_CLUSTERED 4     /* forward only, OR-ed into `layout`: every 256 consecutive points are spatially
                                          clustered (the S PSF samples of a slice pixel are contiguous) - selects the
                                          one-workgroup-per-cloud forward kernel; results do not depend on the hint */
+#define NESVOR_LAYOUT_UNCLUSTERED 8   /* backward (owner-computes variants) only, OR-ed into `layout`: consecutive points are NOT
+                                         spatially clustered (uniform points, a shuffled batch).  The backward first orders the
+                                         points by the cells of a coarse lattice (counting sort, three small launches, scratch
+                                         inside `workspace`) and hands every workgroup of the aggregation pass 256 points of
+                                         neighbouring cells; the gradients do not depend on the hint beyond the owner pass's
+                                         summation order.  Without it the backward assumes what the training step produces:
+                                         the S PSF samples of a pixel are contiguous.  tcnn's scatter, which this replaces, is
+                                         distribution-agnostic (reference call site nesvor/nesvor/models.py:25). */
+#define NESVOR_LAYOUT_DY_SCRATCH 16   /* with NESVOR_LAYOUT_UNCLUSTERED | NESVOR_LAYOUT_FEATURE_MAJOR: the workspace was sized by
+                                         nesvor_hashgrid_backward_workspace_bytes_ex(.., the same layout) and has room for dpe
+                                         re-ordered into rows (4 L F bytes per point): the aggregation pass then reads whole rows
+                                         instead of 4-byte words at scattered columns (1.80 -> 0.9 ms at N = 2^20 uniform points) */
+#define NESVOR_LAYOUT_MASK 3          /* the layout proper; the other bits are hints */
 
 /* u (N,3) in [0,1]; table flat fp32; pe out. */
 int nesvor_hashgrid_forward(const nesvor_grid_t* grid, const float* u, const float* table, float* pe,
@@ -198,6 +211,9 @@ int nesvor_hashgrid_forward_bounded(const nesvor_grid_t* grid, const float* u, c
  * can start small (a PSF-cloud batch fills a few percent of the worst case at most levels) and grow the levels that
  * overflow.  The same `queue_scale` must be passed to the size query and to every launch on that workspace. */
 int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t* grid, int64_t N, const float* queue_scale);
+/* The same for a backward that will be called with this `layout` (hints included): larger than the above only for
+ * NESVOR_LAYOUT_FEATURE_MAJOR | NESVOR_LAYOUT_UNCLUSTERED | NESVOR_LAYOUT_DY_SCRATCH. */
+int64_t nesvor_hashgrid_backward_workspace_bytes_ex(const nesvor_grid_t* grid, int64_t N, const float* queue_scale, int layout);
 /* The first nesvor_hashgrid_backward_workspace_zero_bytes() bytes of a workspace (its two queue-tail regions) must be
  * zero-filled ONCE after the workspace is allocated; the backward keeps them consistent afterwards (every aggregation
  * pass zero-fills the region the next backward will use, so no memset launch is needed per call). */

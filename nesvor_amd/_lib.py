@@ -14,12 +14,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NESVOR_HIP_LIB: load another build of the same ABI (tools/ablate_hashgrid.py times variants of one kernel this way)
 LIB_PATH = os.environ.get("NESVOR_HIP_LIB") or os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
 STEP_DEFER_JOIN = 8  # nesvor_step_run: OR-ed into `phase` (NESVOR_STEP_DEFER_JOIN)
 LAYOUT_CLUSTERED = 4  # forward hint, OR-ed into the layout: 256 consecutive points are one spatial cluster
+LAYOUT_UNCLUSTERED = 8  # backward hint, OR-ed into the layout: consecutive points are not clustered - order them by cell first
+LAYOUT_DY_SCRATCH = 16  # with LAYOUT_UNCLUSTERED | LAYOUT_FEATURE_MAJOR: the workspace (sized by ..._workspace_bytes_ex) has room for dpe as rows
 
 
 class GridT(Structure):
@@ -123,6 +125,7 @@ _SIGNATURES = {
     "nesvor_hashgrid_forward": ([POINTER(GridT), _P, _P, _P, c_int64, c_int, _P], c_int),
     "nesvor_hashgrid_forward_bounded": ([POINTER(GridT), _P, _P, _P, c_int64, c_int, _P, _P], c_int),
     "nesvor_hashgrid_backward_workspace_bytes": ([POINTER(GridT), c_int64, _P], c_int64),
+    "nesvor_hashgrid_backward_workspace_bytes_ex": ([POINTER(GridT), c_int64, _P, c_int], c_int64),
     "nesvor_hashgrid_backward_workspace_zero_bytes": ([], c_int64),
     "nesvor_hashgrid_backward_overflow_offset": ([_P], c_int64),
     "nesvor_hashgrid_backward": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P, _P], c_int),

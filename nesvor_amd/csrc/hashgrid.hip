@@ -703,7 +703,9 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
                                                               uint32_t* __restrict__ records, int64_t N,
                                                               const float* __restrict__ dy_bound,  // device scalar >= max |dy| over the batch, or null: the kernel reads all dy itself first
                                                               uint8_t* __restrict__ order,         // one byte per sample: the Morton-sorted order of every workgroup's samples
-                                                              int order_mode) {                    // 1: sort and write `order` (first launch of a backward), 2: read it (later launches of a split backward)
+                                                              int order_mode,                      // 1: sort and write `order` (first launch of a backward), 2: read it (later launches of a split backward)
+                                                              const uint32_t* __restrict__ perm,   // null, or the points in lattice-cell order (unclustered input: sort_points below): workgroup w takes points perm[256 w ..]
+                                                              int dy_by_slot) {                    // 1: dpe is already in that order (row r = point perm[r]): gather_dy_rows_kernel
   // the queue tails of the NEXT backward (the other of the workspace's two tail regions) are zero-filled here, so that
   // no launch of its own is needed for it
   for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < (uint32_t)kSubQueues * kTailStride; t += gridDim.x * 256u) tails_next[t] = 0u;
@@ -738,6 +740,7 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
                                       // previous level's distinct vertices (they grow ~1.3-1.5x per level), so that
                                       // the drain only walks what can be occupied
   __shared__ uint32_t merge_off;      // set once merging stops paying: finer levels skip the table
+  __shared__ uint32_t prev_cnt;       // vertices that received something at the previous level (0: unknown)
   __shared__ float ubox[4][6];        // per wave min / max of the samples' coordinates
   // per level: first cell (x,y,z), cells spanned - 1 (x,y,z), vertices of the lattice box (0: the box does not fit the
   // table), largest slot a sample's first corner may take
@@ -764,7 +767,7 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
   for (int t = tid; t < kSlots; t += 256) tkeys[t] = kEmpty;
   for (int t = tid; t < kSlots * kWords; t += 256) tvals[t] = 0ull;
   if (tid < 2) merge_stat[tid] = 0;
-  if (tid == 0) { merge_off = MERGE ? 0u : 1u; slots_log2 = __builtin_ctz(kSlots); }
+  if (tid == 0) { merge_off = MERGE ? 0u : 1u; slots_log2 = __builtin_ctz(kSlots); prev_cnt = 0u; }
   if constexpr (kPerLevel) {
     if (tid <= NESVOR_MAX_LEVELS) lmax_bits[tid] = 0u;
   }
@@ -772,9 +775,10 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
   // ---- sort the workgroup's samples by Morton code of the finest-level cell
   uint32_t sv;
   {
-    const int64_t i0 = base + tid;
+    const int64_t s0_ = base + tid;
     uint32_t code = 0x00ffffffu;
-    if (i0 < N) {
+    if (s0_ < N) {
+      const int64_t i0 = perm != nullptr ? (int64_t)perm[s0_] : s0_;
       const LevelParams pf = load_level(g, g.n_levels - 1);
       const CellPos c = locate(pf, u[3 * i0], u[3 * i0 + 1], u[3 * i0 + 2]);
       code = spread3(c.gx) | (spread3(c.gy) << 1) | (spread3(c.gz) << 2);
@@ -792,20 +796,22 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
     }
   }
   if (order_mode == 1) order[base + tid] = (uint8_t)(sv & 255u);
-  const int64_t i = base + (sv & 255u);  // the sample this lane owns from now on
-  const bool valid = i < N;
+  const int64_t slot_i = base + (sv & 255u);  // the sample this lane owns from now on: position in the (cell-ordered) batch ...
+  const bool valid = slot_i < N;
+  const int64_t i = (valid && perm != nullptr) ? (int64_t)perm[slot_i] : slot_i;  // ... and its index in u / dpe / grad_u
   const int64_t ii = valid ? i : N - 1;
+  const int64_t id = dy_by_slot ? (valid ? slot_i : N - 1) : ii;  // row / column of dpe
   const float ux = u[3 * ii], uy = u[3 * ii + 1], uz = u[3 * ii + 2];
   float gux = 0.f, guy = 0.f, guz = 0.f;
 
   auto load_dy = [&](int level, float (&dy)[F]) __attribute__((always_inline)) {
     if constexpr (LAYOUT == NESVOR_LAYOUT_ROW_MAJOR) {
-      const float* o = dpe + (size_t)ii * E + level * F;
+      const float* o = dpe + (size_t)id * E + level * F;
 #pragma unroll
       for (int f = 0; f < F; ++f) dy[f] = valid ? o[f] : 0.f;
     } else {
 #pragma unroll
-      for (int f = 0; f < F; ++f) dy[f] = valid ? dpe[(size_t)(level * F + f) * N + ii] : 0.f;
+      for (int f = 0; f < F; ++f) dy[f] = valid ? dpe[(size_t)(level * F + f) * N + id] : 0.f;
     }
   };
 
@@ -1232,6 +1238,7 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
           for (int j = 0; j < NRB; ++j) tkeys[j * 256 + tid] = kEmpty;  // the hashed table of the next level starts empty
         }
         rmask = 0;
+        uint32_t n_last = 0;  // vertices of the round's last level that received something
 #pragma unroll
         for (int j = 0; j < NRB; ++j) {
           rank[j] = 0; rkey[j] = 0; rmeta[j] = 0;
@@ -1245,7 +1252,13 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
             rmeta[j] = (lv << 8) | bucket;
             rmask |= 1u << j;
             rank[j] = atomicAdd(&bcount[bucket], 1u);
+            n_last += lv + 1u == (uint32_t)rb ? 1u : 0u;
           }
+        }
+        if (!next_box) {
+          // the last box level's count decides whether the first hashed level merges at all (see the test behind the loop)
+          const uint32_t wave_last = (uint32_t)wave_sum_u32(n_last);
+          if (lane == 0 && wave_last) atomicAdd(&merge_stat[1], wave_last);
         }
         if (next_box) store_feat(na, nfeat);  // every read of the current round's copy happened before the barrier above
         have_prev = true;
@@ -1271,6 +1284,15 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
         ra = na; rb = nb_;
       }
       __syncthreads();
+      // The hashed table of the levels behind the boxes must not get crowded: vertices grow by up to 2x per level (1.45x on PSF
+      // clouds), a table more than ~3/4 full walks tens of probes per insert.  More than half the slots at the last box level
+      // (cell-ordered uniform points: ~600 of the 780 vertices of a level-11 box): the finer levels write direct records.
+      // (Rounds 1-4 only looked at a hashed level after it had been inserted.)
+      if (tid == 0) {
+        if (NESVOR_HG_SPATIAL && merge_stat[1] * 2u > (uint32_t)kSlots) merge_off = 1u;
+        prev_cnt = merge_stat[1];
+        merge_stat[1] = 0u;
+      }
       // W(last box round)
       if (!NESVOR_ABL(8)) {
 #pragma unroll
@@ -1328,6 +1350,9 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
         // crowded
         const uint32_t drained = merge_stat[1];
         if (drained * 4u > merge_stat[0] * 3u || drained * 10u > (uint32_t)kSlots * 7u) merge_off = 1u;
+        // (the next level at this level's growth: keep it below ~4/5 of the slots)
+        if (NESVOR_HG_SPATIAL && prev_cnt != 0u && (uint64_t)drained * drained * 5u > (uint64_t)prev_cnt * (uint32_t)kSlots * 4u) merge_off = 1u;
+        prev_cnt = drained;
         uint32_t lg = 8;
         while ((1u << lg) < 4u * drained && (1u << lg) < (uint32_t)kSlots) ++lg;
         slots_log2 = lg;
@@ -1840,10 +1865,219 @@ inline int tails_parity(void* workspace, bool advance) {
   return p;
 }
 
+// ---- unclustered input (NESVOR_LAYOUT_UNCLUSTERED): the points in the order of a coarse lattice's cells -------------------
+// The aggregation pass lives on the lattice vertices that the 256 samples of a workgroup share (PSF clouds: all of them at the
+// coarse levels).  256 CONSECUTIVE points of an arbitrary batch share nothing; 256 points of neighbouring coarse cells do.  The
+// points are binned by the Morton code of a 2^b-per-axis grid (b chosen so that a cell holds 32..255 points: 32^3 cells at
+// N = 2^20), ONE returning atomic per point:
+//   place    point i -> slot (cell, k) of the cell's kCap-slot strip, k = its ticket; a ticket >= cap goes to a spill list
+//            (a batch that is clustered after all: its dense cells overflow, the spilled points are processed in arrival order)
+//   scan     first rank of every cell = exclusive sum of min(count, cap); the spill list follows the last cell (one workgroup,
+//            the counters pass through LDS)
+//   compact  perm[first rank of the cell + k] = the strip's k-th point
+// Workgroup w of the aggregation pass takes points perm[256 w ..]: ~8 neighbouring cells, a box of ~1/16 of the cube's side,
+// which the box rounds take up to level 11 of the headline grid (vertices shared 3-70x); the finer levels, where uniform points
+// share nothing, write direct records as before.  (First version, gpurun_out/r05s: an exact counting sort - count, scan, place -
+// 50 + 51 + 73 us at N = 2^20; both of its atomic passes ran at ~20 G atomics/s and its one-workgroup scan read the counters
+// strided.)  The order inside a cell is that of the tickets: sums are formed in fixed point / per chunk owner, so the result does
+// not depend on it beyond the owner pass's usual last-bit differences.
+constexpr int kSortMaxBits = 6;  // <= 64 cells per axis (2^18 counters)
+struct SortPlan {
+  int b;            // cells per axis = 2^b
+  uint32_t n_cells; // 8^b
+  uint32_t cap;     // slots per cell: twice the mean occupancy, rounded up to a power of two
+};
+inline SortPlan sort_plan(int64_t N) {
+  int lg = 0;
+  while (((int64_t)2 << lg) <= N) ++lg;  // floor(log2 N)
+  int b = (lg - 5) / 3;
+  b = b < 1 ? 1 : (b > kSortMaxBits ? kSortMaxBits : b);
+  SortPlan p;
+  p.b = b; p.n_cells = 1u << (3 * b);
+  const int64_t mean = (N + p.n_cells - 1) / p.n_cells;
+  uint32_t cap = 2;
+  while ((int64_t)cap < 2 * mean) cap *= 2;
+  p.cap = cap;
+  return p;
+}
+// scratch behind `order` (all uint32 unless noted): perm [n_pad] | count [n_cells + 1, the last = spilled points] |
+// first [n_cells + 2] | spill [n_pad] | where [n_pad] uint64: (cell << 32 | ticket) of every point | strips [n_cells * cap]
+struct SortBufs {
+  uint32_t *perm, *count, *first, *spill, *strips;
+  unsigned long long* where;
+};
+inline uint64_t sort_max_cells() { return (uint64_t)1 << (3 * kSortMaxBits); }
+inline SortBufs sort_bufs(uint32_t* base, int64_t N, const SortPlan& p) {
+  const size_t n_pad = (size_t)((N + 255) / 256) * 256;
+  SortBufs s;
+  s.perm = base;
+  s.count = s.perm + n_pad;
+  s.first = s.count + sort_max_cells() + 2;
+  s.spill = s.first + sort_max_cells() + 2;
+  s.where = reinterpret_cast<unsigned long long*>(s.spill + n_pad);
+  s.strips = reinterpret_cast<uint32_t*>(s.where + n_pad);
+  return s;
+}
+inline uint64_t sort_bytes(int64_t N) {
+  const uint64_t n_pad = (uint64_t)((N + 255) / 256) * 256;
+  const SortPlan p = sort_plan(N);
+  return (n_pad * 2 + 2 * (sort_max_cells() + 2)) * sizeof(uint32_t) + n_pad * sizeof(unsigned long long) +
+         (uint64_t)p.n_cells * p.cap * sizeof(uint32_t);
+}
+__device__ __forceinline__ uint32_t sort_cell(const float* __restrict__ u, int64_t i, int b) {
+  const float s = (float)(1 << b);
+  const int top = (1 << b) - 1;
+  // (NaN / out-of-range coordinates land in an edge cell: the order is only a matter of speed)
+  const int x = min(max((int)(u[3 * i] * s), 0), top), y = min(max((int)(u[3 * i + 1] * s), 0), top), z = min(max((int)(u[3 * i + 2] * s), 0), top);
+  return spread3((uint32_t)x) | (spread3((uint32_t)y) << 1) | (spread3((uint32_t)z) << 2);
+}
+__global__ __launch_bounds__(256) void sort_place_kernel(const float* __restrict__ u, int64_t N, SortPlan p, SortBufs s) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  uint32_t c = sort_cell(u, i, p.b);
+  uint32_t k = atomicAdd(&s.count[c], 1u);
+  if (k < p.cap) s.strips[(size_t)c * p.cap + k] = (uint32_t)i;
+  else {
+    k = atomicAdd(&s.count[p.n_cells], 1u);
+    c = p.n_cells;
+    s.spill[k] = (uint32_t)i;
+  }
+  s.where[i] = ((unsigned long long)c << 32) | k;
+}
+// first[c] = sum over c' < c of min(count[c'], cap) for c <= n_cells; first[n_cells + 1] = N.  One workgroup of 1024 threads; the
+// counters go through LDS in tiles of 32768 (coalesced loads, every thread then owns 32 consecutive ones).
+__global__ __launch_bounds__(1024) void sort_scan_kernel(SortPlan p, SortBufs s) {
+  constexpr int kTile = 32768, kPer = kTile / 1024;
+  extern __shared__ uint32_t cnt[];  // [kTile + kTile / 32]: one pad word per 32 (a thread's 32 counters would share a bank)
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  const uint32_t total = p.n_cells + 1;  // (the spill counter is the last "cell", uncapped)
+  for (uint32_t t0 = 0; t0 < total; t0 += kTile) {
+    {
+      uint32_t v[kPer];  // (all loads of the tile in flight before the first LDS store)
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const uint32_t c = t0 + (uint32_t)(k * 1024 + tid);
+        v[k] = c < total ? s.count[c] : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const uint32_t c = t0 + (uint32_t)(k * 1024 + tid);
+        const int j = k * 1024 + tid;
+        cnt[j + (j >> 5)] = c < p.n_cells ? min(v[k], p.cap) : v[k];
+      }
+    }
+    __syncthreads();
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) sum += cnt[tid * kPer + k + tid];  // (tid * 32 + k + pad(tid))
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+      if ((tid & 63) >= d) incl += o;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = carry_s + incl - sum;
+    for (int w = 0; w < (tid >> 6); ++w) before += wsum[w];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int j = tid * kPer + k;
+      const uint32_t v = cnt[j + tid];
+      cnt[j + tid] = before;
+      before += v;
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = before;
+    for (int k = 0; k < kPer; ++k) {
+      const uint32_t c = t0 + (uint32_t)(k * 1024 + tid);
+      const int j = k * 1024 + tid;
+      if (c < total) s.first[c] = cnt[j + (j >> 5)];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) s.first[total] = carry_s;
+}
+__global__ __launch_bounds__(256) void sort_compact_kernel(SortPlan p, SortBufs s) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t n_strip = (uint64_t)p.n_cells * p.cap;
+  if (t < n_strip) {
+    const uint32_t c = (uint32_t)(t / p.cap), k = (uint32_t)(t - (uint64_t)c * p.cap);
+    if (k < min(s.count[c], p.cap)) s.perm[s.first[c] + k] = s.strips[t];
+  } else {
+    const uint64_t k = t - n_strip;
+    if (k < (uint64_t)s.count[p.n_cells]) s.perm[s.first[p.n_cells] + (uint32_t)k] = s.spill[k];
+  }
+}
+// Feature-major dpe (E, N) -> rows (N, E) in cell order.  The aggregation pass reads a point's dpe level by level; through perm
+// that is a 4-byte access per (point, feature) into rows of N floats - 33 M scattered sectors at N = 2^20, measured 1.80 ms for
+// the backward against 0.89 ms on row-major input.  Here the columns are READ in their own order (256 consecutive floats per row
+// and workgroup) and every point's E values are WRITTEN as one row of 4 E bytes at its place in the order: both sides whole lines.
+constexpr int kGatherPts = 256;
+__global__ __launch_bounds__(256) void gather_dy_rows_kernel(const float* __restrict__ dpe, SortBufs s, float* __restrict__ rows, int64_t N, int E) {
+  extern __shared__ float tile[];  // [kGatherPts][E + 1]
+  __shared__ uint32_t rank[kGatherPts];
+  const int tid = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * kGatherPts;
+  const bool ok = i0 + tid < N;
+  if (ok) {
+    const unsigned long long w = s.where[i0 + tid];
+    rank[tid] = s.first[(uint32_t)(w >> 32)] + (uint32_t)w;
+  }
+  for (int e0 = 0; e0 < E; e0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (ok && e0 + q < E) ? dpe[(size_t)(e0 + q) * N + i0 + tid] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (e0 + q < E) tile[tid * (E + 1) + e0 + q] = v[q];
+  }
+  __syncthreads();
+  if ((E & 3) == 0) {  // 16 bytes per store: a row of E floats is E / 4 consecutive lanes
+    const int E4 = E >> 2;
+    for (int idx = tid; idx < kGatherPts * E4; idx += 256) {
+      const int q = idx / E4, e = (idx - q * E4) * 4;
+      const float* t = tile + q * (E + 1) + e;
+      if (i0 + q < N) *reinterpret_cast<float4*>(rows + (size_t)rank[q] * E + e) = make_float4(t[0], t[1], t[2], t[3]);
+    }
+  } else {
+    for (int idx = tid; idx < kGatherPts * E; idx += 256) {
+      const int q = idx / E, e = idx - q * E;
+      if (i0 + q < N) rows[(size_t)rank[q] * E + e] = tile[q * (E + 1) + e];
+    }
+  }
+}
+inline int sort_points(const float* u, int64_t N, uint32_t* base, hipStream_t st) {
+  const SortPlan p = sort_plan(N);
+  const SortBufs s = sort_bufs(base, N, p);
+  hipError_t e = hipMemsetAsync(s.count, 0, sizeof(uint32_t) * (p.n_cells + 1), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(sort_place_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, u, N, p, s);
+  static std::once_flag raised;
+  constexpr size_t kScanLds = sizeof(uint32_t) * (32768 + 32768 / 32);
+  std::call_once(raised, []() { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScanLds); });
+  hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), kScanLds, st, p, s);
+  const uint64_t n_threads = (uint64_t)p.n_cells * p.cap + (uint64_t)((N + 255) / 256) * 256;
+  hipLaunchKernelGGL(sort_compact_kernel, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, st, p, s);
+  return (int)hipGetLastError();
+}
+
 template <int F, int LAYOUT>
 int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table, const float* dpe, float* gt,
                      float* gu, int64_t N, void* workspace, int stages, int level_begin, int level_end, const float* queue_scale,
-                     const float* dy_bound, const OwnerAdam* adam, hipStream_t st) {
+                     const float* dy_bound, const OwnerAdam* adam, hipStream_t st, int hints = 0) {
+  const bool unclustered = (hints & NESVOR_LAYOUT_UNCLUSTERED) != 0;
+  if constexpr (LAYOUT == NESVOR_LAYOUT_FEATURE_MAJOR) {
+    // unclustered feature-major dpe with room for its re-ordered copy (NESVOR_LAYOUT_DY_SCRATCH: the workspace was sized by
+    // nesvor_hashgrid_backward_workspace_bytes_ex with the same layout): the aggregation pass runs in its row-major form on the copy
+    if (unclustered && (hints & NESVOR_LAYOUT_DY_SCRATCH) && (stages & 1))
+      return launch_bwd_owner<F, NESVOR_LAYOUT_ROW_MAJOR>(g, u, table, dpe, gt, gu, N, workspace, stages, level_begin, level_end, queue_scale,
+                                                          dy_bound, adam, st, hints | 0x10000);
+  }
   BwdPlan plan;
   uint64_t n_rec;
   if (!make_plan(g, N, &plan, &n_rec, queue_scale)) return (int)hipErrorInvalidValue;
@@ -1856,14 +2090,45 @@ int launch_bwd_owner(const nesvor_grid_t* g, const float* u, const float* table,
   uint32_t* records = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + kHeadBytes);
   uint8_t* order = reinterpret_cast<uint8_t*>(records) + n_rec * (1 + F) * sizeof(uint32_t);  // ceil(N / 256) * 256 bytes
   const int order_mode = (stages & 4) ? 2 : 1;
+  // unclustered input: the points in cell order (a later launch of a split backward finds the first launch's order in place)
+  // (256-byte aligned in absolute terms: the records in front have any multiple of 4 bytes; the size query leaves the slack)
+  uint32_t* const perm_buf = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(order) + (uintptr_t)((N + 255) / 256) * 256 + 255) & ~(uintptr_t)255);
+  const uint32_t* const perm = unclustered ? perm_buf : nullptr;
   dim3 grid((unsigned)((N + 255) / 256)), block(256);
   hipError_t e;
+  int dy_by_slot = 0;
   if (!(stages & 1)) goto owner_stage;
+  if (unclustered && order_mode == 1) {
+    const int se = sort_points(u, N, perm_buf, st);
+    if (se) return se;
+  }
+  if (hints & 0x10000) {  // (re-entered from the feature-major instantiation: see the top)
+    const int E = g->n_levels * F;
+    float* rows = reinterpret_cast<float*>(reinterpret_cast<char*>(perm_buf) + ((sort_bytes(N) + 255) & ~(uint64_t)255));
+    // (a later launch of a split backward finds the first launch's copy in place)
+    if (order_mode == 1) {
+      const size_t lds = sizeof(float) * kGatherPts * (E + 1);
+      if (lds > 48 * 1024) {
+        static std::mutex mu;
+        static size_t raised = 0;
+        std::lock_guard<std::mutex> lock(mu);
+        if (lds > raised) {
+          e = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_dy_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          if (e != hipSuccess) return (int)e;
+          raised = lds;
+        }
+      }
+      hipLaunchKernelGGL(gather_dy_rows_kernel, dim3((unsigned)((N + kGatherPts - 1) / kGatherPts)), dim3(256), lds, st, dpe,
+                         sort_bufs(perm_buf, N, sort_plan(N)), rows, N, E);
+    }
+    dpe = rows;
+    dy_by_slot = 1;
+  }
   {
     static const bool merge = []() { const char* e = getenv("NESVOR_HASHGRID_MERGE"); return e == nullptr || atoi(e) != 0; }();
 #define NESVOR_LAUNCH_AGG(IG, MG, BD)                                                                                     \
     hipLaunchKernelGGL((hashgrid_bwd_aggregate<F, LAYOUT, IG, MG, BD>), grid, block, 0, st, *g, plan, u, table, dpe, gt, gu, \
-                       tails, tails_next, records, N, dy_bound, order, order_mode)
+                       tails, tails_next, records, N, dy_bound, order, order_mode, perm, dy_by_slot)
     const bool bounded = dy_bound != nullptr && merge;  // (the bound only scales the merge table's fixed-point sums)
     if (gu != nullptr) { if (bounded) NESVOR_LAUNCH_AGG(true, true, true); else if (merge) NESVOR_LAUNCH_AGG(true, true, false); else NESVOR_LAUNCH_AGG(true, false, false); }
     else { if (bounded) NESVOR_LAUNCH_AGG(false, true, true); else if (merge) NESVOR_LAUNCH_AGG(false, true, false); else NESVOR_LAUNCH_AGG(false, false, false); }
@@ -1946,7 +2211,7 @@ extern "C" int nesvor_hashgrid_forward_bounded(const nesvor_grid_t* grid, const 
   if (N <= 0) return 0;
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
   const int clustered = (layout & NESVOR_LAYOUT_CLUSTERED) ? 1 : 0;
-  layout &= ~NESVOR_LAYOUT_CLUSTERED;
+  layout &= NESVOR_LAYOUT_MASK;
   DISPATCH_F_LAYOUT(launch_fwd, grid, u, table, pe, N, clustered, pe_absmax, (hipStream_t)stream);
 }
 
@@ -1960,7 +2225,16 @@ extern "C" int nesvor_hashgrid_backward_atomic(const nesvor_grid_t* grid, const 
                                                int layout, void* stream) {
   if (N <= 0) return 0;
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
+  layout &= NESVOR_LAYOUT_MASK;  // (hints of the other kernels)
   DISPATCH_F_LAYOUT(launch_bwd, grid, u, table, dpe, grad_table, grad_u, N, (hipStream_t)stream);
+}
+
+extern "C" int64_t nesvor_hashgrid_backward_workspace_bytes_ex(const nesvor_grid_t* grid, int64_t N, const float* queue_scale, int layout) {
+  const int64_t base = nesvor_hashgrid_backward_workspace_bytes(grid, N, queue_scale);
+  if (base <= 0) return base;
+  if ((layout & NESVOR_LAYOUT_MASK) == NESVOR_LAYOUT_FEATURE_MAJOR && (layout & NESVOR_LAYOUT_UNCLUSTERED) && (layout & NESVOR_LAYOUT_DY_SCRATCH))
+    return base + 256 + (int64_t)((N + 255) / 256) * 256 * grid->n_levels * grid->n_features * (int64_t)sizeof(float);
+  return base;
 }
 
 extern "C" int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t* grid, int64_t N, const float* queue_scale) {
@@ -1970,7 +2244,7 @@ extern "C" int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t*
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return -1;
   if (!make_plan(grid, N, &plan, &n_rec, queue_scale)) return -1;
   if (plan.n_buckets > kOverflowBase) return -1;
-  return (int64_t)(kHeadBytes + n_rec * (1 + grid->n_features) * sizeof(uint32_t) + (uint64_t)((N + 255) / 256) * 256);
+  return (int64_t)(kHeadBytes + n_rec * (1 + grid->n_features) * sizeof(uint32_t) + (uint64_t)((N + 255) / 256) * 256 + 256 + ((sort_bytes(N) + 255) & ~(uint64_t)255));
 }
 
 extern "C" int64_t nesvor_hashgrid_backward_workspace_zero_bytes(void) { return (int64_t)kHeadBytes; }
@@ -1985,8 +2259,10 @@ extern "C" int nesvor_hashgrid_backward(const nesvor_grid_t* grid, const float* 
   if (N <= 0) return 0;
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
   if (workspace == nullptr || (stages & 3) == 0) return (int)hipErrorInvalidValue;
+  const int hints = layout & (NESVOR_LAYOUT_UNCLUSTERED | NESVOR_LAYOUT_DY_SCRATCH);
+  layout &= NESVOR_LAYOUT_MASK;
   DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages & 3, 0, grid->n_levels,
-                    queue_scale, nullptr, nullptr, (hipStream_t)stream);
+                    queue_scale, nullptr, nullptr, (hipStream_t)stream, hints);
 }
 
 extern "C" int nesvor_hashgrid_backward_levels(const nesvor_grid_t* grid, const float* u, const float* table,
@@ -1997,8 +2273,10 @@ extern "C" int nesvor_hashgrid_backward_levels(const nesvor_grid_t* grid, const 
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
   if (workspace == nullptr || (stages & 3) == 0) return (int)hipErrorInvalidValue;
   if (level_begin < 0 || level_end > grid->n_levels || level_begin >= level_end) return (int)hipErrorInvalidValue;
+  const int hints = layout & (NESVOR_LAYOUT_UNCLUSTERED | NESVOR_LAYOUT_DY_SCRATCH);
+  layout &= NESVOR_LAYOUT_MASK;
   DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages, level_begin, level_end,
-                    queue_scale, nullptr, nullptr, (hipStream_t)stream);
+                    queue_scale, nullptr, nullptr, (hipStream_t)stream, hints);
 }
 
 extern "C" int nesvor_hashgrid_backward_bounded(const nesvor_grid_t* grid, const float* u, const float* table,
@@ -2009,8 +2287,10 @@ extern "C" int nesvor_hashgrid_backward_bounded(const nesvor_grid_t* grid, const
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
   if (workspace == nullptr || (stages & 3) == 0) return (int)hipErrorInvalidValue;
   if (level_begin < 0 || level_end > grid->n_levels || level_begin >= level_end) return (int)hipErrorInvalidValue;
+  const int hints = layout & (NESVOR_LAYOUT_UNCLUSTERED | NESVOR_LAYOUT_DY_SCRATCH);
+  layout &= NESVOR_LAYOUT_MASK;
   DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages, level_begin, level_end,
-                    queue_scale, dy_bound, nullptr, (hipStream_t)stream);
+                    queue_scale, dy_bound, nullptr, (hipStream_t)stream, hints);
 }
 
 extern "C" int nesvor_hashgrid_backward_adamw(const nesvor_grid_t* grid, const float* u, float* table, const float* dpe,
@@ -2024,6 +2304,8 @@ extern "C" int nesvor_hashgrid_backward_adamw(const nesvor_grid_t* grid, const f
   oa.param = table; oa.exp_avg = exp_avg; oa.exp_avg_sq = exp_avg_sq; oa.done = nullptr;
   oa.a = make_adam_args(adam->lr, adam->beta1, adam->beta2, adam->eps, adam->weight_decay, adam->bias_correction1,
                         adam->bias_correction2, adam->grad_scale);
+  const int hints = layout & (NESVOR_LAYOUT_UNCLUSTERED | NESVOR_LAYOUT_DY_SCRATCH);
+  layout &= NESVOR_LAYOUT_MASK;
   DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages, 0, grid->n_levels, queue_scale,
-                    dy_bound, &oa, (hipStream_t)stream);
+                    dy_bound, &oa, (hipStream_t)stream, hints);
 }

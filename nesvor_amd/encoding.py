@@ -111,18 +111,21 @@ def save_queue_scales(path: str) -> None:
         json.dump({_key_name(k): [float(v) for v in sz.scale] for k, sz in _SIZERS.items()}, f)
 
 
-def queue_sizer(spec, N, device) -> QueueSizer:
-    key = (device, N, spec.n_levels, spec.n_features, spec.log2_hashmap_size, spec.base_resolution, spec.per_level_scale)
+def queue_sizer(spec, N, device, clustered=True) -> QueueSizer:
+    """One sizer per (device, batch size, grid, clustered hint): an unclustered batch fills the fine levels' queues completely, a
+    PSF-cloud batch a few percent - a capacity grown for the one would make the other's owner pass walk empty slices."""
+    key = (device, N, spec.n_levels, spec.n_features, spec.log2_hashmap_size, spec.base_resolution, spec.per_level_scale, bool(clustered))
     sz = _SIZERS.get(key)
     if sz is None:
         sz = _SIZERS[key] = QueueSizer(spec.n_levels, key)
     return sz
 
 
-def _workspace(spec, N, device, sizer=None):
-    """Scratch for the owner-computes backward (queues of (entry, grad) records), cached per (device, size)."""
+def _workspace(spec, N, device, sizer=None, layout=0):
+    """Scratch for the owner-computes backward (queues of (entry, grad) records), cached per (device, size).  ``layout``: the one
+    the backward will be called with, hints included (an unclustered feature-major backward keeps a re-ordered copy of dpe here)."""
     sizer = sizer or queue_sizer(spec, N, device)
-    nbytes = _lib.load().nesvor_hashgrid_backward_workspace_bytes(ctypes.byref(spec.c_struct), N, sizer.scale)
+    nbytes = _lib.load().nesvor_hashgrid_backward_workspace_bytes_ex(ctypes.byref(spec.c_struct), N, sizer.scale, layout)
     if nbytes < 0:
         return None
     key = (device, nbytes)
@@ -143,7 +146,7 @@ def _workspace(spec, N, device, sizer=None):
 
 
 def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True, layout=_lib.LAYOUT_ROW_MAJOR,
-                      method="owner", levels=None, grad_u=None, first=True, owner_stream=None, dy_bound=None):
+                      method="owner", levels=None, grad_u=None, first=True, owner_stream=None, dy_bound=None, clustered=True):
     """Accumulates into grad_table (allocated zero-filled if None); returns (grad_table, grad_u|None).
     method: "owner" (LDS aggregation + per-chunk owners, the MI355X path) or "atomic" (per-corner atomics).
     levels = (begin, end): only these levels ("owner" method) - a data-parallel step splits the backward in two so
@@ -152,8 +155,13 @@ def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True
     owner_stream: launch the owner pass (which only finishes ``grad_table``) on this stream, behind the aggregation pass;
     ``grad_u`` is complete on the current stream, the caller joins ``owner_stream`` before it reads ``grad_table``.
     dy_bound: 1-element device tensor >= max |dpe| ("owner" method): the aggregation pass then skips its own pass over dpe
-    (the training step gets the bound from the MLP backward that produced dpe, csrc/step.hip)."""
+    (the training step gets the bound from the MLP backward that produced dpe, csrc/step.hip).
+    clustered=False: consecutive points are not spatially clustered (uniform points, a shuffled batch) - the "owner" method
+    then orders them by coarse lattice cell first (``NESVOR_LAYOUT_UNCLUSTERED``); the default is what the training step
+    produces, the S PSF samples of a pixel next to each other.  The gradients do not depend on the hint."""
     _lib.require_device(u, table, dpe, dtype=torch.float32, name="hashgrid backward input")
+    if not clustered:
+        layout = layout | _lib.LAYOUT_UNCLUSTERED | _lib.LAYOUT_DY_SCRATCH
     N = u.shape[0]
     if grad_table is None:
         grad_table = torch.zeros_like(table)
@@ -162,10 +170,10 @@ def hashgrid_backward(spec, u, table, dpe, grad_table=None, need_input_grad=True
             raise RuntimeError("a later part of a split backward needs the first part's grad_u")
         grad_u = torch.empty_like(u) if need_input_grad else None
     lib = _lib.load()
-    sizer = queue_sizer(spec, N, u.device) if method == "owner" else None
+    sizer = queue_sizer(spec, N, u.device, clustered) if method == "owner" else None
     if sizer is not None and first:
         sizer.poll()  # grows the queues of levels that overflowed in an earlier backward (the workspace is then re-made)
-    ws = _workspace(spec, N, u.device, sizer) if method == "owner" else None
+    ws = _workspace(spec, N, u.device, sizer, layout) if method == "owner" else None
     if levels is not None and ws is None:
         raise RuntimeError("level ranges exist for the owner method only")
     with torch.cuda.device(u.device):

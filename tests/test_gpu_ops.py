@@ -489,6 +489,10 @@ def test_hashgrid_fwd_bwd_vs_oracle(device, F, layout, method):
     gt2, none = hashgrid_backward(spec, u.to(device), table.to(device), dyk, gt.clone(), False, layout, method)
     assert none is None
     torch.testing.assert_close(gt2.cpu(), 2 * gt_ref, rtol=1e-4, atol=2e-4)
+    # the unclustered hint (points ordered by coarse lattice cell before the aggregation pass) changes nothing but the order of sums
+    gt3, gu3 = hashgrid_backward(spec, u.to(device), table.to(device), dyk, None, True, layout, method, clustered=False)
+    torch.testing.assert_close(gt3.cpu(), gt_ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gu3.cpu(), gu_ref, rtol=1e-4, atol=2e-3)
 
 
 @pytest.mark.parametrize("layout", [0, 1])
@@ -654,6 +658,13 @@ def test_hashgrid_owner_equals_atomic_full_size_uniform(device):
     scale = float(g_atm.abs().max())
     assert float((g_own - g_atm).abs().max()) < 2e-4 * scale
     torch.testing.assert_close(gu_own, gu_atm, rtol=1e-3, atol=1e-3)
+    # ... and the variant made for this distribution (clustered=False: counting sort by coarse cell, then the same two passes on
+    # workgroups of neighbouring points), in both layouts, three times over (the sort's order inside a cell is arrival order)
+    for layout, d in ((0, dy), (1, dy.t().contiguous())):
+        for _ in range(3 if layout == 0 else 1):
+            g_srt, gu_srt = hashgrid_backward(spec, u, table, d, None, True, layout, "owner", clustered=False)
+            assert float((g_srt - g_atm).abs().max()) < 2e-4 * scale
+            torch.testing.assert_close(gu_srt, gu_atm, rtol=1e-3, atol=1e-3)
 
 
 def test_hashgrid_queue_sizer_grows_only_what_overflows(device, monkeypatch):

@@ -3,7 +3,6 @@ on the two mandated point distributions: U = uniform, P = PSF clouds
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import os as _os
-_os.environ.setdefault("NESVOR_HASHGRID_QUEUE", "worst")  # timing tool: worst-case queues from the first call
 import torch
 from nesvor_amd.encoding import hashgrid_backward, hashgrid_forward
 from nesvor_amd.grid import HashGridSpec
@@ -41,9 +40,17 @@ for name, u in (("U", uU), ("P", uP)):
         dy = torch.randn((N, 32) if layout == 0 else (32, N), device=dev)
         gt = torch.zeros_like(table)
         tf = timeit(lambda: hashgrid_forward(spec, u, table, layout, clustered=name == "P"))
-        for method in ("owner", "atomic"):
-            n = 20 if method == "owner" else 3
-            tb = timeit(lambda: hashgrid_backward(spec, u, table, dy, gt, False, layout, method), n)
-            tbi = timeit(lambda: hashgrid_backward(spec, u, table, dy, gt, True, layout, method), n)
+        for method in ("owner", "owner, points as given", "atomic"):
+            if method == "owner, points as given" and name == "P":
+                continue
+            n = 3 if method == "atomic" else 20
+            # "owner": with the hint a caller of this distribution gives (U: clustered=False, the backward orders the points by cell)
+            cl = name == "P" or method == "owner, points as given"
+            m = "atomic" if method == "atomic" else "owner"
+            for _ in range(8):  # (queue capacities settle)
+                hashgrid_backward(spec, u, table, dy, gt, True, layout, m, clustered=cl)
+                torch.cuda.synchronize()
+            tb = timeit(lambda: hashgrid_backward(spec, u, table, dy, gt, False, layout, m, clustered=cl), n)
+            tbi = timeit(lambda: hashgrid_backward(spec, u, table, dy, gt, True, layout, m, clustered=cl), n)
             print(f"{name} layout={layout} {method}: fwd {tf:.3f} ms ({FWD_B/tf/1e6:.0f} GB/s alg)  bwd {tb:.3f} ms ({BWD_B/tb/1e6:.0f} GB/s)"
                   f"  bwd+input {tbi:.3f} ms ({BWDI_B/tbi/1e6:.0f} GB/s)  fwd+bwd frac of 8TB/s: {(FWD_B+BWD_B)/((tf+tb)*1e-3)/8e12:.3f}", flush=True)
