@@ -202,9 +202,13 @@ def measure_extras(model, args, device, opt):
     out["roofline_uniform"] = {
         "bound": "hbm", "kernel": "hashgrid_bwd (aggregate + owner), u ~ U[0,1)^3, N = 2^20", "achieved": (bwd_b + bwd_in_b) / (tb * 1e-3) / 1e9,
         "peak": 8000.0, "unit": "GB/s", "frac": (bwd_b + bwd_in_b) / (tb * 1e-3) / 1e9 / 8000.0, "launch_ms": tb, "forward_ms": tf,
-        "note": "uniform points share no lattice vertices inside a 256-sample workgroup at the fine levels: the per-cloud merge "
-                "table collapses nothing there and the pass is bound by the record stream (8 records of 12 B per point and level) "
-                "and the owner pass's LDS compare-and-swap adds; the training distribution is the PSF-cloud one"}
+        "note": "hashgrid_backward(clustered=False) = NESVOR_LAYOUT_UNCLUSTERED: the points are binned by coarse lattice cell (one ticket "
+                "per point, scan, compact), the feature-major dpe is re-ordered into rows, and the cloud kernels run on workgroups of "
+                "neighbouring points - 38 records per point instead of 128; what is left is the record stream of the four finest levels "
+                "(uniform points share no vertex there: 8 records of 12 B per point and level, written and read back) and the owner "
+                "pass's LDS adds.  Rounds 1-4 ran this distribution through the clustered path as given: 0.18.  The training "
+                "distribution is the PSF-cloud one",
+        "launches": "memset + sort_place + sort_scan + sort_compact + gather_dy_rows + hashgrid_bwd_aggregate + hashgrid_bwd_owner"}
     tf, tb, tb0, tbb = res["psf_cloud"]
     out["roofline_fwd_bwd_strict"] = {
         "bound": "hbm", "kernel": "hashgrid_fwd + hashgrid_bwd, PSF-cloud points, N = 2^20 (SURVEY 8d definition: forward + "

@@ -84,7 +84,6 @@ int main() {
     run<15>("v_cvt_f32_i32", w, base);
     run<6>("v_rndne_f32", w, base);
     run<7>("v_fmac_f32_dpp row_shr", w, base);
-    run<8>("v_cndmask_b32", w, base);
     run<16>("v_and_b32", w, base);
     run<9>("v_lshlrev_b64", w, base);
     run<13>("ds_add_u64 (no confl.)", w, base);
