@@ -1270,6 +1270,64 @@ def test_fused_mlp_compact_save(device, k_a, k_b, b_row0, rows, depth, out_dim, 
                 assert torch.equal(bit.bool(), h[:, b, :, :, r] > 0), (l, b, r)
 
 
+def test_fused_mlp_gate_convention_at_an_exact_plus_zero(device):
+    """The bits-only save keeps [sign bit of the pre-activation clear] per hidden unit (include/nesvor_hip.h, compact_save):
+    an exact +0 - a sample whose input row is all zeros meeting zero biases - passes its gradient, where torch's / tcnn's
+    ReLU'(0) = 0 drops it (round-4 advisor).  Pinned here: for such samples dX is the LINEAR chain W0^T W1^T Wout^T dy, every
+    other sample follows the reference, and the parameter gradients are the reference's (a +0 unit contributes h = 0 to dW and a
+    gradient that meets x = 0 / h_prev = 0; only the biases see it)."""
+    from nesvor_amd import mlp
+    from nesvor_amd.models import build_network
+
+    torch.manual_seed(5)
+    N, S = 4096, 256
+    net = build_network(n_input_dims=32, n_output_dims=16, activation="ReLU", output_activation="None", n_neurons=64,
+                        n_hidden_layers=2, dtype=torch.float32).to(device)
+    L = mlp.linear_layers(net)
+    with torch.no_grad():
+        for l in L:
+            l.bias.zero_()
+    W, Bs = [l.weight.detach() for l in L], [l.bias.detach() for l in L]
+    xb = torch.randn(32, N, device=device)
+    zero = torch.zeros(N, dtype=torch.bool, device=device)
+    zero[64:96] = True  # two whole 16-sample groups ...
+    zero[1000] = True   # ... and a single sample
+    xb[:, zero] = 0.0
+    dy = torch.randn(16, N, device=device)
+    assert mlp.compact_save(mlp.dims_desc(2, 16, 0, 32, 0, S), N)
+    y, saved = mlp.forward_raw(W, Bs, None, xb, 0, 32, S, True)
+    dxb = torch.empty(32, N, device=device)
+    _, partial = mlp.backward_raw(W, Bs, None, xb, dy, saved, 0, 32, S, dxb, False)
+    assert float(y[:, zero].abs().max()) == 0.0
+    x64 = xb.double().t().requires_grad_(True)
+    h = x64
+    for i, (w, b) in enumerate(zip(W, Bs)):
+        h = h @ w.double().t() + b.double()
+        if i < 2:
+            h = torch.relu(h)
+    h.backward(dy.double().t())
+    ref = x64.grad.t()
+    scale = float(ref.abs().max())
+    assert float((dxb[:, ~zero].double() - ref[:, ~zero]).abs().max()) <= 1e-5 * scale
+    assert float(ref[:, zero].abs().max()) == 0.0  # the reference's convention ...
+    lin = (W[0].double().t() @ W[1].double().t() @ W[2].double().t() @ dy.double())[:, zero]
+    assert float((dxb[:, zero].double() - lin).abs().max()) <= 1e-5 * float(lin.abs().max()) and float(lin.abs().max()) > 0  # ... and this library's
+    # weight gradients: unaffected (layout of `partial`: per layer W then b, as the flat parameter segment)
+    gw = partial.sum(0)
+    h = xb.double().t()
+    ws = [w.double().clone().requires_grad_(True) for w in W]
+    for i, w in enumerate(ws):
+        h = h @ w.t()
+        if i < 2:
+            h = torch.relu(h)
+    h.backward(dy.double().t())
+    off = 0
+    for w, b, wg in zip(W, Bs, ws):
+        got = gw[off: off + w.numel()].view_as(w).double()
+        assert float((got - wg.grad).abs().max()) <= 2e-5 * float(wg.grad.abs().max())
+        off += w.numel() + b.numel()
+
+
 # -------------------------------------------------------------------- fused MLP
 @pytest.mark.parametrize("k_a,k_b,b_row0,rows,depth,out_dim,S,N", [
     (0, 32, 0, 32, 2, 16, 8, 1000),     # density_net (ragged N, not a multiple of 16)
