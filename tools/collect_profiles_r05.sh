@@ -73,7 +73,15 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python $ROOT/tools/step_traffic.py $OUT/step_FETCH_SIZE $OUT/step_WRITE_SIZE 20 > $OUT/step_traffic.json
 # 6. micro-benchmarks
-python $ROOT/tools/bench_hashgrid.py > $OUT/hashgrid_microbench.log 2>&1
-python $ROOT/tools/bench_hg_levels.py > $OUT/hashgrid_per_level.log 2>&1
+python $ROOT/tools/bench_hashgrid.py 2>&1 | grep -v amdgpu.ids > $OUT/hashgrid_microbench.log
+python $ROOT/tools/bench_hg_levels.py 2>&1 | grep -v amdgpu.ids > $OUT/hashgrid_per_level.log
+# 7. uniform points through the unclustered backward: kernel stats of its seven launches, per-level times, record counts
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/uni -- python $ROOT/tools/prof_hg_uniform.py 1 > $OUT/uniform_backward.log 2>/dev/null
+cp $(ls $OUT/uni/*/*kernel_stats.csv | head -1) $OUT/uniform_kernel_stats.csv
+python $ROOT/tools/bench_hg_levels.py U 1 2>&1 | grep -v amdgpu.ids > $OUT/uniform_per_level.log
+python $ROOT/tools/queue_stats.py U 1 2>&1 | grep -v amdgpu.ids > $OUT/uniform_queue_stats.log
+python $ROOT/tools/queue_stats.py 2>&1 | grep -v amdgpu.ids > $OUT/psf_queue_stats.log
+# 8. instruction issue rates
+hipcc --offload-arch=gfx950 -O3 $ROOT/tools/valu_rate_probe.hip -o /tmp/valu_rate_probe 2>/dev/null && /tmp/valu_rate_probe > $OUT/valu_rate_probe.log 2>&1
 rm -rf $OUT/kstats $OUT/tl $OUT/tl512 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/mlp_sq1 $OUT/mlp_sq2 $OUT/mlp_sq3 $OUT/mlp_FETCH_SIZE $OUT/mlp_WRITE_SIZE $OUT/step_FETCH_SIZE $OUT/step_WRITE_SIZE
 ls -la $OUT
