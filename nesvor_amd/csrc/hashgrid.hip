@@ -1527,13 +1527,20 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
   __shared__ uint32_t ticket_s;
   const int tid = threadIdx.x;
   // decode (level, chunk, slice) from the flat workgroup id
+  // (-DNESVOR_OWNER_FINE_FIRST=1: the workgroups of the finest level - the longest queues, 21 K records per chunk at level 15 of a
+  //  PSF-cloud batch - get the lowest ids and start first.  Measured in the step, two alternating rounds: owner launch 95-97 us
+  //  against 84-85, 1031-1033 against 1045-1050 it/s: the coarse levels' short workgroups fill the gaps better when they lead.
+  //  -DNESVOR_OWNER_PF=2 / 4 (more of a chunk's AdamW operands requested before the record phase): 86-87 / 90-91 us against 87.)
+#ifndef NESVOR_OWNER_FINE_FIRST
+#define NESVOR_OWNER_FINE_FIRST 0
+#endif
   uint32_t wg = blockIdx.x;
-  int level = 0;
+  int level = NESVOR_OWNER_FINE_FIRST ? g.n_levels - 1 : 0;
   uint32_t spl = 0;
-  for (;; ++level) {
+  for (;; level += NESVOR_OWNER_FINE_FIRST ? -1 : 1) {
     spl = (plan.cap[level] * plan.n_sub + plan.slice[level] - 1) / plan.slice[level];
     const uint32_t cnt = plan.n_chunks[level] * spl;
-    if (wg < cnt || level + 1 >= g.n_levels) break;
+    if (wg < cnt || (NESVOR_OWNER_FINE_FIRST ? level == 0 : level + 1 >= g.n_levels)) break;
     wg -= cnt;
   }
   if (level < plan.level_begin || level >= plan.level_end) return;  // split backward: another launch owns this level
@@ -1553,17 +1560,31 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
   for (int x = 0; x < kSubQueues; ++x) traw[x] = (uint32_t)x < plan.n_sub ? tails[x * kTailStride + gb] : 0u;
   const uint32_t e0 = chunk << plan.shift[level];
   const uint32_t ne = min((uint32_t)(1u << plan.shift[level]), g.size[level] - e0);
-  float4 pf_p = make_float4(0.f, 0.f, 0.f, 0.f), pf_m = pf_p, pf_v = pf_p, pf_o = pf_p;
+  // NESVOR_OWNER_PF float4 per thread and array (parameters, both moments, old gradient) are requested here, before the record
+  // phase: 1 = the first of a full chunk's four sweeps (round 4), 4 = the whole chunk (64 more VGPRs: two workgroups per CU)
+#ifndef NESVOR_OWNER_PF
+#define NESVOR_OWNER_PF 1
+#endif
+  constexpr int kPF = NESVOR_OWNER_PF;
+  float4 pf_p[kPF], pf_m[kPF], pf_v[kPF], pf_o[kPF];
+#pragma unroll
+  for (int j = 0; j < kPF; ++j) pf_p[j] = pf_m[j] = pf_v[j] = pf_o[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   bool prefetched = false;
   if constexpr (ADAM && NESVOR_OWNER_EARLY) {
     const uint32_t nf = ne * F;
-    if (nf % 4u == 0u && (uint32_t)tid < nf / 4u) {
+    if (nf % 4u == 0u) {
       const size_t first = ((size_t)g.offset[level] + e0) * F;
-      pf_p = reinterpret_cast<const float4*>(adam.param + first)[tid];
-      pf_m = reinterpret_cast<const float4*>(adam.exp_avg + first)[tid];
-      pf_v = reinterpret_cast<const float4*>(adam.exp_avg_sq + first)[tid];
-      pf_o = reinterpret_cast<const float4*>(grad_table + first)[tid];
       prefetched = true;
+#pragma unroll
+      for (int j = 0; j < kPF; ++j) {
+        const uint32_t t = (uint32_t)tid + (uint32_t)j * kOwnerThreads;
+        if (t < nf / 4u) {
+          pf_p[j] = reinterpret_cast<const float4*>(adam.param + first)[t];
+          pf_m[j] = reinterpret_cast<const float4*>(adam.exp_avg + first)[t];
+          pf_v[j] = reinterpret_cast<const float4*>(adam.exp_avg_sq + first)[t];
+          pf_o[j] = reinterpret_cast<const float4*>(grad_table + first)[t];
+        }
+      }
     }
   }
   if (NESVOR_OWNER_EARLY) {
@@ -1724,16 +1745,21 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
     if (nf % 4u == 0u) {  // (chunks and level offsets are multiples of 8 entries: aligned)
       const float4* a4 = reinterpret_cast<const float4*>(acc);
       float4* o4 = reinterpret_cast<float4*>(out);
-      for (uint32_t t = tid; t < nf / 4u; t += kOwnerThreads) {
-        const bool first_it = prefetched && t == (uint32_t)tid;  // (this thread's first float4 arrived during the record phase)
-        float4 p = first_it ? pf_p : reinterpret_cast<float4*>(P)[t], m = first_it ? pf_m : reinterpret_cast<float4*>(M)[t],
-               v = first_it ? pf_v : reinterpret_cast<float4*>(V)[t];
-        const float4 o = first_it ? pf_o : o4[t], a = a4[t];
+      auto sweep = [&](uint32_t t, float4 p, float4 m, float4 v, const float4 o) __attribute__((always_inline)) {
+        const float4 a = a4[t];
         adam1(p.x, a.x + o.x, m.x, v.x, adam.a); adam1(p.y, a.y + o.y, m.y, v.y, adam.a);
         adam1(p.z, a.z + o.z, m.z, v.z, adam.a); adam1(p.w, a.w + o.w, m.w, v.w, adam.a);
         reinterpret_cast<float4*>(P)[t] = p; reinterpret_cast<float4*>(M)[t] = m; reinterpret_cast<float4*>(V)[t] = v;
         if (o.x != 0.f || o.y != 0.f || o.z != 0.f || o.w != 0.f) o4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      };
+      uint32_t t = tid;
+      if (prefetched) {  // (these float4 arrived during the record phase)
+#pragma unroll
+        for (int j = 0; j < kPF; ++j, t += kOwnerThreads)
+          if (t < nf / 4u) sweep(t, pf_p[j], pf_m[j], pf_v[j], pf_o[j]);
       }
+      for (; t < nf / 4u; t += kOwnerThreads)
+        sweep(t, reinterpret_cast<float4*>(P)[t], reinterpret_cast<float4*>(M)[t], reinterpret_cast<float4*>(V)[t], o4[t]);
     } else {
       for (uint32_t t = tid; t < nf; t += kOwnerThreads) {
         const float o = out[t];
