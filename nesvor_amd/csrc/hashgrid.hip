@@ -1522,7 +1522,8 @@ template <int F, bool COALESCED, bool ADAM = false>
 __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor_grid_t g, const BwdPlan plan,
                                                           const uint32_t* __restrict__ tails,
                                                           const uint32_t* __restrict__ records,
-                                                          float* __restrict__ grad_table, const OwnerAdam adam) {
+                                                          float* __restrict__ grad_table, const OwnerAdam adam,
+                                                          uint32_t id_stride) {  // workgroup id -> (id * id_stride) mod grid: coprime to the grid size (1: identity)
   __shared__ __attribute__((aligned(16))) float acc[kOwnerLdsFloats];
   __shared__ uint32_t ticket_s;
   const int tid = threadIdx.x;
@@ -1534,7 +1535,7 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
 #ifndef NESVOR_OWNER_FINE_FIRST
 #define NESVOR_OWNER_FINE_FIRST 0
 #endif
-  uint32_t wg = blockIdx.x;
+  uint32_t wg = (uint32_t)(((uint64_t)blockIdx.x * id_stride) % gridDim.x);
   int level = NESVOR_OWNER_FINE_FIRST ? g.n_levels - 1 : 0;
   uint32_t spl = 0;
   for (;; level += NESVOR_OWNER_FINE_FIRST ? -1 : 1) {
@@ -2166,14 +2167,21 @@ owner_stage:
   if (stages & 2) {
     static const int coalesced = []() { const char* e = getenv("NESVOR_OWNER_COALESCED"); return e == nullptr ? 1 : atoi(e); }();
     OwnerAdam oa{};
+    // NESVOR_OWNER_STRIDE=<odd number> (A/B switch): deal the (level, chunk) pairs to the workgroup ids with that stride instead
+    // of level by level; raised to the next number coprime to the grid size
+    static const uint32_t want = []() { const char* e = getenv("NESVOR_OWNER_STRIDE"); return e ? (uint32_t)atoi(e) : 1u; }();
+    const uint32_t og = owner_grid(g, plan);
+    uint32_t id_stride = want < 1u ? 1u : want;
+    auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+    while (id_stride > 1u && gcd(id_stride, og) != 1u) ++id_stride;
     if (adam != nullptr) {
       oa = *adam;
       oa.done = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + 2 * kTailBytes);
-      hipLaunchKernelGGL((hashgrid_bwd_owner<F, true, true>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt, oa);
+      hipLaunchKernelGGL((hashgrid_bwd_owner<F, true, true>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt, oa, id_stride);
     } else if (coalesced)
-      hipLaunchKernelGGL((hashgrid_bwd_owner<F, true>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt, oa);
+      hipLaunchKernelGGL((hashgrid_bwd_owner<F, true>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt, oa, id_stride);
     else
-      hipLaunchKernelGGL((hashgrid_bwd_owner<F, false>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt, oa);
+      hipLaunchKernelGGL((hashgrid_bwd_owner<F, false>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt, oa, id_stride);
   }
   return (int)hipGetLastError();
 }
