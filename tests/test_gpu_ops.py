@@ -729,11 +729,12 @@ def test_hashgrid_queue_overflow_fallback_is_exact(device, dist, monkeypatch):
     torch.testing.assert_close(gu_small, gu_ref, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("split", [12, 5, 15])
-def test_hashgrid_backward_split_by_levels(device, split):
+@pytest.mark.parametrize("split,clustered", [(12, True), (5, True), (15, True), (12, False), (5, False)])
+def test_hashgrid_backward_split_by_levels(device, split, clustered):
     """nesvor_hashgrid_backward_levels: the fine levels [split, L) first, then [0, split) with the queue tails kept and
     the input gradient accumulated, must equal the one-launch backward (a data-parallel step overlaps the all-reduce
-    of the first part with the second)."""
+    of the first part with the second).  clustered=False: shuffled points through the unclustered variant - the second launch
+    re-uses the first one's point order and re-ordered d pe."""
     from nesvor_amd.encoding import hashgrid_backward
     from nesvor_amd.grid import HashGridSpec
 
@@ -741,16 +742,19 @@ def test_hashgrid_backward_split_by_levels(device, split):
     u = _psf_cloud(512, 256, 7).to(device)
     N = u.shape[0]
     g = torch.Generator().manual_seed(3)
+    if not clustered:
+        u = u[torch.randperm(N, generator=g).to(device)].contiguous()
     table = (torch.randn(spec.n_params, generator=g) * 0.1).to(device)
     dy = torch.randn(32, N, generator=g).to(device)
-    g_ref, gu_ref = hashgrid_backward(spec, u, table, dy, None, True, 1, "owner")
-    g_a, gu = hashgrid_backward(spec, u, table, dy, None, True, 1, "owner", levels=(split, 16))
+    g_ref, gu_ref = hashgrid_backward(spec, u, table, dy, None, True, 1, "atomic" if not clustered else "owner")
+    g_a, gu = hashgrid_backward(spec, u, table, dy, None, True, 1, "owner", levels=(split, 16), clustered=clustered)
     cut = spec.levels[split].offset * 2
+    tol = dict(rtol=1e-5, atol=1e-6) if clustered else dict(rtol=1e-4, atol=2e-5 * float(g_ref.abs().max()))  # (against atomics)
     assert float(g_a[:cut].abs().max()) == 0.0  # nothing of the coarse levels yet
-    torch.testing.assert_close(g_a[cut:], g_ref[cut:], rtol=1e-5, atol=1e-6)
-    g_b, gu = hashgrid_backward(spec, u, table, dy, g_a, True, 1, "owner", levels=(0, split), grad_u=gu, first=False)
-    torch.testing.assert_close(g_b, g_ref, rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(gu, gu_ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(g_a[cut:], g_ref[cut:], **tol)
+    g_b, gu = hashgrid_backward(spec, u, table, dy, g_a, True, 1, "owner", levels=(0, split), grad_u=gu, first=False, clustered=clustered)
+    torch.testing.assert_close(g_b, g_ref, **tol)
+    torch.testing.assert_close(gu, gu_ref, rtol=1e-4, atol=1e-5 if clustered else 1e-4 * float(gu_ref.abs().max()))
 
 
 def test_hashgrid_points_outside_unit_cube(device):
