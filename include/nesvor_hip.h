@@ -442,6 +442,10 @@ int nesvor_imaging_loss(const nesvor_loss_t* args, void* stream);
  *             imageReg = img_scale * sum(loss_pix[:,2]) + img_offset. */
 int nesvor_step_prologue(const float* logit_coef, float* c, const float* axisangle, float* mat, float* zero_buf,
                          int n_zero, int n, void* stream);
+/* The same launch with one more workgroup: NeSVoR.trans_loss (nesvor_trans_loss's arithmetic) for the n slices -
+ * trans_terms (n) and g_trans (n,6) are overwritten.  axisangle_init NULL: exactly nesvor_step_prologue. */
+int nesvor_step_prologue_pose(const float* logit_coef, float* c, const float* axisangle, float* mat, float* zero_buf,
+                              int n_zero, int n, const float* axisangle_init, float* trans_terms, float* g_trans, void* stream);
 int nesvor_step_epilogue(const float* dc, const float* c, float* dlogit, const float* dmat, const float* axisangle,
                          const float* dtrans, float w_trans, float* daxisangle, const float* loss_pix,
                          const float* trans_terms, float* losses, int n, int B, float img_scale, float img_offset,

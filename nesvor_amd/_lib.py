@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NESVOR_HIP_LIB: load another build of the same ABI (tools/ablate_hashgrid.py times variants of one kernel this way)
 LIB_PATH = os.environ.get("NESVOR_HIP_LIB") or os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -156,6 +156,7 @@ _SIGNATURES = {
     "nesvor_slice_grads_by_slice": ([_P] * 9 + [c_int, c_int, c_int, c_int, _P], c_int),
     "nesvor_slice_grads": ([_P] * 9 + [c_int, c_int, c_int, _P], c_int),
     "nesvor_step_prologue": ([_P] * 5 + [c_int, c_int, _P], c_int),
+    "nesvor_step_prologue_pose": ([_P] * 5 + [c_int, c_int, _P, _P, _P, _P], c_int),
     "nesvor_step_epilogue": ([_P] * 6 + [c_float, _P, _P, _P, _P, c_int, c_int, c_float, c_float, _P], c_int),
     "nesvor_hashgrid_backward_adamw": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P, _P, _P, _P, POINTER(AdamwT), _P], c_int),
     "nesvor_adamw_step": (

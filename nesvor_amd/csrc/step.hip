@@ -27,6 +27,7 @@ namespace {
 struct StepCtx {
   nesvor_step_t d;
   hipEvent_t ev_fork, ev_pose, ev_agg, ev_owner, ev_bwd, ev_sums, ev_norms, ev_sg0, ev_sg1;
+  bool head_on_side = false;  // (NESVOR_STEP_HEAD=side: phase 2 of a split run must join what phase 1 forked)
   bool sums_on_side = false;  // the networks' parameter-gradient sums of the current iteration were left on the side stream
   bool pending_join = false;  // a table update of the previous run is still on the side stream (NESVOR_STEP_DEFER_JOIN)
   // nesvor_step_timing: HIP-event brackets around the PRODUCT launches of a run, each pair on the stream its launch goes to
@@ -221,29 +222,39 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   if (ctx->timing) { for (int k = 0; k < NESVOR_STEP_TIMED_SPANS; ++k) ctx->span_used[k] = false; ctx->timed_run = true; }
   if (phase != 2) {
     // ---- forward
-    NESVOR_TRY(nesvor_step_prologue(d.has_c ? d.logit_coef : nullptr, c, d.axisangle, mat, acc, 13 * n + 1 + 3 * NESVOR_MLP_PREP_FLOATS, n, main));
-    // side stream, behind the prologue's zero-fill: the networks' weight norms and the slice embedding's bound (functions of the
-    // parameters alone), then the pose regulariser (a serial chain per slice, independent of the batch; joined at the epilogue)
+    // ONE launch: slice scales, pose matrices, zero-fill of the per-slice accumulators and operand bounds, and the pose regulariser
+    // with its gradient (a function of the parameters alone).  Behind it, on the SAME stream: the networks' weight norms and the
+    // slice embedding's bound.  NESVOR_STEP_HEAD=side (A/B switch) restores rounds 4-5's arrangement - both on the side stream,
+    // forked behind the prologue, joined in front of the first network / at the epilogue: the fork's event record and the joins'
+    // waits each hold the main stream for 6-8 us (kernel -> marker -> kernel), more than the launches they hide.
+    static const bool head_on_side = []() { const char* e = getenv("NESVOR_STEP_HEAD"); return e != nullptr && e[0] == 's'; }();
+    const bool pose_in_prologue = d.opt_T && !head_on_side;
+    NESVOR_TRY(nesvor_step_prologue_pose(d.has_c ? d.logit_coef : nullptr, c, d.axisangle, mat, acc, 13 * n + 1 + 3 * NESVOR_MLP_PREP_FLOATS, n,
+                                         pose_in_prologue ? d.axisangle_init : nullptr, pose_in_prologue ? d.trans_terms : nullptr,
+                                         pose_in_prologue ? d.g_trans : nullptr, main));
     const bool any_split = split_d || split_s || split_b;
-    if (d.opt_T || any_split) {
+    hipStream_t head = main;
+    if (head_on_side && (d.opt_T || any_split)) {
       if (hipEventRecord(ctx->ev_fork, main) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_fork, 0) != hipSuccess) return (int)hipGetLastError();
-      if (any_split) {
-        const nesvor_mlp_t* nets[3]; float* preps[3]; int nn = 0;
-        if (split_d) { nets[nn] = &net_d; preps[nn++] = prep_d; }
-        if (split_s) { nets[nn] = &net_s; preps[nn++] = prep_s; }
-        if (split_b) { nets[nn] = &net_b; preps[nn++] = prep_b; }
-        // ONE launch: the weight norms of all networks and - the pixel features of sigma_net are rows of the slice embedding -
-        // the table's maximum as their bound
-        const bool se_bound = split_s && d.ks > 0;
-        NESVOR_TRY(nesvor_mlp_prepare_weights(nets, preps, nn, se_bound ? d.slice_embedding : nullptr, (int64_t)n * d.ks,
-                                              se_bound ? prep_s + NESVOR_MLP_PREP_XA : nullptr, side));
-        if (hipEventRecord(ctx->ev_norms, side) != hipSuccess) return (int)hipGetLastError();
-      }
-      if (d.opt_T) {
-        NESVOR_TRY(nesvor_trans_loss(d.axisangle, d.axisangle_init, d.trans_terms, d.g_trans, n, side));
-        if (hipEventRecord(ctx->ev_pose, side) != hipSuccess) return (int)hipGetLastError();
-      }
+      head = side;
     }
+    if (any_split) {
+      const nesvor_mlp_t* nets[3]; float* preps[3]; int nn = 0;
+      if (split_d) { nets[nn] = &net_d; preps[nn++] = prep_d; }
+      if (split_s) { nets[nn] = &net_s; preps[nn++] = prep_s; }
+      if (split_b) { nets[nn] = &net_b; preps[nn++] = prep_b; }
+      // ONE launch: the weight norms of all networks and - the pixel features of sigma_net are rows of the slice embedding -
+      // the table's maximum as their bound
+      const bool se_bound = split_s && d.ks > 0;
+      NESVOR_TRY(nesvor_mlp_prepare_weights(nets, preps, nn, se_bound ? d.slice_embedding : nullptr, (int64_t)n * d.ks,
+                                            se_bound ? prep_s + NESVOR_MLP_PREP_XA : nullptr, head));
+      if (head_on_side && hipEventRecord(ctx->ev_norms, side) != hipSuccess) return (int)hipGetLastError();
+    }
+    if (head_on_side && d.opt_T) {
+      NESVOR_TRY(nesvor_trans_loss(d.axisangle, d.axisangle_init, d.trans_terms, d.g_trans, n, side));
+      if (hipEventRecord(ctx->ev_pose, side) != hipSuccess) return (int)hipGetLastError();
+    }
+    ctx->head_on_side = head_on_side;
     {
       Span t(ctx, NESVOR_STEP_SPAN_PSF_FWD, main);
       NESVOR_TRY(nesvor_psf_transform_forward_rng_gather(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.x, d.u, B, S,
@@ -258,7 +269,7 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
       NESVOR_TRY(nesvor_hashgrid_forward_bounded(&d.grid, d.u, d.table, d.pe, N, layout | (S >= 128 ? NESVOR_LAYOUT_CLUSTERED : 0),
                                                  split_d ? prep_d + NESVOR_MLP_PREP_XB : nullptr, main));
     }
-    if (any_split && hipStreamWaitEvent(main, ctx->ev_norms, 0) != hipSuccess) return (int)hipGetLastError();
+    if (head_on_side && any_split && hipStreamWaitEvent(main, ctx->ev_norms, 0) != hipSuccess) return (int)hipGetLastError();
     {
       Span t(ctx, NESVOR_STEP_SPAN_MLP_FWD_DENSITY, main);
       NESVOR_TRY(nesvor_mlp_forward(&net_d, nullptr, d.pe, d.z, d.saved_d, N, main));
@@ -416,7 +427,7 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
     if (d.has_lv && d.has_b && d.ks)  // second consumer of the slice embedding
       NESVOR_TRY(slice_grads(nullptr, nullptr, d.dxa_b, nullptr, nullptr, nullptr, d.g_slice_embedding, nullptr, main));
   }
-  if (d.opt_T && hipStreamWaitEvent(main, ctx->ev_pose, 0) != hipSuccess) return (int)hipGetLastError();
+  if (ctx->head_on_side && d.opt_T && hipStreamWaitEvent(main, ctx->ev_pose, 0) != hipSuccess) return (int)hipGetLastError();
   const float img_scale = (d.reg_type == 0 ? d.delta : 1.f) / (float)N, img_off = d.reg_type == 0 ? -d.delta : 0.f;
   NESVOR_TRY(nesvor_step_epilogue(d.has_c ? dc : nullptr, c, d.has_c ? d.g_logit_coef : nullptr, d.opt_T ? dmat : nullptr, d.axisangle,
                                   d.opt_T ? d.g_trans : nullptr, d.w_T, d.opt_T ? d.g_axisangle : nullptr, d.loss_pix,

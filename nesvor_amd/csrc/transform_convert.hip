@@ -218,10 +218,8 @@ __global__ void mat2ax_bwd(const T* __restrict__ mat, const T* __restrict__ gax,
 // launches incl. batched 3x3 GEMMs, every iteration):
 //   err = axisangle( inv(T_init) o T_cur );  loss = mean(err_R^2) + 1e-3 mean(err_T^2)
 // per slice: loss_k (its share of the two means) and d loss / d axisangle_k.
-__global__ void trans_loss_kernel(const float* __restrict__ ax, const float* __restrict__ ax_init,
-                                  float* __restrict__ loss_k, float* __restrict__ grad_ax, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void trans_loss_one(int i, const float* __restrict__ ax, const float* __restrict__ ax_init,
+                                               float* __restrict__ loss_k, float* __restrict__ grad_ax, int n) {
   float a[6], a0[6], X[12], Y[12], M[12], err[6];
 #pragma unroll
   for (int d = 0; d < 6; ++d) { a[d] = ax[(size_t)i * 6 + d]; a0[d] = ax_init[(size_t)i * 6 + d]; }
@@ -255,6 +253,12 @@ __global__ void trans_loss_kernel(const float* __restrict__ ax, const float* __r
 #pragma unroll
   for (int d = 0; d < 6; ++d) grad_ax[(size_t)i * 6 + d] = g[d];
 }
+__global__ void trans_loss_kernel(const float* __restrict__ ax, const float* __restrict__ ax_init,
+                                  float* __restrict__ loss_k, float* __restrict__ grad_ax, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  trans_loss_one(i, ax, ax_init, loss_k, grad_ax, n);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Small-tensor bookkeeping of one training iteration, two launches instead of ~15 (per-slice tensors of a few
@@ -277,9 +281,18 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red /* 16 floats
 
 __global__ __launch_bounds__(1024) void step_prologue_kernel(const float* __restrict__ logit_coef, float* __restrict__ c,
                                                             const float* __restrict__ axisangle, float* __restrict__ mat,
-                                                            float* __restrict__ zero_buf, int n_zero, int n) {
+                                                            float* __restrict__ zero_buf, int n_zero, int n,
+                                                            const float* __restrict__ ax_init, float* __restrict__ trans_k,
+                                                            float* __restrict__ trans_grad) {
   __shared__ float red[16];
-  // (grid = 3: softmax | pose matrices | zero-fill, one workgroup each)
+  // (grid = 3 or 4: softmax | pose matrices | zero-fill | pose regulariser, one workgroup each)
+  if (blockIdx.x == 3) {
+    // NeSVoR.trans_loss and its gradient (trans_loss_kernel's arithmetic): a function of the parameters alone, so it rides in the
+    // iteration's first launch instead of one of its own on a second stream (round 5: the fork's and the join's event markers
+    // cost the main stream 6-8 us each, more than the kernel)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) trans_loss_one(i, axisangle, ax_init, trans_k, trans_grad, n);
+    return;
+  }
   if (blockIdx.x == 1) {
     if (axisangle != nullptr)
       for (int i = threadIdx.x; i < n; i += blockDim.x) ax2mat_fwd_one(axisangle + (size_t)i * 6, mat + (size_t)i * 12);
@@ -357,12 +370,19 @@ int launch1d(K kernel, int n, void* stream, Args... args) {
 
 }  // namespace
 
+extern "C" int nesvor_step_prologue_pose(const float* logit_coef, float* c, const float* axisangle, float* mat, float* zero_buf,
+                                         int n_zero, int n, const float* axisangle_init, float* trans_terms, float* g_trans, void* stream) {
+  if (n <= 0) return 0;
+  const bool pose = axisangle_init != nullptr;
+  if (pose && (axisangle == nullptr || trans_terms == nullptr || g_trans == nullptr)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(step_prologue_kernel, dim3(pose ? 4 : 3), dim3(1024), 0, (hipStream_t)stream, logit_coef, c, axisangle, mat, zero_buf,
+                     n_zero, n, axisangle_init, trans_terms, g_trans);
+  return (int)hipGetLastError();
+}
+
 extern "C" int nesvor_step_prologue(const float* logit_coef, float* c, const float* axisangle, float* mat, float* zero_buf,
                                     int n_zero, int n, void* stream) {
-  if (n <= 0) return 0;
-  hipLaunchKernelGGL(step_prologue_kernel, dim3(3), dim3(1024), 0, (hipStream_t)stream, logit_coef, c, axisangle, mat, zero_buf,
-                     n_zero, n);
-  return (int)hipGetLastError();
+  return nesvor_step_prologue_pose(logit_coef, c, axisangle, mat, zero_buf, n_zero, n, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int nesvor_step_epilogue(const float* dc, const float* c, float* dlogit, const float* dmat, const float* axisangle,

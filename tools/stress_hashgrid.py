@@ -34,18 +34,23 @@ for case in range(n_cases):
     assert torch.equal(hashgrid_forward(spec, u, table, layout, clustered=True), pe), "cloud forward != level forward"
     g_atm, gu_atm = hashgrid_backward(spec, u, table, dy, None, True, layout, "atomic")
     from nesvor_amd.encoding import _workspace
+    cl = bool(ri(0, 1))  # the clustered hint is free to be wrong: the unclustered variant orders any batch by cell first
+    if ri(0, 3) == 0:
+        perm = torch.randperm(N, generator=g).to(dev)  # a shuffled batch
+        u = u[perm].contiguous(); dy = (dy[perm] if layout == 0 else dy[:, perm]).contiguous(); pe = (pe[perm] if layout == 0 else pe[:, perm]).contiguous()
+        g_atm, gu_atm = hashgrid_backward(spec, u, table, dy, None, True, layout, "atomic")
     if L > 1 and ri(0, 1) and _workspace(spec, N, dev) is not None:  # (tables beyond the plan's 256 chunks per level use the atomic kernel)
         split = ri(1, L - 1)
-        g_own, gu = hashgrid_backward(spec, u, table, dy, None, True, layout, "owner", levels=(split, L))
-        g_own, gu_own = hashgrid_backward(spec, u, table, dy, g_own, True, layout, "owner", levels=(0, split), grad_u=gu, first=False)
+        g_own, gu = hashgrid_backward(spec, u, table, dy, None, True, layout, "owner", levels=(split, L), clustered=cl)
+        g_own, gu_own = hashgrid_backward(spec, u, table, dy, g_own, True, layout, "owner", levels=(0, split), grad_u=gu, first=False, clustered=cl)
     else:
-        g_own, gu_own = hashgrid_backward(spec, u, table, dy, None, True, layout, "owner")
+        g_own, gu_own = hashgrid_backward(spec, u, table, dy, None, True, layout, "owner", clustered=cl)
     scale = float(g_atm.abs().max()) + 1e-12
     e1 = float((g_own - g_atm).abs().max()) / scale
     e2 = float((gu_own - gu_atm).abs().max()) / (float(gu_atm.abs().max()) + 1e-12)
     lhs = float((pe.double() * dy.double()).sum()); rhs = float((table.double() * g_own.double()).sum())
     e3 = abs(lhs - rhs) / (abs(lhs) + 1e-3 * N**0.5 + 1e-9)
     ok = e1 < 5e-4 and e2 < 5e-3 and e3 < 5e-4
-    print(f"case {case:3d} F={F} L={L:2d} T=2^{spec.levels[-1].size.bit_length()-1 if spec.levels[-1].hashed else 0:2d} kind={kind} N={N:7d} layout={layout}: dW {e1:.1e} du {e2:.1e} adj {e3:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+    print(f"case {case:3d} F={F} L={L:2d} T=2^{spec.levels[-1].size.bit_length()-1 if spec.levels[-1].hashed else 0:2d} kind={kind} N={N:7d} layout={layout} {'clustered' if cl else 'unclust. '}: dW {e1:.1e} du {e2:.1e} adj {e3:.1e} {'ok' if ok else 'FAIL'}", flush=True)
     if not ok: sys.exit(1)
 print("all ok")
