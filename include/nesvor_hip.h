@@ -558,6 +558,9 @@ typedef struct {
   float* saved_d[NESVOR_MAX_MLP_LAYERS];
   float* saved_s[NESVOR_MAX_MLP_LAYERS];
   float* saved_b[NESVOR_MAX_MLP_LAYERS];
+  float* dpre_scratch[NESVOR_MAX_MLP_LAYERS]; /* N_pad16 * 64 floats per hidden layer, shared by the networks' backwards one after the
+                                               other; only read for networks nesvor_mlp_backward_fused_ok() refuses (samples per pixel
+                                               or pixel features not in multiples of 16 ...): may be NULL when it takes them all */
   void* hg_workspace;
   const float* queue_scale;
   void* side_stream;

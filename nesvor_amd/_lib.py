@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NESVOR_HIP_LIB: load another build of the same ABI (tools/ablate_hashgrid.py times variants of one kernel this way)
 LIB_PATH = os.environ.get("NESVOR_HIP_LIB") or os.path.join(_HERE, "lib", "libnesvor_hip.so")
 MAX_LEVELS = 32
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 LAYOUT_ROW_MAJOR = 0
 LAYOUT_FEATURE_MAJOR = 1
@@ -79,7 +79,7 @@ class StepT(Structure):
         + [(n, c_void_p) for n in ("small", "x", "u", "pe", "z", "log_var", "log_bias", "se", "dz", "dlv", "dlb", "dxl", "loss_pix", "pix",
                                    "dpe", "dpe_b", "du", "dpix", "dxa", "dxa_b", "trans_terms", "g_trans", "lb_mean", "mean_scratch",
                                    "partial")]
-        + [("saved_d", c_void_p * 4), ("saved_s", c_void_p * 4), ("saved_b", c_void_p * 4)]
+        + [("saved_d", c_void_p * 4), ("saved_s", c_void_p * 4), ("saved_b", c_void_p * 4), ("dpre_scratch", c_void_p * 4)]
         + [("hg_workspace", c_void_p), ("queue_scale", c_void_p), ("side_stream", c_void_p)]
     )
 

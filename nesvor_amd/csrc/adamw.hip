@@ -145,4 +145,4 @@ extern "C" int nesvor_sum_rows_multi(const float* const* in, float* const* out, 
   return (int)hipGetLastError();
 }
 
-extern "C" int nesvor_hip_abi_version(void) { return 34; }
+extern "C" int nesvor_hip_abi_version(void) { return 35; }

@@ -90,10 +90,18 @@ __global__ void square_kernel(const float* __restrict__ m, float* __restrict__ o
 
 int mlp_backward_into(const nesvor_mlp_t& net, int group_sums, const float* xa, const float* xb, const float* dy,
                       float* const* saved, float* dxa, float* dxb, float* partial, float* grad_segment, int n_params,
-                      int64_t N, hipStream_t st, float* dxb_absmax = nullptr) {
+                      int64_t N, hipStream_t st, float* const* dpre_scratch, float* dxb_absmax = nullptr) {
   nesvor_mlp_t d = net;
   d.dxa_group_sums = group_sums;
-  float* no_scratch[NESVOR_MAX_MLP_LAYERS] = {nullptr, nullptr, nullptr, nullptr};  // fused dX + dW + db kernel: no dpre scratch
+  // fused dX + dW + db kernel: no dpre scratch; shapes it refuses (nesvor_mlp_backward_fused_ok) run as a dX launch + a dW launch
+  // through the step's shared scratch
+  float* no_scratch[NESVOR_MAX_MLP_LAYERS] = {nullptr, nullptr, nullptr, nullptr};
+  if (!nesvor_mlp_backward_fused_ok(&d, N)) {
+    for (int l = 0; l < d.n_hidden; ++l) {
+      if (dpre_scratch == nullptr || dpre_scratch[l] == nullptr) return (int)hipErrorInvalidValue;
+      no_scratch[l] = dpre_scratch[l];
+    }
+  }
   // per-workgroup partial sums (columns W0,b0,W1,b1,...); the caller sums them into the network's segment of the flat gradient
   // (ONE launch for all networks of the step, after the last backward: nesvor_sum_rows_multi)
   (void)grad_segment; (void)n_params;
@@ -317,7 +325,7 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
     if (d.has_lv) {  // (its input gradient = rows 1.. of dz: raises the density network's upstream bound next to the loss kernel's row 0)
       Span t(ctx, NESVOR_STEP_SPAN_MLP_BWD_SIGMA, main);
       NESVOR_TRY(mlp_backward_into(net_s, group_sums, d.se, d.z, d.dlv, d.saved_s, d.ks ? d.dxa : nullptr, d.dz + N, part_s,
-                                   d.g_sigma, d.n_sigma_params, N, main, prep_d + NESVOR_MLP_PREP_DY));  // (a scalar publish: slot 0)
+                                   d.g_sigma, d.n_sigma_params, N, main, d.dpre_scratch, prep_d + NESVOR_MLP_PREP_DY));  // (a scalar publish: slot 0)
     }
     // Per-slice sums that do not depend on the hash-grid backward - d slice scale, d slice variance and the slice embedding's
     // gradient (sigma_net's input gradient) - go to the side stream NOW, under the density network's backward and the aggregation
@@ -332,11 +340,11 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
     {
       Span t(ctx, NESVOR_STEP_SPAN_MLP_BWD_DENSITY, main);
       NESVOR_TRY(mlp_backward_into(net_d, 0, nullptr, d.pe, d.dz, d.saved_d, nullptr, d.dpe, part_d, d.g_density,
-                                   d.n_density_params, N, main, dpe_bound));
+                                   d.n_density_params, N, main, d.dpre_scratch, dpe_bound));
     }
     if (d.has_b) {
       NESVOR_TRY(mlp_backward_into(net_b, group_sums, d.se, d.pe, d.dlb, d.saved_b, d.ks ? d.dxa_b : nullptr, d.dpe_b, part_b,
-                                   d.g_bias_net, d.n_bias_params, N, main));
+                                   d.g_bias_net, d.n_bias_params, N, main, d.dpre_scratch));
       const int64_t nb = (int64_t)d.kb_bias * N;
       hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((nb / 4 + 255) / 256 + 1)), dim3(256), 0, main, d.dpe, d.dpe_b, nb);
     }

@@ -180,8 +180,13 @@ class DirectStep:
             return False
         if self.has_b and self.parallel:
             return False
-        # the one-call step launches every network's backward without dpre scratch: the fused kernel must take the shapes
-        # (batch-size independent: asked once)
+        if self.bf16 and not self._fused_backward_takes_all():
+            return False  # (the dX + dW launch pair that other shapes fall back to has no bf16-operand form)
+        return True
+
+    def _fused_backward_takes_all(self) -> bool:
+        """Whether the wave-specialised fused MLP backward takes every network of the model (batch-size independent: asked once);
+        otherwise the one-call step hands the networks a shared dpre scratch (``nesvor_step_t.dpre_scratch``)."""
         if self._native_shapes_ok is None:
             m, a = self.model, self.model.args
             S, E = a.n_samples, m.inr.encoding.spec.n_output_dims
@@ -259,6 +264,11 @@ class DirectStep:
                 slots[i] = new(f"{tag}{i}", n_el)
 
         saved_buffers(d.density, d.saved_d, "saved_d", len(self.d_net.weights) - 1)
+        if not self._fused_backward_takes_all():
+            # some network's backward runs as a dX launch + a dW launch (samples per pixel or pixel features not in multiples of
+            # 16, ...): one set of pre-activation gradients, shared by the networks' backwards one after the other
+            for i in range(max(len(p.weights) - 1 for p in (self.d_net, self.s_net if self.has_lv else self.d_net, self.b_net if self.has_b else self.d_net))):
+                d.dpre_scratch[i] = new(f"dpre{i}", n_pad * 64)
         if self.ks:
             d.se = new("se", B, self.ks)
         rows = N // 16 if (N % 16 == 0 and S % 16 == 0 and self.ks % 16 == 0) else N

@@ -561,7 +561,8 @@ def test_native_step_table_update_in_owner_pass_and_deferred_join(device, golden
     {"n_samples": 16}, {"depth": 2, "n_samples": 16}, {"no_transformation_optimization": True, "n_samples": 16},
     {"no_pixel_variance": True, "n_samples": 16}, {"no_slice_scale": True, "no_slice_variance": True, "n_samples": 16},
     {"image_regularization": "TV", "n_samples": 16}, {"n_levels_bias": 2, "depth": 2, "n_samples": 16},
-    {"n_levels_bias": 2, "no_pixel_variance": True, "n_samples": 32}, {"n_samples": 24}, {"mlp_bf16": True, "n_samples": 16},
+    {"n_levels_bias": 2, "no_pixel_variance": True, "n_samples": 32}, {"n_samples": 24}, {}, {"n_levels_bias": 2, "depth": 2},
+    {"mlp_bf16": True, "n_samples": 16},
 ])
 def test_one_call_step_equals_python_issued_step(device, golden, over):
     """``nesvor_step_run`` (csrc/step.hip: the whole iteration + AdamW enqueued by one C call into buffers allocated once)
@@ -594,12 +595,10 @@ def test_one_call_step_equals_python_issued_step(device, golden, over):
     t2.direct._native_on = False
     if os.environ.get("NESVOR_STEP_NATIVE", "1") == "0":
         pytest.skip("the one-call step is switched off (NESVOR_STEP_NATIVE=0)")
-    if args.n_samples % 16:
-        # the one-call step launches every network's backward without dpre scratch (nesvor_mlp_backward_fused_ok): other sample
-        # counts run as Python-issued launches - checked here, and that they train, by the model tests above
-        assert not t1.direct.native_ready()
-        return
+    # (sample counts that are not multiples of 16 - n_samples = 24 here, 8 in the defaults - leave the wave-specialised MLP backward:
+    #  the one-call step then runs each network's backward as a dX launch + a dW launch through nesvor_step_t.dpre_scratch)
     assert t1.direct.native_ready()
+    assert t1.direct._fused_backward_takes_all() == (args.n_samples % 16 == 0)
     assert not t2.direct.native_ready()
     d = lambda k: torch.tensor(golden[f"fw_{k}"]).to(device)
     # (1) gradients of one iteration, no optimizer: the owner pass of the hash-grid backward sums records in arrival order,
