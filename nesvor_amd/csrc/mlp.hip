@@ -1707,6 +1707,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             settle_group(gy_n, hs_n, mk_n);
           }
         }
+      } else {
+        // (an iteration without a group: nothing was requested - the wait is free, and it tells a reader of the ASSEMBLY, where this
+        //  branch is merged with the one above, that no path leaves an iteration with a prefetch in flight: tools/check_inflight_loads.py)
+        await_loads();
       }
       pair_sync(it);
     };
@@ -1866,6 +1870,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             for (int ib = 0; ib < kHB; ++ib) acc_o[0][ib] = mfma32_f16(a_hl, bh[ib], acc_o[0][ib]);
           }
           settle_xc();
+        } else {
+          await_loads();  // (as in the chain wave's iteration)
         }
         pair_sync(it);
       };
@@ -2025,6 +2031,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
               for (int t = 0; t < 4; ++t) asm volatile("" : "=v"(hraw_c[l][ib][t]));
         }
+      } else {
+        await_loads();  // (as in the chain wave's iteration)
       }
       pair_sync(it);
     };

@@ -1,0 +1,103 @@
+"""CPU: the static check that guards the inline-asm prefetches of csrc/mlp.hip (tools/check_inflight_loads.py, run by the build
+on the generated assembly): it must find a register touched under a load in flight - in straight-line code, around a loop, and
+behind the compiler's merged branch tails - and must stay silent on code that waits, on a re-issue into the same registers and
+on a tail that one arm of a branch enters settled and the other with its flag set."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import check_inflight_loads as chk  # noqa: E402
+
+
+def _findings(text):
+    body = [t.split(";")[0].strip() for t in text.strip().splitlines()]
+    return chk.check([t for t in body if t])
+
+
+def test_use_under_a_load_in_flight_is_found():
+    bad = """
+        global_load_dword v5, v[2:3], off
+        v_add_f32_e32 v6, v5, v5
+        s_waitcnt vmcnt(0)
+    """
+    assert [f[1] for f in _findings(bad)] == ["v_add_f32_e32 v6, v5, v5"]
+    # ... also as a clobber (a register copy INTO a pending destination) and as the address of a later memory operation
+    assert len(_findings("global_load_dwordx4 v[8:11], v[2:3], off\nv_mov_b32_e32 v9, v1\ns_waitcnt vmcnt(0)")) == 1
+    assert len(_findings("global_load_dwordx2 v[4:5], v[2:3], off\nglobal_store_dword v[4:5], v1, off\ns_waitcnt vmcnt(0)")) == 1
+
+
+def test_waits_and_in_order_retirement():
+    ok = """
+        global_load_dword v5, v[2:3], off
+        global_load_dword v7, v[2:3], off offset:4
+        s_waitcnt vmcnt(1)
+        v_add_f32_e32 v6, v5, v5
+        s_waitcnt vmcnt(0)
+        v_add_f32_e32 v6, v7, v6
+    """
+    assert _findings(ok) == []
+    # the older load is retired by vmcnt(1), the younger one is not
+    assert len(_findings(ok.replace("v_add_f32_e32 v6, v5, v5", "v_add_f32_e32 v6, v7, v5"))) == 1
+    # a store behind the load counts as a younger operation (gfx9: one counter)
+    assert _findings("global_load_dword v5, v[2:3], off\nglobal_store_dword v[2:3], v1, off\ns_waitcnt vmcnt(1)\nv_mov_b32_e32 v1, v5") == []
+    # re-issuing into the same registers is fine
+    assert _findings("global_load_dword v5, v[2:3], off\nglobal_load_dword v5, v[2:3], off offset:8\ns_waitcnt vmcnt(0)\nv_mov_b32_e32 v1, v5") == []
+
+
+def test_prefetch_across_a_loop_iteration():
+    loop = """
+        global_load_dword v5, v[2:3], off
+    .LBB0_1:
+        s_waitcnt vmcnt(0)
+        v_add_f32_e32 v6, v5, v6
+        global_load_dword v5, v[2:3], off offset:4
+        v_mul_f32_e32 v7, v6, v6
+        s_cbranch_scc1 .LBB0_1
+        s_waitcnt vmcnt(0)
+        v_mov_b32_e32 v1, v5
+    """
+    assert _findings(loop) == []
+    # without the wait at the loop head the use at the top of the NEXT iteration is under the previous iteration's request
+    assert [f[1] for f in _findings(loop.replace(".LBB0_1:\n        s_waitcnt vmcnt(0)", ".LBB0_1:"))] == ["v_add_f32_e32 v6, v5, v6"]
+
+
+def test_merged_tail_behind_a_flag():
+    """What hipcc makes of `if (group) { issue; ...; settle; } tail;`: both arms jump to ONE tail that tests a flag the arms set
+    - the arm that requested something waits there, the other does not have to."""
+    merged = """
+        s_mov_b64 s[36:37], -1
+        s_cbranch_vccnz .LBB0_3
+        global_load_dword v22, v[2:3], off
+        v_mul_f32_e32 v7, v6, v6
+        s_cbranch_scc1 .LBB0_4
+        s_waitcnt vmcnt(0)
+        v_mov_b32_e32 v1, v22
+    .LBB0_3:
+        s_mov_b64 s[36:37], 0
+    .LBB0_4:
+        s_and_b64 vcc, exec, s[36:37]
+        s_cbranch_vccz .LBB0_5
+        s_waitcnt vmcnt(0)
+        v_mov_b32_e32 v12, v22
+    .LBB0_5:
+        v_mov_b32_e32 v22, s3
+    """
+    assert _findings(merged) == []
+    # the same tail WITHOUT a wait in the flagged arm is a hazard
+    assert len(_findings(merged.replace("        s_waitcnt vmcnt(0)\n        v_mov_b32_e32 v12, v22", "        v_mov_b32_e32 v12, v22"))) >= 1
+
+
+def test_generated_assembly_of_the_mlp_kernels_is_clean():
+    """nesvor_amd/lib/mlp.s is written and checked by the build (nesvor_amd/csrc/build.py: a finding fails the build); here the
+    file of the current library is checked once more, so that a stale or hand-copied library does not slip through."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asm, lib = os.path.join(root, "nesvor_amd", "lib", "mlp.s"), os.path.join(root, "nesvor_amd", "lib", "libnesvor_hip.so")
+    if not (os.path.exists(asm) and os.path.exists(lib)):
+        pytest.skip("library not built here")
+    assert os.path.getmtime(asm) >= os.path.getmtime(os.path.join(root, "nesvor_amd", "csrc", "mlp.hip")), "mlp.s is older than mlp.hip: rebuild"
+    kernels = chk.parse(asm)
+    assert len(kernels) >= 60 and any("mlp_fwd_pf_kernel" in k for k in kernels) and any("mlp_bwd_ws_kernel" in k for k in kernels)
+    found = [(k, f) for k, body in kernels.items() for f in chk.check(body)]
+    assert found == [], found[:5]
