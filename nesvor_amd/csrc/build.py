@@ -36,10 +36,14 @@ def check_inflight_loads(asm_path, verbose=True):
             findings += 1
             print(f"{os.path.basename(asm_path)}: {name}: instruction {where}: `{ins}` touches v{regs} while a load into them is in flight",
                   file=sys.stderr)
+        for where, ins, regs in chk.check_store_data(body):
+            findings += 1
+            print(f"{os.path.basename(asm_path)}: {name}: instruction {where}: `{ins}` overwrites v{regs}, data of the wide store just issued",
+                  file=sys.stderr)
     if verbose:
         print(f"check_inflight_loads: {os.path.basename(asm_path)}: {len(kernels)} kernels, {findings} findings", file=sys.stderr, flush=True)
     if findings:
-        raise RuntimeError(f"{asm_path}: {findings} instruction(s) touch a register with a vector load in flight (see stderr)")
+        raise RuntimeError(f"{asm_path}: {findings} instruction(s) touch a register with a vector load in flight or a wide store's data (see stderr)")
 
 
 def sources():

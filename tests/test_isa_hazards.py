@@ -89,6 +89,16 @@ def test_merged_tail_behind_a_flag():
     assert len(_findings(merged.replace("        s_waitcnt vmcnt(0)\n        v_mov_b32_e32 v12, v22", "        v_mov_b32_e32 v12, v22"))) >= 1
 
 
+def test_wide_store_data_overwritten_too_early():
+    """A dwordx3 / dwordx4 store reads its data registers after issue: the slots right behind it must not overwrite them."""
+    body = lambda text: [t.strip() for t in text.strip().splitlines() if t.strip()]
+    bad = body("global_store_dwordx4 v[2:3], v[8:11], off\nv_mul_f32_e32 v9, v1, v1")
+    assert [f[1] for f in chk.check_store_data(bad)] == ["v_mul_f32_e32 v9, v1, v1"]
+    assert chk.check_store_data(body("global_store_dwordx4 v[2:3], v[8:11], off\ns_nop 1\nv_mul_f32_e32 v9, v1, v1")) == []
+    assert chk.check_store_data(body("global_store_dwordx4 v[2:3], v[8:11], off\nv_mul_f32_e32 v12, v1, v1\nv_add_f32_e32 v13, v1, v1\nv_mul_f32_e32 v9, v1, v1")) == []
+    assert chk.check_store_data(body("global_store_dwordx2 v[2:3], v[8:9], off\nv_mul_f32_e32 v9, v1, v1")) == []  # (64 bits: no hazard)
+
+
 def test_generated_assembly_of_the_mlp_kernels_is_clean():
     """nesvor_amd/lib/mlp.s is written and checked by the build (nesvor_amd/csrc/build.py: a finding fails the build); here the
     file of the current library is checked once more, so that a stale or hand-copied library does not slip through."""
@@ -99,5 +109,5 @@ def test_generated_assembly_of_the_mlp_kernels_is_clean():
     assert os.path.getmtime(asm) >= os.path.getmtime(os.path.join(root, "nesvor_amd", "csrc", "mlp.hip")), "mlp.s is older than mlp.hip: rebuild"
     kernels = chk.parse(asm)
     assert len(kernels) >= 60 and any("mlp_fwd_pf_kernel" in k for k in kernels) and any("mlp_bwd_ws_kernel" in k for k in kernels)
-    found = [(k, f) for k, body in kernels.items() for f in chk.check(body)]
+    found = [(k, f) for k, body in kernels.items() for f in chk.check(body) + chk.check_store_data(body)]
     assert found == [], found[:5]

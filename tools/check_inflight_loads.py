@@ -210,12 +210,48 @@ def check(body):
     return sorted(out)
 
 
+WIDE_STORE = re.compile(r"^(global|buffer|flat|scratch)_store_dwordx[34]\b")
+
+
+def check_store_data(body, wait_states=2):
+    """Second hazard of hand-written memory instructions (the one behind round 5's wrong output-layer dW): a vector store of
+    more than 64 bits reads its data registers AFTER issue, so an instruction that overwrites them within the next
+    `wait_states` issue slots races the read (the compiler inserts s_nop for its own stores; an `asm volatile` store of a
+    temporary has to carry its own).  Straight-line scan: every dwordx3 / dwordx4 store, the slots behind it up to the next
+    label or branch."""
+    out = []
+    for i, t in enumerate(body):
+        mnem = t.split()[0]
+        if not WIDE_STORE.match(mnem):
+            continue
+        toks = [x.strip() for x in t[len(mnem):].split(",")]
+        data = regs_of(toks[1]) if len(toks) > 1 else set()
+        slots, j = 0, i + 1
+        while j < len(body) and slots < wait_states:
+            u = body[j]
+            if LABEL.match(u) or re.match(r"^s_(c?branch|endpgm|setpc)", u):
+                break
+            m2 = u.split()[0]
+            if m2 == "s_nop":
+                slots += int(u.split()[1]) + 1
+            else:
+                if not m2.startswith("s_") and not VMEM.match(m2) and not m2.startswith("ds_write") and not m2.startswith("ds_add"):
+                    dst = regs_of(u[len(m2):].split(",")[0])
+                    if dst & data:
+                        out.append((j, u, sorted(dst & data)))
+                elif LOAD.match(m2) and regs_of(u[len(m2):].split(",")[0]) & data:
+                    pass  # (a load's write-back is many cycles away)
+                slots += 1
+            j += 1
+    return out
+
+
 def main():
     only = sys.argv[2] if len(sys.argv) > 2 else None
     bad = 0
     kernels = parse(sys.argv[1], only)
     for name, body in kernels.items():
-        rep = check(body)
+        rep = check(body) + [(w, i + "   [data registers of the wide store in front of it]", r) for w, i, r in check_store_data(body)]
         n_loads = sum(1 for t in body if LOAD.match(t.split()[0]))
         print(f"{name[:100]}: {len(body)} instructions, {n_loads} vector loads, {len(rep)} findings")
         for where, ins, regs in rep[:20]:
