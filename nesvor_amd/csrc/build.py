@@ -20,7 +20,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off
 # Sources whose kernels keep inline-asm loads in flight across compiler-scheduled code (mlp.hip: issue_load_* / settle_*): the
 # compiler cannot see those loads, so nothing but the register allocation of the day keeps it from touching their destination
 # registers early (round-4 advisor).  The build checks the generated assembly itself: tools/check_inflight_loads.py.
-ASM_CHECKED = ("mlp.hip",)
+ASM_CHECKED = ("mlp.hip", "hashgrid.hip")  # (hashgrid.hip: the segmented scan is inline-asm DPP; its fences are checked the same way)
 
 
 def check_inflight_loads(asm_path, verbose=True):
@@ -35,6 +35,10 @@ def check_inflight_loads(asm_path, verbose=True):
         for where, ins, regs in chk.check(body):
             findings += 1
             print(f"{os.path.basename(asm_path)}: {name}: instruction {where}: `{ins}` touches v{regs} while a load into them is in flight",
+                  file=sys.stderr)
+        for where, ins, regs in chk.check_dpp(body):
+            findings += 1
+            print(f"{os.path.basename(asm_path)}: {name}: instruction {where}: `{ins}` reads v{regs} by DPP less than two slots after a VALU wrote it",
                   file=sys.stderr)
         for where, ins, regs in chk.check_store_data(body):
             findings += 1

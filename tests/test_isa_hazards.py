@@ -99,6 +99,17 @@ def test_wide_store_data_overwritten_too_early():
     assert chk.check_store_data(body("global_store_dwordx2 v[2:3], v[8:9], off\nv_mul_f32_e32 v9, v1, v1")) == []  # (64 bits: no hazard)
 
 
+def test_dpp_source_written_too_late():
+    """A DPP operand must have left the VALU two issue slots before it is read across lanes (csrc/hashgrid.hip's asm scan fences
+    with `s_nop 1`)."""
+    body = lambda text: [t.strip() for t in text.strip().splitlines() if t.strip()]
+    bad = body("v_mul_f32_e32 v4, v1, v2\nv_fmac_f32_dpp v4, v4, v9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+    assert len(chk.check_dpp(bad)) == 1
+    assert chk.check_dpp(body("v_mul_f32_e32 v4, v1, v2\ns_nop 1\nv_fmac_f32_dpp v4, v4, v9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")) == []
+    assert chk.check_dpp(body("v_mul_f32_e32 v4, v1, v2\nv_mul_f32_e32 v5, v1, v2\nv_mul_f32_e32 v6, v1, v2\nv_mov_b32_dpp v7, v4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")) == []
+    assert len(chk.check_dpp(body("v_mul_f32_e32 v4, v1, v2\nv_mul_f32_e32 v5, v1, v2\nv_mov_b32_dpp v7, v4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"))) == 1
+
+
 def test_generated_assembly_of_the_mlp_kernels_is_clean():
     """nesvor_amd/lib/mlp.s is written and checked by the build (nesvor_amd/csrc/build.py: a finding fails the build); here the
     file of the current library is checked once more, so that a stale or hand-copied library does not slip through."""
@@ -109,5 +120,11 @@ def test_generated_assembly_of_the_mlp_kernels_is_clean():
     assert os.path.getmtime(asm) >= os.path.getmtime(os.path.join(root, "nesvor_amd", "csrc", "mlp.hip")), "mlp.s is older than mlp.hip: rebuild"
     kernels = chk.parse(asm)
     assert len(kernels) >= 60 and any("mlp_fwd_pf_kernel" in k for k in kernels) and any("mlp_bwd_ws_kernel" in k for k in kernels)
-    found = [(k, f) for k, body in kernels.items() for f in chk.check(body) + chk.check_store_data(body)]
+    found = [(k, f) for k, body in kernels.items() for f in chk.check(body) + chk.check_store_data(body) + chk.check_dpp(body)]
     assert found == [], found[:5]
+    hg = os.path.join(root, "nesvor_amd", "lib", "hashgrid.s")
+    if os.path.exists(hg):
+        kernels = chk.parse(hg)
+        assert any("hashgrid_bwd_aggregate" in k for k in kernels)
+        found = [(k, f) for k, body in kernels.items() for f in chk.check(body) + chk.check_store_data(body) + chk.check_dpp(body)]
+        assert found == [], found[:5]

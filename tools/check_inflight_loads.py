@@ -246,12 +246,42 @@ def check_store_data(body, wait_states=2):
     return out
 
 
+DPP = re.compile(r"\b(row_shr|row_shl|row_ror|quad_perm|row_bcast|row_mirror|row_half_mirror|wave_shr|wave_shl|wave_ror|wave_rol|row_newbcast)\b")
+
+
+def check_dpp(body, wait_states=2):
+    """Third hazard the hazard recogniser cannot see through inline asm (csrc/hashgrid.hip's segmented scan is written as
+    `v_fmac_f32_dpp` in asm): a DPP instruction reads its source VGPR from the neighbouring lanes' register file ports, and
+    a VALU write of that VGPR needs `wait_states` issue slots before it.  Straight-line scan inside basic blocks."""
+    out = []
+    recent = []  # (slots ago is implied by position) destination registers of the last VALU instructions, newest last
+    for i, t in enumerate(body):
+        if LABEL.match(t) or re.match(r"^s_(c?branch|endpgm|setpc)", t):
+            recent = []
+            continue
+        mnem = t.split()[0]
+        if mnem == "s_nop":
+            recent += [set()] * (int(t.split()[1]) + 1)
+            recent = recent[-wait_states:]
+            continue
+        toks = [x.strip() for x in t[len(mnem):].split(",")]
+        if mnem.startswith("v_") and DPP.search(t) and len(toks) > 1:
+            src = regs_of(toks[1].split()[0])
+            clash = set().union(*recent[-wait_states:]) & src if recent else set()
+            if clash:
+                out.append((i, t, sorted(clash)))
+        recent.append(regs_of(toks[0]) if mnem.startswith("v_") and not mnem.startswith("v_cmp") and toks else set())
+        recent = recent[-wait_states:]
+    return out
+
+
 def main():
     only = sys.argv[2] if len(sys.argv) > 2 else None
     bad = 0
     kernels = parse(sys.argv[1], only)
     for name, body in kernels.items():
         rep = check(body) + [(w, i + "   [data registers of the wide store in front of it]", r) for w, i, r in check_store_data(body)]
+        rep += [(w, i + "   [DPP source written by the VALU less than two slots before]", r) for w, i, r in check_dpp(body)]
         n_loads = sum(1 for t in body if LOAD.match(t.split()[0]))
         print(f"{name[:100]}: {len(body)} instructions, {n_loads} vector loads, {len(rep)} findings")
         for where, ins, regs in rep[:20]:
