@@ -40,6 +40,10 @@ def check_inflight_loads(asm_path, verbose=True):
             findings += 1
             print(f"{os.path.basename(asm_path)}: {name}: instruction {where}: `{ins}` reads v{regs} by DPP less than two slots after a VALU wrote it",
                   file=sys.stderr)
+        for where, ins, regs in chk.check_valu_sgpr(body):
+            findings += 1
+            print(f"{os.path.basename(asm_path)}: {name}: instruction {where}: `{ins}` takes s{regs} as scalar base less than five slots after the VALU wrote it",
+                  file=sys.stderr)
         for where, ins, regs in chk.check_store_data(body):
             findings += 1
             print(f"{os.path.basename(asm_path)}: {name}: instruction {where}: `{ins}` overwrites v{regs}, data of the wide store just issued",

@@ -110,6 +110,15 @@ def test_dpp_source_written_too_late():
     assert len(chk.check_dpp(body("v_mul_f32_e32 v4, v1, v2\nv_mul_f32_e32 v5, v1, v2\nv_mov_b32_dpp v7, v4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"))) == 1
 
 
+def test_scalar_base_written_by_the_valu_too_late():
+    body = lambda text: [t.strip() for t in text.strip().splitlines() if t.strip()]
+    bad = body("v_readfirstlane_b32 s4, v1\nv_readfirstlane_b32 s5, v2\nglobal_load_dword v9, v3, s[4:5] offset:0")
+    assert len(chk.check_valu_sgpr(bad)) == 1
+    assert chk.check_valu_sgpr(body("v_readfirstlane_b32 s4, v1\nv_readfirstlane_b32 s5, v2\ns_nop 4\nglobal_load_dword v9, v3, s[4:5] offset:0")) == []
+    # a SALU write in between makes it the SALU's value (no hazard)
+    assert chk.check_valu_sgpr(body("v_readlane_b32 s4, v1, 0\nv_readlane_b32 s5, v1, 1\ns_and_b64 s[4:5], exec, s[4:5]\nglobal_load_dword v9, v3, s[4:5] offset:0")) == []
+
+
 def test_generated_assembly_of_the_mlp_kernels_is_clean():
     """nesvor_amd/lib/mlp.s is written and checked by the build (nesvor_amd/csrc/build.py: a finding fails the build); here the
     file of the current library is checked once more, so that a stale or hand-copied library does not slip through."""
@@ -120,11 +129,11 @@ def test_generated_assembly_of_the_mlp_kernels_is_clean():
     assert os.path.getmtime(asm) >= os.path.getmtime(os.path.join(root, "nesvor_amd", "csrc", "mlp.hip")), "mlp.s is older than mlp.hip: rebuild"
     kernels = chk.parse(asm)
     assert len(kernels) >= 60 and any("mlp_fwd_pf_kernel" in k for k in kernels) and any("mlp_bwd_ws_kernel" in k for k in kernels)
-    found = [(k, f) for k, body in kernels.items() for f in chk.check(body) + chk.check_store_data(body) + chk.check_dpp(body)]
+    found = [(k, f) for k, body in kernels.items() for f in chk.check(body) + chk.check_store_data(body) + chk.check_dpp(body) + chk.check_valu_sgpr(body)]
     assert found == [], found[:5]
     hg = os.path.join(root, "nesvor_amd", "lib", "hashgrid.s")
     if os.path.exists(hg):
         kernels = chk.parse(hg)
         assert any("hashgrid_bwd_aggregate" in k for k in kernels)
-        found = [(k, f) for k, body in kernels.items() for f in chk.check(body) + chk.check_store_data(body) + chk.check_dpp(body)]
+        found = [(k, f) for k, body in kernels.items() for f in chk.check(body) + chk.check_store_data(body) + chk.check_dpp(body) + chk.check_valu_sgpr(body)]
         assert found == [], found[:5]

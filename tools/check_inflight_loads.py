@@ -275,6 +275,41 @@ def check_dpp(body, wait_states=2):
     return out
 
 
+def check_valu_sgpr(body, wait_states=5):
+    """Fourth: an SGPR written by the VALU (v_readfirstlane / v_readlane / a compare into an SGPR pair) and read as the scalar
+    base of a vector-memory instruction needs `wait_states` issue slots in between (the asm loads of csrc/mlp.hip take their
+    bases in SGPRs).  A later SALU write of the register ends the hazard.  Straight-line scan inside basic blocks."""
+    out, recent = [], []  # recent: per issue slot, the SGPRs the VALU wrote (newest last)
+    for i, t in enumerate(body):
+        if LABEL.match(t) or re.match(r"^s_(c?branch|endpgm|setpc)", t):
+            recent = []
+            continue
+        mnem = t.split()[0]
+        if mnem == "s_nop":
+            recent = (recent + [set()] * (int(t.split()[1]) + 1))[-wait_states:]
+            continue
+        toks = [x.strip() for x in t[len(mnem):].split(",")]
+        if VMEM.match(mnem):
+            used = set()
+            for tok in toks:
+                for w in tok.split():
+                    r = sregs(w)
+                    if r is not None:
+                        used |= set(r)
+            clash = (set().union(*recent) & used) if recent else set()
+            if clash:
+                out.append((i, t, sorted(clash)))
+        written = set()
+        r = sregs(toks[0]) if toks else None
+        if r is not None:
+            if mnem.startswith("v_"):
+                written = set(r)
+            elif mnem.startswith("s_") and not mnem.startswith(("s_cmp", "s_bitcmp", "s_waitcnt")):
+                recent = [w - set(r) for w in recent]  # overwritten by the SALU: no longer the VALU's value
+        recent = (recent + [written])[-wait_states:]
+    return out
+
+
 def main():
     only = sys.argv[2] if len(sys.argv) > 2 else None
     bad = 0
@@ -282,6 +317,7 @@ def main():
     for name, body in kernels.items():
         rep = check(body) + [(w, i + "   [data registers of the wide store in front of it]", r) for w, i, r in check_store_data(body)]
         rep += [(w, i + "   [DPP source written by the VALU less than two slots before]", r) for w, i, r in check_dpp(body)]
+        rep += [(w, i + "   [scalar base written by the VALU less than five slots before]", [f"s{x}" for x in r]) for w, i, r in check_valu_sgpr(body)]
         n_loads = sum(1 for t in body if LOAD.match(t.split()[0]))
         print(f"{name[:100]}: {len(body)} instructions, {n_loads} vector loads, {len(rep)} findings")
         for where, ins, regs in rep[:20]:
