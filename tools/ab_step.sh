@@ -6,7 +6,7 @@ mkdir -p $OUT
 for round in 1 2; do
   for spec in "$@"; do
     name=${spec%%=*}; rest=${spec#*=}; lib=${rest%%,*}; extra=""
-    if [ "$lib" != "$rest" ]; then extra=${rest#*,}; fi   # name=lib.so,ENV=VAL : one extra environment setting
+    if [ "$lib" != "$rest" ]; then extra=${rest#*,}; extra=${extra//,/ }; fi   # name=lib.so,ENV=VAL[,ENV2=VAL2]: extra environment settings
     env NESVOR_HIP_LIB=$lib $extra python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras --no-strict --small-batches "" 2>/dev/null > $OUT/ab_${name}_$round.json
     python - $OUT/ab_${name}_$round.json $name $round <<'PY'
 import json, sys
