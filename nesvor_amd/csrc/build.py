@@ -20,7 +20,9 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off
 # Sources whose kernels keep inline-asm loads in flight across compiler-scheduled code (mlp.hip: issue_load_* / settle_*): the
 # compiler cannot see those loads, so nothing but the register allocation of the day keeps it from touching their destination
 # registers early (round-4 advisor).  The build checks the generated assembly itself: tools/check_inflight_loads.py.
-ASM_CHECKED = ("mlp.hip", "hashgrid.hip")  # (hashgrid.hip: the segmented scan is inline-asm DPP; its fences are checked the same way)
+# (every translation unit: common.h carries issue-now loads of its own - the loss kernel's - and hashgrid.hip's segmented scan is
+#  inline-asm DPP whose fences are checked the same way; the small files cost the build nothing)
+ASM_CHECKED = tuple(sorted(f for f in os.listdir(HERE) if f.endswith(".hip")))
 
 
 def check_inflight_loads(asm_path, verbose=True):

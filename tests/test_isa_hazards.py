@@ -131,9 +131,13 @@ def test_generated_assembly_of_the_mlp_kernels_is_clean():
     assert len(kernels) >= 60 and any("mlp_fwd_pf_kernel" in k for k in kernels) and any("mlp_bwd_ws_kernel" in k for k in kernels)
     found = [(k, f) for k, body in kernels.items() for f in chk.check(body) + chk.check_store_data(body) + chk.check_dpp(body) + chk.check_valu_sgpr(body)]
     assert found == [], found[:5]
-    hg = os.path.join(root, "nesvor_amd", "lib", "hashgrid.s")
-    if os.path.exists(hg):
-        kernels = chk.parse(hg)
-        assert any("hashgrid_bwd_aggregate" in k for k in kernels)
+    # ... and every other translation unit the build wrote (common.h carries issue-now loads of its own; hashgrid.hip an asm DPP scan)
+    import glob
+
+    others = [p for p in glob.glob(os.path.join(root, "nesvor_amd", "lib", "*.s")) if os.path.basename(p) != "mlp.s"]
+    assert any(os.path.basename(p) == "hashgrid.s" for p in others)
+    for path in others:
+        kernels = chk.parse(path)
+        assert kernels, path
         found = [(k, f) for k, body in kernels.items() for f in chk.check(body) + chk.check_store_data(body) + chk.check_dpp(body) + chk.check_valu_sgpr(body)]
-        assert found == [], found[:5]
+        assert found == [], (path, found[:5])
