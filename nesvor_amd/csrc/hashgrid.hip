@@ -28,7 +28,8 @@
 //         wave scan on the VALU sums runs of lanes in the same cell; the run
 //         tails go through a workgroup-wide merge table in LDS (64-bit fixed
 //         point; slots addressed by position in the cloud's lattice box where it
-//         fits, hashed with double hashing otherwise), and the merged (entry,
+//         fits, by the low bits of the vertex's lattice coordinates - a window
+//         over the box - with double hashing on a miss otherwise), and the merged (entry,
 //         grad) records are binned by table chunk and appended to that chunk's
 //         queue in HBM (one LDS counter op per record, one returning atomic per
 //         non-empty (workgroup, chunk) pair, on a counter set private to the
@@ -38,7 +39,11 @@
 //         per 3 cycles on gfx950) and adds the chunk to grad_table with
 //         plain coalesced read-modify-writes - it is the only writer.
 //   Records that do not fit a queue fall back to global atomics, so the
-//   result is exact for any input distribution.  The legacy all-atomics
+//   result is exact for any input distribution.  A batch whose consecutive
+//   points are NOT spatially clustered (NESVOR_LAYOUT_UNCLUSTERED) is first put
+//   into the order of a coarse lattice's cells (sort_place / sort_scan /
+//   sort_compact below; feature-major d pe re-ordered into rows by
+//   gather_dy_rows_kernel) and then takes the same two launches.  The legacy all-atomics
 //   kernel is kept as hashgrid_bwd (used for tiny N and as a cross-check).
 #include <hip/hip_runtime.h>
 #include <mutex>
