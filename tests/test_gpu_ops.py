@@ -667,6 +667,40 @@ def test_hashgrid_owner_equals_atomic_full_size_uniform(device):
             torch.testing.assert_close(gu_srt, gu_atm, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("case", ["one_point", "n255", "n257", "all_in_one_cell", "two_cells", "outside_and_nan_free"])
+def test_hashgrid_unclustered_variant_edge_cases(device, case):
+    """The unclustered backward orders the batch by coarse lattice cell through per-cell strips with a spill list: batches smaller
+    than a workgroup, batches whose points ALL fall into one cell (every ticket beyond the strip's capacity spills), two dense
+    cells, and points outside the unit cube must give the atomic kernel's gradients."""
+    from nesvor_amd.encoding import hashgrid_backward
+    from nesvor_amd.grid import HashGridSpec
+
+    spec = HashGridSpec(16, 2, 19, 9, 1.26)
+    g = torch.Generator().manual_seed(11)
+    if case == "one_point":
+        u = torch.rand(1, 3, generator=g)
+    elif case == "n255":
+        u = torch.rand(255, 3, generator=g)
+    elif case == "n257":
+        u = torch.rand(257, 3, generator=g)
+    elif case == "all_in_one_cell":
+        u = 0.4 + 1e-3 * torch.rand(5000, 3, generator=g)
+    elif case == "two_cells":
+        u = torch.cat([0.1 + 1e-3 * torch.rand(3000, 3, generator=g), 0.9 + 1e-3 * torch.rand(3000, 3, generator=g)])[torch.randperm(6000, generator=g)]
+    else:
+        u = torch.rand(4000, 3, generator=g) * 1.2 - 0.1  # a tenth of the cube's side beyond every face
+    u = u.contiguous().to(device)
+    N = u.shape[0]
+    table = (torch.randn(spec.n_params, generator=g) * 0.1).to(device)
+    for layout in (0, 1):
+        dy = torch.randn((N, 32) if layout == 0 else (32, N), generator=g).to(device)
+        g_atm, gu_atm = hashgrid_backward(spec, u, table, dy, None, True, layout, "atomic")
+        g_srt, gu_srt = hashgrid_backward(spec, u, table, dy, None, True, layout, "owner", clustered=False)
+        scale = float(g_atm.abs().max())
+        assert float((g_srt - g_atm).abs().max()) <= 2e-4 * scale + 1e-12, case
+        torch.testing.assert_close(gu_srt, gu_atm, rtol=1e-3, atol=1e-3 * float(gu_atm.abs().max()) + 1e-9)
+
+
 def test_hashgrid_queue_sizer_grows_only_what_overflows(device, monkeypatch):
     """The record queues start at 1/16 of the worst case per level (encoding.QueueSizer); a level whose overflow counter
     the kernels raise is grown x4 before a later backward.  Every backward on the way is exact (overflowing records take
