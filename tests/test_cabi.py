@@ -112,3 +112,29 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "from .. import oracle" not in src and "from oracle" not in src, f
+
+
+def test_backward_workspace_size_queries_follow_the_layout_hints():
+    """Host-side arithmetic only (no GPU): ``nesvor_hashgrid_backward_workspace_bytes_ex`` asks for the re-ordered copy of d pe
+    exactly when the backward will be called feature-major, unclustered AND with the scratch hint; every other combination is the
+    plain size, which already holds the point order (perm, per-cell strips, spill list)."""
+    import ctypes
+
+    from nesvor_amd import _lib
+    from nesvor_amd.grid import HashGridSpec
+
+    lib = _lib.load()
+    spec = HashGridSpec(16, 2, 19, 9, 1.26)
+    N = (1 << 20) - 77
+    n_pad = (N + 255) // 256 * 256
+    base = lib.nesvor_hashgrid_backward_workspace_bytes(ctypes.byref(spec.c_struct), N, None)
+    assert base > 0
+    ex = lambda layout: lib.nesvor_hashgrid_backward_workspace_bytes_ex(ctypes.byref(spec.c_struct), N, None, layout)
+    U, S = _lib.LAYOUT_UNCLUSTERED, _lib.LAYOUT_DY_SCRATCH
+    assert ex(0) == ex(1) == ex(0 | U | S) == ex(1 | U) == ex(1 | S) == ex(1 | _lib.LAYOUT_CLUSTERED) == base
+    assert ex(1 | U | S) == base + 256 + n_pad * 32 * 4
+    # the order's scratch is part of every workspace: 4 N (perm) + counters + 4 N (spill) + 8 N (tickets) + strips, on top of the
+    # worst-case record queues (8 records of 12 B per point and level, with slack)
+    assert base > 128 * 12 * N and base - 128 * 12 * N * 1.2 < 64 * N
+    small = lib.nesvor_hashgrid_backward_workspace_bytes(ctypes.byref(spec.c_struct), 1000, None)
+    assert 0 < small < base
