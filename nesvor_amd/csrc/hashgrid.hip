@@ -83,6 +83,26 @@ __device__ __forceinline__ LevelParams load_level(const nesvor_grid_t& g, int le
   return p;
 }
 
+// Lane l of a wave gets level l's parameters through scalar loads and selects instead of load_level(g, lane), which indexes the
+// kernel arguments per lane (vector loads from the kernarg segment).  Aggregation pass: 296.1 -> 292.9 us in the step together
+// with the scalar level indices of prepare() / finish_level (two alternating rounds, gpurun_out/r05an).
+__device__ __forceinline__ LevelParams load_level_of_lane(const nesvor_grid_t& g, int lane) {
+  LevelParams p;
+  p.scale = 0.f; p.res = 0u; p.size = 0u; p.offset = 0u; p.hashed = 0u;
+  for (int l = 0; l < g.n_levels; ++l) {
+    // (readfirstlane on the loaded words: without it the compiler folds `lane == l` back into the address and emits exactly the
+    //  per-lane vector load this loop is here to avoid)
+    LevelParams q = load_level(g, l);
+    q.scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q.scale)));
+    q.res = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.res);
+    q.size = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.size);
+    q.offset = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.offset);
+    q.hashed = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.hashed);
+    if (lane == l) p = q;
+  }
+  return p;
+}
+
 __device__ __forceinline__ uint32_t corner_index(const LevelParams& p, uint32_t x, uint32_t y, uint32_t z) {
   if (p.hashed) {
     const uint32_t h = x ^ (y * kPrimeY) ^ (z * kPrimeZ);
@@ -285,6 +305,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
     }
     uint32_t b[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     if (tid < L) {
+      // (per-lane index into the kernel arguments = vector loads from the kernarg segment: measured FASTER here than the uniform
+      //  loop of scalar loads + selects that the aggregation pass uses - forward 71.8 -> 75.0 us with it)
       const LevelParams p = load_level(g, tid);
       const CellPos blo = locate(p, ulo[0], ulo[1], ulo[2]), bhi = locate(p, uhi[0], uhi[1], uhi[2]);
       const uint32_t ex = bhi.gx - blo.gx, ey = bhi.gy - blo.gy, ez = bhi.gz - blo.gz;
@@ -697,6 +719,23 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) {
 #ifndef NESVOR_HG_SPATIAL
 #define NESVOR_HG_SPATIAL 1
 #endif
+// -DNESVOR_HG_TIMELINE=1 (tools/hg_timeline.py): thread 0 of the first 64 workgroups of the aggregation pass writes (site, time)
+// marks - s_memtime, the 100 MHz constant clock - at its barriers; nesvor_debug_hg_timeline() copies them out.  Where a
+// workgroup's ~65 us go, phase by phase, without a profiler in the way.
+#ifndef NESVOR_HG_TIMELINE
+#define NESVOR_HG_TIMELINE 0
+#endif
+#if NESVOR_HG_TIMELINE
+constexpr int kTlWgs = 64, kTlMarks = 96;
+__device__ unsigned long long g_hg_timeline[kTlWgs][kTlMarks];
+#define HG_TICK(site)                                                                                              \
+  do {                                                                                                             \
+    if (blockIdx.x < (unsigned)kTlWgs && threadIdx.x == 0 && tl_n < kTlMarks)                                      \
+      g_hg_timeline[blockIdx.x][tl_n++] = ((unsigned long long)(site) << 56) | (__builtin_amdgcn_s_memtime() & 0x00FFFFFFFFFFFFFFull); \
+  } while (0)
+#else
+#define HG_TICK(site) do { } while (0)
+#endif
 template <int F, int LAYOUT, bool INPUT_GRAD, bool MERGE, bool BOUND = false>
 __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2)) void hashgrid_bwd_aggregate(const nesvor_grid_t g, const BwdPlan plan,
                                                               const float* __restrict__ u,
@@ -762,6 +801,11 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t base = (int64_t)blockIdx.x * 256;
   const int E = g.n_levels * F;
+#if NESVOR_HG_TIMELINE
+  int tl_n = 0;
+  if (blockIdx.x < (unsigned)kTlWgs && tid == 0) for (int k = 0; k < kTlMarks; ++k) g_hg_timeline[blockIdx.x][k] = 0ull;
+#endif
+  HG_TICK(0);  // entry
   const int level_end = plan.level_end;
   // Queue tails are hot counters (every workgroup reserves space in ~100 of them per level).  The L2s of the eight
   // XCCs are kept coherent by hardware, so a counter shared by all workgroups migrates between L2s on every
@@ -800,6 +844,7 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
       if (rep) sv ^= 0x80000000u;
     }
   }
+  HG_TICK(1);  // sorted
   if (order_mode == 1) order[base + tid] = (uint8_t)(sv & 255u);
   const int64_t slot_i = base + (sv & 255u);  // the sample this lane owns from now on: position in the (cell-ordered) batch ...
   const bool valid = slot_i < N;
@@ -874,6 +919,7 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
     }
   }
   __syncthreads();
+  HG_TICK(2);  // bounding box / max |dy| published
   float ulo[3] = {0.f, 0.f, 0.f}, uhi[3] = {0.f, 0.f, 0.f};
   float fscale = 1.f, finv = 1.f;
   if constexpr (MERGE) {
@@ -895,11 +941,18 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
     }
     // the lattice boxes of all levels at once (wave 0, lane l: level l) instead of two locate() per level in every
     // thread, and the round schedule from them (uniform loop over the levels, v_readlane picks a level's numbers)
+    HG_TICK(6);  // box of the samples, fixed-point scale (all threads)
     if (tid < 64) {
       uint32_t b[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
       uint32_t nch = 0u;
+      const LevelParams p = load_level_of_lane(g, tid);
+      uint32_t pl_nch = 0u, pl_cap = 0u, pl_base = 0u, pl_rec = 0u, pl_shift = 0u;  // the plan's numbers of this lane's level, the same way
+      for (int l = 0; l < g.n_levels; ++l) {
+        auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+        const uint32_t a0 = uni(plan.n_chunks[l]), a1 = uni(plan.cap[l]), a2 = uni(plan.bucket_base[l]), a3 = uni((uint32_t)plan.rec_off[l]), a4 = uni(plan.shift[l]);
+        if (tid == l) { pl_nch = a0; pl_cap = a1; pl_base = a2; pl_rec = a3; pl_shift = a4; }
+      }
       if (tid < g.n_levels) {
-        const LevelParams p = load_level(g, tid);
         const CellPos blo = locate(p, ulo[0], ulo[1], ulo[2]), bhi = locate(p, uhi[0], uhi[1], uhi[2]);
         const uint32_t ex = bhi.gx - blo.gx, ey = bhi.gy - blo.gy, ez = bhi.gz - blo.gz;  // cells spanned - 1 (wrap if out of range)
         const bool fits = plan.box_slots != 0u && ex < (uint32_t)kSlots && ey < (uint32_t)kSlots && ez < (uint32_t)kSlots &&
@@ -919,10 +972,10 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
           }
           lwin[tid] = ba | (bb << 8) | (bc << 16);
         }
-        nch = plan.n_chunks[tid];
+        nch = pl_nch;
         lpar[tid][0] = p.res; lpar[tid][1] = p.size; lpar[tid][2] = p.offset; lpar[tid][3] = p.hashed;
-        lpar[tid][4] = plan.cap[tid]; lpar[tid][5] = plan.bucket_base[tid]; lpar[tid][6] = (uint32_t)plan.rec_off[tid];
-        lpar[tid][7] = plan.shift[tid];
+        lpar[tid][4] = pl_cap; lpar[tid][5] = pl_base; lpar[tid][6] = pl_rec;
+        lpar[tid][7] = pl_shift;
         if constexpr (kPerLevel) {
           // a slot sums at most 256 values of at most max |dy| each: mapped below 2^30
           const float mxl = 256.f * __uint_as_float(lmax_bits[tid]);
@@ -932,6 +985,7 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
           lscale[tid][1] = __uint_as_float((uint32_t)(127 - se) << 23);
         }
       }
+      HG_TICK(7);  // per-level boxes, window bits, lpar (lane = level)
       if (tid <= g.n_levels) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) lbox[tid][q] = b[q];  // row n_levels: all zero (a level past the end is "not a box")
@@ -958,8 +1012,10 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
         }
         a = bnd;
       }
+      HG_TICK(8);  // round schedule (wave 0)
     }
     __syncthreads();
+    HG_TICK(3);  // lattice boxes and round schedule
   }
   const int box_end = MERGE ? __builtin_amdgcn_readfirstlane(box_end_s) : plan.level_begin;
   auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };  // wave-uniform values
@@ -972,6 +1028,10 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
   auto prepare = [&](auto box_c, int level, const float (&dy)[F], uint32_t (&idx)[8], uint32_t& s0, uint32_t& nx, uint32_t& nxy,
                      float (&val)[8][F], bool& tail) __attribute__((always_inline)) {
     constexpr bool BOX = decltype(box_c)::value;
+    // (the level is wave-uniform, but it lives in loops whose exit tests read LDS, so the compiler keeps it in a VGPR - and a
+    //  kernel argument indexed by a VGPR is a VECTOR load from the kernarg segment: five of them at the head of every level's
+    //  dependency chain.  Through readfirstlane the same reads are scalar loads: worth 1 % of the pass, round 5)
+    level = __builtin_amdgcn_readfirstlane(level);
     const LevelParams p = load_level(g, level);
     const CellPos c = locate(p, ux, uy, uz);
     if constexpr (BOX) {
@@ -1202,12 +1262,15 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
         store_feat(ra, feat);
       }
       if constexpr (INPUT_GRAD) __syncthreads();
+      HG_TICK(4);  // first round's table copy in place
       insert_round(ra, rb);
+      HG_TICK(5);  // a round's inserts issued (0x10 | first level below)
       uint32_t rkey[NRB], rmeta[NRB], rank[NRB], rmask = 0;  // records of the round being finished: entry index,
       float rval[NRB][F];                                    // level << 8 | round-local bucket, rank inside the bucket
       bool have_prev = false;
       for (;;) {
         __syncthreads();  // -- insertions of round [ra, rb) complete; bbase4 of the previous round published
+        HG_TICK(0x20 | ra);  // inserts of the round starting at level ra complete
         // W(r-1)
         if (have_prev && !NESVOR_ABL(8)) {
 #pragma unroll
@@ -1267,7 +1330,9 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
         }
         if (next_box) store_feat(na, nfeat);  // every read of the current round's copy happened before the barrier above
         have_prev = true;
+        HG_TICK(0x40 | ra);  // previous records written, round drained
         __syncthreads();  // -- bucket counts of round [ra, rb) complete, table drained, next round's copy in place
+        HG_TICK(0x60 | ra);  // ... and everyone has
         // R(r): one returning (memory-side, ~2 us) atomic per non-empty bucket of the round
         const uint32_t nbk = sgpr(rnd_bkts[ra]);
         uint4 mine = make_uint4(0u, 0u, 0u, 0u);
@@ -1284,7 +1349,9 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
         // ... hidden behind P(r+1)
         level = rb;
         if (next_box) insert_round(na, nb_);
+        HG_TICK(0x80 | ra);  // reservation issued, next round's inserts issued
         if ((uint32_t)tid < nbk) bbase4[tid] = mine;
+        HG_TICK(0xA0 | ra);  // reservation returned
         if (!next_box) break;
         ra = na; rb = nb_;
       }
@@ -1340,14 +1407,16 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
     // next level is prepared straight into them - no copy at the end of the level
     auto finish_level = [&](auto& rkey, auto& rank, auto& rval, uint32_t rmask, auto in_place) __attribute__((always_inline)) {
       constexpr int NR = sizeof(rkey) / sizeof(rkey[0]);
+      HG_TICK(0xE0 | level);  // single-level round: drained / ranked
       __syncthreads();
+      const int lu = __builtin_amdgcn_readfirstlane(level);  // (scalar index into the kernel arguments: see prepare())
       // reserve queue space: one returning (memory-side, ~2 us) atomic per non-empty chunk ...
-      const uint32_t nb = plan.n_chunks[level];
-      const uint32_t cap = plan.cap[level];
+      const uint32_t nb = plan.n_chunks[lu];
+      const uint32_t cap = plan.cap[lu];
       uint32_t my_base = 0;
       if (tid < nb) {
         const uint32_t cnt = bcount[tid];
-        if (cnt && !NESVOR_ABL(16)) my_base = atomicAdd(&tails[sub * kTailStride + plan.bucket_base[level] + tid], cnt);
+        if (cnt && !NESVOR_ABL(16)) my_base = atomicAdd(&tails[sub * kTailStride + plan.bucket_base[lu] + tid], cnt);
         bcount[tid] = 0;
       }
       if (merge && tid == 255) {
@@ -1372,13 +1441,14 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
         else prepare(std::false_type{}, level + 1, dy_a, idx_n, su, nxu, nxyu, val_n, tail_n);
       }
       if (tid < nb) bbase[level & 1][tid] = make_uint2(my_base, (tid * plan.n_sub + sub) * cap);
+      HG_TICK(0xF0 | level);  // reservation returned, next level prepared
       __syncthreads();
       // records of the level: (entry, grad...) = (1 + F) words each; a level's queues stay below 2^32 bytes (make_plan)
-      char* const level_rec = reinterpret_cast<char*>(records) + plan.rec_off[level] * (uint64_t)(4 * (1 + F));
+      char* const level_rec = reinterpret_cast<char*>(records) + plan.rec_off[lu] * (uint64_t)(4 * (1 + F));
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
         if (NESVOR_ABL(8) || !(rmask & (1u << k))) continue;
-        const uint2 bb = bbase[level & 1][rkey[k] >> plan.shift[level]];
+        const uint2 bb = bbase[level & 1][rkey[k] >> plan.shift[lu]];
         const uint32_t pos = bb.x + rank[k];
         if (pos < cap) {
           uint32_t* r = reinterpret_cast<uint32_t*>(level_rec + (bb.y + pos) * (uint32_t)(4 * (1 + F)));
@@ -1388,7 +1458,7 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
         } else {  // queue full: exact fallback
           atomicAdd(&tails[kOverflowBase + level], 1u);
 #pragma unroll
-          for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + rkey[k]) * F + f, rval[k][f]);
+          for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[lu] + rkey[k]) * F + f, rval[k][f]);
         }
       }
     };
@@ -1451,7 +1521,7 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
           for (int k = 0; k < 8; ++k) {
             if (pending & (1u << k)) {  // table crowded: exact fallback
 #pragma unroll
-              for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[level] + idx[k]) * F + f, val[k][f]);
+              for (int f = 0; f < F; ++f) atomicAdd(grad_table + ((size_t)g.offset[__builtin_amdgcn_readfirstlane(level)] + idx[k]) * F + f, val[k][f]);
             } else {
               slot_add(h[k], val[k], scale_of((uint32_t)level));
             }
@@ -1459,7 +1529,9 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
         }
         const uint32_t n_tail = __builtin_popcountll(__ballot(tail));
         if (lane == 0 && n_tail) atomicAdd(&merge_stat[0], 8u * n_tail);
+        HG_TICK(0xC0 | level);  // hashed level: slots claimed, adds issued
         __syncthreads();
+        HG_TICK(0xD0 | level);  // ... by everyone
         // drain: slot -> register record, slot cleared for the next level
         uint32_t mine = 0;
         const uint32_t n_slots = 1u << slog;  // slots in use at this level: thread t drains t, t + 256, ...
@@ -1475,7 +1547,7 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
             tkeys[slot] = kEmpty;
             rmask |= 1u << j; rkey[j] = key;
             slot_take(slot, rval[j], inv_of((uint32_t)level));
-            rank[j] = atomicAdd(&bcount[key >> plan.shift[level]], 1u);
+            rank[j] = atomicAdd(&bcount[key >> plan.shift[__builtin_amdgcn_readfirstlane(level)]], 1u);
             ++mine;
           }
         }
@@ -1489,11 +1561,12 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
       // rank of every record inside its chunk's span (LDS integer atomics: ~6 cycles / wave-instruction)
       uint32_t rank[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) rank[k] = tail ? atomicAdd(&bcount[idx[k] >> plan.shift[level]], 1u) : 0u;
+      for (int k = 0; k < 8; ++k) rank[k] = tail ? atomicAdd(&bcount[idx[k] >> plan.shift[__builtin_amdgcn_readfirstlane(level)]], 1u) : 0u;
       finish_level(idx, rank, val, tail ? 0xFFu : 0u, std::false_type{});
       advance();
     }
   }
+  HG_TICK(0x0F);  // last records written
   if constexpr (INPUT_GRAD) {
     if (valid) {
       if (plan.accumulate_u) { gux += grad_u[3 * i]; guy += grad_u[3 * i + 1]; guz += grad_u[3 * i + 2]; }
@@ -2287,6 +2360,13 @@ extern "C" int64_t nesvor_hashgrid_backward_workspace_bytes(const nesvor_grid_t*
 }
 
 extern "C" int64_t nesvor_hashgrid_backward_workspace_zero_bytes(void) { return (int64_t)kHeadBytes; }
+
+#if NESVOR_HG_TIMELINE
+// (debug builds only; not part of include/nesvor_hip.h)  64 workgroups x 96 marks of (site << 56 | 100 MHz time)
+extern "C" int nesvor_debug_hg_timeline(unsigned long long* dst_host) {
+  return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_hg_timeline), sizeof(unsigned long long) * kTlWgs * kTlMarks);
+}
+#endif
 
 extern "C" int64_t nesvor_hashgrid_backward_overflow_offset(void* workspace) {
   return (int64_t)(tails_parity(workspace, false) ? kTailBytes : 0) + (int64_t)kOverflowBase * (int64_t)sizeof(uint32_t);
