@@ -83,26 +83,6 @@ __device__ __forceinline__ LevelParams load_level(const nesvor_grid_t& g, int le
   return p;
 }
 
-// Lane l of a wave gets level l's parameters through scalar loads and selects instead of load_level(g, lane), which indexes the
-// kernel arguments per lane (vector loads from the kernarg segment).  Aggregation pass: 296.1 -> 292.9 us in the step together
-// with the scalar level indices of prepare() / finish_level (two alternating rounds, gpurun_out/r05an).
-__device__ __forceinline__ LevelParams load_level_of_lane(const nesvor_grid_t& g, int lane) {
-  LevelParams p;
-  p.scale = 0.f; p.res = 0u; p.size = 0u; p.offset = 0u; p.hashed = 0u;
-  for (int l = 0; l < g.n_levels; ++l) {
-    // (readfirstlane on the loaded words: without it the compiler folds `lane == l` back into the address and emits exactly the
-    //  per-lane vector load this loop is here to avoid)
-    LevelParams q = load_level(g, l);
-    q.scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q.scale)));
-    q.res = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.res);
-    q.size = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.size);
-    q.offset = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.offset);
-    q.hashed = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.hashed);
-    if (lane == l) p = q;
-  }
-  return p;
-}
-
 __device__ __forceinline__ uint32_t corner_index(const LevelParams& p, uint32_t x, uint32_t y, uint32_t z) {
   if (p.hashed) {
     const uint32_t h = x ^ (y * kPrimeY) ^ (z * kPrimeZ);
@@ -945,13 +925,12 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
     if (tid < 64) {
       uint32_t b[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
       uint32_t nch = 0u;
-      const LevelParams p = load_level_of_lane(g, tid);
-      uint32_t pl_nch = 0u, pl_cap = 0u, pl_base = 0u, pl_rec = 0u, pl_shift = 0u;  // the plan's numbers of this lane's level, the same way
-      for (int l = 0; l < g.n_levels; ++l) {
-        auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-        const uint32_t a0 = uni(plan.n_chunks[l]), a1 = uni(plan.cap[l]), a2 = uni(plan.bucket_base[l]), a3 = uni((uint32_t)plan.rec_off[l]), a4 = uni(plan.shift[l]);
-        if (tid == l) { pl_nch = a0; pl_cap = a1; pl_base = a2; pl_rec = a3; pl_shift = a4; }
-      }
+      // (lane = level: per-lane reads of the kernel arguments are vector loads from the kernarg segment - measured faster here than a
+      //  uniform loop of scalar loads with selects: 26 against 93 timeline units)
+      const LevelParams p = load_level(g, tid < g.n_levels ? tid : 0);
+      const int tl_ = tid < g.n_levels ? tid : 0;
+      const uint32_t pl_nch = plan.n_chunks[tl_], pl_cap = plan.cap[tl_], pl_base = plan.bucket_base[tl_], pl_rec = (uint32_t)plan.rec_off[tl_],
+                     pl_shift = plan.shift[tl_];
       if (tid < g.n_levels) {
         const CellPos blo = locate(p, ulo[0], ulo[1], ulo[2]), bhi = locate(p, uhi[0], uhi[1], uhi[2]);
         const uint32_t ex = bhi.gx - blo.gx, ey = bhi.gy - blo.gy, ez = bhi.gz - blo.gz;  // cells spanned - 1 (wrap if out of range)
@@ -1012,6 +991,8 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
         }
         a = bnd;
       }
+      // (a branch-free form - fixed loop over the levels, constant-lane v_readlane, selects - was measured: 115 against 83 timeline
+      //  units of a workgroup's ~1400; wave 0 shares its SIMD with three other workgroups either way)
       HG_TICK(8);  // round schedule (wave 0)
     }
     __syncthreads();
