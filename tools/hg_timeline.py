@@ -25,7 +25,7 @@ if len(sys.argv) == 1:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off", "-w",
                            "-DNESVOR_HG_TIMELINE=1", "-I", os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "nesvor_amd", "csrc", "hashgrid.hip"), "-o", f"{out}/hg.o"])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", f"{out}/hg.o", *others, "-o", f"{out}/libtl.so"])
-    for n_clouds in (4096,):
+    for n_clouds in (4096, 512):
         subprocess.check_call([sys.executable, __file__, "run", str(n_clouds)], env={**os.environ, "NESVOR_HIP_LIB": f"{out}/libtl.so", "NESVOR_HASHGRID_QUEUE": "worst"})
 else:
     sys.path.insert(0, ROOT)
