@@ -302,8 +302,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
       for (int q = 0; q < 8; ++q) lbox[tid][q] = b[q];
     }
     auto vol_of = [&](int l) { return (uint32_t)__builtin_amdgcn_readlane((int)b[6], l); };
-    int e = 0;
-    while (e < L && vol_of(e) != 0u) ++e;
+    const int e = __builtin_ctzll(__ballot(b[6] == 0u) | ~((1ull << L) - 1ull));  // first level whose box does not fit
     if (tid == 0) box_end_s = e;
     int a = 0;
     while (a < e) {
@@ -314,10 +313,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
         slots += vol_of(bnd);
         ++bnd;
       }
-      if (tid == 0) {
-        for (int l = a; l < bnd; ++l) grp_end[l] = (uint32_t)bnd;
-        rnd_slots[a] = slots;
-      }
+      if (tid >= a && tid < bnd) grp_end[tid] = (uint32_t)bnd;
+      if (tid == 0) rnd_slots[a] = slots;
       a = bnd;
     }
   }
@@ -973,8 +970,9 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
       // while their boxes fit the table together and their chunks the bucket counters
       auto vol_of = [&](int l) { return (uint32_t)__builtin_amdgcn_readlane((int)b[6], l); };
       auto nch_of = [&](int l) { return (uint32_t)__builtin_amdgcn_readlane((int)nch, l); };
-      int e = plan.level_begin;
-      while (e < level_end && vol_of(e) != 0u) ++e;
+      // (first level at or behind level_begin whose box does not fit: one ballot instead of a loop of v_readlane)
+      const unsigned long long no_box = __ballot(b[6] == 0u) | ~((1ull << level_end) - 1ull);
+      const int e = __builtin_ctzll(no_box & ~((1ull << plan.level_begin) - 1ull));
       if (tid == 0) box_end_s = e;
       int a = plan.level_begin;
       while (a < e) {
@@ -985,10 +983,8 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
           slots += vol_of(bnd); bk += nch_of(bnd);
           ++bnd;
         }
-        if (tid == 0) {
-          for (int l = a; l < bnd; ++l) grp_end[l] = (uint32_t)bnd;
-          rnd_slots[a] = slots; rnd_bkts[a] = bk;
-        }
+        if (tid >= a && tid < bnd) grp_end[tid] = (uint32_t)bnd;  // (lane = level: one masked store)
+        if (tid == 0) { rnd_slots[a] = slots; rnd_bkts[a] = bk; }
         a = bnd;
       }
       // (a branch-free form - fixed loop over the levels, constant-lane v_readlane, selects - was measured: 115 against 83 timeline
