@@ -96,6 +96,55 @@ __device__ __forceinline__ uint32_t corner_index(const LevelParams& p, uint32_t 
   return idx;
 }
 
+// Inclusive prefix sum over the first 32 lanes of a wave (lane = level; NESVOR_MAX_LEVELS = 32): DPP row_shr inside the two
+// 16-lane rows, then row 0's total onto row 1.
+__device__ __forceinline__ uint32_t scan32_u32(uint32_t v, int lane) {
+#define NESVOR_SCAN_STEP_(SHR)                                                                        \
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 | (SHR), 0xf, 0xf, true);
+  NESVOR_SCAN_STEP_(1) NESVOR_SCAN_STEP_(2) NESVOR_SCAN_STEP_(4) NESVOR_SCAN_STEP_(8)
+#undef NESVOR_SCAN_STEP_
+  const uint32_t row0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+  return v + ((lane >= 16 && lane < 32) ? row0 : 0u);
+}
+
+// Round schedule of the per-cloud kernels.  Lane l of the calling wave (all 64 lanes active) holds level l's box volume `vol` (0:
+// the box does not fit the LDS table) and chunk count `nch`.  Box levels = the run of levels from `first` with vol != 0; they are
+// cut greedily into rounds of consecutive levels whose boxes fit the table together (<= max_slots), whose chunks fit the bucket
+// counters (<= max_bkts) and which are at most max_group long.  Returns level l's numbers in lane l: first slot / bucket inside
+// its round, the level behind its round and, on a round's first level, the round's totals.  One iteration per ROUND over prefix
+// sums (rounds 1-5 walked level by level with run-time v_readlane and single-lane LDS stores: 6 % of a workgroup's life in the
+// aggregation pass, tools/hg_timeline.py).
+struct RoundSchedule {
+  uint32_t slot_off, bkt_off, grp_end, rnd_slots, rnd_bkts;
+  int box_end;
+};
+__device__ __forceinline__ RoundSchedule round_schedule(uint32_t vol, uint32_t nch, int first, int last, int lane, uint32_t max_slots,
+                                                        uint32_t max_bkts, int max_group) {
+  const unsigned long long no_box = __ballot(vol == 0u) | ~((1ull << last) - 1ull);
+  const int e = __builtin_ctzll(no_box & ~((1ull << first) - 1ull));  // first level at or behind `first` that is no box level
+  const bool in = lane >= first && lane < e;
+  const uint32_t v_in = in ? vol : 0u, n_in = in ? nch : 0u;
+  const uint32_t C = scan32_u32(v_in, lane), N = scan32_u32(n_in, lane);
+  RoundSchedule r;
+  r.slot_off = 0u; r.bkt_off = 0u; r.grp_end = 0u; r.rnd_slots = 0u; r.rnd_bkts = 0u; r.box_end = e;
+  int g0 = first;
+  while (g0 < e) {  // (uniform: a handful of rounds)
+    const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane((int)(C - v_in), g0), nb = (uint32_t)__builtin_amdgcn_readlane((int)(N - n_in), g0);
+    const bool ok = lane >= g0 && lane < e && C - cb <= max_slots && N - nb <= max_bkts && lane - g0 < max_group;
+    int bnd = __builtin_ctzll((__ballot(!ok) & ~((1ull << g0) - 1ull)) | (1ull << 63));
+    bnd = bnd > g0 ? bnd : g0 + 1;  // (a level always fits on its own: vol <= max_slots by construction)
+    const bool mine = lane >= g0 && lane < bnd;
+    r.slot_off = mine ? (C - v_in) - cb : r.slot_off;
+    r.bkt_off = mine ? (N - n_in) - nb : r.bkt_off;
+    r.grp_end = mine ? (uint32_t)bnd : r.grp_end;
+    const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)C, bnd - 1) - cb, ns = (uint32_t)__builtin_amdgcn_readlane((int)N, bnd - 1) - nb;
+    r.rnd_slots = lane == g0 ? cs : r.rnd_slots;
+    r.rnd_bkts = lane == g0 ? ns : r.rnd_bkts;
+    g0 = bnd;
+  }
+  return r;
+}
+
 struct CellPos {
   uint32_t gx, gy, gz;
   float wx, wy, wz;
@@ -301,22 +350,9 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
 #pragma unroll
       for (int q = 0; q < 8; ++q) lbox[tid][q] = b[q];
     }
-    auto vol_of = [&](int l) { return (uint32_t)__builtin_amdgcn_readlane((int)b[6], l); };
-    const int e = __builtin_ctzll(__ballot(b[6] == 0u) | ~((1ull << L) - 1ull));  // first level whose box does not fit
-    if (tid == 0) box_end_s = e;
-    int a = 0;
-    while (a < e) {
-      uint32_t slots = 0;
-      int bnd = a;
-      while (bnd < e && bnd - a < kMaxGroup && slots + vol_of(bnd) <= (uint32_t)kSlots) {
-        if (tid == 0) slot_off[bnd] = slots;
-        slots += vol_of(bnd);
-        ++bnd;
-      }
-      if (tid >= a && tid < bnd) grp_end[tid] = (uint32_t)bnd;
-      if (tid == 0) rnd_slots[a] = slots;
-      a = bnd;
-    }
+    const RoundSchedule rs = round_schedule(b[6], 0u, 0, L, tid, (uint32_t)kSlots, 0xFFFFFFFFu, kMaxGroup);
+    if (tid == 0) box_end_s = rs.box_end;
+    if (tid < NESVOR_MAX_LEVELS) { slot_off[tid] = rs.slot_off; grp_end[tid] = rs.grp_end; rnd_slots[tid] = rs.rnd_slots; }
   }
   __syncthreads();
   const int box_end = __builtin_amdgcn_readfirstlane(box_end_s);
@@ -968,27 +1004,12 @@ __global__ __launch_bounds__(256, F <= 2 ? NESVOR_HG_MINBLOCKS : (F == 4 ? 3 : 2
       }
       // box levels = the longest prefix of levels whose box fits the table; consecutive box levels share a round
       // while their boxes fit the table together and their chunks the bucket counters
-      auto vol_of = [&](int l) { return (uint32_t)__builtin_amdgcn_readlane((int)b[6], l); };
-      auto nch_of = [&](int l) { return (uint32_t)__builtin_amdgcn_readlane((int)nch, l); };
-      // (first level at or behind level_begin whose box does not fit: one ballot instead of a loop of v_readlane)
-      const unsigned long long no_box = __ballot(b[6] == 0u) | ~((1ull << level_end) - 1ull);
-      const int e = __builtin_ctzll(no_box & ~((1ull << plan.level_begin) - 1ull));
-      if (tid == 0) box_end_s = e;
-      int a = plan.level_begin;
-      while (a < e) {
-        uint32_t slots = 0, bk = 0;
-        int bnd = a;
-        while (bnd < e && bnd - a < kMaxGroup && slots + vol_of(bnd) <= (uint32_t)kSlots && bk + nch_of(bnd) <= (uint32_t)kMaxChunks) {
-          if (tid == 0) { slot_off[bnd] = slots; bkt_off[bnd] = bk; }
-          slots += vol_of(bnd); bk += nch_of(bnd);
-          ++bnd;
-        }
-        if (tid >= a && tid < bnd) grp_end[tid] = (uint32_t)bnd;  // (lane = level: one masked store)
-        if (tid == 0) { rnd_slots[a] = slots; rnd_bkts[a] = bk; }
-        a = bnd;
+      const RoundSchedule rs = round_schedule(b[6], nch, plan.level_begin, level_end, tid, (uint32_t)kSlots, (uint32_t)kMaxChunks, kMaxGroup);
+      if (tid == 0) box_end_s = rs.box_end;
+      if (tid < NESVOR_MAX_LEVELS) {
+        slot_off[tid] = rs.slot_off; bkt_off[tid] = rs.bkt_off; grp_end[tid] = rs.grp_end;
+        rnd_slots[tid] = rs.rnd_slots; rnd_bkts[tid] = rs.rnd_bkts;
       }
-      // (a branch-free form - fixed loop over the levels, constant-lane v_readlane, selects - was measured: 115 against 83 timeline
-      //  units of a workgroup's ~1400; wave 0 shares its SIMD with three other workgroups either way)
       HG_TICK(8);  // round schedule (wave 0)
     }
     __syncthreads();
