@@ -47,7 +47,7 @@ def _training_flags(p: argparse.ArgumentParser) -> None:
                    help="(not in the reference) with --single-precision: bf16 MLP matrix operands, fp32 accumulation / weights")
     g.add_argument("--mlp-fp32-mfma", action="store_true",
                    help="(not in the reference) with --single-precision: evaluate the MLP products with fp32 MFMAs instead of the "
-                        "default split-bf16 evaluation of the same fp32 products (same accuracy, slower)")
+                        "default split-fp16 evaluation of the same fp32 products (same accuracy, slower)")
     g = p.add_argument_group("loss function")
     g.add_argument("--weight-transformation", default=0.1, type=float)
     g.add_argument("--weight-bias", default=100.0, type=float)

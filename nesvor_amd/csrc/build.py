@@ -104,7 +104,16 @@ def build(force=False, verbose=True):
     for src, asm, p in asm_jobs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc -S failed on {src}")
-        check_inflight_loads(asm, verbose)
+        try:
+            check_inflight_loads(asm, verbose)
+        except Exception as e:
+            # the checker reads the compiler's assembly heuristically (tools/check_inflight_loads.py): a compiler update may need
+            # the checker updated, not the kernels - NESVOR_SKIP_ASM_CHECK=1 turns a finding into a warning (round-5 advisor)
+            if os.environ.get("NESVOR_SKIP_ASM_CHECK") == "1":
+                print(f"WARNING (NESVOR_SKIP_ASM_CHECK=1): {e}", file=sys.stderr, flush=True)
+            else:
+                raise RuntimeError(f"{e}\n(the assembly check of the build failed; NESVOR_SKIP_ASM_CHECK=1 builds anyway - only "
+                                   f"if tools/check_inflight_loads.py, not the kernel, is what a compiler update broke)") from e
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr, flush=True)

@@ -76,7 +76,7 @@ struct MlpArgs {
   int fast;                     // N % 16 == 0, S % 16 == 0, k_a % 16 == 0: group = one pixel, input blocks homogeneous
   int spg_shift;                // log2(S / 16) when that is a power of two, else -1
   int dxa_group;                // dxa holds one row per 16-sample GROUP (sum over its samples) instead of one per sample
-  int bf16;                     // 1: matrix operands rounded to bf16 (fp32 accumulation); 2: operands split into three bf16 (fp32-equivalent)
+  int bf16;                     // 1: matrix operands rounded to bf16 (fp32 accumulation); 2: every operand split into two fp16 of a power-of-two-scaled copy (split mode, see below)
   int off32;                    // every row of xb / y starts below 2^32 bytes: lane offsets fit the 32-bit VGPR offset of scalar-base loads
   uint32_t* Hm;                 // compact save (nesvor_mlp_t.compact_save): one word per (group, lane), bit 16 l + 4 b + r = [h_l > 0]
   float* dx_absmax;             // bwd, optional: device scalar raised (atomic max) to max |dxb| - the consumer of dxb (the hash-grid

@@ -210,14 +210,22 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   const bool fuse_adamw = adam != nullptr && phase == 0 && (d.overlap_owner & 2) != 0 && d.table != nullptr && d.flat_param != nullptr &&
                           d.g_table == d.flat_grad + table_off && table_off >= 0 && table_off < d.flat_numel;
 
-  const int group_sums_sg = (N % 16 == 0 && S % 16 == 0 && d.ks % 16 == 0) ? 1 : 0;
-  const int rows_per_pixel = group_sums_sg ? S / 16 : S;
-  const float* dxa_first = (d.has_lv && d.ks) ? d.dxa : ((d.has_b && d.ks) ? d.dxa_b : nullptr);
+  // Pixel-feature gradients arrive as one row per 16-sample group (summed in the kernel) only from the wave-specialised fused
+  // backward: per NETWORK, divisibility AND nesvor_mlp_backward_fused_ok (round-5 advisor: a network that kernel refuses - e.g. a
+  // sigma_net with more than 32 inputs at two hidden layers, or N beyond 32-bit row offsets - runs as a dX launch + a dW launch
+  // through dpre_scratch and writes one row per SAMPLE; nesvor_amd/direct.py sizes dxa / dxa_b by the same rule)
+  const int group_div = (N % 16 == 0 && S % 16 == 0 && d.ks % 16 == 0) ? 1 : 0;
+  const int group_sums_s = (group_div && d.has_lv && nesvor_mlp_backward_fused_ok(&net_s, N)) ? 1 : 0;
+  const int group_sums_b = (group_div && d.has_b && nesvor_mlp_backward_fused_ok(&net_b, N)) ? 1 : 0;
+  const int rows_pp_s = group_sums_s ? S / 16 : S, rows_pp_b = group_sums_b ? S / 16 : S;
+  const bool first_is_sigma = d.has_lv && d.ks;
+  const float* dxa_first = first_is_sigma ? d.dxa : ((d.has_b && d.ks) ? d.dxa_b : nullptr);
+  const int rows_pp_first = first_is_sigma ? rows_pp_s : rows_pp_b;
   // NESVOR_SLICE_GRADS=by_slice: one workgroup per slice, no atomics, reproducible sums (where the batch fits its pixel list).
   // Default: the per-pixel atomic kernel - measured 1.136-1.140 ms per iteration against 1.152-1.160: a few hundred workgroups
   // with serial sums start behind the owner pass's workgroups and finish later (61 us) than 4096 x 30 contended atomics (46 us)
-  auto slice_grads = [&](const float* dc_pix, const float* dlvs_pix, const float* dxa, const float* dpix, float* dc_, float* dlvs_,
-                         float* dse_, float* dmat_, hipStream_t st_) -> int {
+  auto slice_grads = [&](const float* dc_pix, const float* dlvs_pix, const float* dxa, int rows_per_pixel, const float* dpix, float* dc_,
+                         float* dlvs_, float* dse_, float* dmat_, hipStream_t st_) -> int {
     static const bool by_slice = []() { const char* e = getenv("NESVOR_SLICE_GRADS"); return e != nullptr && strcmp(e, "by_slice") == 0; }();
     if (by_slice) {
       const int e = nesvor_slice_grads_by_slice(slice_idx, dc_pix, dlvs_pix, dxa, dpix, dc_, dlvs_, dse_, dmat_, B, rows_per_pixel, d.ks, n, st_);
@@ -313,7 +321,6 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
       NESVOR_TRY(nesvor_imaging_loss(&la, main));
     }
     // ---- backward through the networks
-    const int group_sums = (N % 16 == 0 && S % 16 == 0 && d.ks % 16 == 0) ? 1 : 0;
     // every network writes its per-workgroup partial parameter gradients into its own third of `partial` (the host allocates
     // 3 x NESVOR_STEP_MLP_PARTIALS rows of the widest network)
     int widest = d.n_density_params;
@@ -324,7 +331,7 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
     float* part_b = d.partial + 2 * (size_t)NESVOR_STEP_MLP_PARTIALS * widest;
     if (d.has_lv) {  // (its input gradient = rows 1.. of dz: raises the density network's upstream bound next to the loss kernel's row 0)
       Span t(ctx, NESVOR_STEP_SPAN_MLP_BWD_SIGMA, main);
-      NESVOR_TRY(mlp_backward_into(net_s, group_sums, d.se, d.z, d.dlv, d.saved_s, d.ks ? d.dxa : nullptr, d.dz + N, part_s,
+      NESVOR_TRY(mlp_backward_into(net_s, group_sums_s, d.se, d.z, d.dlv, d.saved_s, d.ks ? d.dxa : nullptr, d.dz + N, part_s,
                                    d.g_sigma, d.n_sigma_params, N, main, d.dpre_scratch, prep_d + NESVOR_MLP_PREP_DY));  // (a scalar publish: slot 0)
     }
     // Per-slice sums that do not depend on the hash-grid backward - d slice scale, d slice variance and the slice embedding's
@@ -333,7 +340,7 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
     // ran one slice_grads launch behind the sampler backward: 46 us of the step's serial tail next to the owner pass.
     if (early_sg) {
       if (hipEventRecord(ctx->ev_sg0, main) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_sg0, 0) != hipSuccess) return (int)hipGetLastError();
-      NESVOR_TRY(slice_grads(d.has_c ? d.pix : nullptr, d.has_lvs ? d.pix + B : nullptr, (d.has_lv && d.ks) ? d.dxa : nullptr, nullptr, dc,
+      NESVOR_TRY(slice_grads(d.has_c ? d.pix : nullptr, d.has_lvs ? d.pix + B : nullptr, (d.has_lv && d.ks) ? d.dxa : nullptr, rows_pp_s, nullptr, dc,
                              d.has_lvs ? d.g_log_var_slice : nullptr, d.ks ? d.g_slice_embedding : nullptr, nullptr, side));
       if (hipEventRecord(ctx->ev_sg1, side) != hipSuccess) return (int)hipGetLastError();
     }
@@ -343,7 +350,7 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
                                    d.n_density_params, N, main, d.dpre_scratch, dpe_bound));
     }
     if (d.has_b) {
-      NESVOR_TRY(mlp_backward_into(net_b, group_sums, d.se, d.pe, d.dlb, d.saved_b, d.ks ? d.dxa_b : nullptr, d.dpe_b, part_b,
+      NESVOR_TRY(mlp_backward_into(net_b, group_sums_b, d.se, d.pe, d.dlb, d.saved_b, d.ks ? d.dxa_b : nullptr, d.dpe_b, part_b,
                                    d.g_bias_net, d.n_bias_params, N, main, d.dpre_scratch));
       const int64_t nb = (int64_t)d.kb_bias * N;
       hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((nb / 4 + 255) / 256 + 1)), dim3(256), 0, main, d.dpe, d.dpe_b, nb);
@@ -430,10 +437,10 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   if (early_sg) {
     if (hipStreamWaitEvent(main, ctx->ev_sg1, 0) != hipSuccess) return (int)hipGetLastError();
   } else {
-    NESVOR_TRY(slice_grads(d.has_c ? d.pix : nullptr, d.has_lvs ? d.pix + B : nullptr, dxa_first, d.opt_T ? d.dpix : nullptr, dc,
+    NESVOR_TRY(slice_grads(d.has_c ? d.pix : nullptr, d.has_lvs ? d.pix + B : nullptr, dxa_first, rows_pp_first, d.opt_T ? d.dpix : nullptr, dc,
                            d.has_lvs ? d.g_log_var_slice : nullptr, d.ks ? d.g_slice_embedding : nullptr, dmat, main));
     if (d.has_lv && d.has_b && d.ks)  // second consumer of the slice embedding
-      NESVOR_TRY(slice_grads(nullptr, nullptr, d.dxa_b, nullptr, nullptr, nullptr, d.g_slice_embedding, nullptr, main));
+      NESVOR_TRY(slice_grads(nullptr, nullptr, d.dxa_b, rows_pp_b, nullptr, nullptr, nullptr, d.g_slice_embedding, nullptr, main));
   }
   if (ctx->head_on_side && d.opt_T && hipStreamWaitEvent(main, ctx->ev_pose, 0) != hipSuccess) return (int)hipGetLastError();
   const float img_scale = (d.reg_type == 0 ? d.delta : 1.f) / (float)N, img_off = d.reg_type == 0 ? -d.delta : 0.f;

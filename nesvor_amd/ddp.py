@@ -42,11 +42,17 @@ def cap_hw_queues(limit: int = 4) -> Optional[str]:
     1.86 ms) whatever the stream layout or stream priorities - the command processor's queue switching, not an ordering problem
     this code could fix.  ROCm's default (4) and 2 do not show it.  Round 4 only warned; a launcher or a harness that exports the
     variable would have made the first scaling curve ever measured read 50 % low, so it is overridden (and logged).  Returns what
-    happened ("lowered" / "too late: HIP already initialised" / None)."""
+    happened ("lowered" / "kept" / "too late: HIP already initialised" / None).  The rewrite is visible to child processes of this one
+    (os.environ); ``NESVOR_KEEP_HW_QUEUES=1`` opts out."""
     hwq = os.environ.get("GPU_MAX_HW_QUEUES")
     if hwq is None or not hwq.strip().isdigit() or int(hwq) <= limit:
         return None
     import logging
+
+    if os.environ.get("NESVOR_KEEP_HW_QUEUES") == "1":  # opt-out (round-5 advisor): the caller's export stands, child processes see it unchanged
+        logging.warning("GPU_MAX_HW_QUEUES=%s kept (NESVOR_KEEP_HW_QUEUES=1): expect the data-parallel step ~50 %% slower above %d "
+                        "hardware queues on MI355X (nesvor_amd/ddp.py)", hwq, limit)
+        return "kept"
 
     if torch.cuda.is_initialized():
         logging.warning("GPU_MAX_HW_QUEUES=%s and the HIP runtime is already initialised: the data-parallel step runs ~50 %% slower "
@@ -54,7 +60,7 @@ def cap_hw_queues(limit: int = 4) -> Optional[str]:
         return "too late: HIP already initialised"
     os.environ["GPU_MAX_HW_QUEUES"] = str(limit)
     logging.warning("GPU_MAX_HW_QUEUES=%s lowered to %d for this process (above %d every kernel of the data-parallel step starts ~40 us "
-                    "late on MI355X: nesvor_amd/ddp.py)", hwq, limit, limit)
+                    "late on MI355X: nesvor_amd/ddp.py; NESVOR_KEEP_HW_QUEUES=1 keeps the exported value)", hwq, limit, limit)
     return "lowered"
 
 

@@ -96,7 +96,7 @@ class DirectStep:
         # gradient and update (no data-parallel exchange in between): the table gradient then never goes through HBM
         self._adamw_in_owner = __import__("os").environ.get("NESVOR_ADAMW_IN_OWNER", "1") != "0"
         # evaluation of the MLP matrix products (mlp.operand_mode): bf16-rounded operands for the half-precision model
-        # structure and, opt-in, for the fp32 model (args.mlp_bf16); otherwise fp32 - the split-bf16 default, or the
+        # structure and, opt-in, for the fp32 model (args.mlp_bf16); otherwise fp32 - the split-fp16 default, or the
         # plain fp32 MFMAs with args.mlp_fp32_mfma
         if bool(getattr(a, "mlp_bf16", False)) or half_precision_model(model):
             self.bf16 = True
@@ -184,19 +184,31 @@ class DirectStep:
             return False  # (the dX + dW launch pair that other shapes fall back to has no bf16-operand form)
         return True
 
-    def _fused_backward_takes_all(self) -> bool:
-        """Whether the wave-specialised fused MLP backward takes every network of the model (batch-size independent: asked once);
-        otherwise the one-call step hands the networks a shared dpre scratch (``nesvor_step_t.dpre_scratch``)."""
+    def _fused_backward_ok(self, N=None):
+        """Per network (density, sigma | None, bias | None): does the wave-specialised fused MLP backward take it at N points per
+        iteration?  (``nesvor_mlp_backward_fused_ok``; the answer depends on the shapes and - through the 32-bit row offsets of
+        its scalar-base addressing - on N: asked once per N, with the REAL N of the batch, round-5 advisor.)  A network it refuses
+        runs as a dX launch + a dW launch through ``nesvor_step_t.dpre_scratch`` and returns its pixel-feature gradient per
+        sample, not per 16-sample group."""
+        m, a = self.model, self.model.args
+        S = a.n_samples
+        N = 16 * S if N is None else int(N)
         if self._native_shapes_ok is None:
-            m, a = self.model, self.model.args
-            S, E = a.n_samples, m.inr.encoding.spec.n_output_dims
-            descs = [mlp_mod.dims_desc(len(self.d_net.weights) - 1, 1 + a.n_features_z, 0, E, 0, S, self.bf16)]
-            if self.has_lv:
-                descs.append(mlp_mod.dims_desc(len(self.s_net.weights) - 1, 1, self.ks, a.n_features_z, 1, S, self.bf16))
-            if self.has_b:
-                descs.append(mlp_mod.dims_desc(len(self.b_net.weights) - 1, 1, self.ks, self.kb_bias, 0, S, self.bf16))
-            self._native_shapes_ok = all(bool(_lib.load().nesvor_mlp_backward_fused_ok(ctypes.byref(dd), 16 * S)) for dd in descs)
-        return self._native_shapes_ok
+            self._native_shapes_ok = {}
+        key = (N, mlp_mod.operand_mode(self.bf16))  # (bench.py switches the evaluation mode of a live trainer)
+        if key not in self._native_shapes_ok:
+            E = m.inr.encoding.spec.n_output_dims
+            ok = lambda dd: bool(_lib.load().nesvor_mlp_backward_fused_ok(ctypes.byref(dd), N))
+            self._native_shapes_ok[key] = (
+                ok(mlp_mod.dims_desc(len(self.d_net.weights) - 1, 1 + a.n_features_z, 0, E, 0, S, self.bf16)),
+                ok(mlp_mod.dims_desc(len(self.s_net.weights) - 1, 1, self.ks, a.n_features_z, 1, S, self.bf16)) if self.has_lv else None,
+                ok(mlp_mod.dims_desc(len(self.b_net.weights) - 1, 1, self.ks, self.kb_bias, 0, S, self.bf16)) if self.has_b else None)
+        return self._native_shapes_ok[key]
+
+    def _fused_backward_takes_all(self, N=None) -> bool:
+        """Whether the fused MLP backward takes EVERY network of the model at N points per iteration; otherwise the one-call step
+        hands the networks a shared dpre scratch (``nesvor_step_t.dpre_scratch``)."""
+        return all(v is not False for v in self._fused_backward_ok(N))
 
     def _native_state(self, B: int):
         key = (B, mlp_mod.operand_mode(self.bf16), self._overlap_owner, self._adamw_in_owner)  # (bench.py switches the evaluation mode of a live trainer)
@@ -264,25 +276,30 @@ class DirectStep:
                 slots[i] = new(f"{tag}{i}", n_el)
 
         saved_buffers(d.density, d.saved_d, "saved_d", len(self.d_net.weights) - 1)
-        if not self._fused_backward_takes_all():
+        if not self._fused_backward_takes_all(N):
             # some network's backward runs as a dX launch + a dW launch (samples per pixel or pixel features not in multiples of
             # 16, ...): one set of pre-activation gradients, shared by the networks' backwards one after the other
             for i in range(max(len(p.weights) - 1 for p in (self.d_net, self.s_net if self.has_lv else self.d_net, self.b_net if self.has_b else self.d_net))):
                 d.dpre_scratch[i] = new(f"dpre{i}", n_pad * 64)
         if self.ks:
             d.se = new("se", B, self.ks)
-        rows = N // 16 if (N % 16 == 0 and S % 16 == 0 and self.ks % 16 == 0) else N
+        # pixel-feature gradients: one row per 16-sample group from the fused backward, one per sample from the launch pair
+        # (csrc/step.hip decides per network by the same rule: divisibility and nesvor_mlp_backward_fused_ok at this N)
+        group_div = N % 16 == 0 and S % 16 == 0 and self.ks % 16 == 0
+        _, fused_s, fused_b = self._fused_backward_ok(N)
+        rows_s = N // 16 if (group_div and fused_s) else N
+        rows_b = N // 16 if (group_div and fused_b) else N
         if self.has_lv:
             d.log_var, d.dlv = new("log_var", N), new("dlv", N)
             saved_buffers(d.sigma, d.saved_s, "saved_s", len(self.s_net.weights) - 1)
             if self.ks:
-                d.dxa = new("dxa", rows, self.ks)
+                d.dxa = new("dxa", rows_s, self.ks)
         if self.has_b:
             d.log_bias, d.dlb, d.dpe_b = new("log_bias", N), new("dlb", N), new("dpe_b", self.kb_bias, N)
             d.lb_mean, d.mean_scratch = new("lb_mean", 1), new("mean_scratch", 256)
             saved_buffers(d.bias_net, d.saved_b, "saved_b", len(self.b_net.weights) - 1)
             if self.ks:
-                d.dxa_b = new("dxa_b", rows, self.ks)
+                d.dxa_b = new("dxa_b", rows_b, self.ks)
         if self.opt_T:
             d.dxl, d.du, d.dpix = new("dxl", B, S, 3), new("du", N, 3), new("dpix", B, 3, 4)
             d.trans_terms, d.g_trans = new("trans_terms", n), new("g_trans", n, 6)

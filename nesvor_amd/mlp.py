@@ -430,7 +430,7 @@ def flat_network(net, x):
 def inference_operands(inr, args):
     """How the density network's products are evaluated at inference (the `bf16` argument of ``forward_raw``) -
     the same choice the training step makes (nesvor_amd.direct): bf16 operands for the half-precision model structure
-    and for ``args.mlp_bf16``, otherwise fp32 (split-bf16 evaluation, or the fp32 MFMAs with ``args.mlp_fp32_mfma``)."""
+    and for ``args.mlp_bf16``, otherwise fp32 (split-fp16 evaluation, or the fp32 MFMAs with ``args.mlp_fp32_mfma``)."""
     from .tinycudann import Network
 
     net = inr.density_net

@@ -63,11 +63,26 @@ _ACTIVATIONS = {
 }
 
 
+# Behind an explicit flag (round-5 advisor: configs that named them used to run): tiny-cuda-nn's Softplus / Squareplus AS RECALLED,
+# the K_ACT = 10 scaled variants - unverifiable here, hence never picked silently.  NESVOR_TCNN_UNVERIFIED_ACTIVATIONS=1 enables them.
+_UNVERIFIED = {
+    "Softplus": lambda t: torch.nn.functional.softplus(t * 10.0) / 10.0,
+    "Squareplus": lambda t: 0.5 * (t * 10.0 + torch.sqrt((t * 10.0) ** 2 + 4.0)) / 10.0,
+}
+
+
 def _activation(name: str):
-    try:
+    if name in _ACTIVATIONS:
         return _ACTIVATIONS[name]
-    except KeyError:
-        raise NotImplementedError(f"tinycudann activation {name!r} is not implemented (known: {sorted(_ACTIVATIONS)})") from None
+    if name in _UNVERIFIED:
+        import os
+
+        if os.environ.get("NESVOR_TCNN_UNVERIFIED_ACTIVATIONS") == "1":
+            return _UNVERIFIED[name]
+        raise NotImplementedError(f"tinycudann activation {name!r}: its definition cannot be verified here (tiny-cuda-nn is absent); "
+                                  f"NESVOR_TCNN_UNVERIFIED_ACTIVATIONS=1 enables the recalled K_ACT = 10 variant")
+    raise NotImplementedError(f"tinycudann activation {name!r} is not implemented (known: {sorted(_ACTIVATIONS)}, "
+                              f"unverified: {sorted(_UNVERIFIED)})")
 
 
 class Network(nn.Module):

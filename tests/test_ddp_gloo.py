@@ -159,6 +159,10 @@ def test_cap_hw_queues_overrides_before_hip_initialises(monkeypatch):
         pytest.skip("the HIP runtime is already up in this process")
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
     assert ddp.cap_hw_queues() == "lowered" and os.environ["GPU_MAX_HW_QUEUES"] == "4"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    monkeypatch.setenv("NESVOR_KEEP_HW_QUEUES", "1")  # the opt-out: the caller's export stands
+    assert ddp.cap_hw_queues() == "kept" and os.environ["GPU_MAX_HW_QUEUES"] == "8"
+    monkeypatch.delenv("NESVOR_KEEP_HW_QUEUES")
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
     assert ddp.cap_hw_queues() is None and os.environ["GPU_MAX_HW_QUEUES"] == "2"
     monkeypatch.delenv("GPU_MAX_HW_QUEUES")

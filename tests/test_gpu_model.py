@@ -563,6 +563,9 @@ def test_native_step_table_update_in_owner_pass_and_deferred_join(device, golden
     {"image_regularization": "TV", "n_samples": 16}, {"n_levels_bias": 2, "depth": 2, "n_samples": 16},
     {"n_levels_bias": 2, "no_pixel_variance": True, "n_samples": 32}, {"n_samples": 24}, {}, {"n_levels_bias": 2, "depth": 2},
     {"mlp_bf16": True, "n_samples": 16},
+    # round-5 advisor: sigma_net with 32 + 15 inputs at two hidden layers - samples and pixel features in multiples of 16, yet the
+    # wave-specialised backward refuses the shape: the step must run THAT network as a dX + dW launch pair (per-sample dxa rows)
+    {"depth": 2, "n_samples": 16, "n_features_slice": 32},
 ])
 def test_one_call_step_equals_python_issued_step(device, golden, over):
     """``nesvor_step_run`` (csrc/step.hip: the whole iteration + AdamW enqueued by one C call into buffers allocated once)
@@ -598,7 +601,8 @@ def test_one_call_step_equals_python_issued_step(device, golden, over):
     # (sample counts that are not multiples of 16 - n_samples = 24 here, 8 in the defaults - leave the wave-specialised MLP backward:
     #  the one-call step then runs each network's backward as a dX launch + a dW launch through nesvor_step_t.dpre_scratch)
     assert t1.direct.native_ready()
-    assert t1.direct._fused_backward_takes_all() == (args.n_samples % 16 == 0)
+    assert t1.direct._fused_backward_takes_all(args.batch_size * args.n_samples) == (
+        args.n_samples % 16 == 0 and not (args.depth == 2 and args.n_features_slice + args.n_features_z > 32))
     assert not t2.direct.native_ready()
     d = lambda k: torch.tensor(golden[f"fw_{k}"]).to(device)
     # (1) gradients of one iteration, no optimizer: the owner pass of the hash-grid backward sums records in arrival order,
