@@ -196,6 +196,17 @@ int nesvor_hashgrid_forward(const nesvor_grid_t* grid, const float* u, const flo
  * be NULL) to max |pe| - the input bound of the network that consumes pe (nesvor_mlp_t.prep + NESVOR_MLP_PREP_XB). */
 int nesvor_hashgrid_forward_bounded(const nesvor_grid_t* grid, const float* u, const float* table, float* pe,
                                     int64_t N, int layout, float* pe_absmax, void* stream);
+/* The forward for a batch whose consecutive points are NOT spatially clustered (uniform points, a shuffled batch, one point per
+ * voxel: the reference's `--no-output-psf` inference, nesvor/nesvor/sample.py:17-33 -> models.py:154-174, and any tcnn-style
+ * caller, models.py:25).  `layout` carries NESVOR_LAYOUT_UNCLUSTERED; the points are first put into the order of a coarse
+ * lattice's cells (the counting sort of the unclustered backward: three small launches), the one-workgroup-per-256-points kernel
+ * runs on workgroups of neighbouring points (lattice boxes in LDS up to the middle levels instead of 8 gathers per point and
+ * level), and - feature-major output - the encoded rows are re-ordered into columns by one more launch.  Results are identical to
+ * nesvor_hashgrid_forward's (same arithmetic per point).  `workspace`: nesvor_hashgrid_forward_workspace_bytes(grid, N, layout)
+ * bytes of scratch (0 without the hint); N < 2^32. */
+int64_t nesvor_hashgrid_forward_workspace_bytes(const nesvor_grid_t* grid, int64_t N, int layout);
+int nesvor_hashgrid_forward_unclustered(const nesvor_grid_t* grid, const float* u, const float* table, float* pe, int64_t N,
+                                        int layout, float* pe_absmax, void* workspace, int64_t workspace_bytes, void* stream);
 /* grad_table is ACCUMULATED into (caller zero-fills when needed);
  * grad_u (N,3) is OVERWRITTEN, or NULL to skip the input gradient.
  * Owner-computes scatter (LDS aggregation per 256 samples -> per-chunk queues ->

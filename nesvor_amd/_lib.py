@@ -124,6 +124,8 @@ _SIGNATURES = {
     "nesvor_slice_acq_adjoint_backward_interp_f64": ([_P] * 10 + [c_int] * 9 + [c_double, c_int, _P], c_int),
     "nesvor_hashgrid_forward": ([POINTER(GridT), _P, _P, _P, c_int64, c_int, _P], c_int),
     "nesvor_hashgrid_forward_bounded": ([POINTER(GridT), _P, _P, _P, c_int64, c_int, _P, _P], c_int),
+    "nesvor_hashgrid_forward_workspace_bytes": ([POINTER(GridT), c_int64, c_int], c_int64),
+    "nesvor_hashgrid_forward_unclustered": ([POINTER(GridT), _P, _P, _P, c_int64, c_int, _P, _P, c_int64, _P], c_int),
     "nesvor_hashgrid_backward_workspace_bytes": ([POINTER(GridT), c_int64, _P], c_int64),
     "nesvor_hashgrid_backward_workspace_bytes_ex": ([POINTER(GridT), c_int64, _P, c_int], c_int64),
     "nesvor_hashgrid_backward_workspace_zero_bytes": ([], c_int64),

@@ -112,6 +112,9 @@ def build(force=False, verbose=True):
             if os.environ.get("NESVOR_SKIP_ASM_CHECK") == "1":
                 print(f"WARNING (NESVOR_SKIP_ASM_CHECK=1): {e}", file=sys.stderr, flush=True)
             else:
+                obj = asm[:-2] + ".o"
+                if os.path.exists(obj):
+                    os.remove(obj)  # (a later build must not link the unchecked object: it recompiles and re-checks this unit)
                 raise RuntimeError(f"{e}\n(the assembly check of the build failed; NESVOR_SKIP_ASM_CHECK=1 builds anyway - only "
                                    f"if tools/check_inflight_loads.py, not the kernel, is what a compiler update broke)") from e
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]

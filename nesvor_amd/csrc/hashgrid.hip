@@ -293,10 +293,18 @@ __global__ __launch_bounds__(256) void hashgrid_fwd(const nesvor_grid_t g, const
 #ifndef NESVOR_FWD_SSTORE
 #define NESVOR_FWD_SSTORE 1
 #endif
+// Unclustered input (round 6, NESVOR_LAYOUT_UNCLUSTERED on the forward): `perm` = the points in the order of a coarse lattice's
+// cells (sort_points below: the same order the unclustered backward uses); workgroup w takes points perm[256 w ..], so that
+// its lattice boxes are small again and the box rounds reach the middle levels.  Row-major output goes straight to the
+// points' own rows (a row is 4 L F contiguous bytes, written level by level by one thread); feature-major output would be a
+// 4-byte store per (point, feature) into rows of N floats - 33 M scattered sectors at N = 2^20 - so it is written as ROWS in
+// the sorted order into `rows` (whole lines) and scatter_pe_rows_kernel turns those into columns (the inverse of
+// gather_dy_rows_kernel).
 template <int F, int LAYOUT>
 __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g, const float* __restrict__ u,
                                                           const float* __restrict__ table, float* __restrict__ pe, int64_t N,
-                                                          float* __restrict__ pe_absmax) {  // optional: raised to max |pe| (the density network's input bound)
+                                                          float* __restrict__ pe_absmax,  // optional: raised to max |pe| (the density network's input bound)
+                                                          const uint32_t* __restrict__ perm = nullptr, float* __restrict__ rows = nullptr) {
 #ifndef NESVOR_FWD_CLOUD_SLOTS
 #define NESVOR_FWD_CLOUD_SLOTS 512
 #endif
@@ -310,9 +318,11 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
   __shared__ uint32_t slot_off[NESVOR_MAX_LEVELS + 1], grp_end[NESVOR_MAX_LEVELS + 1], rnd_slots[NESVOR_MAX_LEVELS + 1];
   __shared__ int32_t box_end_s;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
-  const bool valid = i < N;
-  const int64_t ii = valid ? i : N - 1;
+  const int64_t slot_i = (int64_t)blockIdx.x * 256 + tid;   // position in the processing order
+  const bool valid = slot_i < N;
+  const int64_t si = valid ? slot_i : N - 1;
+  const int64_t i = perm != nullptr ? (int64_t)perm[si] : slot_i;  // the point (output index); == slot_i without an order
+  const int64_t ii = perm != nullptr ? i : si;
   const int L = g.n_levels, E = L * F;
   const float ux = u[3 * ii], uy = u[3 * ii + 1], uz = u[3 * ii + 2];
   {
@@ -365,6 +375,12 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
     if (!valid) return;
 #pragma unroll
     for (int f = 0; f < F; ++f) pe_mx = fmaxf(pe_mx, fabsf(acc[f]));
+    if (rows != nullptr) {  // (kernel argument: uniform) feature-major output of an ordered batch: rows in the sorted order
+      float* o = rows + (size_t)slot_i * E + level * F;
+#pragma unroll
+      for (int f = 0; f < F; ++f) o[f] = acc[f];
+      return;
+    }
     if constexpr (LAYOUT == NESVOR_LAYOUT_ROW_MAJOR) {
       float* o = pe + (size_t)i * E + level * F;
 #pragma unroll
@@ -2154,6 +2170,41 @@ __global__ __launch_bounds__(256) void gather_dy_rows_kernel(const float* __rest
     }
   }
 }
+// The inverse, for the unclustered FORWARD: rows (N, E) in cell order -> feature-major pe (E, N).  Every point's row is READ
+// whole (4 E contiguous bytes at its rank), the columns are WRITTEN in their own order (256 consecutive floats per row and
+// workgroup).
+__global__ __launch_bounds__(256) void scatter_pe_rows_kernel(const float* __restrict__ rows, SortBufs s, float* __restrict__ pe, int64_t N, int E) {
+  extern __shared__ float tile[];  // [kGatherPts][E + 1]
+  __shared__ uint32_t rank[kGatherPts];
+  const int tid = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * kGatherPts;
+  const bool ok = i0 + tid < N;
+  if (ok) {
+    const unsigned long long w = s.where[i0 + tid];
+    rank[tid] = s.first[(uint32_t)(w >> 32)] + (uint32_t)w;
+  }
+  __syncthreads();
+  if ((E & 3) == 0) {
+    const int E4 = E >> 2;
+    for (int idx = tid; idx < kGatherPts * E4; idx += 256) {
+      const int q = idx / E4, e = (idx - q * E4) * 4;
+      if (i0 + q < N) {
+        const float4 v = *reinterpret_cast<const float4*>(rows + (size_t)rank[q] * E + e);
+        float* t = tile + q * (E + 1) + e;
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+      }
+    }
+  } else {
+    for (int idx = tid; idx < kGatherPts * E; idx += 256) {
+      const int q = idx / E, e = idx - q * E;
+      if (i0 + q < N) tile[q * (E + 1) + e] = rows[(size_t)rank[q] * E + e];
+    }
+  }
+  __syncthreads();
+  if (ok) {
+    for (int e = 0; e < E; ++e) pe[(size_t)e * N + i0 + tid] = tile[tid * (E + 1) + e];
+  }
+}
 inline int sort_points(const float* u, int64_t N, uint32_t* base, hipStream_t st) {
   const SortPlan p = sort_plan(N);
   const SortBufs s = sort_bufs(base, N, p);
@@ -2262,6 +2313,43 @@ owner_stage:
   return (int)hipGetLastError();
 }
 
+// scratch of the unclustered forward: the order (sort_bytes) | feature-major output: rows (n_pad, E) in that order
+inline uint64_t fwd_ws_bytes(const nesvor_grid_t* g, int64_t N, int layout) {
+  const uint64_t n_pad = (uint64_t)((N + 255) / 256) * 256;
+  uint64_t b = 256 + ((sort_bytes(N) + 255) & ~(uint64_t)255);
+  if ((layout & NESVOR_LAYOUT_MASK) == NESVOR_LAYOUT_FEATURE_MAJOR) b += n_pad * (uint64_t)(g->n_levels * g->n_features) * sizeof(float);
+  return b;
+}
+template <int F, int LAYOUT>
+int launch_fwd_unclustered(const nesvor_grid_t* g, const float* u, const float* table, float* pe, int64_t N, float* pe_absmax,
+                           void* workspace, hipStream_t st) {
+  uint32_t* const perm_buf = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+  const int se = sort_points(u, N, perm_buf, st);
+  if (se) return se;
+  float* rows = nullptr;
+  const int E = g->n_levels * F;
+  if constexpr (LAYOUT == NESVOR_LAYOUT_FEATURE_MAJOR)
+    rows = reinterpret_cast<float*>(reinterpret_cast<char*>(perm_buf) + ((sort_bytes(N) + 255) & ~(uint64_t)255));
+  hipLaunchKernelGGL((hashgrid_fwd_cloud<F, LAYOUT>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, *g, u, table, pe, N, pe_absmax,
+                     (const uint32_t*)perm_buf, rows);
+  if constexpr (LAYOUT == NESVOR_LAYOUT_FEATURE_MAJOR) {
+    const size_t lds = sizeof(float) * kGatherPts * (E + 1);
+    if (lds > 48 * 1024) {
+      static std::mutex mu;
+      static size_t raised = 0;
+      std::lock_guard<std::mutex> lock(mu);
+      if (lds > raised) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_pe_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        raised = lds;
+      }
+    }
+    hipLaunchKernelGGL(scatter_pe_rows_kernel, dim3((unsigned)((N + kGatherPts - 1) / kGatherPts)), dim3(256), lds, st, rows,
+                       sort_bufs(perm_buf, N, sort_plan(N)), pe, N, E);
+  }
+  return (int)hipGetLastError();
+}
+
 template <int F, int LAYOUT>
 int launch_fwd(const nesvor_grid_t* g, const float* u, const float* table, float* pe, int64_t N, int clustered, float* pe_absmax, hipStream_t st) {
   // Two kernels, identical results: "cloud" (one workgroup per 256 samples, all levels: the fastest on spatially
@@ -2330,6 +2418,23 @@ extern "C" int nesvor_hashgrid_forward(const nesvor_grid_t* grid, const float* u
   return nesvor_hashgrid_forward_bounded(grid, u, table, pe, N, layout, nullptr, stream);
 }
 
+extern "C" int64_t nesvor_hashgrid_forward_workspace_bytes(const nesvor_grid_t* grid, int64_t N, int layout) {
+  if (grid == nullptr || N <= 0) return 0;
+  if (!(layout & NESVOR_LAYOUT_UNCLUSTERED)) return 0;
+  return (int64_t)fwd_ws_bytes(grid, N, layout);
+}
+
+extern "C" int nesvor_hashgrid_forward_unclustered(const nesvor_grid_t* grid, const float* u, const float* table, float* pe,
+                                                   int64_t N, int layout, float* pe_absmax, void* workspace, int64_t workspace_bytes,
+                                                   void* stream) {
+  if (N <= 0) return 0;
+  if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
+  if (N >= ((int64_t)1 << 32)) return (int)hipErrorInvalidValue;  // (32-bit point indices in the order)
+  if (workspace == nullptr || workspace_bytes < (int64_t)fwd_ws_bytes(grid, N, layout)) return (int)hipErrorInvalidValue;
+  layout &= NESVOR_LAYOUT_MASK;
+  DISPATCH_F_LAYOUT(launch_fwd_unclustered, grid, u, table, pe, N, pe_absmax, workspace, (hipStream_t)stream);
+}
+
 extern "C" int nesvor_hashgrid_backward_atomic(const nesvor_grid_t* grid, const float* u, const float* table,
                                                const float* dpe, float* grad_table, float* grad_u, int64_t N,
                                                int layout, void* stream) {
@@ -2340,8 +2445,11 @@ extern "C" int nesvor_hashgrid_backward_atomic(const nesvor_grid_t* grid, const 
 }
 
 extern "C" int64_t nesvor_hashgrid_backward_workspace_bytes_ex(const nesvor_grid_t* grid, int64_t N, const float* queue_scale, int layout) {
-  const int64_t base = nesvor_hashgrid_backward_workspace_bytes(grid, N, queue_scale);
+  int64_t base = nesvor_hashgrid_backward_workspace_bytes(grid, N, queue_scale);
   if (base <= 0) return base;
+  // (round-5 advisor) the order's scratch - ~26 MB at N = 2^20 - only for callers that will pass NESVOR_LAYOUT_UNCLUSTERED; the
+  // plain query above keeps it (its callers may pass any hint later)
+  if (!(layout & NESVOR_LAYOUT_UNCLUSTERED)) base -= (int64_t)((sort_bytes(N) + 255) & ~(uint64_t)255);
   if ((layout & NESVOR_LAYOUT_MASK) == NESVOR_LAYOUT_FEATURE_MAJOR && (layout & NESVOR_LAYOUT_UNCLUSTERED) && (layout & NESVOR_LAYOUT_DY_SCRATCH))
     return base + 256 + (int64_t)((N + 255) / 256) * 256 * grid->n_levels * grid->n_features * (int64_t)sizeof(float);
   return base;

@@ -1633,6 +1633,44 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
         else stage_tile(buf, go, j, q);
         dbc_o[0] += go;
         pin(dbc_o[0]);  // (the sum stays HERE: sunk to the end of the iteration it keeps `go` alive past its in-place split)
+        // Split mode, round 6: a power of two PER SAMPLE on top of the launch's scale.  The launch's scale maps the largest |dY| of
+        // the whole batch to 2^15; a sample whose upstream gradient lies 2^-20 below that kept 14-16 bits of its input gradient
+        // and one 2^-30 below it 4-8 (measured: tests/test_gpu_ops.py::test_fused_mlp_split_dynamic_range) - and AdamW turns the
+        // smallest gradients into full-size steps.  The chain is linear per sample (a column of every product, the gates included),
+        // so sample j runs it on dY_j 2^k_j with k_j = 13 - exponent(sd max_r |dY[r][j]|) clamped to [0, 24]: its values sit where
+        // the launch's largest do (never above: the propagated bounds stay valid), the input gradient leaves multiplied by 2^-k_j,
+        // the bias-gradient sums take d 2^-k_j (one FMA instead of one add), and the planes handed to the dW wave - whose sums over
+        // the samples need the LAUNCH's units - are the chain's own split scaled back by 2^-k_j in fp16 (v_pk_mul_f16: exact down
+        // to the subnormals, where the absolute resolution is the one a direct split in the launch's units has).
+        float inv_pj = 1.f;
+        uint32_t inv_pj_h2 = 0x3C003C00u;  // (1.0, 1.0) in fp16
+        if constexpr (SPL && !BF16) {
+          float mxj;
+          if constexpr (OUT1) {
+            mxj = fabsf(__shfl(go[0], j, 64));
+          } else {
+            mxj = fmaxf(fmaxf(fabsf(go[0]), fabsf(go[1])), fmaxf(fabsf(go[2]), fabsf(go[3])));
+            // over the four feature quads of sample j (lanes j, j + 16, j + 32, j + 48) on the VALU: gfx950's row / half swaps
+            // (v_permlane16_swap, v_permlane32_swap) instead of two ds_bpermute round trips at the head of the chain
+            {
+              typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+              const unsigned int b0 = __float_as_uint(mxj);
+              const u32x2 s16 = __builtin_amdgcn_permlane16_swap(b0, b0, false, false);
+              const float m16 = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+              const unsigned int b1 = __float_as_uint(m16);
+              const u32x2 s32 = __builtin_amdgcn_permlane32_swap(b1, b1, false, false);
+              mxj = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+            }
+          }
+          const int e = (int)((__float_as_uint(mxj * sc.sd[NH]) >> 23) & 0xFFu) - 127;  // zero / subnormal: -127 -> the clamp
+          const int k = min(max(13 - e, 0), 24);
+          const float pj = __uint_as_float((uint32_t)(127 + k) << 23);
+          inv_pj = __uint_as_float((uint32_t)(127 - k) << 23);
+          const uint32_t h = k <= 14 ? (uint32_t)(15 - k) << 10 : 1u << (24 - k);  // 2^-k in fp16 (subnormal beyond 2^-14)
+          inv_pj_h2 = h | (h << 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) go[r] *= pj;
+        }
         f32x4 gov[1] = {go};
         f32x4 d[kHB];
         if constexpr (!SPL) {
@@ -1665,13 +1703,32 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
                 d[ib][r] = hs[l][ib][r] > 0.f ? d[ib][r] : 0.f;
               }
             }
-            // (the bias-gradient sums take d BEFORE the split, in the units d arrives in: flush_dw_ws scales them back)
-            if (l > 0) { dbc_h[l > 0 ? l - 1 : 0][ib] += d[ib]; pin(dbc_h[l > 0 ? l - 1 : 0][ib]); }
-            else { dbc_1[ib] += d[ib]; pin(dbc_1[ib]); }
+            // (the bias-gradient sums take d BEFORE the split, in the units d arrives in: flush_dw_ws scales them back; split mode:
+            //  times the sample's 2^-k_j - an FMA where the other modes add)
+            if constexpr (SPL && !BF16) {
+              f32x4& acc_b = l > 0 ? dbc_h[l > 0 ? l - 1 : 0][ib] : dbc_1[ib];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc_b[r] = __builtin_fmaf(d[ib][r], inv_pj, acc_b[r]);
+              pin(acc_b);
+            } else {
+              if (l > 0) { dbc_h[l > 0 ? l - 1 : 0][ib] += d[ib]; pin(dbc_h[l > 0 ? l - 1 : 0][ib]); }
+              else { dbc_1[ib] += d[ib]; pin(dbc_1[ib]); }
+            }
             if constexpr (PLANES) {
               __builtin_amdgcn_sched_barrier(0x07FC);  // VALU instructions stay on their side: the adds above, the split below
               ds[ib] = split2(d[ib], m_d[l]);  // once: for the planes and for this wave's own product below
-              stage_planes(buf + kTile0Floats + ((NH - 1 - l) * kHB + ib) * kPlaneTileFloats, ds[ib], j, q);
+              Split2 dp = ds[ib];
+              if constexpr (!BF16) {  // the dW wave's sums run in the launch's units: the sample's scale comes off (fp16, packed)
+                typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+                const h16x2 ip = __builtin_bit_cast(h16x2, inv_pj_h2);
+                uint2 hh = __builtin_bit_cast(uint2, ds[ib].hi), ll = __builtin_bit_cast(uint2, ds[ib].lo);
+                hh.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h16x2, hh.x) * ip);
+                hh.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h16x2, hh.y) * ip);
+                ll.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h16x2, ll.x) * ip);
+                ll.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h16x2, ll.y) * ip);
+                dp.hi = __builtin_bit_cast(s16x4, hh); dp.lo = __builtin_bit_cast(s16x4, ll);
+              }
+              stage_planes(buf + kTile0Floats + ((NH - 1 - l) * kHB + ib) * kPlaneTileFloats, dp, j, q);
             } else {
               stage_tile(buf + (1 + (NH - 1 - l) * kHB + ib) * kTileFloats, d[ib], j, q);
             }
@@ -1695,8 +1752,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             if constexpr (PLANES) apply_layer_g1_s<kHB, KB1, true>(img1, ds, dx, lane);
             else apply_layer_g1<kHB, KB1, BF16, SPL, SPL>(img1, d, dx, lane);
             if constexpr (SPL) {
+              const float un = inv_dx * inv_pj;  // the accumulators' units and the sample's scale: both powers of two
 #pragma unroll
-              for (int kb = 0; kb < KB1; ++kb) dx[kb] *= inv_dx;
+              for (int kb = 0; kb < KB1; ++kb) dx[kb] *= un;
             }
             if (a.dx_absmax != nullptr) track_absmax<KB1>(a, dx, dx_mx);
             // drain the prefetch BEFORE the stores below: loads and stores share vmcnt, and the wait would otherwise

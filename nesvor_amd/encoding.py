@@ -9,19 +9,39 @@ from . import _lib
 from .grid import HashGridSpec
 
 
+_FWD_WS = {}
+UNCLUSTERED_FWD_MIN_POINTS = 1 << 15  # below this the four launches of the ordered forward cost more than they save
+_FWD_MODE = __import__("os").environ.get("NESVOR_HASHGRID_FWD", "")  # cloud | level | gather: force one kernel (csrc/hashgrid.hip); sorted: force the ordered forward
+
+
 def hashgrid_forward(spec: HashGridSpec, u: torch.Tensor, table: torch.Tensor, layout=_lib.LAYOUT_ROW_MAJOR, clustered=False):
-    """clustered: the caller's promise that every 256 consecutive points are spatially clustered (the PSF samples of a
-    slice pixel are contiguous): picks the one-workgroup-per-cloud kernel.  A performance hint only."""
+    """clustered=True: the caller's promise that every 256 consecutive points are spatially clustered (the PSF samples of a
+    slice pixel are contiguous, consecutive voxels of a lattice): the one-workgroup-per-256-points kernel on the points as
+    given.  clustered=False (the default: any tcnn-style caller, nesvor/nesvor/models.py:25; one point per voxel in arbitrary
+    order, sample.py:29): from ``UNCLUSTERED_FWD_MIN_POINTS`` points on, the points are first put into the order of a coarse
+    lattice's cells and the same kernel runs on workgroups of neighbouring points (``nesvor_hashgrid_forward_unclustered``,
+    round 6); smaller batches take one block per (256 points, level).  A performance hint only: the encoded values are the same."""
     _lib.require_device(u, table, dtype=torch.float32, name="hashgrid input/table")
     N = u.shape[0]
     E = spec.n_output_dims
     shape = (N, E) if layout == _lib.LAYOUT_ROW_MAJOR else (E, N)
     pe = torch.empty(shape, dtype=torch.float32, device=u.device)
+    lib = _lib.load()
+    ordered = (not clustered and N >= UNCLUSTERED_FWD_MIN_POINTS and _FWD_MODE == "") or (_FWD_MODE == "sorted" and N > 0)
     with torch.cuda.device(u.device), _lib.kernel_timer.span("hashgrid_fwd"):
-        err = _lib.load().nesvor_hashgrid_forward(
-            ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(pe), N,
-            layout | (_lib.LAYOUT_CLUSTERED if clustered else 0), _lib.stream_ptr()
-        )
+        if ordered:
+            lay = layout | _lib.LAYOUT_UNCLUSTERED
+            nbytes = lib.nesvor_hashgrid_forward_workspace_bytes(ctypes.byref(spec.c_struct), N, lay)
+            ws = _FWD_WS.get(u.device)
+            if ws is None or ws.numel() < nbytes:
+                ws = _FWD_WS[u.device] = torch.empty(nbytes, dtype=torch.uint8, device=u.device)
+            err = lib.nesvor_hashgrid_forward_unclustered(ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(pe), N, lay,
+                                                          None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        else:
+            err = lib.nesvor_hashgrid_forward(
+                ctypes.byref(spec.c_struct), _lib.ptr(u), _lib.ptr(table), _lib.ptr(pe), N,
+                layout | (_lib.LAYOUT_CLUSTERED if clustered else 0), _lib.stream_ptr()
+            )
     _lib.check(err, "hashgrid forward")
     return pe
 

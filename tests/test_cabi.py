@@ -131,10 +131,19 @@ def test_backward_workspace_size_queries_follow_the_layout_hints():
     assert base > 0
     ex = lambda layout: lib.nesvor_hashgrid_backward_workspace_bytes_ex(ctypes.byref(spec.c_struct), N, None, layout)
     U, S = _lib.LAYOUT_UNCLUSTERED, _lib.LAYOUT_DY_SCRATCH
-    assert ex(0) == ex(1) == ex(0 | U | S) == ex(1 | U) == ex(1 | S) == ex(1 | _lib.LAYOUT_CLUSTERED) == base
+    assert ex(0 | U | S) == ex(1 | U) == ex(0 | U) == base
     assert ex(1 | U | S) == base + 256 + n_pad * 32 * 4
-    # the order's scratch is part of every workspace: 4 N (perm) + counters + 4 N (spill) + 8 N (tickets) + strips, on top of the
-    # worst-case record queues (8 records of 12 B per point and level, with slack)
+    # the order's scratch - 4 N (perm) + counters + 4 N (spill) + 8 N (tickets) + strips (4096 cells x 512 slots at this N) - is
+    # part of the plain query (whose callers may pass any hint later) and of every query WITH the unclustered hint; a caller that
+    # names a layout without it - the training step - does not pay for it (round-5 advisor: 26 MB at N = 2^20)
+    sort_bytes = (n_pad * 2 + 2 * ((1 << 18) + 2)) * 4 + n_pad * 8 + 4096 * 512 * 4
+    sort_bytes = (sort_bytes + 255) // 256 * 256
+    assert ex(0) == ex(1) == ex(1 | S) == ex(1 | _lib.LAYOUT_CLUSTERED) == base - sort_bytes
+    # ... on top of the worst-case record queues (8 records of 12 B per point and level, with slack)
     assert base > 128 * 12 * N and base - 128 * 12 * N * 1.2 < 64 * N
+    # the unclustered FORWARD's scratch: the order, plus the encoded rows in that order for feature-major output
+    fw = lambda layout: lib.nesvor_hashgrid_forward_workspace_bytes(ctypes.byref(spec.c_struct), N, layout)
+    assert fw(0) == fw(1) == fw(1 | _lib.LAYOUT_CLUSTERED) == 0
+    assert fw(0 | U) == 256 + sort_bytes and fw(1 | U) == 256 + sort_bytes + n_pad * 32 * 4
     small = lib.nesvor_hashgrid_backward_workspace_bytes(ctypes.byref(spec.c_struct), 1000, None)
     assert 0 < small < base

@@ -141,3 +141,16 @@ def test_generated_assembly_of_the_mlp_kernels_is_clean():
         assert kernels, path
         found = [(k, f) for k, body in kernels.items() for f in chk.check(body) + chk.check_store_data(body) + chk.check_dpp(body) + chk.check_valu_sgpr(body)]
         assert found == [], (path, found[:5])
+
+
+def test_packed_fp32_broadcast_operand_reads_one_register():
+    """`v_pk_fma_f32 d, x, v[46:47], d op_sel_hi:[1,0,1]` multiplies both halves by v46 (op_sel and op_sel_hi of that source both
+    pick the low half): v47 does not reach the result, so a load in flight into v47 is no finding (round 6: the compiler forms
+    these for the per-sample scale of the MLP backward's bias sums) - while the same instruction without the broadcast, or with
+    the pending register in the half it does read, still is."""
+    head = "global_load_dword v47, v[2:3], off\n"
+    tail = "\ns_waitcnt vmcnt(0)"
+    assert _findings(head + "v_pk_fma_f32 v[36:37], v[28:29], v[46:47], v[36:37] op_sel_hi:[1,0,1]" + tail) == []
+    assert len(_findings(head + "v_pk_fma_f32 v[36:37], v[28:29], v[46:47], v[36:37]" + tail)) == 1
+    assert len(_findings(head + "v_pk_fma_f32 v[36:37], v[28:29], v[46:47], v[36:37] op_sel:[0,1,0] op_sel_hi:[1,1,1]" + tail)) == 1
+    assert len(_findings("global_load_dword v46, v[2:3], off\nv_pk_fma_f32 v[36:37], v[28:29], v[46:47], v[36:37] op_sel_hi:[1,0,1]" + tail)) == 1

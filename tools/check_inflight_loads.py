@@ -69,6 +69,35 @@ def sregs(tok):
     return range(int(m.group(2)), int(m.group(3)) + 1)
 
 
+PK32 = re.compile(r"^v_pk_(fma|mul|add)_f32$|^v_pk_mov_b32$")
+OPSEL = re.compile(r"\bop_sel:\[([01,]+)\]")
+OPSELHI = re.compile(r"\bop_sel_hi:\[([01,]+)\]")
+
+
+def pk32_regs(toks, ops):
+    """Registers a packed-fp32 instruction actually reads / writes: a source pair v[a:a+1] whose op_sel and op_sel_hi bits both
+    pick the LOW (or both the HIGH) half is a broadcast of ONE register - the compiler uses it for a scalar-in-VGPR multiplier
+    (`v_pk_fma_f32 d, x, v[46:47], d op_sel_hi:[1,0,1]` reads v46 twice and never v47, which may then hold anything, a load
+    in flight included: the half that is not selected does not reach the result)."""
+    m, mh = OPSEL.search(ops), OPSELHI.search(ops)
+    n_src = len([t for t in toks[1:] if not t.startswith(("op_sel", "neg_", "clamp"))])
+    sel = [int(x) for x in m.group(1).split(",")] if m else [0] * n_src
+    sel_hi = [int(x) for x in mh.group(1).split(",")] if mh else [1] * n_src
+    out = regs_of(toks[0])
+    k = 0
+    for t in toks[1:]:
+        t = t.split(" op_sel")[0].strip()
+        if t.startswith(("op_sel", "neg_", "clamp")):
+            continue
+        rs = sorted(regs_of(t))
+        if len(rs) == 2 and k < len(sel) and k < len(sel_hi) and sel[k] == sel_hi[k]:
+            out.add(rs[sel[k]])
+        else:
+            out.update(rs)
+        k += 1
+    return out
+
+
 class State:
     """pending: {vgpr: vector-memory operations issued after the pending load that writes it} (the MINIMUM over the paths
     merged into this state: the fewer younger operations, the later a `vmcnt(n)` retires the load).
@@ -124,6 +153,8 @@ def transfer(ins, st, report, where):
         return
     # ---- vector side: the pending loads
     used = regs_of(ops)
+    if PK32.match(mnem):
+        used = pk32_regs(toks, ops)
     if VMEM.match(mnem):
         dst = set()
         if LOAD.match(mnem) and "lds" not in mnem:
