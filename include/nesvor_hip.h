@@ -314,11 +314,11 @@ typedef struct {
                                  --width / --depth (nesvor/cli/main.py:68-73, build_network models.py:42-67): widths below 64
                                  run zero-padded on these kernels (exactly the same function; nesvor_amd/mlp.py::kernel_params),
                                  depth up to NESVOR_MAX_MLP_LAYERS - 1 hidden layers is native, and anything wider or deeper is
-                                 REFUSED here (hipErrorInvalidValue) - the host side (nesvor_amd/mlp.py::library_mlp) then keeps
-                                 sampler, hash grid and loss on the HIP kernels and evaluates those matrix products with
-                                 rocBLAS under autograd (tests/test_gpu_parity.py::test_other_widths_and_depths_match_oracle_losses:
-                                 128 x 1, 64 x 4, 96 x 5 against the oracle) - a stated fallback off BASELINE's configuration,
-                                 not a hand-written path */
+                                 REFUSED here (hipErrorInvalidValue) and taken by nesvor_mlp_wide_t below (round 6: width <= 128,
+                                 up to seven hidden layers, hand-written fp32-MFMA kernels; rounds 3-5 evaluated those shapes
+                                 with rocBLAS under autograd).  tests/test_gpu_parity.py::test_other_widths_and_depths_match_oracle_losses
+                                 holds 128 x 1, 64 x 4 and 96 x 5 to the oracle.  Only beyond THOSE limits does the host side
+                                 (nesvor_amd/mlp.py::library_mlp) fall back to library GEMMs */
   int32_t n_hidden;           /* hidden layers, 1..NESVOR_MAX_MLP_LAYERS-1 */
   int32_t out_dim;            /* 1..16 */
   int32_t k_a, k_b, b_row0;
@@ -408,6 +408,41 @@ int nesvor_mlp_backward(const nesvor_mlp_t* net, const float* xa, const float* x
 int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float* xa, const float* xb, const float* dy,
                                 float* const* saved_hidden, float* const* dpre_scratch, float* dxa, float* dxb,
                                 float* dw_partial, int n_partial, int64_t N, float* dxb_absmax, void* stream);
+
+/* ------------------------------------------------------------------------
+ * The same networks at ANY width up to 128 and up to NESVOR_MLP_WIDE_MAX_LAYERS - 1 hidden layers (round 6; csrc/mlp_wide.hip):
+ * the reference builds its MLPs with any --width / --depth (nesvor/cli/main.py:68-73 -> build_network,
+ * nesvor/nesvor/models.py:42-67; bias-free tinycudann.Network in half precision, models.py:28-41), and shapes outside
+ * nesvor_mlp_t's (width 64, at most three hidden layers) used to leave the hand-written path for library GEMMs.  fp32 matrix
+ * cores (v_mfma_f32_16x16x4_f32: an fp32 FMA chain), activations in registers from input to output, ONE layer's weights in LDS
+ * at a time (a 128 x 128 layer is 64 KB: the workgroup swaps the operand image between layers of a 256-sample tile).  Widths
+ * that are not multiples of 16 run zero-padded (exactly the same function).  Input composition, layouts and the meaning of
+ * xa / xb / b_row0 / k_a / k_b / samples_per_pixel as for nesvor_mlp_t; k_a + k_b <= 64, out_dim <= 16.
+ *   forward : y (out_dim, N); saved_hidden = n_hidden device buffers of nesvor_mlp_wide_saved_floats(net, N) floats each (the
+ *             post-ReLU activations in MFMA fragment layout) or NULL (inference);
+ *   backward: dy (out_dim, N) -> dxa (N, k_a) per SAMPLE (or NULL), dxb (k_b, N) (or NULL), dw_partial (n_partial,
+ *             nesvor_mlp_wide_param_count(net)): per-workgroup partial sums in nn.Linear parameter order W0, b0, W1, b1, ...
+ *             (no b columns for a NULL bias), to be summed over the rows by the caller; dpre_scratch = n_hidden buffers of the
+ *             saved buffers' size.  Two launches (dX chain, then dW / db), no atomics.
+ * Errors: hipErrorInvalidValue for shapes outside the limits or missing buffers. */
+#define NESVOR_MLP_WIDE_MAX_LAYERS 8
+typedef struct {
+  int32_t width;              /* hidden width, 1..128 */
+  int32_t n_hidden;           /* 1..NESVOR_MLP_WIDE_MAX_LAYERS-1 */
+  int32_t out_dim;            /* 1..16 */
+  int32_t k_a, k_b, b_row0;
+  int32_t samples_per_pixel;
+  int32_t reserved;
+  const float* weight[NESVOR_MLP_WIDE_MAX_LAYERS];  /* nn.Linear layout (out, in), fp32 */
+  const float* bias[NESVOR_MLP_WIDE_MAX_LAYERS];    /* (out) or NULL: bias-free layer */
+} nesvor_mlp_wide_t;
+int64_t nesvor_mlp_wide_saved_floats(const nesvor_mlp_wide_t* net, int64_t N);
+int nesvor_mlp_wide_param_count(const nesvor_mlp_wide_t* net);
+int nesvor_mlp_wide_forward(const nesvor_mlp_wide_t* net, const float* xa, const float* xb, float* y, float* const* saved_hidden,
+                            int64_t N, void* stream);
+int nesvor_mlp_wide_backward(const nesvor_mlp_wide_t* net, const float* xa, const float* xb, const float* dy,
+                             float* const* saved_hidden, float* const* dpre_scratch, float* dxa, float* dxb, float* dw_partial,
+                             int n_partial, int64_t N, void* stream);
 
 /* ------------------------------------------------------------------------
  * Imaging model + losses, value and gradient in one launch.  Replaces the tail of

@@ -50,6 +50,16 @@ class MlpT(Structure):
     ]
 
 
+class MlpWideT(Structure):
+    """Mirror of nesvor_mlp_wide_t (width <= 128, up to seven hidden layers: csrc/mlp_wide.hip)."""
+
+    _fields_ = [
+        ("width", c_int32), ("n_hidden", c_int32), ("out_dim", c_int32),
+        ("k_a", c_int32), ("k_b", c_int32), ("b_row0", c_int32), ("samples_per_pixel", c_int32), ("reserved", c_int32),
+        ("weight", c_void_p * 8), ("bias", c_void_p * 8),
+    ]
+
+
 class LossT(Structure):
     """Mirror of nesvor_loss_t."""
 
@@ -152,6 +162,13 @@ _SIGNATURES = {
     ),
     "nesvor_mlp_backward_bounded": (
         [POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), POINTER(c_void_p), _P, _P, _P, c_int, c_int64, _P, _P],
+        c_int,
+    ),
+    "nesvor_mlp_wide_saved_floats": ([POINTER(MlpWideT), c_int64], c_int64),
+    "nesvor_mlp_wide_param_count": ([POINTER(MlpWideT)], c_int),
+    "nesvor_mlp_wide_forward": ([POINTER(MlpWideT), _P, _P, _P, POINTER(c_void_p), c_int64, _P], c_int),
+    "nesvor_mlp_wide_backward": (
+        [POINTER(MlpWideT), _P, _P, _P, POINTER(c_void_p), POINTER(c_void_p), _P, _P, _P, c_int, c_int64, _P],
         c_int,
     ),
     "nesvor_imaging_loss": ([POINTER(LossT), _P], c_int),

@@ -175,6 +175,39 @@ __device__ __forceinline__ void load_feat(const float* __restrict__ p, float (&v
   }
 }
 
+// The two corners of a lattice cell that differ in x only, (x, y, z) and (x + 1, y, z), as ONE request where their table
+// entries are neighbours (round 6).  Every gather is one L2 transaction, and on input that shares nothing between the lanes of a
+// wave - uniform points: 134 M gathers per 2^20 points - the forward runs at the L2s' transaction rate (~0.3 T/s chip-wide:
+// 0.40 ms).  On a dense level the pair is adjacent by construction (idx, idx + 1); on a hashed level x ^ (y P1) ^ (z P2) maps an
+// even x and x + 1 to entries that differ in bit 0.  F <= 2 (a pair is at most 16 bytes): one load of the pair at the lower
+// index - only 4 F-byte aligned, which global loads take - plus, for the lanes whose pair is NOT adjacent (odd x on a hashed
+// level, the wrap at the u = 1 face), the aligned pair around i0 and a second request for i1.  Transactions per point and
+// level: 4-4.5 (dense) / 6 (hashed) instead of 8.  The values are the same table entries: results do not change.
+template <int F>
+__device__ __forceinline__ void load_feat_pair(const float* __restrict__ tab, uint32_t i0, uint32_t i1, float (&v0)[F], float (&v1)[F]) {
+  if constexpr (F <= 2) {
+    const bool adj = (i1 == i0 + 1u) || (i0 == i1 + 1u);
+    const uint32_t p = adj ? min(i0, i1) : (i0 & ~1u);   // (level sizes are multiples of 8: the aligned pair around i0 exists)
+    float t[2 * F];
+    if constexpr (F == 1) {
+      struct __attribute__((packed, aligned(4))) P2 { float a, b; };
+      const P2 w = *reinterpret_cast<const P2*>(tab + (size_t)p);
+      t[0] = w.a; t[1] = w.b;
+    } else {
+      struct __attribute__((packed, aligned(8))) P4 { float a, b, c, d; };
+      const P4 w = *reinterpret_cast<const P4*>(tab + (size_t)p * 2);
+      t[0] = w.a; t[1] = w.b; t[2] = w.c; t[3] = w.d;
+    }
+    const bool second0 = i0 != p;
+#pragma unroll
+    for (int f = 0; f < F; ++f) { v0[f] = second0 ? t[F + f] : t[f]; v1[f] = second0 ? t[f] : t[F + f]; }
+    if (!adj) load_feat<F>(tab + (size_t)i1 * F, v1);
+  } else {
+    load_feat<F>(tab + (size_t)i0 * F, v0);
+    load_feat<F>(tab + (size_t)i1 * F, v1);
+  }
+}
+
 // ------------------------------------------------------------------ forward
 // A workgroup = 256 consecutive samples = (for S = 256) one PSF cloud.  Where the lattice box spanned by its cells at
 // this level has at most kFwdSlots vertices (the coarse and middle levels), the box is copied into LDS once - every
@@ -244,9 +277,10 @@ __global__ __launch_bounds__(256) void hashgrid_fwd(const nesvor_grid_t g, const
   }
   if (!cached) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const uint32_t idx = corner_index(p, c.gx + (k & 1), c.gy + ((k >> 1) & 1), c.gz + (k >> 2));
-      load_feat<F>(tab + (size_t)idx * F, v[k]);
+    for (int k = 0; k < 8; k += 2) {  // x-pairs: one request where the two entries are neighbours (load_feat_pair)
+      const uint32_t i0 = corner_index(p, c.gx, c.gy + ((k >> 1) & 1), c.gz + (k >> 2));
+      const uint32_t i1 = corner_index(p, c.gx + 1u, c.gy + ((k >> 1) & 1), c.gz + (k >> 2));
+      load_feat_pair<F>(tab, i0, i1, v[k], v[k + 1]);
     }
   }
   float acc[F];
@@ -502,6 +536,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
     const float* tab1 = table + (size_t)p1.offset * F;
     float v0[8][F], v1[8][F], acc[F];
     {
+    // (single requests here: the lanes of a cloud share cache lines, the memory pipeline merges them; the paired form of the
+    //  per-level kernel measured SLOWER in this kernel - raster lattice 0.062 -> 0.079 ms, gpurun_out/r06d)
 #pragma unroll
     for (int k = 0; k < 8; ++k) load_feat<F>(tab0 + (size_t)corner_index(p0, c0.gx + (k & 1), c0.gy + ((k >> 1) & 1), c0.gz + (k >> 2)) * F, v0[k]);
     if (two) {

@@ -10,24 +10,31 @@ from .grid import HashGridSpec
 
 
 _FWD_WS = {}
-UNCLUSTERED_FWD_MIN_POINTS = 1 << 15  # below this the four launches of the ordered forward cost more than they save
+UNCLUSTERED_FWD_MIN_POINTS = 1 << 15  # below this the launches of the ordered forward cost more than they save
 _FWD_MODE = __import__("os").environ.get("NESVOR_HASHGRID_FWD", "")  # cloud | level | gather: force one kernel (csrc/hashgrid.hip); sorted: force the ordered forward
 
 
 def hashgrid_forward(spec: HashGridSpec, u: torch.Tensor, table: torch.Tensor, layout=_lib.LAYOUT_ROW_MAJOR, clustered=False):
     """clustered=True: the caller's promise that every 256 consecutive points are spatially clustered (the PSF samples of a
-    slice pixel are contiguous, consecutive voxels of a lattice): the one-workgroup-per-256-points kernel on the points as
-    given.  clustered=False (the default: any tcnn-style caller, nesvor/nesvor/models.py:25; one point per voxel in arbitrary
-    order, sample.py:29): from ``UNCLUSTERED_FWD_MIN_POINTS`` points on, the points are first put into the order of a coarse
-    lattice's cells and the same kernel runs on workgroups of neighbouring points (``nesvor_hashgrid_forward_unclustered``,
-    round 6); smaller batches take one block per (256 points, level).  A performance hint only: the encoded values are the same."""
+    slice pixel are contiguous; consecutive voxels of a raster-ordered lattice): the one-workgroup-per-256-points kernel on the
+    points as given.  clustered=False (the default: any tcnn-style caller, nesvor/nesvor/models.py:25; points in arbitrary
+    order, sample.py:29) - what was measured at N = 2^20 uniform points (tools/bench_hg_fwd_unclustered.py,
+    profiles/r06_hashgrid_fwd_unclustered.log) decides:
+      * feature-major output: one block per (256 points, level) on the points as given - every level's table slice in turn is
+        what the L2s hold, and the x-pairs of corners are fetched with one request where their entries are neighbours;
+      * row-major output (tinycudann's layout) from ``UNCLUSTERED_FWD_MIN_POINTS`` points on: the points are first put into the
+        order of a coarse lattice's cells and the per-cloud kernel runs on workgroups of neighbouring points, every thread
+        writing its point's whole row (``nesvor_hashgrid_forward_unclustered``; 0.36 against 0.49 ms - the per-level kernel
+        writes 8 bytes per (point, level) into rows of 128).
+    A performance hint only: the encoded values are the same."""
     _lib.require_device(u, table, dtype=torch.float32, name="hashgrid input/table")
     N = u.shape[0]
     E = spec.n_output_dims
     shape = (N, E) if layout == _lib.LAYOUT_ROW_MAJOR else (E, N)
     pe = torch.empty(shape, dtype=torch.float32, device=u.device)
     lib = _lib.load()
-    ordered = (not clustered and N >= UNCLUSTERED_FWD_MIN_POINTS and _FWD_MODE == "") or (_FWD_MODE == "sorted" and N > 0)
+    ordered = ((not clustered and layout == _lib.LAYOUT_ROW_MAJOR and N >= UNCLUSTERED_FWD_MIN_POINTS and _FWD_MODE == "")
+               or (_FWD_MODE == "sorted" and N > 0))
     with torch.cuda.device(u.device), _lib.kernel_timer.span("hashgrid_fwd"):
         if ordered:
             lay = layout | _lib.LAYOUT_UNCLUSTERED
@@ -44,6 +51,18 @@ def hashgrid_forward(spec: HashGridSpec, u: torch.Tensor, table: torch.Tensor, l
             )
     _lib.check(err, "hashgrid forward")
     return pe
+
+
+def points_are_ordered(u: torch.Tensor, box_fraction: float = 1.0 / 16) -> bool:
+    """Whether consecutive points of ``u`` (N, 3, normalised to the unit cube) are spatial neighbours - a raster-ordered lattice
+    (``sample_volume``'s voxel list), PSF clouds - so that 256 of them span a small lattice box: the median step between
+    neighbours of a 4096-point prefix is below ``box_fraction`` of the cube.  One small reduction and one host read per CALL of an
+    inference entry point (not per chunk): picks the forward kernel, never the result."""
+    n = min(int(u.shape[0]), 4096)
+    if n < 2:
+        return False
+    step = (u[1:n] - u[: n - 1]).abs().amax(-1)
+    return bool(step.median() < box_fraction)
 
 
 _WORKSPACES = {}

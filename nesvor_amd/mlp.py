@@ -314,6 +314,108 @@ def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_d
     return dxa, partial
 
 
+# ------------------------------------------------------------------------------------------------ wider / deeper networks
+WIDE_MAX_WIDTH, WIDE_MAX_HIDDEN = 128, 7  # nesvor_mlp_wide_t (csrc/mlp_wide.hip)
+N_PARTIAL_WIDE = 1024
+
+
+def wide_supported(seq) -> bool:
+    """Linear/ReLU stacks (with or without biases) outside the 64-wide fused kernels but inside the hand-written wide kernels
+    (round 6): one hidden width <= 128, 1-7 hidden layers, <= 64 inputs, <= 16 outputs; and the bias-free ``tinycudann.Network``
+    of such shapes."""
+    from .tinycudann import Network
+
+    if isinstance(seq, Network):
+        sh = seq.shapes
+        return (seq.activation == "ReLU" and seq.output_activation == "None" and 2 <= len(sh) <= WIDE_MAX_HIDDEN + 1 and sh[0][1] <= 64
+                and len({o for o, _ in sh[:-1]}) == 1 and sh[0][0] <= WIDE_MAX_WIDTH and seq.n_output_dims <= 16)
+    if not isinstance(seq, nn.Sequential):
+        return False
+    try:
+        layers = linear_layers(seq)
+    except ValueError:
+        return False
+    if not 2 <= len(layers) <= WIDE_MAX_HIDDEN + 1:
+        return False
+    widths = {l.out_features for l in layers[:-1]}
+    if len(widths) != 1 or not 1 <= next(iter(widths)) <= WIDE_MAX_WIDTH or any(a.out_features != b.in_features for a, b in zip(layers, layers[1:])):
+        return False
+    has_bias = {l.bias is not None for l in layers}
+    return layers[-1].out_features <= 16 and layers[0].in_features <= 64 and len(has_bias) == 1
+
+
+def _wide_desc(weights, biases, k_a, k_b, b_row0, S):
+    d = _lib.MlpWideT()
+    d.width, d.n_hidden, d.out_dim = weights[0].shape[0], len(weights) - 1, weights[-1].shape[0]
+    d.k_a, d.k_b, d.b_row0, d.samples_per_pixel = k_a, k_b, b_row0, S
+    for i, w in enumerate(weights):
+        d.weight[i] = w.data_ptr()
+        d.bias[i] = biases[i].data_ptr() if biases else None
+    return d
+
+
+def _ptr_array8(tensors):
+    arr = (ctypes.c_void_p * 8)()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def wide_forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved):
+    """One forward launch of the wide kernels, no autograd: -> (y (out_dim, N), saved hidden activations).  ``biases``: one per
+    layer, or an empty list (bias-free network)."""
+    _lib.require_device(xb, *weights, *biases, dtype=torch.float32, name="wide MLP input/params")
+    N = xb.shape[1]
+    k_a = 0 if xa is None else xa.shape[1]
+    if xa is not None:
+        _lib.require_device(xa, dtype=torch.float32, name="wide MLP pixel features")
+        if xa.shape[0] * S != N:
+            raise RuntimeError("pixel features: P * samples_per_pixel must equal N")
+    if weights[0].shape[1] != k_a + k_b:
+        raise RuntimeError("first layer width does not match k_a + k_b")
+    d = _wide_desc(weights, biases, k_a, k_b, b_row0, S)
+    lib = _lib.load()
+    saved = []
+    if need_saved:
+        n_el = lib.nesvor_mlp_wide_saved_floats(ctypes.byref(d), N)
+        saved = [torch.empty(n_el, dtype=torch.float32, device=xb.device) for _ in range(d.n_hidden)]
+    y = torch.empty((d.out_dim, N), dtype=torch.float32, device=xb.device)
+    with torch.cuda.device(xb.device), _lib.kernel_timer.span("mlp_fwd"):
+        err = lib.nesvor_mlp_wide_forward(ctypes.byref(d), _lib.ptr(xa), _lib.ptr(xb), _lib.ptr(y), _ptr_array8(saved) if need_saved else None,
+                                          N, _lib.stream_ptr())
+    _lib.check(err, "wide mlp forward")
+    return y, saved
+
+
+def wide_backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_dxa):
+    """-> (dxa (N, k_a) per sample | None, partial (N_PARTIAL_WIDE, n_params): sum over dim 0 = W0, b0, W1, b1, ... gradients)."""
+    N = xb.shape[1]
+    k_a = 0 if xa is None else xa.shape[1]
+    d = _wide_desc(weights, biases, k_a, k_b, b_row0, S)
+    lib = _lib.load()
+    dpre = [torch.empty_like(s) for s in saved]
+    dxa = torch.empty((N, k_a), dtype=torch.float32, device=xb.device) if (xa is not None and need_dxa) else None
+    total = lib.nesvor_mlp_wide_param_count(ctypes.byref(d))
+    partial = torch.empty((N_PARTIAL_WIDE, total), dtype=torch.float32, device=xb.device)
+    with torch.cuda.device(xb.device), _lib.kernel_timer.span("mlp_bwd"):
+        err = lib.nesvor_mlp_wide_backward(ctypes.byref(d), _lib.ptr(xa), _lib.ptr(xb), _lib.ptr(dy), _ptr_array8(saved), _ptr_array8(dpre),
+                                           _lib.ptr(dxa), _lib.ptr(dxb), _lib.ptr(partial), N_PARTIAL_WIDE, N, _lib.stream_ptr())
+    _lib.check(err, "wide mlp backward")
+    return dxa, partial
+
+
+def wide_mlp(seq: nn.Sequential, xa, xb, b_row0: int, k_b: int, samples_per_pixel: int):
+    """``seq`` (a shape ``wide_supported`` accepts) on [xa broadcast | xb rows] -> (out_dim, N) feature-major, differentiable in
+    xa, xb and the parameters: the dispatcher op ``torch.ops.nesvor.wide_mlp``."""
+    layers = linear_layers(seq)
+    need = torch.is_grad_enabled() and (xb.requires_grad or (xa is not None and xa.requires_grad) or any(
+        p.requires_grad for l in layers for p in l.parameters()))
+    weights = [l.weight for l in layers]
+    biases = [l.bias for l in layers] if layers[0].bias is not None else []
+    y, _ = torch.ops.nesvor.wide_mlp(xa, xb.contiguous(), weights, biases, b_row0, k_b, samples_per_pixel, need)
+    return y
+
+
 def fused_mlp(seq: nn.Sequential, xa, xb, b_row0: int, k_b: int, samples_per_pixel: int):
     """Evaluate `seq` on [xa broadcast | xb rows] -> (out_dim, N) feature-major; differentiable in xa, xb and the
     parameters: the dispatcher op ``torch.ops.nesvor.fused_mlp`` (``nesvor_amd.ops``)."""
@@ -359,8 +461,9 @@ def apply_net(net, xa, xb, b_row0: int, k_b: int, samples_per_pixel: int):
     feature-major xb] -> (out_dim, N) feature-major, differentiable.  Picks the evaluation:
 
     * Linear/ReLU stacks inside the fused kernels' shapes: ``fused_mlp`` (the dispatcher op);
-    * other ``nn.Sequential`` stacks (``--width`` > 64, ``--depth`` > 3, ...: the reference accepts any,
-      cli/main.py:68-73): ``library_mlp`` - correct, but several times slower, and the autograd-free step does not apply;
+    * Linear/ReLU stacks up to width 128 / seven hidden layers (``--width`` > 64, ``--depth`` > 3: the reference accepts any,
+      cli/main.py:68-73): ``wide_mlp`` - hand-written fp32-MFMA kernels with one layer's weights in LDS at a time (round 6);
+    * anything beyond (other activations, width > 128): ``library_mlp`` - correct, but on library GEMMs;
     * the half-precision structure (``tinycudann.Network``): its row-major module interface."""
     from .tinycudann import Network
 
@@ -371,13 +474,15 @@ def apply_net(net, xa, xb, b_row0: int, k_b: int, samples_per_pixel: int):
         return net(x).t()
     if supported(net):
         return fused_mlp(net, xa, xb, b_row0, k_b, samples_per_pixel)
+    if wide_supported(net):  # width <= 128, up to seven hidden layers: the hand-written wide kernels (csrc/mlp_wide.hip)
+        return wide_mlp(net, xa, xb, b_row0, k_b, samples_per_pixel)
     key = tuple((type(m).__name__, getattr(m, "in_features", 0), getattr(m, "out_features", 0)) for m in net)
     if key not in _warned_library:
         _warned_library.add(key)
         import logging
 
-        logging.warning("MLP %s is outside the fused HIP kernels (ReLU, width <= 64, 1-3 hidden layers, <= 64 inputs, <= 16 "
-                        "outputs): its products run on library GEMMs - expect a several times slower iteration",
+        logging.warning("MLP %s is outside the hand-written HIP kernels (ReLU; width <= 128, 1-7 hidden layers of one width, <= 64 "
+                        "inputs, <= 16 outputs): its products run on library GEMMs - expect a several times slower iteration",
                         [k[1:] for k in key if k[0] == "Linear"])
     return library_mlp(net, xa, xb, b_row0, k_b, samples_per_pixel)
 

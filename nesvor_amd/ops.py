@@ -414,6 +414,69 @@ _op("fused_mlp(Tensor? xa, Tensor xb, Tensor[] weights, Tensor[] biases, int b_r
     "bool save) -> (Tensor, Tensor[])", _mlp_forward, fake=_mlp_fake, backward=_mlp_backward_formula, setup_context=_mlp_setup)
 
 
+# ---- the same networks at width <= 128 / up to seven hidden layers (csrc/mlp_wide.hip); `biases` empty = bias-free
+def _wide_forward(xa, xb, weights, biases, b_row0, k_b, samples_per_pixel, save):
+    return _mlp.wide_forward_raw(list(weights), list(biases), xa, xb, b_row0, k_b, samples_per_pixel, save)
+
+
+def _wide_backward(xa, xb, dy, weights, biases, saved, b_row0, k_b, samples_per_pixel, need_dxa, need_dxb):
+    dxb = torch.empty((k_b, xb.shape[1]), dtype=torch.float32, device=xb.device) if need_dxb else None
+    dxa, partial = _mlp.wide_backward_raw(list(weights), list(biases), xa, xb, dy, list(saved), b_row0, k_b, samples_per_pixel, dxb, need_dxa)
+    return (dxa if dxa is not None else _empty(xb), dxb if dxb is not None else _empty(xb), partial)
+
+
+def _wide_setup(ctx, inputs, output):
+    xa, xb, weights, biases, b_row0, k_b, S, save = inputs
+    ctx.n_layers, ctx.n_bias = len(weights), len(biases)
+    ctx.has_xa = xa is not None
+    ctx.save_for_backward(*([xa] if xa is not None else []), xb, *weights, *biases, *output[1])
+    ctx.cfg = (b_row0, k_b, S)
+    ctx.set_materialize_grads(False)
+
+
+def _wide_backward_formula(ctx, dy, d_saved):
+    if dy is None:
+        return (None,) * 8
+    t = list(ctx.saved_tensors)
+    xa = t.pop(0) if ctx.has_xa else None
+    xb = t.pop(0)
+    n, nb = ctx.n_layers, ctx.n_bias
+    weights, biases, saved = t[:n], t[n : n + nb], t[n + nb :]
+    if len(saved) != n - 1:
+        raise RuntimeError("wide_mlp was called with save=False but a gradient is requested: pass save=True")
+    b_row0, k_b, S = ctx.cfg
+    need_xa, need_xb = ctx.has_xa and ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    dxa, dxb, partial = torch.ops.nesvor.wide_mlp_backward(xa, xb, dy.contiguous(), weights, biases, saved, b_row0, k_b, S, need_xa, need_xb)
+    g_xb = None
+    if need_xb:
+        g_xb = torch.zeros_like(xb)
+        g_xb[b_row0 : b_row0 + k_b] = dxb
+    g_xa = dxa.view(xa.shape[0], -1, dxa.shape[1]).sum(1) if need_xa else None
+    flat = partial.sum(0)
+    gw, gb, off = [], [], 0
+    for i, w in enumerate(weights):
+        gw.append(flat[off : off + w.numel()].view_as(w))
+        off += w.numel()
+        if nb:
+            gb.append(flat[off : off + biases[i].numel()].view_as(biases[i]))
+            off += biases[i].numel()
+    return g_xa, g_xb, gw, gb, None, None, None, None
+
+
+def _wide_fake(xa, xb, weights, biases, b_row0, k_b, S, save):
+    n = xb.shape[1]
+    n_pad = (n + 15) // 16 * 16
+    hb = 4 if weights[0].shape[0] <= 64 else 8
+    saved = [xb.new_empty(n_pad * 16 * hb) for _ in range(len(weights) - 1)] if save else []
+    return xb.new_empty((weights[-1].shape[0], n)), saved
+
+
+_op("wide_mlp_backward(Tensor? xa, Tensor xb, Tensor dy, Tensor[] weights, Tensor[] biases, Tensor[] saved, int b_row0, int k_b, "
+    "int samples_per_pixel, bool need_dxa, bool need_dxb) -> (Tensor, Tensor, Tensor)", _wide_backward)
+_op("wide_mlp(Tensor? xa, Tensor xb, Tensor[] weights, Tensor[] biases, int b_row0, int k_b, int samples_per_pixel, bool save) -> "
+    "(Tensor, Tensor[])", _wide_forward, fake=_wide_fake, backward=_wide_backward_formula, setup_context=_wide_setup)
+
+
 # =====================================================================================================================
 # PSF sampling + rigid transform + box normalisation (models.py:267-278, transform.py:259-280, models.py:143)
 # =====================================================================================================================

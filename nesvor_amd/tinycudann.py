@@ -113,8 +113,18 @@ class Network(nn.Module):
 
         if mlp_mod.supported(self):
             return mlp_mod.flat_network(self, x)
-        # shapes outside the fused kernels (tinycudann takes any n_neurons / n_hidden_layers its CutlassMLP supports): library
-        # GEMMs on the same flat parameters, fp32
+        if mlp_mod.wide_supported(self):
+            # wider / deeper than the fused kernels take (tinycudann accepts any n_neurons / n_hidden_layers its CutlassMLP
+            # supports): the hand-written wide kernels (csrc/mlp_wide.hip) on per-layer views of the flat parameters, bias-free
+            ws, off = [], 0
+            for o, i in self.shapes:
+                ws.append(self.params[off : off + o * i].view(o, i))
+                off += o * i
+            need = torch.is_grad_enabled() and (x.requires_grad or self.params.requires_grad)
+            y, _ = torch.ops.nesvor.wide_mlp(None, x.to(torch.float32).t().contiguous(), ws, [], 0, x.shape[1], 1, need)
+            return y[: self.n_output_dims].t()
+        # shapes outside both kernel families (other activations, more than 128 neurons): library GEMMs on the same flat
+        # parameters, fp32
         if not Network._warned:
             Network._warned = True
             import logging

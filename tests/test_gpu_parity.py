@@ -213,9 +213,9 @@ def test_shared_noise_training_matches_oracle_within_0p1_db(device):
 def test_other_widths_and_depths_match_oracle_losses(device, width, depth):
     """``--width`` / ``--depth`` are free in the reference (cli/main.py:68-73).  Widths below 64 run zero-padded on the
     64-wide kernels (nesvor_amd.mlp.kernel_params: the same function, evaluated exactly), three hidden layers run on the
-    separate dX / dW kernels; wider / deeper networks (128 x 1, 64 x 4, 96 x 5) keep sampler, hash grid and loss on the HIP
-    kernels and evaluate their matrix products on library GEMMs (nesvor_amd.mlp.library_mlp).  All train through the
-    autograd path.  Held to the oracle's restatement of the reference loop from the same random stream: every loss of the
+    separate dX / dW kernels; wider / deeper networks (128 x 1, 64 x 4, 96 x 5) run on the hand-written wide kernels
+    (csrc/mlp_wide.hip, round 6; rounds 3-5: library GEMMs) - no network of this test may reach ``library_mlp``.  All train
+    through the autograd path.  Held to the oracle's restatement of the reference loop from the same random stream: every loss of the
     first 10 iterations to rtol 1e-4."""
     from nesvor_amd.phantom import phantom3d, simulate_stacks
     from nesvor_amd.train import Dataset, train
@@ -231,6 +231,10 @@ def test_other_widths_and_depths_match_oracle_losses(device, width, depth):
     torch.manual_seed(0)
     inr, _, _ = train(slices, args, on_iteration=lambda i, losses: hist.append(torch.stack([losses[k].detach() for k in losses])))
     assert [l.out_features for l in inr.density_net if hasattr(l, "out_features")][:-1] == [width] * depth
+    from nesvor_amd import mlp as mlp_mod
+
+    assert mlp_mod.supported(inr.density_net) or mlp_mod.wide_supported(inr.density_net)
+    assert not mlp_mod._warned_library, mlp_mod._warned_library  # the library-GEMM fallback stayed unreachable
     torch.manual_seed(0)
     _, _, _, info = otl.train(cds, small_args(**{**vars(args), "device": torch.device("cpu")}))
     keys = list(info["history"][0].keys())
