@@ -76,6 +76,7 @@ struct MlpArgs {
   int fast;                     // N % 16 == 0, S % 16 == 0, k_a % 16 == 0: group = one pixel, input blocks homogeneous
   int spg_shift;                // log2(S / 16) when that is a power of two, else -1
   int dxa_group;                // dxa holds one row per 16-sample GROUP (sum over its samples) instead of one per sample
+  int half16;                   // with bf16 == 1: the 16-bit operand type is fp16, not bf16 (nesvor_mlp_t.bf16_operands == 3)
   int bf16;                     // 1: matrix operands rounded to bf16 (fp32 accumulation); 2: every operand split into two fp16 of a power-of-two-scaled copy (split mode, see below)
   int off32;                    // every row of xb / y starts below 2^32 bytes: lane offsets fit the 32-bit VGPR offset of scalar-base loads
   uint32_t* Hm;                 // compact save (nesvor_mlp_t.compact_save): one word per (group, lane), bit 16 l + 4 b + r = [h_l > 0]
@@ -127,6 +128,36 @@ __device__ __forceinline__ s16x4 pack_bf16(const f32x4& v) {
 }
 __device__ __forceinline__ f32x4 mfma16_bf16(s16x4 a, s16x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+// The 16-bit operand modes share every kernel: HT = 1 rounds the matrix operands to bf16 (nesvor_mlp_t.bf16_operands == 1),
+// HT = 2 to fp16 (mode 3, round 6: the reference's default arithmetic - fp16 CutlassMLP, nesvor/nesvor/models.py:28-41 - whose
+// narrow exponent range is what its GradScaler exists for, train.py:161-164).  Same lane maps, same instruction shapes, fp32
+// accumulation; an operand beyond 65504 becomes inf in fp16 and poisons the step - which the loss scaler then skips.
+typedef _Float16 h16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+template <int HT>
+__device__ __forceinline__ s16x4 pack16(const f32x4& v) {
+  if constexpr (HT == 2) {
+    const h16x2_t a = __builtin_convertvector(f32x2{v[0], v[1]}, h16x2_t), b = __builtin_convertvector(f32x2{v[2], v[3]}, h16x2_t);
+    return __builtin_bit_cast(s16x4, __builtin_shufflevector(a, b, 0, 1, 2, 3));
+  } else {
+    return pack_bf16(v);
+  }
+}
+template <int HT>
+__device__ __forceinline__ f32x4 mfma16h(s16x4 a, s16x4 b, f32x4 c) {
+  if constexpr (HT == 2) return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4_t, a), __builtin_bit_cast(h16x4_t, b), c, 0, 0, 0);
+  else return mfma16_bf16(a, b, c);
+}
+template <int HT>
+__device__ __forceinline__ void store16(float* img, int e, float w) {
+  if constexpr (HT == 2) reinterpret_cast<_Float16*>(img)[e] = (_Float16)w;
+  else reinterpret_cast<__bf16*>(img)[e] = (__bf16)w;
+}
+template <int HT>
+__device__ __forceinline__ float widen16(uint32_t low16) {  // a 16-bit operand (zero-extended in a register) as fp32
+  if constexpr (HT == 2) return (float)__builtin_bit_cast(_Float16, (unsigned short)low16);
+  else return __uint_as_float(low16 << 16);
 }
 
 // Split mode (nesvor_mlp_t.bf16_operands == 2), round 5: every fp32 operand x is written as TWO fp16 numbers of a scaled copy,
@@ -182,6 +213,12 @@ __device__ __forceinline__ bf16x8 join8(const s16x4& a, const s16x4& b) {
 }
 __device__ __forceinline__ f32x4 mfma32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+template <int HT>
+__device__ __forceinline__ f32x4 mfma32h(bf16x8 a, bf16x8 b, f32x4 c) {  // (operands carried as 8 x 16 raw bits; HT names their type)
+  if constexpr (HT == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8_t, a), __builtin_bit_cast(h16x8_t, b), c, 0, 0, 0);
+  else return mfma32_bf16(a, b, c);
 }
 __device__ __forceinline__ f16x8 join8h(const s16x4& a, const s16x4& b) {
   return __builtin_bit_cast(f16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -249,7 +286,7 @@ __device__ __forceinline__ MlpScales mlp_scales(const float* __restrict__ prep, 
 // ---------------------------------------------------------------- LDS images
 // forward image of a layer with `ob_n` output blocks and `kb_n` input blocks
 // (BF16: the image holds bf16 elements at the same element indices, i.e. it uses the first half of the fp32 carve)
-template <bool BF16 = false>
+template <int BF16 = 0>
 __device__ void build_image(float* img, const float* __restrict__ W, int out_dim, int in_dim, int ob_n, int kb_n) {
   if (NESVOR_MLP_ABLATE & 8) return;  // timing experiment: what the image build costs a launch
   const int total = ob_n * kb_n * 256;
@@ -258,12 +295,12 @@ __device__ void build_image(float* img, const float* __restrict__ W, int out_dim
     const int kb = blk % kb_n, ob = blk / kb_n;
     const int o = 16 * ob + (lane & 15), k = 16 * kb + 4 * (lane >> 4) + r;
     const float w = (o < out_dim && k < in_dim) ? W[(size_t)o * in_dim + k] : 0.f;
-    if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w;
+    if constexpr (BF16) store16<BF16>(img, e, w);
     else img[e] = w;
   }
 }
 // transposed image: rows i = input features (ib blocks), k = output features (kb blocks)
-template <bool BF16 = false>
+template <int BF16 = 0>
 __device__ void build_image_T(float* img, const float* __restrict__ W, int out_dim, int in_dim, int ib_n, int kb_n) {
   if (NESVOR_MLP_ABLATE & 8) return;
   const int total = ib_n * kb_n * 256;
@@ -272,7 +309,7 @@ __device__ void build_image_T(float* img, const float* __restrict__ W, int out_d
     const int kb = blk % kb_n, ib = blk / kb_n;
     const int in = 16 * ib + (lane & 15), o = 16 * kb + 4 * (lane >> 4) + r;
     const float w = (o < out_dim && in < in_dim) ? W[(size_t)o * in_dim + in] : 0.f;
-    if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w;
+    if constexpr (BF16) store16<BF16>(img, e, w);
     else img[e] = w;
   }
 }
@@ -282,7 +319,7 @@ __device__ void build_image_T(float* img, const float* __restrict__ W, int out_d
 // thread before the first tile, 6-11 us of every launch of the pipelined forward (tools/mlp_variants.py, -DNESVOR_MLP_ABLATE=8).
 // T: transposed image (build_image_T); A_N / B_N = (ob_n, kb_n) or (ib_n, kb_n) of the generic versions.
 // SPL: two fp16 planes hi | lo of `total` elements each of W * scale (split2's arithmetic) - the size of the fp32 carve.
-template <bool BF16, bool SPL, bool T, int A_N, int B_N, int THREADS>
+template <int BF16, bool SPL, bool T, int A_N, int B_N, int THREADS>
 __device__ __forceinline__ void build_image_ct(float* img, const float* __restrict__ W, int out_dim, int in_dim, float scale = 1.f) {
   if (NESVOR_MLP_ABLATE & 8) return;
   constexpr int total = A_N * B_N * 256;
@@ -309,7 +346,7 @@ __device__ __forceinline__ void build_image_ct(float* img, const float* __restri
           const float ws = w[u] * scale;
           const _Float16 hi = (_Float16)ws;
           p[e] = hi; p[total + e] = (_Float16)(ws - (float)hi);
-        } else if constexpr (BF16) reinterpret_cast<__bf16*>(img)[e] = (__bf16)w[u];
+        } else if constexpr (BF16) store16<BF16>(img, e, w[u]);
         else img[e] = w[u];
       }
     }
@@ -318,7 +355,7 @@ __device__ __forceinline__ void build_image_ct(float* img, const float* __restri
 
 // y[g][ob] (+)= img . x   for G groups at once; KB input blocks, OB output blocks
 // SPL: `mult` = (scale of this layer's B operand) / (units x arrives in); y accumulates in units sw sx (MlpScales)
-template <int KB, int OB, bool BF16 = false, bool SPL = false>
+template <int KB, int OB, int BF16 = 0, bool SPL = false>
 __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const f32x4 (&x)[kG][KB], f32x4 (&y)[kG][OB],
                                             int lane, float mult = 1.f) {
   if constexpr (SPL) {
@@ -380,25 +417,25 @@ __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const
     for (int kb = 0; kb + 1 < KB; kb += 2) {
       bf16x8 pb[kG];
 #pragma unroll
-      for (int g = 0; g < kG; ++g) pb[g] = join8(pack_bf16(x[g][kb]), pack_bf16(x[g][kb + 1]));
+      for (int g = 0; g < kG; ++g) pb[g] = join8(pack16<BF16>(x[g][kb]), pack16<BF16>(x[g][kb + 1]));
 #pragma unroll
       for (int ob = 0; ob < OB; ++ob) {
         const bf16x8 a = join8(*reinterpret_cast<const s16x4*>(img16 + ((ob * KB + kb) * 64 + lane) * 4),
                                *reinterpret_cast<const s16x4*>(img16 + ((ob * KB + kb + 1) * 64 + lane) * 4));
 #pragma unroll
-        for (int g = 0; g < kG; ++g) y[g][ob] = mfma32_bf16(a, pb[g], y[g][ob]);
+        for (int g = 0; g < kG; ++g) y[g][ob] = mfma32h<BF16>(a, pb[g], y[g][ob]);
       }
     }
     if constexpr (KB % 2 == 1) {
       constexpr int kb = KB - 1;
       s16x4 pb[kG];
 #pragma unroll
-      for (int g = 0; g < kG; ++g) pb[g] = pack_bf16(x[g][kb]);
+      for (int g = 0; g < kG; ++g) pb[g] = pack16<BF16>(x[g][kb]);
 #pragma unroll
       for (int ob = 0; ob < OB; ++ob) {
         const s16x4 a = *reinterpret_cast<const s16x4*>(img16 + ((ob * KB + kb) * 64 + lane) * 4);
 #pragma unroll
-        for (int g = 0; g < kG; ++g) y[g][ob] = mfma16_bf16(a, pb[g], y[g][ob]);
+        for (int g = 0; g < kG; ++g) y[g][ob] = mfma16h<BF16>(a, pb[g], y[g][ob]);
       }
     }
     return;
@@ -474,7 +511,7 @@ __device__ __forceinline__ void apply_layer_g1_s(const float* __restrict__ img, 
 
 // ZERO (split mode): y is an output, not an accumulator - the first term of every block product takes a literal zero as its C
 // operand instead of OB x 4 registers the caller would have to clear.
-template <int KB, int OB, bool BF16 = false, bool SPL = false, bool ZERO = false>
+template <int KB, int OB, int BF16 = 0, bool SPL = false, bool ZERO = false>
 __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, const f32x4 (&x)[KB], f32x4 (&y)[OB], int lane, float mult = 1.f) {
   static_assert(!ZERO || SPL, "ZERO: split mode only");
   if constexpr (SPL) {
@@ -488,17 +525,17 @@ __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, co
     const __bf16* img16 = reinterpret_cast<const __bf16*>(img);
 #pragma unroll
     for (int kb = 0; kb + 1 < KB; kb += 2) {
-      const bf16x8 pb = join8(pack_bf16(x[kb]), pack_bf16(x[kb + 1]));
+      const bf16x8 pb = join8(pack16<BF16>(x[kb]), pack16<BF16>(x[kb + 1]));
 #pragma unroll
       for (int ob = 0; ob < OB; ++ob)
-        y[ob] = mfma32_bf16(join8(*reinterpret_cast<const s16x4*>(img16 + ((ob * KB + kb) * 64 + lane) * 4),
+        y[ob] = mfma32h<BF16>(join8(*reinterpret_cast<const s16x4*>(img16 + ((ob * KB + kb) * 64 + lane) * 4),
                                   *reinterpret_cast<const s16x4*>(img16 + ((ob * KB + kb + 1) * 64 + lane) * 4)), pb, y[ob]);
     }
     if constexpr (KB % 2 == 1) {
-      const s16x4 pb = pack_bf16(x[KB - 1]);
+      const s16x4 pb = pack16<BF16>(x[KB - 1]);
 #pragma unroll
       for (int ob = 0; ob < OB; ++ob)
-        y[ob] = mfma16_bf16(*reinterpret_cast<const s16x4*>(img16 + ((ob * KB + KB - 1) * 64 + lane) * 4), pb, y[ob]);
+        y[ob] = mfma16h<BF16>(*reinterpret_cast<const s16x4*>(img16 + ((ob * KB + KB - 1) * 64 + lane) * 4), pb, y[ob]);
     }
     return;
   }
@@ -642,11 +679,13 @@ __device__ __forceinline__ void issue_load_u16(float& dst, const void* p) {  // 
   asm volatile("global_load_ushort %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
 __device__ __forceinline__ void pin(f32x2& x) { asm volatile("" : "+v"(x)); }
-// four bf16 packed in two dwords -> fp32 (exact)
-__device__ __forceinline__ f32x4 unpack_bf16(const f32x2& v) {
+// four 16-bit operands (bf16 / fp16) packed in two dwords -> fp32 (exact)
+template <int HT>
+__device__ __forceinline__ f32x4 unpack16(const f32x2& v) {
   const uint32_t u0 = __float_as_uint(v[0]), u1 = __float_as_uint(v[1]);
-  return f32x4{__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xFFFF0000u), __uint_as_float(u1 << 16),
-               __uint_as_float(u1 & 0xFFFF0000u)};
+  if constexpr (HT == 2) return f32x4{widen16<2>(u0 & 0xFFFFu), widen16<2>(u0 >> 16), widen16<2>(u1 & 0xFFFFu), widen16<2>(u1 >> 16)};
+  else return f32x4{__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xFFFF0000u), __uint_as_float(u1 << 16),
+                    __uint_as_float(u1 & 0xFFFF0000u)};
 }
 __device__ __forceinline__ void await_loads() {
   __builtin_amdgcn_sched_barrier(0);  // nothing (in particular no MFMA) may be scheduled across the wait
@@ -932,7 +971,7 @@ __global__ __launch_bounds__(256, (SPL && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) 
 // (the general kernel: any N, any input composition, up to three hidden layers; fp32 MFMAs or bf16-rounded operands - the
 //  split mode lives in the pipelined kernel above, and shapes it does not take are evaluated here on the fp32 pipe, which is
 //  always a valid evaluation of the split mode)
-template <int KB1, bool BF16 = false>
+template <int KB1, int BF16 = 0>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n_hidden = a.n_linear - 1;
@@ -991,7 +1030,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
           if (a.H[l] != nullptr && g0 + g < n_groups) {
             const size_t e = (((size_t)(g0 + g) * kHB + ob) * 64 + lane) * 4;
             // written once, read by the backward many kernels later: streaming stores (no L2 allocation)
-            if constexpr (BF16) __builtin_nontemporal_store(pack_bf16(h[g][ob]), reinterpret_cast<s16x4*>(reinterpret_cast<__bf16*>(a.H[l]) + e));
+            if constexpr (BF16) __builtin_nontemporal_store(pack16<BF16>(h[g][ob]), reinterpret_cast<s16x4*>(reinterpret_cast<__bf16*>(a.H[l]) + e));
             else __builtin_nontemporal_store(h[g][ob], reinterpret_cast<f32x4*>(a.H[l] + e));
           }
         }
@@ -1339,7 +1378,7 @@ __device__ void flush_dw_ws(float* red /* 4 x OB x IB x 256 + 4 x kWidth floats 
 }
 
 // dW accumulation from a staged A tile set and B operands already in registers
-template <int OB, int IB, bool BF16 = false>
+template <int OB, int IB, int BF16 = 0>
 __device__ __forceinline__ void accumulate_dw_regs(const float* tiles, const f32x4 (&bv)[IB], f32x4 (&acc)[OB][IB], int i, int q) {
   float av[OB][4];
 #pragma unroll
@@ -1347,12 +1386,12 @@ __device__ __forceinline__ void accumulate_dw_regs(const float* tiles, const f32
   if constexpr (BF16) {
     s16x4 pb[IB];
 #pragma unroll
-    for (int ib = 0; ib < IB; ++ib) pb[ib] = pack_bf16(bv[ib]);
+    for (int ib = 0; ib < IB; ++ib) pb[ib] = pack16<BF16>(bv[ib]);
 #pragma unroll
     for (int ob = 0; ob < OB; ++ob) {
-      const s16x4 pa = pack_bf16(f32x4{av[ob][0], av[ob][1], av[ob][2], av[ob][3]});
+      const s16x4 pa = pack16<BF16>(f32x4{av[ob][0], av[ob][1], av[ob][2], av[ob][3]});
 #pragma unroll
-      for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma16_bf16(pa, pb[ib], acc[ob][ib]);
+      for (int ib = 0; ib < IB; ++ib) acc[ob][ib] = mfma16h<BF16>(pa, pb[ib], acc[ob][ib]);
     }
     return;
   }
@@ -1441,7 +1480,7 @@ __device__ __forceinline__ void accumulate_dw_tuples(const float* tiles, const f
 // OUT1 (split mode, out_dim == 1): the output layer's two products are rank one - d h = w_out dy and dW_out = sum_s dy_s h_s -
 // and run as fp32 VALU work (16 multiplies per lane in the chain wave, 16 FMAs in the dW wave) instead of 24 + 12 MFMAs on
 // 15/16 padding and the splits of their operands.
-template <int KB1, int NH, bool BF16 = false, bool SPL = false, bool COMPACT = false, bool OUT1 = false>
+template <int KB1, int NH, int BF16 = 0, bool SPL = false, bool COMPACT = false, bool OUT1 = false>
 __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   static_assert(!COMPACT || (SPL && !BF16), "compact save: split-operand mode only");
   static_assert(!OUT1 || (SPL && !BF16), "OUT1: split-operand mode only");
@@ -1567,7 +1606,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   if (role == 0) {
     // ------------------------------------------------------------------ chain waves
     // saved activations: fp32 fragments (16 B per lane) or, in the bf16 mode, bf16 fragments (8 B per lane)
-    using RawH = typename std::conditional<BF16, f32x2, f32x4>::type;
+    using RawH = typename std::conditional<(BF16 != 0), f32x2, f32x4>::type;
     uint32_t yoff[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) yoff[r] = (uint32_t)(((int64_t)min(4 * q + r, a.out_dim - 1) * a.N + j) * 4);
@@ -1620,7 +1659,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           for (int l = 0; l < NH; ++l)
 #pragma unroll
             for (int ib = 0; ib < kHB; ++ib) {
-              if constexpr (BF16) hs[l][ib] = unpack_bf16(hs_c[l][ib]);
+              if constexpr (BF16) hs[l][ib] = unpack16<BF16>(hs_c[l][ib]);
               else hs[l][ib] = hs_c[l][ib];
             }
         }
@@ -2013,7 +2052,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           for (int ib = 0; ib < kHB; ++ib)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-              hb[l][ib][t] = BF16 ? __uint_as_float(__float_as_uint(hraw_c[l][ib][t]) << 16) : hraw_c[l][ib][t];
+              hb[l][ib][t] = BF16 ? widen16<(BF16 == 2 ? 2 : 1)>(__float_as_uint(hraw_c[l][ib][t])) : hraw_c[l][ib][t];
         const int64_t gnext = min(gi + gstride, n_groups - 1);  // (the last iteration re-requests a valid group: no control flow between an issue and its settle)
         issue_x(gi, xraw, xsraw);
         // the next group's activations: a whole iteration ahead
@@ -2329,8 +2368,10 @@ int fill_args(MlpArgs* a, const nesvor_mlp_t* d, int64_t N) {
   const int S = d->samples_per_pixel;
   a->fast = (N % 16 == 0 && S % 16 == 0 && d->k_a % 16 == 0) ? 1 : 0;
   a->dxa_group = d->dxa_group_sums ? 1 : 0;
-  a->bf16 = d->bf16_operands;  // 0: fp32 MFMA, 1: bf16-rounded operands, 2: split (fp32-equivalent) operands
-  if (a->bf16 < 0 || a->bf16 > 2) return (int)hipErrorInvalidValue;
+  a->bf16 = d->bf16_operands;  // 0: fp32 MFMA, 1: bf16-rounded operands, 2: split (fp32-equivalent) operands, 3: fp16-rounded operands
+  if (a->bf16 < 0 || a->bf16 > 3) return (int)hipErrorInvalidValue;
+  a->half16 = a->bf16 == 3 ? 1 : 0;
+  if (a->half16) a->bf16 = 1;  // (every host-side decision below is that of the 16-bit operand modes; the launches pick the type)
   a->prep = d->prep;
   a->y_absmax = d->y_absmax;
   {
@@ -2490,6 +2531,9 @@ extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, cons
 #undef NESVOR_PF
   }
   // (the split mode of a shape the pipelined kernel does not take: the plain fp32 MFMAs - always a valid evaluation of it)
+  if (a.bf16 == 1 && a.half16)
+    return launch_kb(mlp_fwd_kernel<1, 2>, mlp_fwd_kernel<2, 2>, mlp_fwd_kernel<3, 2>, mlp_fwd_kernel<4, 2>, kb1,
+                     grid, fwd_lds_bytes(a.n_linear, kb1), (hipStream_t)stream, a);
   if (a.bf16 == 1)
     return launch_kb(mlp_fwd_kernel<1, true>, mlp_fwd_kernel<2, true>, mlp_fwd_kernel<3, true>, mlp_fwd_kernel<4, true>, kb1,
                      grid, fwd_lds_bytes(a.n_linear, kb1), (hipStream_t)stream, a);
@@ -2548,6 +2592,15 @@ extern "C" int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float*
     // fused dX + dW + db (the caller signals it by passing no dpre scratch); grid = n_partial workgroups
     if (ws_ok(a, net)) {  // wave-specialised: 8 waves per workgroup
       const size_t lds_ws = ws_bwd_lds_bytes(net->n_hidden, kb1);
+      if (a.bf16 && a.half16) {
+        if (net->n_hidden == 1)
+          return launch_kb(mlp_bwd_ws_kernel<1, 1, 2>, mlp_bwd_ws_kernel<2, 1, 2>, mlp_bwd_ws_kernel<3, 1, 2>,
+                           mlp_bwd_ws_kernel<4, 1, 2>, kb1, dim3((unsigned)n_partial), lds_ws, (hipStream_t)stream, a, 512);
+        // (ws_ok admits two hidden layers with at most two input blocks: the wider instantiations are never launched - and the
+        //  build's assembly check rejects the register allocation the compiler finds for <4, 2, fp16>)
+        return launch_kb(mlp_bwd_ws_kernel<1, 2, 2>, mlp_bwd_ws_kernel<2, 2, 2>, mlp_bwd_ws_kernel<2, 2, 2>,
+                         mlp_bwd_ws_kernel<2, 2, 2>, kb1, dim3((unsigned)n_partial), lds_ws, (hipStream_t)stream, a, 512);
+      }
       if (a.bf16) {
         if (net->n_hidden == 1)
           return launch_kb(mlp_bwd_ws_kernel<1, 1, true>, mlp_bwd_ws_kernel<2, 1, true>, mlp_bwd_ws_kernel<3, 1, true>,

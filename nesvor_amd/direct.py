@@ -79,6 +79,7 @@ class DirectStep:
         self.gw = torch.tensor([w.get(D_LOSS, 0), w.get(S_LOSS, 0) if self.has_var else 0, w.get(I_REG, 0),
                                 w.get(B_REG, 0) if self.has_b else 0.0], dtype=torch.float32, device=dev)
         self.w_T = float(w.get(T_REG, 0))
+        self._gw_base, self._w_T_base, self.loss_scale = self.gw.clone(), self.w_T, 1.0
         self.reg_type = loss_mod.REG_TYPES[a.image_regularization]
         self.delta = float(model.delta)
         # the parameters were re-homed into `flat` before this point: the views taken here stay valid
@@ -98,7 +99,9 @@ class DirectStep:
         # evaluation of the MLP matrix products (mlp.operand_mode): bf16-rounded operands for the half-precision model
         # structure and, opt-in, for the fp32 model (args.mlp_bf16); otherwise fp32 - the split-fp16 default, or the
         # plain fp32 MFMAs with args.mlp_fp32_mfma
-        if bool(getattr(a, "mlp_bf16", False)) or half_precision_model(model):
+        if half_precision_model(model) and getattr(a, "fp16_loss_scaling", False):
+            self.bf16 = mlp_mod.FP16  # the reference's default arithmetic, under its loss scaler (fused.LossScaler)
+        elif bool(getattr(a, "mlp_bf16", False)) or half_precision_model(model):
             self.bf16 = True
         else:
             self.bf16 = mlp_mod.MFMA_FP32 if getattr(a, "mlp_fp32_mfma", False) else False
@@ -172,8 +175,10 @@ class DirectStep:
         the bias field under data parallelism, whose global mean needs the host's all-reduce mid-step - not that combination."""
         if not (self._native_on and noise is None and self._kernel_noise and not _lib.kernel_timer.enabled):
             return False
-        if self.bf16 is True and half_precision_model(self.model):
+        if (self.bf16 is True or self.bf16 == mlp_mod.FP16) and half_precision_model(self.model):
             return False
+        if self.loss_scale != 1.0:
+            return False  # (the one-call step's descriptors hold the unscaled pose-regulariser weight)
         nets = [self.d_net] + ([self.s_net] if self.has_lv else []) + ([self.b_net] if self.has_b else [])
         if not all((not p.flat_params) and p.segment is not None and p.segment.numel() == sum(
                 w.numel() + b.numel() for w, b in zip(p.weights, p.biases)) for p in nets):
@@ -183,6 +188,15 @@ class DirectStep:
         if self.bf16 and not self._fused_backward_takes_all():
             return False  # (the dX + dW launch pair that other shapes fall back to has no bf16-operand form)
         return True
+
+    def set_loss_scale(self, scale: float) -> None:
+        """Every gradient of the step times ``scale`` (the loss scaler of the fp16 mode, train.py:190 of the reference:
+        ``scaler.scale(loss).backward()``): the loss kernel's four upstream weights and the pose regulariser's.  A host float
+        that changes on growth / backoff events only - no device traffic per step.  The reported loss VALUES are unscaled."""
+        if scale != self.loss_scale:
+            self.loss_scale = float(scale)
+            self.gw.copy_(self._gw_base * self.loss_scale)
+            self.w_T = self._w_T_base * self.loss_scale
 
     def _fused_backward_ok(self, N=None):
         """Per network (density, sigma | None, bias | None): does the wave-specialised fused MLP backward take it at N points per

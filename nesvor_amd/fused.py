@@ -54,6 +54,30 @@ class FlatParams:
         return self.grad[off : off + cnt]
 
 
+class LossScaler:
+    """``torch.cuda.amp.GradScaler`` as the reference configures it (nesvor/nesvor/train.py:161-164: ``init_scale=1.0,
+    growth_factor=2.0, backoff_factor=0.5``, PyTorch's default ``growth_interval=2000``), host side: the scale is a Python
+    float, the verdict of an iteration (all gradients finite?) is the one device value read per step."""
+
+    def __init__(self, init_scale: float = 1.0, growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000):
+        self.scale, self.growth_factor, self.backoff_factor, self.growth_interval = float(init_scale), growth_factor, backoff_factor, growth_interval
+        self.growth_tracker, self.skipped = 0, 0
+
+    def update(self, found_inf: bool) -> None:
+        if found_inf:
+            self.scale *= self.backoff_factor
+            self.growth_tracker = 0
+            self.skipped += 1
+        else:
+            self.growth_tracker += 1
+            if self.growth_tracker == self.growth_interval:
+                self.scale *= self.growth_factor
+                self.growth_tracker = 0
+
+    def state_dict(self):
+        return {"scale": self.scale, "growth_tracker": self.growth_tracker, "skipped": self.skipped}
+
+
 class FusedTrainer:
     def __init__(self, model: NeSVoR, args: Namespace, world_size: int = 1, distributed: Optional[bool] = None):
         if next(model.parameters()).device.type != "cuda":
@@ -84,12 +108,43 @@ class FusedTrainer:
         from . import direct
 
         self.direct = direct.DirectStep(model, self.flat, self.weights) if direct.supported(model) else None
+        # the reference's default numerics, opt-in (round 6): fp16 matrix operands + its GradScaler (train.py:161-164)
+        self.scaler = None
+        if getattr(args, "fp16_loss_scaling", False):
+            if self.direct is None or not direct.half_precision_model(model) or distributed:
+                raise RuntimeError("args.fp16_loss_scaling: the half-precision model structure (no --single-precision) on the "
+                                   "autograd-free step, single process (the reference's loop, which it restates, has no data parallelism)")
+            from . import mlp as _mlp
+
+            _mlp.HALF_OPERANDS[0] = _mlp.FP16  # (the module path of tinycudann.Network: inference between / after training)
+            self.scaler = LossScaler()
         if getattr(args, "mlp_bf16", False) and self.direct is None:
             raise RuntimeError("args.mlp_bf16 needs the autograd-free step (fused fp32 model, MLPs of at most two hidden layers)")
 
     @property
     def reduce_hook(self):
         return self._reduce_hook
+
+    def _scaled_step(self, xyz, v, slice_idx, noise=None) -> Dict[str, torch.Tensor]:
+        """One iteration under the loss scaler (``args.fp16_loss_scaling``): what the reference's loop does around its optimizer
+        (train.py:190-196: ``scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()``) - every gradient carries the
+        scale, a step whose gradients are not all finite is SKIPPED (parameters, moments and step count untouched, gradients
+        dropped) and halves the scale, ``growth_interval`` finite steps in a row double it.  Like ``GradScaler.step`` this reads one
+        device flag per iteration (a host synchronisation the fp32 path does not have)."""
+        sc = self.scaler
+        self.direct.set_loss_scale(sc.scale)
+        losses = self._forward_backward(xyz, v, slice_idx, noise)
+        self.direct.join_owner()
+        finite = bool(torch.isfinite(self.flat.grad).all())
+        if finite:
+            self.t += 1
+            f = self.flat
+            torch.ops.nesvor.adamw_step_(f.param, f.grad, f.exp_avg, f.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
+                                         self.weight_decay, self.t, 1.0 / (self.world_size * sc.scale), True)
+        else:
+            self.flat.grad.zero_()
+        sc.update(found_inf=not finite)
+        return losses
 
     @reduce_hook.setter
     def reduce_hook(self, hook) -> None:
@@ -144,6 +199,8 @@ class FusedTrainer:
         return losses
 
     def step(self, xyz, v, slice_idx, noise=None) -> Dict[str, torch.Tensor]:
+        if self.scaler is not None:
+            return self._scaled_step(xyz, v, slice_idx, noise)
         if self.direct is not None and self.reduce_hook is None and not self.sharded and self.direct.native_ready(noise):
             # single process: forward, backward AND AdamW behind one native call (csrc/step.hip)
             from . import _lib

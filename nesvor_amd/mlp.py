@@ -26,7 +26,10 @@ FUSED_BACKWARD = True  # False: separate dX and dW kernels (kept as cross-check 
 #     or below the fp32 FMA chain's (profiles/r05_f16_split_probe.log: 2.1e-7 vs 3.6e-7 of the largest result), because the
 #     fp32 matrix pipe of gfx950 is 16x slower than the 16-bit one.  (Rounds 2-4: three bf16 terms per operand, six MFMAs.)
 # SPLIT is what "fp32" means by default; NESVOR_MLP_FP32=mfma (or FP32_OPERANDS = MFMA_FP32) selects the plain path.
-MFMA_FP32, BF16, SPLIT = 0, 1, 2
+#   FP16 (3): operands rounded to fp16 (round 6) - the arithmetic of the reference's DEFAULT mode (fp16 CutlassMLP,
+#     nesvor/nesvor/models.py:28-41), same kernels as BF16 with fp16 MFMAs; its narrow exponent range is what the reference's
+#     GradScaler exists for (train.py:161-164): opt-in with ``args.fp16_loss_scaling`` (nesvor_amd.fused.LossScaler).
+MFMA_FP32, BF16, SPLIT, FP16 = 0, 1, 2, 3
 FP32_OPERANDS = MFMA_FP32 if os.environ.get("NESVOR_MLP_FP32", "split").lower() == "mfma" else SPLIT
 
 
@@ -266,7 +269,7 @@ def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False,
         d.y_absmax = y_absmax.data_ptr()
     # saved hidden activations, MFMA fragment layout; bf16 mode stores them as bf16 (they are only used as bf16 operands);
     # compact save (split-operand mode, whole tiles): saved[0] holds sign bits only
-    sdt = torch.bfloat16 if operand_mode(bf16) == BF16 else torch.float32
+    sdt = {BF16: torch.bfloat16, FP16: torch.float16}.get(operand_mode(bf16), torch.float32)
     saved = []
     if need_saved:
         sizes = saved_sizes(d, N, len(weights) - 1)
@@ -488,7 +491,8 @@ def apply_net(net, xa, xb, b_row0: int, k_b: int, samples_per_pixel: int):
 
 
 class FlatNetworkFunction(Function):
-    """``tinycudann.Network`` (one flat bias-free parameter vector) on the fused kernels, bf16 matrix operands:
+    """``tinycudann.Network`` (one flat bias-free parameter vector) on the fused kernels, 16-bit matrix operands (``HALF_OPERANDS``:
+    bf16 by default, fp16 under ``args.fp16_loss_scaling``):
     x (N, k) row-major -> y (N, n_output_dims).  The kernels read a feature-major input and write a feature-major
     output; the two transposes are the price of tinycudann's row-major module interface (the training step proper
     never pays it: nesvor_amd.direct feeds the kernels feature-major tensors)."""
@@ -503,8 +507,8 @@ class FlatNetworkFunction(Function):
         need = any(ctx.needs_input_grad)
         if need and (p.n_hidden() > 2 or (p.n_hidden() == 2 and x.shape[1] > 32)):
             raise NotImplementedError("half-precision Network backward: built for 1-2 hidden layers (<= 32 inputs with 2)")
-        y, saved = forward_raw(p.weights, p.biases, None, xb, 0, xb.shape[0], 16, need, True)
-        ctx.net, ctx.n = net, n
+        y, saved = forward_raw(p.weights, p.biases, None, xb, 0, xb.shape[0], 16, need, HALF_OPERANDS[0])
+        ctx.net, ctx.n, ctx.mode = net, n, HALF_OPERANDS[0]
         ctx.save_for_backward(xb, *saved)
         return y[:, :n].t()
 
@@ -516,7 +520,7 @@ class FlatNetworkFunction(Function):
         dyb = torch.zeros((dy.shape[1], xb.shape[1]), dtype=torch.float32, device=xb.device)
         dyb[:, :n] = dy.t()
         dxb = torch.empty_like(xb) if ctx.needs_input_grad[0] else None
-        _, partial = backward_raw(p.weights, p.biases, None, xb, dyb, saved, 0, xb.shape[0], 16, dxb, False, True)
+        _, partial = backward_raw(p.weights, p.biases, None, xb, dyb, saved, 0, xb.shape[0], 16, dxb, False, ctx.mode)
         g = None
         if ctx.needs_input_grad[1]:
             g = torch.zeros_like(net.params)
@@ -525,6 +529,9 @@ class FlatNetworkFunction(Function):
                 g[off : off + w.numel()] = flat[col : col + w.numel()]
                 col += w.numel() + w.shape[0]
         return (None if dxb is None else dxb[:, :n].t()), g, None
+
+
+HALF_OPERANDS = [True]  # the 16-bit operand mode of the half-precision structure's module path: True (bf16) or FP16 (set by train())
 
 
 def flat_network(net, x):
@@ -541,6 +548,8 @@ def inference_operands(inr, args):
     net = inr.density_net
     if not supported(net):
         return None  # library GEMMs (apply_net)
-    if isinstance(net, Network) or getattr(args, "mlp_bf16", False):
+    if isinstance(net, Network):
+        return FP16 if getattr(args, "fp16_loss_scaling", False) else True
+    if getattr(args, "mlp_bf16", False):
         return True
     return MFMA_FP32 if getattr(args, "mlp_fp32_mfma", False) else False

@@ -129,7 +129,8 @@ class INR(nn.Module):
 
             pe_fm = hashgrid_forward(enc.spec, x.reshape(-1, 3).float().contiguous(), enc.params, _lib.LAYOUT_FEATURE_MAJOR)
             net = fused_mlp_mod.NetParams(self.density_net)
-            z_fm, _ = fused_mlp_mod.forward_raw(net.weights, net.biases, None, pe_fm, 0, pe_fm.shape[0], 1, False, bf16=True)
+            z_fm, _ = fused_mlp_mod.forward_raw(net.weights, net.biases, None, pe_fm, 0, pe_fm.shape[0], 1, False,
+                                                bf16=fused_mlp_mod.HALF_OPERANDS[0])
         else:
             # feature-major hash grid -> fused MLP; (N,E)/(N,16) views are returned for API parity
             pe_fm = hashgrid_encode(x.reshape(-1, 3).float(), enc.params, enc.spec, _lib.LAYOUT_FEATURE_MAJOR, enc.grad_accum)

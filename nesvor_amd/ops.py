@@ -400,7 +400,7 @@ def _mlp_fake(xa, xb, weights, biases, b_row0, k_b, S, operands, save):
     # pointer-less descriptor and forward_raw's real one always agree (tests/test_cabi.py::test_mlp_fake_sizes_match_forward)
     n = xb.shape[1]
     n_pad = (n + 15) // 16 * 16
-    sdt = torch.bfloat16 if operands == _mlp.BF16 else torch.float32
+    sdt = {_mlp.BF16: torch.bfloat16, _mlp.FP16: torch.float16}.get(operands, torch.float32)
     saved = []
     if save:
         d = _mlp.dims_desc(len(weights) - 1, weights[-1].shape[0], 0 if xa is None else xa.shape[1], k_b, b_row0, S, _operands(operands))

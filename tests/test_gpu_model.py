@@ -266,6 +266,70 @@ def test_train_phantom_half_precision_model_keeps_psnr(device):
     assert psnr[torch.float16] > 8.0 and abs(psnr[torch.float16] - psnr[torch.float32]) <= 0.5
 
 
+def test_train_phantom_fp16_loss_scaling_keeps_psnr_and_skips_overflowing_steps(device):
+    """Round 6, the reference's DEFAULT numerics as an opt-in (nesvor/nesvor/models.py:28-41, train.py:161-164, 190-196): fp16
+    matrix operands with ``torch.cuda.amp.GradScaler(init_scale=1, growth_factor=2, backoff_factor=0.5)`` semantics
+    (``args.fp16_loss_scaling``).  (a) The scaler: a step whose gradients overflow leaves parameters, moments and the step count
+    untouched, drops the gradients and halves the scale; finite steps grow it every ``growth_interval``; the reported loss values
+    do not carry the scale.  (b) Training reaches the fp32 model's PSNR within 0.5 dB (stated delta of the mode)."""
+    from nesvor_amd import mlp
+    from nesvor_amd.fused import FusedTrainer
+    from nesvor_amd.phantom import phantom3d, simulate_stacks
+    from nesvor_amd.train import Dataset, train
+    from nesvor_amd.models import NeSVoR
+
+    vol = torch.tensor(phantom3d(n=32), dtype=torch.float32, device=device)
+    slices, _ = simulate_stacks(vol, n_stacks=3)
+    mk = lambda **kw: small_args(device=device, n_iter=300, batch_size=512, n_samples=16, finest_resolution=1.0, log2_hashmap_size=14,
+                                 no_transformation_optimization=True, depth=2, **kw)
+    try:
+        # ---- (a) mechanics on a live trainer
+        args = mk(dtype=torch.float16, single_precision=False, fp16_loss_scaling=True)
+        ds = Dataset(slices, args)
+        torch.manual_seed(0)
+        model = NeSVoR(ds.transformation, ds.resolution, ds.mean, ds.bounding_box, args)
+        tr = FusedTrainer(model, args)
+        assert tr.scaler is not None and tr.scaler.scale == 1.0 and tr.direct.bf16 == mlp.FP16
+        batch = ds.get_batch(args.batch_size, device)
+        l0 = tr.step(batch["xyz"], batch["v"], batch["slice_idx"])
+        assert tr.t == 1 and tr.scaler.growth_tracker == 1 and all(bool(torch.isfinite(v)) for v in l0.values())
+        before = tr.flat.param.clone(), tr.flat.exp_avg.clone(), tr.flat.exp_avg_sq.clone()
+        tr.scaler.scale = 2.0 ** 60  # every gradient overflows fp16 (and fp32 products of it)
+        l1 = tr.step(batch["xyz"], batch["v"], batch["slice_idx"])
+        assert tr.t == 1 and tr.scaler.scale == 2.0 ** 59 and tr.scaler.skipped == 1 and tr.scaler.growth_tracker == 0
+        assert torch.equal(tr.flat.param, before[0]) and torch.equal(tr.flat.exp_avg, before[1]) and torch.equal(tr.flat.exp_avg_sq, before[2])
+        assert float(tr.flat.grad.abs().max()) == 0.0
+        tr.scaler.scale, tr.scaler.growth_interval = 4.0, 2
+        la = tr.step(batch["xyz"], batch["v"], batch["slice_idx"])
+        assert tr.t == 2 and tr.scaler.scale == 4.0
+        tr.step(batch["xyz"], batch["v"], batch["slice_idx"])
+        assert tr.t == 3 and tr.scaler.scale == 8.0  # two finite steps in a row: growth
+        # the loss values are those of the unscaled loss (same parameters as l1's step - which changed nothing - would give)
+        for k in l0:
+            assert abs(float(la[k])) < 1e3 * (abs(float(l0[k])) + 1e-3), k
+        tr.finish()
+        # ---- (b) reconstruction quality against the fp32 model
+        g = (torch.arange(32, dtype=torch.float32) - 15.5)
+        zz, yy, xx = torch.meshgrid(g, g, g, indexing="ij")
+        pts = torch.stack([xx, yy, zz], -1).reshape(-1, 3).to(device)
+        truth = vol.reshape(-1)
+        inside = truth > 0
+        psnr = {}
+        for name, kw in (("fp32", dict(dtype=torch.float32, single_precision=True)),
+                         ("fp16+scaler", dict(dtype=torch.float16, single_precision=False, fp16_loss_scaling=True))):
+            mlp.HALF_OPERANDS[0] = True
+            torch.manual_seed(0)
+            inr, _, _ = train(slices, mk(**kw))
+            with torch.no_grad():
+                r = inr(pts[:, None], False).mean(-1).float()
+            sc = float((r[inside] * truth[inside]).sum() / (r[inside] ** 2).sum())
+            psnr[name] = _psnr(r[inside] * sc, truth[inside], float(truth.max()))
+        print(f"PSNR fp32 model {psnr['fp32']:.2f} dB, fp16 operands + loss scaler {psnr['fp16+scaler']:.2f} dB")
+        assert psnr["fp16+scaler"] > 8.0 and abs(psnr["fp16+scaler"] - psnr["fp32"]) <= 0.5
+    finally:
+        mlp.HALF_OPERANDS[0] = True
+
+
 def _psnr(a, b, peak):
     return 10 * math.log10(peak**2 / float(((a - b) ** 2).mean()))
 

@@ -608,18 +608,17 @@ def test_hashgrid_full_size_properties(device):
     const = torch.full((spec.n_params,), 0.75, device=device)
     from nesvor_amd import encoding as _enc
 
+    pe_by_mode = {}
     for mode in ("", "sorted"):  # the per-level kernel with paired corner requests / the ordered forward
         _enc._FWD_MODE = mode
         try:
-            pe = hashgrid_forward(spec, uu, const, 1, clustered=False)
-            torch.testing.assert_close(pe, torch.full_like(pe, 0.75), rtol=1e-6, atol=1e-6)
-            pe_m = hashgrid_forward(spec, uu, table, 1, clustered=False)
+            pc = hashgrid_forward(spec, uu, const, 1, clustered=False)
+            torch.testing.assert_close(pc, torch.full_like(pc, 0.75), rtol=1e-6, atol=1e-6)
+            pe_by_mode[mode] = hashgrid_forward(spec, uu, table, 1, clustered=False)
         finally:
             _enc._FWD_MODE = ""
-        if mode == "":
-            pe = pe_m
-        else:
-            assert torch.equal(pe_m, pe)
+    assert torch.equal(pe_by_mode["sorted"], pe_by_mode[""])
+    pe = pe_by_mode[""]
     gu_, _ = hashgrid_backward(spec, uu, table, dy1, None, False, 1, clustered=False)
     lhs = (pe.double() * dy1.double()).sum()
     rhs = (table.double() * gu_.double()).sum()
@@ -1110,14 +1109,18 @@ def _bf(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
 @pytest.mark.parametrize("k_a,k_b,b_row0,rows,out_dim", [(0, 32, 0, 32, 16), (16, 15, 1, 16, 1)])
-def test_fused_mlp_bf16_operand_mode(device, k_a, k_b, b_row0, rows, out_dim):
-    """Opt-in mixed precision (nesvor_mlp_t.bf16_operands): every matrix product takes bf16-rounded operands and
-    accumulates in fp32.  Reference = the same arithmetic spelled out in torch (fp64 accumulation of the rounded
-    operands): forward, input gradients and parameter gradients.  Tolerance 2e-3 of the largest element (fp32
-    accumulation order)."""
+def test_fused_mlp_bf16_operand_mode(device, k_a, k_b, b_row0, rows, out_dim, half):
+    """Opt-in mixed precision (nesvor_mlp_t.bf16_operands 1 / 3): every matrix product takes bf16- (fp16-, round 6: the reference's
+    default arithmetic) rounded operands and accumulates in fp32.  Reference = the same arithmetic spelled out in torch (fp64
+    accumulation of the rounded operands): forward, input gradients and parameter gradients.  Tolerance 2e-3 of the largest
+    element (fp32 accumulation order)."""
     from nesvor_amd import mlp
     from nesvor_amd.models import build_network
+
+    mode = True if half == "bf16" else mlp.FP16
+    _bf = (lambda x: x.to(torch.bfloat16).to(torch.float32)) if half == "bf16" else (lambda x: x.to(torch.float16).to(torch.float32))
 
     torch.manual_seed(0)
     N, S = 4096, 256
@@ -1128,9 +1131,9 @@ def test_fused_mlp_bf16_operand_mode(device, k_a, k_b, b_row0, rows, out_dim):
     xa = torch.randn(N // S, k_a, device=device) if k_a else None
     xb = torch.randn(rows, N, device=device)
     dy = torch.randn(out_dim, N, device=device)
-    y, saved = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, True, bf16=True)
+    y, saved = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, True, bf16=mode)
     dxb = torch.empty(k_b, N, device=device)
-    dxa, partial = mlp.backward_raw(W, Bs, xa, xb, dy, saved, b_row0, k_b, S, dxb, xa is not None, bf16=True)
+    dxa, partial = mlp.backward_raw(W, Bs, xa, xb, dy, saved, b_row0, k_b, S, dxb, xa is not None, bf16=mode)
     flat = partial.sum(0).cpu().double()
     # reference (N, features) row-major, fp64 accumulation of bf16-rounded operands
     X = xb[b_row0 : b_row0 + k_b].t()
