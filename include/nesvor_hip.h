@@ -536,6 +536,17 @@ int nesvor_hashgrid_backward_adamw(const nesvor_grid_t* grid, const float* u, fl
                                    float* grad_table, float* grad_u, int64_t N, int layout, void* workspace, int stages,
                                    const float* queue_scale, const float* dy_bound, float* exp_avg, float* exp_avg_sq,
                                    const nesvor_adamw_t* adam, void* stream);
+/* The owner stage (stages == 2) of that backward for levels [level_begin, level_end) only, and the per-cloud forward for a level
+ * range (round 6).  The table's update is what the NEXT iteration's forward waits for; updated range by range - the coarse
+ * levels first - the next forward starts on the finished levels while the owner pass still works on the others
+ * (csrc/step.hip: 84 us of owner pass + 70 us of forward, both latency-bound, no longer strictly one after the other).
+ * nesvor_hashgrid_forward_levels: the NESVOR_LAYOUT_CLUSTERED kernel; rows of pe outside the range are not touched. */
+int nesvor_hashgrid_backward_adamw_levels(const nesvor_grid_t* grid, const float* u, float* table, const float* dpe,
+                                          float* grad_table, float* grad_u, int64_t N, int layout, void* workspace, int stages,
+                                          int level_begin, int level_end, const float* queue_scale, const float* dy_bound,
+                                          float* exp_avg, float* exp_avg_sq, const nesvor_adamw_t* adam, void* stream);
+int nesvor_hashgrid_forward_levels(const nesvor_grid_t* grid, const float* u, const float* table, float* pe, int64_t N, int layout,
+                                   float* pe_absmax, int level_begin, int level_end, void* stream);
 
 /* out[c] = sum_r in[r * ld + c], c < cols, for a row-major matrix of row pitch ld >= cols floats: reduces the
  * dw_partial of nesvor_mlp_backward (the `partial.sum(0)` of the host side) straight into a gradient segment; with
@@ -581,7 +592,11 @@ int nesvor_sum_rows_multi(const float* const* in, float* const* out, const int* 
 #define NESVOR_STEP_SPAN_HASHGRID_BWD_AGGREGATE 7
 #define NESVOR_STEP_SPAN_HASHGRID_BWD_OWNER 8   /* the owner pass; with the fused optimizer: owner pass + the table's AdamW step */
 #define NESVOR_STEP_SPAN_PSF_BWD 9
-#define NESVOR_STEP_TIMED_SPANS 10
+#define NESVOR_STEP_SPAN_HASHGRID_FWD_LATE 10   /* pipelined table update (round 6): the forward of the levels the previous step's owner pass
+                                                   finished LAST; NESVOR_STEP_SPAN_HASHGRID_FWD then covers the other levels only */
+#define NESVOR_STEP_SPAN_HASHGRID_UNION 11      /* pipelined table update: from the start of the PREVIOUS step's owner pass to the end of this
+                                                   step's hash-grid forward - the time the device spends on those overlapped launches */
+#define NESVOR_STEP_TIMED_SPANS 12
 typedef struct {
   nesvor_grid_t grid;
   nesvor_mlp_t density, sigma, bias_net;   /* weights / biases: the model's parameters; bf16_operands: evaluation mode */

@@ -178,6 +178,8 @@ _SIGNATURES = {
     "nesvor_step_prologue_pose": ([_P] * 5 + [c_int, c_int, _P, _P, _P, _P], c_int),
     "nesvor_step_epilogue": ([_P] * 6 + [c_float, _P, _P, _P, _P, c_int, c_int, c_float, c_float, _P], c_int),
     "nesvor_hashgrid_backward_adamw": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P, _P, _P, _P, POINTER(AdamwT), _P], c_int),
+    "nesvor_hashgrid_backward_adamw_levels": ([POINTER(GridT), _P, _P, _P, _P, _P, c_int64, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P, POINTER(AdamwT), _P], c_int),
+    "nesvor_hashgrid_forward_levels": ([POINTER(GridT), _P, _P, _P, c_int64, c_int, _P, c_int, c_int, _P], c_int),
     "nesvor_adamw_step": (
         [_P, _P, _P, _P, c_int64] + [c_float] * 8 + [c_int, _P],
         c_int,

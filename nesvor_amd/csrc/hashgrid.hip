@@ -338,7 +338,8 @@ template <int F, int LAYOUT>
 __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g, const float* __restrict__ u,
                                                           const float* __restrict__ table, float* __restrict__ pe, int64_t N,
                                                           float* __restrict__ pe_absmax,  // optional: raised to max |pe| (the density network's input bound)
-                                                          const uint32_t* __restrict__ perm = nullptr, float* __restrict__ rows = nullptr) {
+                                                          const uint32_t* __restrict__ perm = nullptr, float* __restrict__ rows = nullptr,
+                                                          int level_begin = 0, int level_stop = NESVOR_MAX_LEVELS) {  // levels [level_begin, min(level_stop, L)): see nesvor_hashgrid_forward_levels
 #ifndef NESVOR_FWD_CLOUD_SLOTS
 #define NESVOR_FWD_CLOUD_SLOTS 512
 #endif
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
   const int64_t i = perm != nullptr ? (int64_t)perm[si] : slot_i;  // the point (output index); == slot_i without an order
   const int64_t ii = perm != nullptr ? i : si;
   const int L = g.n_levels, E = L * F;
+  const int lb = level_begin, le = min(level_stop, L);  // (uniform kernel arguments)
   const float ux = u[3 * ii], uy = u[3 * ii + 1], uz = u[3 * ii + 2];
   {
     float lo[3] = {ux, uy, uz}, hi[3] = {ux, uy, uz};
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
 #pragma unroll
       for (int q = 0; q < 8; ++q) lbox[tid][q] = b[q];
     }
-    const RoundSchedule rs = round_schedule(b[6], 0u, 0, L, tid, (uint32_t)kSlots, 0xFFFFFFFFu, kMaxGroup);
+    const RoundSchedule rs = round_schedule(b[6], 0u, lb, le, tid, (uint32_t)kSlots, 0xFFFFFFFFu, kMaxGroup);
     if (tid == 0) box_end_s = rs.box_end;
     if (tid < NESVOR_MAX_LEVELS) { slot_off[tid] = rs.slot_off; grp_end[tid] = rs.grp_end; rnd_slots[tid] = rs.rnd_slots; }
   }
@@ -490,8 +492,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
       }
     }
   };
-  if (box_end > 0) {
-    int ra = 0, rb = (int)sgpr(grp_end[0]), buf = 0;
+  if (box_end > lb) {
+    int ra = lb, rb = (int)sgpr(grp_end[lb]), buf = 0;
     {
       float feat[NRB][F];
       fetch_round(ra, rb, feat);
@@ -528,8 +530,8 @@ __global__ __launch_bounds__(256) void hashgrid_fwd_cloud(const nesvor_grid_t g,
   }
   // levels whose box does not fit the copy: two levels at a time, 16 independent gathers per lane in flight
 #pragma unroll 1
-  for (int lv = box_end; lv < L; lv += 2) {
-    const bool two = lv + 1 < L;
+  for (int lv = box_end; lv < le; lv += 2) {
+    const bool two = lv + 1 < le;
     const LevelParams p0 = load_level(g, lv), p1 = load_level(g, two ? lv + 1 : lv);
     const CellPos c0 = locate(p0, ux, uy, uz), c1 = locate(p1, ux, uy, uz);
     const float* tab0 = table + (size_t)p0.offset * F;
@@ -1651,7 +1653,8 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
                                                           const uint32_t* __restrict__ tails,
                                                           const uint32_t* __restrict__ records,
                                                           float* __restrict__ grad_table, const OwnerAdam adam,
-                                                          uint32_t id_stride) {  // workgroup id -> (id * id_stride) mod grid: coprime to the grid size (1: identity)
+                                                          uint32_t id_stride,  // workgroup id -> (id * id_stride) mod grid: coprime to the grid size (1: identity)
+                                                          uint32_t wg_base) {  // flat id of the launch's first workgroup (a launch for a level range starts at its first level's)
   __shared__ __attribute__((aligned(16))) float acc[kOwnerLdsFloats];
   __shared__ uint32_t ticket_s;
   const int tid = threadIdx.x;
@@ -1663,7 +1666,7 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
 #ifndef NESVOR_OWNER_FINE_FIRST
 #define NESVOR_OWNER_FINE_FIRST 0
 #endif
-  uint32_t wg = (uint32_t)(((uint64_t)blockIdx.x * id_stride) % gridDim.x);
+  uint32_t wg = (uint32_t)(((uint64_t)blockIdx.x * id_stride) % gridDim.x) + wg_base;
   int level = NESVOR_OWNER_FINE_FIRST ? g.n_levels - 1 : 0;
   uint32_t spl = 0;
   for (;; level += NESVOR_OWNER_FINE_FIRST ? -1 : 1) {
@@ -1927,9 +1930,9 @@ __global__ __launch_bounds__(kOwnerThreads) void hashgrid_bwd_owner(const nesvor
   }
 }
 
-inline uint32_t owner_grid(const nesvor_grid_t* g, const BwdPlan& plan) {
+inline uint32_t owner_grid(const nesvor_grid_t* g, const BwdPlan& plan, int l0 = 0, int l1 = NESVOR_MAX_LEVELS) {  // workgroups of levels [l0, l1)
   uint32_t n = 0;
-  for (int l = 0; l < g->n_levels; ++l) n += plan.n_chunks[l] * ((plan.cap[l] * plan.n_sub + plan.slice[l] - 1) / plan.slice[l]);
+  for (int l = l0; l < g->n_levels && l < l1; ++l) n += plan.n_chunks[l] * ((plan.cap[l] * plan.n_sub + plan.slice[l] - 1) / plan.slice[l]);
   return n;
 }
 
@@ -2333,18 +2336,22 @@ owner_stage:
     // NESVOR_OWNER_STRIDE=<odd number> (A/B switch): deal the (level, chunk) pairs to the workgroup ids with that stride instead
     // of level by level; raised to the next number coprime to the grid size
     static const uint32_t want = []() { const char* e = getenv("NESVOR_OWNER_STRIDE"); return e ? (uint32_t)atoi(e) : 1u; }();
-    const uint32_t og = owner_grid(g, plan);
+    // only the workgroups of this launch's level range (a launch over all ids, the others returning at once, cost the pipelined
+    // table update of the training step 30 us per pair of launches: gpurun_out/r06g)
+    const uint32_t wg_base = NESVOR_OWNER_FINE_FIRST ? 0u : owner_grid(g, plan, 0, plan.level_begin);
+    const uint32_t og = NESVOR_OWNER_FINE_FIRST ? owner_grid(g, plan) : owner_grid(g, plan, plan.level_begin, plan.level_end);
+    if (og == 0u) return (int)hipGetLastError();
     uint32_t id_stride = want < 1u ? 1u : want;
     auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
     while (id_stride > 1u && gcd(id_stride, og) != 1u) ++id_stride;
     if (adam != nullptr) {
       oa = *adam;
       oa.done = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + 2 * kTailBytes);
-      hipLaunchKernelGGL((hashgrid_bwd_owner<F, true, true>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt, oa, id_stride);
+      hipLaunchKernelGGL((hashgrid_bwd_owner<F, true, true>), dim3(og), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt, oa, id_stride, wg_base);
     } else if (coalesced)
-      hipLaunchKernelGGL((hashgrid_bwd_owner<F, true>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt, oa, id_stride);
+      hipLaunchKernelGGL((hashgrid_bwd_owner<F, true>), dim3(og), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt, oa, id_stride, wg_base);
     else
-      hipLaunchKernelGGL((hashgrid_bwd_owner<F, false>), dim3(owner_grid(g, plan)), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt, oa, id_stride);
+      hipLaunchKernelGGL((hashgrid_bwd_owner<F, false>), dim3(og), dim3(kOwnerThreads), 0, st, *g, plan, tails, records, gt, oa, id_stride, wg_base);
   }
   return (int)hipGetLastError();
 }
@@ -2454,6 +2461,25 @@ extern "C" int nesvor_hashgrid_forward(const nesvor_grid_t* grid, const float* u
   return nesvor_hashgrid_forward_bounded(grid, u, table, pe, N, layout, nullptr, stream);
 }
 
+namespace {
+template <int F, int LAYOUT>
+int launch_fwd_levels(const nesvor_grid_t* g, const float* u, const float* table, float* pe, int64_t N, float* pe_absmax, int lb, int le,
+                      hipStream_t st) {
+  hipLaunchKernelGGL((hashgrid_fwd_cloud<F, LAYOUT>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, *g, u, table, pe, N, pe_absmax,
+                     (const uint32_t*)nullptr, (float*)nullptr, lb, le);
+  return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int nesvor_hashgrid_forward_levels(const nesvor_grid_t* grid, const float* u, const float* table, float* pe, int64_t N,
+                                              int layout, float* pe_absmax, int level_begin, int level_end, void* stream) {
+  if (N <= 0) return 0;
+  if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
+  if (level_begin < 0 || level_end > grid->n_levels || level_begin >= level_end) return (int)hipErrorInvalidValue;
+  layout &= NESVOR_LAYOUT_MASK;
+  DISPATCH_F_LAYOUT(launch_fwd_levels, grid, u, table, pe, N, pe_absmax, level_begin, level_end, (hipStream_t)stream);
+}
+
 extern "C" int64_t nesvor_hashgrid_forward_workspace_bytes(const nesvor_grid_t* grid, int64_t N, int layout) {
   if (grid == nullptr || N <= 0) return 0;
   if (!(layout & NESVOR_LAYOUT_UNCLUSTERED)) return 0;
@@ -2558,8 +2584,21 @@ extern "C" int nesvor_hashgrid_backward_adamw(const nesvor_grid_t* grid, const f
                                               float* grad_table, float* grad_u, int64_t N, int layout, void* workspace,
                                               int stages, const float* queue_scale, const float* dy_bound, float* exp_avg,
                                               float* exp_avg_sq, const nesvor_adamw_t* adam, void* stream) {
+  return nesvor_hashgrid_backward_adamw_levels(grid, u, table, dpe, grad_table, grad_u, N, layout, workspace, stages, 0, grid->n_levels,
+                                               queue_scale, dy_bound, exp_avg, exp_avg_sq, adam, stream);
+}
+
+extern "C" int nesvor_hashgrid_backward_adamw_levels(const nesvor_grid_t* grid, const float* u, float* table, const float* dpe,
+                                                     float* grad_table, float* grad_u, int64_t N, int layout, void* workspace,
+                                                     int stages, int level_begin, int level_end, const float* queue_scale,
+                                                     const float* dy_bound, float* exp_avg, float* exp_avg_sq, const nesvor_adamw_t* adam,
+                                                     void* stream) {
   if (grid->n_levels <= 0 || grid->n_levels > NESVOR_MAX_LEVELS) return (int)hipErrorInvalidValue;
   if (N <= 0 || workspace == nullptr || (stages & ~3) != 0 || (stages & 3) == 0) return (int)hipErrorInvalidValue;
+  if (level_begin < 0 || level_end > grid->n_levels || level_begin >= level_end) return (int)hipErrorInvalidValue;
+  // (a level range is for the OWNER stage alone - stages == 2: the table's update level range by level range, so that the next
+  //  forward can start on the levels that are done; the aggregation stage always covers every level)
+  if ((level_begin != 0 || level_end != grid->n_levels) && stages != 2) return (int)hipErrorInvalidValue;
   if (table == nullptr || grad_table == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr || adam == nullptr) return (int)hipErrorInvalidValue;
   OwnerAdam oa;
   oa.param = table; oa.exp_avg = exp_avg; oa.exp_avg_sq = exp_avg_sq; oa.done = nullptr;
@@ -2567,6 +2606,6 @@ extern "C" int nesvor_hashgrid_backward_adamw(const nesvor_grid_t* grid, const f
                         adam->bias_correction2, adam->grad_scale);
   const int hints = layout & (NESVOR_LAYOUT_UNCLUSTERED | NESVOR_LAYOUT_DY_SCRATCH);
   layout &= NESVOR_LAYOUT_MASK;
-  DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages, 0, grid->n_levels, queue_scale,
+  DISPATCH_F_LAYOUT(launch_bwd_owner, grid, u, table, dpe, grad_table, grad_u, N, workspace, stages, level_begin, level_end, queue_scale,
                     dy_bound, &oa, (hipStream_t)stream, hints);
 }

@@ -26,7 +26,12 @@ namespace {
 
 struct StepCtx {
   nesvor_step_t d;
-  hipEvent_t ev_fork, ev_pose, ev_agg, ev_owner, ev_bwd, ev_sums, ev_norms, ev_sg0, ev_sg1;
+  hipEvent_t ev_fork, ev_pose, ev_agg, ev_owner, ev_bwd, ev_sums, ev_norms, ev_sg0, ev_sg1, ev_owner_early;
+  // Pipelined table update (round 6): the owner pass of the previous run went out as two launches - levels [0, pipe_level), event
+  // ev_owner_early, then the rest, event ev_owner - and this run's hash-grid forward follows it level range by level range
+  int pending_pipe_level = 0;
+  hipEvent_t tu0[2] = {nullptr, nullptr};  // timing: start of a run's owner pass (double-buffered: read by the NEXT run's union span)
+  unsigned run_no = 0;
   bool head_on_side = false;  // (NESVOR_STEP_HEAD=side: phase 2 of a split run must join what phase 1 forked)
   bool sums_on_side = false;  // the networks' parameter-gradient sums of the current iteration were left on the side stream
   bool pending_join = false;  // a table update of the previous run is still on the side stream (NESVOR_STEP_DEFER_JOIN)
@@ -115,7 +120,8 @@ extern "C" void* nesvor_step_create(const nesvor_step_t* desc) {
   StepCtx* c = new (std::nothrow) StepCtx;
   if (c == nullptr) return nullptr;
   c->d = *desc;
-  hipEvent_t* evs[9] = {&c->ev_fork, &c->ev_pose, &c->ev_agg, &c->ev_owner, &c->ev_bwd, &c->ev_sums, &c->ev_norms, &c->ev_sg0, &c->ev_sg1};
+  hipEvent_t* evs[10] = {&c->ev_fork, &c->ev_pose, &c->ev_agg, &c->ev_owner, &c->ev_bwd, &c->ev_sums, &c->ev_norms, &c->ev_sg0, &c->ev_sg1,
+                         &c->ev_owner_early};
   for (hipEvent_t* e : evs) {
     if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
   }
@@ -133,6 +139,7 @@ extern "C" int nesvor_step_timing(void* handle, int on) {
   if (on && c->t0[0] == nullptr) {
     for (int k = 0; k < NESVOR_STEP_TIMED_SPANS; ++k)
       if (hipEventCreate(&c->t0[k]) != hipSuccess || hipEventCreate(&c->t1[k]) != hipSuccess) return (int)hipGetLastError();
+    if (hipEventCreate(&c->tu0[0]) != hipSuccess || hipEventCreate(&c->tu0[1]) != hipSuccess) return (int)hipGetLastError();
   }
   c->timing = on != 0;
   c->timed_run = false;
@@ -145,7 +152,9 @@ extern "C" int nesvor_step_timing_read(void* handle, float* ms) {
   if (!c->timed_run) return 0;
   for (int k = 0; k < NESVOR_STEP_TIMED_SPANS; ++k) {
     if (!c->span_used[k]) continue;
-    if (hipEventSynchronize(c->t1[k]) != hipSuccess || hipEventElapsedTime(&ms[k], c->t0[k], c->t1[k]) != hipSuccess) return (int)hipGetLastError();
+    // (the union span starts at the PREVIOUS run's owner pass: its first event is that run's tu0)
+    hipEvent_t e0 = k == NESVOR_STEP_SPAN_HASHGRID_UNION ? c->tu0[(c->run_no - 1u) & 1u] : c->t0[k];
+    if (hipEventSynchronize(c->t1[k]) != hipSuccess || hipEventElapsedTime(&ms[k], e0, c->t1[k]) != hipSuccess) return (int)hipGetLastError();
   }
   return 0;
 }
@@ -161,7 +170,8 @@ extern "C" void nesvor_step_destroy(void* handle) {
   StepCtx* c = static_cast<StepCtx*>(handle);
   (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_pose); (void)hipEventDestroy(c->ev_agg); (void)hipEventDestroy(c->ev_owner);
   (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_sums); (void)hipEventDestroy(c->ev_norms);
-  (void)hipEventDestroy(c->ev_sg0); (void)hipEventDestroy(c->ev_sg1);
+  (void)hipEventDestroy(c->ev_sg0); (void)hipEventDestroy(c->ev_sg1); (void)hipEventDestroy(c->ev_owner_early);
+  if (c->tu0[0] != nullptr) { (void)hipEventDestroy(c->tu0[0]); (void)hipEventDestroy(c->tu0[1]); }
   for (int k = 0; k < NESVOR_STEP_TIMED_SPANS; ++k) {
     if (c->t0[k] != nullptr) (void)hipEventDestroy(c->t0[k]);
     if (c->t1[k] != nullptr) (void)hipEventDestroy(c->t1[k]);
@@ -276,6 +286,23 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
       NESVOR_TRY(nesvor_psf_transform_forward_rng_gather(mat, slice_idx, xyz, d.psf_sigma, seed, offset, d.bounding_box, d.x, d.u, B, S,
                                                          d.ks > 0 ? d.slice_embedding : nullptr, d.ks > 0 ? d.se : nullptr, d.ks, main));
     }
+    const int pipe = ctx->pending_join ? ctx->pending_pipe_level : 0;
+    if (pipe > 0 && pipe < L && S >= 128) {
+      // the previous run's table update arrives level range by level range: the forward of levels [0, pipe) runs while the owner
+      // pass still updates the finer ones
+      if (hipStreamWaitEvent(main, ctx->ev_owner_early, 0) != hipSuccess) return (int)hipGetLastError();
+      {
+        Span t(ctx, NESVOR_STEP_SPAN_HASHGRID_FWD, main);
+        NESVOR_TRY(nesvor_hashgrid_forward_levels(&d.grid, d.u, d.table, d.pe, N, layout, split_d ? prep_d + NESVOR_MLP_PREP_XB : nullptr, 0, pipe, main));
+      }
+      if (hipStreamWaitEvent(main, ctx->ev_owner, 0) != hipSuccess) return (int)hipGetLastError();
+      {
+        Span t(ctx, NESVOR_STEP_SPAN_HASHGRID_FWD_LATE, main);
+        NESVOR_TRY(nesvor_hashgrid_forward_levels(&d.grid, d.u, d.table, d.pe, N, layout, split_d ? prep_d + NESVOR_MLP_PREP_XB : nullptr, pipe, L, main));
+      }
+      if (ctx->timing) { (void)hipEventRecord(ctx->t1[NESVOR_STEP_SPAN_HASHGRID_UNION], main); ctx->span_used[NESVOR_STEP_SPAN_HASHGRID_UNION] = true; }
+      ctx->pending_join = false;
+    } else {
     if (ctx->pending_join) {  // the previous run left its table update on the side stream
       if (hipStreamWaitEvent(main, ctx->ev_owner, 0) != hipSuccess) return (int)hipGetLastError();
       ctx->pending_join = false;
@@ -284,6 +311,7 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
       Span t(ctx, NESVOR_STEP_SPAN_HASHGRID_FWD, main);
       NESVOR_TRY(nesvor_hashgrid_forward_bounded(&d.grid, d.u, d.table, d.pe, N, layout | (S >= 128 ? NESVOR_LAYOUT_CLUSTERED : 0),
                                                  split_d ? prep_d + NESVOR_MLP_PREP_XB : nullptr, main));
+    }
     }
     if (head_on_side && any_split && hipStreamWaitEvent(main, ctx->ev_norms, 0) != hipSuccess) return (int)hipGetLastError();
     {
@@ -398,9 +426,29 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
       if (hipEventRecord(ctx->ev_agg, main) != hipSuccess || hipStreamWaitEvent(side, ctx->ev_agg, 0) != hipSuccess) return (int)hipGetLastError();
       owner_stream = side;
     }
+    // Pipelined table update (round 6; NESVOR_STEP_PIPE_LEVEL=<level>, default 0 = OFF): when this run leaves the table's update on the
+    // side stream for the next run to join (NESVOR_STEP_DEFER_JOIN), the owner pass goes out as TWO launches - levels [0, pipe), then
+    // the rest - and the next run's forward starts on the first range while the second is still being updated.  Owner pass (84 us
+    // with the table's AdamW) and forward (70 us) are strictly one after the other on the step's critical path, and both are
+    // latency-bound - yet MEASURED (tools/ab_pipe_level.sh, profiles/r06_ab_pipe_level.log, two alternating rounds): 0.944 ms ->
+    // 0.960-0.970 ms at pipe levels 11 / 12 / 14.  The overlapped owner launch stretches by 24 us for 44 us of forward (the two
+    // kernels contend: ~45 % overlap efficiency), the second forward launch repeats the set-up (44 + 44 us against 72), and the
+    // extra event hand-overs take the rest.  Kept as a switch; off.
+    static const int pipe_level = []() { const char* e = getenv("NESVOR_STEP_PIPE_LEVEL"); return e != nullptr ? atoi(e) : 0; }();
+    const int pipe = (fuse_adamw && overlap_owner && defer_join && S >= 128 && pipe_level > 0 && pipe_level < L) ? pipe_level : 0;
+    ctx->pending_pipe_level = pipe;
+    if (ctx->timing) (void)hipEventRecord(ctx->tu0[ctx->run_no & 1u], owner_stream);
     {
       Span t(ctx, NESVOR_STEP_SPAN_HASHGRID_BWD_OWNER, owner_stream);  // (with fuse_adamw: the owner pass AND the table's AdamW step)
-      if (fuse_adamw)
+      if (pipe > 0) {
+        NESVOR_TRY(nesvor_hashgrid_backward_adamw_levels(&d.grid, d.u, d.flat_param + table_off, d.dpe, d.g_table, du, N, layout, d.hg_workspace,
+                                                         2, 0, pipe, d.queue_scale, dpe_bound, d.flat_exp_avg + table_off,
+                                                         d.flat_exp_avg_sq + table_off, adam, owner_stream));
+        if (hipEventRecord(ctx->ev_owner_early, side) != hipSuccess) return (int)hipGetLastError();
+        NESVOR_TRY(nesvor_hashgrid_backward_adamw_levels(&d.grid, d.u, d.flat_param + table_off, d.dpe, d.g_table, du, N, layout, d.hg_workspace,
+                                                         2, pipe, L, d.queue_scale, dpe_bound, d.flat_exp_avg + table_off,
+                                                         d.flat_exp_avg_sq + table_off, adam, owner_stream));
+      } else if (fuse_adamw)
         NESVOR_TRY(nesvor_hashgrid_backward_adamw(&d.grid, d.u, d.flat_param + table_off, d.dpe, d.g_table, du, N, layout, d.hg_workspace, 2,
                                                   d.queue_scale, dpe_bound, d.flat_exp_avg + table_off, d.flat_exp_avg_sq + table_off, adam,
                                                   owner_stream));
@@ -476,6 +524,7 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
                                    adam->eps, adam->weight_decay, adam->bias_correction1, adam->bias_correction2, adam->grad_scale, 1, main));
     }
   }
+  ++ctx->run_no;
   return (int)hipGetLastError();
 }
 

@@ -328,7 +328,8 @@ class DirectStep:
 
     # names of the spans nesvor_step_timing_read returns (NESVOR_STEP_SPAN_*), in order
     TIMED_SPANS = ("psf_transform_fwd", "hashgrid_fwd", "mlp_fwd_density", "mlp_fwd_sigma", "imaging_loss_bwd", "mlp_bwd_sigma",
-                   "mlp_bwd_density", "hashgrid_bwd_aggregate", "hashgrid_bwd_owner", "psf_transform_bwd")
+                   "mlp_bwd_density", "hashgrid_bwd_aggregate", "hashgrid_bwd_owner", "psf_transform_bwd", "hashgrid_fwd_late",
+                   "hashgrid_owner_fwd_union")
 
     def set_native_timing(self, on: bool) -> None:
         """HIP-event brackets around the launches of the one-call step, each on the stream its launch goes to (``nesvor_step_timing``:
