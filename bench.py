@@ -523,7 +523,9 @@ def main():
             # points, input gradient on: poses are optimised).  Bytes: SURVEY 8d's 2328 B/point; the owner launch of the product
             # step also takes the table's AdamW step (SURVEY 8d "other per-iter algorithmic traffic": 28 B per table parameter),
             # so both accountings of THOSE launches are first-class fields.
-            t_f, t_agg, t_own = kt.get("hashgrid_fwd", 0.0), kt.get("hashgrid_bwd_aggregate", 0.0), kt.get("hashgrid_bwd_owner", 0.0)
+            # (NESVOR_STEP_PIPE_LEVEL > 0 - off by default, measured slower - issues the forward as two launches: both are the forward)
+            t_f = kt.get("hashgrid_fwd", 0.0) + kt.get("hashgrid_fwd_late", 0.0)
+            t_agg, t_own = kt.get("hashgrid_bwd_aggregate", 0.0), kt.get("hashgrid_bwd_owner", 0.0)
             t_b = t_agg + t_own
             fwd_B, bwd_B, bwd_in_B = (12 + 32 * F * L + 4 * F * L), (12 + 4 * F * L + 32 * F * L), (32 * F * L + 12)
             adamw_bytes = 28 * n_table if product_timing else 0  # (the Python-issued owner pass carries no optimizer)

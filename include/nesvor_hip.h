@@ -443,6 +443,13 @@ int nesvor_mlp_wide_forward(const nesvor_mlp_wide_t* net, const float* xa, const
 int nesvor_mlp_wide_backward(const nesvor_mlp_wide_t* net, const float* xa, const float* xb, const float* dy,
                              float* const* saved_hidden, float* const* dpre_scratch, float* dxa, float* dxb, float* dw_partial,
                              int n_partial, int64_t N, void* stream);
+/* ... additionally raising the device scalar *dxb_absmax to max |dxb| (as nesvor_mlp_backward_bounded does; NULL: not wanted).  At
+ * width 64 the saved / dpre buffers have the fragment layout of nesvor_mlp_t's full save: nesvor_mlp_backward_bounded hands the
+ * shapes its wave-specialised kernel does not take (ragged N, samples per pixel or pixel features not in multiples of 16, three
+ * hidden layers) to this entry point - round 6 retired mlp.hip's own dX / dW launch pair. */
+int nesvor_mlp_wide_backward_bounded(const nesvor_mlp_wide_t* net, const float* xa, const float* xb, const float* dy,
+                                     float* const* saved_hidden, float* const* dpre_scratch, float* dxa, float* dxb,
+                                     float* dw_partial, int n_partial, int64_t N, float* dxb_absmax, void* stream);
 
 /* ------------------------------------------------------------------------
  * Imaging model + losses, value and gradient in one launch.  Replaces the tail of

@@ -171,6 +171,10 @@ _SIGNATURES = {
         [POINTER(MlpWideT), _P, _P, _P, POINTER(c_void_p), POINTER(c_void_p), _P, _P, _P, c_int, c_int64, _P],
         c_int,
     ),
+    "nesvor_mlp_wide_backward_bounded": (
+        [POINTER(MlpWideT), _P, _P, _P, POINTER(c_void_p), POINTER(c_void_p), _P, _P, _P, c_int, c_int64, _P, _P],
+        c_int,
+    ),
     "nesvor_imaging_loss": ([POINTER(LossT), _P], c_int),
     "nesvor_slice_grads_by_slice": ([_P] * 9 + [c_int, c_int, c_int, c_int, _P], c_int),
     "nesvor_slice_grads": ([_P] * 9 + [c_int, c_int, c_int, _P], c_int),

@@ -1068,199 +1068,8 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
   if (a.y_absmax != nullptr) publish_absmax_wg(a.y_absmax, y_mx);
 }
 
-// -------------------------------------------------------------- backward: dX
-// dY (out_dim, N) -> dpre of every hidden layer (fragment layout, saved for the dW pass) and the
-// input gradients.  Needs the saved post-ReLU fragments H[l] for the masks.
-template <int KB1>
-__global__ __launch_bounds__(256) void mlp_bwd_dx_kernel(const MlpArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int n_hidden = a.n_linear - 1;
-  const int k_in = a.k_a + a.k_b;
-  float* imgo = lds;                                    // W_out^T : ib = 4 (hidden), kb = 1 (out padded to 16)
-  float* imgh = imgo + kHB * 1 * 256;                   // W_l^T for l = 1..n_hidden-1 : 4 x 4
-  float* img1 = imgh + (n_hidden - 1) * kHB * kHB * 256;  // W_1^T : ib = KB1, kb = 4
-  build_image_T(imgo, a.W[n_hidden], a.out_dim, kWidth, kHB, 1);
-  for (int l = 1; l < n_hidden; ++l) build_image_T(imgh + (l - 1) * kHB * kHB * 256, a.W[l], kWidth, kWidth, kHB, kHB);
-  build_image_T(img1, a.W[0], kWidth, k_in, KB1, kHB);
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 15, q = lane >> 4;
-  const int64_t n_groups = (a.N + 15) / 16;
-  const int64_t n_tiles = (n_groups + 4 * kG - 1) / (4 * kG);
-  float dx_mx = 0.f;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t g0 = (tile * 4 + wave) * kG;
-    f32x4 go[kG][1];
-#pragma unroll
-    for (int g = 0; g < kG; ++g) {
-      const int64_t n = (g0 + g) * 16 + j;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        go[g][0][r] = (n < a.N && 4 * q + r < a.out_dim) ? a.y[(size_t)(4 * q + r) * a.N + n] : 0.f;
-    }
-    f32x4 d[kG][kHB];
-#pragma unroll
-    for (int g = 0; g < kG; ++g)
-#pragma unroll
-      for (int ib = 0; ib < kHB; ++ib) d[g][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-    apply_layer<1, kHB>(imgo, go, d, lane);
-    for (int l = n_hidden - 1;; --l) {
-      // d holds dL/dH_l (post-ReLU); mask -> dpre_l, save
-#pragma unroll
-      for (int g = 0; g < kG; ++g) {
-        const bool ok = g0 + g < n_groups;
-#pragma unroll
-        for (int ib = 0; ib < kHB; ++ib) {
-          const size_t off = (((size_t)(g0 + g) * kHB + ib) * 64 + lane) * 4;
-          f32x4 hv = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (ok) hv = *reinterpret_cast<const f32x4*>(a.H[l] + off);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) d[g][ib][r] = hv[r] > 0.f ? d[g][ib][r] : 0.f;
-          if (ok) *reinterpret_cast<f32x4*>(a.dpre[l] + off) = d[g][ib];
-        }
-      }
-      if (l == 0) break;
-      f32x4 d2[kG][kHB];
-#pragma unroll
-      for (int g = 0; g < kG; ++g)
-#pragma unroll
-        for (int ib = 0; ib < kHB; ++ib) d2[g][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-      apply_layer<kHB, kHB>(imgh + (l - 1) * kHB * kHB * 256, d, d2, lane);
-#pragma unroll
-      for (int g = 0; g < kG; ++g)
-#pragma unroll
-        for (int ib = 0; ib < kHB; ++ib) d[g][ib] = d2[g][ib];
-    }
-    if (a.dxa != nullptr || a.dxb != nullptr) {
-      f32x4 dx[kG][KB1];
-#pragma unroll
-      for (int g = 0; g < kG; ++g)
-#pragma unroll
-        for (int ib = 0; ib < KB1; ++ib) dx[g][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-      apply_layer<kHB, KB1>(img1, d, dx, lane);
-#pragma unroll
-      for (int g = 0; g < kG; ++g) {
-        const int64_t n = (g0 + g) * 16 + j;
-        if (n >= a.N) continue;
-        if (a.dx_absmax != nullptr) track_absmax<KB1>(a, dx[g], dx_mx);
-#pragma unroll
-        for (int ib = 0; ib < KB1; ++ib)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int kk = 16 * ib + 4 * q + r;
-            if (kk < a.k_a) {
-              if (a.dxa != nullptr) a.dxa[(size_t)n * a.k_a + kk] = dx[g][ib][r];
-            } else if (kk - a.k_a < a.k_b) {
-              if (a.dxb != nullptr) a.dxb[(size_t)(kk - a.k_a) * a.N + n] = dx[g][ib][r];
-            }
-          }
-      }
-    }
-  }
-  if (a.dx_absmax != nullptr) publish_absmax(a, dx_mx);
-}
-
-// ----------------------------------------------------------- backward: dW, db
-// One workgroup accumulates, layer after layer, over its share of the sample groups:
-//   dW_l[out][in] = sum_n dY_l[out][n] X_l[in][n]   (MFMA rows = out, cols = in, k = samples)
-//   db_l[out]     = sum_n dY_l[out][n]
-// and writes its partial sums to dW_partial[wg][...] (PyTorch parameter order W0,b0,W1,b1,...);
-// the (n_wg x params) partials are summed by the caller.  No atomics anywhere.
-__device__ __forceinline__ float frag_elem(const float* __restrict__ F, int64_t gi, int f, int s) {
-  // element (feature f, sample s) of group gi in the saved fragment layout
-  return F[(((size_t)gi * kHB + (f >> 4)) * 64 + ((f & 15) >> 2) * 16 + s) * 4 + (f & 3)];
-}
-
-template <int KB1>
-__global__ __launch_bounds__(256) void mlp_bwd_dw_kernel(const MlpArgs a) {
-  __shared__ float red[4][kHB * 256];  // per-wave staging of one accumulator column (16 KB)
-  const int n_hidden = a.n_linear - 1;
-  const int k_in = a.k_a + a.k_b;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = lane & 15, q = lane >> 4;
-  const int64_t n_groups = (a.N + 15) / 16;
-  float* out = a.dW_partial + (size_t)blockIdx.x * a.total_params;
-  int poff = 0;
-  for (int l = 0; l < a.n_linear; ++l) {
-    const int in_dim = (l == 0) ? k_in : kWidth;
-    const int out_dim = (l == n_hidden) ? a.out_dim : kWidth;
-    const int IB = (l == 0) ? KB1 : kHB;   // runtime, <= 4
-    const int OB = (l == n_hidden) ? 1 : kHB;
-    f32x4 acc[kHB][4];  // [ob][ib], ib up to max(KB1, 4) <= 4
-    float db[kHB];
-#pragma unroll
-    for (int ob = 0; ob < kHB; ++ob) {
-      db[ob] = 0.f;
-#pragma unroll
-      for (int ib = 0; ib < 4; ++ib) acc[ob][ib] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (int64_t gi = (int64_t)blockIdx.x * 4 + wave; gi < n_groups; gi += (int64_t)gridDim.x * 4) {
-      // operands: lane (i,q) holds feature 16 b + i of samples 4q .. 4q+3 of the group
-      float av[kHB][4], bv[4][4];
-#pragma unroll
-      for (int ob = 0; ob < kHB; ++ob) {
-        if (ob < OB) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int64_t n = gi * 16 + 4 * q + t;
-            float v;
-            if (l == n_hidden) v = (n < a.N && i < a.out_dim) ? a.y[(size_t)i * a.N + n] : 0.f;
-            else v = (n < a.N) ? frag_elem(a.dpre[l], gi, 16 * ob + i, 4 * q + t) : 0.f;
-            av[ob][t] = v;
-          }
-          db[ob] += (av[ob][0] + av[ob][1]) + (av[ob][2] + av[ob][3]);
-        }
-      }
-#pragma unroll
-      for (int ib = 0; ib < 4; ++ib) {
-        if (ib < IB) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int64_t n = min(gi * 16 + 4 * q + t, a.N - 1);
-            bv[ib][t] = (l == 0) ? fetch_input(a, 16 * ib + i, n) : frag_elem(a.H[l - 1], gi, 16 * ib + i, 4 * q + t);
-          }
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int ob = 0; ob < kHB; ++ob)
-#pragma unroll
-          for (int ib = 0; ib < 4; ++ib)
-            if (ob < OB && ib < IB) acc[ob][ib] = mfma4(av[ob][t], bv[ib][t], acc[ob][ib]);
-    }
-    // reduce the four waves' partials through LDS, one output block at a time, and write W (out,in)
-#pragma unroll
-    for (int ob = 0; ob < kHB; ++ob) {  // static index into acc[]; OB is workgroup-uniform
-      if (ob >= OB) break;
-      __syncthreads();
-#pragma unroll
-      for (int ib = 0; ib < 4; ++ib)
-        *reinterpret_cast<f32x4*>(&red[wave][(ib * 64 + lane) * 4]) = acc[ob][ib];
-      __syncthreads();
-      for (int e = threadIdx.x; e < IB * 256; e += blockDim.x) {
-        const float s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-        const int r = e & 3, ln = (e >> 2) & 63, ib = e >> 8;
-        const int o = 16 * ob + 4 * (ln >> 4) + r, in = 16 * ib + (ln & 15);
-        if (o < out_dim && in < in_dim) out[poff + o * in_dim + in] = s;
-      }
-    }
-    // bias grads: sum over q (lanes i, i+16, i+32, i+48) and over waves
-    __syncthreads();
-#pragma unroll
-    for (int ob = 0; ob < kHB; ++ob) red[wave][ob * 64 + lane] = db[ob];
-    __syncthreads();
-    for (int e = threadIdx.x; e < OB * 16; e += blockDim.x) {
-      const int ob = e >> 4, ii = e & 15;
-      float s = 0.f;
-      for (int w = 0; w < 4; ++w)
-        for (int qq = 0; qq < 4; ++qq) s += red[w][ob * 64 + qq * 16 + ii];
-      if (16 * ob + ii < out_dim) out[poff + out_dim * in_dim + 16 * ob + ii] = s;
-    }
-    poff += out_dim * in_dim + out_dim;
-  }
-}
+// (backward as a dX launch + a dW launch, for the shapes the wave-specialised kernel below does not take: since round 6 the wide
+//  kernels of csrc/mlp_wide.hip at width 64 - same fragment layouts, one implementation instead of two; nesvor_mlp_backward_bounded)
 
 // ------------------------------------------------- backward, fused dX + dW + db
 // Staging tiles of the wave-specialised backward (fp32 / bf16-operand modes): 16 x 16 fp32, padded rows.
@@ -2290,10 +2099,6 @@ size_t fwd_lds_bytes(int n_linear, int kb1) {
   constexpr size_t blk = 256;
   return sizeof(float) * ((size_t)kHB * kb1 * blk + (size_t)(n_hidden - 1) * kHB * kHB * blk + kHB * blk + (size_t)n_linear * kWidth + kWidth);
 }
-size_t bwd_lds_bytes(int n_linear, int kb1) {
-  const int n_hidden = n_linear - 1;
-  return sizeof(float) * ((size_t)kHB * 256 + (size_t)(n_hidden - 1) * kHB * kHB * 256 + (size_t)kb1 * kHB * 256);
-}
 
 // persistent_tiles > 0: the kernel walks `persistent_tiles` tiles with a grid-stride loop and wants as many workgroups as the
 // device holds at once - CUs x min(occupancy of THIS instantiation at this LDS size, NESVOR_FWD_WGS_PER_CU); `grid` is then
@@ -2628,11 +2433,11 @@ extern "C" int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float*
     return (int)hipErrorInvalidValue;
   }
   if (a.bf16) return (int)hipErrorInvalidValue;
-  const int64_t n_tiles = ((N + 15) / 16 + 4 * kG - 1) / (4 * kG);
-  dim3 grid((unsigned)(n_tiles < 1024 ? n_tiles : 1024));
-  e = launch_kb(mlp_bwd_dx_kernel<1>, mlp_bwd_dx_kernel<2>, mlp_bwd_dx_kernel<3>, mlp_bwd_dx_kernel<4>, kb1, grid,
-                bwd_lds_bytes(a.n_linear, kb1), (hipStream_t)stream, a);
-  if (e) return e;
-  return launch_kb(mlp_bwd_dw_kernel<1>, mlp_bwd_dw_kernel<2>, mlp_bwd_dw_kernel<3>, mlp_bwd_dw_kernel<4>, kb1,
-                   dim3((unsigned)n_partial), 0, (hipStream_t)stream, a);
+  // dX launch + dW launch on fp32 MFMAs (always a valid evaluation of the split mode): the wide kernels at width 64
+  nesvor_mlp_wide_t w{};
+  w.width = kWidth; w.n_hidden = net->n_hidden; w.out_dim = net->out_dim; w.k_a = net->k_a; w.k_b = net->k_b; w.b_row0 = net->b_row0;
+  w.samples_per_pixel = net->samples_per_pixel;
+  for (int l = 0; l <= net->n_hidden; ++l) { w.weight[l] = net->weight[l]; w.bias[l] = net->bias[l]; }
+  return nesvor_mlp_wide_backward_bounded(&w, xa, xb, dy, saved_hidden, dpre_scratch, dxa, dxb, dw_partial, n_partial, N,
+                                          dxb != nullptr ? dxb_absmax : nullptr, stream);
 }

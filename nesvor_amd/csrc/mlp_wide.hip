@@ -42,6 +42,7 @@ struct WideArgs {
   float* dxa;             // bwd: (N, k_a) per-sample gradient of the pixel features, or null
   float* dxb;             // bwd: (k_b, N), or null
   float* dW_partial;      // dW kernel: (n_wg, total_params)
+  float* dx_absmax;       // dX kernel, optional: device scalar raised (atomic max) to max |dxb| (nesvor_mlp_backward_bounded's contract)
   int64_t N;
   int n_linear, width, k_a, k_b, b_row0, out_dim, S, total_params;
 };
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(kWaves * 64) void wide_bwd_dx_kernel(const WideArgs
   const int64_t n_groups = (a.N + 15) / 16;
   const int64_t n_tiles = (n_groups + kWaves * kG - 1) / (kWaves * kG);
   const bool want_dx = a.dxa != nullptr || a.dxb != nullptr;
+  float dx_mx = 0.f;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t g0 = (tile * kWaves + wave) * kG;
     f32x4 d[kG][HB];  // the chain's state; block 0 first carries dY
@@ -281,11 +283,15 @@ __global__ __launch_bounds__(kWaves * 64) void wide_bwd_dx_kernel(const WideArgs
             if (kk < a.k_a) {
               if (a.dxa != nullptr) a.dxa[(size_t)n * a.k_a + kk] = d[g][ib][r];
             } else if (kk - a.k_a < a.k_b) {
-              if (a.dxb != nullptr) a.dxb[(size_t)(kk - a.k_a) * a.N + n] = d[g][ib][r];
+              if (a.dxb != nullptr) { a.dxb[(size_t)(kk - a.k_a) * a.N + n] = d[g][ib][r]; dx_mx = fmaxf(dx_mx, fabsf(d[g][ib][r])); }
             }
           }
       }
     }
+  }
+  if (a.dx_absmax != nullptr && a.dxb != nullptr) {
+    dx_mx = wave_max(dx_mx);
+    if (lane == 0 && dx_mx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(a.dx_absmax), __float_as_uint(dx_mx));
   }
 }
 
@@ -468,6 +474,12 @@ extern "C" int nesvor_mlp_wide_forward(const nesvor_mlp_wide_t* net, const float
 extern "C" int nesvor_mlp_wide_backward(const nesvor_mlp_wide_t* net, const float* xa, const float* xb, const float* dy,
                                         float* const* saved_hidden, float* const* dpre_scratch, float* dxa, float* dxb,
                                         float* dw_partial, int n_partial, int64_t N, void* stream) {
+  return nesvor_mlp_wide_backward_bounded(net, xa, xb, dy, saved_hidden, dpre_scratch, dxa, dxb, dw_partial, n_partial, N, nullptr, stream);
+}
+
+extern "C" int nesvor_mlp_wide_backward_bounded(const nesvor_mlp_wide_t* net, const float* xa, const float* xb, const float* dy,
+                                                float* const* saved_hidden, float* const* dpre_scratch, float* dxa, float* dxb,
+                                                float* dw_partial, int n_partial, int64_t N, float* dxb_absmax, void* stream) {
   if (N <= 0) return 0;
   WideArgs a;
   int e = fill(&a, net, N);
@@ -476,6 +488,7 @@ extern "C" int nesvor_mlp_wide_backward(const nesvor_mlp_wide_t* net, const floa
       (a.k_a > 0 && xa == nullptr))
     return (int)hipErrorInvalidValue;
   a.xa = xa; a.xb = xb; a.y = const_cast<float*>(dy); a.dxa = a.k_a > 0 ? dxa : nullptr; a.dxb = dxb; a.dW_partial = dw_partial;
+  a.dx_absmax = dxb != nullptr ? dxb_absmax : nullptr;
   for (int l = 0; l < net->n_hidden; ++l) {
     if (saved_hidden[l] == nullptr || dpre_scratch[l] == nullptr) return (int)hipErrorInvalidValue;
     a.H[l] = saved_hidden[l]; a.dpre[l] = dpre_scratch[l];
