@@ -1131,6 +1131,19 @@ __device__ __forceinline__ void read_planes2(const float* tile, int i, int q, ui
 }
 
 
+// -DNESVOR_MLP_TIMELINE=1 (tools/mlp_timeline.py): lane 0 of every wave of the first 64 workgroups of the wave-specialised backward
+// records s_memtime (100 MHz) at the start / end of its group loop and the ticks it spent inside pair_sync() and behind the
+// prefetch waits; nesvor_debug_mlp_timeline() copies them out.  Who waits for whom in a wave pair, without a profiler in the way.
+#ifndef NESVOR_MLP_TIMELINE
+#define NESVOR_MLP_TIMELINE 0
+#endif
+#if NESVOR_MLP_TIMELINE
+__device__ unsigned long long g_mlp_timeline[64][8][4];
+#define MLP_TL(x) x
+#else
+#define MLP_TL(x)
+#endif
+
 // ------------------------------------------------- backward, wave-specialised (dX chain | dW)
 // The fused kernel above runs ONE wave per SIMD (its dW accumulators fill the register file), so every LDS
 // round trip, every layer-boundary dependency and every bit of index arithmetic is paid with an idle matrix
@@ -1368,7 +1381,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
   __shared__ int arrive[2][4];
   if (threadIdx.x < 8) arrive[threadIdx.x >> 2][threadIdx.x & 3] = 0;
   __syncthreads();
+  MLP_TL(unsigned long long tl_sync = 0ull; unsigned long long tl_wait = 0ull; unsigned long long tl_t0 = 0ull;)
   auto pair_sync = [&](int it) __attribute__((always_inline)) {
+    MLP_TL(const unsigned long long ts_ = __builtin_amdgcn_s_memtime();)
     if (NESVOR_MLP_PAIR_SYNC) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) __hip_atomic_store(&arrive[role][pair], it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1381,6 +1396,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     } else {
       __syncthreads();
     }
+    MLP_TL(tl_sync += __builtin_amdgcn_s_memtime() - ts_;)
   };
   // split mode: tile 0 (dY) fp32 without padding, the NH x 4 dpre tiles as fp16 planes (see stage_planes)
   constexpr bool PLANES = SPL;
@@ -1607,7 +1623,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             if (a.dx_absmax != nullptr) track_absmax<KB1>(a, dx, dx_mx);
             // drain the prefetch BEFORE the stores below: loads and stores share vmcnt, and the wait would otherwise
             // also cover the latency of these stores
+            MLP_TL(const unsigned long long tw_ = __builtin_amdgcn_s_memtime();)
             settle_group(gy_n, hs_n, mk_n);
+            MLP_TL(tl_wait += __builtin_amdgcn_s_memtime() - tw_;)
             store_dx_fast<KB1>(a, gi, j, q, dx);
           } else {
             settle_group(gy_n, hs_n, mk_n);
@@ -1631,6 +1649,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
       }
     float mk_a = 0.f, mk_b = 0.f;
     if (g_first < n_groups) { issue_group(g_first, gy_a, hs_a, mk_a); settle_group(gy_a, hs_a, mk_a); }
+    MLP_TL(tl_t0 = __builtin_amdgcn_s_memtime();)
     for (int it = 0; it <= n_it; it += 2) {
       chain_iter(it, gy_a, hs_a, mk_a, gy_b, hs_b, mk_b);
       if (it + 1 <= n_it) chain_iter(it + 1, gy_b, hs_b, mk_b, gy_a, hs_a, mk_a);
@@ -1775,7 +1794,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
             for (int ib = 0; ib < kHB; ++ib) acc_o[0][ib] = mfma32_f16(a_hl, bh[ib], acc_o[0][ib]);
           }
+          MLP_TL(const unsigned long long tw_ = __builtin_amdgcn_s_memtime();)
           settle_xc();
+          MLP_TL(tl_wait += __builtin_amdgcn_s_memtime() - tw_;)
         } else {
           await_loads();  // (as in the chain wave's iteration)
         }
@@ -1786,6 +1807,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) xcr[kb][r] = 0.f;
       if (g_first < n_groups) { issue_xc(g_first, xcr); settle_xc(); }
+      MLP_TL(tl_t0 = __builtin_amdgcn_s_memtime();)
       for (int it = 0; it <= n_it; ++it) dw_iter(it);
     } else {
     // B operands (layer inputs) of one group: lane (feature j, sample quad q) holds feature j of samples 4q..4q+3
@@ -1985,6 +2007,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
       }
     }
   }
+#if NESVOR_MLP_TIMELINE
+  if (blockIdx.x < 64u && lane == 0) {
+    unsigned long long* o = g_mlp_timeline[blockIdx.x][wave];
+    o[0] = tl_t0; o[1] = __builtin_amdgcn_s_memtime(); o[2] = tl_sync; o[3] = tl_wait;
+  }
+#endif
   // epilogue: per-workgroup partial sums in nn.Linear parameter order W0,b0,W1,b1,... (accumulators live in waves 4-7)
   const int slot = role == 1 ? pair : -1, chain = role == 0 ? pair : -1;
   float* out = a.dW_partial + (size_t)blockIdx.x * a.total_params;
@@ -2217,6 +2245,12 @@ bool ws_ok(const MlpArgs& a, const nesvor_mlp_t* net) {
 }
 
 }  // namespace
+
+#if NESVOR_MLP_TIMELINE
+extern "C" int nesvor_debug_mlp_timeline(unsigned long long* dst_host) {
+  return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_mlp_timeline), sizeof(unsigned long long) * 64 * 8 * 4);
+}
+#endif
 
 extern "C" int nesvor_mlp_backward_fused_ok(const nesvor_mlp_t* net, int64_t N) {
   if (net == nullptr || N <= 0) return 0;

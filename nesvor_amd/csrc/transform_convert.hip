@@ -268,6 +268,12 @@ __global__ void trans_loss_kernel(const float* __restrict__ ax, const float* __r
 //   epilogue: d logit_coef from d c (softmax backward), d axisangle = axisangle2mat_backward(dmat) + w_T dtrans,
 //             and the loss values {MSE, logVar, MSE+logVar, transReg, imageReg} from the per-pixel partial sums.
 // One workgroup each (n and B are small); block-wide sums through LDS.
+// Round 6: 256 threads per workgroup, not 1024.  Both launches run NEXT TO the owner pass of the hash-grid backward (side stream),
+// whose 512-thread workgroups leave most CUs with 8 free wave slots: a 1024-thread workgroup cannot start before a CU has drained
+// to half - the epilogue took 41 us (21 us at 2^17 points) on the chain that decides when the next iteration's forward may start
+// (profiles/r05_step_timeline.txt), for a few microseconds of work.
+constexpr int kStepBlock = 256;
+// (any block size that is a multiple of 64 up to 1024)
 __device__ __forceinline__ float block_sum_1024(float v, float* red /* 16 floats */) {
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -279,7 +285,7 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red /* 16 floats
   return s;
 }
 
-__global__ __launch_bounds__(1024) void step_prologue_kernel(const float* __restrict__ logit_coef, float* __restrict__ c,
+__global__ __launch_bounds__(kStepBlock) void step_prologue_kernel(const float* __restrict__ logit_coef, float* __restrict__ c,
                                                             const float* __restrict__ axisangle, float* __restrict__ mat,
                                                             float* __restrict__ zero_buf, int n_zero, int n,
                                                             const float* __restrict__ ax_init, float* __restrict__ trans_k,
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(1024) void step_prologue_kernel(const float* __rest
   }
 }
 
-__global__ __launch_bounds__(1024) void step_epilogue_kernel(const float* __restrict__ dc, const float* __restrict__ c,
+__global__ __launch_bounds__(kStepBlock) void step_epilogue_kernel(const float* __restrict__ dc, const float* __restrict__ c,
                                                             float* __restrict__ dlogit, const float* __restrict__ dmat,
                                                             const float* __restrict__ axisangle, const float* __restrict__ dtrans,
                                                             float w_trans, float* __restrict__ daxisangle,
@@ -375,7 +381,7 @@ extern "C" int nesvor_step_prologue_pose(const float* logit_coef, float* c, cons
   if (n <= 0) return 0;
   const bool pose = axisangle_init != nullptr;
   if (pose && (axisangle == nullptr || trans_terms == nullptr || g_trans == nullptr)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(step_prologue_kernel, dim3(pose ? 4 : 3), dim3(1024), 0, (hipStream_t)stream, logit_coef, c, axisangle, mat, zero_buf,
+  hipLaunchKernelGGL(step_prologue_kernel, dim3(pose ? 4 : 3), dim3(kStepBlock), 0, (hipStream_t)stream, logit_coef, c, axisangle, mat, zero_buf,
                      n_zero, n, axisangle_init, trans_terms, g_trans);
   return (int)hipGetLastError();
 }
@@ -390,7 +396,7 @@ extern "C" int nesvor_step_epilogue(const float* dc, const float* c, float* dlog
                                     const float* trans_terms, float* losses, int n, int B, float img_scale, float img_offset,
                                     void* stream) {
   if (n <= 0 || B <= 0) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(step_epilogue_kernel, dim3(3), dim3(1024), 0, (hipStream_t)stream, dc, c, dlogit, dmat, axisangle, dtrans,
+  hipLaunchKernelGGL(step_epilogue_kernel, dim3(3), dim3(kStepBlock), 0, (hipStream_t)stream, dc, c, dlogit, dmat, axisangle, dtrans,
                      w_trans, daxisangle, loss_pix, trans_terms, losses, n, B, 1.f / (float)B, img_scale, img_offset);
   return (int)hipGetLastError();
 }
