@@ -445,6 +445,21 @@ def main():
                   "ms_per_step": e2 / opt.steps * 1e3,
                   "note": "same run, MLP products as v_mfma_f32_16x16x4_f32 (python bench.py --mlp-fp32-mfma)"}
         trainer.direct.bf16 = False
+    # ... and with the matrix operands rounded to fp16 (fp32 accumulation, fp32 master weights): the arithmetic TYPE of the
+    # reference's default mode (fp16 CutlassMLP, nesvor/nesvor/models.py:28-41).  Not the headline (the headline stays fp32-equivalent).
+    fp16_ops = None
+    if trainer.direct is not None and trainer.direct.bf16 is False and not opt.no_strict:
+        from nesvor_amd import mlp as _mlp
+
+        trainer.direct.bf16 = _mlp.FP16
+        for _ in range(opt.warmup):
+            step()
+        e2h, _ = timed(opt.steps)
+        fp16_ops = {"value": opt.steps * (global_b * opt.n_samples / float(1 << 20)) / e2h, "ms_per_step": e2h / opt.steps * 1e3,
+                    "note": "same run, same networks, MLP matrix operands rounded to fp16 (one fp16 MFMA per product, fp32 accumulation; "
+                            "nesvor_mlp_t.bf16_operands = 3): the reference's default arithmetic type, without its loss scaling "
+                            "(python bench.py --half-precision-model / --fp16-loss-scaling run the bias-free structure)"}
+        trainer.direct.bf16 = False
 
     # BASELINE config 3 as written (2^20 samples per iteration in total): the same job with the batch split over the ranks
     strong = None
@@ -701,6 +716,7 @@ def main():
                              "below the fp32 MFMA chain's (tests/test_gpu_ops.py::test_fused_mlp_split_operands_keep_fp32_accuracy, "
                              "profiles/r05_f16_split_probe.log); forward, dX chain and dW all run on the 16-bit matrix pipe"),
             "strict_fp32_mfma": strict,
+            "fp16_operands": fp16_ops,
             "strong_scaling": strong,
             "small_batch": small,
             "roofline": roof,

@@ -368,6 +368,12 @@ typedef struct {
                                  kernel: max |d z|, max |d log_var|) and one launch per step takes the weight norms.  Forward
                                  and backward of one step must see the same [0], [1] and weights. */
   float* y_absmax;            /* forward, optional: a slotted bound (NESVOR_ABSMAX_FLOATS zero-filled device floats) raised to max |y| */
+  const void* weight_images;  /* mode 2, optional (NULL: every launch builds its LDS operand images from `weight`, as rounds 2-5 did):
+                                 nesvor_mlp_weight_images_bytes(net) device bytes holding the split fp16 operand images of ALL layers
+                                 for the CURRENT weights - written by nesvor_mlp_prepare_weights_images() together with the weight
+                                 norms, so that the images' scales are the ones `prep` yields.  The training step (csrc/step.hip)
+                                 builds them once per iteration for its four MLP launches (round 6: the per-launch builds cost
+                                 ~30 us of a 0.94 ms step, and as much of a 0.28 ms one).  Bit-identical to the in-kernel builds. */
 } nesvor_mlp_t;
 #define NESVOR_ABSMAX_SLOTS 16      /* a slotted bound: this many floats, NESVOR_ABSMAX_STRIDE floats (one 256-byte line) apart - */
 #define NESVOR_ABSMAX_STRIDE 64     /* atomics on one cache line serialise at the memory side, publishers spread by workgroup */
@@ -389,6 +395,13 @@ int nesvor_mlp_prepare(const nesvor_mlp_t* net, const float* xa, const float* xb
  * sigma_net / b_net are rows of it).  preps[i] as nesvor_mlp_t.prep of nets[i]; nothing is zero-filled. */
 int nesvor_mlp_prepare_weights(const nesvor_mlp_t* const* nets, float* const* preps, int n_nets, const float* x, int64_t n_x,
                                float* x_slots, void* stream);
+
+/* ... the same launch also writing each network's split operand images (nesvor_mlp_t.weight_images): images[i] = NULL or
+ * nesvor_mlp_weight_images_bytes(nets[i]) device bytes (16-byte aligned); `images` itself may be NULL. */
+int nesvor_mlp_prepare_weights_images(const nesvor_mlp_t* const* nets, float* const* preps, void* const* images, int n_nets,
+                                      const float* x, int64_t n_x, float* x_slots, void* stream);
+/* Size of a network's prebuilt operand images (0: a shape the split-mode kernels do not take). */
+int64_t nesvor_mlp_weight_images_bytes(const nesvor_mlp_t* net);
 
 /* 1 if (net, N) can run with compact_save = 1 (the field itself is ignored by this query), else 0. */
 int nesvor_mlp_compact_save_ok(const nesvor_mlp_t* net, int64_t N);

@@ -46,7 +46,7 @@ class MlpT(Structure):
         ("k_a", c_int32), ("k_b", c_int32), ("b_row0", c_int32), ("samples_per_pixel", c_int32),
         ("dxa_group_sums", c_int32), ("bf16_operands", c_int32), ("compact_save", c_int32),
         ("weight", c_void_p * 4), ("bias", c_void_p * 4),
-        ("prep", c_void_p), ("y_absmax", c_void_p),
+        ("prep", c_void_p), ("y_absmax", c_void_p), ("weight_images", c_void_p),
     ]
 
 
@@ -155,6 +155,8 @@ _SIGNATURES = {
     "nesvor_mlp_backward_fused_ok": ([POINTER(MlpT), c_int64], c_int),
     "nesvor_mlp_prepare": ([POINTER(MlpT), _P, _P, _P, c_int64, _P, c_int, _P], c_int),
     "nesvor_mlp_prepare_weights": ([_P, _P, c_int, _P, c_int64, _P, _P], c_int),
+    "nesvor_mlp_prepare_weights_images": ([_P, _P, _P, c_int, _P, c_int64, _P, _P], c_int),
+    "nesvor_mlp_weight_images_bytes": ([POINTER(MlpT)], c_int64),
     "nesvor_mlp_forward": ([POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), c_int64, _P], c_int),
     "nesvor_mlp_backward": (
         [POINTER(MlpT), _P, _P, _P, POINTER(c_void_p), POINTER(c_void_p), _P, _P, _P, c_int, c_int64, _P],

@@ -15,7 +15,8 @@ namespace {
 
 template <bool ZERO>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, int64_t n, const AdamArgs a) {
+                                                    float* __restrict__ v, int64_t n, const AdamArgs a, int prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);  // small launches on the step's critical tail, next to the owner pass (see step_epilogue_kernel)
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -48,10 +49,10 @@ extern "C" int nesvor_adamw_step(float* param, float* grad, float* exp_avg, floa
   if (blocks > 256 * 8) blocks = 256 * 8;
   if (zero_grad)
     hipLaunchKernelGGL((adamw_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad,
-                       exp_avg, exp_avg_sq, n, a);
+                       exp_avg, exp_avg_sq, n, a, blocks <= 256 ? 1 : 0);
   else
     hipLaunchKernelGGL((adamw_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad,
-                       exp_avg, exp_avg_sq, n, a);
+                       exp_avg, exp_avg_sq, n, a, blocks <= 256 ? 1 : 0);
   return (int)hipGetLastError();
 }
 

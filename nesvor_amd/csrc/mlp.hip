@@ -84,6 +84,7 @@ struct MlpArgs {
                                 // backward) scales its fixed-point sums by it instead of reading dxb an extra time
   const float* prep;            // split mode: operand bounds and weight norms of this launch (nesvor_mlp_t.prep; see MlpScales)
   float* y_absmax;              // fwd, optional: slotted bound raised to max |y| (the next network's input bound)
+  const _Float16* wimg;         // split mode, optional: the operand images of all layers, prebuilt for the current weights (nesvor_mlp_t.weight_images)
 };
 
 // max |dx| over the xb blocks of a lane's dX fragments, folded into `mx`
@@ -351,6 +352,37 @@ __device__ __forceinline__ void build_image_ct(float* img, const float* __restri
       }
     }
   }
+}
+
+// Prebuilt operand images (nesvor_mlp_t.weight_images, round 6).  Every launch of the split mode used to build its LDS images from
+// the fp32 weights - a few dependent L2 round trips plus the splitting of every element, per workgroup: measured with the build
+// compiled out (-DNESVOR_MLP_ABLATE=8) 9-11 us of the two forward launches and 20 us of the two backward launches of a training
+// step, at 2^20 points and at 2^17 alike (profiles/r06_mlp_image_build.log).  The training step now builds them ONCE per iteration -
+// in the launch that takes the weight norms, which has each layer's matrix in LDS and knows its scale - and a workgroup copies
+// them: 16-byte loads, all of a thread's in flight at once, no arithmetic.  Layout of a network's buffer, in fp16 elements, layer
+// after layer (l = 0 .. n_hidden):   [F hi | F lo | T hi | T lo],  each plane E_l = (output blocks) x (input blocks) x 256 elements,
+// F = the forward image (build_image_ct<.., T = false, output blocks, input blocks>), T = the transposed one (T = true, input
+// blocks, output blocks); blocks: KB1 for the network input, kHB for a hidden layer, 1 for the output.  An LDS image of the split
+// mode is [hi plane | lo plane] = one contiguous range of this buffer.
+__host__ __device__ constexpr int wimg_plane(int n_hidden, int kb1, int l) {
+  return (l == n_hidden ? 1 : kHB) * (l == 0 ? kb1 : kHB) * 256;
+}
+__host__ __device__ constexpr int wimg_offset(int n_hidden, int kb1, int l) {  // first element of layer l's F image
+  int off = 0;
+  for (int t = 0; t < l; ++t) off += 4 * wimg_plane(n_hidden, kb1, t);
+  return off;
+}
+// LDS image <- FLOATS fp32-sized words of a prebuilt image: all loads of a thread issued before the first LDS store
+template <int FLOATS, int THREADS>
+__device__ __forceinline__ void copy_image_ct(float* __restrict__ dst, const _Float16* __restrict__ src) {
+  static_assert(FLOATS % 4 == 0, "images are whole 16-byte vectors");
+  constexpr int V = FLOATS / 4, PER = (V + THREADS - 1) / THREADS;
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  float4 v[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) { const int i = (int)threadIdx.x + u * THREADS; v[u] = s4[i < V ? i : 0]; }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) { const int i = (int)threadIdx.x + u * THREADS; if (i < V) reinterpret_cast<float4*>(dst)[i] = v[u]; }
 }
 
 // y[g][ob] (+)= img . x   for G groups at once; KB input blocks, OB output blocks
@@ -772,10 +804,17 @@ __global__ __launch_bounds__(256, (SPL && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) 
       inv_unit[l] = pow2_inv(unit[l]);
       mult[l] = l == 0 ? sc.sx[0] : uniform_f(sc.sx[l] * inv_unit[l - 1]);
     }
-    build_image_ct<false, SPL, false, kHB, KB1, 256>(img1, a.W[0], kWidth, k_in, sc.sw[0]);
+    if (a.wimg != nullptr) {  // prebuilt for the current weights (see wimg_plane)
+      copy_image_ct<kHB * KB1 * kBlk, 256>(img1, a.wimg + wimg_offset(NH, KB1, 0));
 #pragma unroll
-    for (int l = 1; l < NH; ++l) build_image_ct<false, SPL, false, kHB, kHB, 256>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, sc.sw[l]);
-    if constexpr (!OUT1) build_image_ct<false, SPL, false, 1, kHB, 256>(imgo, a.W[NH], a.out_dim, kWidth, sc.sw[NH]);
+      for (int l = 1; l < NH; ++l) copy_image_ct<kHB * kHB * kBlk, 256>(imgh + (l - 1) * kHB * kHB * kBlk, a.wimg + wimg_offset(NH, KB1, l));
+      if constexpr (!OUT1) copy_image_ct<kHB * kBlk, 256>(imgo, a.wimg + wimg_offset(NH, KB1, NH));
+    } else {
+      build_image_ct<false, SPL, false, kHB, KB1, 256>(img1, a.W[0], kWidth, k_in, sc.sw[0]);
+#pragma unroll
+      for (int l = 1; l < NH; ++l) build_image_ct<false, SPL, false, kHB, kHB, 256>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, sc.sw[l]);
+      if constexpr (!OUT1) build_image_ct<false, SPL, false, 1, kHB, 256>(imgo, a.W[NH], a.out_dim, kWidth, sc.sw[NH]);
+    }
   } else {
     build_image_ct<false, SPL, false, kHB, KB1, 256>(img1, a.W[0], kWidth, k_in);
     for (int l = 1; l < NH; ++l) build_image_ct<false, SPL, false, kHB, kHB, 256>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth);
@@ -1347,18 +1386,31 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
     unit_h[l] = uniform_f(sc.sw[l] * sc.sx[l]);
     m_h[l] = uniform_f(sc.sx[l + 1] * pow2_inv(unit_h[l]));
   }
+  // (SPL && !BF16: a prebuilt set may stand in for the builds - wimg_plane; T images at + 2 planes of a layer's range)
+  const bool prebuilt = SPL && !BF16 && a.wimg != nullptr;
   if constexpr (OUT1) {
     for (int e = threadIdx.x; e < kWidth; e += blockDim.x) wout[e] = a.W[NH][e];
   } else {
-    build_image_ct<BF16, SPL, true, kHB, 1, 512>(imgo, a.W[NH], a.out_dim, kWidth, sc.sw[NH]);
+    if (prebuilt) copy_image_ct<kHB * kBlk, 512>(imgo, a.wimg + wimg_offset(NH, KB1, NH) + 2 * wimg_plane(NH, KB1, NH));
+    else build_image_ct<BF16, SPL, true, kHB, 1, 512>(imgo, a.W[NH], a.out_dim, kWidth, sc.sw[NH]);
   }
 #pragma unroll
-  for (int l = 1; l < NH; ++l) build_image_ct<BF16, SPL, true, kHB, kHB, 512>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, sc.sw[l]);
-  build_image_ct<BF16, SPL, true, KB1, kHB, 512>(img1, a.W[0], kWidth, k_in, sc.sw[0]);
+  for (int l = 1; l < NH; ++l) {
+    if (prebuilt) copy_image_ct<kHB * kHB * kBlk, 512>(imgh + (l - 1) * kHB * kHB * kBlk, a.wimg + wimg_offset(NH, KB1, l) + 2 * wimg_plane(NH, KB1, l));
+    else build_image_ct<BF16, SPL, true, kHB, kHB, 512>(imgh + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, sc.sw[l]);
+  }
+  if (prebuilt) copy_image_ct<KB1 * kHB * kBlk, 512>(img1, a.wimg + wimg_offset(NH, KB1, 0) + 2 * wimg_plane(NH, KB1, 0));
+  else build_image_ct<BF16, SPL, true, KB1, kHB, 512>(img1, a.W[0], kWidth, k_in, sc.sw[0]);
   if constexpr (COMPACT) {
-    build_image_ct<false, SPL, false, kHB, KB1, 512>(imgf1, a.W[0], kWidth, k_in, sc.sw[0]);
+    if (prebuilt) {
+      copy_image_ct<kHB * KB1 * kBlk, 512>(imgf1, a.wimg + wimg_offset(NH, KB1, 0));
 #pragma unroll
-    for (int l = 1; l < NH; ++l) build_image_ct<false, SPL, false, kHB, kHB, 512>(imgf2 + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, sc.sw[l]);
+      for (int l = 1; l < NH; ++l) copy_image_ct<kHB * kHB * kBlk, 512>(imgf2 + (l - 1) * kHB * kHB * kBlk, a.wimg + wimg_offset(NH, KB1, l));
+    } else {
+      build_image_ct<false, SPL, false, kHB, KB1, 512>(imgf1, a.W[0], kWidth, k_in, sc.sw[0]);
+#pragma unroll
+      for (int l = 1; l < NH; ++l) build_image_ct<false, SPL, false, kHB, kHB, 512>(imgf2 + (l - 1) * kHB * kHB * kBlk, a.W[l], kWidth, kWidth, sc.sw[l]);
+    }
     for (int e = threadIdx.x; e < NH * kWidth; e += blockDim.x) {
       float us = unit_h[0];
 #pragma unroll
@@ -2056,12 +2108,16 @@ constexpr int kNormJobs = 3 * kMaxLayers;
 struct NormJobs {
   const float* W[kNormJobs]; const float* b[kNormJobs]; float* dst[kNormJobs];  // dst: prep + NESVOR_MLP_PREP_LAYER0 + 4 l of the layer's network
   int out[kNormJobs], in[kNormJobs];
+  _Float16* img[kNormJobs];                  // null, or the layer's range [F hi | F lo | T hi | T lo] of its network's image buffer (wimg_plane)
+  int oblk[kNormJobs], iblk[kNormJobs];      // output / input blocks of the layer's images
   int n_jobs;
   const float* x; int64_t n_x; float* x_slots;
 };
 __global__ __launch_bounds__(256) void weight_norms_kernel(const NormJobs jobs) {
   __shared__ float w[64 * 65];
+  __shared__ float wsg[64 * 65];  // the signed values (the images below)
   __shared__ float red[4][4];
+  __builtin_amdgcn_s_setprio(3);  // (a short launch at the head of an iteration, next to the previous one's owner pass: csrc/transform_convert.hip::step_epilogue_kernel)
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= jobs.n_jobs) {
     float m = 0.f;
@@ -2082,7 +2138,7 @@ __global__ __launch_bounds__(256) void weight_norms_kernel(const NormJobs jobs) 
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     const int e = tid + 256 * u;
-    if (e < total) { const float a = fabsf(v[u]); wmax = fmaxf(wmax, a); w[(e / in_dim) * 65 + e % in_dim] = a; }
+    if (e < total) { const float a = fabsf(v[u]); wmax = fmaxf(wmax, a); w[(e / in_dim) * 65 + e % in_dim] = a; wsg[(e / in_dim) * 65 + e % in_dim] = v[u]; }
   }
   __syncthreads();
   // rows: thread (o = tid >> 2, part = tid & 3) sums columns part, part + 4, ...; columns likewise
@@ -2106,6 +2162,34 @@ __global__ __launch_bounds__(256) void weight_norms_kernel(const NormJobs jobs) 
   }
   __syncthreads();
   if (tid < 4) jobs.dst[l][tid] = fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid]));
+  // The layer's operand images of the split mode, once per iteration instead of once per workgroup of every launch
+  // (nesvor_mlp_t.weight_images; build_image_ct's arithmetic, element for element: scale = pow2_scale(max |W|) - the value just
+  // written to dst[0], which is what mlp_scales() derives sw[l] from)
+  _Float16* img = jobs.img[l];
+  if (img != nullptr) {
+    const float scale = pow2_scale(fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0])));
+    const int oblk = jobs.oblk[l], iblk = jobs.iblk[l];
+    const int E = oblk * iblk * 256;
+    for (int e = tid; e < E; e += 256) {
+      const int r = e & 3, lane = (e >> 2) & 63, blk = e >> 8;
+      {  // forward image: rows = output features (oblk blocks), k = input features (iblk blocks)
+        const int kb = blk % iblk, ab = blk / iblk;
+        const int o = 16 * ab + (lane & 15), k = 16 * kb + 4 * (lane >> 4) + r;
+        const float wv = (o < out_dim && k < in_dim) ? wsg[o * 65 + k] : 0.f;
+        const float ws = wv * scale;
+        const _Float16 hi = (_Float16)ws;
+        img[e] = hi; img[E + e] = (_Float16)(ws - (float)hi);
+      }
+      {  // transposed image: rows = input features (iblk blocks), k = output features (oblk blocks)
+        const int kb = blk % oblk, ab = blk / oblk;
+        const int k = 16 * ab + (lane & 15), o = 16 * kb + 4 * (lane >> 4) + r;
+        const float wv = (o < out_dim && k < in_dim) ? wsg[o * 65 + k] : 0.f;
+        const float ws = wv * scale;
+        const _Float16 hi = (_Float16)ws;
+        img[2 * E + e] = hi; img[3 * E + e] = (_Float16)(ws - (float)hi);
+      }
+    }
+  }
 }
 
 size_t ws_bwd_lds_bytes(int n_hidden, int kb1, bool split = false, bool compact = false) {
@@ -2207,6 +2291,7 @@ int fill_args(MlpArgs* a, const nesvor_mlp_t* d, int64_t N) {
   if (a->half16) a->bf16 = 1;  // (every host-side decision below is that of the 16-bit operand modes; the launches pick the type)
   a->prep = d->prep;
   a->y_absmax = d->y_absmax;
+  a->wimg = (a->bf16 == 2) ? static_cast<const _Float16*>(d->weight_images) : nullptr;
   {
     const int64_t rows = (int64_t)(d->b_row0 + d->k_b > d->out_dim ? d->b_row0 + d->k_b : d->out_dim);
     a->off32 = rows * N * 4 + 64 < ((int64_t)1 << 32) ? 1 : 0;
@@ -2259,8 +2344,16 @@ extern "C" int nesvor_mlp_backward_fused_ok(const nesvor_mlp_t* net, int64_t N) 
   return ws_ok(a, net) ? 1 : 0;
 }
 
-extern "C" int nesvor_mlp_prepare_weights(const nesvor_mlp_t* const* nets, float* const* preps, int n_nets, const float* x, int64_t n_x,
-                                          float* x_slots, void* stream) {
+extern "C" int64_t nesvor_mlp_weight_images_bytes(const nesvor_mlp_t* net) {
+  if (net == nullptr || net->n_hidden < 1 || net->n_hidden + 1 > kMaxLayers || net->width != kWidth || net->k_a + net->k_b < 1 ||
+      net->k_a + net->k_b > 64 || net->out_dim < 1 || net->out_dim > 16)
+    return 0;
+  const int kb1 = (net->k_a + net->k_b + 15) / 16;
+  return (int64_t)sizeof(_Float16) * wimg_offset(net->n_hidden, kb1, net->n_hidden + 1);
+}
+
+extern "C" int nesvor_mlp_prepare_weights_images(const nesvor_mlp_t* const* nets, float* const* preps, void* const* images, int n_nets,
+                                                 const float* x, int64_t n_x, float* x_slots, void* stream) {
   if (n_nets < 0 || n_nets > 3 || (n_nets > 0 && (nets == nullptr || preps == nullptr))) return (int)hipErrorInvalidValue;
   NormJobs jobs{};
   int nj = 0;
@@ -2269,11 +2362,16 @@ extern "C" int nesvor_mlp_prepare_weights(const nesvor_mlp_t* const* nets, float
     if (net == nullptr || preps[i] == nullptr || net->n_hidden < 1 || net->n_hidden + 1 > kMaxLayers || net->width != kWidth ||
         net->k_a + net->k_b > 64 || net->out_dim > 64)
       return (int)hipErrorInvalidValue;
+    _Float16* img = (images != nullptr && net->out_dim <= 16) ? static_cast<_Float16*>(images[i]) : nullptr;
+    const int kb1 = (net->k_a + net->k_b + 15) / 16;
     for (int l = 0; l <= net->n_hidden; ++l, ++nj) {
       jobs.W[nj] = net->weight[l]; jobs.b[nj] = net->bias[l];
       jobs.in[nj] = l == 0 ? net->k_a + net->k_b : net->width;
       jobs.out[nj] = l == net->n_hidden ? net->out_dim : net->width;
       jobs.dst[nj] = preps[i] + NESVOR_MLP_PREP_LAYER0 + 4 * l;
+      jobs.img[nj] = img != nullptr ? img + wimg_offset(net->n_hidden, kb1, l) : nullptr;
+      jobs.oblk[nj] = l == net->n_hidden ? 1 : kHB;
+      jobs.iblk[nj] = l == 0 ? kb1 : kHB;
       if (jobs.W[nj] == nullptr || jobs.b[nj] == nullptr) return (int)hipErrorInvalidValue;
     }
   }
@@ -2283,6 +2381,11 @@ extern "C" int nesvor_mlp_prepare_weights(const nesvor_mlp_t* const* nets, float
   if (nj + (with_x ? 1 : 0) == 0) return 0;
   hipLaunchKernelGGL(weight_norms_kernel, dim3((unsigned)(nj + (with_x ? 1 : 0))), dim3(256), 0, (hipStream_t)stream, jobs);
   return (int)hipGetLastError();
+}
+
+extern "C" int nesvor_mlp_prepare_weights(const nesvor_mlp_t* const* nets, float* const* preps, int n_nets, const float* x, int64_t n_x,
+                                          float* x_slots, void* stream) {
+  return nesvor_mlp_prepare_weights_images(nets, preps, nullptr, n_nets, x, n_x, x_slots, stream);
 }
 
 extern "C" int nesvor_mlp_prepare(const nesvor_mlp_t* net, const float* xa, const float* xb, const float* dy, int64_t N, float* prep,

@@ -32,6 +32,10 @@ struct StepCtx {
   int pending_pipe_level = 0;
   hipEvent_t tu0[2] = {nullptr, nullptr};  // timing: start of a run's owner pass (double-buffered: read by the NEXT run's union span)
   unsigned run_no = 0;
+  // Split operand images of the three networks' weights (nesvor_mlp_t.weight_images), rebuilt once per iteration by the launch that
+  // takes the weight norms and copied - not rebuilt - by the workgroups of the four MLP launches.  One allocation, owned here.
+  void* wimg = nullptr;
+  size_t wimg_stride = 0;
   bool head_on_side = false;  // (NESVOR_STEP_HEAD=side: phase 2 of a split run must join what phase 1 forked)
   bool sums_on_side = false;  // the networks' parameter-gradient sums of the current iteration were left on the side stream
   bool pending_join = false;  // a table update of the previous run is still on the side stream (NESVOR_STEP_DEFER_JOIN)
@@ -126,6 +130,15 @@ extern "C" void* nesvor_step_create(const nesvor_step_t* desc) {
     if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { delete c; return nullptr; }
   }
   for (int k = 0; k < NESVOR_STEP_TIMED_SPANS; ++k) { c->t0[k] = nullptr; c->t1[k] = nullptr; c->span_used[k] = false; }
+  {
+    // NESVOR_STEP_WEIGHT_IMAGES=0: every MLP launch builds its own images (rounds 2-5; A/B switch)
+    static const bool on = []() { const char* e = getenv("NESVOR_STEP_WEIGHT_IMAGES"); return e == nullptr || atoi(e) != 0; }();
+    int64_t need = nesvor_mlp_weight_images_bytes(&desc->density);
+    if (desc->has_lv && nesvor_mlp_weight_images_bytes(&desc->sigma) > need) need = nesvor_mlp_weight_images_bytes(&desc->sigma);
+    if (desc->has_b && nesvor_mlp_weight_images_bytes(&desc->bias_net) > need) need = nesvor_mlp_weight_images_bytes(&desc->bias_net);
+    c->wimg_stride = ((size_t)need + 255) / 256 * 256;
+    if (on && need > 0 && hipMalloc(&c->wimg, 3 * c->wimg_stride) != hipSuccess) { c->wimg = nullptr; (void)hipGetLastError(); }  // (without it: the in-kernel builds)
+  }
   return c;
 }
 
@@ -172,6 +185,7 @@ extern "C" void nesvor_step_destroy(void* handle) {
   (void)hipEventDestroy(c->ev_bwd); (void)hipEventDestroy(c->ev_sums); (void)hipEventDestroy(c->ev_norms);
   (void)hipEventDestroy(c->ev_sg0); (void)hipEventDestroy(c->ev_sg1); (void)hipEventDestroy(c->ev_owner_early);
   if (c->tu0[0] != nullptr) { (void)hipEventDestroy(c->tu0[0]); (void)hipEventDestroy(c->tu0[1]); }
+  if (c->wimg != nullptr) (void)hipFree(c->wimg);
   for (int k = 0; k < NESVOR_STEP_TIMED_SPANS; ++k) {
     if (c->t0[k] != nullptr) (void)hipEventDestroy(c->t0[k]);
     if (c->t1[k] != nullptr) (void)hipEventDestroy(c->t1[k]);
@@ -211,6 +225,14 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   nesvor_mlp_t net_d = d.density, net_s = d.sigma, net_b = d.bias_net;
   net_d.prep = prep_d; net_s.prep = prep_s; net_b.prep = prep_b;
   net_d.y_absmax = d.has_lv ? prep_s + NESVOR_MLP_PREP_XB : nullptr;  // z rows 1.. are sigma_net's matrix input
+  void* wimg_d = ctx->wimg;
+  void* wimg_s = ctx->wimg != nullptr ? static_cast<char*>(ctx->wimg) + ctx->wimg_stride : nullptr;
+  void* wimg_b = ctx->wimg != nullptr ? static_cast<char*>(ctx->wimg) + 2 * ctx->wimg_stride : nullptr;
+  // (an image set is valid for the launches of THIS call and - data-parallel runs - of the phase-2 call that follows a phase-1
+  //  call: the weights only change in between runs; networks whose shape has no images - 0 bytes - keep building their own)
+  net_d.weight_images = nesvor_mlp_weight_images_bytes(&net_d) > 0 ? wimg_d : nullptr;
+  net_s.weight_images = (d.has_lv && nesvor_mlp_weight_images_bytes(&net_s) > 0) ? wimg_s : nullptr;
+  net_b.weight_images = (d.has_b && nesvor_mlp_weight_images_bytes(&net_b) > 0) ? wimg_b : nullptr;
   const bool split_d = net_d.bf16_operands == 2, split_s = d.has_lv && net_s.bf16_operands == 2, split_b = d.has_b && net_b.bf16_operands == 2;
   const int layout = NESVOR_LAYOUT_FEATURE_MAJOR;
   const bool overlap_owner = (d.overlap_owner & 1) != 0;
@@ -265,15 +287,15 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
       head = side;
     }
     if (any_split) {
-      const nesvor_mlp_t* nets[3]; float* preps[3]; int nn = 0;
-      if (split_d) { nets[nn] = &net_d; preps[nn++] = prep_d; }
-      if (split_s) { nets[nn] = &net_s; preps[nn++] = prep_s; }
-      if (split_b) { nets[nn] = &net_b; preps[nn++] = prep_b; }
+      const nesvor_mlp_t* nets[3]; float* preps[3]; void* imgs[3]; int nn = 0;
+      if (split_d) { nets[nn] = &net_d; imgs[nn] = const_cast<void*>(net_d.weight_images); preps[nn++] = prep_d; }
+      if (split_s) { nets[nn] = &net_s; imgs[nn] = const_cast<void*>(net_s.weight_images); preps[nn++] = prep_s; }
+      if (split_b) { nets[nn] = &net_b; imgs[nn] = const_cast<void*>(net_b.weight_images); preps[nn++] = prep_b; }
       // ONE launch: the weight norms of all networks and - the pixel features of sigma_net are rows of the slice embedding -
       // the table's maximum as their bound
       const bool se_bound = split_s && d.ks > 0;
-      NESVOR_TRY(nesvor_mlp_prepare_weights(nets, preps, nn, se_bound ? d.slice_embedding : nullptr, (int64_t)n * d.ks,
-                                            se_bound ? prep_s + NESVOR_MLP_PREP_XA : nullptr, head));
+      NESVOR_TRY(nesvor_mlp_prepare_weights_images(nets, preps, imgs, nn, se_bound ? d.slice_embedding : nullptr, (int64_t)n * d.ks,
+                                                   se_bound ? prep_s + NESVOR_MLP_PREP_XA : nullptr, head));
       if (head_on_side && hipEventRecord(ctx->ev_norms, side) != hipSuccess) return (int)hipGetLastError();
     }
     if (head_on_side && d.opt_T) {

@@ -291,6 +291,7 @@ __global__ __launch_bounds__(kStepBlock) void step_prologue_kernel(const float* 
                                                             const float* __restrict__ ax_init, float* __restrict__ trans_k,
                                                             float* __restrict__ trans_grad) {
   __shared__ float red[16];
+  __builtin_amdgcn_s_setprio(3);  // (see step_epilogue_kernel)
   // (grid = 3 or 4: softmax | pose matrices | zero-fill | pose regulariser, one workgroup each)
   if (blockIdx.x == 3) {
     // NeSVoR.trans_loss and its gradient (trans_loss_kernel's arithmetic): a function of the parameters alone, so it rides in the
@@ -335,6 +336,10 @@ __global__ __launch_bounds__(kStepBlock) void step_epilogue_kernel(const float* 
   // three independent pieces, one workgroup each (grid = 3): five block reductions in a row were 10-13 us on the branch that
   // decides when the next iteration can start
   __shared__ float red[16];
+  // A few dependent steps next to the owner pass's thousands of waves: the SIMD arbiter issues the OLDEST ready wave first, and
+  // this kernel's waves are the youngest on the chip - 40 us for a few microseconds of work (profiles/r06_step_timeline.txt).
+  // Raised wave priority puts its instructions in front.
+  __builtin_amdgcn_s_setprio(3);
   if (blockIdx.x == 0) {
     if (dc != nullptr) {  // c = n softmax(l):  dl = c (dc - <dc, c> / n)
       float dot = 0.f;

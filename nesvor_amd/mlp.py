@@ -213,6 +213,23 @@ def prepare(d, xa, xb, dy, N, what, prep=None):
     return prep
 
 
+def build_weight_images(d, prep):
+    """The network's split operand images for its CURRENT weights (``nesvor_mlp_t.weight_images``): one launch that also rewrites the
+    weight norms of ``prep`` (same values), so that a launch copies its LDS images instead of building them.  The training step does
+    this once per iteration inside ``nesvor_step_run``; standalone calls normally leave the field NULL (in-kernel builds) - this helper
+    exists for tests and tools.  Returns the buffer (keep it alive while ``d`` is in use)."""
+    lib = _lib.load()
+    n = int(lib.nesvor_mlp_weight_images_bytes(ctypes.byref(d)))
+    if n <= 0:
+        raise RuntimeError("no prebuilt operand images for this shape")
+    buf = torch.empty(n, dtype=torch.uint8, device=prep.device)
+    nets, preps, imgs = (ctypes.c_void_p * 1)(ctypes.addressof(d)), (ctypes.c_void_p * 1)(prep.data_ptr()), (ctypes.c_void_p * 1)(buf.data_ptr())
+    with torch.cuda.device(prep.device):
+        _lib.check(lib.nesvor_mlp_prepare_weights_images(nets, preps, imgs, 1, None, 0, None, _lib.stream_ptr()), "mlp weight images")
+    d.weight_images = buf.data_ptr()
+    return buf
+
+
 def compact_save(d, N: int) -> bool:
     """Whether a training forward of descriptor ``d`` over N samples saves compactly (``nesvor_mlp_t.compact_save``): one
     sign bit per hidden unit and sample (16 N bytes in ``saved[0]``) and nothing else; the backward recomputes the hidden
@@ -247,7 +264,7 @@ def _ptr_array(tensors):
     return arr
 
 
-def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False, prep=None, y_absmax=None):
+def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False, prep=None, y_absmax=None, weight_images=False):
     """One forward launch, no autograd: -> (y (out_dim, N), saved hidden activations [] when not need_saved).
     bf16: False = fp32 (FP32_OPERANDS picks split-fp16 or fp32-MFMA evaluation of the products), True = matrix operands
     rounded to bf16 with fp32 accumulation (opt-in mixed precision); an int selects a mode constant directly.
@@ -265,6 +282,7 @@ def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False,
     d = _desc(weights, biases, k_a, k_b, b_row0, S, bf16, prep)
     if d.bf16_operands == SPLIT and prep is None:
         prep = prepare(d, xa, xb, None, N, PREP_INPUT | PREP_WEIGHTS)
+    images = build_weight_images(d, prep) if (weight_images and d.bf16_operands == SPLIT) else None  # noqa: F841 (kept alive until the launch is enqueued; the stream orders the free)
     if y_absmax is not None:
         d.y_absmax = y_absmax.data_ptr()
     # saved hidden activations, MFMA fragment layout; bf16 mode stores them as bf16 (they are only used as bf16 operands);
@@ -284,7 +302,8 @@ def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False,
     return y, saved
 
 
-def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_dxa, bf16=False, dxb_absmax=None, prep=None):
+def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_dxa, bf16=False, dxb_absmax=None, prep=None,
+                 weight_images=False):
     """One backward pass, no autograd.  dxb: (k_b, N) contiguous tensor the input gradient is written to (or
     None); -> (dxa (N, k_a) per-sample or (N/16, k_a) per 16-sample group | None - sum it over each pixel's rows -,
     partial (n_partial, n_params) to be summed over dim 0).  dxb_absmax: zero-filled 1-element tensor raised to max |dxb|
@@ -295,6 +314,7 @@ def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_d
     d = _desc(weights, biases, k_a, k_b, b_row0, S, bf16, prep)
     if d.bf16_operands == SPLIT and prep is None:  # (the same input bounds and weight norms as the forward's: same data)
         prep = prepare(d, xa, xb, dy, N, PREP_INPUT | PREP_DY | PREP_WEIGHTS)
+    images = build_weight_images(d, prep) if (weight_images and d.bf16_operands == SPLIT) else None  # noqa: F841
     d.compact_save = int(saved[0].numel() == (N + 15) // 16 * 16 * 4)  # (the forward that wrote `saved` decided)
     dev = xb.device
     # the wave-specialised fused kernel (dX + dW + db in one launch) needs no dpre scratch (signalled by NULL entries); shapes it

@@ -1557,6 +1557,39 @@ def test_fused_mlp_compact_save(device, k_a, k_b, b_row0, rows, depth, out_dim, 
                 assert torch.equal(bit.bool(), h[:, b, :, :, r] > 0), (l, b, r)
 
 
+@pytest.mark.parametrize("k_a,k_b,b_row0,rows,depth,out_dim,S,N", [
+    (0, 32, 0, 32, 2, 16, 256, 1 << 16),   # density_net
+    (16, 15, 1, 16, 2, 1, 256, 1 << 16),   # sigma_net
+    (16, 4, 0, 32, 1, 1, 256, 1 << 15),    # b_net, one hidden layer
+    (0, 16, 0, 16, 2, 16, 16, 1 << 14),    # one input block
+])
+def test_fused_mlp_prebuilt_weight_images_are_bit_identical(device, k_a, k_b, b_row0, rows, depth, out_dim, S, N):
+    """``nesvor_mlp_t.weight_images`` (round 6): the operand images of the split mode built ONCE by the launch that takes the weight
+    norms (``nesvor_mlp_prepare_weights_images`` - what the training step does per iteration) and copied by the launches, against
+    the launches building them themselves: outputs, saved bits, input gradients and parameter gradients BIT FOR BIT."""
+    from nesvor_amd import mlp
+    from nesvor_amd.models import build_network
+
+    torch.manual_seed(N + k_a)
+    net = build_network(n_input_dims=k_a + k_b, n_output_dims=out_dim, activation="ReLU", output_activation="None",
+                        n_neurons=64, n_hidden_layers=depth, dtype=torch.float32).to(device)
+    L = mlp.linear_layers(net)
+    W, Bs = [l.weight.detach() * 3.0 for l in L], [l.bias.detach() for l in L]
+    xa = torch.randn(N // S, k_a, device=device) if k_a else None
+    xb = torch.randn(rows, N, device=device)
+    dy = torch.randn(out_dim, N, device=device)
+    res = {}
+    for images in (False, True):
+        y, saved = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, True, weight_images=images)
+        dxb = torch.empty(k_b, N, device=device)
+        dxa, partial = mlp.backward_raw(W, Bs, xa, xb, dy, saved, b_row0, k_b, S, dxb, xa is not None, weight_images=images)
+        torch.cuda.synchronize()
+        res[images] = (y, saved[0], dxb, partial) + ((dxa,) if xa is not None else ())
+    for a_, b_ in zip(res[False], res[True]):
+        assert torch.equal(a_, b_)
+    assert float(res[True][0].abs().max()) > 0 and float(res[True][3].abs().max()) > 0
+
+
 def test_fused_mlp_gate_convention_at_an_exact_plus_zero(device):
     """The bits-only save keeps [sign bit of the pre-activation clear] per hidden unit (include/nesvor_hip.h, compact_save):
     an exact +0 - a sample whose input row is all zeros meeting zero biases - passes its gradient, where torch's / tcnn's
