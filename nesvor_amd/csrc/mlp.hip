@@ -355,11 +355,13 @@ __device__ __forceinline__ void build_image_ct(float* img, const float* __restri
 }
 
 // Prebuilt operand images (nesvor_mlp_t.weight_images, round 6).  Every launch of the split mode used to build its LDS images from
-// the fp32 weights - a few dependent L2 round trips plus the splitting of every element, per workgroup: measured with the build
-// compiled out (-DNESVOR_MLP_ABLATE=8) 9-11 us of the two forward launches and 20 us of the two backward launches of a training
-// step, at 2^20 points and at 2^17 alike (profiles/r06_mlp_image_build.log).  The training step now builds them ONCE per iteration -
-// in the launch that takes the weight norms, which has each layer's matrix in LDS and knows its scale - and a workgroup copies
-// them: 16-byte loads, all of a thread's in flight at once, no arithmetic.  Layout of a network's buffer, in fp16 elements, layer
+// the fp32 weights - a few dependent L2 round trips plus the splitting of every element, per workgroup.  The training step now
+// builds them ONCE per iteration - in the launch that takes the weight norms, which has each layer's matrix in LDS and knows its
+// scale - and a workgroup copies them: 16-byte loads, all of a thread's in flight at once, no arithmetic.  Measured in the step
+// (in-job A/B, NESVOR_STEP_WEIGHT_IMAGES=0/1, profiles/r06_mlp_image_build.log): the four MLP launches -3.4 us of 129 us at 2^17
+// points per iteration, within noise at 2^20 (the builds had been brought down to ~1 us per launch in round 4; an ablation
+// with the builds compiled out, -DNESVOR_MLP_ABLATE=8, had suggested 30 us - it trains on garbage images, the poses turn NaN and
+// every kernel of that step gets faster for reasons that have nothing to do with the builds).  Layout of a network's buffer, in fp16 elements, layer
 // after layer (l = 0 .. n_hidden):   [F hi | F lo | T hi | T lo],  each plane E_l = (output blocks) x (input blocks) x 256 elements,
 // F = the forward image (build_image_ct<.., T = false, output blocks, input blocks>), T = the transposed one (T = true, input
 // blocks, output blocks); blocks: KB1 for the network input, kHB for a hidden layer, 1 for the output.  An LDS image of the split

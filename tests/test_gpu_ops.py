@@ -1586,7 +1586,7 @@ def test_fused_mlp_prebuilt_weight_images_are_bit_identical(device, k_a, k_b, b_
         torch.cuda.synchronize()
         res[images] = (y, saved[0], dxb, partial) + ((dxa,) if xa is not None else ())
     for a_, b_ in zip(res[False], res[True]):
-        assert torch.equal(a_, b_)
+        assert torch.equal(a_.view(torch.int32), b_.view(torch.int32))  # (bit patterns: the saved words are gate bits, some of them NaN patterns)
     assert float(res[True][0].abs().max()) > 0 and float(res[True][3].abs().max()) > 0
 
 
