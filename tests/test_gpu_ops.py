@@ -1400,7 +1400,7 @@ def test_fused_mlp_split_dynamic_range(device, k_a, k_b, b_row0, rows, out_dim):
     # The contract (include/nesvor_hip.h, next to `bf16_operands`).
     # Backward: the chain carries a power of two PER SAMPLE on top of the launch's scale (round 6), so a sample's input gradient
     # keeps the fp32 chain's accuracy RELATIVE TO ITSELF however far its upstream gradient lies below the batch's largest
-    # (before: 8-9 bits lost at 2^-20, 18-19 at 2^-30 - the first run of this test, profiles/r06_mlp_split_dynamic_range.log).
+    # (before: 8-9 bits lost at 2^-20, 18-19 at 2^-30 - the first run of this test, profiles/r06_mlp_split_dynamic_range_before.log; after: profiles/r06_mlp_split_dynamic_range_k*.json).
     rep = report["dy_scaled"]
     for g in range(4):
         assert rep["err_split"][g] <= 1.5 * rep["err_fp32_mfma"][g] + 1e-7, ("dy_scaled", g, rep)
