@@ -265,6 +265,9 @@ def main():
     ap.add_argument("--stacks", type=int, default=3)
     ap.add_argument("--phantom", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mlp-fp16", action="store_true",
+                    help="opt-in mixed precision: power-of-two-scaled MLP operands rounded to fp16, one MFMA per product, on the split "
+                         "mode's kernels (nesvor_mlp_t.bf16_operands = 4): NOT the headline configuration")
     ap.add_argument("--mlp-bf16", action="store_true",
                     help="opt-in mixed precision (bf16 MLP matrix operands, fp32 accumulation): NOT the headline configuration")
     ap.add_argument("--mlp-fp32-mfma", action="store_true",
@@ -317,6 +320,7 @@ def main():
     slices, _ = simulate_stacks(vol, n_stacks=opt.stacks)
     args = make_args(device, opt.batch_size, opt.n_samples, opt.depth, n_iter=6000)
     args.mlp_bf16 = opt.mlp_bf16
+    args.mlp_fp16 = opt.mlp_fp16
     args.mlp_fp32_mfma = opt.mlp_fp32_mfma
     if opt.half_precision_model:
         args.dtype, args.single_precision = torch.float16, False
@@ -451,14 +455,15 @@ def main():
     if trainer.direct is not None and trainer.direct.bf16 is False and not opt.no_strict:
         from nesvor_amd import mlp as _mlp
 
-        trainer.direct.bf16 = _mlp.FP16
+        trainer.direct.bf16 = _mlp.FP16S
         for _ in range(opt.warmup):
             step()
         e2h, _ = timed(opt.steps)
         fp16_ops = {"value": opt.steps * (global_b * opt.n_samples / float(1 << 20)) / e2h, "ms_per_step": e2h / opt.steps * 1e3,
-                    "note": "same run, same networks, MLP matrix operands rounded to fp16 (one fp16 MFMA per product, fp32 accumulation; "
-                            "nesvor_mlp_t.bf16_operands = 3): the reference's default arithmetic type, without its loss scaling "
-                            "(python bench.py --half-precision-model / --fp16-loss-scaling run the bias-free structure)"}
+                    "note": "same run, same networks, MLP matrix operands scaled by a power of two per tensor and rounded to fp16 - ONE fp16 "
+                            "MFMA per product, fp32 accumulation, on the split mode's kernels (nesvor_mlp_t.bf16_operands = 4; python "
+                            "bench.py --mlp-fp16): the reference's default arithmetic type (fp16 CutlassMLP) without the need for its loss "
+                            "scaler.  Plain fp16 rounding under the reference's GradScaler: --half-precision-model --fp16-loss-scaling"}
         trainer.direct.bf16 = False
 
     # BASELINE config 3 as written (2^20 samples per iteration in total): the same job with the batch split over the ranks

@@ -339,7 +339,14 @@ typedef struct {
                                     faster 16-bit matrix pipe.  Pipelined forward and wave-specialised backward (dX chain and dW
                                     products); every other kernel evaluates this mode as mode 0, which is always a valid
                                     evaluation of it.  (Rounds 2-4: three bf16 terms per operand, six MFMAs per product.)
-                                    REQUIRES `prep` */
+                                    REQUIRES `prep`;
+                                 3: operands rounded to fp16 (the reference's default arithmetic; overflows beyond 65504: its
+                                    GradScaler's job), same kernels as mode 1;
+                                 4: "scaled fp16" (round 6): mode 2's scales, operand images, bits-only save and per-sample
+                                    backward scale with the LEADING term of every split alone - operands rounded to fp16 after
+                                    scaling (no overflow, no loss scaler), ONE MFMA per product in the pipelined forward and the
+                                    compact wave-specialised backward; every other kernel evaluates it as mode 2 or mode 0 (more
+                                    accurate, always valid).  REQUIRES `prep`.  Measured: DESIGN.md section 4. */
   int32_t compact_save;       /* 1: training keeps, per hidden unit and sample, ONE BIT (h > 0) of every hidden layer and nothing
                                  else: saved_hidden[0] = one uint32 per (16-sample group, lane) - 16 N bytes instead of 256 N
                                  per hidden layer - with bit 16 l + 4 b + r = [pre-activation sign bit clear] (= [h_l > 0] for every

@@ -47,6 +47,9 @@ def _training_flags(p: argparse.ArgumentParser) -> None:
                    help="(not a flag of the reference: it is the reference's DEFAULT behaviour) without --single-precision: fp16 MLP "
                         "operands and torch.cuda.amp.GradScaler semantics (init_scale 1, growth 2 every 2000 finite steps, backoff 0.5, "
                         "steps with non-finite gradients skipped) instead of this package's bf16 operands without loss scaling")
+    g.add_argument("--mlp-fp16", action="store_true",
+                   help="(not in the reference) with --single-precision: power-of-two-scaled fp16 MLP matrix operands (one MFMA per "
+                        "product, no loss scaler needed), fp32 accumulation / weights")
     g.add_argument("--mlp-bf16", action="store_true",
                    help="(not in the reference) with --single-precision: bf16 MLP matrix operands, fp32 accumulation / weights")
     g.add_argument("--mlp-fp32-mfma", action="store_true",
@@ -247,6 +250,8 @@ def reconstruct(args: Namespace) -> None:
     args.dtype = torch.float32 if args.single_precision else torch.float16
     if args.mlp_bf16 and not args.single_precision:
         raise SystemExit("--mlp-bf16 is a variant of the fp32 model: pass --single-precision too")
+    if getattr(args, "mlp_fp16", False) and not args.single_precision:
+        raise SystemExit("--mlp-fp16 is a variant of the fp32 model: pass --single-precision too")
     if getattr(args, "fp16_loss_scaling", False) and args.single_precision:
         raise SystemExit("--fp16-loss-scaling is the reference's DEFAULT numerics (fp16 operands + GradScaler): drop --single-precision")
     if not args.single_precision:

@@ -78,6 +78,7 @@ struct MlpArgs {
   int dxa_group;                // dxa holds one row per 16-sample GROUP (sum over its samples) instead of one per sample
   int half16;                   // with bf16 == 1: the 16-bit operand type is fp16, not bf16 (nesvor_mlp_t.bf16_operands == 3)
   int bf16;                     // 1: matrix operands rounded to bf16 (fp32 accumulation); 2: every operand split into two fp16 of a power-of-two-scaled copy (split mode, see below)
+  int hi1;                      // with bf16 == 2: only the first term of the split (nesvor_mlp_t.bf16_operands == 4: power-of-two-scaled operands rounded to fp16, ONE MFMA per product)
   int off32;                    // every row of xb / y starts below 2^32 bytes: lane offsets fit the 32-bit VGPR offset of scalar-base loads
   uint32_t* Hm;                 // compact save (nesvor_mlp_t.compact_save): one word per (group, lane), bit 16 l + 4 b + r = [h_l > 0]
   float* dx_absmax;             // bwd, optional: device scalar raised (atomic max) to max |dxb| - the consumer of dxb (the hash-grid
@@ -230,10 +231,13 @@ __device__ __forceinline__ f32x4 mfma32_f16(f16x8 a, f16x8 b, f32x4 c) {
 __device__ __forceinline__ f32x4 mfma16_f16(s16x4 a, s16x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
 }
-// one 16-k block (an odd last block): the three terms, smallest first
+// one 16-k block (an odd last block): the three terms, smallest first (HI1: the leading term alone - see kernels' SPL == 2)
+template <bool HI1 = false>
 __device__ __forceinline__ f32x4 mfma_split(const Split2& a, const Split2& b, f32x4 c) {
-  c = mfma16_f16(a.lo, b.hi, c);
-  c = mfma16_f16(a.hi, b.lo, c);
+  if constexpr (!HI1) {
+    c = mfma16_f16(a.lo, b.hi, c);
+    c = mfma16_f16(a.hi, b.lo, c);
+  }
   return mfma16_f16(a.hi, b.hi, c);
 }
 
@@ -389,10 +393,12 @@ __device__ __forceinline__ void copy_image_ct(float* __restrict__ dst, const _Fl
 
 // y[g][ob] (+)= img . x   for G groups at once; KB input blocks, OB output blocks
 // SPL: `mult` = (scale of this layer's B operand) / (units x arrives in); y accumulates in units sw sx (MlpScales)
-template <int KB, int OB, int BF16 = 0, bool SPL = false>
+// SPL: 0 off, 1 the two-way split (three terms), 2 its leading term alone (scaled fp16 operands, one MFMA per product: mode 4)
+template <int KB, int OB, int BF16 = 0, int SPL = 0>
 __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const f32x4 (&x)[kG][KB], f32x4 (&y)[kG][OB],
                                             int lane, float mult = 1.f) {
-  if constexpr (SPL) {
+  if constexpr (SPL != 0) {
+    constexpr bool HI1 = SPL == 2;
     const _Float16* img16 = reinterpret_cast<const _Float16*>(img);
     constexpr int plane = OB * KB * 256;
     auto load_a = [&](int ob, int kb) __attribute__((always_inline)) {
@@ -426,7 +432,8 @@ __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const
 #define NESVOR_TERM(A, B)                                                                       \
   _Pragma("unroll") for (int o = 0; o < kPair; ++o)                                             \
     _Pragma("unroll") for (int g = 0; g < kG; ++g) y[g][ob + o] = mfma32_f16(A[o], B[g], y[g][ob + o]);
-        NESVOR_TERM(al, bh) NESVOR_TERM(ah, bl) NESVOR_TERM(ah, bh)
+        if constexpr (!HI1) { NESVOR_TERM(al, bh) NESVOR_TERM(ah, bl) }
+        NESVOR_TERM(ah, bh)
 #undef NESVOR_TERM
       }
     }
@@ -439,7 +446,7 @@ __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const
       for (int ob = 0; ob < OB; ++ob) {
         const Split2 a = load_a(ob, kb);
 #pragma unroll
-        for (int g = 0; g < kG; ++g) y[g][ob] = mfma_split(a, pb[g], y[g][ob]);
+        for (int g = 0; g < kG; ++g) y[g][ob] = mfma_split<HI1>(a, pb[g], y[g][ob]);
       }
     }
     return;
@@ -490,7 +497,7 @@ __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const
 // single 16-sample group variant (used by the fused backward, where registers hold the dW accumulators)
 // Split-mode layer product on operands that are already split (the chain waves of the wave-specialised backward split a
 // fragment once, for this product AND for the planes they hand to the dW waves).
-template <int KB, int OB, bool ZERO = false>
+template <int KB, int OB, bool ZERO = false, bool HI1 = false>
 __device__ __forceinline__ void apply_layer_g1_s(const float* __restrict__ img, const Split2 (&xs)[KB], f32x4 (&y)[OB], int lane) {
   const _Float16* img16 = reinterpret_cast<const _Float16*>(img);
   constexpr int plane = OB * KB * 256;
@@ -522,13 +529,22 @@ __device__ __forceinline__ void apply_layer_g1_s(const float* __restrict__ img, 
     f16x8 nh[OB], nl[OB];
     const bool more = kb + 3 < KB;
 #define NESVOR_TERM(A, B) _Pragma("unroll") for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_f16(A[ob], B, y[ob]);
-    if (ZERO && kb == 0) {
+    if constexpr (HI1) {  // the leading term alone
+      if (ZERO && kb == 0) {
 #pragma unroll
-      for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_f16(al[ob], bh, f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_f16(ah[ob], bh, f32x4{0.f, 0.f, 0.f, 0.f});
+      } else {
+        NESVOR_TERM(ah, bh)
+      }
     } else {
-      NESVOR_TERM(al, bh)
+      if (ZERO && kb == 0) {
+#pragma unroll
+        for (int ob = 0; ob < OB; ++ob) y[ob] = mfma32_f16(al[ob], bh, f32x4{0.f, 0.f, 0.f, 0.f});
+      } else {
+        NESVOR_TERM(al, bh)
+      }
+      NESVOR_TERM(ah, bl) NESVOR_TERM(ah, bh)
     }
-    NESVOR_TERM(ah, bl) NESVOR_TERM(ah, bh)
 #undef NESVOR_TERM
     if (more) {
       load_pair(kb + 2, nh, nl);
@@ -539,20 +555,20 @@ __device__ __forceinline__ void apply_layer_g1_s(const float* __restrict__ img, 
   if constexpr (KB % 2 == 1) {
     const Split2& pb = xs[KB - 1];
 #pragma unroll
-    for (int ob = 0; ob < OB; ++ob) y[ob] = mfma_split(load_a(ob, KB - 1), pb, (ZERO && KB == 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : y[ob]);
+    for (int ob = 0; ob < OB; ++ob) y[ob] = mfma_split<HI1>(load_a(ob, KB - 1), pb, (ZERO && KB == 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : y[ob]);
   }
 }
 
 // ZERO (split mode): y is an output, not an accumulator - the first term of every block product takes a literal zero as its C
 // operand instead of OB x 4 registers the caller would have to clear.
-template <int KB, int OB, int BF16 = 0, bool SPL = false, bool ZERO = false>
+template <int KB, int OB, int BF16 = 0, int SPL = 0, bool ZERO = false>
 __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, const f32x4 (&x)[KB], f32x4 (&y)[OB], int lane, float mult = 1.f) {
-  static_assert(!ZERO || SPL, "ZERO: split mode only");
-  if constexpr (SPL) {
+  static_assert(!ZERO || SPL != 0, "ZERO: split mode only");
+  if constexpr (SPL != 0) {
     Split2 xs[KB];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) xs[kb] = split2(x[kb], mult);
-    apply_layer_g1_s<KB, OB, ZERO>(img, xs, y, lane);
+    apply_layer_g1_s<KB, OB, ZERO, SPL == 2>(img, xs, y, lane);
     return;
   }
   if constexpr (BF16) {
@@ -783,8 +799,11 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 #define NESVOR_FWD_MINBLOCKS 2  // (round 4: with the scalar-base input addressing the split-mode instantiations need 144-156 VGPRs - three
                                 // workgroups would fit a CU; launch_kb explains why two are launched)
 #endif
-template <int KB1, int NH, bool SPL, bool SAVE, bool COMPACT = false, bool OUT1 = false>
-__global__ __launch_bounds__(256, (SPL && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) void mlp_fwd_pf_kernel(const MlpArgs a) {
+// SPLM: 0 fp32 MFMAs, 1 (true) the split mode, 2 the split mode's leading term alone (nesvor_mlp_t.bf16_operands == 4: scaled fp16
+// operands, ONE MFMA per product - same scales, images and save formats, a third of the matrix work and half of the splitting)
+template <int KB1, int NH, int SPLM, bool SAVE, bool COMPACT = false, bool OUT1 = false>
+__global__ __launch_bounds__(256, (SPLM != 0 && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) void mlp_fwd_pf_kernel(const MlpArgs a) {
+  constexpr bool SPL = SPLM != 0;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int k_in = a.k_a + a.k_b;
   constexpr int kBlk = 256;  // floats per image block (split mode: two fp16 planes)
@@ -917,8 +936,8 @@ __global__ __launch_bounds__(256, (SPL && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) 
 #pragma unroll
         for (int g = 0; g < kG; ++g) h[l][g][ob] = bq;
       }
-      if (l == 0) apply_layer<KB1, kHB, false, SPL>(img1, x, h[0], lane, mult[0]);
-      else apply_layer<kHB, kHB, false, SPL>(imgh + (l - 1) * kHB * kHB * kBlk, h[l - 1], h[l], lane, mult[l]);
+      if (l == 0) apply_layer<KB1, kHB, false, SPLM>(img1, x, h[0], lane, mult[0]);
+      else apply_layer<kHB, kHB, false, SPLM>(imgh + (l - 1) * kHB * kHB * kBlk, h[l - 1], h[l], lane, mult[l]);
       if constexpr (SAVE && COMPACT) {
         // The gate bits of a layer from the SIGN bits of the pre-activations: v_alignbit_b32 sg, sg, x, 31 = (sg << 1) | (x >> 31)
         // shifts one sign in per instruction (rounds 1-3: v_min_u32 + v_lshl_or_b32 on the ReLU output, two per value).
@@ -965,7 +984,7 @@ __global__ __launch_bounds__(256, (SPL && KB1 <= 2) ? NESVOR_FWD_MINBLOCKS : 1) 
       const f32x4 bq = *reinterpret_cast<const f32x4*>(bias + NH * kWidth + 4 * q);
 #pragma unroll
       for (int g = 0; g < kG; ++g) o[g][0] = bq;
-      apply_layer<kHB, 1, false, SPL>(imgo, h[NH - 1], o, lane, mult[NH]);
+      apply_layer<kHB, 1, false, SPLM>(imgo, h[NH - 1], o, lane, mult[NH]);
       if constexpr (SPL) {
 #pragma unroll
         for (int g = 0; g < kG; ++g) o[g][0] *= inv_unit[NH];
@@ -1150,10 +1169,17 @@ __device__ __forceinline__ void read_operand0(const float* tile, int i, int q, f
   for (int t = 0; t < 4; ++t) v[t] = tile[(4 * q + t) * kTile0Stride + i];
 }
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+template <bool HI1 = false>
 __device__ __forceinline__ void stage_planes(float* tile, const Split2& s, int j, int q) {
   char* p = reinterpret_cast<char*>(tile) + 8 * ((j ^ ((q >> 1) << 2)) + kPlaneQ * q);
   *reinterpret_cast<s16x4*>(p) = s.hi;
-  *reinterpret_cast<s16x4*>(p + kPlaneBytes) = s.lo;
+  if constexpr (!HI1) *reinterpret_cast<s16x4*>(p + kPlaneBytes) = s.lo;
+}
+// HI1: the high plane of a tile alone, as the A (feature i, samples 4q..4q+3) or B operand of a 16x16x16 product
+__device__ __forceinline__ s16x4 read_plane_hi(const float* tile, int i, int q) {
+  const int js = 4 * q + (i >> 2);
+  const char* p = reinterpret_cast<const char*>(tile) + 8 * ((js ^ ((i & 2) << 1)) + kPlaneQ * (i & 3));
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
 }
 // The two A tuples of a dW block product - (lo | hi) and (hi | lo): each plane is needed in both halves of a register
 // quadruple.  Every tuple is READ into place (four transposing reads per tile instead of two reads and four register
@@ -1336,6 +1362,23 @@ __device__ __forceinline__ void accumulate_dw_tuples(const float* tiles, const f
   }
 }
 
+// HI1 (mode 4): the same products from the high planes alone - one 16x16x16 MFMA per block product; `ap` holds the requested high
+// plane of the first A tile, the next one is requested before the current one is multiplied (as above)
+template <int OB, int IB>
+__device__ __forceinline__ void accumulate_dw_hi(const float* tiles, const s16x4 (&b_hi)[IB], f32x4 (&acc)[OB][IB], int i, int q,
+                                                 s16x4& ap, const float* next_tile) {
+#pragma unroll
+  for (int ob = 0; ob < OB; ++ob) {
+    s16x4 an = ap;
+    const float* nt = ob + 1 < OB ? tiles + (ob + 1) * kPlaneTileFloats : next_tile;
+    if (nt != nullptr) an = read_plane_hi(nt, i, q);
+    __builtin_amdgcn_sched_barrier(0x047F);  // everything but LDS instructions may cross: the read above stays above
+#pragma unroll
+    for (int c = 0; c < IB; ++c) acc[ob][c] = mfma16_f16(ap, b_hi[c], acc[ob][c]);
+    ap = an;
+  }
+}
+
 // SPL: the dX chain (contraction over features, 32 at a time) AND the dW products (contraction over the 16 samples of a group,
 // two terms per instruction: accumulate_dw_planes) run on split-fp16 operands - see split2() and MlpScales for the units.
 // COMPACT (nesvor_mlp_t.compact_save): the chain waves gate with the saved sign bits (one word per lane and group instead of
@@ -1343,8 +1386,14 @@ __device__ __forceinline__ void accumulate_dw_tuples(const float* tiles, const f
 // OUT1 (split mode, out_dim == 1): the output layer's two products are rank one - d h = w_out dy and dW_out = sum_s dy_s h_s -
 // and run as fp32 VALU work (16 multiplies per lane in the chain wave, 16 FMAs in the dW wave) instead of 24 + 12 MFMAs on
 // 15/16 padding and the splits of their operands.
-template <int KB1, int NH, int BF16 = 0, bool SPL = false, bool COMPACT = false, bool OUT1 = false>
+// SPLM: as in mlp_fwd_pf_kernel (2 = HI1: the leading term of the split alone; COMPACT instantiations only - every operand still goes
+// through split2(), stage_planes() and the transposing reads, minus their low planes: one MFMA per block product in the chain and the
+// recomputation, one 16x16x16 MFMA per block product of a weight gradient)
+template <int KB1, int NH, int BF16 = 0, int SPLM = 0, bool COMPACT = false, bool OUT1 = false>
 __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
+  constexpr bool SPL = SPLM != 0;
+  constexpr bool HI1 = SPLM == 2;
+  static_assert(!HI1 || COMPACT, "HI1: compact-save instantiations only");
   static_assert(!COMPACT || (SPL && !BF16), "compact save: split-operand mode only");
   static_assert(!OUT1 || (SPL && !BF16), "OUT1: split-operand mode only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1604,7 +1653,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             for (int r = 0; r < 4; ++r) d[ib][r] = w[r] * dyj;
           }
         } else {
-          apply_layer_g1<1, kHB, BF16, SPL, SPL>(imgo, gov, d, lane, m_d[NH]);
+          apply_layer_g1<1, kHB, BF16, SPLM, SPL>(imgo, gov, d, lane, m_d[NH]);
         }
 #pragma unroll
         for (int l = NH - 1; l >= 0; --l) {
@@ -1646,7 +1695,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
                 ll.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h16x2, ll.y) * ip);
                 dp.hi = __builtin_bit_cast(s16x4, hh); dp.lo = __builtin_bit_cast(s16x4, ll);
               }
-              stage_planes(buf + kTile0Floats + ((NH - 1 - l) * kHB + ib) * kPlaneTileFloats, dp, j, q);
+              stage_planes<HI1>(buf + kTile0Floats + ((NH - 1 - l) * kHB + ib) * kPlaneTileFloats, dp, j, q);
             } else {
               stage_tile(buf + (1 + (NH - 1 - l) * kHB + ib) * kTileFloats, d[ib], j, q);
             }
@@ -1657,8 +1706,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
               for (int ib = 0; ib < kHB; ++ib) d2[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            if constexpr (PLANES) apply_layer_g1_s<kHB, kHB, true>(imgh + (l - 1) * kHB * kHB * kBlk, ds, d2, lane);
-            else apply_layer_g1<kHB, kHB, BF16, SPL, SPL>(imgh + (l - 1) * kHB * kHB * kBlk, d, d2, lane);
+            if constexpr (PLANES) apply_layer_g1_s<kHB, kHB, true, HI1>(imgh + (l - 1) * kHB * kHB * kBlk, ds, d2, lane);
+            else apply_layer_g1<kHB, kHB, BF16, SPLM, SPL>(imgh + (l - 1) * kHB * kHB * kBlk, d, d2, lane);
 #pragma unroll
             for (int ib = 0; ib < kHB; ++ib) d[ib] = d2[ib];
           } else if (a.dxa != nullptr || a.dxb != nullptr) {
@@ -1667,8 +1716,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
               for (int ib = 0; ib < KB1; ++ib) dx[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            if constexpr (PLANES) apply_layer_g1_s<kHB, KB1, true>(img1, ds, dx, lane);
-            else apply_layer_g1<kHB, KB1, BF16, SPL, SPL>(img1, d, dx, lane);
+            if constexpr (PLANES) apply_layer_g1_s<kHB, KB1, true, HI1>(img1, ds, dx, lane);
+            else apply_layer_g1<kHB, KB1, BF16, SPLM, SPL>(img1, d, dx, lane);
             if constexpr (SPL) {
               const float un = inv_dx * inv_pj;  // the accumulators' units and the sample's scale: both powers of two
 #pragma unroll
@@ -1779,23 +1828,30 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
               xc[kb][r] = (kb < ka_blocks || 16 * (kb - ka_blocks) + 4 * q + r < a.k_b) ? xcr[kb][r] : 0.f;
           issue_xc(gnext, xcr);
           PlanesA ap;
-          read_planes2(dt0, j, q, dup, ap);
+          s16x4 ap1 = s16x4{0, 0, 0, 0};  // HI1: the high plane of the next A tile
+          if constexpr (HI1) ap1 = read_plane_hi(dt0, j, q);
+          else read_planes2(dt0, j, q, dup, ap);
           // the input: split once - the B operand of the first layer's product here and, through the planes, of dW_0
           Split2 xs[KB1];
 #pragma unroll
           for (int kb = 0; kb < KB1; ++kb) {
             xs[kb] = split2(xc[kb], sc.sx[0]);
-            stage_planes(my_b + kb * kPlaneTileFloats, xs[kb], j, q);
+            stage_planes<HI1>(my_b + kb * kPlaneTileFloats, xs[kb], j, q);
           }
           f32x4 h[kHB];
 #pragma unroll
           for (int ob = 0; ob < kHB; ++ob) h[ob] = *reinterpret_cast<const f32x4*>(bias0 + 16 * ob + 4 * q);
-          apply_layer_g1_s<KB1, kHB>(imgf1, xs, h, lane);
+          apply_layer_g1_s<KB1, kHB, false, HI1>(imgf1, xs, h, lane);
 #pragma unroll
           for (int ob = 0; ob < kHB; ++ob)
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[ob][r] = relu_f(h[ob][r]);
-          {
+          if constexpr (HI1) {
+            s16x4 bx[KB1];
+#pragma unroll
+            for (int kb = 0; kb < KB1; ++kb) bx[kb] = read_plane_hi(my_b + kb * kPlaneTileFloats, j, q);
+            accumulate_dw_hi<kHB, KB1>(dt0, bx, acc_1, j, q, ap1, NH > 1 ? dt0 - kHB * kPlaneTileFloats : nullptr);
+          } else {
             f16x8 bx[KB1];
 #pragma unroll
             for (int kb = 0; kb < KB1; ++kb) bx[kb] = read_planes_b(my_b + kb * kPlaneTileFloats, j, q);
@@ -1809,19 +1865,26 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
 #pragma unroll
             for (int ib = 0; ib < kHB; ++ib) {
               hs[ib] = split2(h[ib], m_h[l - 1]);
-              stage_planes(my_b + ib * kPlaneTileFloats, hs[ib], j, q);
+              stage_planes<HI1>(my_b + ib * kPlaneTileFloats, hs[ib], j, q);
             }
 #pragma unroll
             for (int ob = 0; ob < kHB; ++ob) h[ob] = *reinterpret_cast<const f32x4*>(bias0 + l * kWidth + 16 * ob + 4 * q);
-            apply_layer_g1_s<kHB, kHB>(imgf2 + (l - 1) * kHB * kHB * kBlk, hs, h, lane);
+            apply_layer_g1_s<kHB, kHB, false, HI1>(imgf2 + (l - 1) * kHB * kHB * kBlk, hs, h, lane);
 #pragma unroll
             for (int ob = 0; ob < kHB; ++ob)
 #pragma unroll
               for (int r = 0; r < 4; ++r) h[ob][r] = relu_f(h[ob][r]);
-            f16x8 bh[kHB];
+            if constexpr (HI1) {
+              s16x4 bh[kHB];
 #pragma unroll
-            for (int ib = 0; ib < kHB; ++ib) bh[ib] = read_planes_b(my_b + ib * kPlaneTileFloats, j, q);
-            accumulate_dw_tuples<kHB, kHB>(dtl, bh, acc_h[l - 1], j, q, ap, l + 1 < NH ? dtl - kHB * kPlaneTileFloats : nullptr, dup);
+              for (int ib = 0; ib < kHB; ++ib) bh[ib] = read_plane_hi(my_b + ib * kPlaneTileFloats, j, q);
+              accumulate_dw_hi<kHB, kHB>(dtl, bh, acc_h[l - 1], j, q, ap1, l + 1 < NH ? dtl - kHB * kPlaneTileFloats : nullptr);
+            } else {
+              f16x8 bh[kHB];
+#pragma unroll
+              for (int ib = 0; ib < kHB; ++ib) bh[ib] = read_planes_b(my_b + ib * kPlaneTileFloats, j, q);
+              accumulate_dw_tuples<kHB, kHB>(dtl, bh, acc_h[l - 1], j, q, ap, l + 1 < NH ? dtl - kHB * kPlaneTileFloats : nullptr, dup);
+            }
           }
           // output layer: h = activations of the last hidden layer (units unit_h[NH - 1])
           if constexpr (OUT1) {
@@ -1833,20 +1896,25 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           } else {
             float av[4];
             read_operand0(buf, j, q, av);
-            f16x8 bh[kHB];
 #pragma unroll
             for (int ib = 0; ib < kHB; ++ib) {
               const Split2 hs = split2(h[ib], m_h[NH - 1]);
-              stage_planes(my_b + ib * kPlaneTileFloats, hs, j, q);
+              stage_planes<HI1>(my_b + ib * kPlaneTileFloats, hs, j, q);
             }
-#pragma unroll
-            for (int ib = 0; ib < kHB; ++ib) bh[ib] = read_planes_b(my_b + ib * kPlaneTileFloats, j, q);
             const Split2 sa = split2(f32x4{av[0], av[1], av[2], av[3]}, m_d[NH]);
-            const f16x8 a_lh = join8h(sa.lo, sa.hi), a_hl = join8h(sa.hi, sa.lo);
+            if constexpr (HI1) {
 #pragma unroll
-            for (int ib = 0; ib < kHB; ++ib) acc_o[0][ib] = mfma32_f16(a_lh, bh[ib], acc_o[0][ib]);
+              for (int ib = 0; ib < kHB; ++ib) acc_o[0][ib] = mfma16_f16(sa.hi, read_plane_hi(my_b + ib * kPlaneTileFloats, j, q), acc_o[0][ib]);
+            } else {
+              f16x8 bh[kHB];
 #pragma unroll
-            for (int ib = 0; ib < kHB; ++ib) acc_o[0][ib] = mfma32_f16(a_hl, bh[ib], acc_o[0][ib]);
+              for (int ib = 0; ib < kHB; ++ib) bh[ib] = read_planes_b(my_b + ib * kPlaneTileFloats, j, q);
+              const f16x8 a_lh = join8h(sa.lo, sa.hi), a_hl = join8h(sa.hi, sa.lo);
+#pragma unroll
+              for (int ib = 0; ib < kHB; ++ib) acc_o[0][ib] = mfma32_f16(a_lh, bh[ib], acc_o[0][ib]);
+#pragma unroll
+              for (int ib = 0; ib < kHB; ++ib) acc_o[0][ib] = mfma32_f16(a_hl, bh[ib], acc_o[0][ib]);
+            }
           }
           MLP_TL(const unsigned long long tw_ = __builtin_amdgcn_s_memtime();)
           settle_xc();
@@ -2287,8 +2355,10 @@ int fill_args(MlpArgs* a, const nesvor_mlp_t* d, int64_t N) {
   const int S = d->samples_per_pixel;
   a->fast = (N % 16 == 0 && S % 16 == 0 && d->k_a % 16 == 0) ? 1 : 0;
   a->dxa_group = d->dxa_group_sums ? 1 : 0;
-  a->bf16 = d->bf16_operands;  // 0: fp32 MFMA, 1: bf16-rounded operands, 2: split (fp32-equivalent) operands, 3: fp16-rounded operands
-  if (a->bf16 < 0 || a->bf16 > 3) return (int)hipErrorInvalidValue;
+  a->bf16 = d->bf16_operands;  // 0: fp32 MFMA, 1: bf16-rounded operands, 2: split (fp32-equivalent) operands, 3: fp16-rounded operands, 4: scaled fp16 operands
+  if (a->bf16 < 0 || a->bf16 > 4) return (int)hipErrorInvalidValue;
+  a->hi1 = 0;
+  if (a->bf16 == 4) { a->bf16 = 2; a->hi1 = 1; }  // (the split mode's scales, images and save formats; its leading term alone where a kernel has that form - every other kernel evaluates the full split or fp32 MFMAs: more accurate, always valid)
   a->half16 = a->bf16 == 3 ? 1 : 0;
   if (a->half16) a->bf16 = 1;  // (every host-side decision below is that of the 16-bit operand modes; the launches pick the type)
   a->prep = d->prep;
@@ -2446,6 +2516,22 @@ extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, cons
     a.Hm = reinterpret_cast<uint32_t*>(saved_hidden[0]);
     a.H[0] = nullptr;
     const size_t lds = fwd_lds_bytes(a.n_linear, kb1);
+    if (a.hi1) {  // mode 4: the leading term alone
+      if (net->out_dim == 1 && out1_on()) {
+        if (net->n_hidden == 1)
+          return launch_kb(mlp_fwd_pf_kernel<1, 1, 2, true, true, true>, mlp_fwd_pf_kernel<2, 1, 2, true, true, true>,
+                           mlp_fwd_pf_kernel<2, 1, 2, true, true, true>, mlp_fwd_pf_kernel<2, 1, 2, true, true, true>, kb1, grid, lds,
+                           (hipStream_t)stream, a, 256, n_tiles);
+        return launch_kb(mlp_fwd_pf_kernel<1, 2, 2, true, true, true>, mlp_fwd_pf_kernel<2, 2, 2, true, true, true>,
+                         mlp_fwd_pf_kernel<2, 2, 2, true, true, true>, mlp_fwd_pf_kernel<2, 2, 2, true, true, true>, kb1, grid, lds,
+                         (hipStream_t)stream, a, 256, n_tiles);
+      }
+      if (net->n_hidden == 1)
+        return launch_kb(mlp_fwd_pf_kernel<1, 1, 2, true, true>, mlp_fwd_pf_kernel<2, 1, 2, true, true>, mlp_fwd_pf_kernel<2, 1, 2, true, true>,
+                         mlp_fwd_pf_kernel<2, 1, 2, true, true>, kb1, grid, lds, (hipStream_t)stream, a, 256, n_tiles);
+      return launch_kb(mlp_fwd_pf_kernel<1, 2, 2, true, true>, mlp_fwd_pf_kernel<2, 2, 2, true, true>, mlp_fwd_pf_kernel<2, 2, 2, true, true>,
+                       mlp_fwd_pf_kernel<2, 2, 2, true, true>, kb1, grid, lds, (hipStream_t)stream, a, 256, n_tiles);
+    }
     if (net->out_dim == 1 && out1_on()) {  // single output row: VALU output layer
       if (net->n_hidden == 1)
         return launch_kb(mlp_fwd_pf_kernel<1, 1, true, true, true, true>, mlp_fwd_pf_kernel<2, 1, true, true, true, true>,
@@ -2464,6 +2550,13 @@ extern "C" int nesvor_mlp_forward(const nesvor_mlp_t* net, const float* xa, cons
   if (use_pf && a.bf16 != 1 && a.fast && a.off32 && net->n_hidden <= 2 && ((N >> 4) % (4 * kG)) == 0 && (save_all || save_none)) {
     const bool x6 = a.bf16 == 2;
     const size_t lds = fwd_lds_bytes(a.n_linear, kb1);
+    if (x6 && a.hi1 && save_none && kb1 <= 2) {  // mode 4, nothing saved (inference): the leading term alone
+      if (net->n_hidden == 1)
+        return launch_kb(mlp_fwd_pf_kernel<1, 1, 2, false>, mlp_fwd_pf_kernel<2, 1, 2, false>, mlp_fwd_pf_kernel<2, 1, 2, false>,
+                         mlp_fwd_pf_kernel<2, 1, 2, false>, kb1, grid, lds, (hipStream_t)stream, a, 256, n_tiles);
+      return launch_kb(mlp_fwd_pf_kernel<1, 2, 2, false>, mlp_fwd_pf_kernel<2, 2, 2, false>, mlp_fwd_pf_kernel<2, 2, 2, false>,
+                       mlp_fwd_pf_kernel<2, 2, 2, false>, kb1, grid, lds, (hipStream_t)stream, a, 256, n_tiles);
+    }
 #define NESVOR_PF(NH, SPL, SAVE) launch_kb(mlp_fwd_pf_kernel<1, NH, SPL, SAVE>, mlp_fwd_pf_kernel<2, NH, SPL, SAVE>, \
       mlp_fwd_pf_kernel<3, NH, SPL, SAVE>, mlp_fwd_pf_kernel<4, NH, SPL, SAVE>, kb1, grid, lds, (hipStream_t)stream, a, 256, n_tiles)
     if (net->n_hidden == 1) {
@@ -2515,6 +2608,24 @@ extern "C" int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float*
   if (compact) {
     a.Hm = reinterpret_cast<uint32_t*>(saved_hidden[0]);
     a.H[0] = nullptr;
+    if (a.hi1) {  // mode 4: the leading term alone
+      if (net->out_dim == 1 && out1_on()) {
+        const size_t lds_o = ws_bwd_lds_bytes(net->n_hidden, kb1, true, true) + sizeof(float) * kWidth;
+        if (net->n_hidden == 1)
+          return launch_kb(mlp_bwd_ws_kernel<1, 1, 0, 2, true, true>, mlp_bwd_ws_kernel<2, 1, 0, 2, true, true>,
+                           mlp_bwd_ws_kernel<2, 1, 0, 2, true, true>, mlp_bwd_ws_kernel<2, 1, 0, 2, true, true>, kb1,
+                           dim3((unsigned)n_partial), lds_o, (hipStream_t)stream, a, 512);
+        return launch_kb(mlp_bwd_ws_kernel<1, 2, 0, 2, true, true>, mlp_bwd_ws_kernel<2, 2, 0, 2, true, true>,
+                         mlp_bwd_ws_kernel<2, 2, 0, 2, true, true>, mlp_bwd_ws_kernel<2, 2, 0, 2, true, true>, kb1,
+                         dim3((unsigned)n_partial), lds_o, (hipStream_t)stream, a, 512);
+      }
+      const size_t lds_c = ws_bwd_lds_bytes(net->n_hidden, kb1, true, true);
+      if (net->n_hidden == 1)
+        return launch_kb(mlp_bwd_ws_kernel<1, 1, 0, 2, true>, mlp_bwd_ws_kernel<2, 1, 0, 2, true>, mlp_bwd_ws_kernel<2, 1, 0, 2, true>,
+                         mlp_bwd_ws_kernel<2, 1, 0, 2, true>, kb1, dim3((unsigned)n_partial), lds_c, (hipStream_t)stream, a, 512);
+      return launch_kb(mlp_bwd_ws_kernel<1, 2, 0, 2, true>, mlp_bwd_ws_kernel<2, 2, 0, 2, true>, mlp_bwd_ws_kernel<2, 2, 0, 2, true>,
+                       mlp_bwd_ws_kernel<2, 2, 0, 2, true>, kb1, dim3((unsigned)n_partial), lds_c, (hipStream_t)stream, a, 512);
+    }
     if (net->out_dim == 1 && out1_on()) {  // single output row: VALU output layer
       const size_t lds_o = ws_bwd_lds_bytes(net->n_hidden, kb1, true, true) + sizeof(float) * kWidth;
       if (net->n_hidden == 1)

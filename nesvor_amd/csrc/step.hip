@@ -233,7 +233,9 @@ extern "C" int nesvor_step_run(void* handle, const float* xyz, const float* v, c
   net_d.weight_images = nesvor_mlp_weight_images_bytes(&net_d) > 0 ? wimg_d : nullptr;
   net_s.weight_images = (d.has_lv && nesvor_mlp_weight_images_bytes(&net_s) > 0) ? wimg_s : nullptr;
   net_b.weight_images = (d.has_b && nesvor_mlp_weight_images_bytes(&net_b) > 0) ? wimg_b : nullptr;
-  const bool split_d = net_d.bf16_operands == 2, split_s = d.has_lv && net_s.bf16_operands == 2, split_b = d.has_b && net_b.bf16_operands == 2;
+  // (modes 2 and 4 - the split and its leading term alone - share scales, bounds and images)
+  auto scaled = [](const nesvor_mlp_t& n_) { return n_.bf16_operands == 2 || n_.bf16_operands == 4; };
+  const bool split_d = scaled(net_d), split_s = d.has_lv && scaled(net_s), split_b = d.has_b && scaled(net_b);
   const int layout = NESVOR_LAYOUT_FEATURE_MAJOR;
   const bool overlap_owner = (d.overlap_owner & 1) != 0;
   // AdamW on the table inside the owner pass (single call covers gradient and update, nothing to exchange in between);

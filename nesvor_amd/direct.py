@@ -103,6 +103,8 @@ class DirectStep:
             self.bf16 = mlp_mod.FP16  # the reference's default arithmetic, under its loss scaler (fused.LossScaler)
         elif bool(getattr(a, "mlp_bf16", False)) or half_precision_model(model):
             self.bf16 = True
+        elif bool(getattr(a, "mlp_fp16", False)):
+            self.bf16 = mlp_mod.FP16S  # scaled fp16 operands on the split mode's kernels: one MFMA per product (opt-in)
         else:
             self.bf16 = mlp_mod.MFMA_FP32 if getattr(a, "mlp_fp32_mfma", False) else False
         import os
@@ -185,8 +187,8 @@ class DirectStep:
             return False
         if self.has_b and self.parallel:
             return False
-        if self.bf16 and not self._fused_backward_takes_all():
-            return False  # (the dX + dW launch pair that other shapes fall back to has no bf16-operand form)
+        if mlp_mod.operand_mode(self.bf16) in (mlp_mod.BF16, mlp_mod.FP16) and not self._fused_backward_takes_all():
+            return False  # (the dX + dW launch pair that other shapes fall back to has no bf16-operand form; the scaled modes 2 / 4 run it on fp32 MFMAs)
         return True
 
     def set_loss_scale(self, scale: float) -> None:

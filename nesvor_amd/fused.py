@@ -118,8 +118,8 @@ class FusedTrainer:
 
             _mlp.HALF_OPERANDS[0] = _mlp.FP16  # (the module path of tinycudann.Network: inference between / after training)
             self.scaler = LossScaler()
-        if getattr(args, "mlp_bf16", False) and self.direct is None:
-            raise RuntimeError("args.mlp_bf16 needs the autograd-free step (fused fp32 model, MLPs of at most two hidden layers)")
+        if (getattr(args, "mlp_bf16", False) or getattr(args, "mlp_fp16", False)) and self.direct is None:
+            raise RuntimeError("args.mlp_bf16 / args.mlp_fp16 need the autograd-free step (fused fp32 model, MLPs of at most two hidden layers)")
 
     @property
     def reduce_hook(self):

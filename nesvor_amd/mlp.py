@@ -29,7 +29,13 @@ FUSED_BACKWARD = True  # False: separate dX and dW kernels (kept as cross-check 
 #   FP16 (3): operands rounded to fp16 (round 6) - the arithmetic of the reference's DEFAULT mode (fp16 CutlassMLP,
 #     nesvor/nesvor/models.py:28-41), same kernels as BF16 with fp16 MFMAs; its narrow exponent range is what the reference's
 #     GradScaler exists for (train.py:161-164): opt-in with ``args.fp16_loss_scaling`` (nesvor_amd.fused.LossScaler).
-MFMA_FP32, BF16, SPLIT, FP16 = 0, 1, 2, 3
+#   FP16S (4): "scaled fp16" (round 6) - the SPLIT mode's machinery (power-of-two scales from ``prep``, the same operand images,
+#     the bits-only save, the backward's per-sample scale) with the leading term of every split alone: operands rounded to fp16
+#     AFTER scaling (11 bits, no overflow and no loss scaler), ONE MFMA per product.  What fp16 arithmetic buys on the kernels the
+#     fp32 path runs on; opt-in for the fp32 model structure (``args.mlp_fp16``).  Kernels without that form evaluate the full
+#     split or fp32 MFMAs - more accurate, always valid.
+MFMA_FP32, BF16, SPLIT, FP16, FP16S = 0, 1, 2, 3, 4
+SCALED_MODES = (SPLIT, FP16S)  # modes that need ``prep`` (operand bounds + weight norms)
 FP32_OPERANDS = MFMA_FP32 if os.environ.get("NESVOR_MLP_FP32", "split").lower() == "mfma" else SPLIT
 
 
@@ -280,9 +286,9 @@ def forward_raw(weights, biases, xa, xb, b_row0, k_b, S, need_saved, bf16=False,
     if weights[0].shape[1] != k_a + k_b:
         raise RuntimeError("first layer width does not match k_a + k_b")
     d = _desc(weights, biases, k_a, k_b, b_row0, S, bf16, prep)
-    if d.bf16_operands == SPLIT and prep is None:
+    if d.bf16_operands in SCALED_MODES and prep is None:
         prep = prepare(d, xa, xb, None, N, PREP_INPUT | PREP_WEIGHTS)
-    images = build_weight_images(d, prep) if (weight_images and d.bf16_operands == SPLIT) else None  # noqa: F841 (kept alive until the launch is enqueued; the stream orders the free)
+    images = build_weight_images(d, prep) if (weight_images and d.bf16_operands in SCALED_MODES) else None  # noqa: F841 (kept alive until the launch is enqueued; the stream orders the free)
     if y_absmax is not None:
         d.y_absmax = y_absmax.data_ptr()
     # saved hidden activations, MFMA fragment layout; bf16 mode stores them as bf16 (they are only used as bf16 operands);
@@ -312,9 +318,9 @@ def backward_raw(weights, biases, xa, xb, dy, saved, b_row0, k_b, S, dxb, need_d
     N = xb.shape[1]
     k_a = 0 if xa is None else xa.shape[1]
     d = _desc(weights, biases, k_a, k_b, b_row0, S, bf16, prep)
-    if d.bf16_operands == SPLIT and prep is None:  # (the same input bounds and weight norms as the forward's: same data)
+    if d.bf16_operands in SCALED_MODES and prep is None:  # (the same input bounds and weight norms as the forward's: same data)
         prep = prepare(d, xa, xb, dy, N, PREP_INPUT | PREP_DY | PREP_WEIGHTS)
-    images = build_weight_images(d, prep) if (weight_images and d.bf16_operands == SPLIT) else None  # noqa: F841
+    images = build_weight_images(d, prep) if (weight_images and d.bf16_operands in SCALED_MODES) else None  # noqa: F841
     d.compact_save = int(saved[0].numel() == (N + 15) // 16 * 16 * 4)  # (the forward that wrote `saved` decided)
     dev = xb.device
     # the wave-specialised fused kernel (dX + dW + db in one launch) needs no dpre scratch (signalled by NULL entries); shapes it
@@ -572,4 +578,6 @@ def inference_operands(inr, args):
         return FP16 if getattr(args, "fp16_loss_scaling", False) else True
     if getattr(args, "mlp_bf16", False):
         return True
+    if getattr(args, "mlp_fp16", False):
+        return FP16S
     return MFMA_FP32 if getattr(args, "mlp_fp32_mfma", False) else False

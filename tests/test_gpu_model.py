@@ -389,18 +389,21 @@ def test_train_phantom_bf16_mlp_mode_keeps_psnr(device):
     truth = vol.reshape(-1)
     inside = truth > 0
     psnr = {}
-    for bf16 in (False, True):
+    for bf16 in (False, True, "fp16 scaled"):
         # S = 16 and a batch that is a multiple of 16 samples: the wave-specialised backward (the only one with a bf16 mode)
+        # "fp16 scaled" (round 6, args.mlp_fp16): the split mode's kernels on their leading term alone - nesvor_mlp_t.bf16_operands = 4
         args = small_args(device=device, n_iter=300, batch_size=512, n_samples=16, finest_resolution=1.0,
-                          log2_hashmap_size=14, no_transformation_optimization=True, depth=2, mlp_bf16=bf16)
+                          log2_hashmap_size=14, no_transformation_optimization=True, depth=2, mlp_bf16=bf16 is True,
+                          mlp_fp16=bf16 == "fp16 scaled")
         torch.manual_seed(0)
         inr, _, _ = train(slices, args)
         with torch.no_grad():
             r = inr(pts[:, None], False).mean(-1)
         s = float((r[inside] * truth[inside]).sum() / (r[inside] ** 2).sum())
         psnr[bf16] = _psnr(r[inside] * s, truth[inside], float(truth.max()))
-    print(f"PSNR fp32 {psnr[False]:.2f} dB, bf16-operand MLPs {psnr[True]:.2f} dB")
+    print(f"PSNR fp32 {psnr[False]:.2f} dB, bf16-operand MLPs {psnr[True]:.2f} dB, scaled-fp16-operand MLPs {psnr['fp16 scaled']:.2f} dB")
     assert psnr[True] > 8.0 and abs(psnr[True] - psnr[False]) <= 0.5
+    assert psnr["fp16 scaled"] > 8.0 and abs(psnr["fp16 scaled"] - psnr[False]) <= 0.5
 
 
 def test_sample_volume_runs_and_matches_inr(device, golden):
@@ -626,7 +629,7 @@ def test_native_step_table_update_in_owner_pass_and_deferred_join(device, golden
     {"no_pixel_variance": True, "n_samples": 16}, {"no_slice_scale": True, "no_slice_variance": True, "n_samples": 16},
     {"image_regularization": "TV", "n_samples": 16}, {"n_levels_bias": 2, "depth": 2, "n_samples": 16},
     {"n_levels_bias": 2, "no_pixel_variance": True, "n_samples": 32}, {"n_samples": 24}, {}, {"n_levels_bias": 2, "depth": 2},
-    {"mlp_bf16": True, "n_samples": 16},
+    {"mlp_bf16": True, "n_samples": 16}, {"mlp_fp16": True, "n_samples": 16}, {"mlp_fp16": True},
     # round-5 advisor: sigma_net with 32 + 15 inputs at two hidden layers - samples and pixel features in multiples of 16, yet the
     # wave-specialised backward refuses the shape: the step must run THAT network as a dX + dW launch pair (per-sample dxa rows)
     {"depth": 2, "n_samples": 16, "n_features_slice": 32},

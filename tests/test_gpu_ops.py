@@ -1170,6 +1170,88 @@ def test_fused_mlp_bf16_operand_mode(device, k_a, k_b, b_row0, rows, out_dim, ha
     assert float((y_mfma - y_split).abs().max()) < 2e-6 * float(y_mfma.abs().max())
 
 
+@pytest.mark.parametrize("depth", [1, 2])
+@pytest.mark.parametrize("k_a,k_b,b_row0,rows,out_dim", [(0, 32, 0, 32, 16), (16, 15, 1, 16, 1), (0, 16, 0, 16, 16)])
+def test_fused_mlp_scaled_fp16_mode(device, k_a, k_b, b_row0, rows, out_dim, depth):
+    """``nesvor_mlp_t.bf16_operands = 4`` (round 6, opt-in ``args.mlp_fp16``): the split mode's kernels with the leading term of every
+    split alone - operands rounded to fp16 AFTER a power-of-two scaling, one MFMA per product.  Against the exact network in fp64:
+    fp16-rounding accuracy (2^-11 per operand) in the outputs, input gradients and parameter gradients; really coarser than the fp32
+    evaluation; the inference launch (nothing saved) equals the training launch bit for bit; and - the backward chain's per-sample
+    scale - samples whose upstream gradient lies 2^-20 below the batch's largest keep that accuracy relative to THEMSELVES."""
+    from nesvor_amd import mlp
+    from nesvor_amd.models import build_network
+
+    torch.manual_seed(3 + depth)
+    N, S = 8192, 256
+    net = build_network(n_input_dims=k_a + k_b, n_output_dims=out_dim, activation="ReLU", output_activation="None",
+                        n_neurons=64, n_hidden_layers=depth, dtype=torch.float32).to(device)
+    L = mlp.linear_layers(net)
+    W, Bs = [l.weight.detach() for l in L], [l.bias.detach() for l in L]
+    xa = torch.randn(N // S, k_a, device=device) if k_a else None
+    xb = torch.randn(rows, N, device=device)
+    dy = torch.randn(out_dim, N, device=device)
+    small = torch.zeros(N, dtype=torch.bool, device=device)
+    small.view(-1, 16)[1::2] = True  # every second 16-sample group: upstream gradient 2^-20 below the others
+    dy[:, small] *= 2.0 ** -20
+    y, saved = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, True, bf16=mlp.FP16S)
+    assert saved[0].numel() == N * 4  # the bits-only save of the split mode
+    y_inf, _ = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, False, bf16=mlp.FP16S)
+    if out_dim > 1:
+        assert torch.equal(y, y_inf)
+    else:  # (one output row: the training launch evaluates the output layer on the VALU in fp32, the inference launch on the matrix pipe)
+        assert float((y - y_inf).abs().max()) < 2e-3 * float(y.abs().max())
+    dxb = torch.empty(k_b, N, device=device)
+    dxa, partial = mlp.backward_raw(W, Bs, xa, xb, dy, saved, b_row0, k_b, S, dxb, xa is not None, bf16=mlp.FP16S)
+    flat = partial.sum(0).cpu().double()
+    X = xb[b_row0 : b_row0 + k_b].t()
+    if xa is not None:
+        X = torch.cat([xa.repeat_interleave(S, 0), X], 1)
+    X, Wd, Bd = X.cpu().double(), [w.cpu().double() for w in W], [b.cpu().double() for b in Bs]
+    hs, h = [], X
+    for l in range(depth):
+        h = torch.relu(h @ Wd[l].t() + Bd[l])
+        hs.append(h)
+    yr = h @ Wd[depth].t() + Bd[depth]
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+    e_y = rel(y.t().cpu(), yr)
+    assert 1e-5 < e_y < 3e-3, e_y
+    y32, _ = mlp.forward_raw(W, Bs, xa, xb, b_row0, k_b, S, False)
+    assert rel(y32.t().cpu(), yr) < 3e-6
+    # the gates the backward uses are the forward's saved bits (word (group, lane = 16 q + sample), bit 16 l + 4 b + r = unit 16 b +
+    # 4 q + r of layer l): a unit whose pre-activation is within fp16 rounding of zero may be gated differently from the exact
+    # network - either is a valid subgradient there - so the reference backward takes the kernel's gates
+    words = saved[0].view(torch.int32).view(N // 16, 4, 16).cpu()  # [group][q][sample]
+    gates = []
+    for l in range(depth):
+        g_l = torch.zeros(N // 16, 16, 64, dtype=torch.bool)  # [group][sample][unit]
+        for b in range(4):
+            for r in range(4):
+                g_l[:, :, [16 * b + 4 * q + r for q in range(4)]] = (((words >> (16 * l + 4 * b + r)) & 1) != 0).permute(0, 2, 1)
+        gates.append(g_l.view(N, 64))
+        assert float((gates[l] == (hs[l] > 0)).double().mean()) > 0.99
+    G = dy.t().cpu().double()
+    d, gW, gB = G, [None] * (depth + 1), [None] * (depth + 1)
+    for l in range(depth, -1, -1):
+        inp = hs[l - 1] if l > 0 else X
+        gW[l], gB[l] = d.t() @ inp, d.sum(0)
+        d = d @ Wd[l]
+        if l > 0:
+            d = d * gates[l - 1]
+    dX = d
+    sm = small.cpu()
+    for name, grp in (("large", ~sm), ("2^-20", sm)):
+        e = rel(dxb.t().cpu()[grp], dX[grp][:, k_a:])
+        assert e < 5e-3, (name, e)
+    if xa is not None:
+        assert rel(dxa.view(N // S, -1, k_a).sum(1).cpu(), dX[:, :k_a].view(N // S, S, k_a).sum(1)) < 5e-3
+    off = 0
+    for w, gw, gb in zip(Wd, gW, gB):
+        assert rel(flat[off : off + w.numel()].view_as(w), gw) < 5e-3
+        off += w.numel()
+        assert rel(flat[off : off + gb.numel()], gb) < 5e-3
+        off += gb.numel()
+
+
 @pytest.mark.parametrize("N", [8192, 1 << 20])
 @pytest.mark.parametrize("k_a,k_b,b_row0,rows,out_dim", [(0, 32, 0, 32, 16), (16, 15, 1, 16, 1)])
 def test_fused_mlp_split_operands_keep_fp32_accuracy(device, k_a, k_b, b_row0, rows, out_dim, N):
