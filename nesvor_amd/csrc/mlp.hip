@@ -199,11 +199,41 @@ __device__ __forceinline__ Split2 split2(const f32x4& v, float m) {
   asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(v[0]), "s"(m), "v"(h0));
   asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(v[1]), "s"(m), "v"(h0));
   asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(v[2]), "s"(m), "v"(h1));
+  // (s_nop 1 below: a VALU result must be two wait states old before a matrix instruction reads it, and the hazard recogniser does
+  //  not see writes made by inline asm - see split2m().  The statements of a split are scheduled one by one, so the wait states sit in
+  //  a statement of their own that "redefines" all four results: every consumer is ordered behind it, it behind every write.  17 sites
+  //  of the round-5 build had a v_fma_mix*, one s_waitcnt and the consuming MFMA in a row - the headline density forward among them;
+  //  tools/check_inflight_loads.py::check_asm_valu_mfma now holds every site to the rule.)
   asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(v[3]), "s"(m), "v"(h1));
+  asm("s_nop 1" : "+v"(h0), "+v"(h1), "+v"(l0), "+v"(l1));  // (every consumer of the four results sits behind this statement)
   Split2 r;
   r.hi = __builtin_bit_cast(s16x4, uint2{h0, h1});
   r.lo = __builtin_bit_cast(s16x4, uint2{l0, l1});
   return r;
+}
+// Mode 4 (HI1): the leading term alone.  A VALU write of a VGPR must be TWO wait states old before a matrix instruction reads that
+// register; the compiler's hazard recogniser inserts them for instructions it emits, but it cannot see a write made by inline asm.
+// The full split is safe by construction - its last writes are the low halves, which no product reads first - but with the low half
+// dead the last v_fma_mixhi_f16 sits right in front of the MFMA that consumes it: found as run-to-run differences of ONE weight-gradient
+// block in one instantiation (tools/diag_fp16s_repro.py: 6 of 19 runs; a single s_nop in between: 0 of 200).  The wait states therefore
+// sit in an asm statement behind the writes that every consumer depends on, and the build's assembly check knows the rule
+// (tools/check_inflight_loads.py: v_fma_mix* / v_bfe_i32 results read by v_mfma* fewer than two wait states later).
+template <bool HI1>
+__device__ __forceinline__ Split2 split2m(const f32x4& v, float m) {
+  if constexpr (!HI1) {
+    return split2(v, m);
+  } else {
+    uint32_t h0, h1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(v[0]), "s"(m));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1) : "v"(v[2]), "s"(m));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(v[1]), "s"(m));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(v[3]), "s"(m));
+    asm("s_nop 1" : "+v"(h0), "+v"(h1));
+    Split2 r;
+    r.hi = __builtin_bit_cast(s16x4, uint2{h0, h1});
+    r.lo = r.hi;  // (never read: the HI1 paths take the leading term only)
+    return r;
+  }
 }
 // gfx950's full-rate 16-bit shapes contract 32 k-values per instruction: lane (j, q) supplies k-slots (q, 0..7).  The
 // k index may be numbered freely as long as A and B agree, so slots 0..3 take the lane's four values of one 16-feature
@@ -417,7 +447,7 @@ __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const
       f16x8 bh[kG], bl[kG];
 #pragma unroll
       for (int g = 0; g < kG; ++g) {
-        const Split2 p0 = split2(x[g][kb], mult), p1 = split2(x[g][kb + 1], mult);
+        const Split2 p0 = split2m<HI1>(x[g][kb], mult), p1 = split2m<HI1>(x[g][kb + 1], mult);
         bh[g] = join8h(p0.hi, p1.hi); bl[g] = join8h(p0.lo, p1.lo);
       }
 #pragma unroll
@@ -441,7 +471,7 @@ __device__ __forceinline__ void apply_layer(const float* __restrict__ img, const
       constexpr int kb = KB - 1;
       Split2 pb[kG];
 #pragma unroll
-      for (int g = 0; g < kG; ++g) pb[g] = split2(x[g][kb], mult);
+      for (int g = 0; g < kG; ++g) pb[g] = split2m<HI1>(x[g][kb], mult);
 #pragma unroll
       for (int ob = 0; ob < OB; ++ob) {
         const Split2 a = load_a(ob, kb);
@@ -567,7 +597,7 @@ __device__ __forceinline__ void apply_layer_g1(const float* __restrict__ img, co
   if constexpr (SPL != 0) {
     Split2 xs[KB];
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) xs[kb] = split2(x[kb], mult);
+    for (int kb = 0; kb < KB; ++kb) xs[kb] = split2m<SPL == 2>(x[kb], mult);
     apply_layer_g1_s<KB, OB, ZERO, SPL == 2>(img, xs, y, lane);
     return;
   }
@@ -1683,7 +1713,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             }
             if constexpr (PLANES) {
               __builtin_amdgcn_sched_barrier(0x07FC);  // VALU instructions stay on their side: the adds above, the split below
-              ds[ib] = split2(d[ib], m_d[l]);  // once: for the planes and for this wave's own product below
+              ds[ib] = split2m<HI1>(d[ib], m_d[l]);  // once: for the planes and for this wave's own product below
               Split2 dp = ds[ib];
               if constexpr (!BF16) {  // the dW wave's sums run in the launch's units: the sample's scale comes off (fp16, packed)
                 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
@@ -1835,7 +1865,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
           Split2 xs[KB1];
 #pragma unroll
           for (int kb = 0; kb < KB1; ++kb) {
-            xs[kb] = split2(xc[kb], sc.sx[0]);
+            xs[kb] = split2m<HI1>(xc[kb], sc.sx[0]);
             stage_planes<HI1>(my_b + kb * kPlaneTileFloats, xs[kb], j, q);
           }
           f32x4 h[kHB];
@@ -1864,7 +1894,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             Split2 hs[kHB];
 #pragma unroll
             for (int ib = 0; ib < kHB; ++ib) {
-              hs[ib] = split2(h[ib], m_h[l - 1]);
+              hs[ib] = split2m<HI1>(h[ib], m_h[l - 1]);
               stage_planes<HI1>(my_b + ib * kPlaneTileFloats, hs[ib], j, q);
             }
 #pragma unroll
@@ -1898,10 +1928,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_ws_kernel(const MlpArgs a) {
             read_operand0(buf, j, q, av);
 #pragma unroll
             for (int ib = 0; ib < kHB; ++ib) {
-              const Split2 hs = split2(h[ib], m_h[NH - 1]);
+              const Split2 hs = split2m<HI1>(h[ib], m_h[NH - 1]);
               stage_planes<HI1>(my_b + ib * kPlaneTileFloats, hs, j, q);
             }
-            const Split2 sa = split2(f32x4{av[0], av[1], av[2], av[3]}, m_d[NH]);
+            const Split2 sa = split2m<HI1>(f32x4{av[0], av[1], av[2], av[3]}, m_d[NH]);
             if constexpr (HI1) {
 #pragma unroll
               for (int ib = 0; ib < kHB; ++ib) acc_o[0][ib] = mfma16_f16(sa.hi, read_plane_hi(my_b + ib * kPlaneTileFloats, j, q), acc_o[0][ib]);
@@ -2668,8 +2698,9 @@ extern "C" int nesvor_mlp_backward_bounded(const nesvor_mlp_t* net, const float*
         if (net->n_hidden == 1)
           return launch_kb(mlp_bwd_ws_kernel<1, 1, false, true>, mlp_bwd_ws_kernel<2, 1, false, true>, mlp_bwd_ws_kernel<3, 1, false, true>,
                            mlp_bwd_ws_kernel<4, 1, false, true>, kb1, dim3((unsigned)n_partial), lds_x6, (hipStream_t)stream, a, 512);
-        return launch_kb(mlp_bwd_ws_kernel<1, 2, false, true>, mlp_bwd_ws_kernel<2, 2, false, true>, mlp_bwd_ws_kernel<3, 2, false, true>,
-                         mlp_bwd_ws_kernel<4, 2, false, true>, kb1, dim3((unsigned)n_partial), lds_x6, (hipStream_t)stream, a, 512);
+        // (ws_ok admits two hidden layers with at most two input blocks: wider instantiations would never be launched)
+        return launch_kb(mlp_bwd_ws_kernel<1, 2, false, true>, mlp_bwd_ws_kernel<2, 2, false, true>, mlp_bwd_ws_kernel<2, 2, false, true>,
+                         mlp_bwd_ws_kernel<2, 2, false, true>, kb1, dim3((unsigned)n_partial), lds_x6, (hipStream_t)stream, a, 512);
       }
       if (net->n_hidden == 1)
         return launch_kb(mlp_bwd_ws_kernel<1, 1>, mlp_bwd_ws_kernel<2, 1>, mlp_bwd_ws_kernel<3, 1>, mlp_bwd_ws_kernel<4, 1>,

@@ -119,6 +119,25 @@ def test_scalar_base_written_by_the_valu_too_late():
     assert chk.check_valu_sgpr(body("v_readlane_b32 s4, v1, 0\nv_readlane_b32 s5, v1, 1\ns_and_b64 s[4:5], exec, s[4:5]\nglobal_load_dword v9, v3, s[4:5] offset:0")) == []
 
 
+def test_inline_asm_valu_result_read_by_a_matrix_instruction_too_early():
+    """Round 6: a VGPR written by an inline-asm VALU instruction (split2()'s v_fma_mix*, the gates' v_bfe_i32 - invisible to the
+    compiler's hazard recogniser) must be two issue slots old when a matrix instruction reads it.  Found on the device: one
+    weight-gradient block of one instantiation differed from run to run with `v_fma_mixhi_f16; s_waitcnt; v_mfma` in a row
+    (s_waitcnt is not a slot: it need not stall)."""
+    body = lambda text: [t.strip() for t in text.strip().splitlines() if t.strip()]
+    bad = body("v_fma_mixhi_f16 v23, v119, s72, 0\ns_waitcnt lgkmcnt(0)\nv_mfma_f32_16x16x16_f16 v[10:13], v[22:23], v[100:101], v[10:13]")
+    assert len(chk.check_asm_valu_mfma(bad)) == 1
+    # ... as the B or the C operand too, and with one slot in between
+    assert len(chk.check_asm_valu_mfma(body("v_fma_mixlo_f16 v100, v1, s2, 0\nv_mov_b32_e32 v7, v8\nv_mfma_f32_16x16x32_f16 v[10:13], v[22:25], v[100:103], v[10:13]"))) == 1
+    assert len(chk.check_asm_valu_mfma(body("v_bfe_i32 v12, v1, 3, 1\nv_mfma_f32_16x16x16_f16 v[10:13], v[22:23], v[100:101], v[10:13]"))) == 1
+    # two slots (s_nop 1, or two other instructions) are enough; a compiler-emitted VALU write is the hazard recogniser's business
+    assert chk.check_asm_valu_mfma(body("v_fma_mixhi_f16 v23, v119, s72, 0\ns_nop 1\nv_mfma_f32_16x16x16_f16 v[10:13], v[22:23], v[100:101], v[10:13]")) == []
+    assert chk.check_asm_valu_mfma(body("v_fma_mixhi_f16 v23, v119, s72, 0\nv_mov_b32_e32 v7, v8\nv_mov_b32_e32 v9, v8\nv_mfma_f32_16x16x16_f16 v[10:13], v[22:23], v[100:101], v[10:13]")) == []
+    assert chk.check_asm_valu_mfma(body("v_mov_b32_e32 v23, v119\nv_mfma_f32_16x16x16_f16 v[10:13], v[22:23], v[100:101], v[10:13]")) == []
+    # a branch target in between: another path may arrive there (conservative: the window restarts)
+    assert chk.check_asm_valu_mfma(body("v_fma_mixhi_f16 v23, v119, s72, 0\n.LBB0_3:\nv_mfma_f32_16x16x16_f16 v[10:13], v[22:23], v[100:101], v[10:13]")) == []
+
+
 def test_generated_assembly_of_the_mlp_kernels_is_clean():
     """nesvor_amd/lib/mlp.s is written and checked by the build (nesvor_amd/csrc/build.py: a finding fails the build); here the
     file of the current library is checked once more, so that a stale or hand-copied library does not slip through."""
@@ -129,7 +148,7 @@ def test_generated_assembly_of_the_mlp_kernels_is_clean():
     assert os.path.getmtime(asm) >= os.path.getmtime(os.path.join(root, "nesvor_amd", "csrc", "mlp.hip")), "mlp.s is older than mlp.hip: rebuild"
     kernels = chk.parse(asm)
     assert len(kernels) >= 60 and any("mlp_fwd_pf_kernel" in k for k in kernels) and any("mlp_bwd_ws_kernel" in k for k in kernels)
-    found = [(k, f) for k, body in kernels.items() for f in chk.check(body) + chk.check_store_data(body) + chk.check_dpp(body) + chk.check_valu_sgpr(body)]
+    found = [(k, f) for k, body in kernels.items() for f in chk.check(body) + chk.check_store_data(body) + chk.check_dpp(body) + chk.check_valu_sgpr(body) + chk.check_asm_valu_mfma(body)]
     assert found == [], found[:5]
     # ... and every other translation unit the build wrote (common.h carries issue-now loads of its own; hashgrid.hip an asm DPP scan)
     import glob
@@ -139,7 +158,7 @@ def test_generated_assembly_of_the_mlp_kernels_is_clean():
     for path in others:
         kernels = chk.parse(path)
         assert kernels, path
-        found = [(k, f) for k, body in kernels.items() for f in chk.check(body) + chk.check_store_data(body) + chk.check_dpp(body) + chk.check_valu_sgpr(body)]
+        found = [(k, f) for k, body in kernels.items() for f in chk.check(body) + chk.check_store_data(body) + chk.check_dpp(body) + chk.check_valu_sgpr(body) + chk.check_asm_valu_mfma(body)]
         assert found == [], (path, found[:5])
 
 

@@ -13,6 +13,10 @@ kernel of an assembly file:
     confused with one that issued none;
   * an instruction naming a VGPR with a pending load is reported (the re-issue of a load into the same registers is allowed).
 
+Further straight-line checks of hazards the compiler cannot see through inline asm: wide-store data (check_store_data), DPP
+sources (check_dpp), VALU-written scalar bases (check_valu_sgpr), inline-asm VALU results read by matrix instructions
+(check_asm_valu_mfma, round 6).
+
     python tools/check_inflight_loads.py file.s [kernel-name-substring]      exit status 1 if anything is reported
 """
 import re
@@ -341,6 +345,38 @@ def check_valu_sgpr(body, wait_states=5):
     return out
 
 
+ASM_VALU = ("v_fma_mixlo_f16", "v_fma_mixhi_f16", "v_bfe_i32")  # VALU mnemonics this code base only writes in inline asm
+
+
+def check_asm_valu_mfma(body, wait_states=2):
+    """Fifth (round 6): a VGPR written by the VALU and read by a matrix instruction needs `wait_states` issue slots in between.
+    The hazard recogniser provides them for the instructions the compiler emits; a write made by inline asm (csrc/mlp.hip's
+    split2(): v_fma_mix*; its gates: v_bfe_i32) is invisible to it.  Found on the device as run-to-run differences of one
+    weight-gradient block (tools/diag_fp16s_repro.py).  s_waitcnt is not counted as a slot (it may not stall).  Straight-line
+    scan inside basic blocks."""
+    out, recent = [], []  # per issue slot: registers written by an asm-only VALU mnemonic (newest last)
+    for i, t in enumerate(body):
+        if LABEL.match(t) or re.match(r"^s_(c?branch|endpgm|setpc)", t):
+            recent = []
+            continue
+        mnem = t.split()[0]
+        if mnem == "s_nop":
+            recent = (recent + [set()] * (int(t.split()[1]) + 1))[-wait_states:]
+            continue
+        if mnem == "s_waitcnt":
+            continue
+        toks = [x.strip() for x in t[len(mnem):].split(",")]
+        if mnem.startswith("v_mfma") and len(toks) > 1:
+            src = set()
+            for tok in toks[1:]:
+                src |= regs_of(tok)
+            clash = (set().union(*recent) & src) if recent else set()
+            if clash:
+                out.append((i, t, sorted(clash)))
+        recent = (recent + [regs_of(toks[0]) if mnem in ASM_VALU and toks else set()])[-wait_states:]
+    return out
+
+
 def main():
     only = sys.argv[2] if len(sys.argv) > 2 else None
     bad = 0
@@ -349,6 +385,7 @@ def main():
         rep = check(body) + [(w, i + "   [data registers of the wide store in front of it]", r) for w, i, r in check_store_data(body)]
         rep += [(w, i + "   [DPP source written by the VALU less than two slots before]", r) for w, i, r in check_dpp(body)]
         rep += [(w, i + "   [scalar base written by the VALU less than five slots before]", [f"s{x}" for x in r]) for w, i, r in check_valu_sgpr(body)]
+        rep += [(w, i + "   [operand written by an inline-asm VALU instruction less than two slots before]", r) for w, i, r in check_asm_valu_mfma(body)]
         n_loads = sum(1 for t in body if LOAD.match(t.split()[0]))
         print(f"{name[:100]}: {len(body)} instructions, {n_loads} vector loads, {len(rep)} findings")
         for where, ins, regs in rep[:20]:
