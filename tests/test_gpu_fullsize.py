@@ -159,6 +159,42 @@ def test_c1_oracle_run_replayed_by_hip(device, phantom, fixture, max_db):
     assert rms <= 0.02 * float(phantom.max())
 
 
+def test_c1_oracle_run_replayed_in_scaled_fp16_mode(device, phantom):
+    """What the opt-in 16-bit mode (``args.mlp_fp16``: nesvor_mlp_t.bf16_operands = 4, power-of-two-scaled fp16 operands, one MFMA per
+    product) costs at the STATED phantom: BASELINE C1 at the reduced batch, 200 iterations from the oracle run's random stream.  The
+    first iteration's losses agree with the fp32 oracle to fp16 rounding (1e-2); the reconstruction stays within 0.3 dB of the
+    oracle's PSNR, whole object and interior (the fp32-equivalent default is held to 0.1 dB above)."""
+    from bench import make_args
+    from nesvor_amd.phantom import simulate_stacks
+    from nesvor_amd.train import train
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_run_c1.npz")
+    if not os.path.exists(path):
+        pytest.skip("oracle_run_c1.npz not generated")
+    gold = np.load(path, allow_pickle=False)
+    n_iter, B, S = (int(x) for x in gold["config"][:3])
+    slices, _ = simulate_stacks(phantom, n_stacks=3)
+    args = make_args(device, B, S, 2, n_iter)
+    args.host_rng = True
+    args.mlp_fp16 = True
+    hist = []
+    torch.manual_seed(0)
+    inr, _, _ = train(slices, args, on_iteration=lambda i, losses: hist.append(torch.stack([losses[k].detach() for k in losses])))
+    got, ref = torch.stack(hist).cpu().double().numpy(), gold["loss_history"]
+    keys = [str(k) for k in gold["loss_keys"]]
+    for j, k in enumerate(keys):
+        assert abs(got[0, j] - ref[0, j]) <= 1e-2 * abs(ref[0, j]) + 1e-6, (k, got[0, j], ref[0, j])
+    pts = _points(device)
+    rec = torch.empty(pts.shape[0], device=device)
+    with torch.no_grad():
+        for i in range(0, pts.shape[0], 1 << 18):
+            rec[i : i + (1 << 18)] = inr(pts[i : i + (1 << 18), None], False).mean(-1)
+    p_whole, p_int = _psnr_pair(rec, phantom.reshape(-1), float(gold["skull_threshold"]))
+    o_whole, o_int = float(gold["psnr_whole_db"]), float(gold["psnr_interior_db"])
+    print(f"scaled-fp16 MLP operands: PSNR whole object HIP {p_whole:.3f} / fp32 oracle {o_whole:.3f} dB; interior HIP {p_int:.3f} / oracle {o_int:.3f} dB")
+    assert abs(p_whole - o_whole) <= 0.3 and abs(p_int - o_int) <= 0.3
+
+
 def _sample_lattice(output_resolution, stride, device):
     """tests/golden/make_oracle_run.py::sample_lattice"""
     n = int(round(N / output_resolution))
