@@ -162,8 +162,8 @@ def test_c1_oracle_run_replayed_by_hip(device, phantom, fixture, max_db):
 def test_c1_oracle_run_replayed_in_scaled_fp16_mode(device, phantom):
     """What the opt-in 16-bit mode (``args.mlp_fp16``: nesvor_mlp_t.bf16_operands = 4, power-of-two-scaled fp16 operands, one MFMA per
     product) costs at the STATED phantom: BASELINE C1 at the reduced batch, 200 iterations from the oracle run's random stream.  The
-    first iteration's losses agree with the fp32 oracle to fp16 rounding (1e-2); the reconstruction stays within 0.3 dB of the
-    oracle's PSNR, whole object and interior (the fp32-equivalent default is held to 0.1 dB above)."""
+    first iteration's losses agree with the fp32 oracle to fp16 rounding (1e-2); the reconstruction stays within the north-star's
+    0.1 dB of the fp32 oracle's PSNR, whole object and interior (measured: 0.005 / 0.008 dB)."""
     from bench import make_args
     from nesvor_amd.phantom import simulate_stacks
     from nesvor_amd.train import train
@@ -192,7 +192,7 @@ def test_c1_oracle_run_replayed_in_scaled_fp16_mode(device, phantom):
     p_whole, p_int = _psnr_pair(rec, phantom.reshape(-1), float(gold["skull_threshold"]))
     o_whole, o_int = float(gold["psnr_whole_db"]), float(gold["psnr_interior_db"])
     print(f"scaled-fp16 MLP operands: PSNR whole object HIP {p_whole:.3f} / fp32 oracle {o_whole:.3f} dB; interior HIP {p_int:.3f} / oracle {o_int:.3f} dB")
-    assert abs(p_whole - o_whole) <= 0.3 and abs(p_int - o_int) <= 0.3
+    assert abs(p_whole - o_whole) <= 0.1 and abs(p_int - o_int) <= 0.1
 
 
 def _sample_lattice(output_resolution, stride, device):
